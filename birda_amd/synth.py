@@ -1,0 +1,233 @@
+"""Seeded synthetic models, labels and audio for the birda HIP hot path.
+
+No BirdNET / Perch weights, no ONNX Runtime and no network exist on the build or
+GPU boxes, so parity and throughput are measured on a seeded
+"BirdNET-v2.4-shaped" model: the published v2.4 front-end (SURVEY.md Appendix B:
+two Hann STFT branches -> Re() -> HTK mel -> square -> power law -> flip) feeding
+an EfficientNet-B0-like depthwise/pointwise stack with BN folded, GELU, global
+average pool, 1024-d embedding and a 6522-way dense head (label count =
+`data/labels/birdnet_v2.4/*_en_uk.txt`).  Weights are He-normal,
+seed 2024.
+
+Synthetic segments follow SURVEY.md §8d exactly: segment i = 0.1*N(0,1) (seed
+0xB17DA + i) + two sines, clipped to [-1, 1].
+"""
+from __future__ import annotations
+
+import math
+import struct
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import modelfile as mf
+
+SEG_SEED_BASE = 0xB17DA
+WEIGHT_SEED = 2024
+
+
+# --------------------------------------------------------------------------
+# mel filterbank (restates tf.signal.linear_to_mel_weight_matrix, HTK mel)  [EXT]
+# --------------------------------------------------------------------------
+def hertz_to_mel(f):
+    return 1127.0 * np.log1p(np.asarray(f, np.float64) / 700.0)
+
+
+def linear_to_mel_weight_matrix(n_mels: int, n_bins: int, sample_rate: float,
+                                fmin: float, fmax: float) -> np.ndarray:
+    """[n_bins, n_mels] triangular HTK-mel weights; the DC bin row is zero."""
+    nyquist = sample_rate / 2.0
+    lin = np.linspace(0.0, nyquist, n_bins)[1:]
+    bins_mel = hertz_to_mel(lin)[:, None]
+    edges = np.linspace(hertz_to_mel(fmin), hertz_to_mel(fmax), n_mels + 2)
+    lower, center, upper = edges[None, :-2], edges[None, 1:-1], edges[None, 2:]
+    lo = (bins_mel - lower) / (center - lower)
+    up = (upper - bins_mel) / (upper - center)
+    w = np.maximum(0.0, np.minimum(lo, up))
+    return np.pad(w, [[1, 0], [0, 0]]).astype(np.float32)
+
+
+# --------------------------------------------------------------------------
+# model builder
+# --------------------------------------------------------------------------
+def _same_pad(n: int, k: int, s: int) -> Tuple[int, int]:
+    out = -(-n // s)
+    total = max((out - 1) * s + k - n, 0)
+    return out, total // 2
+
+
+class _Builder:
+    def __init__(self, rng: np.random.Generator):
+        self.rng = rng
+        self.chunks: List[np.ndarray] = []
+        self.off = 0
+        self.layers: List[mf.Layer] = []
+
+    def put(self, a: np.ndarray) -> int:
+        a = np.ascontiguousarray(a, np.float32).ravel()
+        # keep every tensor 64-B aligned inside the blob (16-B vector loads on device)
+        pad = (-self.off) % 16
+        if pad:
+            self.chunks.append(np.zeros(pad, np.float32))
+            self.off += pad
+        off = self.off
+        self.chunks.append(a)
+        self.off += a.size
+        return off
+
+    def he(self, shape, fan_in: int) -> np.ndarray:
+        return (self.rng.standard_normal(shape) * math.sqrt(2.0 / fan_in)).astype(np.float32)
+
+    def bias(self, n: int) -> np.ndarray:
+        return (self.rng.standard_normal(n) * 0.05).astype(np.float32)
+
+    def add(self, L: mf.Layer) -> int:
+        self.layers.append(L)
+        return len(self.layers)  # tensor index of this layer's output
+
+    def conv(self, tin, h, w, cin, cout, k, s, act, in_layout=0):
+        oh, pt = _same_pad(h, k, s)
+        ow, pl = _same_pad(w, k, s)
+        wt = self.he((k, k, cin, cout), k * k * cin)
+        L = mf.Layer(mf.OP_CONV, act, tin, mf.NO_TENSOR, cin, cout, k, k, s, s, pt, pl, h, w, oh, ow,
+                     in_layout, self.put(wt), self.put(self.bias(cout)))
+        return self.add(L), oh, ow
+
+    def dwconv(self, tin, h, w, c, k, s, act):
+        oh, pt = _same_pad(h, k, s)
+        ow, pl = _same_pad(w, k, s)
+        wt = self.he((k, k, c), k * k)
+        L = mf.Layer(mf.OP_DWCONV, act, tin, mf.NO_TENSOR, c, c, k, k, s, s, pt, pl, h, w, oh, ow,
+                     0, self.put(wt), self.put(self.bias(c)))
+        return self.add(L), oh, ow
+
+    def pwconv(self, tin, h, w, cin, cout, act, res=mf.NO_TENSOR, gain=1.0):
+        wt = self.he((cin, cout), cin) * np.float32(gain)
+        L = mf.Layer(mf.OP_PWCONV, act, tin, res, cin, cout, 1, 1, 1, 1, 0, 0, h, w, h, w,
+                     0, self.put(wt), self.put(self.bias(cout)))
+        return self.add(L)
+
+    def gap(self, tin, h, w, c):
+        L = mf.Layer(mf.OP_GAP, mf.ACT_NONE, tin, mf.NO_TENSOR, c, c, h, w, 1, 1, 0, 0, h, w, 1, 1)
+        return self.add(L)
+
+    def dense(self, tin, cin, cout, gain=1.0):
+        wt = self.he((cin, cout), cin) * np.float32(gain)
+        b = (self.rng.standard_normal(cout) * 0.5 - 2.0).astype(np.float32)
+        L = mf.Layer(mf.OP_DENSE, mf.ACT_NONE, tin, mf.NO_TENSOR, cin, cout, 1, 1, 1, 1, 0, 0, 1, 1, 1, 1,
+                     0, self.put(wt), self.put(b))
+        return self.add(L)
+
+
+# EfficientNet-B0 stage table: (expand, kernel, stride, cout, repeats)
+_B0_STAGES = [(1, 3, 1, 16, 1), (6, 3, 2, 24, 2), (6, 5, 2, 40, 2), (6, 3, 2, 80, 3),
+              (6, 5, 1, 112, 3), (6, 5, 2, 192, 4), (6, 3, 1, 320, 1)]
+# a two-stage toy stack for CPU-speed tests (same op mix: conv, dw s1/s2 k3/k5, pw, residual)
+_TINY_STAGES = [(1, 3, 1, 8, 1), (4, 5, 2, 16, 2), (4, 3, 2, 24, 1)]
+
+
+def build_model(kind: str = "birdnet_v24", seed: int = WEIGHT_SEED,
+                n_classes: Optional[int] = None) -> mf.Model:
+    """kind: 'birdnet_v24' (full shape), 'birdnet_v24_tiny' (same front-end, toy stack),
+    'mini' (short segments + toy stack, for second-scale CPU tests),
+    'perch_v2' (5 s / 32 kHz, Perch-shaped: one 128-mel branch, 14 795 classes)."""
+    rng = np.random.default_rng(seed)
+    b = _Builder(rng)
+    act = mf.ACT_GELU_ERF
+    if kind in ("birdnet_v24", "birdnet_v24_tiny"):
+        sr, n, dur = 48000, 144000, 3.0
+        branches = [mf.Branch(2048, 278, 96, 511, 0.0, 3000.0, 1.23),
+                    mf.Branch(1024, 280, 96, 511, 500.0, 15000.0, 1.23)]
+        stages = _B0_STAGES if kind == "birdnet_v24" else _TINY_STAGES
+        stem, head, ncls, family = (32, 1024, 6522, 0) if kind == "birdnet_v24" else (8, 64, 50, 0)
+        out_act = mf.OUT_SIGMOID
+    elif kind == "mini":
+        sr, n, dur = 48000, 12000, 0.25
+        branches = [mf.Branch(512, 100, 32, (n - 512) // 100 + 1, 0.0, 3000.0, 1.23),
+                    mf.Branch(256, 103, 32, (n - 256) // 103 + 1, 500.0, 15000.0, 1.23)]
+        assert branches[0].n_frames == branches[1].n_frames
+        stages, stem, head, ncls, family, out_act = _TINY_STAGES, 8, 64, 50, 0, mf.OUT_SIGMOID
+    elif kind == "perch_v2":
+        # Perch v2: 5 s @ 32 kHz, 14 795 classes, softmax (manifests/Perch-v2-*).
+        sr, n, dur = 32000, 160000, 5.0
+        branches = [mf.Branch(1024, 320, 128, (n - 1024) // 320 + 1, 60.0, 16000.0, 1.23)]
+        stages, stem, head, ncls, family, out_act = _B0_STAGES, 32, 1280, 14795, 1, mf.OUT_SOFTMAX
+    else:
+        raise ValueError(kind)
+    if n_classes is not None:
+        ncls = n_classes
+    for br in branches:
+        w = linear_to_mel_weight_matrix(br.n_mels, br.n_bins, sr, br.fmin, br.fmax)
+        br.mel_w_off = b.put(w)
+        # the graph's BatchNorm on the spectrogram, folded to a per-channel affine
+        br.out_scale, br.out_shift = 0.8, -0.4
+    h, w_, c = branches[0].n_mels, branches[0].n_frames, len(branches)
+    t, h, w_ = b.conv(0, h, w_, c, stem, 3, 2, act, in_layout=1)
+    c = stem
+    for (e, k, s, cout, reps) in stages:
+        for r in range(reps):
+            stride = s if r == 0 else 1
+            tin, cin = t, c
+            if e != 1:
+                t = b.pwconv(t, h, w_, c, c * e, act)
+                c = c * e
+            t, h, w_ = b.dwconv(t, h, w_, c, k, stride, act)
+            res = tin if (stride == 1 and cin == cout) else mf.NO_TENSOR
+            # damp residual branches so the synthetic net keeps O(1) activations
+            t = b.pwconv(t, h, w_, c, cout, mf.ACT_NONE, res, gain=0.5 if res != mf.NO_TENSOR else 1.0)
+            c = cout
+    t = b.pwconv(t, h, w_, c, head, act)
+    t = b.gap(t, h, w_, head)
+    emb_t = t
+    t = b.dense(t, head, ncls, gain=1.5)
+    blob = np.concatenate(b.chunks) if b.chunks else np.zeros(0, np.float32)
+    m = mf.Model(family, sr, n, dur, ncls, head, out_act, emb_t, branches[0].n_mels,
+                 branches[0].n_frames, 1e-6, branches, b.layers, blob)
+    return m
+
+
+def write_labels(path: str, n: int) -> List[str]:
+    """`Scientific name_Common name` lines, the BirdNET label format split at the
+    first '_' by `Detection::from_label` (reference src/output/types.rs:58-79)."""
+    labels = []
+    for i in range(n):
+        if i % 97 == 13:
+            labels.append(f"Nonevent {i}")  # no underscore: both names = whole label
+        elif i % 89 == 7:
+            labels.append(f"Genus{i // 10} species{i}_Common, \"quoted\" Name {i}")  # needs CSV escaping
+        else:
+            labels.append(f"Genus{i // 10} species{i}_Common Name {i}")
+    with open(path, "w", encoding="utf-8") as f:
+        f.write("\n".join(labels) + "\n")
+    return labels
+
+
+# --------------------------------------------------------------------------
+# synthetic audio
+# --------------------------------------------------------------------------
+def synth_segment(i: int, n: int = 144000, rate: int = 48000) -> np.ndarray:
+    rng = np.random.default_rng(SEG_SEED_BASE + i)
+    t = np.arange(n, dtype=np.float64) / rate
+    f1 = 500.0 + 37.0 * (i % 200)
+    f2 = 3000.0 + 53.0 * (i % 200)
+    x = 0.1 * rng.standard_normal(n) + 0.3 * np.sin(2 * np.pi * f1 * t) + 0.3 * np.sin(2 * np.pi * f2 * t)
+    return np.clip(x, -1.0, 1.0).astype(np.float32)
+
+
+def synth_segments(count: int, n: int = 144000, rate: int = 48000, start: int = 0) -> np.ndarray:
+    out = np.empty((count, n), np.float32)
+    for j in range(count):
+        out[j] = synth_segment(start + j, n, rate)
+    return out
+
+
+def write_wav_pcm16(path: str, samples: np.ndarray, rate: int, channels: int = 1) -> None:
+    """Canonical 44-byte-header PCM16 WAV; `samples` is float in [-1, 1], shape [frames]
+    or [frames, channels]."""
+    pcm = np.clip(np.round(np.asarray(samples, np.float64) * 32767.0), -32768, 32767).astype("<i2")
+    data = pcm.tobytes()
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt " + struct.pack(
+        "<IHHIIHH", 16, 1, channels, rate, rate * channels * 2, channels * 2, 16)
+    hdr += b"data" + struct.pack("<I", len(data))
+    with open(path, "wb") as f:
+        f.write(hdr + data)
