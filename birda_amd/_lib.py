@@ -1,0 +1,93 @@
+"""ctypes loader for libbirda_hip.so (C ABI: include/birda_hip.h).
+
+Fails loudly when the HIP library is missing: there is no CPU fallback anywhere in the
+product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbirda_hip.so")
+BH_MAX_TOP_K = 32
+BH_N_STAGES = 8
+STAGE_NAMES = ["minmax", "mel", "stem", "depthwise", "pointwise", "pool", "dense", "topk"]
+
+
+class BhConfig(C.Structure):
+    _fields_ = [("model_path", C.c_char_p), ("labels_path", C.c_char_p), ("top_k", C.c_uint32),
+                ("min_confidence", C.c_float), ("device", C.c_int32), ("flags", C.c_uint32)]
+
+
+class BhModelInfo(C.Structure):
+    _fields_ = [("sample_rate", C.c_uint32), ("segment_duration", C.c_float), ("sample_count", C.c_uint32),
+                ("n_classes", C.c_uint32), ("embedding_dim", C.c_uint32), ("output_activation", C.c_uint32),
+                ("spec_channels", C.c_uint32), ("spec_h", C.c_uint32), ("spec_w", C.c_uint32),
+                ("n_layers", C.c_uint32), ("macs_per_segment", C.c_uint64), ("mel_flops_per_segment", C.c_uint64)]
+
+
+class BhResult(C.Structure):
+    _fields_ = [("n_pred", C.c_uint32), ("index", C.c_int32 * BH_MAX_TOP_K), ("confidence", C.c_float * BH_MAX_TOP_K)]
+
+
+# every symbol include/birda_hip.h declares: (name, restype, argtypes)
+_VP, _SZ = C.c_void_p, C.c_size_t
+SYMBOLS = [
+    ("bh_device_count", C.c_int, []),
+    ("bh_backend_name", C.c_char_p, []),
+    ("bh_last_error", C.c_char_p, []),
+    ("bh_classifier_create", C.c_int, [C.POINTER(BhConfig), C.POINTER(_VP)]),
+    ("bh_classifier_destroy", None, [_VP]),
+    ("bh_classifier_info", C.c_int, [_VP, C.POINTER(BhModelInfo)]),
+    ("bh_classifier_label", C.c_char_p, [_VP, C.c_uint32]),
+    ("bh_classifier_ensure_warm", C.c_int, [_VP, _SZ]),
+    ("bh_classifier_is_warm", C.c_int, [_VP, _SZ]),
+    ("bh_batch_context_create", C.c_int, [_VP, _SZ, C.POINTER(_VP)]),
+    ("bh_batch_context_destroy", None, [_VP]),
+    ("bh_batch_context_bytes", _SZ, [_VP]),
+    ("bh_batch_context_device_bytes", _SZ, [_VP]),
+    ("bh_predict", C.c_int, [_VP, _VP, _SZ, C.POINTER(BhResult)]),
+    ("bh_predict_batch", C.c_int, [_VP, C.POINTER(_VP), _SZ, _SZ, C.POINTER(BhResult)]),
+    ("bh_predict_batch_with_context", C.c_int, [_VP, _VP, C.POINTER(_VP), _SZ, _SZ, C.POINTER(BhResult)]),
+    ("bh_predict_batch_contig", C.c_int, [_VP, _VP, _VP, _SZ, C.POINTER(BhResult)]),
+    ("bh_predict_batch_logits", C.c_int, [_VP, _VP, _VP, _SZ, _VP, _VP]),
+    ("bh_forward_device", C.c_int, [_VP, _VP, _VP, _SZ, _VP, _VP, _VP]),
+    ("bh_batch_context_synchronize", C.c_int, [_VP]),
+    ("bh_batch_context_stream", _VP, [_VP]),
+    ("bh_debug_read_tensor", C.c_int, [_VP, _VP, C.c_uint32, _VP, _SZ]),
+    ("bh_tensor_floats", C.c_uint64, [_VP, C.c_uint32]),
+    ("bh_batch_context_set_profiling", C.c_int, [_VP, C.c_int]),
+    ("bh_batch_context_stage_ms", C.c_int, [_VP, _VP, _VP]),
+    ("bh_resample", C.c_int, [_VP, _VP, _SZ, C.c_uint32, C.c_uint32, _VP, _SZ, C.POINTER(_SZ)]),
+]
+
+_lib = None
+
+
+def load():
+    """Load libbirda_hip.so; raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C birda_amd/csrc` "
+                           "(the HIP hot path has no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(L, name)  # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+class BirdaHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libbirda_hip error {code}: {msg}")
+        self.code = code
+
+
+def check(rc: int):
+    if rc != 0:
+        raise BirdaHipError(rc, load().bh_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,201 @@
+"""Host-side mirror of the reference's `BirdClassifier` over the C ABI.
+
+Same names, argument meaning and error behaviour as reference
+`src/inference/classifier.rs:191-646` (`sample_rate`, `segment_duration`, `sample_count`,
+`ensure_warm`, `predict`, `predict_batch`, `create_batch_context`,
+`predict_batch_with_context`), so parity tests read like the reference's own.  All compute
+happens in libbirda_hip.so; nothing here falls back to the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import BhConfig, BhModelInfo, BhResult, check
+
+DEFAULT_TOP_K = 5            # reference src/constants.rs:178
+DEFAULT_MIN_CONFIDENCE = 0.1  # reference src/constants.rs:25
+
+
+@dataclass
+class Prediction:
+    """birdnet_onnx::Prediction{species, confidence, index} (processor.rs:372)."""
+    species: str
+    confidence: float
+    index: int
+
+
+@dataclass
+class PredictionResult:
+    predictions: List[Prediction]
+
+
+class BatchInferenceContext:
+    """create_batch_context(max_batch_size) -- classifier.rs:559-565."""
+
+    def __init__(self, classifier: "BirdClassifier", max_batch_size: int):
+        self._L = classifier._L
+        self.classifier = classifier
+        self.max_batch_size = max_batch_size
+        h = C.c_void_p()
+        check(self._L.bh_batch_context_create(classifier._h, max_batch_size, C.byref(h)))
+        self._h = h
+
+    def input_buffer_bytes(self) -> int:  # processor.rs:588
+        return int(self._L.bh_batch_context_bytes(self._h))
+
+    def device_bytes(self) -> int:
+        return int(self._L.bh_batch_context_device_bytes(self._h))
+
+    def synchronize(self):
+        check(self._L.bh_batch_context_synchronize(self._h))
+
+    def stream(self) -> int:
+        return int(self._L.bh_batch_context_stream(self._h) or 0)
+
+    def set_profiling(self, on: bool):
+        check(self._L.bh_batch_context_set_profiling(self._h, int(on)))
+
+    def stage_ms(self):
+        ms = (C.c_float * _lib.BH_N_STAGES)()
+        n = (C.c_uint32 * _lib.BH_N_STAGES)()
+        check(self._L.bh_batch_context_stage_ms(self._h, ms, n))
+        return {name: (float(ms[i]), int(n[i])) for i, name in enumerate(_lib.STAGE_NAMES)}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.bh_batch_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BirdClassifier:
+    def __init__(self, model_path: str, labels_path: Optional[str] = None, top_k: int = DEFAULT_TOP_K,
+                 min_confidence: float = DEFAULT_MIN_CONFIDENCE, device: int = 0):
+        self._L = _lib.load()
+        self._keep = (model_path.encode(), labels_path.encode() if labels_path else None)
+        cfg = BhConfig(self._keep[0], self._keep[1], top_k, min_confidence, device, 0)
+        h = C.c_void_p()
+        check(self._L.bh_classifier_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        info = BhModelInfo()
+        check(self._L.bh_classifier_info(self._h, C.byref(info)))
+        self.info = info
+        self.top_k = top_k
+        self.min_confidence = min_confidence
+        self.device = device
+
+    # ---- ModelConfig accessors (classifier.rs:360-377) ----
+    def sample_rate(self) -> int:
+        return int(self.info.sample_rate)
+
+    def segment_duration(self) -> float:
+        return float(self.info.segment_duration)
+
+    def sample_count(self) -> int:
+        return int(self.info.sample_count)
+
+    def n_classes(self) -> int:
+        return int(self.info.n_classes)
+
+    def label(self, index: int) -> Optional[str]:
+        s = self._L.bh_classifier_label(self._h, index)
+        return s.decode("utf-8") if s is not None else None
+
+    # ---- warm-up (classifier.rs:414-466) ----
+    def ensure_warm(self, batch_size: int):
+        check(self._L.bh_classifier_ensure_warm(self._h, batch_size))
+
+    def is_warm(self, batch_size: int) -> bool:
+        return bool(self._L.bh_classifier_is_warm(self._h, batch_size))
+
+    # ---- inference ----
+    def _results(self, arr, n) -> List[PredictionResult]:
+        out = []
+        for i in range(n):
+            r = arr[i]
+            preds = []
+            for k in range(r.n_pred):
+                idx = int(r.index[k])
+                preds.append(Prediction(self.label(idx) or str(idx), float(r.confidence[k]), idx))
+            out.append(PredictionResult(preds))
+        return out
+
+    def predict(self, segment: np.ndarray) -> PredictionResult:
+        seg = np.ascontiguousarray(segment, np.float32)
+        res = BhResult()
+        check(self._L.bh_predict(self._h, seg.ctypes.data, seg.size, C.byref(res)))
+        return self._results([res], 1)[0]
+
+    def _ptrs(self, segments: Sequence[np.ndarray]):
+        keep = [np.ascontiguousarray(s, np.float32) for s in segments]
+        lens = {k.size for k in keep}
+        n_samples = lens.pop() if len(lens) == 1 else -1
+        if n_samples < 0:
+            # mixed lengths: let the library reject the first wrong one with its own message
+            n_samples = keep[0].size if keep[0].size != self.sample_count() else next(
+                k.size for k in keep if k.size != self.sample_count())
+        ptrs = (C.c_void_p * len(keep))(*[k.ctypes.data for k in keep])
+        return keep, ptrs, n_samples
+
+    def predict_batch(self, segments: Sequence[np.ndarray]) -> List[PredictionResult]:
+        n = len(segments)
+        if n == 0:
+            return []
+        keep, ptrs, ns = self._ptrs(segments)
+        res = (BhResult * n)()
+        check(self._L.bh_predict_batch(self._h, ptrs, n, ns, res))
+        return self._results(res, n)
+
+    def create_batch_context(self, max_batch_size: int) -> BatchInferenceContext:
+        return BatchInferenceContext(self, max_batch_size)
+
+    def predict_batch_with_context(self, ctx: BatchInferenceContext, segments: Sequence[np.ndarray]):
+        n = len(segments)
+        if n == 0:
+            return []
+        keep, ptrs, ns = self._ptrs(segments)
+        res = (BhResult * n)()
+        check(self._L.bh_predict_batch_with_context(self._h, ctx._h, ptrs, n, ns, res))
+        return self._results(res, n)
+
+    def predict_logits(self, ctx: BatchInferenceContext, segments: np.ndarray, want_embeddings: bool = False):
+        segs = np.ascontiguousarray(segments, np.float32).reshape(-1, self.sample_count())
+        n = segs.shape[0]
+        logits = np.empty((n, self.n_classes()), np.float32)
+        emb = np.empty((n, int(self.info.embedding_dim)), np.float32) if want_embeddings else None
+        check(self._L.bh_predict_batch_logits(self._h, ctx._h, segs.ctypes.data, n, logits.ctypes.data,
+                                              emb.ctypes.data if want_embeddings else None))
+        return (logits, emb) if want_embeddings else logits
+
+    def forward_device(self, ctx: BatchInferenceContext, d_segments: int, n: int, d_logits: int,
+                       d_topk_index: int = 0, d_topk_conf: int = 0):
+        """Device pointers in, device pointers out; enqueued on the context stream."""
+        check(self._L.bh_forward_device(self._h, ctx._h, d_segments, n, d_logits, d_topk_index or None,
+                                        d_topk_conf or None))
+
+    def read_tensor(self, ctx: BatchInferenceContext, tensor: int, n: int) -> np.ndarray:
+        nfl = int(self._L.bh_tensor_floats(self._h, tensor))
+        out = np.empty((n, nfl), np.float32)
+        check(self._L.bh_debug_read_tensor(self._h, ctx._h, tensor, out.ctypes.data, out.size))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.bh_classifier_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

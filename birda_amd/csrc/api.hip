@@ -1,0 +1,627 @@
+// libbirda_hip.so -- C ABI (include/birda_hip.h) and the host executor for the gfx950 hot path.
+//
+// Plays the role of birdnet_onnx::Classifier + ONNX Runtime in the reference
+// (src/inference/classifier.rs:191-646): owns the model, the device weights, the batch
+// contexts and the per-layer kernel schedule.  No CPU compute path exists here: every
+// numeric result comes from the kernels in kernels_frontend.hip / kernels_conv.hip.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/birda_hip.h"
+#include "kernels.hpp"
+#include "model.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(BH_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+enum Stage { ST_MINMAX = 0, ST_MEL, ST_STEM, ST_DW, ST_PW, ST_GAP, ST_DENSE, ST_TOPK };
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace
+
+struct bh_classifier {
+    bh::Model model;
+    int device = 0;
+    uint32_t top_k = 5;
+    float min_conf = 0.1f;
+    std::vector<std::string> labels;
+    float *d_blob = nullptr;                 // raw model blob (dw / conv weights, biases)
+    std::vector<float *> d_w;                // per layer: weights as the kernels want them
+    std::vector<int> ldw;                    // per layer: padded row length of d_w (pw / dense)
+    std::vector<float *> d_owned;            // re-laid buffers to free
+    bh::FrontendParams fe{};
+    uint64_t mel_flops = 0;
+    std::mutex warm_mu;
+    std::set<size_t> warmed;                 // WarmupRegistry, classifier.rs:221-246
+    bh_batch_context *internal_ctx = nullptr;
+    std::mutex internal_mu;
+};
+
+struct bh_batch_context {
+    bh_classifier *c = nullptr;
+    size_t max_batch = 0;
+    bool keep_tensors = false;
+    hipStream_t stream = nullptr;
+    float *d_input = nullptr;    // [max_batch][sample_count]
+    float *d_minmax = nullptr;   // [max_batch][8][2]
+    float *d_arena = nullptr;
+    size_t arena_floats = 0;
+    std::vector<size_t> t_off;   // per tensor offset (floats) into the arena
+    float *d_logits = nullptr;   // [max_batch][n_classes]
+    int32_t *d_topk_idx = nullptr;
+    float *d_topk_conf = nullptr;
+    float *h_input = nullptr;    // pinned staging
+    int32_t *h_topk_idx = nullptr;
+    float *h_topk_conf = nullptr;
+    size_t device_bytes = 0;
+    size_t last_n = 0;
+    const float *last_logits = nullptr;
+    // profiling
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<int> ev_stage;
+    float stage_ms[BH_N_STAGES] = {0};
+    uint32_t stage_launches[BH_N_STAGES] = {0};
+};
+
+namespace {
+
+// Gf for one branch (see kernels_frontend.hip): double precision on the host, once.
+std::vector<float> build_gf(const bh::BranchRec &b, const float *W, int nm_pad) {
+    const int L = (int)b.frame_length, K = L / 2, nb = (int)b.n_bins, nm = (int)b.n_mels;
+    std::vector<double> ct(L);
+    for (int i = 0; i < L; i++) ct[i] = std::cos(2.0 * M_PI * (double)i / (double)L);
+    std::vector<int> rows;
+    for (int k = 0; k < nb; k++) {
+        bool nz = false;
+        for (int m = 0; m < nm && !nz; m++) nz = W[(size_t)k * nm + m] != 0.0f;
+        if (nz) rows.push_back(k);
+    }
+    std::vector<float> gf((size_t)K * nm_pad, 0.0f);
+    std::vector<double> acc(nm);
+    for (int j = 0; j < K; j++) {
+        const int n = j + 1;
+        const double wn = 0.5 - 0.5 * ct[n % L];
+        std::fill(acc.begin(), acc.end(), 0.0);
+        for (int k : rows) {
+            const double cv = ct[(size_t)((long long)k * n % L)];
+            const float *wr = W + (size_t)k * nm;
+            for (int m = 0; m < nm; m++) acc[m] += cv * (double)wr[m];
+        }
+        const double scale = (j == K - 1) ? 0.5 * wn : wn;  // the centre sample is added to itself
+        for (int m = 0; m < nm; m++) gf[(size_t)j * nm_pad + m] = (float)(scale * acc[m]);
+    }
+    return gf;
+}
+
+int upload(const void *src, size_t bytes, float **dst) {
+    HIPCHK(hipMalloc((void **)dst, bytes ? bytes : 4));
+    if (bytes) HIPCHK(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return BH_OK;
+}
+
+int read_labels(const char *path, std::vector<std::string> &out) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(BH_ERR_IO, "cannot open labels file %s", path);
+    std::string cur;
+    int ch;
+    bool any = false;
+    while ((ch = fgetc(f)) != EOF) {
+        any = true;
+        if (ch == '\n') {
+            if (!cur.empty() && cur.back() == '\r') cur.pop_back();
+            out.push_back(cur);
+            cur.clear();
+        } else cur.push_back((char)ch);
+    }
+    if (any && !cur.empty()) {
+        if (cur.back() == '\r') cur.pop_back();
+        out.push_back(cur);
+    }
+    fclose(f);
+    if (!out.empty() && out[0].size() >= 3 && (unsigned char)out[0][0] == 0xEF && (unsigned char)out[0][1] == 0xBB &&
+        (unsigned char)out[0][2] == 0xBF)
+        out[0] = out[0].substr(3);
+    return BH_OK;
+}
+
+void ctx_mark(bh_batch_context *ctx, int stage) {
+    if (!ctx->profiling) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, ctx->stream);
+    ctx->ev.push_back(e);
+    ctx->ev_stage.push_back(stage);
+}
+
+// liveness-based arena plan: tensor t is born at step t (tensor 0 = front-end) and dies after
+// the last layer that reads it; the embedding tensor and the logits live to the end.
+void plan_arena(const bh::Model &m, size_t max_batch, bool keep, std::vector<size_t> &off, size_t &total) {
+    const size_t nt = m.layers.size() + 1;
+    std::vector<size_t> last(nt, 0), sz(nt);
+    for (size_t t = 0; t < nt; t++) { last[t] = t; sz[t] = align_up(m.tensor_floats[t] * max_batch, 64); }
+    for (size_t i = 0; i < m.layers.size(); i++) {
+        const auto &L = m.layers[i];
+        last[L.in_tensor] = std::max(last[L.in_tensor], i + 1);
+        if (L.res_tensor != bh::NO_TENSOR) last[L.res_tensor] = std::max(last[L.res_tensor], i + 1);
+    }
+    last[m.h.embedding_tensor] = nt;
+    last[nt - 1] = nt;
+    off.assign(nt, 0);
+    total = 0;
+    if (keep) {
+        for (size_t t = 0; t < nt; t++) { off[t] = total; total += sz[t]; }
+        return;
+    }
+    struct Live { size_t off, size, last; };
+    std::vector<Live> live;
+    for (size_t t = 0; t < nt; t++) {
+        // tensors whose last reader ran before step t are dead (step t writes tensor t while
+        // reading tensors with last >= t)
+        live.erase(std::remove_if(live.begin(), live.end(), [&](const Live &l) { return l.last < t; }), live.end());
+        std::sort(live.begin(), live.end(), [](const Live &a, const Live &b) { return a.off < b.off; });
+        size_t pos = 0;
+        for (const auto &l : live) {
+            if (pos + sz[t] <= l.off) break;
+            pos = std::max(pos, l.off + l.size);
+        }
+        off[t] = pos;
+        live.push_back({pos, sz[t], last[t]});
+        total = std::max(total, pos + sz[t]);
+    }
+}
+
+int ctx_create(bh_classifier *c, size_t max_batch, bool keep, bh_batch_context **out) {
+    if (!c || !out || max_batch == 0) return fail(BH_ERR_INVALID, "batch context: bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    auto ctx = std::make_unique<bh_batch_context>();
+    ctx->c = c;
+    ctx->max_batch = max_batch;
+    ctx->keep_tensors = keep;
+    const auto &m = c->model;
+    HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    const size_t in_bytes = max_batch * (size_t)m.h.sample_count * sizeof(float);
+    HIPCHK(hipMalloc((void **)&ctx->d_input, in_bytes));
+    HIPCHK(hipMalloc((void **)&ctx->d_minmax, max_batch * 16 * sizeof(float)));
+    plan_arena(m, max_batch, keep, ctx->t_off, ctx->arena_floats);
+    HIPCHK(hipMalloc((void **)&ctx->d_arena, ctx->arena_floats * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&ctx->d_logits, max_batch * (size_t)m.h.n_classes * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&ctx->d_topk_idx, max_batch * c->top_k * sizeof(int32_t)));
+    HIPCHK(hipMalloc((void **)&ctx->d_topk_conf, max_batch * c->top_k * sizeof(float)));
+    HIPCHK(hipHostMalloc((void **)&ctx->h_input, in_bytes, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&ctx->h_topk_idx, max_batch * c->top_k * sizeof(int32_t), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void **)&ctx->h_topk_conf, max_batch * c->top_k * sizeof(float), hipHostMallocDefault));
+    ctx->device_bytes = in_bytes + max_batch * 16 * sizeof(float) + ctx->arena_floats * sizeof(float) +
+                        max_batch * (size_t)m.h.n_classes * sizeof(float) + max_batch * c->top_k * 8;
+    *out = ctx.release();
+    return BH_OK;
+}
+
+void ctx_destroy(bh_batch_context *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->c->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (auto e : ctx->ev) (void)hipEventDestroy(e);
+    (void)hipFree(ctx->d_input); (void)hipFree(ctx->d_minmax); (void)hipFree(ctx->d_arena);
+    (void)hipFree(ctx->d_logits); (void)hipFree(ctx->d_topk_idx); (void)hipFree(ctx->d_topk_conf);
+    (void)hipHostFree(ctx->h_input); (void)hipHostFree(ctx->h_topk_idx); (void)hipHostFree(ctx->h_topk_conf);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+// one slice (n <= max_batch) of the forward pass, enqueued on ctx->stream
+int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, size_t n, float *d_logits,
+                  int32_t *d_idx, float *d_conf) {
+    const auto &m = c->model;
+    hipStream_t s = ctx->stream;
+    auto T = [&](uint32_t t) { return ctx->d_arena + ctx->t_off[t]; };
+    const uint32_t nl = (uint32_t)m.layers.size();
+    ctx_mark(ctx, -1);
+    bh::launch_minmax(d_seg, ctx->d_minmax, (int)n, (int)m.h.sample_count, s);
+    ctx_mark(ctx, ST_MINMAX);
+    bh::launch_mel(d_seg, ctx->d_minmax, T(0), c->fe, (int)n, s);
+    ctx_mark(ctx, ST_MEL);
+    for (uint32_t i = 0; i < nl; i++) {
+        const auto &L = m.layers[i];
+        const float *in = T(L.in_tensor);
+        float *out = (i == nl - 1) ? d_logits : T(i + 1);
+        const float *res = L.res_tensor != bh::NO_TENSOR ? T(L.res_tensor) : nullptr;
+        const float *bias = c->d_blob + L.b_off;
+        bh::ConvParams p{(int)L.in_h, (int)L.in_w, (int)L.out_h, (int)L.out_w, (int)L.cin, (int)L.cout,
+                         (int)L.kh, (int)L.kw, (int)L.sh, (int)L.sw, (int)L.pad_t, (int)L.pad_l,
+                         (int)L.in_layout, (int)L.act};
+        switch (L.op) {
+        case bh::OP_CONV:
+            bh::launch_conv_direct(in, c->d_w[i], bias, out, p, (int)n, s);
+            ctx_mark(ctx, ST_STEM);
+            break;
+        case bh::OP_DWCONV:
+            bh::launch_dwconv(in, c->d_w[i], bias, out, p, (int)n, s);
+            ctx_mark(ctx, ST_DW);
+            break;
+        case bh::OP_PWCONV:
+            bh::launch_pw_gemm(in, c->d_w[i], bias, res, out, (int)(n * L.out_h * L.out_w), (int)L.cin,
+                               (int)L.cout, c->ldw[i], (int)L.act, s);
+            ctx_mark(ctx, ST_PW);
+            break;
+        case bh::OP_DENSE:
+            bh::launch_pw_gemm(in, c->d_w[i], bias, res, out, (int)n, (int)L.cin, (int)L.cout, c->ldw[i],
+                               (int)L.act, s);
+            ctx_mark(ctx, ST_DENSE);
+            break;
+        case bh::OP_GAP:
+            bh::launch_gap(in, out, (int)n, (int)(L.in_h * L.in_w), (int)L.cout, s);
+            ctx_mark(ctx, ST_GAP);
+            break;
+        default: return fail(BH_ERR_UNSUPPORTED, "layer %u: unsupported op %u", i, L.op);
+        }
+    }
+    if (d_idx && d_conf) {
+        bh::launch_topk(d_logits, (int)n, (int)m.h.n_classes, (int)m.h.output_activation, (int)c->top_k,
+                        c->min_conf, d_idx, d_conf, s);
+        ctx_mark(ctx, ST_TOPK);
+    }
+    HIPCHK(hipGetLastError());
+    ctx->last_n = n;
+    ctx->last_logits = d_logits;
+    return BH_OK;
+}
+
+int check_ctx(bh_classifier *c, bh_batch_context *ctx) {
+    if (!c || !ctx) return fail(BH_ERR_INVALID, "null classifier or batch context");
+    if (ctx->c != c) return fail(BH_ERR_INVALID, "batch context belongs to another classifier");
+    return BH_OK;
+}
+
+// host slices -> results through ctx
+int predict_slices(bh_classifier *c, bh_batch_context *ctx, const float *const *segments, const float *contig,
+                   size_t n, bh_result *out, float *logits_out, float *emb_out) {
+    const auto &m = c->model;
+    const size_t S = m.h.sample_count;
+    HIPCHK(hipSetDevice(c->device));
+    for (size_t b0 = 0; b0 < n; b0 += ctx->max_batch) {
+        const size_t nb = std::min(ctx->max_batch, n - b0);
+        for (size_t i = 0; i < nb; i++) {
+            const float *src = segments ? segments[b0 + i] : contig + (b0 + i) * S;
+            if (!src) return fail(BH_ERR_INVALID, "segment %zu is null", b0 + i);
+            memcpy(ctx->h_input + i * S, src, S * sizeof(float));
+        }
+        HIPCHK(hipMemcpyAsync(ctx->d_input, ctx->h_input, nb * S * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        int rc = forward_slice(c, ctx, ctx->d_input, nb, ctx->d_logits, ctx->d_topk_idx, ctx->d_topk_conf);
+        if (rc != BH_OK) return rc;
+        if (out) {
+            HIPCHK(hipMemcpyAsync(ctx->h_topk_idx, ctx->d_topk_idx, nb * c->top_k * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipMemcpyAsync(ctx->h_topk_conf, ctx->d_topk_conf, nb * c->top_k * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        }
+        if (logits_out)
+            HIPCHK(hipMemcpyAsync(logits_out + b0 * m.h.n_classes, ctx->d_logits, nb * (size_t)m.h.n_classes * sizeof(float),
+                                  hipMemcpyDeviceToHost, ctx->stream));
+        if (emb_out)
+            HIPCHK(hipMemcpyAsync(emb_out + b0 * m.h.embedding_dim, ctx->d_arena + ctx->t_off[m.h.embedding_tensor],
+                                  nb * (size_t)m.h.embedding_dim * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (out)
+            for (size_t i = 0; i < nb; i++) {
+                bh_result &r = out[b0 + i];
+                r.n_pred = 0;
+                for (uint32_t k = 0; k < c->top_k; k++) {
+                    const int32_t id = ctx->h_topk_idx[i * c->top_k + k];
+                    if (id < 0) break;
+                    r.index[r.n_pred] = id;
+                    r.confidence[r.n_pred] = ctx->h_topk_conf[i * c->top_k + k];
+                    r.n_pred++;
+                }
+            }
+    }
+    return BH_OK;
+}
+
+int internal_ctx(bh_classifier *c, size_t n, bh_batch_context **out) {
+    if (c->internal_ctx && c->internal_ctx->max_batch >= n) { *out = c->internal_ctx; return BH_OK; }
+    if (c->internal_ctx) { ctx_destroy(c->internal_ctx); c->internal_ctx = nullptr; }
+    int rc = ctx_create(c, n, false, &c->internal_ctx);
+    *out = c->internal_ctx;
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bh_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *bh_backend_name(void) { return "HIP (gfx950)"; }
+const char *bh_last_error(void) { return g_err.c_str(); }
+
+int bh_classifier_create(const bh_config *cfg, bh_classifier **out) {
+    if (!cfg || !out || !cfg->model_path) return fail(BH_ERR_INVALID, "classifier_create: null config/model_path");
+    *out = nullptr;
+    if (cfg->top_k == 0 || cfg->top_k > BH_MAX_TOP_K) return fail(BH_ERR_INVALID, "top_k must be 1..%d", BH_MAX_TOP_K);
+    auto c = std::make_unique<bh_classifier>();
+    std::string err;
+    if (!bh::load_model(cfg->model_path, c->model, err)) return fail(BH_ERR_IO, "%s", err.c_str());
+    const auto &m = c->model;
+    if (cfg->labels_path) {
+        int rc = read_labels(cfg->labels_path, c->labels);
+        if (rc != BH_OK) return rc;
+        if (c->labels.size() != m.h.n_classes)
+            return fail(BH_ERR_LABELS, "label count %zu does not match model output width %u", c->labels.size(), m.h.n_classes);
+    }
+    int ndev = bh_device_count();
+    if (ndev <= 0) return fail(BH_ERR_NO_DEVICE, "no HIP device available (libbirda_hip has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(BH_ERR_NO_DEVICE, "device %d out of range (0..%d)", cfg->device, ndev - 1);
+    c->device = cfg->device;
+    c->top_k = cfg->top_k;
+    c->min_conf = cfg->min_confidence;
+    HIPCHK(hipSetDevice(c->device));
+    if (m.h.n_branches > bh::MAX_BRANCHES) return fail(BH_ERR_UNSUPPORTED, "too many front-end branches");
+    // front-end operators
+    c->fe.n_branches = (int)m.h.n_branches;
+    c->fe.sample_count = (int)m.h.sample_count;
+    c->fe.norm_eps = m.h.norm_eps;
+    for (uint32_t b = 0; b < m.h.n_branches; b++) {
+        const auto &br = m.branches[b];
+        const int nm_pad = (int)align_up(br.n_mels, 16);
+        if (nm_pad != 32 && nm_pad != 96 && nm_pad != 128)
+            return fail(BH_ERR_UNSUPPORTED, "front-end: n_mels %u not built (32/96/128)", br.n_mels);
+        if (b > 0 && nm_pad != c->fe.br[0].nm_pad) return fail(BH_ERR_UNSUPPORTED, "front-end: branches differ in n_mels");
+        if (br.frame_length % 64 || br.fft_length != br.frame_length)
+            return fail(BH_ERR_UNSUPPORTED, "front-end: frame_length %u must be a multiple of 64 and equal fft_length", br.frame_length);
+        if ((64 * br.frame_step) % 4) return fail(BH_ERR_UNSUPPORTED, "front-end: hop %u unsupported", br.frame_step);
+        std::vector<float> gf = build_gf(br, m.blob.data() + br.mel_w_off, nm_pad);
+        float *d = nullptr;
+        int rc = upload(gf.data(), gf.size() * sizeof(float), &d);
+        if (rc != BH_OK) return rc;
+        c->d_owned.push_back(d);
+        auto &p = c->fe.br[b];
+        p.gf = d; p.L = (int)br.frame_length; p.H = (int)br.frame_step; p.K = p.L / 2;
+        p.n_mels = (int)br.n_mels; p.nm_pad = nm_pad; p.n_frames = (int)br.n_frames;
+        p.expo = 1.0f / (1.0f + expf(br.mag_scale));
+        p.out_scale = br.out_scale; p.out_shift = br.out_shift; p.flip = (int)(br.flags & 1u);
+        c->mel_flops += 2ull * (uint64_t)p.K * nm_pad * br.n_frames;
+    }
+    // weights
+    int rc = upload(m.blob.data(), m.blob.size() * sizeof(float), &c->d_blob);
+    if (rc != BH_OK) return rc;
+    c->d_w.resize(m.layers.size());
+    c->ldw.assign(m.layers.size(), 0);
+    for (size_t i = 0; i < m.layers.size(); i++) {
+        const auto &L = m.layers[i];
+        c->d_w[i] = c->d_blob + L.w_off;
+        if (L.op == bh::OP_PWCONV || L.op == bh::OP_DENSE) {
+            if (L.cin % 4) return fail(BH_ERR_UNSUPPORTED, "layer %zu: cin %u not a multiple of 4", i, L.cin);
+            const int ld = (int)align_up(L.cout, 4);
+            c->ldw[i] = ld;
+            if (ld != (int)L.cout) {  // pad rows so 16-B loads stay aligned
+                std::vector<float> w((size_t)L.cin * ld, 0.0f);
+                for (uint32_t k = 0; k < L.cin; k++)
+                    memcpy(&w[(size_t)k * ld], m.blob.data() + L.w_off + (size_t)k * L.cout, L.cout * sizeof(float));
+                float *d = nullptr;
+                rc = upload(w.data(), w.size() * sizeof(float), &d);
+                if (rc != BH_OK) return rc;
+                c->d_owned.push_back(d);
+                c->d_w[i] = d;
+            }
+        } else if (L.op == bh::OP_DWCONV) {
+            if (L.cout % 4 || L.kh != L.kw || L.sh != L.sw || !((L.kh == 3 || L.kh == 5) && (L.sh == 1 || L.sh == 2)))
+                return fail(BH_ERR_UNSUPPORTED, "layer %zu: depthwise %ux%u stride %u channels %u not built", i, L.kh, L.kw, L.sh, L.cout);
+        } else if (L.op == bh::OP_CONV) {
+            if (L.cout % 8 || (size_t)L.kh * L.kw * L.cin * L.cout * 4 > 64 * 1024)
+                return fail(BH_ERR_UNSUPPORTED, "layer %zu: direct conv shape not built", i);
+        } else if (L.op == bh::OP_GAP) {
+            if (L.cout % 4) return fail(BH_ERR_UNSUPPORTED, "layer %zu: pool channels %u not a multiple of 4", i, L.cout);
+        }
+    }
+    if (m.layers.empty() || m.layers.back().cout != m.h.n_classes)
+        return fail(BH_ERR_IO, "model: last layer width != n_classes");
+    *out = c.release();
+    return BH_OK;
+}
+
+void bh_classifier_destroy(bh_classifier *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->internal_ctx) ctx_destroy(c->internal_ctx);
+    for (float *d : c->d_owned) (void)hipFree(d);
+    (void)hipFree(c->d_blob);
+    delete c;
+}
+
+int bh_classifier_info(const bh_classifier *c, bh_model_info *info) {
+    if (!c || !info) return fail(BH_ERR_INVALID, "classifier_info: null argument");
+    const auto &h = c->model.h;
+    info->sample_rate = h.sample_rate; info->segment_duration = h.segment_duration; info->sample_count = h.sample_count;
+    info->n_classes = h.n_classes; info->embedding_dim = h.embedding_dim; info->output_activation = h.output_activation;
+    info->spec_channels = h.n_branches; info->spec_h = h.spec_h; info->spec_w = h.spec_w;
+    info->n_layers = h.n_layers; info->macs_per_segment = c->model.macs_per_segment();
+    info->mel_flops_per_segment = c->mel_flops;
+    return BH_OK;
+}
+
+const char *bh_classifier_label(const bh_classifier *c, uint32_t index) {
+    if (!c || index >= c->labels.size()) return nullptr;
+    return c->labels[index].c_str();
+}
+
+int bh_classifier_is_warm(const bh_classifier *c, size_t batch_size) {
+    if (!c) return 0;
+    auto *cc = const_cast<bh_classifier *>(c);
+    std::lock_guard<std::mutex> g(cc->warm_mu);
+    return cc->warmed.count(batch_size) ? 1 : 0;
+}
+
+int bh_classifier_ensure_warm(bh_classifier *c, size_t batch_size) {
+    if (!c || batch_size == 0) return fail(BH_ERR_INVALID, "ensure_warm: bad arguments");
+    if (bh_classifier_is_warm(c, batch_size)) return BH_OK;
+    // warmup(batch_size): all-zero segments through the real path (classifier.rs:443-466)
+    std::vector<float> zero(c->model.h.sample_count, 0.0f);
+    std::vector<const float *> segs(batch_size, zero.data());
+    std::vector<bh_result> res(batch_size);
+    int rc = bh_predict_batch(c, segs.data(), batch_size, zero.size(), res.data());
+    if (rc != BH_OK) return rc;  // recorded only after success (classifier.rs:424)
+    std::lock_guard<std::mutex> g(c->warm_mu);
+    c->warmed.insert(batch_size);
+    return BH_OK;
+}
+
+int bh_batch_context_create(bh_classifier *c, size_t max_batch, bh_batch_context **out) {
+    const char *keep = getenv("BIRDA_HIP_KEEP_TENSORS");
+    return ctx_create(c, max_batch, keep && keep[0] == '1', out);
+}
+void bh_batch_context_destroy(bh_batch_context *ctx) { ctx_destroy(ctx); }
+size_t bh_batch_context_bytes(const bh_batch_context *ctx) {
+    return ctx ? ctx->max_batch * (size_t)ctx->c->model.h.sample_count * sizeof(float) : 0;
+}
+size_t bh_batch_context_device_bytes(const bh_batch_context *ctx) { return ctx ? ctx->device_bytes : 0; }
+
+int bh_predict(bh_classifier *c, const float *segment, size_t n_samples, bh_result *out) {
+    const float *segs[1] = {segment};
+    return bh_predict_batch(c, segs, 1, n_samples, out);
+}
+
+int bh_predict_batch(bh_classifier *c, const float *const *segments, size_t n, size_t n_samples, bh_result *out) {
+    if (!c || !segments || !out) return fail(BH_ERR_INVALID, "predict_batch: null argument");
+    if (n == 0) return BH_OK;
+    if (n_samples != c->model.h.sample_count)
+        return fail(BH_ERR_INVALID, "segment has %zu samples, model expects %u", n_samples, c->model.h.sample_count);
+    std::lock_guard<std::mutex> g(c->internal_mu);
+    bh_batch_context *ctx = nullptr;
+    int rc = internal_ctx(c, n, &ctx);
+    if (rc != BH_OK) return rc;
+    return predict_slices(c, ctx, segments, nullptr, n, out, nullptr, nullptr);
+}
+
+int bh_predict_batch_with_context(bh_classifier *c, bh_batch_context *ctx, const float *const *segments, size_t n,
+                                  size_t n_samples, bh_result *out) {
+    int rc = check_ctx(c, ctx);
+    if (rc != BH_OK) return rc;
+    if (!segments || !out) return fail(BH_ERR_INVALID, "predict_batch_with_context: null argument");
+    if (n > ctx->max_batch) return fail(BH_ERR_INVALID, "batch of %zu exceeds context capacity %zu", n, ctx->max_batch);
+    if (n_samples != c->model.h.sample_count)
+        return fail(BH_ERR_INVALID, "segment has %zu samples, model expects %u", n_samples, c->model.h.sample_count);
+    return predict_slices(c, ctx, segments, nullptr, n, out, nullptr, nullptr);
+}
+
+int bh_predict_batch_contig(bh_classifier *c, bh_batch_context *ctx, const float *base, size_t n, bh_result *out) {
+    int rc = check_ctx(c, ctx);
+    if (rc != BH_OK) return rc;
+    if (!base || !out) return fail(BH_ERR_INVALID, "predict_batch_contig: null argument");
+    return predict_slices(c, ctx, nullptr, base, n, out, nullptr, nullptr);
+}
+
+int bh_predict_batch_logits(bh_classifier *c, bh_batch_context *ctx, const float *base, size_t n, float *logits,
+                            float *embeddings) {
+    int rc = check_ctx(c, ctx);
+    if (rc != BH_OK) return rc;
+    if (!base || !logits) return fail(BH_ERR_INVALID, "predict_batch_logits: null argument");
+    return predict_slices(c, ctx, nullptr, base, n, nullptr, logits, embeddings);
+}
+
+int bh_forward_device(bh_classifier *c, bh_batch_context *ctx, const float *d_segments, size_t n, float *d_logits,
+                      int32_t *d_topk_index, float *d_topk_conf) {
+    int rc = check_ctx(c, ctx);
+    if (rc != BH_OK) return rc;
+    if (!d_segments || !d_logits) return fail(BH_ERR_INVALID, "forward_device: null device pointer");
+    HIPCHK(hipSetDevice(c->device));
+    if (ctx->profiling) {
+        for (auto e : ctx->ev) (void)hipEventDestroy(e);
+        ctx->ev.clear(); ctx->ev_stage.clear();
+    }
+    const auto &h = c->model.h;
+    for (size_t b0 = 0; b0 < n; b0 += ctx->max_batch) {
+        const size_t nb = std::min(ctx->max_batch, n - b0);
+        rc = forward_slice(c, ctx, d_segments + b0 * h.sample_count, nb, d_logits + b0 * h.n_classes,
+                           d_topk_index ? d_topk_index + b0 * c->top_k : nullptr,
+                           d_topk_conf ? d_topk_conf + b0 * c->top_k : nullptr);
+        if (rc != BH_OK) return rc;
+    }
+    return BH_OK;
+}
+
+int bh_batch_context_synchronize(bh_batch_context *ctx) {
+    if (!ctx) return fail(BH_ERR_INVALID, "synchronize: null context");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return BH_OK;
+}
+void *bh_batch_context_stream(bh_batch_context *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+uint64_t bh_tensor_floats(const bh_classifier *c, uint32_t tensor) {
+    if (!c || tensor >= c->model.tensor_floats.size()) return 0;
+    return c->model.tensor_floats[tensor];
+}
+
+int bh_debug_read_tensor(bh_classifier *c, bh_batch_context *ctx, uint32_t tensor, float *host, size_t max_floats) {
+    int rc = check_ctx(c, ctx);
+    if (rc != BH_OK) return rc;
+    if (!ctx->keep_tensors) return fail(BH_ERR_INVALID, "context was not created with BIRDA_HIP_KEEP_TENSORS=1");
+    if (tensor >= c->model.tensor_floats.size()) return fail(BH_ERR_INVALID, "tensor %u out of range", tensor);
+    const size_t nfl = c->model.tensor_floats[tensor] * ctx->last_n;
+    if (nfl > max_floats) return fail(BH_ERR_INVALID, "host buffer too small (%zu < %zu)", max_floats, nfl);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    const float *src = (tensor == c->model.layers.size()) ? ctx->last_logits : ctx->d_arena + ctx->t_off[tensor];
+    HIPCHK(hipMemcpy(host, src, nfl * sizeof(float), hipMemcpyDeviceToHost));
+    return BH_OK;
+}
+
+int bh_batch_context_set_profiling(bh_batch_context *ctx, int enabled) {
+    if (!ctx) return fail(BH_ERR_INVALID, "set_profiling: null context");
+    ctx->profiling = enabled != 0;
+    return BH_OK;
+}
+
+int bh_batch_context_stage_ms(bh_batch_context *ctx, float *ms, uint32_t *launches) {
+    if (!ctx || !ms) return fail(BH_ERR_INVALID, "stage_ms: null argument");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < BH_N_STAGES; i++) { ctx->stage_ms[i] = 0.f; ctx->stage_launches[i] = 0; }
+    for (size_t i = 1; i < ctx->ev.size(); i++) {
+        const int st = ctx->ev_stage[i];
+        if (st < 0) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, ctx->ev[i - 1], ctx->ev[i]) == hipSuccess) {
+            ctx->stage_ms[st] += t;
+            ctx->stage_launches[st]++;
+        }
+    }
+    for (int i = 0; i < BH_N_STAGES; i++) { ms[i] = ctx->stage_ms[i]; if (launches) launches[i] = ctx->stage_launches[i]; }
+    return BH_OK;
+}
+
+int bh_resample(bh_classifier *, const float *, size_t, uint32_t, uint32_t, float *, size_t, size_t *) {
+    return fail(BH_ERR_UNSUPPORTED, "bh_resample: HIP resampler not built in this revision");
+}
+
+}  // extern "C"

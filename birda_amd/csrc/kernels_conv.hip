@@ -1,0 +1,409 @@
+// Conv-stack kernels for gfx950 (NHWC f32, BN folded into weights + bias).
+//
+// These replace the ORT kernels the reference reaches through birdnet_onnx::Classifier
+// (reference src/inference/classifier.rs:478-488): Conv (group = 1 / group = C),
+// activation, residual Add, GlobalAveragePool, Gemm.
+//   * pointwise 1x1 conv and the dense head: LDS-tiled GEMM on v_mfma_f32_16x16x4_f32
+//   * depthwise kxk: direct NHWC conv, 4 channels per lane (16-B loads/stores)
+//   * stem conv (tiny Cin): direct conv, weights in LDS, 8 output channels per lane
+#include "kernels.hpp"
+
+namespace bh {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    switch (act) {
+    case ACT_RELU: return fmaxf(v, 0.f);
+    case ACT_RELU6: return fminf(fmaxf(v, 0.f), 6.f);
+    case ACT_SWISH: return v / (1.0f + expf(-v));
+    case ACT_GELU_ERF: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    case ACT_GELU_TANH: return 0.5f * v * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * v * v * v)));
+    case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    default: return v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Pointwise / dense GEMM.  C[M][N] = act(A[M][K] W[K][ldw] + bias[N]) (+ R[M][N]).
+// Block = 256 threads = 4 waves stacked along M; wave tile (BM/4) x (16 NT).
+// K is consumed in chunks of 32 (whole 128-B lines of every A row), staged through LDS with
+// a register prefetch of the next chunk.  Inside a 16-deep group the k order is permuted
+// (MFMA step c of lane-quad q uses k = 16g + 4q + c) so that a lane's four A operands are
+// one ds_read_b128; the B operand applies the same permutation through its LDS row index.
+// ---------------------------------------------------------------------------------------
+constexpr int PW_BK = 32;
+
+template <int BM, int NT>
+__global__ __launch_bounds__(256) void pw_gemm_kernel(const float *__restrict__ A, const float *__restrict__ W,
+                                                       const float *__restrict__ bias, const float *__restrict__ R,
+                                                       float *__restrict__ C, int M, int K, int N, int ldw, int act) {
+    constexpr int BN = NT * 16;
+    constexpr int WM = BM / 4;
+    constexpr int MT = WM / 16;
+    constexpr int AS = PW_BK + 4;  // As row stride (floats): 16-B aligned rows, odd 16-B slot stride
+    constexpr int BS = BN + 4;     // Bs row stride: rows 4 apart land 16 banks apart
+    constexpr int A4 = BM * PW_BK / 4 / 256;               // float4 per thread per chunk (A)
+    constexpr int B4 = (PW_BK * BN / 4 + 255) / 256;       // float4 per thread per chunk (W)
+    __shared__ __attribute__((aligned(16))) float As[2][BM * AS];
+    __shared__ __attribute__((aligned(16))) float Bs[2][PW_BK * BS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+
+    float4 pa[A4], pb[B4];
+    auto load_chunk = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < A4; i++) {
+            const int f = tid + 256 * i;
+            const int row = f >> 3, kc = (f & 7) << 2;
+            const int gm = m0 + row, gk = k0 + kc;
+            pa[i] = (gm < M && gk < K) ? *reinterpret_cast<const float4 *>(A + (size_t)gm * K + gk)
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < B4; i++) {
+            const int f = tid + 256 * i;
+            const int row = f / (BN / 4), nc = (f % (BN / 4)) << 2;
+            const int gk = k0 + row, gn = n0 + nc;
+            pb[i] = (f < PW_BK * BN / 4 && gk < K && gn < ldw)
+                        ? *reinterpret_cast<const float4 *>(W + (size_t)gk * ldw + gn)
+                        : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A4; i++) {
+            const int f = tid + 256 * i;
+            const int row = f >> 3, kc = (f & 7) << 2;
+            *reinterpret_cast<float4 *>(&As[buf][row * AS + kc]) = pa[i];
+        }
+#pragma unroll
+        for (int i = 0; i < B4; i++) {
+            const int f = tid + 256 * i;
+            if (f < PW_BK * BN / 4) {
+                const int row = f / (BN / 4), nc = (f % (BN / 4)) << 2;
+                *reinterpret_cast<float4 *>(&Bs[buf][row * BS + nc]) = pb[i];
+            }
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; i++)
+#pragma unroll
+        for (int j = 0; j < NT; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+
+    const int nchunks = (K + PW_BK - 1) / PW_BK;
+    for (int c = 0; c < nchunks; c++) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) load_chunk((c + 1) * PW_BK);
+        const int kleft = K - c * PW_BK;
+        const int groups = kleft >= PW_BK ? 2 : (kleft + 15) >> 4;
+        const float *as = &As[buf][(wave * WM + li) * AS + 4 * kq];
+        const float *bs = &Bs[buf][(4 * kq) * BS + li];
+        for (int g = 0; g < groups; g++) {
+            float4 a4[MT];
+#pragma unroll
+            for (int i = 0; i < MT; i++) a4[i] = *reinterpret_cast<const float4 *>(as + i * 16 * AS + g * 16);
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) {
+                float b[NT];
+#pragma unroll
+                for (int j = 0; j < NT; j++) b[j] = bs[(g * 16 + cc) * BS + j * 16];
+#pragma unroll
+                for (int i = 0; i < MT; i++) {
+                    const float a = cc == 0 ? a4[i].x : cc == 1 ? a4[i].y : cc == 2 ? a4[i].z : a4[i].w;
+#pragma unroll
+                    for (int j = 0; j < NT; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+        if (c + 1 < nchunks) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: D row = 4*(lane>>4) + r, col = lane & 15
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+        const int col = n0 + j * 16 + li;
+        if (col >= N) continue;
+        const float bv = bias[col];
+#pragma unroll
+        for (int i = 0; i < MT; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = m0 + wave * WM + i * 16 + kq * 4 + r;
+                if (row < M) {
+                    float v = act_apply(acc[i][j][r] + bv, act);
+                    if (R) v += R[(size_t)row * N + col];
+                    C[(size_t)row * N + col] = v;
+                }
+            }
+    }
+}
+
+template <int BM, int NT>
+static void pw_launch(const float *A, const float *W, const float *bias, const float *R, float *C, int M, int K,
+                      int N, int ldw, int act, hipStream_t s) {
+    dim3 grid((N + NT * 16 - 1) / (NT * 16), (M + BM - 1) / BM), block(256);
+    hipLaunchKernelGGL((pw_gemm_kernel<BM, NT>), grid, block, 0, s, A, W, bias, R, C, M, K, N, ldw, act);
+}
+
+// pick the widest column tile that wastes the fewest padded columns
+static int pick_nt(int N) {
+    int best = 1;
+    long best_pad = -1;
+    for (int nt = 8; nt >= 1; nt--) {
+        long bn = nt * 16;
+        long padded = ((N + bn - 1) / bn) * bn;
+        if (best_pad < 0 || padded < best_pad) { best_pad = padded; best = nt; }
+    }
+    return best;
+}
+
+void launch_pw_gemm(const float *A, const float *W, const float *bias, const float *R, float *C, int M, int K,
+                    int N, int ldw, int act, hipStream_t s) {
+    const int nt = pick_nt(N);
+    const long blocks128 = (long)((M + 127) / 128) * ((N + nt * 16 - 1) / (nt * 16));
+    const bool small = blocks128 < 512;  // keep >= 2 blocks per CU in flight when M is short
+#define BH_PW_CASE(NTV)                                                                    \
+    case NTV:                                                                              \
+        if (small) pw_launch<64, NTV>(A, W, bias, R, C, M, K, N, ldw, act, s);             \
+        else pw_launch<128, NTV>(A, W, bias, R, C, M, K, N, ldw, act, s);                  \
+        break;
+    switch (nt) {
+        BH_PW_CASE(1) BH_PW_CASE(2) BH_PW_CASE(3) BH_PW_CASE(4)
+        BH_PW_CASE(5) BH_PW_CASE(6) BH_PW_CASE(7) BH_PW_CASE(8)
+    }
+#undef BH_PW_CASE
+}
+
+// ---------------------------------------------------------------------------------------
+// Depthwise conv, NHWC.  One lane = one output pixel x 4 channels; lanes run over the
+// channel groups first, so a wave reads/writes contiguous 16-B pieces of NHWC rows.
+// ---------------------------------------------------------------------------------------
+template <int KS, int ST>
+__global__ __launch_bounds__(256) void dwconv_kernel(const float *__restrict__ in, const float *__restrict__ w,
+                                                      const float *__restrict__ b, float *__restrict__ out,
+                                                      ConvParams p, int n_seg) {
+    const int c4n = p.cout >> 2;
+    const long total = (long)n_seg * p.out_h * p.out_w * c4n;
+    for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
+        const int c4 = (int)(g % c4n);
+        long px = g / c4n;
+        const int ox = (int)(px % p.out_w);
+        px /= p.out_w;
+        const int oy = (int)(px % p.out_h);
+        const int seg = (int)(px / p.out_h);
+        const int c = c4 << 2;
+        float4 acc = *reinterpret_cast<const float4 *>(b + c);
+        const float *ib = in + (size_t)seg * p.in_h * p.in_w * p.cout + c;
+        const int iy0 = oy * ST - p.pad_t, ix0 = ox * ST - p.pad_l;
+#pragma unroll
+        for (int dy = 0; dy < KS; dy++) {
+            const int iy = iy0 + dy;
+            if (iy < 0 || iy >= p.in_h) continue;
+#pragma unroll
+            for (int dx = 0; dx < KS; dx++) {
+                const int ix = ix0 + dx;
+                if (ix < 0 || ix >= p.in_w) continue;
+                const float4 a = *reinterpret_cast<const float4 *>(ib + ((size_t)iy * p.in_w + ix) * p.cout);
+                const float4 ww = *reinterpret_cast<const float4 *>(w + (size_t)(dy * KS + dx) * p.cout + c);
+                acc.x += a.x * ww.x; acc.y += a.y * ww.y; acc.z += a.z * ww.z; acc.w += a.w * ww.w;
+            }
+        }
+        acc.x = act_apply(acc.x, p.act); acc.y = act_apply(acc.y, p.act);
+        acc.z = act_apply(acc.z, p.act); acc.w = act_apply(acc.w, p.act);
+        *reinterpret_cast<float4 *>(out + (((size_t)seg * p.out_h + oy) * p.out_w + ox) * p.cout + c) = acc;
+    }
+}
+
+void launch_dwconv(const float *in, const float *w, const float *b, float *out, const ConvParams &p, int n_seg,
+                   hipStream_t s) {
+    const long total = (long)n_seg * p.out_h * p.out_w * (p.cout / 4);
+    long blocks = (total + 255) / 256;
+    if (blocks > 256L * 64) blocks = 256L * 64;
+    dim3 grid((unsigned)blocks), block(256);
+#define BH_DW_CASE(KSV, STV)                                                                       \
+    if (p.kh == KSV && p.sh == STV) {                                                               \
+        hipLaunchKernelGGL((dwconv_kernel<KSV, STV>), grid, block, 0, s, in, w, b, out, p, n_seg);  \
+        return;                                                                                     \
+    }
+    BH_DW_CASE(3, 1) BH_DW_CASE(3, 2) BH_DW_CASE(5, 1) BH_DW_CASE(5, 2)
+#undef BH_DW_CASE
+}
+
+// ---------------------------------------------------------------------------------------
+// Direct conv for the stem (Cin = n_branches = 2): weights [kh][kw][cin][cout] in LDS,
+// one lane = one output pixel x 8 output channels.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_direct_kernel(const float *__restrict__ in, const float *__restrict__ w,
+                                                           const float *__restrict__ b, float *__restrict__ out,
+                                                           ConvParams p, int n_seg) {
+    extern __shared__ __attribute__((aligned(16))) float ws[];
+    const int wn = p.kh * p.kw * p.cin * p.cout;
+    for (int i = threadIdx.x; i < wn; i += 256) ws[i] = w[i];
+    __syncthreads();
+    const int cgn = p.cout >> 3;
+    const long total = (long)n_seg * p.out_h * p.out_w * cgn;
+    for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
+        const int cg = (int)(g % cgn);
+        long px = g / cgn;
+        const int ox = (int)(px % p.out_w);
+        px /= p.out_w;
+        const int oy = (int)(px % p.out_h);
+        const int seg = (int)(px / p.out_h);
+        const int co = cg << 3;
+        float acc[8];
+#pragma unroll
+        for (int n = 0; n < 8; n++) acc[n] = b[co + n];
+        const float *ib = in + (size_t)seg * p.in_h * p.in_w * p.cin;
+        for (int dy = 0; dy < p.kh; dy++) {
+            const int iy = oy * p.sh - p.pad_t + dy;
+            if (iy < 0 || iy >= p.in_h) continue;
+            for (int dx = 0; dx < p.kw; dx++) {
+                const int ix = ox * p.sw - p.pad_l + dx;
+                if (ix < 0 || ix >= p.in_w) continue;
+                for (int c = 0; c < p.cin; c++) {
+                    const float a = p.in_layout == 1 ? ib[((size_t)c * p.in_h + iy) * p.in_w + ix]
+                                                     : ib[((size_t)iy * p.in_w + ix) * p.cin + c];
+                    const float *wr = ws + ((dy * p.kw + dx) * p.cin + c) * p.cout + co;
+#pragma unroll
+                    for (int n = 0; n < 8; n++) acc[n] += a * wr[n];
+                }
+            }
+        }
+        float *o = out + (((size_t)seg * p.out_h + oy) * p.out_w + ox) * p.cout + co;
+        float4 v0 = make_float4(act_apply(acc[0], p.act), act_apply(acc[1], p.act), act_apply(acc[2], p.act),
+                                act_apply(acc[3], p.act));
+        float4 v1 = make_float4(act_apply(acc[4], p.act), act_apply(acc[5], p.act), act_apply(acc[6], p.act),
+                                act_apply(acc[7], p.act));
+        *reinterpret_cast<float4 *>(o) = v0;
+        *reinterpret_cast<float4 *>(o + 4) = v1;
+    }
+}
+
+void launch_conv_direct(const float *in, const float *w, const float *b, float *out, const ConvParams &p,
+                        int n_seg, hipStream_t s) {
+    const long total = (long)n_seg * p.out_h * p.out_w * (p.cout / 8);
+    long blocks = (total + 255) / 256;
+    if (blocks > 256L * 32) blocks = 256L * 32;
+    const size_t smem = (size_t)p.kh * p.kw * p.cin * p.cout * sizeof(float);
+    hipLaunchKernelGGL(conv_direct_kernel, dim3((unsigned)blocks), dim3(256), smem, s, in, w, b, out, p, n_seg);
+}
+
+// ---------------------------------------------------------------------------------------
+// Global average pool [n][P][C] -> [n][C]; sum in pixel order then * (1/P) like the oracle
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gap_kernel(const float *__restrict__ in, float *__restrict__ out, int n_seg,
+                                                   int P, int C) {
+    const int c4n = C >> 2;
+    const long total = (long)n_seg * c4n;
+    const long g = (long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= total) return;
+    const int c = (int)(g % c4n) << 2;
+    const int seg = (int)(g / c4n);
+    const float *ib = in + (size_t)seg * P * C + c;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int px = 0; px < P; px++) {
+        const float4 a = *reinterpret_cast<const float4 *>(ib + (size_t)px * C);
+        acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+    }
+    const float inv = 1.0f / (float)P;
+    *reinterpret_cast<float4 *>(out + (size_t)seg * C + c) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+}
+
+void launch_gap(const float *in, float *out, int n_seg, int P, int C, hipStream_t s) {
+    const long total = (long)n_seg * (C / 4);
+    hipLaunchKernelGGL(gap_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, n_seg, P, C);
+}
+
+// ---------------------------------------------------------------------------------------
+// activation + top-k (block per segment).  Ranks on the logit (monotone in the confidence,
+// immune to saturated-sigmoid ties), ties to the lower class index -- same rule as the
+// oracle's bo_topk.  idx = -1 / conf = 0 pad the unused slots.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ logits, int n_classes, int out_act,
+                                                    int top_k, float min_conf, int32_t *__restrict__ idx,
+                                                    float *__restrict__ conf) {
+    const int seg = blockIdx.x;
+    const float *lg = logits + (size_t)seg * n_classes;
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    __shared__ int chosen[32];
+    __shared__ float red[2];
+    const int tid = threadIdx.x;
+    // softmax statistics
+    float mx = -INFINITY, sum = 0.f;
+    if (out_act == 2) {
+        float m = -INFINITY;
+        for (int i = tid; i < n_classes; i += 256) m = fmaxf(m, lg[i]);
+        sv[tid] = m;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) { if (tid < s) sv[tid] = fmaxf(sv[tid], sv[tid + s]); __syncthreads(); }
+        mx = sv[0];
+        __syncthreads();
+        // the oracle sums exp() in class order; do the same on one lane for bit-stable sums
+        if (tid == 0) {
+            float sacc = 0.f;
+            for (int i = 0; i < n_classes; i++) sacc += expf(lg[i] - mx);
+            red[0] = sacc;
+        }
+        __syncthreads();
+        sum = red[0];
+    }
+    int kept = 0;
+    bool stop = false;
+    for (int k = 0; k < top_k; k++) {
+        float bv = -INFINITY; int bi = -1;
+        if (!stop) {
+            for (int i = tid; i < n_classes; i += 256) {
+                const float v = lg[i];
+                if (v != v) continue;
+                bool taken = false;
+                for (int j = 0; j < kept; j++) taken |= (chosen[j] == i);
+                if (taken) continue;
+                if (bi < 0 || v > bv) { bv = v; bi = i; }
+            }
+        }
+        sv[tid] = bv; si[tid] = bi;
+        __syncthreads();
+        for (int s = 128; s > 0; s >>= 1) {
+            if (tid < s) {
+                const float ov = sv[tid + s]; const int oi = si[tid + s];
+                const bool take = oi >= 0 && (si[tid] < 0 || ov > sv[tid] || (ov == sv[tid] && oi < si[tid]));
+                if (take) { sv[tid] = ov; si[tid] = oi; }
+            }
+            __syncthreads();
+        }
+        const int best = si[0];
+        float p = 0.f;
+        if (best >= 0) {
+            const float v = sv[0];
+            p = out_act == 1 ? 1.0f / (1.0f + expf(-v)) : out_act == 2 ? expf(v - mx) / sum : v;
+        }
+        const bool ok = !stop && best >= 0 && p >= min_conf;
+        if (!ok) stop = true;
+        if (tid == 0) {
+            idx[(size_t)seg * top_k + k] = ok ? best : -1;
+            conf[(size_t)seg * top_k + k] = ok ? p : 0.f;
+            if (ok) chosen[kept] = best;
+        }
+        if (ok) kept++;
+        __syncthreads();
+    }
+}
+
+void launch_topk(const float *logits, int n_seg, int n_classes, int out_act, int top_k, float min_conf,
+                 int32_t *idx, float *conf, hipStream_t s) {
+    hipLaunchKernelGGL(topk_kernel, dim3(n_seg), dim3(256), 0, s, logits, n_classes, out_act, top_k, min_conf, idx, conf);
+}
+
+}  // namespace bh

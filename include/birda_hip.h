@@ -1,0 +1,161 @@
+/*
+ * birda_hip.h -- C ABI of libbirda_hip.so, the MI355X (gfx950) implementation of birda's
+ * classifier hot path: raw f32 segments -> [resample] -> STFT/mel front-end -> conv stack
+ * -> logits -> activation/top-k.
+ *
+ * birda reaches this path through the Rust API of the third-party crate birdnet-onnx
+ * (reference src/inference/classifier.rs:9-13); there is no FFI in the reference, so every
+ * entry point below names the Rust call it replaces (file:line under /root/reference).
+ * A maintainer binds these with `extern "C"` behind `BirdClassifier`.
+ *
+ * Conventions: plain pointers and sizes only; every function returns BH_OK (0) or a
+ * negative bh_status and never aborts; bh_last_error() returns a thread-local message
+ * (the `reason` of Error::Inference / Error::ClassifierBuild, classifier.rs:281-283,472-474).
+ * A classifier handle may be used from one thread at a time per batch context (the
+ * reference calls `&self` methods from the main thread only, processor.rs:647-671).
+ * There is NO CPU fallback: without a HIP device every compute entry point fails with
+ * BH_ERR_NO_DEVICE.
+ */
+#ifndef BIRDA_HIP_H
+#define BIRDA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BH_API __attribute__((visibility("default")))
+
+typedef enum {
+    BH_OK = 0,
+    BH_ERR_INVALID = -1,   /* bad argument (wrong segment length, null pointer, batch > context) */
+    BH_ERR_IO = -2,        /* model / labels file unreadable or malformed */
+    BH_ERR_NO_DEVICE = -3, /* no HIP device / device index out of range */
+    BH_ERR_HIP = -4,       /* a HIP runtime call failed; message carries hipGetErrorString */
+    BH_ERR_LABELS = -5,    /* label count != model output width (inference/mod.rs:34-37) */
+    BH_ERR_UNSUPPORTED = -6
+} bh_status;
+
+#define BH_MAX_TOP_K 32
+
+/* ClassifierBuilder::new().model_path().labels_path().top_k().min_confidence()
+ * (classifier.rs:269-273) + execution-provider choice (classifier.rs:662-691 -> device). */
+typedef struct {
+    const char *model_path;  /* BHM1 container (birda_amd/modelfile.py) */
+    const char *labels_path; /* one label per line; NULL = no labels (logits-only use) */
+    uint32_t top_k;          /* DEFAULT_TOP_K = 5, constants.rs:178 */
+    float min_confidence;    /* DEFAULT_MIN_CONFIDENCE = 0.1, constants.rs:25 */
+    int32_t device;          /* HIP device ordinal (one process per GPU) */
+    uint32_t flags;          /* reserved, 0 */
+} bh_config;
+
+/* birdnet_onnx::ModelConfig{sample_rate, segment_duration, sample_count} + labels().len()
+ * (classifier.rs:295-297,306,360-377) */
+typedef struct {
+    uint32_t sample_rate;
+    float segment_duration;
+    uint32_t sample_count;
+    uint32_t n_classes;
+    uint32_t embedding_dim;
+    uint32_t output_activation; /* 0 none, 1 sigmoid (v2.4), 2 softmax (Perch) */
+    uint32_t spec_channels, spec_h, spec_w;
+    uint32_t n_layers;
+    uint64_t macs_per_segment;  /* conv stack multiply-accumulates (for MFMA utilisation) */
+    uint64_t mel_flops_per_segment;
+} bh_model_info;
+
+/* birdnet_onnx::PredictionResult{predictions: Vec<Prediction{species, confidence, index}>}
+ * as consumed at processor.rs:363-385; `species` = bh_classifier_label(index[i]). */
+typedef struct {
+    uint32_t n_pred;
+    int32_t index[BH_MAX_TOP_K];
+    float confidence[BH_MAX_TOP_K];
+} bh_result;
+
+typedef struct bh_classifier bh_classifier;
+typedef struct bh_batch_context bh_batch_context;
+
+/* available_execution_providers() / provider metadata (classifier.rs:259; provider.rs:17-85) */
+BH_API int bh_device_count(void);
+BH_API const char *bh_backend_name(void); /* "HIP (gfx950)" */
+BH_API const char *bh_last_error(void);
+
+/* ClassifierBuilder::build() (classifier.rs:281-283).  Loads the model, uploads weights,
+ * precomputes the folded STFT*mel operators, validates the label count. */
+BH_API int bh_classifier_create(const bh_config *cfg, bh_classifier **out);
+BH_API void bh_classifier_destroy(bh_classifier *c);
+
+/* .config() / .labels() (classifier.rs:360-377) */
+BH_API int bh_classifier_info(const bh_classifier *c, bh_model_info *info);
+BH_API const char *bh_classifier_label(const bh_classifier *c, uint32_t index);
+
+/* BirdClassifier::ensure_warm / warmup (classifier.rs:414-466): one all-zero inference per
+ * distinct batch size, recorded only on success. */
+BH_API int bh_classifier_ensure_warm(bh_classifier *c, size_t batch_size);
+BH_API int bh_classifier_is_warm(const bh_classifier *c, size_t batch_size);
+
+/* create_batch_context(max_batch_size) / ctx.input_buffer_bytes()
+ * (classifier.rs:559-565; processor.rs:582-603).  Owns every device buffer a batch needs. */
+BH_API int bh_batch_context_create(bh_classifier *c, size_t max_batch, bh_batch_context **out);
+BH_API void bh_batch_context_destroy(bh_batch_context *ctx);
+BH_API size_t bh_batch_context_bytes(const bh_batch_context *ctx);       /* input buffer bytes */
+BH_API size_t bh_batch_context_device_bytes(const bh_batch_context *ctx); /* all device memory */
+
+/* Classifier::predict(&[f32]) (classifier.rs:469-475): exactly sample_count samples. */
+BH_API int bh_predict(bh_classifier *c, const float *segment, size_t n_samples, bh_result *out);
+
+/* Classifier::predict_batch(&[&[f32]]) (classifier.rs:478-488): independent host slices,
+ * order preserved, one result per input.  Uses an internal context sized on demand. */
+BH_API int bh_predict_batch(bh_classifier *c, const float *const *segments, size_t n,
+                            size_t n_samples, bh_result *out);
+
+/* Classifier::predict_batch_with_context (classifier.rs:571-582). n <= ctx max_batch. */
+BH_API int bh_predict_batch_with_context(bh_classifier *c, bh_batch_context *ctx,
+                                         const float *const *segments, size_t n,
+                                         size_t n_samples, bh_result *out);
+
+/* Contiguous host fast path [n][sample_count] (same semantics as predict_batch). */
+BH_API int bh_predict_batch_contig(bh_classifier *c, bh_batch_context *ctx, const float *base,
+                                   size_t n, bh_result *out);
+
+/* Raw outputs.  Not exposed to birda today; BASELINE.json's max |dlogit| needs them.
+ * logits: host [n][n_classes]; embeddings (nullable): host [n][embedding_dim]
+ * (PredictionResult.embeddings, processor.rs:325-329). */
+BH_API int bh_predict_batch_logits(bh_classifier *c, bh_batch_context *ctx, const float *base,
+                                   size_t n, float *logits, float *embeddings);
+
+/* ---- device-resident path (bench / multi-GPU sharding: inputs already in HBM) -------- */
+/* d_segments: device f32 [n][sample_count]; d_logits: device f32 [n][n_classes];
+ * d_topk_index/d_topk_conf (nullable): device [n][top_k], -1 / 0 padded.
+ * Enqueues on the context stream; call bh_batch_context_synchronize before reading.
+ * n may exceed the context's max_batch: it is processed in max_batch slices. */
+BH_API int bh_forward_device(bh_classifier *c, bh_batch_context *ctx, const float *d_segments,
+                             size_t n, float *d_logits, int32_t *d_topk_index,
+                             float *d_topk_conf);
+BH_API int bh_batch_context_synchronize(bh_batch_context *ctx);
+BH_API void *bh_batch_context_stream(bh_batch_context *ctx); /* hipStream_t */
+
+/* Debug/parity: copy tensor `t` (0 = spectrogram, i = output of layer i-1... see
+ * modelfile.py) of the LAST forward on this context to host; rows = n of that forward. */
+BH_API int bh_debug_read_tensor(bh_classifier *c, bh_batch_context *ctx, uint32_t tensor,
+                                float *host, size_t max_floats);
+BH_API uint64_t bh_tensor_floats(const bh_classifier *c, uint32_t tensor);
+
+/* Per-stage kernel timing of the last bh_forward_device call when profiling is enabled:
+ * stage 0 = min/max, 1 = mel front-end, 2 = stem conv, 3 = depthwise, 4 = pointwise,
+ * 5 = pool, 6 = dense, 7 = top-k.  ms[] receives BH_N_STAGES floats (HIP-event times). */
+#define BH_N_STAGES 8
+BH_API int bh_batch_context_set_profiling(bh_batch_context *ctx, int enabled);
+BH_API int bh_batch_context_stage_ms(bh_batch_context *ctx, float *ms, uint32_t *launches);
+
+/* ---- resampler (reference src/audio/resample.rs:10-105; rubato Fft, FixedSync::Both) -- */
+/* host in / host out convenience: returns output length via *n_out */
+BH_API int bh_resample(bh_classifier *c, const float *in, size_t n_in, uint32_t from_rate,
+                       uint32_t to_rate, float *out, size_t out_cap, size_t *n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BIRDA_HIP_H */
