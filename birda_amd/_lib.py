@@ -62,6 +62,40 @@ SYMBOLS = [
     ("bh_resample", C.c_int, [_VP, _VP, _SZ, C.c_uint32, C.c_uint32, _VP, _SZ, C.POINTER(_SZ)]),
 ]
 
+
+class BhhProcessingConfig(C.Structure):
+    _fields_ = [("input_path", C.c_char_p), ("output_dir", C.c_char_p), ("display_path", C.c_char_p),
+                ("min_confidence", C.c_float), ("overlap", C.c_float), ("batch_size", C.c_size_t),
+                ("csv_bom", C.c_int)]
+
+
+class BhhProcessResult(C.Structure):
+    _fields_ = [("detections", C.c_size_t), ("segments", C.c_size_t), ("duration_secs", C.c_double),
+                ("audio_duration_secs", C.c_double), ("segments_per_sec", C.c_double),
+                ("effective_batch", C.c_size_t), ("batches", C.c_size_t), ("padded_rows", C.c_size_t),
+                ("output_path", C.c_char * 1024)]
+
+
+# every symbol include/birda_host.h declares
+HOST_SYMBOLS = [
+    ("bhh_last_error", C.c_char_p, []),
+    ("bhh_decoder_open", C.c_int, [C.c_char_p, C.POINTER(_VP)]),
+    ("bhh_decoder_close", None, [_VP]),
+    ("bhh_decoder_sample_rate", C.c_uint32, [_VP]),
+    ("bhh_decoder_duration_hint", C.c_int, [_VP, C.POINTER(C.c_double)]),
+    ("bhh_decoder_next_segment", C.c_int, [_VP, _SZ, _SZ, _VP, C.POINTER(_SZ)]),
+    ("bhh_estimate_segment_count", C.c_int64, [C.c_int, C.c_double, C.c_float, C.c_float]),
+    ("bhh_effective_batch_size", _SZ, [_SZ, C.c_int64]),
+    ("bhh_source_samples", _SZ, [_SZ, C.c_uint32, C.c_uint32]),
+    ("bhh_duration_to_samples", _SZ, [C.c_float, C.c_uint32]),
+    ("bhh_watchdog_timeout_secs", C.c_uint64, []),
+    ("bhh_watchdog_start", _VP, [C.c_uint64, _SZ]),
+    ("bhh_watchdog_cancel", None, [_VP]),
+    ("bhh_csv_header", _SZ, [C.c_int, C.c_char_p, _SZ]),
+    ("bhh_csv_row", _SZ, [C.c_char_p, C.c_float, C.c_float, C.c_float, C.c_char_p, C.c_char_p, _SZ]),
+    ("bhh_process_file", C.c_int, [_VP, C.POINTER(BhhProcessingConfig), C.POINTER(BhhProcessResult)]),
+]
+
 _lib = None
 
 
@@ -74,7 +108,7 @@ def load():
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C birda_amd/csrc` "
                            "(the HIP hot path has no CPU fallback)")
     L = C.CDLL(LIB_PATH)
-    for name, res, args in SYMBOLS:
+    for name, res, args in SYMBOLS + HOST_SYMBOLS:
         fn = getattr(L, name)  # AttributeError if the export is missing
         fn.restype = res
         fn.argtypes = args

@@ -1,0 +1,221 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every symbol the
+headers declare, fails loudly without a device, and the C++ host logic (decoder/segmenter,
+batch sizing, CSV, watchdog) agrees with the oracle and the reference's unit-test cases."""
+import ctypes as C
+import json
+import os
+import re
+import struct
+import time
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+
+@pytest.fixture(scope="module")
+def L():
+    from birda_amd import _lib
+    return _lib.load()
+
+
+@pytest.fixture(scope="module")
+def cases():
+    with open(os.path.join(GOLDEN, "reference_unit_cases.json")) as f:
+        return json.load(f)
+
+
+def _declared(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    return sorted(set(re.findall(r"BH_API[^;(]*?\b(bhh?_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(L):
+    from birda_amd import _lib
+    names = _declared("birda_hip.h") + _declared("birda_host.h")
+    assert len(names) >= 40
+    bound = {n for n, _, _ in _lib.SYMBOLS + _lib.HOST_SYMBOLS}
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/ but not exported"
+        assert n in bound, f"{n} has no ctypes prototype in birda_amd/_lib.py"
+
+
+def test_no_oracle_in_product_library():
+    """The product must not link or embed the checker."""
+    blob = open(os.path.join(ROOT, "birda_amd", "libbirda_hip.so"), "rb").read()
+    assert b"bo_forward" not in blob and b"birda_oracle" not in blob
+    for root, _, files in os.walk(os.path.join(ROOT, "birda_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp")):
+                src = open(os.path.join(root, f), errors="replace").read()
+                assert "from oracle" not in src and "import oracle" not in src and "libbirda_oracle" not in src, f
+                assert "dlopen" not in src, f
+
+
+def test_backend_name_and_failing_loudly_without_device(L, model_dir):
+    import torch
+    assert L.bh_backend_name() == b"HIP (gfx950)"
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from birda_amd._lib import BirdaHipError
+    from birda_amd.classifier import BirdClassifier
+    with pytest.raises(BirdaHipError) as e:
+        BirdClassifier(model_dir["mini"][0])
+    assert e.value.code == -3 and "no CPU path" in str(e.value)
+
+
+def test_classifier_create_rejects_bad_inputs(L, tmp_path, model_dir):
+    from birda_amd._lib import BirdaHipError
+    from birda_amd.classifier import BirdClassifier
+    with pytest.raises(BirdaHipError) as e:
+        BirdClassifier(str(tmp_path / "missing.bhm"))
+    assert e.value.code == -2
+    bad = tmp_path / "bad.bhm"
+    bad.write_bytes(b"ONNX" + b"\0" * 600)
+    with pytest.raises(BirdaHipError) as e:
+        BirdClassifier(str(bad))
+    assert e.value.code == -2 and "BHM1" in str(e.value)
+    # label count must equal the output width (reference src/inference/mod.rs:34-37)
+    short = tmp_path / "short.txt"
+    short.write_text("a_b\nc_d\n")
+    with pytest.raises(BirdaHipError) as e:
+        BirdClassifier(model_dir["mini"][0], str(short))
+    assert e.value.code == -5
+    with pytest.raises(BirdaHipError):
+        BirdClassifier(model_dir["mini"][0], top_k=0)
+
+
+# ---------------- host logic ----------------
+def _write_wav(path, pcm_bytes, rate, channels, bits, fmt_tag=1, extra_chunk=False):
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(pcm_bytes) + (12 if extra_chunk else 0)) + b"WAVE"
+    if extra_chunk:
+        hdr += b"LIST" + struct.pack("<I", 3) + b"abc\0"  # odd-sized chunk + pad byte
+    hdr += b"fmt " + struct.pack("<IHHIIHH", 16, fmt_tag, channels, rate, rate * channels * bits // 8, channels * bits // 8, bits)
+    hdr += b"data" + struct.pack("<I", len(pcm_bytes))
+    with open(path, "wb") as f:
+        f.write(hdr + pcm_bytes)
+
+
+def test_decoder_matches_oracle_segmenter_and_pcm_scaling(tmp_path, oracle_lib, cases):
+    from birda_amd.pipeline import StreamingDecoder
+    OL = oracle_lib.lib()
+    rng = np.random.default_rng(5)
+    for (channels, bits, tag, extra) in [(1, 16, 1, False), (2, 16, 1, True), (1, 32, 1, False), (2, 32, 3, False), (1, 24, 1, False)]:
+        frames = 30011
+        if tag == 3:
+            raw = rng.uniform(-1, 1, frames * channels).astype("<f4")
+            mono = np.zeros(frames, np.float32)
+            OL.bo_f32_to_mono(raw, frames, channels, mono)
+            data = raw.tobytes()
+        elif bits == 16:
+            raw = rng.integers(-32768, 32768, frames * channels).astype("<i2")
+            mono = np.zeros(frames, np.float32)
+            OL.bo_pcm16_to_mono(raw.ctypes.data, frames, channels, mono)
+            data = raw.tobytes()
+        elif bits == 32:
+            raw = rng.integers(-2**31, 2**31, frames * channels).astype("<i4")
+            mono = np.zeros(frames, np.float32)
+            OL.bo_pcm32_to_mono(raw.ctypes.data, frames, channels, mono)
+            data = raw.tobytes()
+        else:  # 24-bit: widened to S32 (<< 8) then the S32 rule
+            v = rng.integers(-2**23, 2**23, frames * channels).astype("<i4")
+            data = b"".join(int(x).to_bytes(3, "little", signed=True) for x in v)
+            wide = (v.astype(np.int64) << 8).astype("<i4")
+            mono = np.zeros(frames, np.float32)
+            OL.bo_pcm32_to_mono(wide.ctypes.data, frames, channels, mono)
+        p = str(tmp_path / f"t_{channels}_{bits}_{tag}.wav")
+        _write_wav(p, data, 22050, channels, bits, tag, extra)
+        d = StreamingDecoder(p)
+        assert d.sample_rate() == 22050
+        assert abs(d.duration_hint() - frames / 22050) < 1e-12
+        want = oracle_lib.segment_stream(mono, 7000, 1300)
+        got = []
+        while True:
+            r = d.next_segment(7000, 1300)
+            if r is None:
+                break
+            got.append((r[0].copy(), r[1]))
+        assert [s for _, s in got] == [s for _, s in want]
+        for (a, _), (b, _) in zip(got, want):
+            assert np.array_equal(a, b)
+        d.close()
+
+
+def test_decoder_reference_segment_traces(tmp_path, cases):
+    from birda_amd import synth
+    from birda_amd.pipeline import StreamingDecoder
+    from birda_amd._lib import BirdaHipError
+    for i, c in enumerate(cases["segmenter"]):
+        p = str(tmp_path / f"s{i}.wav")
+        x = ((np.arange(c["n_samples"]) % 2000) - 1000) / 1000.0 * 0.9
+        synth.write_wav_pcm16(p, x, c["rate"])
+        d = StreamingDecoder(p)
+        starts = []
+        while True:
+            r = d.next_segment(c["seg"], c["ovl"])
+            if r is None:
+                break
+            starts.append(r[1])
+            assert r[0].size == c["seg"]
+        assert starts == c["starts"], c["src"]
+    d = StreamingDecoder(p)
+    with pytest.raises(BirdaHipError):   # overlap >= segment -> Error::Internal (decode.rs:156-162)
+        d.next_segment(100, 100)
+    with pytest.raises(BirdaHipError):
+        StreamingDecoder(str(tmp_path / "nope.wav"))
+    junk = tmp_path / "junk.wav"
+    junk.write_bytes(b"not a wav file at all")
+    with pytest.raises(BirdaHipError):
+        StreamingDecoder(str(junk))
+
+
+def test_batch_sizing_and_estimates_match_reference_cases(L, cases, oracle_lib):
+    from birda_amd import pipeline
+    OL = oracle_lib.lib()
+    for c in cases["estimate_segment_count"]:
+        assert pipeline.estimate_segment_count(c["duration"], c["seg"], c["ovl"]) == c["expect"], c["src"]
+    for c in cases["batching"]:
+        assert pipeline.effective_batch_size(c["batch_size"], c["estimated"]) == c["effective"]
+    assert pipeline.effective_batch_size(8, None) == 8
+    for c in cases["source_sizing"]:
+        assert pipeline.source_samples(c["target"], c["src_rate"], c["dst_rate"]) == c["expect"]
+    # f32 arithmetic of (seconds * rate) as usize, against the oracle over awkward values
+    for secs, rate in [(3.0, 48000), (5.0, 32000), (0.25, 48000), (1.5, 44100), (0.1, 22050), (2.9999, 48000), (0.0, 48000)]:
+        assert L.bhh_duration_to_samples(secs, rate) == OL.bo_duration_to_samples(secs, rate)
+
+
+def test_csv_writer_matches_reference_cases_and_oracle(L, cases, oracle_lib):
+    from birda_amd import pipeline
+    OL = oracle_lib.lib()
+    for r in cases["csv"]["rows"]:
+        assert pipeline.csv_row(r["label"], r["start"], r["end"], r["conf"], r["path"]).decode() == r["row"] + "\n"
+    for c in cases["detection_from_label"]:
+        assert pipeline.csv_row(c["label"], 0.0, 3.0, 0.5, "f.wav").decode() == f"0.0,3.0,{c['scientific']},{c['common']},0.5000,f.wav\n"
+    for e in cases["csv"]["escape"]:
+        assert pipeline.csv_row("a_b", 0.0, 3.0, 0.5, e["in"]).decode() == f"0.0,3.0,a,b,0.5000,{e['out']}\n"
+    assert list(pipeline.csv_header(True)[:3]) == cases["csv"]["bom"]
+    assert pipeline.csv_header(False).decode() == cases["csv"]["header"] + "\n"
+    # rounding of {:.1}/{:.4} on awkward f32 values: byte-identical to the oracle
+    buf = C.create_string_buffer(8192)
+    rng = np.random.default_rng(3)
+    for _ in range(200):
+        st, conf = np.float32(rng.uniform(0, 4000)), np.float32(rng.uniform(0, 1))
+        lab = "Genus x_Name, \"q\"" if rng.random() < 0.3 else "Plain label"
+        n = OL.bo_csv_row(lab.encode(), st, np.float32(st + np.float32(3.0)), conf, b"/a b/c,d.wav", buf)
+        assert pipeline.csv_row(lab, float(st), float(np.float32(st + np.float32(3.0))), float(conf), "/a b/c,d.wav") == buf.raw[:n]
+    for conf in (0.00005, 0.99995, 0.12345, 0.5, 0.25, 0.1):
+        n = OL.bo_csv_row(b"a_b", 1.25, 4.25, np.float32(conf), b"f", buf)
+        assert pipeline.csv_row("a_b", 1.25, 4.25, float(np.float32(conf)), "f") == buf.raw[:n]
+
+
+def test_watchdog_cancelled_when_dropped(L, monkeypatch):
+    """reference src/gpu/watchdog.rs:73-84: a dropped guard must not kill the process."""
+    g = L.bhh_watchdog_start(300, 32)
+    L.bhh_watchdog_cancel(g)
+    time.sleep(0.6)
+    monkeypatch.delenv("BIRDA_INFERENCE_TIMEOUT", raising=False)
+    assert L.bhh_watchdog_timeout_secs() == 10          # processor.rs:196
+    for v, want in (("25", 25), ("0", 10), ("3601", 10), ("abc", 10), ("3600", 3600), ("1", 1)):
+        monkeypatch.setenv("BIRDA_INFERENCE_TIMEOUT", v)
+        assert L.bhh_watchdog_timeout_secs() == want    # processor.rs:205-211

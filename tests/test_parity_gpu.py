@@ -1,0 +1,290 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded inputs, against the committed golden vectors, and -- at full BASELINE sizes --
+through size-independent properties.
+
+Tolerances (fp32 path).  Two fp32 implementations of this model cannot agree bit for bit:
+  * the spectrogram ends in |v|^0.45 (square then ^(1/(1+e^1.23))), which is not Lipschitz at
+    v = 0: an fp32 rounding d in the mel projection moves a pixel by up to ~|d|^0.45 (~1e-3
+    for d ~ 1e-7).  Such pixels are rare (mean |d| stays ~1e-7), so spectrograms are compared
+    with a loose max (2e-3) and a tight mean (1e-5);
+  * every later layer is Lipschitz; differences come from summation order (oracle: plain
+    mul+add in k order; MFMA: fmaf chain in a permuted k order) and from libm vs ocml erff.
+LOGIT_RTOL is the stated fp32 logit tolerance: max |dlogit| <= 2e-5 * max(1, max|logit|)
+... measured 1.3e-6 relative on the full model (profiles/README.md).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_RTOL = 2e-5
+SPEC_MAX_ATOL = 2e-3
+SPEC_MEAN_ATOL = 1e-5
+
+
+def _logit_close(got, ref):
+    scale = max(1.0, float(np.abs(ref).max()))
+    err = float(np.abs(got - ref).max())
+    assert np.isfinite(got).all()
+    assert err <= LOGIT_RTOL * scale, f"max|dlogit| {err:.3e} > {LOGIT_RTOL * scale:.3e}"
+    return err
+
+
+@pytest.fixture(scope="module")
+def clf_mini(model_dir):
+    from birda_amd.classifier import BirdClassifier
+    path, labels, m, _ = model_dir["mini"]
+    c = BirdClassifier(path, labels, top_k=5, min_confidence=0.1)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def clf_tiny(model_dir):
+    from birda_amd.classifier import BirdClassifier
+    path, labels, m, _ = model_dir["birdnet_v24_tiny"]
+    c = BirdClassifier(path, labels, top_k=5, min_confidence=0.1)
+    yield c
+    c.close()
+
+
+def test_native_library_is_the_one_loaded():
+    from birda_amd import _lib
+    L = _lib.load()
+    assert L.bh_device_count() >= 1
+    maps = open("/proc/self/maps").read()
+    assert "birda_amd/libbirda_hip.so" in maps
+
+
+def test_mini_logits_match_golden_vectors_and_oracle(clf_mini, model_dir, oracle_lib):
+    from birda_amd import synth
+    path, _, m, _ = model_dir["mini"]
+    vec = np.load(os.path.join(GOLDEN, "model_vectors.npz"))
+    segs = synth.synth_segments(4, m.sample_count, m.sample_rate)
+    ctx = clf_mini.create_batch_context(4)
+    logits, emb = clf_mini.predict_logits(ctx, segs, want_embeddings=True)
+    assert np.abs(logits - vec["mini_logits"]).max() < 1e-3       # float64 torch/numpy vectors
+    assert np.abs(emb - vec["mini_embedding"]).max() < 1e-3
+    om = oracle_lib.OracleModel(path)
+    ref, ref_emb = om.forward(segs, want_embeddings=True)
+    _logit_close(logits, ref)
+    _logit_close(emb, ref_emb)
+    ctx.close()
+
+
+def test_every_tensor_matches_oracle_layer_by_layer(model_dir, oracle_lib, monkeypatch):
+    from birda_amd import synth
+    from birda_amd.classifier import BirdClassifier
+    monkeypatch.setenv("BIRDA_HIP_KEEP_TENSORS", "1")
+    for kind, n in (("mini", 3), ("birdnet_v24_tiny", 2)):
+        path, _, m, _ = model_dir[kind]
+        segs = synth.synth_segments(n, m.sample_count, m.sample_rate, start=11)
+        clf = BirdClassifier(path)
+        ctx = clf.create_batch_context(n)
+        clf.predict_logits(ctx, segs)
+        om = oracle_lib.OracleModel(path)
+        for t in range(len(m.layers) + 1):
+            ref = om.forward(segs, dump_tensor=t)[1]
+            got = clf.read_tensor(ctx, t, n)
+            d = np.abs(got - ref)
+            scale = max(1.0, float(np.abs(ref).max()))
+            assert np.isfinite(got).all(), (kind, t)
+            # the spectrogram's rare |d|^0.45 pixels propagate through the first layers
+            assert d.max() <= SPEC_MAX_ATOL * scale, (kind, t, d.max())
+            assert d.mean() <= SPEC_MEAN_ATOL * scale, (kind, t, d.mean())
+        ctx.close()
+        clf.close()
+
+
+def test_v24_frontend_matches_golden_spectrogram(clf_tiny, model_dir, monkeypatch):
+    from birda_amd import synth
+    from birda_amd.classifier import BirdClassifier
+    monkeypatch.setenv("BIRDA_HIP_KEEP_TENSORS", "1")
+    path, _, m, _ = model_dir["birdnet_v24_tiny"]
+    vec = np.load(os.path.join(GOLDEN, "model_vectors.npz"))
+    clf = BirdClassifier(path)
+    ctx = clf.create_batch_context(1)
+    logits = clf.predict_logits(ctx, synth.synth_segment(3)[None])
+    spec = clf.read_tensor(ctx, 0, 1).reshape(2, 96, 511)[:, :, ::7]
+    ref = vec["tiny_spec_seg3_frames_every7"]
+    assert np.abs(spec - ref).max() < SPEC_MAX_ATOL and np.abs(spec - ref).mean() < SPEC_MEAN_ATOL
+    assert np.abs(logits[0] - vec["tiny_logits_seg3"]).max() < 1e-3
+    ctx.close()
+    clf.close()
+
+
+def test_full_model_logits_and_topk_match_oracle(full_model, oracle_lib):
+    """BirdNET-v2.4-shaped model (51 layers, 6 522 classes), 6 segments incl. edge inputs."""
+    from birda_amd import synth
+    from birda_amd.classifier import BirdClassifier
+    path, labels, m, names = full_model
+    segs = synth.synth_segments(6, m.sample_count, m.sample_rate, start=100)
+    segs[3] = 0.0                                   # all-zero segment = warm-up / padding row
+    segs[4] = np.float32(0.25)                      # constant: max - min = 0 -> eps path
+    segs[5, ::2] = 1.0; segs[5, 1::2] = -1.0        # full-scale Nyquist square wave
+    clf = BirdClassifier(path, labels, top_k=5, min_confidence=0.01)
+    ctx = clf.create_batch_context(8)
+    logits = clf.predict_logits(ctx, segs)
+    om = oracle_lib.OracleModel(path)
+    ref = om.forward(segs)
+    err = _logit_close(logits, ref)
+    print(f"full model max|dlogit| = {err:.3e} on max|logit| {np.abs(ref).max():.2f}")
+    res = clf.predict_batch_with_context(ctx, list(segs))
+    for i, r in enumerate(res):
+        idx, conf = oracle_lib.topk(ref[i], 1, 5, 0.01)
+        got_idx = [p.index for p in r.predictions]
+        # ties / near-ties may swap under fp32 noise: compare as sets unless well separated
+        top = np.sort(ref[i])[::-1][:6]
+        if np.min(np.abs(np.diff(top))) > 1e-2:
+            assert got_idx == idx.tolist()
+        assert np.allclose([p.confidence for p in r.predictions], 1 / (1 + np.exp(-logits[i][got_idx])), atol=1e-6)
+        assert all(p.species == names[p.index] for p in r.predictions)
+    ctx.close()
+    clf.close()
+
+
+def test_predict_entry_points_agree_and_preserve_order(clf_tiny, model_dir):
+    from birda_amd import synth
+    _, _, m, _ = model_dir["birdnet_v24_tiny"]
+    segs = synth.synth_segments(5, m.sample_count, m.sample_rate, start=40)
+    ctx = clf_tiny.create_batch_context(3)          # smaller than n: logits path slices internally
+    logits = clf_tiny.predict_logits(ctx, segs)
+    one = [clf_tiny.predict(s) for s in segs]
+    batch = clf_tiny.predict_batch([s for s in segs])
+    ctx5 = clf_tiny.create_batch_context(5)
+    with_ctx = clf_tiny.predict_batch_with_context(ctx5, [s for s in segs])
+    for a, b, c in zip(one, batch, with_ctx):
+        assert [p.index for p in a.predictions] == [p.index for p in b.predictions] == [p.index for p in c.predictions]
+        assert np.allclose([p.confidence for p in a.predictions], [p.confidence for p in b.predictions], atol=1e-6)
+    # order preservation + batch independence: reversing the batch reverses the rows bit for bit
+    rev = clf_tiny.predict_logits(ctx5, segs[::-1])
+    assert np.array_equal(rev[::-1], clf_tiny.predict_logits(ctx5, segs))
+    # padding rows (zeros) do not change real rows (process_batch pads, processor.rs:240-258)
+    padded = np.concatenate([segs[:2], np.zeros((3, m.sample_count), np.float32)])
+    assert np.array_equal(clf_tiny.predict_logits(ctx5, padded)[:2], clf_tiny.predict_logits(ctx5, segs[:2]))
+    assert ctx.input_buffer_bytes() == 3 * m.sample_count * 4
+    ctx.close(); ctx5.close()
+
+
+def test_error_behaviour(clf_tiny, model_dir):
+    from birda_amd._lib import BirdaHipError
+    _, _, m, _ = model_dir["birdnet_v24_tiny"]
+    with pytest.raises(BirdaHipError) as e:          # wrong segment length is rejected, not padded
+        clf_tiny.predict(np.zeros(m.sample_count - 1, np.float32))
+    assert e.value.code == -1 and "samples" in str(e.value)
+    ctx = clf_tiny.create_batch_context(2)
+    with pytest.raises(BirdaHipError) as e:          # batch larger than the context
+        clf_tiny.predict_batch_with_context(ctx, [np.zeros(m.sample_count, np.float32)] * 3)
+    assert e.value.code == -1
+    assert clf_tiny.predict_batch([]) == []
+    ctx.close()
+
+
+def test_warmup_registry(model_dir):
+    """ensure_warm: per-size independence and idempotence (reference classifier.rs:1114-1173)."""
+    from birda_amd.classifier import BirdClassifier
+    clf = BirdClassifier(model_dir["mini"][0])
+    assert not clf.is_warm(4) and not clf.is_warm(2)
+    clf.ensure_warm(4)
+    assert clf.is_warm(4) and not clf.is_warm(2)
+    clf.ensure_warm(4)
+    clf.ensure_warm(2)
+    assert clf.is_warm(2) and clf.is_warm(4) and not clf.is_warm(1)
+    clf.close()
+
+
+def test_c1_wav_to_csv_matches_oracle(full_model, oracle_lib, tmp_path):
+    """Config C1: 30 s / 48 kHz mono PCM16 WAV -> CSV, defaults (batch 8, overlap 0, BOM)."""
+    from birda_amd import pipeline, synth
+    from birda_amd.classifier import BirdClassifier
+    path, labels, m, names = full_model
+    x = synth.synth_segments(10, m.sample_count, m.sample_rate).reshape(-1)
+    wav = str(tmp_path / "rec30s.wav")
+    synth.write_wav_pcm16(wav, x, m.sample_rate)
+    clf = BirdClassifier(path, labels, top_k=5, min_confidence=0.1)
+    res = pipeline.process_file(clf, wav, str(tmp_path), min_confidence=0.1, overlap=0.0, batch_size=8)
+    assert res.segments == 10 and res.effective_batch == 8 and res.batches == 2 and res.padded_rows == 6
+    assert res.output_path.endswith("rec30s.BirdNET.results.csv")
+    got = open(res.output_path, "rb").read()
+    # oracle on the PCM16-quantised samples, exactly what the decoder produces
+    pcm = np.clip(np.round(x.astype(np.float64) * 32767.0), -32768, 32767).astype(np.int16)
+    mono = np.zeros(pcm.size, np.float32)
+    oracle_lib.lib().bo_pcm16_to_mono(pcm.ctypes.data, pcm.size, 1, mono)
+    om = oracle_lib.OracleModel(path)
+    want, st, ref_logits = om.process_stream(names, mono, m.sample_rate, 0.0, 0.1, 5, 8, True, wav, want_logits=True)
+    assert st.n_segments == 10 and st.n_batches == 2 and st.n_padded_rows == 6
+    assert got[:3] == b"\xef\xbb\xbf"
+    if got != want:
+        # CSV parity modulo fp32 noise: same rows, confidences equal to 4 decimals +- 1e-4
+        g, w = got.decode().splitlines(), want.decode().splitlines()
+        assert len(g) == len(w) and g[0] == w[0]
+        for a, b in zip(g[1:], w[1:]):
+            fa, fb = a.rsplit(",", 2), b.rsplit(",", 2)
+            assert fa[0] == fb[0] and fa[2] == fb[2] and abs(float(fa[1]) - float(fb[1])) <= 1.01e-4
+    assert res.detections == len(got.decode().splitlines()) - 1
+    clf.close()
+
+
+def test_overlap_and_short_file_batching(clf_tiny, model_dir, oracle_lib, tmp_path):
+    from birda_amd import pipeline, synth
+    path, _, m, names = model_dir["birdnet_v24_tiny"]
+    om = oracle_lib.OracleModel(path)
+    x = synth.synth_segments(4, m.sample_count, m.sample_rate, start=7).reshape(-1)[: int(10 * m.sample_rate)]
+    wav = str(tmp_path / "ten.wav")
+    synth.write_wav_pcm16(wav, x, m.sample_rate)
+    pcm = np.clip(np.round(x.astype(np.float64) * 32767.0), -32768, 32767).astype(np.int16)
+    mono = np.zeros(pcm.size, np.float32)
+    oracle_lib.lib().bo_pcm16_to_mono(pcm.ctypes.data, pcm.size, 1, mono)
+    for overlap, batch, n_seg in ((0.0, 16, 4), (1.0, 4, 6), (1.5, 1, 7)):
+        res = pipeline.process_file(clf_tiny, wav, str(tmp_path), min_confidence=0.05, overlap=overlap, batch_size=batch)
+        want, st = om.process_stream(names, mono, m.sample_rate, overlap, 0.05, 5, batch, True, wav)
+        assert res.segments == st.n_segments == n_seg
+        assert res.effective_batch == st.effective_batch and res.batches == st.n_batches
+        assert res.padded_rows == st.n_padded_rows
+        g, w = open(res.output_path, "rb").read().decode().splitlines(), want.decode().splitlines()
+        assert len(g) == len(w)
+        for a, b in zip(g[1:], w[1:]):
+            fa, fb = a.rsplit(",", 2), b.rsplit(",", 2)
+            assert fa[0] == fb[0] and abs(float(fa[1]) - float(fb[1])) <= 1.01e-4
+
+
+def test_full_size_batch_properties(full_model):
+    """BASELINE configs[1] size (1 000 segments, device resident): properties that need no
+    oracle -- determinism, row independence across micro-batch boundaries, checksum of rows."""
+    import torch
+    from birda_amd import synth
+    from birda_amd.classifier import BirdClassifier
+    path, _, m, _ = full_model
+    clf = BirdClassifier(path)
+    uniq = synth.synth_segments(8, m.sample_count, m.sample_rate)
+    order = np.arange(1000) % 8
+    x = torch.from_numpy(uniq[order]).cuda()
+    logits = torch.empty((1000, m.n_classes), device="cuda")
+    idx = torch.empty((1000, 5), dtype=torch.int32, device="cuda")
+    conf = torch.empty((1000, 5), device="cuda")
+    ctx = clf.create_batch_context(256)
+    clf.forward_device(ctx, x.data_ptr(), 1000, logits.data_ptr(), idx.data_ptr(), conf.data_ptr())
+    ctx.synchronize()
+    a = logits.cpu().numpy()
+    assert np.isfinite(a).all()
+    for k in range(8):                                   # identical inputs -> identical rows anywhere in the batch
+        rows = a[order == k]
+        assert (rows == rows[0]).all()
+    ctx2 = clf.create_batch_context(96)                  # different micro-batch slicing, same answers
+    logits2 = torch.empty_like(logits)
+    clf.forward_device(ctx2, x.data_ptr(), 1000, logits2.data_ptr())
+    ctx2.synchronize()
+    assert torch.equal(logits, logits2)
+    ii = idx.cpu().numpy(); cc = conf.cpu().numpy()
+    assert ((ii >= -1) & (ii < m.n_classes)).all()
+    valid = ii >= 0
+    assert (np.diff(np.where(valid, cc, 0.0), axis=1) <= 1e-7).all()      # confidence descending
+    assert (cc[valid] >= 0.1).all() and (cc[~valid] == 0).all()
+    want_top1 = a.argmax(1)
+    has = valid[:, 0]
+    assert (ii[has, 0] == want_top1[has]).all()
+    ctx.close(); ctx2.close(); clf.close()
