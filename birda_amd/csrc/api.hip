@@ -59,6 +59,7 @@ struct bh_classifier {
     std::vector<int> ldw;                    // per layer: padded row length of d_w (pw / dense)
     std::vector<float *> d_owned;            // re-laid buffers to free
     bh::FrontendParams fe{};
+    bh::FrontendParams *d_fe = nullptr;      // device copy read by the mel kernel
     uint64_t mel_flops = 0;
     std::mutex warm_mu;
     std::set<size_t> warmed;                 // WarmupRegistry, classifier.rs:221-246
@@ -120,7 +121,17 @@ std::vector<float> build_gf(const bh::BranchRec &b, const float *W, int nm_pad) 
         const double scale = (j == K - 1) ? 0.5 * wn : wn;  // the centre sample is added to itself
         for (int m = 0; m < nm; m++) gf[(size_t)j * nm_pad + m] = (float)(scale * acc[m]);
     }
-    return gf;
+    // MFMA-fragment-major relayout (kernels.hpp BranchParams::gf)
+    const int mt_n = nm_pad / 16;
+    std::vector<float> frag((size_t)K * nm_pad);
+    for (int g = 0; g < K / 16; g++)
+        for (int mt = 0; mt < mt_n; mt++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int c = 0; c < 4; c++) {
+                    const int k = 16 * g + 4 * (lane >> 4) + c, mel = 16 * mt + (lane & 15);
+                    frag[(((size_t)g * mt_n + mt) * 64 + lane) * 4 + c] = gf[(size_t)k * nm_pad + mel];
+                }
+    return frag;
 }
 
 int upload(const void *src, size_t bytes, float **dst) {
@@ -248,7 +259,7 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
     ctx_mark(ctx, -1);
     bh::launch_minmax(d_seg, ctx->d_minmax, (int)n, (int)m.h.sample_count, s);
     ctx_mark(ctx, ST_MINMAX);
-    bh::launch_mel(d_seg, ctx->d_minmax, T(0), c->fe, (int)n, s);
+    bh::launch_mel(d_seg, ctx->d_minmax, T(0), c->fe, c->d_fe, (int)n, s);
     ctx_mark(ctx, ST_MEL);
     for (uint32_t i = 0; i < nl; i++) {
         const auto &L = m.layers[i];
@@ -398,8 +409,8 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) {
         if (nm_pad != 32 && nm_pad != 96 && nm_pad != 128)
             return fail(BH_ERR_UNSUPPORTED, "front-end: n_mels %u not built (32/96/128)", br.n_mels);
         if (b > 0 && nm_pad != c->fe.br[0].nm_pad) return fail(BH_ERR_UNSUPPORTED, "front-end: branches differ in n_mels");
-        if (br.frame_length % 64 || br.fft_length != br.frame_length)
-            return fail(BH_ERR_UNSUPPORTED, "front-end: frame_length %u must be a multiple of 64 and equal fft_length", br.frame_length);
+        if (br.frame_length % 128 || br.fft_length != br.frame_length)
+            return fail(BH_ERR_UNSUPPORTED, "front-end: frame_length %u must be a multiple of 128 and equal fft_length", br.frame_length);
         if ((64 * br.frame_step) % 4) return fail(BH_ERR_UNSUPPORTED, "front-end: hop %u unsupported", br.frame_step);
         std::vector<float> gf = build_gf(br, m.blob.data() + br.mel_w_off, nm_pad);
         float *d = nullptr;
@@ -412,6 +423,13 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) {
         p.expo = 1.0f / (1.0f + expf(br.mag_scale));
         p.out_scale = br.out_scale; p.out_shift = br.out_shift; p.flip = (int)(br.flags & 1u);
         c->mel_flops += 2ull * (uint64_t)p.K * nm_pad * br.n_frames;
+    }
+    {
+        float *d = nullptr;
+        int rcf = upload(&c->fe, sizeof c->fe, &d);
+        if (rcf != BH_OK) return rcf;
+        c->d_fe = reinterpret_cast<bh::FrontendParams *>(d);
+        c->d_owned.push_back(d);
     }
     // weights
     int rc = upload(m.blob.data(), m.blob.size() * sizeof(float), &c->d_blob);

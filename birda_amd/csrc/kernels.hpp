@@ -12,7 +12,9 @@ constexpr int MAX_BRANCHES = 4;
 // One STFT/mel branch of the front-end, with the Hann window, the
 // real-part DFT and the mel projection folded into one operator Gf[K = L/2][n_mels_pad].
 struct BranchParams {
-    const float *gf;  // device [K][nm_pad], row j <-> sample offset n = j + 1 (last row halved)
+    const float *gf;  // device, MFMA-fragment-major gfF[K/16][nm_pad/16][64 lanes][4]: element
+                      // (g, mt, lane, c) = Gf[k = 16g + 4(lane>>4) + c][mel = 16mt + (lane&15)],
+                      // Gf row k <-> sample offset n = k + 1 (last row halved)
     int L, H, K;      // frame length, hop, folded depth L/2
     int n_mels, nm_pad, n_frames;
     float expo;       // 1 / (1 + exp(mag_scale))
@@ -27,8 +29,8 @@ struct FrontendParams {
 };
 
 void launch_minmax(const float *x, float *minmax, int n_seg, int sample_count, hipStream_t s);
-void launch_mel(const float *x, const float *minmax, float *spec, const FrontendParams &p, int n_seg,
-                hipStream_t s);
+void launch_mel(const float *x, const float *minmax, float *spec, const FrontendParams &p,
+                const FrontendParams *d_p, int n_seg, hipStream_t s);
 
 struct ConvParams {
     int in_h, in_w, out_h, out_w, cin, cout, kh, kw, sh, sw, pad_t, pad_l, in_layout, act;

@@ -66,120 +66,142 @@ void launch_minmax(const float *x, float *minmax, int n_seg, int sample_count, h
 }
 
 // ---------------------------------------------------------------------------------------
-// mel kernel: grid (frame tiles of TN, n_branches, n_seg), block 256 = 4 waves.
-// Wave w owns frames [16w, 16w+16) of the tile and all MT mel tiles (MT x 4 accumulators).
-// LDS: the tile's normalised sample span xs[(TN-1)H + L] + a double-buffered KC-row slab of
-// Gf.  D = A.B with A = Gf^T (mel on M, lane&15), B = folded frames (frame on N, lane&15).
+// mel kernel: grid (frame tiles of 64, n_branches, n_seg), block 256 = 4 waves, 2 blocks/CU.
+//
+// LDS holds only the tile's normalised sample span xs[(64-1)H + L] (78 KB for L = 2048).
+// The K = L/2 reduction is SPLIT ACROSS THE 4 WAVES: wave w accumulates k in
+// [wK/4, (w+1)K/4) for all 64 frames x all mel tiles (4 x MT accumulator tiles), so the main
+// loop has no block barrier.  A = Gf^T comes straight from global/L2 in an MFMA-fragment-major
+// layout gfF[g][mt][lane][c] (k = 16g + 4(lane>>4) + c, mel = 16mt + (lane&15)): one coalesced
+// 1-KiB dwordx4 load per mel tile feeds four MFMA k-steps, prefetched one 16-k group ahead.
+// B = folded frames from LDS.  The four partial sums meet in LDS (reusing xs); wave w then
+// owns frame tile w for the epilogue (square, power law, affine, flip, store).
 // ---------------------------------------------------------------------------------------
 constexpr int MEL_TN = 64;
-constexpr int MEL_KC = 32;
 
 template <int MT>
-__global__ __launch_bounds__(256) void mel_kernel(const float *__restrict__ x, const float *__restrict__ mm,
-                                                   float *__restrict__ spec, const FrontendParams p) {
+__global__ __launch_bounds__(256, 2) void mel_kernel(const float *__restrict__ x, const float *__restrict__ mm,
+                                                      float *__restrict__ spec,
+                                                      const FrontendParams *__restrict__ pp) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const BranchParams &bp = p.br[blockIdx.y];
+    const BranchParams bp = pp->br[blockIdx.y];
+    const int n_branches = pp->n_branches;
+    const int S = pp->sample_count;
     const int seg = blockIdx.z;
     const int t0 = blockIdx.x * MEL_TN;
     const int L = bp.L, H = bp.H, K = bp.K;
-    const int S = p.sample_count;
-    constexpr int NMP = MT * 16;
-    constexpr int GS = NMP + 16;  // slab row stride: k-rows 4q apart land 16 banks apart
     const int span = (MEL_TN - 1) * H + L;
     const int span_pad = (span + 3) & ~3;
     float *xs = smem;
-    float *gs = smem + span_pad;  // [2][MEL_KC][GS]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
 
-    // segment min/max from the MM_SPLIT partials
     float mn = INFINITY, mx = -INFINITY;
 #pragma unroll
     for (int i = 0; i < MM_SPLIT; i++) {
         mn = fminf(mn, mm[((size_t)seg * MM_SPLIT + i) * 2]);
         mx = fmaxf(mx, mm[((size_t)seg * MM_SPLIT + i) * 2 + 1]);
     }
-    const float denom = (mx - mn) + p.norm_eps;
+    const float denom = (mx - mn) + pp->norm_eps;
 
     // stage the normalised span (16-B loads; the span start t0*H is a multiple of 4 samples)
     const float *xseg = x + (size_t)seg * S;
-    const int g0 = t0 * H;
+    const int g0s = t0 * H;
     for (int i = tid * 4; i < span_pad; i += 256 * 4) {
-        float v[4];
-        if (g0 + i + 3 < S) {
-            float4 q = *reinterpret_cast<const float4 *>(xseg + g0 + i);
-            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        float4 q;
+        if (g0s + i + 3 < S) {
+            q = *reinterpret_cast<const float4 *>(xseg + g0s + i);
         } else {
-#pragma unroll
-            for (int e = 0; e < 4; e++) v[e] = (g0 + i + e < S) ? xseg[g0 + i + e] : mn;
+            q.x = (g0s + i + 0 < S) ? xseg[g0s + i + 0] : mn;
+            q.y = (g0s + i + 1 < S) ? xseg[g0s + i + 1] : mn;
+            q.z = (g0s + i + 2 < S) ? xseg[g0s + i + 2] : mn;
+            q.w = (g0s + i + 3 < S) ? xseg[g0s + i + 3] : mn;
         }
-#pragma unroll
-        for (int e = 0; e < 4; e++) v[e] = ((v[e] - mn) / denom - 0.5f) * 2.0f;
-        *reinterpret_cast<float4 *>(xs + i) = make_float4(v[0], v[1], v[2], v[3]);
+        q.x = ((q.x - mn) / denom - 0.5f) * 2.0f;
+        q.y = ((q.y - mn) / denom - 0.5f) * 2.0f;
+        q.z = ((q.z - mn) / denom - 0.5f) * 2.0f;
+        q.w = ((q.w - mn) / denom - 0.5f) * 2.0f;
+        *reinterpret_cast<float4 *>(xs + i) = q;
     }
-
-    // Gf slab staging: chunk c is MEL_KC contiguous rows of NMP floats
-    constexpr int SLAB4 = MEL_KC * NMP / 4;           // float4 per slab
-    constexpr int PER_T = (SLAB4 + 255) / 256;        // float4 per thread
-    const float4 *gf4 = reinterpret_cast<const float4 *>(bp.gf);
-    float4 pre[PER_T];
-    auto slab_load = [&](int c) {
-#pragma unroll
-        for (int i = 0; i < PER_T; i++) {
-            int f = tid + 256 * i;
-            if (f < SLAB4) pre[i] = gf4[(size_t)c * SLAB4 + f];
-        }
-    };
-    auto slab_store = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < PER_T; i++) {
-            int f = tid + 256 * i;
-            if (f < SLAB4) {
-                int row = (f * 4) / NMP, col = (f * 4) % NMP;
-                *reinterpret_cast<float4 *>(gs + (size_t)buf * MEL_KC * GS + row * GS + col) = pre[i];
-            }
-        }
-    };
-    slab_load(0);
-    slab_store(0);
     __syncthreads();
 
-    f32x4 acc[MT];
+    f32x4 acc[4][MT];
 #pragma unroll
-    for (int m = 0; m < MT; m++) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int f = 0; f < 4; f++)
+#pragma unroll
+        for (int m = 0; m < MT; m++) acc[f][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int fb = (wave * 16 + li) * H;  // this lane's frame origin inside the span
-    const int nchunks = K / MEL_KC;
-    for (int c = 0; c < nchunks; c++) {
-        const int buf = c & 1;
-        if (c + 1 < nchunks) slab_load(c + 1);
-        const float *g = gs + (size_t)buf * MEL_KC * GS;
+    const int gpw = K / 64;          // 16-k groups per wave
+    const int gbeg = wave * gpw;
+    const float4 *gA = reinterpret_cast<const float4 *>(bp.gf) + lane;
+    float4 a_cur[MT], a_nxt[MT];
 #pragma unroll
-        for (int kk = 0; kk < MEL_KC / 4; kk++) {
-            const int j = c * MEL_KC + kk * 4 + kq;
-            const float b = xs[fb + j + 1] + xs[fb + L - 1 - j];
+    for (int m = 0; m < MT; m++) a_cur[m] = gA[((size_t)gbeg * MT + m) * 64];
+
+    const float *xf = xs + li * H;   // frame tile f adds f*16*H
+    for (int gi = 0; gi < gpw; gi++) {
+        const int gn = gbeg + min(gi + 1, gpw - 1);
+#pragma unroll
+        for (int m = 0; m < MT; m++) a_nxt[m] = gA[((size_t)gn * MT + m) * 64];
+        const int jb = (gbeg + gi) * 16 + 4 * kq;
+        float b[4][4];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
+#pragma unroll
+            for (int f = 0; f < 4; f++)
+                b[c][f] = xf[f * 16 * H + jb + c + 1] + xf[f * 16 * H + L - 1 - jb - c];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
 #pragma unroll
             for (int m = 0; m < MT; m++) {
-                const float a = g[(kk * 4 + kq) * GS + m * 16 + li];
-                acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[m], 0, 0, 0);
+                const float a = c == 0 ? a_cur[m].x : c == 1 ? a_cur[m].y : c == 2 ? a_cur[m].z : a_cur[m].w;
+#pragma unroll
+                for (int f = 0; f < 4; f++)
+                    acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[c][f], acc[f][m], 0, 0, 0);
             }
+#pragma unroll
+        for (int m = 0; m < MT; m++) a_cur[m] = a_nxt[m];
+    }
+
+    // cross-wave reduction: wave s parks its partials for the frame tiles it does not own
+    __syncthreads();  // every wave is done reading xs
+    float4 *red = reinterpret_cast<float4 *>(smem);
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+        if (f == wave) continue;
+        const int slot = f - (f > wave ? 1 : 0);
+#pragma unroll
+        for (int m = 0; m < MT; m++)
+            red[((wave * 3 + slot) * MT + m) * 64 + lane] = make_float4(acc[f][m][0], acc[f][m][1], acc[f][m][2], acc[f][m][3]);
+    }
+    __syncthreads();
+    f32x4 tot[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        // own partial, selected without dynamic register indexing
+        f32x4 v = wave == 0 ? acc[0][m] : wave == 1 ? acc[1][m] : wave == 2 ? acc[2][m] : acc[3][m];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            if (s == wave) continue;
+            const int slot = wave - (wave > s ? 1 : 0);
+            const float4 q = red[((s * 3 + slot) * MT + m) * 64 + lane];
+            v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
         }
-        if (c + 1 < nchunks) slab_store(buf ^ 1);
-        __syncthreads();
+        tot[m] = v;
     }
 
     // epilogue: square, power law, folded-BN affine, mel flip, [mel][time] store
     const int t = t0 + wave * 16 + li;
     if (t < bp.n_frames) {
-        float *out = spec + ((size_t)seg * p.n_branches + blockIdx.y) * bp.n_mels * bp.n_frames;
+        float *out = spec + ((size_t)seg * n_branches + blockIdx.y) * bp.n_mels * bp.n_frames;
 #pragma unroll
         for (int m = 0; m < MT; m++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int mel = m * 16 + kq * 4 + r;
                 if (mel < bp.n_mels) {
-                    const float v = acc[m][r];
+                    const float v = tot[m][r];
                     float o = powf(v * v, bp.expo);
                     o = o * bp.out_scale + bp.out_shift;
                     const int row = bp.flip ? (bp.n_mels - 1 - mel) : mel;
@@ -189,18 +211,19 @@ __global__ __launch_bounds__(256) void mel_kernel(const float *__restrict__ x, c
     }
 }
 
-void launch_mel(const float *x, const float *minmax, float *spec, const FrontendParams &p, int n_seg,
-                hipStream_t s) {
+void launch_mel(const float *x, const float *minmax, float *spec, const FrontendParams &p,
+                const FrontendParams *d_p, int n_seg, hipStream_t s) {
     int max_span = 0, max_frames = 0, nmp = p.br[0].nm_pad;
     for (int b = 0; b < p.n_branches; b++) {
         int span = (MEL_TN - 1) * p.br[b].H + p.br[b].L;
         max_span = span > max_span ? span : max_span;
         max_frames = p.br[b].n_frames > max_frames ? p.br[b].n_frames : max_frames;
     }
-    const int span_pad = (max_span + 3) & ~3;
-    const size_t smem = ((size_t)span_pad + 2 * MEL_KC * (nmp + 16)) * sizeof(float);
-    dim3 grid((max_frames + MEL_TN - 1) / MEL_TN, p.n_branches, n_seg), block(256);
     const int mt = nmp / 16;
+    const size_t span_bytes = (size_t)((max_span + 3) & ~3) * sizeof(float);
+    const size_t red_bytes = (size_t)4 * 3 * mt * 64 * sizeof(float4);
+    const size_t smem = span_bytes > red_bytes ? span_bytes : red_bytes;
+    dim3 grid((max_frames + MEL_TN - 1) / MEL_TN, p.n_branches, n_seg), block(256);
 #define BH_MEL_CASE(MTV)                                                                                   \
     case MTV: {                                                                                            \
         static bool attr_set = false;                                                                      \
@@ -209,7 +232,7 @@ void launch_mel(const float *x, const float *minmax, float *spec, const Frontend
                                 160 * 1024);                                                              \
             attr_set = true;                                                                               \
         }                                                                                                  \
-        hipLaunchKernelGGL(mel_kernel<MTV>, grid, block, smem, s, x, minmax, spec, p);                     \
+        hipLaunchKernelGGL(mel_kernel<MTV>, grid, block, smem, s, x, minmax, spec, d_p);                   \
     } break;
     switch (mt) {
         BH_MEL_CASE(2)
