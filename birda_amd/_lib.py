@@ -11,8 +11,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libbirda_hip.so")
 BH_MAX_TOP_K = 32
-BH_N_STAGES = 8
-STAGE_NAMES = ["minmax", "mel", "stem", "depthwise", "pointwise", "pool", "dense", "topk"]
+BH_N_STAGES = 9
+STAGE_NAMES = ["minmax", "mel", "stem", "depthwise", "pointwise", "pool", "dense", "topk", "mbconv"]
 
 
 class BhConfig(C.Structure):
@@ -59,6 +59,8 @@ SYMBOLS = [
     ("bh_tensor_floats", C.c_uint64, [_VP, C.c_uint32]),
     ("bh_batch_context_set_profiling", C.c_int, [_VP, C.c_int]),
     ("bh_batch_context_stage_ms", C.c_int, [_VP, _VP, _VP]),
+    ("bh_classifier_fused_blocks", C.c_int, [_VP, _VP, _SZ]),
+    ("bh_debug_mb_stamps", C.c_int, [_VP, _VP, _SZ]),
     ("bh_resample", C.c_int, [_VP, _VP, _SZ, C.c_uint32, C.c_uint32, _VP, _SZ, C.POINTER(_SZ)]),
 ]
 

@@ -111,6 +111,12 @@ class BirdClassifier:
         s = self._L.bh_classifier_label(self._h, index)
         return s.decode("utf-8") if s is not None else None
 
+    def fused_blocks(self) -> List[int]:
+        """Tile-configuration index of every expand->depthwise->project block that runs fused."""
+        buf = (C.c_int32 * 256)()
+        n = int(self._L.bh_classifier_fused_blocks(self._h, buf, 256))
+        return [int(buf[i]) for i in range(min(n, 256))]
+
     # ---- warm-up (classifier.rs:414-466) ----
     def ensure_warm(self, batch_size: int):
         check(self._L.bh_classifier_ensure_warm(self._h, batch_size))

@@ -42,7 +42,7 @@ int fail(int code, const char *fmt, ...) {
             return fail(BH_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
     } while (0)
 
-enum Stage { ST_MINMAX = 0, ST_MEL, ST_STEM, ST_DW, ST_PW, ST_GAP, ST_DENSE, ST_TOPK };
+enum Stage { ST_MINMAX = 0, ST_MEL, ST_STEM, ST_DW, ST_PW, ST_GAP, ST_DENSE, ST_TOPK, ST_MBCONV };
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -60,6 +60,9 @@ struct bh_classifier {
     std::vector<float *> d_owned;            // re-laid buffers to free
     bh::FrontendParams fe{};
     bh::FrontendParams *d_fe = nullptr;      // device copy read by the mel kernel
+    std::vector<int> fused_at;               // per layer: index into mb (expand layer of a fused block) or -1
+    std::vector<bh::MbDesc> mb;              // fused MBConv blocks (kernels_mbconv.hip)
+    unsigned long long *d_stamps = nullptr;  // BIRDA_HIP_MB_STAMPS=1: [mb.size()][8] phase counters
     uint64_t mel_flops = 0;
     std::mutex warm_mu;
     std::set<size_t> warmed;                 // WarmupRegistry, classifier.rs:221-246
@@ -176,7 +179,8 @@ void ctx_mark(bh_batch_context *ctx, int stage) {
 
 // liveness-based arena plan: tensor t is born at step t (tensor 0 = front-end) and dies after
 // the last layer that reads it; the embedding tensor and the logits live to the end.
-void plan_arena(const bh::Model &m, size_t max_batch, bool keep, std::vector<size_t> &off, size_t &total) {
+void plan_arena(const bh::Model &m, const std::vector<int> &fused_at, size_t max_batch, bool keep,
+                std::vector<size_t> &off, size_t &total) {
     const size_t nt = m.layers.size() + 1;
     std::vector<size_t> last(nt, 0), sz(nt);
     for (size_t t = 0; t < nt; t++) { last[t] = t; sz[t] = align_up(m.tensor_floats[t] * max_batch, 64); }
@@ -185,6 +189,14 @@ void plan_arena(const bh::Model &m, size_t max_batch, bool keep, std::vector<siz
         last[L.in_tensor] = std::max(last[L.in_tensor], i + 1);
         if (L.res_tensor != bh::NO_TENSOR) last[L.res_tensor] = std::max(last[L.res_tensor], i + 1);
     }
+    if (!keep)
+        for (size_t i = 0; i < fused_at.size(); i++)
+            if (fused_at[i] >= 0) {
+                // one launch reads the block input while it writes tensor i+3; the expanded
+                // tensors i+1, i+2 stay in LDS and take no arena space
+                last[m.layers[i].in_tensor] = std::max(last[m.layers[i].in_tensor], i + 3);
+                sz[i + 1] = sz[i + 2] = 0;
+            }
     last[m.h.embedding_tensor] = nt;
     last[nt - 1] = nt;
     off.assign(nt, 0);
@@ -223,7 +235,7 @@ int ctx_create(bh_classifier *c, size_t max_batch, bool keep, bh_batch_context *
     const size_t in_bytes = max_batch * (size_t)m.h.sample_count * sizeof(float);
     HIPCHK(hipMalloc((void **)&ctx->d_input, in_bytes));
     HIPCHK(hipMalloc((void **)&ctx->d_minmax, max_batch * 16 * sizeof(float)));
-    plan_arena(m, max_batch, keep, ctx->t_off, ctx->arena_floats);
+    plan_arena(m, c->fused_at, max_batch, keep, ctx->t_off, ctx->arena_floats);
     HIPCHK(hipMalloc((void **)&ctx->d_arena, ctx->arena_floats * sizeof(float)));
     HIPCHK(hipMalloc((void **)&ctx->d_logits, max_batch * (size_t)m.h.n_classes * sizeof(float)));
     HIPCHK(hipMalloc((void **)&ctx->d_topk_idx, max_batch * c->top_k * sizeof(int32_t)));
@@ -270,6 +282,18 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
         bh::ConvParams p{(int)L.in_h, (int)L.in_w, (int)L.out_h, (int)L.out_w, (int)L.cin, (int)L.cout,
                          (int)L.kh, (int)L.kw, (int)L.sh, (int)L.sw, (int)L.pad_t, (int)L.pad_l,
                          (int)L.in_layout, (int)L.act};
+        if (!ctx->keep_tensors && c->fused_at[i] >= 0) {
+            // expand (i) -> depthwise (i+1) -> project (i+2) in one launch
+            bh::MbDesc d = c->mb[c->fused_at[i]];
+            const auto &LP = m.layers[i + 2];
+            d.X = in;
+            d.Y = (i + 2 == nl - 1) ? d_logits : T(i + 3);
+            d.R = LP.res_tensor != bh::NO_TENSOR ? T(LP.res_tensor) : nullptr;
+            bh::launch_mbconv(d, (int)n, s);
+            ctx_mark(ctx, ST_MBCONV);
+            i += 2;
+            continue;
+        }
         switch (L.op) {
         case bh::OP_CONV:
             bh::launch_conv_direct(in, c->d_w[i], bias, out, p, (int)n, s);
@@ -352,6 +376,70 @@ int predict_slices(bh_classifier *c, bh_batch_context *ctx, const float *const *
                     r.n_pred++;
                 }
             }
+    }
+    return BH_OK;
+}
+
+// Finds expand(1x1) -> depthwise -> project(1x1) triples whose intermediates have no other reader
+// and prepares a fused launch for each (weights re-laid fragment-major for the picked tile config).
+int plan_fusion(bh_classifier *c) {
+    const auto &m = c->model;
+    const size_t nl = m.layers.size();
+    c->fused_at.assign(nl, -1);
+    const char *fuse_env = getenv("BIRDA_HIP_FUSE");
+    if (fuse_env && fuse_env[0] == '0') return BH_OK;
+    const char *cfg_env = getenv("BIRDA_HIP_MB_CFG");
+    const int force_cfg = cfg_env ? atoi(cfg_env) : -1;
+    std::vector<int> readers(nl + 1, 0);
+    for (const auto &L : m.layers) {
+        readers[L.in_tensor]++;
+        if (L.res_tensor != bh::NO_TENSOR) readers[L.res_tensor]++;
+    }
+    readers[m.h.embedding_tensor]++;
+    for (size_t i = 0; i + 2 < nl; i++) {
+        const auto &E = m.layers[i], &D = m.layers[i + 1], &P = m.layers[i + 2];
+        if (E.op != bh::OP_PWCONV || D.op != bh::OP_DWCONV || P.op != bh::OP_PWCONV) continue;
+        if (D.in_tensor != i + 1 || P.in_tensor != i + 2 || readers[i + 1] != 1 || readers[i + 2] != 1) continue;
+        if (E.res_tensor != bh::NO_TENSOR || D.res_tensor != bh::NO_TENSOR) continue;
+        if (D.kh != D.kw || D.sh != D.sw || E.cout != D.cout || D.cout != P.cin) continue;
+        bh::MbDesc d{};
+        d.H = (int)E.in_h; d.W = (int)E.in_w; d.Cin = (int)E.cin; d.Cexp = (int)E.cout; d.Cout = (int)P.cout;
+        d.Ho = (int)D.out_h; d.Wo = (int)D.out_w; d.pad_t = (int)D.pad_t; d.pad_l = (int)D.pad_l;
+        d.KS = (int)D.kh; d.ST = (int)D.sh;
+        d.act_e = (int)E.act; d.act_d = (int)D.act; d.act_p = (int)P.act;
+        if (!bh::mb_plan(d, force_cfg)) continue;
+        // fragment-major weights
+        const int CE = d.CE, NTE = CE / 16, KG = d.KG, NTOP = d.NTOP, nch = d.nchunks;
+        const float *We = m.blob.data() + E.w_off, *Wp = m.blob.data() + P.w_off;
+        std::vector<float> wef((size_t)nch * KG * NTE * 256, 0.0f), wpf((size_t)nch * NTE * NTOP * 256, 0.0f);
+        for (int ch = 0; ch < nch; ch++)
+            for (int g = 0; g < KG; g++)
+                for (int j = 0; j < NTE; j++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int cc = 0; cc < 4; cc++) {
+                            const int k = 16 * g + 4 * (lane >> 4) + cc, n = ch * CE + 16 * j + (lane & 15);
+                            if (k < d.Cin) wef[((((size_t)ch * KG + g) * NTE + j) * 64 + lane) * 4 + cc] = We[(size_t)k * d.Cexp + n];
+                        }
+        for (int ch = 0; ch < nch; ch++)
+            for (int g = 0; g < NTE; g++)
+                for (int j = 0; j < NTOP; j++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int cc = 0; cc < 4; cc++) {
+                            const int k = ch * CE + 16 * g + 4 * (lane >> 4) + cc, n = 16 * j + (lane & 15);
+                            if (n < d.Cout) wpf[((((size_t)ch * NTE + g) * NTOP + j) * 64 + lane) * 4 + cc] = Wp[(size_t)k * d.Cout + n];
+                        }
+        float *dwe = nullptr, *dwp = nullptr;
+        int rc = upload(wef.data(), wef.size() * sizeof(float), &dwe);
+        if (rc != BH_OK) return rc;
+        c->d_owned.push_back(dwe);
+        rc = upload(wpf.data(), wpf.size() * sizeof(float), &dwp);
+        if (rc != BH_OK) return rc;
+        c->d_owned.push_back(dwp);
+        d.We = dwe; d.Wp = dwp;
+        d.be = c->d_blob + E.b_off; d.Wd = c->d_blob + D.w_off; d.bd = c->d_blob + D.b_off; d.bp = c->d_blob + P.b_off;
+        c->fused_at[i] = (int)c->mb.size();
+        c->mb.push_back(d);
+        i += 2;
     }
     return BH_OK;
 }
@@ -465,6 +553,13 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) {
     }
     if (m.layers.empty() || m.layers.back().cout != m.h.n_classes)
         return fail(BH_ERR_IO, "model: last layer width != n_classes");
+    rc = plan_fusion(c.get());
+    if (rc != BH_OK) return rc;
+    if (const char *st = getenv("BIRDA_HIP_MB_STAMPS"); st && st[0] == '1' && !c->mb.empty()) {
+        HIPCHK(hipMalloc((void **)&c->d_stamps, c->mb.size() * 8 * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(c->d_stamps, 0, c->mb.size() * 8 * sizeof(unsigned long long)));
+        for (size_t i = 0; i < c->mb.size(); i++) c->mb[i].stamps = c->d_stamps + i * 8;
+    }
     *out = c.release();
     return BH_OK;
 }
@@ -475,6 +570,7 @@ void bh_classifier_destroy(bh_classifier *c) {
     if (c->internal_ctx) ctx_destroy(c->internal_ctx);
     for (float *d : c->d_owned) (void)hipFree(d);
     (void)hipFree(c->d_blob);
+    (void)hipFree(c->d_stamps);
     delete c;
 }
 
@@ -613,6 +709,22 @@ int bh_debug_read_tensor(bh_classifier *c, bh_batch_context *ctx, uint32_t tenso
     const float *src = (tensor == c->model.layers.size()) ? ctx->last_logits : ctx->d_arena + ctx->t_off[tensor];
     HIPCHK(hipMemcpy(host, src, nfl * sizeof(float), hipMemcpyDeviceToHost));
     return BH_OK;
+}
+
+int bh_classifier_fused_blocks(const bh_classifier *c, int32_t *cfgs, size_t cap) {
+    if (!c) return 0;
+    for (size_t i = 0; i < c->mb.size() && cfgs && i < cap; i++) cfgs[i] = c->mb[i].cfg;
+    return (int)c->mb.size();
+}
+
+int bh_debug_mb_stamps(bh_classifier *c, uint64_t *out, size_t cap) {
+    if (!c || !c->d_stamps) return 0;
+    const size_t n = std::min(cap, c->mb.size() * 8);
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    if (out && hipMemcpy(out, c->d_stamps, n * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    (void)hipMemset(c->d_stamps, 0, c->mb.size() * 8 * sizeof(unsigned long long));
+    return (int)(n / 8);
 }
 
 int bh_batch_context_set_profiling(bh_batch_context *ctx, int enabled) {

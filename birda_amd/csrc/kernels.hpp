@@ -9,6 +9,35 @@ enum Act : int { ACT_NONE = 0, ACT_RELU, ACT_RELU6, ACT_SWISH, ACT_GELU_ERF, ACT
 
 constexpr int MAX_BRANCHES = 4;
 
+// GELU(v) = 0.5 v (1 + erf(v / sqrt 2)) with erf from Abramowitz & Stegun 7.1.26
+// (|err(erf)| <= 1.5e-7): GELU(v) = max(v, 0) - 0.5 |v| P(t) exp(-v^2 / 2), t = 1 / (1 + p |v| / sqrt 2).
+// 13 VALU instructions, two of them transcendental (v_rcp_f32, v_exp_f32), against ~30 for
+// ocml erff; max |err| 5e-7 absolute (~1 ulp of v for |v| in [4, 8)), the same as the f32
+// rounding of the erff form itself.
+__device__ __forceinline__ float gelu_erf_fast(float v) {
+    const float ax = __builtin_fabsf(v);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+    float p = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
+    p = __builtin_fmaf(p, t, 1.421413741f);
+    p = __builtin_fmaf(p, t, -0.284496736f);
+    p = __builtin_fmaf(p, t, 0.254829592f);
+    p = p * t;
+    const float e = __builtin_amdgcn_exp2f((-0.5f * 1.4426950408889634f) * v * v);
+    return __builtin_fmaf(-0.5f * ax * p, e, __builtin_fmaxf(v, 0.0f));
+}
+
+__device__ __forceinline__ float act_apply_slow(float v, int act) {
+    switch (act) {
+    case ACT_RELU: return fmaxf(v, 0.f);
+    case ACT_RELU6: return fminf(fmaxf(v, 0.f), 6.f);
+    case ACT_SWISH: return v / (1.0f + expf(-v));
+    case ACT_GELU_ERF: return gelu_erf_fast(v);
+    case ACT_GELU_TANH: return 0.5f * v * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * v * v * v)));
+    case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
+    default: return v;
+    }
+}
+
 // One STFT/mel branch of the front-end, with the Hann window, the
 // real-part DFT and the mel projection folded into one operator Gf[K = L/2][n_mels_pad].
 struct BranchParams {
@@ -49,5 +78,29 @@ void launch_gap(const float *in, float *out, int n_seg, int P, int C, hipStream_
 // activation + top-k over logits [n][n_classes] -> idx/conf [n][top_k]
 void launch_topk(const float *logits, int n_seg, int n_classes, int out_act, int top_k, float min_conf,
                  int32_t *idx, float *conf, hipStream_t s);
+
+// Fused MBConv block (kernels_mbconv.hip): expand 1x1 -> depthwise -> project 1x1 (+ residual).
+struct MbDesc {
+    const float *X, *R;  // input NHWC [n][H][W][Cin]; residual (nullable) shaped like Y
+    float *Y;            // output NHWC [n][Ho][Wo][Cout]
+    // We: fragment-major [chunk][KG][CE/16][64 lanes][4], element (ch, g, j, lane, c) =
+    //     We[k = 16g + 4(lane>>4) + c][n = ch*CE + 16j + (lane&15)] (0 for k >= Cin)
+    // Wp: fragment-major [chunk][CE/16][NTOP][64][4], element (ch, g, j, lane, c) =
+    //     Wp[k = ch*CE + 16g + 4(lane>>4) + c][n = 16j + (lane&15)] (0 for n >= Cout)
+    // Wd: [KS*KS][Cexp] as in the model blob; be / bd / bp: biases
+    const float *We, *be, *Wd, *bd, *Wp, *bp;
+    int H, W, Cin, Cexp, Cout, Ho, Wo, pad_t, pad_l, KS, ST;
+    int act_e, act_d, act_p;
+    // diagnostic: 8 phase counters (wave-cycles: setup, dw-weight stage, P1, barrier, P2, barrier, P3,
+    // epilogue) or nullptr
+    unsigned long long *stamps;
+    // filled by mb_plan()
+    int cfg, CE, TH, S, tiles_y, tiles_x, IH, IW, KG, nchunks, NTOP, mpad_max;
+    size_t lds_bytes;
+};
+int mb_config_count();
+// picks the instantiation (force_cfg >= 0: that entry or fail) and fills the derived fields
+bool mb_plan(MbDesc &d, int force_cfg);
+void launch_mbconv(const MbDesc &d, int n_seg, hipStream_t s);
 
 }  // namespace bh

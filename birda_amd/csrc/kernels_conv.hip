@@ -12,17 +12,7 @@ namespace bh {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float act_apply(float v, int act) {
-    switch (act) {
-    case ACT_RELU: return fmaxf(v, 0.f);
-    case ACT_RELU6: return fminf(fmaxf(v, 0.f), 6.f);
-    case ACT_SWISH: return v / (1.0f + expf(-v));
-    case ACT_GELU_ERF: return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-    case ACT_GELU_TANH: return 0.5f * v * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * v * v * v)));
-    case ACT_SIGMOID: return 1.0f / (1.0f + expf(-v));
-    default: return v;
-    }
-}
+__device__ __forceinline__ float act_apply(float v, int act) { return act_apply_slow(v, act); }
 
 // ---------------------------------------------------------------------------------------
 // Pointwise / dense GEMM.  C[M][N] = act(A[M][K] W[K][ldw] + bias[N]) (+ R[M][N]).

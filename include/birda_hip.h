@@ -145,10 +145,21 @@ BH_API uint64_t bh_tensor_floats(const bh_classifier *c, uint32_t tensor);
 
 /* Per-stage kernel timing of the last bh_forward_device call when profiling is enabled:
  * stage 0 = min/max, 1 = mel front-end, 2 = stem conv, 3 = depthwise, 4 = pointwise,
- * 5 = pool, 6 = dense, 7 = top-k.  ms[] receives BH_N_STAGES floats (HIP-event times). */
-#define BH_N_STAGES 8
+ * 5 = pool, 6 = dense, 7 = top-k, 8 = fused MBConv blocks (expand + depthwise + project in
+ * one launch).  ms[] receives BH_N_STAGES floats (HIP-event times). */
+#define BH_N_STAGES 9
 BH_API int bh_batch_context_set_profiling(bh_batch_context *ctx, int enabled);
 BH_API int bh_batch_context_stage_ms(bh_batch_context *ctx, float *ms, uint32_t *launches);
+
+/* Number of expand -> depthwise -> project triples that run as one fused launch; cfgs
+ * (nullable) receives the tile configuration index of each.  Environment: BIRDA_HIP_FUSE=0
+ * disables fusion, BIRDA_HIP_MB_CFG=<i> forces configuration i where it is valid. */
+BH_API int bh_classifier_fused_blocks(const bh_classifier *c, int32_t *cfgs, size_t cap);
+
+/* Diagnostic (BIRDA_HIP_MB_STAMPS=1 at create): per fused block, 8 counters of wave-cycles spent in
+ * setup, dw-weight staging, expand, barrier, depthwise, barrier, project, epilogue since the
+ * last call.  Returns the number of blocks written (8 values each). */
+BH_API int bh_debug_mb_stamps(bh_classifier *c, uint64_t *out, size_t cap);
 
 /* ---- resampler (reference src/audio/resample.rs:10-105; rubato Fft, FixedSync::Both) -- */
 /* host in / host out convenience: returns output length via *n_out */

@@ -299,3 +299,67 @@ def test_full_size_batch_properties(full_model):
     has = valid[:, 0]
     assert (ii[has, 0] == want_top1[has]).all()
     ctx.close(); ctx2.close(); clf.close()
+
+
+# ---- fused MBConv blocks (expand -> depthwise -> project in one launch) -----------------
+def test_full_model_runs_every_inverted_residual_block_fused(full_model):
+    from birda_amd.classifier import BirdClassifier
+    path, labels, m, _ = full_model
+    clf = BirdClassifier(path, labels)
+    cfgs = clf.fused_blocks()
+    assert len(cfgs) == 15, cfgs          # EfficientNet-B0: 16 blocks, the first has no expand conv
+    clf.close()
+
+
+def test_fused_blocks_match_unfused_and_oracle_on_small_images(model_dir, oracle_lib, monkeypatch):
+    """mini_b0 = the full B0 channel plan on 16x58 ... 1x4 images: partial tiles everywhere, images
+    smaller than a tile, and 5 segments so that the two-segments-per-workgroup tiles see an odd tail."""
+    from birda_amd import synth
+    from birda_amd.classifier import BirdClassifier
+    path, _, m, _ = model_dir["mini_b0"]
+    segs = synth.synth_segments(5, m.sample_count, m.sample_rate, start=40)
+    ref = oracle_lib.OracleModel(path).forward(segs)
+    monkeypatch.setenv("BIRDA_HIP_FUSE", "0")
+    clf = BirdClassifier(path)
+    assert clf.fused_blocks() == []
+    ctx = clf.create_batch_context(8)
+    unfused = clf.predict_logits(ctx, segs)
+    ctx.close(); clf.close()
+    _logit_close(unfused, ref)
+    monkeypatch.setenv("BIRDA_HIP_FUSE", "1")
+    clf = BirdClassifier(path)
+    assert len(clf.fused_blocks()) == 15
+    ctx = clf.create_batch_context(8)
+    fused = clf.predict_logits(ctx, segs)
+    # a context smaller than the batch: slices of 2 (+ odd tail) through the same kernels
+    ctx2 = clf.create_batch_context(2)
+    sliced = clf.predict_logits(ctx2, segs)
+    ctx.close(); ctx2.close(); clf.close()
+    _logit_close(fused, ref)
+    _logit_close(fused, unfused)
+    assert np.array_equal(fused, sliced)
+
+
+def test_every_fused_tile_configuration(model_dir, oracle_lib, monkeypatch):
+    """Force each tile configuration in turn; blocks it cannot run fall back to the layer kernels."""
+    from birda_amd import _lib, synth
+    from birda_amd.classifier import BirdClassifier
+    path, _, m, _ = model_dir["mini_b0"]
+    segs = synth.synth_segments(3, m.sample_count, m.sample_rate, start=7)
+    ref = oracle_lib.OracleModel(path).forward(segs)
+    used = set()
+    for cfg in range(32):
+        monkeypatch.setenv("BIRDA_HIP_MB_CFG", str(cfg))
+        clf = BirdClassifier(path)
+        blocks = clf.fused_blocks()
+        if not blocks:
+            clf.close()
+            if cfg >= 10:
+                break
+            continue
+        assert set(blocks) == {cfg}
+        used.add(cfg)
+        ctx = clf.create_batch_context(4)
+        _logit_close(clf.predict_logits(ctx, segs), ref)
+        ctx.close(); clf.close()
+    assert used == set(range(10)), used
