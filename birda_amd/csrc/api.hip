@@ -408,35 +408,44 @@ int plan_fusion(bh_classifier *c) {
         d.KS = (int)D.kh; d.ST = (int)D.sh;
         d.act_e = (int)E.act; d.act_d = (int)D.act; d.act_p = (int)P.act;
         if (!bh::mb_plan(d, force_cfg)) continue;
-        // fragment-major weights
-        const int CE = d.CE, NTE = CE / 16, KG = d.KG, NTOP = d.NTOP, nch = d.nchunks;
-        const float *We = m.blob.data() + E.w_off, *Wp = m.blob.data() + P.w_off;
-        std::vector<float> wef((size_t)nch * KG * NTE * 256, 0.0f), wpf((size_t)nch * NTE * NTOP * 256, 0.0f);
-        for (int ch = 0; ch < nch; ch++)
+        // per-chunk weight blocks (kernels.hpp MbDesc)
+        const int CE = d.CE, NTE = CE / 16, KG = d.KG, NTOP = d.NTOP, nch = d.nchunks, KK = d.KS * d.KS;
+        const float *We = m.blob.data() + E.w_off, *Wp = m.blob.data() + P.w_off, *Wd = m.blob.data() + D.w_off;
+        const float *be = m.blob.data() + E.b_off, *bd = m.blob.data() + D.b_off;
+        const size_t we_fl = (size_t)KG * NTE * 256 + CE, wp_fl = (size_t)NTE * NTOP * 256, wd_fl = (size_t)KK * CE + CE;
+        std::vector<float> wef(nch * we_fl, 0.0f), wpf(nch * wp_fl, 0.0f), wdf(nch * wd_fl, 0.0f);
+        for (int ch = 0; ch < nch; ch++) {
             for (int g = 0; g < KG; g++)
                 for (int j = 0; j < NTE; j++)
                     for (int lane = 0; lane < 64; lane++)
                         for (int cc = 0; cc < 4; cc++) {
                             const int k = 16 * g + 4 * (lane >> 4) + cc, n = ch * CE + 16 * j + (lane & 15);
-                            if (k < d.Cin) wef[((((size_t)ch * KG + g) * NTE + j) * 64 + lane) * 4 + cc] = We[(size_t)k * d.Cexp + n];
+                            if (k < d.Cin) wef[ch * we_fl + (((size_t)g * NTE + j) * 64 + lane) * 4 + cc] = We[(size_t)k * d.Cexp + n];
                         }
-        for (int ch = 0; ch < nch; ch++)
+            for (int n = 0; n < CE; n++) wef[ch * we_fl + (size_t)KG * NTE * 256 + n] = be[ch * CE + n];
             for (int g = 0; g < NTE; g++)
                 for (int j = 0; j < NTOP; j++)
                     for (int lane = 0; lane < 64; lane++)
                         for (int cc = 0; cc < 4; cc++) {
                             const int k = ch * CE + 16 * g + 4 * (lane >> 4) + cc, n = 16 * j + (lane & 15);
-                            if (n < d.Cout) wpf[((((size_t)ch * NTE + g) * NTOP + j) * 64 + lane) * 4 + cc] = Wp[(size_t)k * d.Cout + n];
+                            if (n < d.Cout) wpf[ch * wp_fl + (((size_t)g * NTOP + j) * 64 + lane) * 4 + cc] = Wp[(size_t)k * d.Cout + n];
                         }
-        float *dwe = nullptr, *dwp = nullptr;
+            for (int tap = 0; tap < KK; tap++)
+                for (int n = 0; n < CE; n++) wdf[ch * wd_fl + (size_t)tap * CE + n] = Wd[(size_t)tap * d.Cexp + ch * CE + n];
+            for (int n = 0; n < CE; n++) wdf[ch * wd_fl + (size_t)KK * CE + n] = bd[ch * CE + n];
+        }
+        float *dwe = nullptr, *dwp = nullptr, *dwd = nullptr;
         int rc = upload(wef.data(), wef.size() * sizeof(float), &dwe);
         if (rc != BH_OK) return rc;
         c->d_owned.push_back(dwe);
         rc = upload(wpf.data(), wpf.size() * sizeof(float), &dwp);
         if (rc != BH_OK) return rc;
         c->d_owned.push_back(dwp);
-        d.We = dwe; d.Wp = dwp;
-        d.be = c->d_blob + E.b_off; d.Wd = c->d_blob + D.w_off; d.bd = c->d_blob + D.b_off; d.bp = c->d_blob + P.b_off;
+        rc = upload(wdf.data(), wdf.size() * sizeof(float), &dwd);
+        if (rc != BH_OK) return rc;
+        c->d_owned.push_back(dwd);
+        d.We = dwe; d.Wp = dwp; d.Wd = dwd;
+        d.bp = c->d_blob + P.b_off;
         c->fused_at[i] = (int)c->mb.size();
         c->mb.push_back(d);
         i += 2;

@@ -83,12 +83,13 @@ void launch_topk(const float *logits, int n_seg, int n_classes, int out_act, int
 struct MbDesc {
     const float *X, *R;  // input NHWC [n][H][W][Cin]; residual (nullable) shaped like Y
     float *Y;            // output NHWC [n][Ho][Wo][Cout]
-    // We: fragment-major [chunk][KG][CE/16][64 lanes][4], element (ch, g, j, lane, c) =
-    //     We[k = 16g + 4(lane>>4) + c][n = ch*CE + 16j + (lane&15)] (0 for k >= Cin)
-    // Wp: fragment-major [chunk][CE/16][NTOP][64][4], element (ch, g, j, lane, c) =
-    //     Wp[k = ch*CE + 16g + 4(lane>>4) + c][n = 16j + (lane&15)] (0 for n >= Cout)
-    // Wd: [KS*KS][Cexp] as in the model blob; be / bd / bp: biases
-    const float *We, *be, *Wd, *bd, *Wp, *bp;
+    // Per-chunk weight blocks, each one contiguous LDS-DMA transfer (built by api.hip plan_fusion):
+    // We: [chunk]{ fragments [KG][CE/16][64 lanes][4], element (g, j, lane, c) =
+    //              We[k = 16g + 4(lane>>4) + c][n = ch*CE + 16j + (lane&15)] (0 for k >= Cin); be[CE] }
+    // Wp: [chunk]{ fragments [CE/16][NTOP][64][4], element (g, j, lane, c) =
+    //              Wp[k = ch*CE + 16g + 4(lane>>4) + c][n = 16j + (lane&15)] (0 for n >= Cout) }
+    // Wd: [chunk]{ Wd[tap][CE]; bd[CE] }
+    const float *We, *Wd, *Wp, *bp;
     int H, W, Cin, Cexp, Cout, Ho, Wo, pad_t, pad_l, KS, ST;
     int act_e, act_d, act_p;
     // diagnostic: 8 phase counters (wave-cycles: setup, dw-weight stage, P1, barrier, P2, barrier, P3,

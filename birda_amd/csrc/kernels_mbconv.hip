@@ -11,8 +11,8 @@
 //   in-tile   IH x IW = ((TH-1)s + k) x ((TW-1)s + k) input positions; the part inside the image is
 //             the "valid rect", M = S * vh * vw source rows.
 //   per chunk of CE expanded channels:
-//     P1  E[M x CE]   = act(X[M x Cin] . We[Cin x CE] + be)   f32 MFMA; A straight from global/L2,
-//                       B fragment-major from L2; rows scattered into the LDS grid Es (the grid's
+//     P1  E[M x CE]   = act(X[M x Cin] . We[Cin x CE] + be)   f32 MFMA; A resident in registers,
+//                       B fragment-major in LDS; rows scattered into the LDS grid Es (the grid's
 //                       out-of-image border stays zero = the depthwise conv's zero padding)
 //     P2  D[P x CE]   = act(dw_kxk(Es) + bd)                  VALU + LDS, 4 channels per lane
 //     P3  acc[P x Co] += D[P x CE] . Wp[CE x Co]              f32 MFMA, accumulators live across chunks
@@ -28,13 +28,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-__device__ __forceinline__ float mb_act(float v, int act) {
-    switch (act) {
-    case ACT_NONE: return v;
-    case ACT_GELU_ERF: return gelu_erf_fast(v);
-    default: return act_apply_slow(v, act);
-    }
+// The activation is a compile-time constant: a run-time switch inlined at ~40 call sites blew the
+// kernel up to >100 KB of code (instruction-cache misses in the depthwise loop).
+template <int ACT>
+__device__ __forceinline__ float mb_act(float v) {
+    if constexpr (ACT == ACT_NONE) return v;
+    else if constexpr (ACT == ACT_GELU_ERF) return gelu_erf_fast(v);
+    else if constexpr (ACT == ACT_RELU) return fmaxf(v, 0.f);
+    else return act_apply_slow(v, ACT);
 }
+constexpr int MB_ACT = ACT_GELU_ERF;  // expand + depthwise activation of every instantiation below
 
 // diagnostic phase clock (only when d.stamps != nullptr): cycles since the last stamp are added to
 // slot `ph` by lane 0 of every wave
@@ -45,38 +48,80 @@ __device__ __forceinline__ void mb_stamp(unsigned long long *stamps, unsigned lo
     t_last = now;
 }
 
-template <int KS, int ST, int CE, int NCS, int WM, int WN, int MT_W, int NT_W, int TWL>
-__global__ __launch_bounds__(256) void mbconv_kernel(const MbDesc d, const int n_seg) {
+// Template parameters
+//   KS, ST      depthwise kernel size / stride          CE     expanded channels per chunk
+//   KG          16-deep k groups of the expand GEMM (ceil(Cin / 16))
+//   RT_W        most source-row tiles (16 rows) one wave owns in P1
+//   NCS         waves splitting the chunk's columns in P1 (1 or 2)
+//   WM x WN     wave grid of P3, MT_W x NT_W accumulator tiles per wave
+//   TWL         log2(tile width)   XBL  log2(pixels per lane along x in P2)   SS  segments per workgroup
+//   OCC         waves per SIMD the register allocator must leave room for
+//
+// Operand residency: the wave's A fragments of the expand GEMM (its rows of X, all of Cin) are
+// loaded ONCE and stay in registers for every chunk.  The chunk's weights reach LDS by LDS-DMA
+// (global_load_lds_dwordx4, no VGPRs), issued behind one barrier and drained before the next:
+//     after B1(ch): We+be of chunk ch+1, Wp of chunk ch      (waited before B2(ch))
+//     after B2(ch): Wd+bd of chunk ch+1                      (waited before B1(ch+1))
+// so the MFMA loops read every operand from registers or LDS and never wait on memory.
+template <int NFLOATS>
+__device__ __forceinline__ void mb_dma(const float *gsrc, float *lds_dst, int wave, int lane) {
+    constexpr int NP = (NFLOATS + 255) / 256;  // 1-KiB pieces, dealt round-robin to the 4 waves
+#pragma unroll
+    for (int p0 = 0; p0 < NP; p0 += 4) {
+        const int p = p0 + wave;
+        const int off = p * 256 + lane * 4;
+        if (p < NP && off < NFLOATS)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + off),
+                                             (__attribute__((address_space(3))) void *)(lds_dst + p * 256), 16, 0, 0);
+    }
+}
+
+template <int KS, int ST, int CE, int KG, int RT_W, int NCS, int WM, int WN, int MT_W, int NT_W, int TWL, int XBL,
+          int SS, int OCC>
+__global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const int n_seg) {
     static_assert(WM * WN == 4, "4 waves");
     constexpr int NT_E = CE / 16, NT_U = NT_E / NCS, CES = CE + 4, C4N = CE / 4, TW = 1 << TWL;
     constexpr int POUT_PAD = WM * MT_W * 16, NTOP = WN * NT_W;
+    constexpr int XB = 1 << XBL, XBN = TW / XB, NCOL = (XB - 1) * ST + KS;
+    constexpr int RSTEP = 4 / NCS;  // row-tile stride between a wave's P1 tiles
+    constexpr int RG = (RT_W * NT_U <= 8) ? RT_W : (8 / NT_U >= 1 ? 8 / NT_U : 1);  // row tiles in flight
+    constexpr int WE_FLOATS = KG * NT_E * 256 + CE;   // We fragments + be
+    constexpr int WP_FLOATS = NT_E * NTOP * 256;
+    constexpr int WD_FLOATS = KS * KS * CE + CE;      // Wd [tap][CE] + bd
     static_assert(NT_U * NCS == NT_E, "column split");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
-    const int IH = d.IH, IW = d.IW, S = d.S, TH = d.TH, THTW = d.TH << TWL;
-    const int egrid = S * IH * IW;
+    const int IH = d.IH, IW = d.IW, TH = d.TH, THTW = d.TH << TWL;
+    const int egrid = SS * IH * IW;
     float *Es = smem;
     float *Ds = Es + (size_t)egrid * CES;
-    float *Wds = Ds + POUT_PAD * CES;
-    float *bds = Wds + KS * KS * CE;
-    int *emap = reinterpret_cast<int *>(bds + CE);
+    float *WeS = Ds + POUT_PAD * CES;
+    float *WpS = WeS + WE_FLOATS;
+    float *Wds = WpS + WP_FLOATS;
+    int *emap = reinterpret_cast<int *>(Wds + WD_FLOATS);
     int *xoff = emap + d.mpad_max;
     int *omap = xoff + d.mpad_max;
+    const float *bes = WeS + KG * NT_E * 256, *bds = Wds + KS * KS * CE;
 
     unsigned long long t_last = d.stamps ? __builtin_readcyclecounter() : 0ull;
+    mb_dma<WE_FLOATS>(d.We, WeS, wave, lane);
+    mb_dma<WD_FLOATS>(d.Wd, Wds, wave, lane);
+
     const int tyi = blockIdx.x / d.tiles_x, txi = blockIdx.x - tyi * d.tiles_x;
-    const int seg0 = blockIdx.y * S;
-    const int nsv = min(S, n_seg - seg0);
+    const int seg0 = blockIdx.y * SS;
+    const int nsv = min(SS, n_seg - seg0);
     const int oy0 = tyi * TH, ox0 = txi * TW;
     const int iy0 = oy0 * ST - d.pad_t, ix0 = ox0 * ST - d.pad_l;
     const int ya = max(0, -iy0), yb = min(IH, d.H - iy0);
     const int xa = max(0, -ix0), xb = min(IW, d.W - ix0);
     const int vh = max(yb - ya, 0), vw = max(xb - xa, 0);
     const int Mseg = vh * vw, M = Mseg * nsv, nrt = (M + 15) >> 4;
-    const int Cin = d.Cin, Cout = d.Cout, KG = d.KG;
+    const int Cin = d.Cin, Cout = d.Cout, nchunks = d.nchunks;
     const float *Xb = d.X + (size_t)seg0 * d.H * d.W * Cin;
+    const int rw = wave / NCS, cs = wave - rw * NCS;  // P1: row-tile lane of the wave, column split
+    const int wm = wave / WN, wn = wave - wm * WN;    // P3
 
     for (int m = tid; m < nrt * 16; m += 256) {
         int e = -1, xo = 0;
@@ -101,111 +146,137 @@ __global__ __launch_bounds__(256) void mbconv_kernel(const MbDesc d, const int n
         const int n4 = egrid * CES / 4;
         for (int i = tid; i < n4; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    __syncthreads();
+    __syncthreads();  // (drains the two DMAs above: hipcc waits vmcnt(0) ahead of the barrier)
+
+    // ---- the wave's rows of X: A fragments of the expand GEMM, resident for the whole kernel ----
+    float4 afr[RT_W][KG];
+#pragma unroll
+    for (int i = 0; i < RT_W; i++) {
+        const int rt = rw + RSTEP * i;
+        const bool rv = rt < nrt;
+        const float *xp = Xb + (rv ? xoff[rt * 16 + li] : 0) + 4 * kq;
+#pragma unroll
+        for (int g = 0; g < KG; g++)
+            afr[i][g] = (rv && 16 * g + 4 * kq < Cin) ? *reinterpret_cast<const float4 *>(xp + 16 * g)
+                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     mb_stamp(d.stamps, t_last, 0);
 
-    const int wm = wave / WN, wn = wave - wm * WN;
     f32x4 acco[MT_W][NT_W];
 #pragma unroll
     for (int i = 0; i < MT_W; i++)
 #pragma unroll
         for (int j = 0; j < NT_W; j++) acco[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    for (int ch = 0; ch < d.nchunks; ch++) {
-        // depthwise weights + bias of this chunk -> LDS (free since the barrier after the last P2)
-        for (int i = tid; i < KS * KS * C4N; i += 256) {
-            const int tap = i / C4N, c4 = i - tap * C4N;
-            *reinterpret_cast<float4 *>(&Wds[tap * CE + 4 * c4]) =
-                *reinterpret_cast<const float4 *>(&d.Wd[(size_t)tap * d.Cexp + ch * CE + 4 * c4]);
-        }
-        if (tid < C4N)
-            *reinterpret_cast<float4 *>(&bds[4 * tid]) = *reinterpret_cast<const float4 *>(&d.bd[ch * CE + 4 * tid]);
-
+    for (int ch = 0; ch < nchunks; ch++) {
+        const int chn = min(ch + 1, nchunks - 1);
         mb_stamp(d.stamps, t_last, 1);
+
         // ---- P1: expand ------------------------------------------------------------------
-        {
-            const float4 *WeF = reinterpret_cast<const float4 *>(d.We) + (size_t)ch * KG * NT_E * 64 + lane;
-            for (int u = wave; u < nrt * NCS; u += 4) {
-                const int rt = u / NCS, cs = u - rt * NCS;
-                const float *xp = Xb + xoff[rt * 16 + li] + 4 * kq;
-                f32x4 acc[NT_U];
 #pragma unroll
-                for (int j = 0; j < NT_U; j++) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                float4 a_cur = (4 * kq < Cin) ? *reinterpret_cast<const float4 *>(xp) : make_float4(0.f, 0.f, 0.f, 0.f);
-                float4 b_cur[NT_U], b_nxt[NT_U];
+        for (int i0 = 0; i0 < RT_W; i0 += RG) {
+            if (rw + RSTEP * i0 < nrt) {  // wave-uniform
+                f32x4 acc[RG][NT_U];
 #pragma unroll
-                for (int j = 0; j < NT_U; j++) b_cur[j] = WeF[(cs * NT_U + j) * 64];
+                for (int ii = 0; ii < RG; ii++)
+#pragma unroll
+                    for (int j = 0; j < NT_U; j++) acc[ii][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
                 for (int g = 0; g < KG; g++) {
-                    const int gn = min(g + 1, KG - 1);
-                    const float4 a_nxt = (16 * gn + 4 * kq < Cin) ? *reinterpret_cast<const float4 *>(xp + 16 * gn)
-                                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+                    float4 bv[NT_U];
 #pragma unroll
-                    for (int j = 0; j < NT_U; j++) b_nxt[j] = WeF[(gn * NT_E + cs * NT_U + j) * 64];
+                    for (int j = 0; j < NT_U; j++)
+                        bv[j] = *reinterpret_cast<const float4 *>(&WeS[((g * NT_E + cs * NT_U + j) * 64 + lane) * 4]);
 #pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        const float a = c == 0 ? a_cur.x : c == 1 ? a_cur.y : c == 2 ? a_cur.z : a_cur.w;
+                    for (int c = 0; c < 4; c++)
+#pragma unroll
+                        for (int ii = 0; ii < RG; ii++) {
+                            if (i0 + ii >= RT_W) continue;
+                            const float4 av = afr[i0 + ii < RT_W ? i0 + ii : 0][g];
+                            const float a = c == 0 ? av.x : c == 1 ? av.y : c == 2 ? av.z : av.w;
+#pragma unroll
+                            for (int j = 0; j < NT_U; j++) {
+                                const float b = c == 0 ? bv[j].x : c == 1 ? bv[j].y : c == 2 ? bv[j].z : bv[j].w;
+                                acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[ii][j], 0, 0, 0);
+                            }
+                        }
+                }
+#pragma unroll
+                for (int ii = 0; ii < RG; ii++) {
+                    if (i0 + ii >= RT_W) continue;
+                    const int rt = rw + RSTEP * (i0 + ii);
+                    if (rt < nrt) {
+                        const int4 e4 = *reinterpret_cast<const int4 *>(&emap[rt * 16 + 4 * kq]);
+                        const int er[4] = {e4.x, e4.y, e4.z, e4.w};
 #pragma unroll
                         for (int j = 0; j < NT_U; j++) {
-                            const float b = c == 0 ? b_cur[j].x : c == 1 ? b_cur[j].y : c == 2 ? b_cur[j].z : b_cur[j].w;
-                            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j], 0, 0, 0);
+                            const int col = (cs * NT_U + j) * 16 + li;
+                            const float bias = bes[col];
+#pragma unroll
+                            for (int r = 0; r < 4; r++)
+                                if (er[r] >= 0) Es[er[r] * CES + col] = mb_act<MB_ACT>(acc[ii][j][r] + bias);
                         }
                     }
-                    a_cur = a_nxt;
-#pragma unroll
-                    for (int j = 0; j < NT_U; j++) b_cur[j] = b_nxt[j];
-                }
-                const int4 e4 = *reinterpret_cast<const int4 *>(&emap[rt * 16 + 4 * kq]);
-                const int er[4] = {e4.x, e4.y, e4.z, e4.w};
-#pragma unroll
-                for (int j = 0; j < NT_U; j++) {
-                    const int col = (cs * NT_U + j) * 16 + li;
-                    const float bias = d.be[ch * CE + col];
-#pragma unroll
-                    for (int r = 0; r < 4; r++)
-                        if (er[r] >= 0) Es[er[r] * CES + col] = mb_act(acc[j][r] + bias, d.act_e);
                 }
             }
         }
         mb_stamp(d.stamps, t_last, 2);
-        __syncthreads();
+        __syncthreads();  // B1: Es complete; WeS / WpS free; Wds (DMA issued after the last B2) landed
+        mb_dma<WE_FLOATS>(d.We + (size_t)chn * WE_FLOATS, WeS, wave, lane);
+        mb_dma<WP_FLOATS>(d.Wp + (size_t)ch * WP_FLOATS, WpS, wave, lane);
         mb_stamp(d.stamps, t_last, 3);
 
-        // ---- P2: depthwise ---------------------------------------------------------------
-        for (int sl = 0; sl < nsv; sl++) {
-            const float *eseg = Es + (size_t)sl * IH * IW * CES;
-            for (int t = tid; t < THTW * C4N; t += 256) {
-                const int p = t / C4N, c4 = t - p * C4N;
-                const int ty = p >> TWL, tx = p & (TW - 1);
-                const float *eb = eseg + ((ty * ST) * IW + tx * ST) * CES + 4 * c4;
-                float4 acc = *reinterpret_cast<const float4 *>(&bds[4 * c4]);
+        // ---- P2: depthwise, XB output pixels x 4 channels per lane ---------------------------
+        {
+            const int ntask = nsv * TH * XBN * C4N;
+            for (int t = tid; t < ntask; t += 256) {
+                const int q = t / C4N, c4 = t - q * C4N;
+                const int xbi = q & (XBN - 1), r = q >> (TWL - XBL);
+                const int sl = (SS > 1 && r >= TH) ? 1 : 0, ty = r - sl * TH;
+                const int tx0 = xbi * XB;
+                const float *eb = Es + ((size_t)sl * IH * IW + (ty * ST) * IW + tx0 * ST) * CES + 4 * c4;
+                const float4 bd4 = *reinterpret_cast<const float4 *>(&bds[4 * c4]);
+                float4 acc[XB];
+#pragma unroll
+                for (int x = 0; x < XB; x++) acc[x] = bd4;
 #pragma unroll
                 for (int dy = 0; dy < KS; dy++) {
-                    const float *er = eb + dy * IW * CES;
+                    float4 e[NCOL];
+#pragma unroll
+                    for (int j = 0; j < NCOL; j++) e[j] = *reinterpret_cast<const float4 *>(eb + (dy * IW + j) * CES);
 #pragma unroll
                     for (int dx = 0; dx < KS; dx++) {
-                        const float4 e = *reinterpret_cast<const float4 *>(er + dx * CES);
                         const float4 w = *reinterpret_cast<const float4 *>(&Wds[(dy * KS + dx) * CE + 4 * c4]);
-                        acc.x += e.x * w.x; acc.y += e.y * w.y; acc.z += e.z * w.z; acc.w += e.w * w.w;
+#pragma unroll
+                        for (int x = 0; x < XB; x++) {
+                            const float4 ev = e[x * ST + dx];
+                            acc[x].x += ev.x * w.x; acc[x].y += ev.y * w.y; acc[x].z += ev.z * w.z; acc[x].w += ev.w * w.w;
+                        }
                     }
                 }
-                acc.x = mb_act(acc.x, d.act_d); acc.y = mb_act(acc.y, d.act_d);
-                acc.z = mb_act(acc.z, d.act_d); acc.w = mb_act(acc.w, d.act_d);
-                *reinterpret_cast<float4 *>(&Ds[(sl * THTW + p) * CES + 4 * c4]) = acc;
+#pragma unroll
+                for (int x = 0; x < XB; x++) {
+                    float4 v = acc[x];
+                    v.x = mb_act<MB_ACT>(v.x); v.y = mb_act<MB_ACT>(v.y);
+                    v.z = mb_act<MB_ACT>(v.z); v.w = mb_act<MB_ACT>(v.w);
+                    *reinterpret_cast<float4 *>(&Ds[(sl * THTW + (ty << TWL) + tx0 + x) * CES + 4 * c4]) = v;
+                }
             }
         }
         mb_stamp(d.stamps, t_last, 4);
-        __syncthreads();
+        __syncthreads();  // B2: Ds complete; WeS (next chunk) and WpS (this chunk) landed; Wds free
+        mb_dma<WD_FLOATS>(d.Wd + (size_t)chn * WD_FLOATS, Wds, wave, lane);
         mb_stamp(d.stamps, t_last, 5);
 
         // ---- P3: project -----------------------------------------------------------------
         {
-            const float4 *WpF = reinterpret_cast<const float4 *>(d.Wp) + ((size_t)ch * NT_E * NTOP + wn * NT_W) * 64 + lane;
             const float *dsb = Ds + ((wm * MT_W) * 16 + li) * CES + 4 * kq;
 #pragma unroll
             for (int g = 0; g < NT_E; g++) {
                 float4 a[MT_W], b[NT_W];
 #pragma unroll
-                for (int j = 0; j < NT_W; j++) b[j] = WpF[(g * NTOP + j) * 64];
+                for (int j = 0; j < NT_W; j++)
+                    b[j] = *reinterpret_cast<const float4 *>(&WpS[((g * NTOP + wn * NT_W + j) * 64 + lane) * 4]);
 #pragma unroll
                 for (int i = 0; i < MT_W; i++) a[i] = *reinterpret_cast<const float4 *>(dsb + i * 16 * CES + 16 * g);
 #pragma unroll
@@ -222,8 +293,8 @@ __global__ __launch_bounds__(256) void mbconv_kernel(const MbDesc d, const int n
             }
         }
         mb_stamp(d.stamps, t_last, 6);
-        // no barrier here: the next chunk's P1 touches Es / Wds only, and every wave has passed the
-        // barrier after P2; its P2 (which rewrites Ds) sits behind the barrier after P1.
+        // no barrier here: the next chunk's P1 touches Es / WeS (landed before B2) only; its P2
+        // (which rewrites Ds) sits behind B1, which also drains the Wd DMA issued above.
     }
 
     // ---- epilogue: bias, activation, residual, store -----------------------------------------
@@ -242,7 +313,7 @@ __global__ __launch_bounds__(256) void mbconv_kernel(const MbDesc d, const int n
             for (int r = 0; r < 4; r++)
                 if (orow[r] >= 0) {
                     const size_t idx = (size_t)orow[r] * Cout + col;
-                    float v = mb_act(acco[i][j][r] + bias, d.act_p);
+                    float v = acco[i][j][r] + bias;
                     if (Rb) v += Rb[idx];
                     Yb[idx] = v;
                 }
@@ -252,13 +323,14 @@ __global__ __launch_bounds__(256) void mbconv_kernel(const MbDesc d, const int n
 }
 
 struct MbCfg {
-    int KS, ST, CE, NCS, WM, WN, MT_W, NT_W, TWL, TH, S;
+    int KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S;
     void (*launch)(const MbDesc &, int, hipStream_t);
 };
 
-template <int KS, int ST, int CE, int NCS, int WM, int WN, int MT_W, int NT_W, int TWL>
+template <int KS, int ST, int CE, int KG, int RT_W, int NCS, int WM, int WN, int MT_W, int NT_W, int TWL, int XBL,
+          int SS, int OCC>
 void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
-    auto kern = mbconv_kernel<KS, ST, CE, NCS, WM, WN, MT_W, NT_W, TWL>;
+    auto kern = mbconv_kernel<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, SS, OCC>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -268,22 +340,25 @@ void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
     hipLaunchKernelGGL(kern, grid, block, d.lds_bytes, s, d, n_seg);
 }
 
-#define MB_ENTRY(KS, ST, CE, NCS, WM, WN, MT_W, NT_W, TWL, TH, S) \
-    {KS, ST, CE, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, mb_launch<KS, ST, CE, NCS, WM, WN, MT_W, NT_W, TWL>}
+#define MB_ENTRY(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC) \
+    {KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S,                        \
+     mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC>}
 
 // The instantiations cover the BirdNET-v2.4 / Perch-shaped stacks (EfficientNet-B0 stages);
 // mb_plan() picks, per block, the valid entry with the least MFMA work.
+//        KS ST CE KG RT NCS WM WN MT NT TWL XBL TH S OCC
 const MbCfg kCfgs[] = {
-    MB_ENTRY(3, 2, 48, 1, 4, 1, 1, 2, 4, 4, 1),    // 0: 48x256 -> 24x128, Cout <= 32
-    MB_ENTRY(3, 1, 48, 1, 4, 1, 2, 2, 4, 8, 1),    // 1: 24x128 s1, Cout <= 32
-    MB_ENTRY(5, 2, 48, 1, 4, 1, 1, 3, 4, 4, 1),    // 2: 24x128 -> 12x64, Cout <= 48
-    MB_ENTRY(5, 1, 48, 1, 4, 1, 3, 3, 4, 12, 1),   // 3: 12x64 s1 full-height tiles, Cout <= 48
-    MB_ENTRY(3, 2, 48, 1, 2, 2, 3, 3, 4, 6, 1),    // 4: 12x64 -> 6x32, Cout <= 96
-    MB_ENTRY(3, 1, 32, 1, 4, 1, 3, 5, 5, 6, 1),    // 5: 6x32 whole image, Cout <= 80
-    MB_ENTRY(5, 1, 32, 1, 4, 1, 3, 7, 5, 6, 1),    // 6: 6x32 whole image, Cout <= 112
-    MB_ENTRY(5, 2, 32, 1, 1, 4, 3, 3, 4, 3, 1),    // 7: 6x32 -> 3x16, Cout <= 192
-    MB_ENTRY(5, 1, 32, 2, 2, 2, 3, 6, 4, 3, 2),    // 8: 3x16 x 2 segments, Cout <= 192
-    MB_ENTRY(3, 1, 32, 2, 2, 2, 3, 10, 4, 3, 2),   // 9: 3x16 x 2 segments, Cout <= 320
+    MB_ENTRY(3, 2, 48, 1, 5, 1, 4, 1, 1, 2, 4, 0, 4, 1, 2),    // 0: 16 -> 96 -> 24, 48x256 -> 24x128
+    MB_ENTRY(3, 1, 48, 2, 3, 1, 4, 1, 2, 2, 4, 1, 8, 1, 2),    // 1: 24 -> 144 -> 24, 24x128
+    MB_ENTRY(5, 2, 48, 2, 7, 1, 4, 1, 1, 3, 4, 0, 4, 1, 1),    // 2: 24 -> 144 -> 40, 24x128 -> 12x64
+    MB_ENTRY(5, 1, 48, 3, 4, 1, 4, 1, 3, 3, 4, 2, 12, 1, 1),   // 3: 40 -> 240 -> 40, 12x64, full-height tiles
+    MB_ENTRY(3, 2, 48, 3, 7, 1, 2, 2, 3, 3, 4, 1, 6, 1, 1),    // 4: 40 -> 240 -> 80, 12x64 -> 6x32
+    MB_ENTRY(3, 1, 32, 5, 3, 1, 4, 1, 3, 5, 5, 1, 6, 1, 2),    // 5: 80 -> 480 -> 80, 6x32 whole image
+    MB_ENTRY(5, 1, 32, 5, 3, 1, 4, 1, 3, 7, 5, 1, 6, 1, 1),    // 6: 80 -> 480 -> 112, 6x32
+    MB_ENTRY(5, 1, 32, 7, 3, 1, 4, 1, 3, 7, 5, 1, 6, 1, 1),    // 7: 112 -> 672 -> 112, 6x32
+    MB_ENTRY(5, 2, 32, 7, 3, 1, 1, 4, 3, 3, 4, 1, 3, 1, 1),    // 8: 112 -> 672 -> 192, 6x32 -> 3x16
+    MB_ENTRY(5, 1, 32, 12, 3, 2, 2, 2, 3, 6, 4, 2, 3, 2, 1),   // 9: 192 -> 1152 -> 192, 3x16 x 2 segments
+    MB_ENTRY(3, 1, 32, 12, 3, 2, 2, 2, 3, 10, 4, 2, 3, 2, 1),  // 10: 192 -> 1152 -> 320, 3x16 x 2 segments
 };
 constexpr int kNCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
@@ -292,6 +367,8 @@ constexpr int kNCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 double mb_try(MbDesc &d, int ci) {
     const MbCfg &c = kCfgs[ci];
     if (c.KS != d.KS || c.ST != d.ST || d.Cexp % c.CE || d.Cin % 4 || d.Cexp % 4) return -1;
+    if ((d.Cin + 15) / 16 != c.KG) return -1;
+    if (d.act_e != MB_ACT || d.act_d != MB_ACT || d.act_p != ACT_NONE) return -1;
     const int nto = (d.Cout + 15) / 16;
     if (nto > c.WN * c.NT_W) return -1;
     const int TW = 1 << c.TWL;
@@ -302,8 +379,11 @@ double mb_try(MbDesc &d, int ci) {
     t.KG = (d.Cin + 15) / 16; t.nchunks = d.Cexp / c.CE; t.NTOP = c.WN * c.NT_W; t.CE = c.CE;
     const int mseg = std::min(t.IH, d.H) * std::min(t.IW, d.W);
     t.mpad_max = (c.S * mseg + 15) / 16 * 16;
+    if (t.mpad_max / 16 > c.RT_W * (4 / c.NCS)) return -1;  // a wave keeps all its rows of X in registers
     const int ces = c.CE + 4, pout_pad = c.WM * c.MT_W * 16;
-    t.lds_bytes = ((size_t)c.S * t.IH * t.IW * ces + (size_t)pout_pad * ces + (size_t)c.KS * c.KS * c.CE + c.CE) * 4 +
+    const size_t we_fl = (size_t)c.KG * (c.CE / 16) * 256 + c.CE, wp_fl = (size_t)(c.CE / 16) * t.NTOP * 256;
+    const size_t wd_fl = (size_t)c.KS * c.KS * c.CE + c.CE;
+    t.lds_bytes = ((size_t)c.S * t.IH * t.IW * ces + (size_t)pout_pad * ces + we_fl + wp_fl + wd_fl) * 4 +
                   ((size_t)2 * t.mpad_max + pout_pad) * 4;
     if (t.lds_bytes > 160 * 1024) return -1;
     d = t;
