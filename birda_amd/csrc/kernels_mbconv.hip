@@ -39,14 +39,19 @@ __device__ __forceinline__ float mb_act(float v) {
 }
 constexpr int MB_ACT = ACT_GELU_ERF;  // expand + depthwise activation of every instantiation below
 
-// diagnostic phase clock (only when d.stamps != nullptr): cycles since the last stamp are added to
-// slot `ph` by lane 0 of every wave
-__device__ __forceinline__ void mb_stamp(unsigned long long *stamps, unsigned long long &t_last, int ph) {
-    if (!stamps) return;
-    const unsigned long long now = __builtin_readcyclecounter();
-    if ((threadIdx.x & 63) == 0) atomicAdd(&stamps[ph], now - t_last);
-    t_last = now;
-}
+// diagnostic phase clock (only when d.stamps != nullptr): cycles since the last stamp are summed per
+// phase in registers and added to the global counters once, at the end, by lane 0 of every wave
+struct MbClock {
+    unsigned long long last, acc[8];
+};
+#define mb_stamp(stamps, clk, ph)                                          \
+    do {                                                                   \
+        if (stamps) {                                                      \
+            const unsigned long long now_ = __builtin_readcyclecounter(); \
+            clk.acc[ph] += now_ - clk.last;                                \
+            clk.last = now_;                                               \
+        }                                                                  \
+    } while (0)
 
 // Template parameters
 //   KS, ST      depthwise kernel size / stride          CE     expanded channels per chunk
@@ -70,11 +75,18 @@ __device__ __forceinline__ void mb_dma(const float *gsrc, float *lds_dst, int wa
     for (int p0 = 0; p0 < NP; p0 += 4) {
         const int p = p0 + wave;
         const int off = p * 256 + lane * 4;
-        if (p < NP && off < NFLOATS)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + off),
-                                             (__attribute__((address_space(3))) void *)(lds_dst + p * 256), 16, 0, 0);
+        if (p < NP && off < NFLOATS) {
+            // Inline asm on purpose: after the builtin form hipcc drains vmcnt(0) in front of the next
+            // LDS read of ANY array (it cannot prove the DMA's destination is not read), which made
+            // every transfer synchronous.  The waits are placed by hand: mb_dma_wait() before the
+            // barrier that precedes the first reader.  M0 = LDS byte address of the piece.
+            const unsigned la = (unsigned)(size_t)(lds_dst + p * 256);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                         :: "v"(gsrc + off), "s"(__builtin_amdgcn_readfirstlane(la)) : "memory", "m0");
+        }
     }
 }
+__device__ __forceinline__ void mb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <int KS, int ST, int CE, int KG, int RT_W, int NCS, int WM, int WN, int MT_W, int NT_W, int TWL, int XBL,
           int SS, int OCC>
@@ -96,7 +108,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
     const int IH = d.IH, IW = d.IW, TH = d.TH, THTW = d.TH << TWL;
     const int egrid = SS * IH * IW;
     float *Es = smem;
-    float *Ds = Es + (size_t)egrid * CES;
+    float *Ds = Es + (size_t)(egrid + 1) * CES;  // + 1: trash row that padding source rows write to
     float *WeS = Ds + POUT_PAD * CES;
     float *WpS = WeS + WE_FLOATS;
     float *Wds = WpS + WP_FLOATS;
@@ -105,7 +117,8 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
     int *omap = xoff + d.mpad_max;
     const float *bes = WeS + KG * NT_E * 256, *bds = Wds + KS * KS * CE;
 
-    unsigned long long t_last = d.stamps ? __builtin_readcyclecounter() : 0ull;
+    MbClock t_last{};
+    if (d.stamps) t_last.last = __builtin_readcyclecounter();
     mb_dma<WE_FLOATS>(d.We, WeS, wave, lane);
     mb_dma<WD_FLOATS>(d.Wd, Wds, wave, lane);
 
@@ -124,7 +137,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
     const int wm = wave / WN, wn = wave - wm * WN;    // P3
 
     for (int m = tid; m < nrt * 16; m += 256) {
-        int e = -1, xo = 0;
+        int e = egrid, xo = 0;
         if (m < M) {
             const int sl = m / Mseg, mm = m - sl * Mseg;
             const int r = mm / vw, c = mm - r * vw;
@@ -141,12 +154,13 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
         if (sl < nsv && oy0 + ty < d.Ho && ox0 + tx < d.Wo) o = (sl * d.Ho + oy0 + ty) * d.Wo + ox0 + tx;
         omap[p] = o;
     }
-    {
+    if (M != egrid) {  // some of the grid lies outside the image (or a segment is missing): zero padding
         float4 *z = reinterpret_cast<float4 *>(Es);
         const int n4 = egrid * CES / 4;
         for (int i = tid; i < n4; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    __syncthreads();  // (drains the two DMAs above: hipcc waits vmcnt(0) ahead of the barrier)
+    mb_dma_wait();
+    __syncthreads();
 
     // ---- the wave's rows of X: A fragments of the expand GEMM, resident for the whole kernel ----
     float4 afr[RT_W][KG];
@@ -213,14 +227,14 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                             const int col = (cs * NT_U + j) * 16 + li;
                             const float bias = bes[col];
 #pragma unroll
-                            for (int r = 0; r < 4; r++)
-                                if (er[r] >= 0) Es[er[r] * CES + col] = mb_act<MB_ACT>(acc[ii][j][r] + bias);
+                            for (int r = 0; r < 4; r++) Es[er[r] * CES + col] = mb_act<MB_ACT>(acc[ii][j][r] + bias);
                         }
                     }
                 }
             }
         }
         mb_stamp(d.stamps, t_last, 2);
+        mb_dma_wait();
         __syncthreads();  // B1: Es complete; WeS / WpS free; Wds (DMA issued after the last B2) landed
         mb_dma<WE_FLOATS>(d.We + (size_t)chn * WE_FLOATS, WeS, wave, lane);
         mb_dma<WP_FLOATS>(d.Wp + (size_t)ch * WP_FLOATS, WpS, wave, lane);
@@ -264,6 +278,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
             }
         }
         mb_stamp(d.stamps, t_last, 4);
+        mb_dma_wait();
         __syncthreads();  // B2: Ds complete; WeS (next chunk) and WpS (this chunk) landed; Wds free
         mb_dma<WD_FLOATS>(d.Wd + (size_t)chn * WD_FLOATS, Wds, wave, lane);
         mb_stamp(d.stamps, t_last, 5);
@@ -320,6 +335,8 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
         }
     }
     mb_stamp(d.stamps, t_last, 7);
+    if (d.stamps && lane == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&d.stamps[i], t_last.acc[i]);
 }
 
 struct MbCfg {
@@ -383,7 +400,7 @@ double mb_try(MbDesc &d, int ci) {
     const int ces = c.CE + 4, pout_pad = c.WM * c.MT_W * 16;
     const size_t we_fl = (size_t)c.KG * (c.CE / 16) * 256 + c.CE, wp_fl = (size_t)(c.CE / 16) * t.NTOP * 256;
     const size_t wd_fl = (size_t)c.KS * c.KS * c.CE + c.CE;
-    t.lds_bytes = ((size_t)c.S * t.IH * t.IW * ces + (size_t)pout_pad * ces + we_fl + wp_fl + wd_fl) * 4 +
+    t.lds_bytes = (((size_t)c.S * t.IH * t.IW + 1) * ces + (size_t)pout_pad * ces + we_fl + wp_fl + wd_fl) * 4 +
                   ((size_t)2 * t.mpad_max + pout_pad) * 4;
     if (t.lds_bytes > 160 * 1024) return -1;
     d = t;
