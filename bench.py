@@ -3,10 +3,17 @@
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it
 under torch.distributed.run, one rank per GPU over RCCL.  One "step" = one pass of the hot
-path (min/max -> STFT*mel -> conv stack -> logits -> sigmoid/top-k) over 1 000 synthetic
-segments per GPU that are already resident in HBM (BASELINE.json configs[1]); with N > 1 each
-rank owns its own 1 000-segment shard (weak scaling) and the only collective is the gather
-of the top-k results to rank 0.  Prints ONE JSON line on rank 0.
+path (min/max -> STFT*mel -> stem -> fused MBConv blocks -> head -> logits -> sigmoid/top-k)
+over 1 000 synthetic segments per GPU that are already resident in HBM (BASELINE.json
+configs[1]); with N > 1 each rank owns its own 1 000-segment shard (weak scaling) and the only
+collective is the gather of the top-k results to rank 0.  Prints ONE JSON line on rank 0.
+
+`roofline` is the dominant kernel (largest total time in the timed region): one of the fused
+MBConv kernels, priced in ALGORITHMIC flops (2 x MACs of the block's expand + depthwise +
+project convolutions, no halo / padding work) against the f32 MFMA peak; its launch duration
+comes from HIP events recorded on the context stream around every launch of the timed steps.
+`roofline_mel` is the front-end kernel against the HBM roofline (968 448 B per
+segment).  `cpu_baseline` is the oracle timed on this box's host cores over a bounded sample.
 """
 import argparse
 import json
@@ -24,7 +31,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_* den
 PEAK_HBM_GBPS = 8000.0
 
 
-def cpu_baseline(model_path, sample_count, sample_rate):
+def cpu_baseline(model_path, sample_count, sample_rate, budget_s=20.0):
     """The oracle (a port, not the reference: the reference's ORT path cannot run here) timed
     on this box's host cores over a bounded sample of the same synthetic workload."""
     import numpy as np
@@ -34,15 +41,19 @@ def cpu_baseline(model_path, sample_count, sample_rate):
     cores = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     om = O.OracleModel(model_path)
-    n = max(32, min(2 * cores, 256))
-    segs = synth.synth_segments(min(n, 16), sample_count, sample_rate)
-    segs = np.tile(segs, (n // segs.shape[0] + 1, 1))[:n]
-    om.forward(segs[: min(cores, n)])  # touch code/pages once
+    base = synth.synth_segments(min(cores, 16), sample_count, sample_rate)
+    t = time.perf_counter()
+    om.forward(base[: min(cores, base.shape[0])])  # touch code / pages once, and size the sample
+    first = time.perf_counter() - t
+    per_round = max(first, 1e-3)
+    n = int(max(cores, min(4096, cores * max(1, int(budget_s / per_round)))))
+    segs = np.tile(base, (n // base.shape[0] + 1, 1))[:n]
     t = time.perf_counter()
     om.forward(segs)
     dt = time.perf_counter() - t
     return {"value": round(n / dt, 2), "unit": "segments/s", "cores": cores, "kind": "port",
-            "sample": f"{n} synthetic 3 s/48 kHz segments, oracle/birda_oracle.c, OpenMP across segments, fp32"}
+            "sample": f"{n} synthetic 3 s/48 kHz segments, oracle/birda_oracle.c, OpenMP across segments "
+                      f"({cores} threads), fp32, {dt:.1f} s"}
 
 
 def main():
@@ -50,7 +61,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--micro-batch", type=int, default=int(os.environ.get("BIRDA_HIP_MICRO_BATCH", "256")))
+    ap.add_argument("--micro-batch", type=int, default=int(os.environ.get("BIRDA_HIP_MICRO_BATCH", "1000")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -79,6 +90,7 @@ def main():
     clf = BirdClassifier(model_path, None, top_k=5, min_confidence=0.1, device=local_rank)
     ctx = clf.create_batch_context(args.micro_batch)
     info = clf.info
+    fused = clf.fused_blocks()
 
     n_local = SEGMENTS_PER_GPU
     n_total = n_local * world
@@ -108,15 +120,19 @@ def main():
         step()
     sync_all()
 
-    ctx.set_profiling(True)
+    ctx.set_profiling(True)     # HIP events around every launch, on the context stream
     stage_tot = {}
+    layer_tot = [[0.0, 0] for _ in range(int(info.n_layers))]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        for k, (ms, n) in ctx.stage_ms().items():   # HIP events on the context stream
+        for k, (ms, n) in ctx.stage_ms().items():
             a = stage_tot.setdefault(k, [0.0, 0])
             a[0] += ms
             a[1] += n
+        for i, (ms, n) in enumerate(ctx.layer_ms()):
+            layer_tot[i][0] += ms
+            layer_tot[i][1] += n
     sync_all()
     elapsed = time.perf_counter() - t0
     ctx.set_profiling(False)
@@ -127,11 +143,43 @@ def main():
 
     value = n_total * args.steps / elapsed
     segs_done = n_local * args.steps
-    pw_ms, pw_launches = stage_tot["pointwise"]
+
+    def macs(L):
+        px = L.out_h * L.out_w
+        if L.op == mf.OP_CONV:
+            return px * L.kh * L.kw * L.cin * L.cout
+        if L.op == mf.OP_DWCONV:
+            return px * L.kh * L.kw * L.cout
+        if L.op in (mf.OP_PWCONV, mf.OP_DENSE):
+            return px * L.cin * L.cout
+        return 0
+
+    # launches grouped by kernel: fused blocks of equal shape share one instantiation
+    groups = {}
+    li, bi = 0, 0
+    layers = m.layers
+    fused_layers = set()
+    if fused:
+        # fused blocks start at the expand layer of every pw -> dw -> pw triple the library fused
+        i = 0
+        while i + 2 < len(layers) and bi < len(fused):
+            E, D, P = layers[i], layers[i + 1], layers[i + 2]
+            if (E.op == mf.OP_PWCONV and D.op == mf.OP_DWCONV and P.op == mf.OP_PWCONV and D.in_tensor == i + 1
+                    and P.in_tensor == i + 2 and layer_tot[i][1] > 0 and layer_tot[i + 1][1] == 0):
+                key = ("mbconv", E.cin, E.cout, P.cout, D.kh, D.sh, E.in_h, E.in_w)
+                g = groups.setdefault(key, {"ms": 0.0, "launches": 0, "macs": macs(E) + macs(D) + macs(P)})
+                g["ms"] += layer_tot[i][0]
+                g["launches"] += layer_tot[i][1]
+                fused_layers.add(i)
+                bi += 1
+                i += 3
+            else:
+                i += 1
+    dom_key, dom = (max(groups.items(), key=lambda kv: kv[1]["ms"]) if groups else (None, None))
     mel_ms, mel_launches = stage_tot["mel"]
-    pw_macs = sum(L.out_h * L.out_w * L.cin * L.cout for L in m.layers if L.op == mf.OP_PWCONV)
-    pw_tflops = 2.0 * pw_macs * segs_done / (pw_ms * 1e-3) / 1e12
     mel_gbps = MEL_BYTES_PER_SEGMENT * segs_done / (mel_ms * 1e-3) / 1e9
+    mb_ms, mb_launches = stage_tot.get("mbconv", (0.0, 0))
+    mb_macs = sum(g["macs"] * g["launches"] for g in groups.values())   # per segment x launches (launch = n_local segs)
     out = {
         "metric": "3s/48kHz segments/sec (BirdNET v2.4)", "value": round(value, 1), "unit": "segments/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -140,18 +188,34 @@ def main():
         "config": {"workload": "configs[1]: 1000 synthetic 3 s/48 kHz segments per GPU per step, HBM-resident, "
                                "seeded synthetic BirdNET-v2.4-shaped model (EfficientNet-B0-like, 6522 classes)",
                    "segments_per_gpu": n_local, "micro_batch": args.micro_batch,
-                   "gflop_per_segment": round((2 * info.macs_per_segment + info.mel_flops_per_segment) / 1e9, 3)},
-        "roofline": {"kernel": "pw_gemm_kernel (pointwise 1x1 conv, v_mfma_f32_16x16x4_f32)", "bound": "mfma",
-                     "achieved": round(pw_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(pw_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                     "launches": pw_launches, "avg_launch_us": round(pw_ms * 1e3 / max(pw_launches, 1), 2)},
-        "roofline_mel": {"kernel": "mel_kernel (folded STFT x mel, v_mfma_f32_16x16x4_f32)", "bound": "hbm",
-                         "achieved": round(mel_gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                         "frac": round(mel_gbps / PEAK_HBM_GBPS, 4), "traffic": None,
-                         "launches": mel_launches, "avg_launch_us": round(mel_ms * 1e3 / max(mel_launches, 1), 2),
-                         "mfma_tflops": round(info.mel_flops_per_segment * segs_done / (mel_ms * 1e-3) / 1e12, 2)},
-        "stage_us_per_segment": {k: round(v[0] * 1e3 / segs_done, 3) for k, v in stage_tot.items()},
+                   "gflop_per_segment": round((2 * info.macs_per_segment + info.mel_flops_per_segment) / 1e9, 3),
+                   "fused_blocks": len(fused)},
     }
+    if dom:
+        # this kernel runs n_blocks equal-shaped blocks per slice; every block sees every segment once
+        n_blocks = dom["launches"] // (args.steps * max(1, -(-n_local // args.micro_batch)))
+        total_flops = 2.0 * dom["macs"] * segs_done * n_blocks
+        tflops = total_flops / (dom["ms"] * 1e-3) / 1e12
+        out["roofline"] = {
+            "kernel": "mbconv_kernel (fused expand 1x1 -> depthwise %dx%d s%d -> project 1x1, Cin %d -> %d -> %d at %dx%d, "
+                      "v_mfma_f32_16x16x4_f32)" % (dom_key[4], dom_key[4], dom_key[5], dom_key[1], dom_key[2], dom_key[3],
+                                                   dom_key[6], dom_key[7]),
+            "bound": "mfma", "achieved": round(tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "launches": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2),
+            "algorithmic_gflop_per_launch": round(total_flops / max(dom["launches"], 1) / 1e9, 3)}
+        if mb_ms > 0:
+            out["roofline_all_fused_blocks"] = {
+                "achieved": round(2.0 * sum(g["macs"] * (g["launches"] // (args.steps * max(1, -(-n_local // args.micro_batch))))
+                                            for g in groups.values()) * segs_done / (mb_ms * 1e-3) / 1e12, 2),
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "launches": mb_launches}
+            out["roofline_all_fused_blocks"]["frac"] = round(out["roofline_all_fused_blocks"]["achieved"] / PEAK_F32_MFMA_TFLOPS, 4)
+    out["roofline_mel"] = {"kernel": "mel_kernel (folded STFT x mel, v_mfma_f32_16x16x4_f32)", "bound": "hbm",
+                           "achieved": round(mel_gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                           "frac": round(mel_gbps / PEAK_HBM_GBPS, 4), "traffic": None,
+                           "launches": mel_launches, "avg_launch_us": round(mel_ms * 1e3 / max(mel_launches, 1), 2),
+                           "mfma_tflops": round(info.mel_flops_per_segment * segs_done / (mel_ms * 1e-3) / 1e12, 2)}
+    out["stage_us_per_segment"] = {k: round(v[0] * 1e3 / segs_done, 3) for k, v in stage_tot.items()}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model_path, m.sample_count, m.sample_rate)
     elif rank == 0:

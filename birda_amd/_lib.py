@@ -59,6 +59,7 @@ SYMBOLS = [
     ("bh_tensor_floats", C.c_uint64, [_VP, C.c_uint32]),
     ("bh_batch_context_set_profiling", C.c_int, [_VP, C.c_int]),
     ("bh_batch_context_stage_ms", C.c_int, [_VP, _VP, _VP]),
+    ("bh_batch_context_layer_ms", C.c_int, [_VP, _VP, _VP, _SZ]),
     ("bh_classifier_fused_blocks", C.c_int, [_VP, _VP, _SZ]),
     ("bh_debug_mb_stamps", C.c_int, [_VP, _VP, _SZ]),
     ("bh_resample", C.c_int, [_VP, _VP, _SZ, C.c_uint32, C.c_uint32, _VP, _SZ, C.POINTER(_SZ)]),

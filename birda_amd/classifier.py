@@ -66,6 +66,14 @@ class BatchInferenceContext:
         check(self._L.bh_batch_context_stage_ms(self._h, ms, n))
         return {name: (float(ms[i]), int(n[i])) for i, name in enumerate(_lib.STAGE_NAMES)}
 
+    def layer_ms(self):
+        """[(ms, launches)] per layer of the last profiled forward (fused blocks on their expand layer)."""
+        n = int(self.classifier.info.n_layers)
+        ms = (C.c_float * n)()
+        cnt = (C.c_uint32 * n)()
+        check(self._L.bh_batch_context_layer_ms(self._h, ms, cnt, n))
+        return [(float(ms[i]), int(cnt[i])) for i in range(n)]
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.bh_batch_context_destroy(self._h)

@@ -93,6 +93,7 @@ struct bh_batch_context {
     bool profiling = false;
     std::vector<hipEvent_t> ev;
     std::vector<int> ev_stage;
+    std::vector<int> ev_layer;   // layer index of the launch an event closes (-1: front-end / top-k)
     float stage_ms[BH_N_STAGES] = {0};
     uint32_t stage_launches[BH_N_STAGES] = {0};
 };
@@ -168,13 +169,14 @@ int read_labels(const char *path, std::vector<std::string> &out) {
     return BH_OK;
 }
 
-void ctx_mark(bh_batch_context *ctx, int stage) {
+void ctx_mark(bh_batch_context *ctx, int stage, int layer = -1) {
     if (!ctx->profiling) return;
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;
     (void)hipEventRecord(e, ctx->stream);
     ctx->ev.push_back(e);
     ctx->ev_stage.push_back(stage);
+    ctx->ev_layer.push_back(layer);
 }
 
 // liveness-based arena plan: tensor t is born at step t (tensor 0 = front-end) and dies after
@@ -290,32 +292,32 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
             d.Y = (i + 2 == nl - 1) ? d_logits : T(i + 3);
             d.R = LP.res_tensor != bh::NO_TENSOR ? T(LP.res_tensor) : nullptr;
             bh::launch_mbconv(d, (int)n, s);
-            ctx_mark(ctx, ST_MBCONV);
+            ctx_mark(ctx, ST_MBCONV, (int)i);
             i += 2;
             continue;
         }
         switch (L.op) {
         case bh::OP_CONV:
             bh::launch_conv_direct(in, c->d_w[i], bias, out, p, (int)n, s);
-            ctx_mark(ctx, ST_STEM);
+            ctx_mark(ctx, ST_STEM, (int)i);
             break;
         case bh::OP_DWCONV:
             bh::launch_dwconv(in, c->d_w[i], bias, out, p, (int)n, s);
-            ctx_mark(ctx, ST_DW);
+            ctx_mark(ctx, ST_DW, (int)i);
             break;
         case bh::OP_PWCONV:
             bh::launch_pw_gemm(in, c->d_w[i], bias, res, out, (int)(n * L.out_h * L.out_w), (int)L.cin,
                                (int)L.cout, c->ldw[i], (int)L.act, s);
-            ctx_mark(ctx, ST_PW);
+            ctx_mark(ctx, ST_PW, (int)i);
             break;
         case bh::OP_DENSE:
             bh::launch_pw_gemm(in, c->d_w[i], bias, res, out, (int)n, (int)L.cin, (int)L.cout, c->ldw[i],
                                (int)L.act, s);
-            ctx_mark(ctx, ST_DENSE);
+            ctx_mark(ctx, ST_DENSE, (int)i);
             break;
         case bh::OP_GAP:
             bh::launch_gap(in, out, (int)n, (int)(L.in_h * L.in_w), (int)L.cout, s);
-            ctx_mark(ctx, ST_GAP);
+            ctx_mark(ctx, ST_GAP, (int)i);
             break;
         default: return fail(BH_ERR_UNSUPPORTED, "layer %u: unsupported op %u", i, L.op);
         }
@@ -407,6 +409,7 @@ int plan_fusion(bh_classifier *c) {
         d.Ho = (int)D.out_h; d.Wo = (int)D.out_w; d.pad_t = (int)D.pad_t; d.pad_l = (int)D.pad_l;
         d.KS = (int)D.kh; d.ST = (int)D.sh;
         d.act_e = (int)E.act; d.act_d = (int)D.act; d.act_p = (int)P.act;
+        if (const char *dbg = getenv("BIRDA_HIP_MB_DBG")) d.dbg = atoi(dbg);
         if (!bh::mb_plan(d, force_cfg)) continue;
         // per-chunk weight blocks (kernels.hpp MbDesc)
         const int CE = d.CE, NTE = CE / 16, KG = d.KG, NTOP = d.NTOP, nch = d.nchunks, KK = d.KS * d.KS;
@@ -681,7 +684,7 @@ int bh_forward_device(bh_classifier *c, bh_batch_context *ctx, const float *d_se
     HIPCHK(hipSetDevice(c->device));
     if (ctx->profiling) {
         for (auto e : ctx->ev) (void)hipEventDestroy(e);
-        ctx->ev.clear(); ctx->ev_stage.clear();
+        ctx->ev.clear(); ctx->ev_stage.clear(); ctx->ev_layer.clear();
     }
     const auto &h = c->model.h;
     for (size_t b0 = 0; b0 < n; b0 += ctx->max_batch) {
@@ -717,6 +720,19 @@ int bh_debug_read_tensor(bh_classifier *c, bh_batch_context *ctx, uint32_t tenso
     HIPCHK(hipStreamSynchronize(ctx->stream));
     const float *src = (tensor == c->model.layers.size()) ? ctx->last_logits : ctx->d_arena + ctx->t_off[tensor];
     HIPCHK(hipMemcpy(host, src, nfl * sizeof(float), hipMemcpyDeviceToHost));
+    return BH_OK;
+}
+
+int bh_batch_context_layer_ms(bh_batch_context *ctx, float *ms, uint32_t *launches, size_t n_layers) {
+    if (!ctx || !ms) return fail(BH_ERR_INVALID, "layer_ms: null argument");
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < n_layers; i++) { ms[i] = 0.f; if (launches) launches[i] = 0; }
+    for (size_t i = 1; i < ctx->ev.size(); i++) {
+        const int ly = ctx->ev_layer[i];
+        if (ly < 0 || (size_t)ly >= n_layers) continue;
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, ctx->ev[i - 1], ctx->ev[i]) == hipSuccess) { ms[ly] += t; if (launches) launches[ly]++; }
+    }
     return BH_OK;
 }
 

@@ -95,6 +95,8 @@ struct MbDesc {
     // diagnostic: 8 phase counters (wave-cycles: setup, dw-weight stage, P1, barrier, P2, barrier, P3,
     // epilogue) or nullptr
     unsigned long long *stamps;
+    int dbg;  // ablation bits for tuning (BIRDA_HIP_MB_DBG): 1 no GELU in P1, 2 no P2, 4 no P3, 8 no P1 MFMA,
+              // 16 no weight DMA, 32 no output store.  Results are wrong when non-zero.
     // filled by mb_plan()
     int cfg, CE, TH, S, tiles_y, tiles_x, IH, IW, KG, nchunks, NTOP, mpad_max;
     size_t lds_bytes;

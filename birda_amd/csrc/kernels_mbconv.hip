@@ -195,6 +195,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                 for (int ii = 0; ii < RG; ii++)
 #pragma unroll
                     for (int j = 0; j < NT_U; j++) acc[ii][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (!(d.dbg & 8))
 #pragma unroll
                 for (int g = 0; g < KG; g++) {
                     float4 bv[NT_U];
@@ -227,7 +228,8 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                             const int col = (cs * NT_U + j) * 16 + li;
                             const float bias = bes[col];
 #pragma unroll
-                            for (int r = 0; r < 4; r++) Es[er[r] * CES + col] = mb_act<MB_ACT>(acc[ii][j][r] + bias);
+                            for (int r = 0; r < 4; r++)
+                                Es[er[r] * CES + col] = (d.dbg & 1) ? acc[ii][j][r] + bias : mb_act<MB_ACT>(acc[ii][j][r] + bias);
                         }
                     }
                 }
@@ -236,12 +238,14 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
         mb_stamp(d.stamps, t_last, 2);
         mb_dma_wait();
         __syncthreads();  // B1: Es complete; WeS / WpS free; Wds (DMA issued after the last B2) landed
-        mb_dma<WE_FLOATS>(d.We + (size_t)chn * WE_FLOATS, WeS, wave, lane);
-        mb_dma<WP_FLOATS>(d.Wp + (size_t)ch * WP_FLOATS, WpS, wave, lane);
+        if (!(d.dbg & 16)) {
+            mb_dma<WE_FLOATS>(d.We + (size_t)chn * WE_FLOATS, WeS, wave, lane);
+            mb_dma<WP_FLOATS>(d.Wp + (size_t)ch * WP_FLOATS, WpS, wave, lane);
+        }
         mb_stamp(d.stamps, t_last, 3);
 
         // ---- P2: depthwise, XB output pixels x 4 channels per lane ---------------------------
-        {
+        if (!(d.dbg & 2)) {
             const int ntask = nsv * TH * XBN * C4N;
             for (int t = tid; t < ntask; t += 256) {
                 const int q = t / C4N, c4 = t - q * C4N;
@@ -280,11 +284,11 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
         mb_stamp(d.stamps, t_last, 4);
         mb_dma_wait();
         __syncthreads();  // B2: Ds complete; WeS (next chunk) and WpS (this chunk) landed; Wds free
-        mb_dma<WD_FLOATS>(d.Wd + (size_t)chn * WD_FLOATS, Wds, wave, lane);
+        if (!(d.dbg & 16)) mb_dma<WD_FLOATS>(d.Wd + (size_t)chn * WD_FLOATS, Wds, wave, lane);
         mb_stamp(d.stamps, t_last, 5);
 
         // ---- P3: project -----------------------------------------------------------------
-        {
+        if (!(d.dbg & 4)) {
             const float *dsb = Ds + ((wm * MT_W) * 16 + li) * CES + 4 * kq;
 #pragma unroll
             for (int g = 0; g < NT_E; g++) {
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                     const size_t idx = (size_t)orow[r] * Cout + col;
                     float v = acco[i][j][r] + bias;
                     if (Rb) v += Rb[idx];
-                    Yb[idx] = v;
+                    if (!(d.dbg & 32)) Yb[idx] = v;
                 }
         }
     }
@@ -376,6 +380,16 @@ const MbCfg kCfgs[] = {
     MB_ENTRY(5, 2, 32, 7, 3, 1, 1, 4, 3, 3, 4, 1, 3, 1, 1),    // 8: 112 -> 672 -> 192, 6x32 -> 3x16
     MB_ENTRY(5, 1, 32, 12, 3, 2, 2, 2, 3, 6, 4, 2, 3, 2, 1),   // 9: 192 -> 1152 -> 192, 3x16 x 2 segments
     MB_ENTRY(3, 1, 32, 12, 3, 2, 2, 2, 3, 10, 4, 2, 3, 2, 1),  // 10: 192 -> 1152 -> 320, 3x16 x 2 segments
+    // 16-channel chunks: a quarter of the LDS, so 2-4 workgroups share a CU and overlap their phases
+    MB_ENTRY(3, 2, 16, 1, 5, 1, 4, 1, 1, 2, 4, 0, 4, 1, 4),    // 11: as 0
+    MB_ENTRY(3, 1, 16, 2, 3, 1, 4, 1, 2, 2, 4, 1, 8, 1, 4),    // 12: as 1
+    MB_ENTRY(5, 2, 16, 2, 7, 1, 4, 1, 1, 3, 4, 0, 4, 1, 3),    // 13: as 2
+    MB_ENTRY(5, 1, 16, 3, 4, 1, 4, 1, 3, 3, 4, 2, 12, 1, 3),   // 14: as 3
+    MB_ENTRY(3, 2, 16, 3, 7, 1, 2, 2, 3, 3, 4, 1, 6, 1, 3),    // 15: as 4
+    MB_ENTRY(3, 1, 16, 5, 3, 1, 4, 1, 3, 5, 5, 2, 6, 1, 2),    // 16: as 5
+    MB_ENTRY(5, 1, 16, 5, 3, 1, 4, 1, 3, 7, 5, 2, 6, 1, 2),    // 17: as 6
+    MB_ENTRY(5, 1, 16, 7, 3, 1, 4, 1, 3, 7, 5, 2, 6, 1, 2),    // 18: as 7
+    MB_ENTRY(5, 2, 16, 7, 3, 1, 1, 4, 3, 3, 4, 0, 3, 1, 2),    // 19: as 8
 };
 constexpr int kNCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
@@ -420,6 +434,22 @@ bool mb_plan(MbDesc &d, int force_cfg) {
         if (mb_try(t, force_cfg) < 0) return false;
         d = t;
         return true;
+    }
+    if (const char *pref = getenv("BIRDA_HIP_MB_PREFER")) {  // tuning aid: first valid entry of a comma list
+        for (const char *q = pref; *q;) {
+            const int ci = atoi(q);
+            MbDesc t = d;
+            if (ci >= 0 && ci < kNCfgs && mb_try(t, ci) >= 0) { d = t; return true; }
+            while (*q && *q != ',') q++;
+            if (*q == ',') q++;
+        }
+    }
+    // measured on MI355X (profiles/): 16-channel chunks win where LDS, not registers, limits
+    // residency (the large-image blocks and the 3x3 6x32 blocks); 32/48-channel chunks elsewhere
+    static const int kPreferred[] = {11, 12, 13, 3, 4, 16, 6, 7, 19, 9, 10};
+    for (int ci : kPreferred) {
+        MbDesc t = d;
+        if (mb_try(t, ci) >= 0) { d = t; return true; }
     }
     double best = -1;
     MbDesc bestd = d;

@@ -151,6 +151,11 @@ BH_API uint64_t bh_tensor_floats(const bh_classifier *c, uint32_t tensor);
 BH_API int bh_batch_context_set_profiling(bh_batch_context *ctx, int enabled);
 BH_API int bh_batch_context_stage_ms(bh_batch_context *ctx, float *ms, uint32_t *launches);
 
+/* Per-launch timing of the last profiled bh_forward_device call, indexed by the layer a launch
+ * starts at (a fused block is booked on its expand layer); slices of one forward are summed and
+ * counted in launches[]. */
+BH_API int bh_batch_context_layer_ms(bh_batch_context *ctx, float *ms, uint32_t *launches, size_t n_layers);
+
 /* Number of expand -> depthwise -> project triples that run as one fused launch; cfgs
  * (nullable) receives the tile configuration index of each.  Environment: BIRDA_HIP_FUSE=0
  * disables fusion, BIRDA_HIP_MB_CFG=<i> forces configuration i where it is valid. */

@@ -354,7 +354,7 @@ def test_every_fused_tile_configuration(model_dir, oracle_lib, monkeypatch):
         blocks = clf.fused_blocks()
         if not blocks:
             clf.close()
-            if cfg >= 11:
+            if cfg >= 20:
                 break
             continue
         assert set(blocks) == {cfg}
@@ -362,4 +362,4 @@ def test_every_fused_tile_configuration(model_dir, oracle_lib, monkeypatch):
         ctx = clf.create_batch_context(4)
         _logit_close(clf.predict_logits(ctx, segs), ref)
         ctx.close(); clf.close()
-    assert used == set(range(11)), used
+    assert used == set(range(20)), used
