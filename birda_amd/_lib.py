@@ -62,7 +62,10 @@ SYMBOLS = [
     ("bh_batch_context_layer_ms", C.c_int, [_VP, _VP, _VP, _SZ]),
     ("bh_classifier_fused_blocks", C.c_int, [_VP, _VP, _SZ]),
     ("bh_debug_mb_stamps", C.c_int, [_VP, _VP, _SZ]),
+    ("bh_predict_batch_source_rate", C.c_int, [_VP, _VP, C.POINTER(_VP), _SZ, _SZ, C.c_uint32, C.POINTER(BhResult)]),
     ("bh_resample", C.c_int, [_VP, _VP, _SZ, C.c_uint32, C.c_uint32, _VP, _SZ, C.POINTER(_SZ)]),
+    ("bh_resample_output_len", C.c_int, [_SZ, C.c_uint32, C.c_uint32, C.POINTER(_SZ)]),
+    ("bh_resample_device", C.c_int, [_VP, _VP, _VP, _SZ, _SZ, C.c_uint32, C.c_uint32, _VP, _SZ, _SZ, _SZ]),
 ]
 
 

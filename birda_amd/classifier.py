@@ -197,6 +197,21 @@ class BirdClassifier:
         check(self._L.bh_forward_device(self._h, ctx._h, d_segments, n, d_logits, d_topk_index or None,
                                         d_topk_conf or None))
 
+    # ---- resampler (reference src/audio/resample.rs:10-105) ----
+    def resample(self, samples: np.ndarray, from_rate: int, to_rate: int) -> np.ndarray:
+        x = np.ascontiguousarray(samples, np.float32)
+        n_out = C.c_size_t()
+        check(self._L.bh_resample_output_len(x.size, from_rate, to_rate, C.byref(n_out)))
+        out = np.empty(max(int(n_out.value), 1), np.float32)
+        got = C.c_size_t()
+        check(self._L.bh_resample(self._h, x.ctypes.data, x.size, from_rate, to_rate, out.ctypes.data, out.size, C.byref(got)))
+        return out[: int(got.value)]
+
+    def resample_device(self, ctx: BatchInferenceContext, d_in: int, in_stride: int, src_len: int, from_rate: int,
+                        to_rate: int, d_out: int, out_stride: int, out_len: int, n_seg: int):
+        check(self._L.bh_resample_device(self._h, ctx._h, d_in, in_stride, src_len, from_rate, to_rate, d_out,
+                                         out_stride, out_len, n_seg))
+
     def read_tensor(self, ctx: BatchInferenceContext, tensor: int, n: int) -> np.ndarray:
         nfl = int(self._L.bh_tensor_floats(self._h, tensor))
         out = np.empty((n, nfl), np.float32)

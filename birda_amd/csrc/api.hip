@@ -84,6 +84,9 @@ struct bh_batch_context {
     int32_t *d_topk_idx = nullptr;
     float *d_topk_conf = nullptr;
     float *h_input = nullptr;    // pinned staging
+    float *d_raw = nullptr;      // source-rate segments awaiting the resampler [max_batch][raw_len]
+    float *h_raw = nullptr;
+    size_t raw_len = 0;
     int32_t *h_topk_idx = nullptr;
     float *h_topk_conf = nullptr;
     size_t device_bytes = 0;
@@ -259,6 +262,7 @@ void ctx_destroy(bh_batch_context *ctx) {
     (void)hipFree(ctx->d_input); (void)hipFree(ctx->d_minmax); (void)hipFree(ctx->d_arena);
     (void)hipFree(ctx->d_logits); (void)hipFree(ctx->d_topk_idx); (void)hipFree(ctx->d_topk_conf);
     (void)hipHostFree(ctx->h_input); (void)hipHostFree(ctx->h_topk_idx); (void)hipHostFree(ctx->h_topk_conf);
+    (void)hipFree(ctx->d_raw); (void)hipHostFree(ctx->h_raw);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -775,8 +779,118 @@ int bh_batch_context_stage_ms(bh_batch_context *ctx, float *ms, uint32_t *launch
     return BH_OK;
 }
 
-int bh_resample(bh_classifier *, const float *, size_t, uint32_t, uint32_t, float *, size_t, size_t *) {
-    return fail(BH_ERR_UNSUPPORTED, "bh_resample: HIP resampler not built in this revision");
+int bh_predict_batch_source_rate(bh_classifier *c, bh_batch_context *ctx, const float *const *segments, size_t n,
+                                 size_t n_src_samples, uint32_t source_rate, bh_result *out) {
+    if (!c || !segments || !out) return fail(BH_ERR_INVALID, "predict_batch_source_rate: null argument");
+    if (n == 0) return BH_OK;
+    const auto &h = c->model.h;
+    if (source_rate == h.sample_rate) {
+        if (ctx) return bh_predict_batch_with_context(c, ctx, segments, n, n_src_samples, out);
+        return bh_predict_batch(c, segments, n, n_src_samples, out);
+    }
+    std::unique_lock<std::mutex> lock(c->internal_mu, std::defer_lock);
+    if (!ctx) {
+        lock.lock();
+        int rc0 = internal_ctx(c, n, &ctx);
+        if (rc0 != BH_OK) return rc0;
+    } else {
+        int rc0 = check_ctx(c, ctx);
+        if (rc0 != BH_OK) return rc0;
+        if (n > ctx->max_batch) return fail(BH_ERR_INVALID, "batch of %zu exceeds context capacity %zu", n, ctx->max_batch);
+    }
+    HIPCHK(hipSetDevice(c->device));
+    if (ctx->raw_len < n_src_samples) {
+        (void)hipFree(ctx->d_raw); (void)hipHostFree(ctx->h_raw);
+        ctx->d_raw = nullptr; ctx->h_raw = nullptr; ctx->raw_len = 0;
+        HIPCHK(hipMalloc((void **)&ctx->d_raw, ctx->max_batch * n_src_samples * sizeof(float)));
+        HIPCHK(hipHostMalloc((void **)&ctx->h_raw, ctx->max_batch * n_src_samples * sizeof(float), hipHostMallocDefault));
+        ctx->raw_len = n_src_samples;
+    }
+    for (size_t b0 = 0; b0 < n; b0 += ctx->max_batch) {
+        const size_t nb = std::min(ctx->max_batch, n - b0);
+        for (size_t i = 0; i < nb; i++) {
+            if (!segments[b0 + i]) return fail(BH_ERR_INVALID, "segment %zu is null", b0 + i);
+            memcpy(ctx->h_raw + i * n_src_samples, segments[b0 + i], n_src_samples * sizeof(float));
+        }
+        HIPCHK(hipMemcpyAsync(ctx->d_raw, ctx->h_raw, nb * n_src_samples * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        // resample_chunk + resize(segment_samples, 0.0) per segment (processor.rs:86-87), on device
+        int rc = bh_resample_device(c, ctx, ctx->d_raw, n_src_samples, n_src_samples, source_rate, h.sample_rate,
+                                    ctx->d_input, h.sample_count, h.sample_count, nb);
+        if (rc != BH_OK) return rc;
+        rc = forward_slice(c, ctx, ctx->d_input, nb, ctx->d_logits, ctx->d_topk_idx, ctx->d_topk_conf);
+        if (rc != BH_OK) return rc;
+        HIPCHK(hipMemcpyAsync(ctx->h_topk_idx, ctx->d_topk_idx, nb * c->top_k * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(ctx->h_topk_conf, ctx->d_topk_conf, nb * c->top_k * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < nb; i++) {
+            bh_result &r = out[b0 + i];
+            r.n_pred = 0;
+            for (uint32_t k = 0; k < c->top_k; k++) {
+                const int32_t id = ctx->h_topk_idx[i * c->top_k + k];
+                if (id < 0) break;
+                r.index[r.n_pred] = id;
+                r.confidence[r.n_pred] = ctx->h_topk_conf[i * c->top_k + k];
+                r.n_pred++;
+            }
+        }
+    }
+    return BH_OK;
+}
+
+int bh_resample_output_len(size_t n_in, uint32_t from_rate, uint32_t to_rate, size_t *n_out) {
+    if (!n_out || from_rate == 0 || to_rate == 0) return fail(BH_ERR_INVALID, "resample_output_len: bad arguments");
+    *n_out = bh::resample_output_len(n_in, from_rate, to_rate);
+    return BH_OK;
+}
+
+int bh_resample_device(bh_classifier *c, bh_batch_context *ctx, const float *d_in, size_t in_stride, size_t src_len,
+                       uint32_t from_rate, uint32_t to_rate, float *d_out, size_t out_stride, size_t out_len,
+                       size_t n_seg) {
+    int rc = check_ctx(c, ctx);
+    if (rc != BH_OK) return rc;
+    if (!d_in || !d_out || from_rate == 0 || to_rate == 0 || src_len > in_stride || out_len > out_stride)
+        return fail(BH_ERR_INVALID, "resample_device: bad arguments");
+    if (n_seg == 0) return BH_OK;
+    HIPCHK(hipSetDevice(c->device));
+    if (from_rate == to_rate) {  // resample.rs:11-13: identity; then resize(segment_samples, 0.0)
+        const size_t ncopy = std::min(src_len, out_len);
+        HIPCHK(hipMemcpy2DAsync(d_out, out_stride * sizeof(float), d_in, in_stride * sizeof(float), ncopy * sizeof(float),
+                                n_seg, hipMemcpyDeviceToDevice, ctx->stream));
+        if (out_len > ncopy)
+            HIPCHK(hipMemset2DAsync(d_out + ncopy, out_stride * sizeof(float), 0, (out_len - ncopy) * sizeof(float), n_seg,
+                                    ctx->stream));
+        return BH_OK;
+    }
+    const char *err = nullptr;
+    const bh::ResamplePlan *pl = bh::resample_plan(from_rate, to_rate, &err);
+    if (!pl) return fail(BH_ERR_UNSUPPORTED, "%s (%u -> %u Hz)", err ? err : "resampler", from_rate, to_rate);
+    bh::launch_resample(*pl, d_in, in_stride, (int)src_len, d_out, out_stride, (int)out_len, (int)n_seg, ctx->stream);
+    HIPCHK(hipGetLastError());
+    return BH_OK;
+}
+
+int bh_resample(bh_classifier *c, const float *in, size_t n_in, uint32_t from_rate, uint32_t to_rate, float *out,
+                size_t out_cap, size_t *n_out) {
+    if (!c || !in || !out || !n_out) return fail(BH_ERR_INVALID, "resample: null argument");
+    const size_t need = bh::resample_output_len(n_in, from_rate, to_rate);
+    if (need > out_cap) return fail(BH_ERR_INVALID, "resample: output buffer too small (%zu < %zu)", out_cap, need);
+    *n_out = need;
+    if (need == 0) return BH_OK;
+    HIPCHK(hipSetDevice(c->device));
+    std::lock_guard<std::mutex> g(c->internal_mu);
+    bh_batch_context *ctx = nullptr;
+    int rc = internal_ctx(c, 1, &ctx);
+    if (rc != BH_OK) return rc;
+    float *d_in = nullptr, *d_out = nullptr;
+    HIPCHK(hipMalloc((void **)&d_in, n_in * sizeof(float)));
+    if (hipMalloc((void **)&d_out, need * sizeof(float)) != hipSuccess) { (void)hipFree(d_in); return fail(BH_ERR_HIP, "resample: hipMalloc failed"); }
+    rc = BH_OK;
+    if (hipMemcpyAsync(d_in, in, n_in * sizeof(float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = fail(BH_ERR_HIP, "resample: H2D failed");
+    if (rc == BH_OK) rc = bh_resample_device(c, ctx, d_in, n_in, n_in, from_rate, to_rate, d_out, need, need, 1);
+    if (rc == BH_OK && hipMemcpyAsync(out, d_out, need * sizeof(float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = fail(BH_ERR_HIP, "resample: D2H failed");
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == BH_OK) rc = fail(BH_ERR_HIP, "resample: stream sync failed");
+    (void)hipFree(d_in); (void)hipFree(d_out);
+    return rc;
 }
 
 }  // extern "C"

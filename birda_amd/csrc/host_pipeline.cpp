@@ -412,9 +412,8 @@ int bhh_process_file(bh_classifier *clf, const bhh_processing_config *cfg, bhh_p
 
     if (segment_samples != info.sample_count)
         return hfail(BH_ERR_INVALID, "segment_duration * sample_rate != model sample_count");
-    if (source_rate != target_rate)
-        return hfail(BH_ERR_UNSUPPORTED, "source rate " + std::to_string(source_rate) + " != model rate " + std::to_string(target_rate) +
-                                             ": the HIP resampler is not built in this revision (no CPU resampling path exists)");
+    const bool resampling = source_rate != target_rate;   // raw source-rate segments go to the device resampler
+    const size_t src_segment_samples = bhh_source_samples(segment_samples, source_rate, target_rate);
 
     rc = bh_classifier_ensure_warm(clf, effective);                                          // :577
     if (rc != BH_OK) return hfail(rc, bh_last_error());
@@ -438,8 +437,10 @@ int bhh_process_file(bh_classifier *clf, const bhh_processing_config *cfg, bhh_p
         size_t start_sample = 0;
         while ((r = bhh_decoder_next_segment(dec, src_seg, src_ovl, raw.data(), &start_sample)) == 1) {  // :84
             AudioChunk c;
-            c.samples.assign(raw.begin(), raw.end());   // rates equal: resample_chunk is the identity (resample.rs:98-100)
-            c.samples.resize(segment_samples, 0.0f);    // :87
+            // equal rates: resample_chunk is the identity (resample.rs:98-100) and resize pads (:87);
+            // otherwise the raw segment travels on and both steps run on the device (bh_resample_device)
+            c.samples.assign(raw.begin(), raw.end());
+            if (source_rate == target_rate) c.samples.resize(segment_samples, 0.0f);
             c.start_time = (float)start_sample / (float)source_rate;                         // :91
             const float seg_dur = (float)segment_samples / (float)target_rate;               // :93
             c.end_time = c.start_time + seg_dur;                                             // :94
@@ -464,14 +465,15 @@ int bhh_process_file(bh_classifier *clf, const bhh_processing_config *cfg, bhh_p
         std::vector<const float *> segs;
         for (auto &c : b) segs.push_back(c.samples.data());
         if (valid < effective) {                                                             // :240-258
-            if (padding.empty()) padding.assign(info.sample_count, 0.0f);
+            if (padding.empty()) padding.assign(resampling ? src_segment_samples : (size_t)info.sample_count, 0.0f);
             res->padded_rows += effective - valid;
             while (segs.size() < effective) segs.push_back(padding.data());
         }
         const size_t bs = segs.size();
         void *guard = bhh_watchdog_start(watchdog_timeout_secs() * 1000, bs);                // :263-266
         int r;
-        if (bs == 1) r = bh_predict(clf, segs[0], info.sample_count, &results[0]);            // :269-277
+        if (resampling) r = bh_predict_batch_source_rate(clf, ctx, segs.data(), bs, src_segment_samples, source_rate, results.data());
+        else if (bs == 1) r = bh_predict(clf, segs[0], info.sample_count, &results[0]);       // :269-277
         else if (ctx) r = bh_predict_batch_with_context(clf, ctx, segs.data(), bs, info.sample_count, results.data());
         else r = bh_predict_batch(clf, segs.data(), bs, info.sample_count, results.data());
         bhh_watchdog_cancel(guard);

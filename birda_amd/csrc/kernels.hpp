@@ -79,6 +79,21 @@ void launch_gap(const float *in, float *out, int n_seg, int P, int C, hipStream_
 void launch_topk(const float *logits, int n_seg, int n_classes, int out_act, int top_k, float min_conf,
                  int32_t *idx, float *conf, hipStream_t s);
 
+// Polyphase resampler (resample.hip): rubato's FFT resampler as one dense operator on the MFMA.
+struct ResamplePlan {
+    uint32_t from, to;
+    int hop, N, nblk, K, dmin;  // y[N m + p] = sum_{k < K} x[hop m + dmin + k] G[k][p]
+    const float *d_op;          // device, fragment-major [nblk][K/16][10][64][4]
+};
+void resample_sizes(uint32_t from, uint32_t to, int *fft_in, int *fft_out);
+size_t resample_output_len(size_t n, uint32_t from, uint32_t to);  // rubato's output length for n inputs
+const ResamplePlan *resample_plan(uint32_t from, uint32_t to, const char **err);
+// d_in [n_seg][in_stride] (src_len valid samples each) -> d_out [n_seg][out_stride]: the first
+// min(out_len, rubato length) samples are the resampled signal, the rest up to out_len zeros
+// (`samples.resize(segment_samples, 0.0)`, reference src/pipeline/processor.rs:87)
+void launch_resample(const ResamplePlan &pl, const float *d_in, size_t in_stride, int src_len, float *d_out,
+                     size_t out_stride, int out_len, int n_seg, hipStream_t s);
+
 // Fused MBConv block (kernels_mbconv.hip): expand 1x1 -> depthwise -> project 1x1 (+ residual).
 struct MbDesc {
     const float *X, *R;  // input NHWC [n][H][W][Cin]; residual (nullable) shaped like Y

@@ -393,9 +393,9 @@ const MbCfg kCfgs[] = {
 };
 constexpr int kNCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
-// fills the derived fields for entry `ci`; returns the estimated MFMA work per segment (in
-// 16x16x4 steps), or -1 when the entry cannot run this block
-double mb_try(MbDesc &d, int ci) {
+// fills the derived fields for entry `ci` with tile height `th`; returns the estimated MFMA work
+// per segment (in 16x16x4 steps), or -1 when the entry cannot run this block at that height
+double mb_try_th(MbDesc &d, int ci, int th) {
     const MbCfg &c = kCfgs[ci];
     if (c.KS != d.KS || c.ST != d.ST || d.Cexp % c.CE || d.Cin % 4 || d.Cexp % 4) return -1;
     if ((d.Cin + 15) / 16 != c.KG) return -1;
@@ -403,15 +403,16 @@ double mb_try(MbDesc &d, int ci) {
     const int nto = (d.Cout + 15) / 16;
     if (nto > c.WN * c.NT_W) return -1;
     const int TW = 1 << c.TWL;
+    const int ces = c.CE + 4, pout_pad = c.WM * c.MT_W * 16;
+    if (th < 1 || c.S * th * TW > pout_pad) return -1;
     MbDesc t = d;
-    t.cfg = ci; t.TH = c.TH; t.S = c.S;
-    t.tiles_y = (d.Ho + c.TH - 1) / c.TH; t.tiles_x = (d.Wo + TW - 1) / TW;
-    t.IH = (c.TH - 1) * c.ST + c.KS; t.IW = (TW - 1) * c.ST + c.KS;
+    t.cfg = ci; t.TH = th; t.S = c.S;
+    t.tiles_y = (d.Ho + th - 1) / th; t.tiles_x = (d.Wo + TW - 1) / TW;
+    t.IH = (th - 1) * c.ST + c.KS; t.IW = (TW - 1) * c.ST + c.KS;
     t.KG = (d.Cin + 15) / 16; t.nchunks = d.Cexp / c.CE; t.NTOP = c.WN * c.NT_W; t.CE = c.CE;
     const int mseg = std::min(t.IH, d.H) * std::min(t.IW, d.W);
     t.mpad_max = (c.S * mseg + 15) / 16 * 16;
     if (t.mpad_max / 16 > c.RT_W * (4 / c.NCS)) return -1;  // a wave keeps all its rows of X in registers
-    const int ces = c.CE + 4, pout_pad = c.WM * c.MT_W * 16;
     const size_t we_fl = (size_t)c.KG * (c.CE / 16) * 256 + c.CE, wp_fl = (size_t)(c.CE / 16) * t.NTOP * 256;
     const size_t wd_fl = (size_t)c.KS * c.KS * c.CE + c.CE;
     t.lds_bytes = (((size_t)c.S * t.IH * t.IW + 1) * ces + (size_t)pout_pad * ces + we_fl + wp_fl + wd_fl) * 4 +
@@ -420,6 +421,16 @@ double mb_try(MbDesc &d, int ci) {
     d = t;
     const double tiles = (double)t.tiles_y * t.tiles_x / c.S;
     return tiles * ((double)t.mpad_max / 16 * t.KG * 4 * (d.Cexp / 16) + (double)pout_pad / 16 * t.NTOP * (d.Cexp / 4));
+}
+
+// the entry's own tile height if it fits this block's image, else the tallest one that does
+double mb_try(MbDesc &d, int ci) {
+    for (int th = std::min(kCfgs[ci].TH, std::max(d.Ho, 1)); th >= 1; th--) {
+        MbDesc t = d;
+        const double w = mb_try_th(t, ci, th);
+        if (w >= 0) { d = t; return w; }
+    }
+    return -1;
 }
 
 }  // namespace
@@ -447,9 +458,9 @@ bool mb_plan(MbDesc &d, int force_cfg) {
     // measured on MI355X (profiles/): 16-channel chunks win where LDS, not registers, limits
     // residency (the large-image blocks and the 3x3 6x32 blocks); 32/48-channel chunks elsewhere
     static const int kPreferred[] = {11, 12, 13, 3, 4, 16, 6, 7, 19, 9, 10};
-    for (int ci : kPreferred) {
+    for (int ci : kPreferred) {  // at the entry's own tile height: the shapes it was measured on
         MbDesc t = d;
-        if (mb_try(t, ci) >= 0) { d = t; return true; }
+        if (mb_try_th(t, ci, kCfgs[ci].TH) >= 0) { d = t; return true; }
     }
     double best = -1;
     MbDesc bestd = d;

@@ -166,10 +166,29 @@ BH_API int bh_classifier_fused_blocks(const bh_classifier *c, int32_t *cfgs, siz
  * last call.  Returns the number of blocks written (8 values each). */
 BH_API int bh_debug_mb_stamps(bh_classifier *c, uint64_t *out, size_t cap);
 
-/* ---- resampler (reference src/audio/resample.rs:10-105; rubato Fft, FixedSync::Both) -- */
-/* host in / host out convenience: returns output length via *n_out */
+/* decode_and_stream + process_batch for source-rate input (processor.rs:84-87, 220-277): every
+ * slice holds n_src_samples = ceil(sample_count * source_rate / sample_rate) samples at
+ * source_rate; they are uploaded as they are, resampled and resized to sample_count on the device,
+ * and classified.  ctx may be NULL (internal context).  Equal rates forward to predict_batch. */
+BH_API int bh_predict_batch_source_rate(bh_classifier *c, bh_batch_context *ctx, const float *const *segments,
+                                        size_t n, size_t n_src_samples, uint32_t source_rate, bh_result *out);
+
+/* ---- resampler (reference src/audio/resample.rs:10-105; rubato Fft<f32>, FixedSync::Both,
+ * chunk 1024, one new resampler per segment).  The device kernel applies rubato's block
+ * operator as a polyphase GEMM (birda_amd/csrc/resample.hip); identity when the rates are equal.
+ * Tolerance vs the block-FFT restatement in the oracle: 2e-5 absolute on |x| <= 1 inputs. */
+/* resample(samples, from, to) -> Vec<f32> (resample.rs:10-91): host in, host out */
 BH_API int bh_resample(bh_classifier *c, const float *in, size_t n_in, uint32_t from_rate,
                        uint32_t to_rate, float *out, size_t out_cap, size_t *n_out);
+/* the length resample() returns for n_in input samples (whole blocks + ceil of the tail, :58-88) */
+BH_API int bh_resample_output_len(size_t n_in, uint32_t from_rate, uint32_t to_rate, size_t *n_out);
+/* decode_and_stream's per-segment step for a batch (processor.rs:84-87): every row of d_in
+ * [n_seg][in_stride] holds src_len source-rate samples of one raw segment; row i of d_out
+ * [n_seg][out_stride] receives resample_chunk(..) followed by resize(out_len, 0.0).  Enqueued on
+ * the context stream; d_out may be passed straight to bh_forward_device. */
+BH_API int bh_resample_device(bh_classifier *c, bh_batch_context *ctx, const float *d_in, size_t in_stride,
+                              size_t src_len, uint32_t from_rate, uint32_t to_rate, float *d_out,
+                              size_t out_stride, size_t out_len, size_t n_seg);
 
 #ifdef __cplusplus
 }

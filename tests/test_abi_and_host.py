@@ -219,3 +219,14 @@ def test_watchdog_cancelled_when_dropped(L, monkeypatch):
     for v, want in (("25", 25), ("0", 10), ("3601", 10), ("abc", 10), ("3600", 3600), ("1", 1)):
         monkeypatch.setenv("BIRDA_INFERENCE_TIMEOUT", v)
         assert L.bhh_watchdog_timeout_secs() == want    # processor.rs:205-211
+
+
+def test_resample_output_length_matches_the_block_rule(L, oracle_lib):
+    """whole blocks + ceil(remaining * to / from) (reference src/audio/resample.rs:34-88); no GPU needed."""
+    import ctypes as C
+    for frm, to in ((44100, 48000), (22050, 48000), (48000, 32000), (44100, 32000), (48000, 48000)):
+        for n in (0, 1, 500, 1026, 1029, 1030, 66150, 132300, 144000, 240000):
+            out = C.c_size_t()
+            assert L.bh_resample_output_len(n, frm, to, C.byref(out)) == 0
+            want = len(oracle_lib.resample(np.zeros(n, np.float32), frm, to)) if n else 0
+            assert out.value == want, (frm, to, n)

@@ -363,3 +363,29 @@ def test_every_fused_tile_configuration(model_dir, oracle_lib, monkeypatch):
         _logit_close(clf.predict_logits(ctx, segs), ref)
         ctx.close(); clf.close()
     assert used == set(range(20)), used
+
+
+# ---- C4: Perch-shaped model (5 s / 32 kHz, one 128-mel branch, 14 795 classes, softmax) --------
+def test_perch_shaped_model_matches_oracle(oracle_lib, tmp_path):
+    from birda_amd import modelfile as mf, synth
+    from birda_amd.classifier import BirdClassifier
+    m = synth.build_model("perch_v2")
+    path = str(tmp_path / "perch.bhm")
+    mf.write_model(path, m)
+    assert (m.sample_rate, m.sample_count, m.n_classes) == (32000, 160000, 14795)
+    segs = synth.synth_segments(3, m.sample_count, m.sample_rate, start=5)
+    clf = BirdClassifier(path, None, top_k=5, min_confidence=0.0)
+    assert clf.sample_rate() == 32000 and clf.sample_count() == 160000 and abs(clf.segment_duration() - 5.0) < 1e-6
+    print("perch-shaped fused blocks:", clf.fused_blocks())
+    assert len(clf.fused_blocks()) >= 8       # blocks whose tiles do not fit a configuration run layer by layer
+    ctx = clf.create_batch_context(4)
+    logits = clf.predict_logits(ctx, segs)
+    ref = oracle_lib.OracleModel(path).forward(segs)
+    err = _logit_close(logits, ref)
+    print(f"perch-shaped max|dlogit| = {err:.3e} on max|logit| {np.abs(ref).max():.2f}")
+    res = clf.predict_batch_with_context(ctx, list(segs))
+    for i, r in enumerate(res):                      # softmax confidences of the kept top-5
+        idx, conf = oracle_lib.topk(ref[i], 2, 5, 0.0)
+        assert len(r.predictions) == 5
+        assert np.allclose([p.confidence for p in r.predictions], conf, rtol=2e-3, atol=1e-7)
+    ctx.close(); clf.close()
