@@ -195,26 +195,40 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                 for (int ii = 0; ii < RG; ii++)
 #pragma unroll
                     for (int j = 0; j < NT_U; j++) acc[ii][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (!(d.dbg & 8))
-#pragma unroll
-                for (int g = 0; g < KG; g++) {
-                    float4 bv[NT_U];
+                if (!(d.dbg & 8)) {
+                    // B fragments double-buffered by hand, and a scheduling fence per k group: left
+                    // alone, hipcc hoists every group's LDS loads to the top of the unrolled loop and
+                    // spills the resident A fragments
+                    float4 bv[NT_U], bn[NT_U];
 #pragma unroll
                     for (int j = 0; j < NT_U; j++)
-                        bv[j] = *reinterpret_cast<const float4 *>(&WeS[((g * NT_E + cs * NT_U + j) * 64 + lane) * 4]);
+                        bv[j] = *reinterpret_cast<const float4 *>(&WeS[((cs * NT_U + j) * 64 + lane) * 4]);
 #pragma unroll
-                    for (int c = 0; c < 4; c++)
+                    for (int g = 0; g < KG; g++) {
+                        if (g + 1 < KG) {
 #pragma unroll
-                        for (int ii = 0; ii < RG; ii++) {
-                            if (i0 + ii >= RT_W) continue;
-                            const float4 av = afr[i0 + ii < RT_W ? i0 + ii : 0][g];
-                            const float a = c == 0 ? av.x : c == 1 ? av.y : c == 2 ? av.z : av.w;
-#pragma unroll
-                            for (int j = 0; j < NT_U; j++) {
-                                const float b = c == 0 ? bv[j].x : c == 1 ? bv[j].y : c == 2 ? bv[j].z : bv[j].w;
-                                acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[ii][j], 0, 0, 0);
-                            }
+                            for (int j = 0; j < NT_U; j++)
+                                bn[j] = *reinterpret_cast<const float4 *>(&WeS[(((g + 1) * NT_E + cs * NT_U + j) * 64 + lane) * 4]);
                         }
+#pragma unroll
+                        for (int c = 0; c < 4; c++)
+#pragma unroll
+                            for (int ii = 0; ii < RG; ii++) {
+                                if (i0 + ii >= RT_W) continue;
+                                const float4 av = afr[i0 + ii < RT_W ? i0 + ii : 0][g];
+                                const float a = c == 0 ? av.x : c == 1 ? av.y : c == 2 ? av.z : av.w;
+#pragma unroll
+                                for (int j = 0; j < NT_U; j++) {
+                                    const float b = c == 0 ? bv[j].x : c == 1 ? bv[j].y : c == 2 ? bv[j].z : bv[j].w;
+                                    acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[ii][j], 0, 0, 0);
+                                }
+                            }
+                        if (g + 1 < KG) {
+#pragma unroll
+                            for (int j = 0; j < NT_U; j++) bv[j] = bn[j];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
 #pragma unroll
                 for (int ii = 0; ii < RG; ii++) {
@@ -271,6 +285,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                             acc[x].x += ev.x * w.x; acc[x].y += ev.y * w.y; acc[x].z += ev.z * w.z; acc[x].w += ev.w * w.w;
                         }
                     }
+                    __builtin_amdgcn_sched_barrier(0);  // keep one kernel row of loads in flight, not all KS
                 }
 #pragma unroll
                 for (int x = 0; x < XB; x++) {
@@ -290,14 +305,20 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
         // ---- P3: project -----------------------------------------------------------------
         if (!(d.dbg & 4)) {
             const float *dsb = Ds + ((wm * MT_W) * 16 + li) * CES + 4 * kq;
+            float4 a[MT_W], b[NT_W], an[MT_W], bn[NT_W];
+#pragma unroll
+            for (int j = 0; j < NT_W; j++) b[j] = *reinterpret_cast<const float4 *>(&WpS[((wn * NT_W + j) * 64 + lane) * 4]);
+#pragma unroll
+            for (int i = 0; i < MT_W; i++) a[i] = *reinterpret_cast<const float4 *>(dsb + i * 16 * CES);
 #pragma unroll
             for (int g = 0; g < NT_E; g++) {
-                float4 a[MT_W], b[NT_W];
+                if (g + 1 < NT_E) {
 #pragma unroll
-                for (int j = 0; j < NT_W; j++)
-                    b[j] = *reinterpret_cast<const float4 *>(&WpS[((g * NTOP + wn * NT_W + j) * 64 + lane) * 4]);
+                    for (int j = 0; j < NT_W; j++)
+                        bn[j] = *reinterpret_cast<const float4 *>(&WpS[(((g + 1) * NTOP + wn * NT_W + j) * 64 + lane) * 4]);
 #pragma unroll
-                for (int i = 0; i < MT_W; i++) a[i] = *reinterpret_cast<const float4 *>(dsb + i * 16 * CES + 16 * g);
+                    for (int i = 0; i < MT_W; i++) an[i] = *reinterpret_cast<const float4 *>(dsb + i * 16 * CES + 16 * (g + 1));
+                }
 #pragma unroll
                 for (int c = 0; c < 4; c++)
 #pragma unroll
@@ -309,6 +330,13 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                             acco[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acco[i][j], 0, 0, 0);
                         }
                     }
+                if (g + 1 < NT_E) {
+#pragma unroll
+                    for (int j = 0; j < NT_W; j++) b[j] = bn[j];
+#pragma unroll
+                    for (int i = 0; i < MT_W; i++) a[i] = an[i];
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         mb_stamp(d.stamps, t_last, 6);
@@ -382,8 +410,8 @@ const MbCfg kCfgs[] = {
     MB_ENTRY(3, 1, 32, 12, 3, 2, 2, 2, 3, 10, 4, 2, 3, 2, 1),  // 10: 192 -> 1152 -> 320, 3x16 x 2 segments
     // 16-channel chunks: a quarter of the LDS, so 2-4 workgroups share a CU and overlap their phases
     MB_ENTRY(3, 2, 16, 1, 5, 1, 4, 1, 1, 2, 4, 0, 4, 1, 4),    // 11: as 0
-    MB_ENTRY(3, 1, 16, 2, 3, 1, 4, 1, 2, 2, 4, 1, 8, 1, 4),    // 12: as 1
-    MB_ENTRY(5, 2, 16, 2, 7, 1, 4, 1, 1, 3, 4, 0, 4, 1, 3),    // 13: as 2
+    MB_ENTRY(3, 1, 16, 2, 3, 1, 4, 1, 2, 2, 4, 1, 8, 1, 3),    // 12: as 1
+    MB_ENTRY(5, 2, 16, 2, 7, 1, 4, 1, 1, 3, 4, 0, 4, 1, 2),    // 13: as 2
     MB_ENTRY(5, 1, 16, 3, 4, 1, 4, 1, 3, 3, 4, 2, 12, 1, 3),   // 14: as 3
     MB_ENTRY(3, 2, 16, 3, 7, 1, 2, 2, 3, 3, 4, 1, 6, 1, 3),    // 15: as 4
     MB_ENTRY(3, 1, 16, 5, 3, 1, 4, 1, 3, 5, 5, 2, 6, 1, 2),    // 16: as 5
