@@ -404,12 +404,18 @@ int plan_fusion(bh_classifier *c) {
     readers[m.h.embedding_tensor]++;
     for (size_t i = 0; i + 2 < nl; i++) {
         const auto &E = m.layers[i], &D = m.layers[i + 1], &P = m.layers[i + 2];
-        if (E.op != bh::OP_PWCONV || D.op != bh::OP_DWCONV || P.op != bh::OP_PWCONV) continue;
+        const bool stem = E.op == bh::OP_CONV && E.in_layout == 1 && E.kh == E.kw && E.sh == E.sw && E.in_tensor == 0;
+        if ((E.op != bh::OP_PWCONV && !stem) || D.op != bh::OP_DWCONV || P.op != bh::OP_PWCONV) continue;
         if (D.in_tensor != i + 1 || P.in_tensor != i + 2 || readers[i + 1] != 1 || readers[i + 2] != 1) continue;
         if (E.res_tensor != bh::NO_TENSOR || D.res_tensor != bh::NO_TENSOR) continue;
         if (D.kh != D.kw || D.sh != D.sw || E.cout != D.cout || D.cout != P.cin) continue;
         bh::MbDesc d{};
         d.H = (int)E.in_h; d.W = (int)E.in_w; d.Cin = (int)E.cin; d.Cexp = (int)E.cout; d.Cout = (int)P.cout;
+        if (stem) {  // the depthwise conv sees the stem's output image; the stem itself is gathered
+            d.stem = 1; d.stem_c = (int)E.cin; d.stem_h = (int)E.in_h; d.stem_w = (int)E.in_w; d.stem_k = (int)E.kh;
+            d.stem_s = (int)E.sh; d.stem_pt = (int)E.pad_t; d.stem_pl = (int)E.pad_l;
+            d.H = (int)E.out_h; d.W = (int)E.out_w; d.Cin = (int)(E.kh * E.kw * E.cin);
+        }
         d.Ho = (int)D.out_h; d.Wo = (int)D.out_w; d.pad_t = (int)D.pad_t; d.pad_l = (int)D.pad_l;
         d.KS = (int)D.kh; d.ST = (int)D.sh;
         d.act_e = (int)E.act; d.act_d = (int)D.act; d.act_p = (int)P.act;

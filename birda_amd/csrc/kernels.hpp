@@ -107,6 +107,10 @@ struct MbDesc {
     const float *We, *Wd, *Wp, *bp;
     int H, W, Cin, Cexp, Cout, Ho, Wo, pad_t, pad_l, KS, ST;
     int act_e, act_d, act_p;
+    // stem variant (first block): "expand" = the k x k stride-s stem conv gathered from the planar
+    // spectrogram X [n][stem_c][stem_h][stem_w]; then H, W are the stem's OUTPUT size and
+    // Cin = stem_k * stem_k * stem_c im2col columns (We rows in [kh][kw][cin] order)
+    int stem, stem_c, stem_h, stem_w, stem_k, stem_s, stem_pt, stem_pl;
     // diagnostic: 8 phase counters (wave-cycles: setup, dw-weight stage, P1, barrier, P2, barrier, P3,
     // epilogue) or nullptr
     unsigned long long *stamps;

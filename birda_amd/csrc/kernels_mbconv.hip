@@ -89,8 +89,9 @@ __device__ __forceinline__ void mb_dma(const float *gsrc, float *lds_dst, int wa
 __device__ __forceinline__ void mb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <int KS, int ST, int CE, int KG, int RT_W, int NCS, int WM, int WN, int MT_W, int NT_W, int TWL, int XBL,
-          int SS, int OCC>
+          int SS, int OCC, int STEM>
 __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const int n_seg) {
+    static_assert(!STEM || SS == 1, "the stem variant handles one segment per workgroup");
     static_assert(WM * WN == 4, "4 waves");
     constexpr int NT_E = CE / 16, NT_U = NT_E / NCS, CES = CE + 4, C4N = CE / 4, TW = 1 << TWL;
     constexpr int POUT_PAD = WM * MT_W * 16, NTOP = WN * NT_W;
@@ -132,7 +133,8 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
     const int vh = max(yb - ya, 0), vw = max(xb - xa, 0);
     const int Mseg = vh * vw, M = Mseg * nsv, nrt = (M + 15) >> 4;
     const int Cin = d.Cin, Cout = d.Cout, nchunks = d.nchunks;
-    const float *Xb = d.X + (size_t)seg0 * d.H * d.W * Cin;
+    // STEM: X is the planar spectrogram [n][C][SH][SW]; "Cin" = kh*kw*C im2col columns
+    const float *Xb = STEM ? d.X + (size_t)seg0 * d.stem_c * d.stem_h * d.stem_w : d.X + (size_t)seg0 * d.H * d.W * Cin;
     const int rw = wave / NCS, cs = wave - rw * NCS;  // P1: row-tile lane of the wave, column split
     const int wm = wave / WN, wn = wave - wm * WN;    // P3
 
@@ -142,7 +144,8 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
             const int sl = m / Mseg, mm = m - sl * Mseg;
             const int r = mm / vw, c = mm - r * vw;
             e = sl * IH * IW + (ya + r) * IW + xa + c;
-            xo = ((sl * d.H + iy0 + ya + r) * d.W + ix0 + xa + c) * Cin;
+            xo = STEM ? (((iy0 + ya + r) << 16) | (ix0 + xa + c))   // stem-output pixel (y, x), gathered below
+                      : ((sl * d.H + iy0 + ya + r) * d.W + ix0 + xa + c) * Cin;
         }
         emap[m] = e;
         xoff[m] = xo;
@@ -168,11 +171,32 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
     for (int i = 0; i < RT_W; i++) {
         const int rt = rw + RSTEP * i;
         const bool rv = rt < nrt;
-        const float *xp = Xb + (rv ? xoff[rt * 16 + li] : 0) + 4 * kq;
+        if constexpr (STEM) {
+            // im2col gather of the stem conv (k x k, stride s, planar input): column
+            // k = (dy * kw + dx) * C + ch, exactly the row order of the [kh][kw][cin][cout] weights
+            const int pk = rv ? xoff[rt * 16 + li] : 0;
+            const int sy = (pk >> 16) * d.stem_s - d.stem_pt, sx = (pk & 0xffff) * d.stem_s - d.stem_pl;
 #pragma unroll
-        for (int g = 0; g < KG; g++)
-            afr[i][g] = (rv && 16 * g + 4 * kq < Cin) ? *reinterpret_cast<const float4 *>(xp + 16 * g)
-                                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int g = 0; g < KG; g++) {
+                float v[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int k = 16 * g + 4 * kq + c;
+                    const int tap = k / d.stem_c, ch = k - tap * d.stem_c;
+                    const int dy = tap / d.stem_k, dx = tap - dy * d.stem_k;
+                    const int y = sy + dy, x = sx + dx;
+                    const bool ok = rv && k < Cin && y >= 0 && y < d.stem_h && x >= 0 && x < d.stem_w;
+                    v[c] = ok ? Xb[((size_t)ch * d.stem_h + y) * d.stem_w + x] : 0.0f;
+                }
+                afr[i][g] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        } else {
+            const float *xp = Xb + (rv ? xoff[rt * 16 + li] : 0) + 4 * kq;
+#pragma unroll
+            for (int g = 0; g < KG; g++)
+                afr[i][g] = (rv && 16 * g + 4 * kq < Cin) ? *reinterpret_cast<const float4 *>(xp + 16 * g)
+                                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
     mb_stamp(d.stamps, t_last, 0);
 
@@ -372,14 +396,14 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
 }
 
 struct MbCfg {
-    int KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S;
+    int KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM;
     void (*launch)(const MbDesc &, int, hipStream_t);
 };
 
 template <int KS, int ST, int CE, int KG, int RT_W, int NCS, int WM, int WN, int MT_W, int NT_W, int TWL, int XBL,
-          int SS, int OCC>
+          int SS, int OCC, int STEM>
 void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
-    auto kern = mbconv_kernel<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, SS, OCC>;
+    auto kern = mbconv_kernel<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, SS, OCC, STEM>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -389,9 +413,11 @@ void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
     hipLaunchKernelGGL(kern, grid, block, d.lds_bytes, s, d, n_seg);
 }
 
+#define MB_ENTRY_S(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM) \
+    {KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM,                           \
+     mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC, STEM>}
 #define MB_ENTRY(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC) \
-    {KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S,                        \
-     mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC>}
+    MB_ENTRY_S(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, 0)
 
 // The instantiations cover the BirdNET-v2.4 / Perch-shaped stacks (EfficientNet-B0 stages);
 // mb_plan() picks, per block, the valid entry with the least MFMA work.
@@ -412,12 +438,15 @@ const MbCfg kCfgs[] = {
     MB_ENTRY(3, 2, 16, 1, 5, 1, 4, 1, 1, 2, 4, 0, 4, 1, 4),    // 11: as 0
     MB_ENTRY(3, 1, 16, 2, 3, 1, 4, 1, 2, 2, 4, 1, 8, 1, 3),    // 12: as 1
     MB_ENTRY(5, 2, 16, 2, 7, 1, 4, 1, 1, 3, 4, 0, 4, 1, 2),    // 13: as 2
-    MB_ENTRY(5, 1, 16, 3, 4, 1, 4, 1, 3, 3, 4, 2, 12, 1, 3),   // 14: as 3
-    MB_ENTRY(3, 2, 16, 3, 7, 1, 2, 2, 3, 3, 4, 1, 6, 1, 3),    // 15: as 4
+    MB_ENTRY(5, 1, 16, 3, 4, 1, 4, 1, 3, 3, 4, 2, 12, 1, 2),   // 14: as 3
+    MB_ENTRY(3, 2, 16, 3, 7, 1, 2, 2, 3, 3, 4, 1, 6, 1, 2),    // 15: as 4
     MB_ENTRY(3, 1, 16, 5, 3, 1, 4, 1, 3, 5, 5, 2, 6, 1, 2),    // 16: as 5
     MB_ENTRY(5, 1, 16, 5, 3, 1, 4, 1, 3, 7, 5, 2, 6, 1, 2),    // 17: as 6
     MB_ENTRY(5, 1, 16, 7, 3, 1, 4, 1, 3, 7, 5, 2, 6, 1, 2),    // 18: as 7
     MB_ENTRY(5, 2, 16, 7, 3, 1, 1, 4, 3, 3, 4, 0, 3, 1, 2),    // 19: as 8
+    // stem conv (im2col gather from the planar spectrogram) -> depthwise 3x3 -> project: the first block
+    MB_ENTRY_S(3, 1, 16, 2, 3, 1, 4, 1, 2, 1, 4, 1, 8, 1, 3, 1),  // 20: 2-channel spectrogram, 3x3 stem (K = 18)
+    MB_ENTRY_S(3, 1, 16, 1, 3, 1, 4, 1, 2, 1, 4, 1, 8, 1, 3, 1),  // 21: 1-channel spectrogram (K = 9)
 };
 constexpr int kNCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
@@ -425,7 +454,8 @@ constexpr int kNCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 // per segment (in 16x16x4 steps), or -1 when the entry cannot run this block at that height
 double mb_try_th(MbDesc &d, int ci, int th) {
     const MbCfg &c = kCfgs[ci];
-    if (c.KS != d.KS || c.ST != d.ST || d.Cexp % c.CE || d.Cin % 4 || d.Cexp % 4) return -1;
+    if (c.KS != d.KS || c.ST != d.ST || d.Cexp % c.CE || (!d.stem && d.Cin % 4) || d.Cexp % 4) return -1;
+    if ((c.STEM != 0) != (d.stem != 0)) return -1;
     if ((d.Cin + 15) / 16 != c.KG) return -1;
     if (d.act_e != MB_ACT || d.act_d != MB_ACT || d.act_p != ACT_NONE) return -1;
     const int nto = (d.Cout + 15) / 16;
@@ -483,9 +513,9 @@ bool mb_plan(MbDesc &d, int force_cfg) {
             if (*q == ',') q++;
         }
     }
-    // measured on MI355X (profiles/): 16-channel chunks win where LDS, not registers, limits
-    // residency (the large-image blocks and the 3x3 6x32 blocks); 32/48-channel chunks elsewhere
-    static const int kPreferred[] = {11, 12, 13, 3, 4, 16, 6, 7, 19, 9, 10};
+    // measured on MI355X (profiles/): 16-channel chunks (2-4 workgroups per CU) win wherever an
+    // instantiation exists; the 192-channel 3x16 blocks need two column-split waves and stay at 32
+    static const int kPreferred[] = {11, 12, 13, 14, 15, 16, 17, 18, 19, 9, 10, 20, 21};
     for (int ci : kPreferred) {  // at the entry's own tile height: the shapes it was measured on
         MbDesc t = d;
         if (mb_try_th(t, ci, kCfgs[ci].TH) >= 0) { d = t; return true; }

@@ -307,7 +307,7 @@ def test_full_model_runs_every_inverted_residual_block_fused(full_model):
     path, labels, m, _ = full_model
     clf = BirdClassifier(path, labels)
     cfgs = clf.fused_blocks()
-    assert len(cfgs) == 15, cfgs          # EfficientNet-B0: 16 blocks, the first has no expand conv
+    assert len(cfgs) == 16, cfgs          # EfficientNet-B0: 15 inverted-residual blocks + stem/first block
     clf.close()
 
 
@@ -328,7 +328,7 @@ def test_fused_blocks_match_unfused_and_oracle_on_small_images(model_dir, oracle
     _logit_close(unfused, ref)
     monkeypatch.setenv("BIRDA_HIP_FUSE", "1")
     clf = BirdClassifier(path)
-    assert len(clf.fused_blocks()) == 15
+    assert len(clf.fused_blocks()) == 16
     ctx = clf.create_batch_context(8)
     fused = clf.predict_logits(ctx, segs)
     # a context smaller than the batch: slices of 2 (+ odd tail) through the same kernels
@@ -354,7 +354,7 @@ def test_every_fused_tile_configuration(model_dir, oracle_lib, monkeypatch):
         blocks = clf.fused_blocks()
         if not blocks:
             clf.close()
-            if cfg >= 20:
+            if cfg >= 22:
                 break
             continue
         assert set(blocks) == {cfg}
@@ -362,7 +362,7 @@ def test_every_fused_tile_configuration(model_dir, oracle_lib, monkeypatch):
         ctx = clf.create_batch_context(4)
         _logit_close(clf.predict_logits(ctx, segs), ref)
         ctx.close(); clf.close()
-    assert used == set(range(20)), used
+    assert used == set(range(21)), used       # 21 = 1-channel stem: the Perch-shaped test
 
 
 # ---- C4: Perch-shaped model (5 s / 32 kHz, one 128-mel branch, 14 795 classes, softmax) --------
@@ -378,6 +378,7 @@ def test_perch_shaped_model_matches_oracle(oracle_lib, tmp_path):
     assert clf.sample_rate() == 32000 and clf.sample_count() == 160000 and abs(clf.segment_duration() - 5.0) < 1e-6
     print("perch-shaped fused blocks:", clf.fused_blocks())
     assert len(clf.fused_blocks()) >= 8       # blocks whose tiles do not fit a configuration run layer by layer
+    assert 21 in clf.fused_blocks()           # the 1-channel stem variant
     ctx = clf.create_batch_context(4)
     logits = clf.predict_logits(ctx, segs)
     ref = oracle_lib.OracleModel(path).forward(segs)
