@@ -25,6 +25,7 @@
 namespace bh {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -292,9 +293,10 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                 const int tx0 = xbi * XB;
                 const float *eb = Es + ((size_t)sl * IH * IW + (ty * ST) * IW + tx0 * ST) * CES + 4 * c4;
                 const float4 bd4 = *reinterpret_cast<const float4 *>(&bds[4 * c4]);
-                float4 acc[XB];
+                // two-wide vectors so the taps become v_pk_fma_f32 (2 FMAs per instruction)
+                f32x2 acc[XB][2];
 #pragma unroll
-                for (int x = 0; x < XB; x++) acc[x] = bd4;
+                for (int x = 0; x < XB; x++) { acc[x][0] = (f32x2){bd4.x, bd4.y}; acc[x][1] = (f32x2){bd4.z, bd4.w}; }
 #pragma unroll
                 for (int dy = 0; dy < KS; dy++) {
                     float4 e[NCOL];
@@ -303,17 +305,19 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
 #pragma unroll
                     for (int dx = 0; dx < KS; dx++) {
                         const float4 w = *reinterpret_cast<const float4 *>(&Wds[(dy * KS + dx) * CE + 4 * c4]);
+                        const f32x2 w0 = (f32x2){w.x, w.y}, w1 = (f32x2){w.z, w.w};
 #pragma unroll
                         for (int x = 0; x < XB; x++) {
                             const float4 ev = e[x * ST + dx];
-                            acc[x].x += ev.x * w.x; acc[x].y += ev.y * w.y; acc[x].z += ev.z * w.z; acc[x].w += ev.w * w.w;
+                            acc[x][0] = __builtin_elementwise_fma((f32x2){ev.x, ev.y}, w0, acc[x][0]);
+                            acc[x][1] = __builtin_elementwise_fma((f32x2){ev.z, ev.w}, w1, acc[x][1]);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);  // keep one kernel row of loads in flight, not all KS
                 }
 #pragma unroll
                 for (int x = 0; x < XB; x++) {
-                    float4 v = acc[x];
+                    float4 v = make_float4(acc[x][0][0], acc[x][0][1], acc[x][1][0], acc[x][1][1]);
                     v.x = mb_act<MB_ACT>(v.x); v.y = mb_act<MB_ACT>(v.y);
                     v.z = mb_act<MB_ACT>(v.z); v.w = mb_act<MB_ACT>(v.w);
                     *reinterpret_cast<float4 *>(&Ds[(sl * THTW + (ty << TWL) + tx0 + x) * CES + 4 * c4]) = v;
