@@ -10,6 +10,8 @@
 //   y_t[j] = x[tH + j + 1] + x[tH + L - 1 - j]      (j = 0..K-1; last row of Gf halved)
 // and spec_t = Gf^T y_t: a [n_mels x K] x [K x n_frames] GEMM per segment and branch, run on
 // the f32 MFMA (v_mfma_f32_16x16x4_f32, exact f32 fmaf chains).
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace bh {
@@ -83,7 +85,8 @@ template <int MT>
 __global__ __launch_bounds__(256, 2) void mel_kernel(const float *__restrict__ x, const float *__restrict__ mm,
                                                       float *__restrict__ spec, const FrontendParams *__restrict__ pp,
                                                       const float *__restrict__ gf0, const float *__restrict__ gf1,
-                                                      const float *__restrict__ gf2, const float *__restrict__ gf3) {
+                                                      const float *__restrict__ gf2, const float *__restrict__ gf3,
+                                                      const int dbg) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     BranchParams bp = pp->br[blockIdx.y];
     // the operator pointer comes in as a kernel argument (global address space): read through the
@@ -118,21 +121,38 @@ __global__ __launch_bounds__(256, 2) void mel_kernel(const float *__restrict__ x
     // stage the normalised span (16-B loads; the span start t0*H is a multiple of 4 samples)
     const float *xseg = x + (size_t)seg * S;
     const int g0s = t0 * H;
-    for (int i = tid * 4; i < span_pad; i += 256 * 4) {
-        float4 q;
-        if (g0s + i + 3 < S) {
-            q = *reinterpret_cast<const float4 *>(xseg + g0s + i);
-        } else {
-            q.x = (g0s + i + 0 < S) ? xseg[g0s + i + 0] : mn;
-            q.y = (g0s + i + 1 < S) ? xseg[g0s + i + 1] : mn;
-            q.z = (g0s + i + 2 < S) ? xseg[g0s + i + 2] : mn;
-            q.w = (g0s + i + 3 < S) ? xseg[g0s + i + 3] : mn;
+    // batches of 5 independent 16-B loads in flight per thread: issued one at a time (as hipcc
+    // compiles the plain loop) the ~20 HBM round trips of a block ran back to back
+    constexpr int SU = 5;
+    if (!(dbg & 4))
+    for (int i0 = tid * 4; i0 < span_pad; i0 += 256 * 4 * SU) {
+        float4 q[SU];
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+            const int i = i0 + u * 1024;
+            if (i < span_pad) {
+                if (g0s + i + 3 < S) {
+                    q[u] = *reinterpret_cast<const float4 *>(xseg + g0s + i);
+                } else {
+                    q[u].x = (g0s + i + 0 < S) ? xseg[g0s + i + 0] : mn;
+                    q[u].y = (g0s + i + 1 < S) ? xseg[g0s + i + 1] : mn;
+                    q[u].z = (g0s + i + 2 < S) ? xseg[g0s + i + 2] : mn;
+                    q[u].w = (g0s + i + 3 < S) ? xseg[g0s + i + 3] : mn;
+                }
+            }
         }
-        q.x = fmaf(q.x - mn, sc, -1.0f);
-        q.y = fmaf(q.y - mn, sc, -1.0f);
-        q.z = fmaf(q.z - mn, sc, -1.0f);
-        q.w = fmaf(q.w - mn, sc, -1.0f);
-        *reinterpret_cast<float4 *>(xs + i) = q;
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+            const int i = i0 + u * 1024;
+            if (i < span_pad) {
+                float4 v = q[u];
+                v.x = fmaf(v.x - mn, sc, -1.0f);
+                v.y = fmaf(v.y - mn, sc, -1.0f);
+                v.z = fmaf(v.z - mn, sc, -1.0f);
+                v.w = fmaf(v.w - mn, sc, -1.0f);
+                *reinterpret_cast<float4 *>(xs + i) = v;
+            }
+        }
     }
     __syncthreads();
 
@@ -145,16 +165,16 @@ __global__ __launch_bounds__(256, 2) void mel_kernel(const float *__restrict__ x
     const int gpw = K / 64;          // 16-k groups per wave
     const int gbeg = wave * gpw;
     const float4 *gA = reinterpret_cast<const float4 *>(gfp) + lane;
-    float4 a_cur[MT], a_nxt[MT];
+    // Two operator register sets, used alternately (no copies): set B is loaded while set A feeds
+    // the MFMAs and vice versa.  The scheduling fences keep each load a full group (96 MFMAs)
+    // ahead of its use; left to itself hipcc re-loads the operator right in front of the MFMAs.
+    float4 a0[MT], a1[MT];
 #pragma unroll
-    for (int m = 0; m < MT; m++) a_cur[m] = gA[((size_t)gbeg * MT + m) * 64];
+    for (int m = 0; m < MT; m++) a0[m] = gA[((size_t)gbeg * MT + m) * 64];
 
     const float *xf = xs + li * H;   // frame tile f adds f*16*H
-    for (int gi = 0; gi < gpw; gi++) {
-        const int gn = gbeg + min(gi + 1, gpw - 1);
-#pragma unroll
-        for (int m = 0; m < MT; m++) a_nxt[m] = gA[((size_t)gn * MT + m) * 64];
-        const int jb = (gbeg + gi) * 16 + 4 * kq;
+    auto group = [&](int g, const float4 (&a)[MT]) {
+        const int jb = g * 16 + 4 * kq;
         float b[4][4];
 #pragma unroll
         for (int c = 0; c < 4; c++)
@@ -165,13 +185,25 @@ __global__ __launch_bounds__(256, 2) void mel_kernel(const float *__restrict__ x
         for (int c = 0; c < 4; c++)
 #pragma unroll
             for (int m = 0; m < MT; m++) {
-                const float a = c == 0 ? a_cur[m].x : c == 1 ? a_cur[m].y : c == 2 ? a_cur[m].z : a_cur[m].w;
+                const float av = c == 0 ? a[m].x : c == 1 ? a[m].y : c == 2 ? a[m].z : a[m].w;
 #pragma unroll
                 for (int f = 0; f < 4; f++)
-                    acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[c][f], acc[f][m], 0, 0, 0);
+                    acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[c][f], acc[f][m], 0, 0, 0);
             }
+    };
+    if (!(dbg & 1))
+    for (int gi = 0; gi < gpw; gi += 2) {   // gpw is even: K % 128 == 0 (checked at create)
 #pragma unroll
-        for (int m = 0; m < MT; m++) a_cur[m] = a_nxt[m];
+        for (int m = 0; m < MT; m++) a1[m] = gA[((size_t)(gbeg + gi + 1) * MT + m) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        group(gbeg + gi, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int gn = gbeg + min(gi + 2, gpw - 1);
+#pragma unroll
+        for (int m = 0; m < MT; m++) a0[m] = gA[((size_t)gn * MT + m) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        group(gbeg + gi + 1, a1);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     // cross-wave reduction: wave s parks its partials for the frame tiles it does not own
@@ -214,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void mel_kernel(const float *__restrict__ x
                     const float v = tot[m][r];
                     // (v^2)^expo = exp2(expo * log2(v^2)): v_log_f32 + v_mul + v_exp_f32 instead of ocml powf
                     // (~70 instructions); relative error <= ~5e-7 for v^2 down to 1e-12, 0 -> 0
-                    float o = __builtin_amdgcn_exp2f(bp.expo * __builtin_amdgcn_logf(v * v));
+                    float o = (dbg & 2) ? v : __builtin_amdgcn_exp2f(bp.expo * __builtin_amdgcn_logf(v * v));
                     o = o * bp.out_scale + bp.out_shift;
                     const int row = bp.flip ? (bp.n_mels - 1 - mel) : mel;
                     out[(size_t)row * bp.n_frames + t] = o;
@@ -231,6 +263,7 @@ void launch_mel(const float *x, const float *minmax, float *spec, const Frontend
         max_span = span > max_span ? span : max_span;
         max_frames = p.br[b].n_frames > max_frames ? p.br[b].n_frames : max_frames;
     }
+    static const int dbg = getenv("BIRDA_HIP_MEL_DBG") ? atoi(getenv("BIRDA_HIP_MEL_DBG")) : 0;  // tuning ablations
     const int mt = nmp / 16;
     const size_t span_bytes = (size_t)((max_span + 3) & ~3) * sizeof(float);
     const size_t red_bytes = (size_t)4 * 3 * mt * 64 * sizeof(float4);
@@ -245,7 +278,7 @@ void launch_mel(const float *x, const float *minmax, float *spec, const Frontend
             attr_set = true;                                                                               \
         }                                                                                                  \
         hipLaunchKernelGGL(mel_kernel<MTV>, grid, block, smem, s, x, minmax, spec, d_p, p.br[0].gf, p.br[1].gf,  \
-                           p.br[2].gf, p.br[3].gf);                                                        \
+                           p.br[2].gf, p.br[3].gf, dbg);                                                   \
     } break;
     switch (mt) {
         BH_MEL_CASE(2)

@@ -147,7 +147,7 @@ const ResamplePlan *resample_plan(uint32_t from, uint32_t to, const char **err) 
     if (dmax < dmin) { *err = "resampler: empty operator"; return nullptr; }
     ResamplePlan pl{};
     pl.from = from; pl.to = to; pl.hop = hop; pl.N = N; pl.nblk = N / 160; pl.dmin = dmin;
-    pl.K = (dmax - dmin + 1 + 63) / 64 * 64;
+    pl.K = (dmax - dmin + 1 + 127) / 128 * 128;   // 4 waves x an even number of 16-deep groups
     const size_t span_floats = (size_t)63 * hop + pl.K;
     if (span_floats * 4 > 150 * 1024) { *err = "resampler: frame span exceeds LDS"; return nullptr; }
     // fragment-major operator per 160-column block: [blk][K/16][10][64 lanes][4]
@@ -189,9 +189,16 @@ __global__ __launch_bounds__(256) void resample_kernel(const float *__restrict__
     const float *xseg = in + (size_t)seg * in_stride;
     const int span = 63 * hop + K;
     const int g0 = t0 * hop + dmin;
-    for (int i = tid; i < span; i += 256) {
-        const int gi = g0 + i;
-        smem[i] = (gi >= 0 && gi < src_len) ? xseg[gi] : 0.0f;
+    for (int i0 = tid; i0 < span; i0 += 256 * 8) {   // 8 independent loads in flight per thread
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int gi = g0 + i0 + u * 256;
+            v[u] = (i0 + u * 256 < span && gi >= 0 && gi < src_len) ? xseg[gi] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (i0 + u * 256 < span) smem[i0 + u * 256] = v[u];
     }
     __syncthreads();
 
@@ -203,15 +210,13 @@ __global__ __launch_bounds__(256) void resample_kernel(const float *__restrict__
 
     const int gpw = K / 64, gbeg = wave * gpw;
     const float4 *gA = reinterpret_cast<const float4 *>(op) + (size_t)cb * (K / 16) * RS_MT * 64 + lane;
-    float4 a_cur[RS_MT], a_nxt[RS_MT];
+    // two operator register sets used alternately; scheduling fences keep each load one group ahead
+    float4 a0[RS_MT], a1[RS_MT];
 #pragma unroll
-    for (int m = 0; m < RS_MT; m++) a_cur[m] = gA[((size_t)gbeg * RS_MT + m) * 64];
+    for (int m = 0; m < RS_MT; m++) a0[m] = gA[((size_t)gbeg * RS_MT + m) * 64];
     const float *xf = smem + li * hop;
-    for (int gi = 0; gi < gpw; gi++) {
-        const int gn = gbeg + min(gi + 1, gpw - 1);
-#pragma unroll
-        for (int m = 0; m < RS_MT; m++) a_nxt[m] = gA[((size_t)gn * RS_MT + m) * 64];
-        const int jb = (gbeg + gi) * 16 + 4 * kq;
+    auto group = [&](int g, const float4 (&a)[RS_MT]) {
+        const int jb = g * 16 + 4 * kq;
         float b[4][4];
 #pragma unroll
         for (int c = 0; c < 4; c++)
@@ -221,13 +226,24 @@ __global__ __launch_bounds__(256) void resample_kernel(const float *__restrict__
         for (int c = 0; c < 4; c++)
 #pragma unroll
             for (int m = 0; m < RS_MT; m++) {
-                const float a = c == 0 ? a_cur[m].x : c == 1 ? a_cur[m].y : c == 2 ? a_cur[m].z : a_cur[m].w;
+                const float av = c == 0 ? a[m].x : c == 1 ? a[m].y : c == 2 ? a[m].z : a[m].w;
 #pragma unroll
                 for (int f = 0; f < 4; f++)
-                    acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[c][f], acc[f][m], 0, 0, 0);
+                    acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[c][f], acc[f][m], 0, 0, 0);
             }
+    };
+    for (int gi = 0; gi < gpw; gi += 2) {   // gpw even: K % 128 == 0
 #pragma unroll
-        for (int m = 0; m < RS_MT; m++) a_cur[m] = a_nxt[m];
+        for (int m = 0; m < RS_MT; m++) a1[m] = gA[((size_t)(gbeg + min(gi + 1, gpw - 1)) * RS_MT + m) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        group(gbeg + gi, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        const int gn = gbeg + min(gi + 2, gpw - 1);
+#pragma unroll
+        for (int m = 0; m < RS_MT; m++) a0[m] = gA[((size_t)gn * RS_MT + m) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+        if (gi + 1 < gpw) group(gbeg + gi + 1, a1);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     __syncthreads();  // every wave is done reading the span
