@@ -68,9 +68,11 @@ void launch_minmax(const float *x, float *minmax, int n_seg, int sample_count, h
 }
 
 // ---------------------------------------------------------------------------------------
-// mel kernel: grid (frame tiles of 64, n_branches, n_seg), block 256 = 4 waves, 2 blocks/CU.
+// mel kernel: grid (frame tiles of 48, n_branches, n_seg), block 256 = 4 waves, 2 blocks/CU.
 //
-// LDS holds only the tile's normalised sample span xs[(64-1)H + L] (78 KB for L = 2048).
+// LDS holds only the tile's normalised sample span xs[(48-1)H + L] (60 KB for L = 2048; with 64
+// frames it was 78 KB and a second block never fitted beside the first: staging and epilogue
+// then ran with the MFMA pipe idle).
 // The K = L/2 reduction is SPLIT ACROSS THE 4 WAVES: wave w accumulates k in
 // [wK/4, (w+1)K/4) for all 64 frames x all mel tiles (4 x MT accumulator tiles), so the main
 // loop has no block barrier.  A = Gf^T comes straight from global/L2 in an MFMA-fragment-major
@@ -79,7 +81,8 @@ void launch_minmax(const float *x, float *minmax, int n_seg, int sample_count, h
 // B = folded frames from LDS.  The four partial sums meet in LDS (reusing xs); wave w then
 // owns frame tile w for the epilogue (square, power law, affine, flip, store).
 // ---------------------------------------------------------------------------------------
-constexpr int MEL_TN = 64;
+constexpr int MEL_FT = 3;           // 16-frame tiles per block: 3 keeps the span at 60 KB -> two blocks per CU
+constexpr int MEL_TN = 16 * MEL_FT;
 
 template <int MT>
 __global__ __launch_bounds__(256, 2) void mel_kernel(const float *__restrict__ x, const float *__restrict__ mm,
@@ -156,9 +159,9 @@ __global__ __launch_bounds__(256, 2) void mel_kernel(const float *__restrict__ x
     }
     __syncthreads();
 
-    f32x4 acc[4][MT];
+    f32x4 acc[MEL_FT][MT];
 #pragma unroll
-    for (int f = 0; f < 4; f++)
+    for (int f = 0; f < MEL_FT; f++)
 #pragma unroll
         for (int m = 0; m < MT; m++) acc[f][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -175,11 +178,11 @@ __global__ __launch_bounds__(256, 2) void mel_kernel(const float *__restrict__ x
     const float *xf = xs + li * H;   // frame tile f adds f*16*H
     auto group = [&](int g, const float4 (&a)[MT]) {
         const int jb = g * 16 + 4 * kq;
-        float b[4][4];
+        float b[4][MEL_FT];
 #pragma unroll
         for (int c = 0; c < 4; c++)
 #pragma unroll
-            for (int f = 0; f < 4; f++)
+            for (int f = 0; f < MEL_FT; f++)
                 b[c][f] = xf[f * 16 * H + jb + c + 1] + xf[f * 16 * H + L - 1 - jb - c];
 #pragma unroll
         for (int c = 0; c < 4; c++)
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void mel_kernel(const float *__restrict__ x
             for (int m = 0; m < MT; m++) {
                 const float av = c == 0 ? a[m].x : c == 1 ? a[m].y : c == 2 ? a[m].z : a[m].w;
 #pragma unroll
-                for (int f = 0; f < 4; f++)
+                for (int f = 0; f < MEL_FT; f++)
                     acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[c][f], acc[f][m], 0, 0, 0);
             }
     };
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void mel_kernel(const float *__restrict__ x
     __syncthreads();  // every wave is done reading xs
     float4 *red = reinterpret_cast<float4 *>(smem);
 #pragma unroll
-    for (int f = 0; f < 4; f++) {
+    for (int f = 0; f < MEL_FT; f++) {
         if (f == wave) continue;
         const int slot = f - (f > wave ? 1 : 0);
 #pragma unroll
@@ -218,11 +221,12 @@ __global__ __launch_bounds__(256, 2) void mel_kernel(const float *__restrict__ x
             red[((wave * 3 + slot) * MT + m) * 64 + lane] = make_float4(acc[f][m][0], acc[f][m][1], acc[f][m][2], acc[f][m][3]);
     }
     __syncthreads();
+    if (wave >= MEL_FT) return;  // waves beyond the frame tiles own no epilogue tile
     f32x4 tot[MT];
 #pragma unroll
     for (int m = 0; m < MT; m++) {
         // own partial, selected without dynamic register indexing
-        f32x4 v = wave == 0 ? acc[0][m] : wave == 1 ? acc[1][m] : wave == 2 ? acc[2][m] : acc[3][m];
+        f32x4 v = wave == 0 ? acc[0][m] : wave == 1 ? acc[1][m] : wave == 2 ? acc[2][m] : acc[MEL_FT - 1][m];
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             if (s == wave) continue;
