@@ -31,7 +31,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_* den
 PEAK_HBM_GBPS = 8000.0
 
 
-def cpu_baseline(model_path, sample_count, sample_rate, budget_s=20.0):
+def cpu_baseline(model_path, sample_count, sample_rate):
     """The oracle (a port, not the reference: the reference's ORT path cannot run here) timed
     on this box's host cores over a bounded sample of the same synthetic workload."""
     import numpy as np
@@ -42,11 +42,8 @@ def cpu_baseline(model_path, sample_count, sample_rate, budget_s=20.0):
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     om = O.OracleModel(model_path)
     base = synth.synth_segments(min(cores, 16), sample_count, sample_rate)
-    t = time.perf_counter()
-    om.forward(base[: min(cores, base.shape[0])])  # touch code / pages once, and size the sample
-    first = time.perf_counter() - t
-    per_round = max(first, 1e-3)
-    n = int(max(cores, min(4096, cores * max(1, int(budget_s / per_round)))))
+    om.forward(base[: min(cores, base.shape[0])])  # touch code / pages once
+    n = int(min(1024, max(64, 4 * cores)))         # ~10-30 s of CPU work on 8 ... 256 cores
     segs = np.tile(base, (n // base.shape[0] + 1, 1))[:n]
     t = time.perf_counter()
     om.forward(segs)
@@ -54,6 +51,33 @@ def cpu_baseline(model_path, sample_count, sample_rate, budget_s=20.0):
     return {"value": round(n / dt, 2), "unit": "segments/s", "cores": cores, "kind": "port",
             "sample": f"{n} synthetic 3 s/48 kHz segments, oracle/birda_oracle.c, OpenMP across segments "
                       f"({cores} threads), fp32, {dt:.1f} s"}
+
+
+def layers_have_fused_stem(m, layer_tot):
+    """True when layer 0 (the stem conv) heads a fused block: it was launched and layers 1, 2 were not."""
+    from birda_amd import modelfile as mf
+    L = m.layers
+    return (len(L) > 2 and L[0].op == mf.OP_CONV and L[1].op == mf.OP_DWCONV and L[2].op == mf.OP_PWCONV
+            and layer_tot[0][1] > 0 and layer_tot[1][1] == 0 and layer_tot[2][1] == 0)
+
+
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of a kernel from the newest committed PMC summary (profiles/*_traffic.json,
+    collected with tools/profile_round.sh on this same command: two rocprofv3 --pmc passes, FETCH_SIZE
+    doubled for gfx950 as MI355X_MICROARCH.md prescribes).  None when no summary is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+    except (OSError, ValueError):
+        return None
+    for k, v in d.items():
+        if k.startswith(kernel_prefix):
+            return {"bytes_per_launch": v["hbm_bytes_per_launch"], "read": v["read_bytes_per_launch"],
+                    "write": v["write_bytes_per_launch"], "source": os.path.basename(files[-1])}
+    return None
 
 
 def main():
@@ -157,6 +181,7 @@ def main():
     # launches grouped by kernel: fused blocks of equal shape share one instantiation
     groups = {}
     li, bi = 0, 0
+    n_stem_blocks = 1 if (fused and layers_have_fused_stem(m, layer_tot)) else 0
     layers = m.layers
     fused_layers = set()
     if fused:
@@ -167,7 +192,8 @@ def main():
             if (E.op == mf.OP_PWCONV and D.op == mf.OP_DWCONV and P.op == mf.OP_PWCONV and D.in_tensor == i + 1
                     and P.in_tensor == i + 2 and layer_tot[i][1] > 0 and layer_tot[i + 1][1] == 0):
                 key = ("mbconv", E.cin, E.cout, P.cout, D.kh, D.sh, E.in_h, E.in_w)
-                g = groups.setdefault(key, {"ms": 0.0, "launches": 0, "macs": macs(E) + macs(D) + macs(P)})
+                g = groups.setdefault(key, {"ms": 0.0, "launches": 0, "macs": macs(E) + macs(D) + macs(P),
+                                            "kernel": clf.fused_kernel_name(fused[bi + n_stem_blocks])})
                 g["ms"] += layer_tot[i][0]
                 g["launches"] += layer_tot[i][1]
                 fused_layers.add(i)
@@ -201,7 +227,8 @@ def main():
                       "v_mfma_f32_16x16x4_f32)" % (dom_key[4], dom_key[4], dom_key[5], dom_key[1], dom_key[2], dom_key[3],
                                                    dom_key[6], dom_key[7]),
             "bound": "mfma", "achieved": round(tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "frac": round(tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(dom["kernel"]),
+            "rocprof_name": "bh::mbconv_kernel<" + dom["kernel"][len("mbconv<"):],
             "launches": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2),
             "algorithmic_gflop_per_launch": round(total_flops / max(dom["launches"], 1) / 1e9, 3)}
         if mb_ms > 0:
@@ -212,7 +239,7 @@ def main():
             out["roofline_all_fused_blocks"]["frac"] = round(out["roofline_all_fused_blocks"]["achieved"] / PEAK_F32_MFMA_TFLOPS, 4)
     out["roofline_mel"] = {"kernel": "mel_kernel (folded STFT x mel, v_mfma_f32_16x16x4_f32)", "bound": "hbm",
                            "achieved": round(mel_gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                           "frac": round(mel_gbps / PEAK_HBM_GBPS, 4), "traffic": None,
+                           "frac": round(mel_gbps / PEAK_HBM_GBPS, 4), "traffic": pmc_traffic("bh::mel_kernel"),
                            "launches": mel_launches, "avg_launch_us": round(mel_ms * 1e3 / max(mel_launches, 1), 2),
                            "mfma_tflops": round(info.mel_flops_per_segment * segs_done / (mel_ms * 1e-3) / 1e12, 2)}
     out["stage_us_per_segment"] = {k: round(v[0] * 1e3 / segs_done, 3) for k, v in stage_tot.items()}

@@ -125,6 +125,11 @@ class BirdClassifier:
         n = int(self._L.bh_classifier_fused_blocks(self._h, buf, 256))
         return [int(buf[i]) for i in range(min(n, 256))]
 
+    def fused_kernel_name(self, cfg: int) -> str:
+        buf = C.create_string_buffer(128)
+        self._L.bh_mb_config_name(cfg, buf, 128)
+        return "mbconv<" + buf.value.decode() + ">"
+
     # ---- warm-up (classifier.rs:414-466) ----
     def ensure_warm(self, batch_size: int):
         check(self._L.bh_classifier_ensure_warm(self._h, batch_size))

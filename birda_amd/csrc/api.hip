@@ -752,6 +752,8 @@ int bh_classifier_fused_blocks(const bh_classifier *c, int32_t *cfgs, size_t cap
     return (int)c->mb.size();
 }
 
+int bh_mb_config_name(int32_t cfg, char *out, size_t cap) { return bh::mb_config_name(cfg, out, cap); }
+
 int bh_debug_mb_stamps(bh_classifier *c, uint64_t *out, size_t cap) {
     if (!c || !c->d_stamps) return 0;
     const size_t n = std::min(cap, c->mb.size() * 8);

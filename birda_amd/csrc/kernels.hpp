@@ -121,6 +121,7 @@ struct MbDesc {
     size_t lds_bytes;
 };
 int mb_config_count();
+int mb_config_name(int ci, char *out, size_t cap);
 // picks the instantiation (force_cfg >= 0: that entry or fail) and fills the derived fields
 bool mb_plan(MbDesc &d, int force_cfg);
 void launch_mbconv(const MbDesc &d, int n_seg, hipStream_t s);

@@ -18,6 +18,7 @@
 //     P3  acc[P x Co] += D[P x CE] . Wp[CE x Co]              f32 MFMA, accumulators live across chunks
 //   epilogue: + bp, activation, + residual, NHWC store.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "kernels.hpp"
@@ -400,7 +401,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
 }
 
 struct MbCfg {
-    int KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM;
+    int KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC;
     void (*launch)(const MbDesc &, int, hipStream_t);
 };
 
@@ -418,7 +419,7 @@ void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
 }
 
 #define MB_ENTRY_S(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM) \
-    {KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM,                           \
+    {KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC,                 \
      mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC, STEM>}
 #define MB_ENTRY(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC) \
     MB_ENTRY_S(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, 0)
@@ -498,6 +499,14 @@ double mb_try(MbDesc &d, int ci) {
 }  // namespace
 
 int mb_config_count() { return kNCfgs; }
+
+// the instantiation's template arguments as rocprofv3 prints them ("mbconv_kernel<...>")
+int mb_config_name(int ci, char *out, size_t cap) {
+    if (ci < 0 || ci >= kNCfgs) return 0;
+    const MbCfg &c = kCfgs[ci];
+    return snprintf(out, cap, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", c.KS, c.ST, c.CE, c.KG, c.RT_W, c.NCS, c.WM,
+                    c.WN, c.MT_W, c.NT_W, c.TWL, c.XBL, c.S, c.OCC, c.STEM);
+}
 
 bool mb_plan(MbDesc &d, int force_cfg) {
     d.cfg = -1;

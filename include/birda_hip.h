@@ -161,6 +161,10 @@ BH_API int bh_batch_context_layer_ms(bh_batch_context *ctx, float *ms, uint32_t 
  * disables fusion, BIRDA_HIP_MB_CFG=<i> forces configuration i where it is valid. */
 BH_API int bh_classifier_fused_blocks(const bh_classifier *c, int32_t *cfgs, size_t cap);
 
+/* Template arguments of tile configuration `cfg` as a profiler prints them after
+ * "mbconv_kernel<" (to match bench timings with rocprofv3 rows); returns the string length. */
+BH_API int bh_mb_config_name(int32_t cfg, char *out, size_t cap);
+
 /* Diagnostic (BIRDA_HIP_MB_STAMPS=1 at create): per fused block, 8 counters of wave-cycles spent in
  * setup, dw-weight staging, expand, barrier, depthwise, barrier, project, epilogue since the
  * last call.  Returns the number of blocks written (8 values each). */
