@@ -41,6 +41,15 @@ __device__ __forceinline__ float mb_act(float v) {
 }
 constexpr int MB_ACT = ACT_GELU_ERF;  // expand + depthwise activation of every instantiation below
 
+// n / d for 0 <= n < 2^22, d > 0 through the float reciprocal (one multiply, a convert and a
+// fix-up) instead of the ~35-instruction 32-bit integer division sequence
+__device__ __forceinline__ int mb_div(int n, int d, float rcp_d) {
+    int q = (int)((float)n * rcp_d);
+    q += (n - q * d >= d) ? 1 : 0;
+    q -= (n - q * d < 0) ? 1 : 0;
+    return q;
+}
+
 // diagnostic phase clock (only when d.stamps != nullptr): cycles since the last stamp are summed per
 // phase in registers and added to the global counters once, at the end, by lane 0 of every wave
 struct MbClock {
@@ -140,11 +149,12 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
     const int rw = wave / NCS, cs = wave - rw * NCS;  // P1: row-tile lane of the wave, column split
     const int wm = wave / WN, wn = wave - wm * WN;    // P3
 
+    const float rcp_vw = 1.0f / (float)max(vw, 1);
     for (int m = tid; m < nrt * 16; m += 256) {
         int e = egrid, xo = 0;
         if (m < M) {
-            const int sl = m / Mseg, mm = m - sl * Mseg;
-            const int r = mm / vw, c = mm - r * vw;
+            const int sl = SS > 1 ? (m >= Mseg ? 1 : 0) : 0, mm = m - sl * Mseg;
+            const int r = mb_div(mm, vw, rcp_vw), c = mm - r * vw;
             e = sl * IH * IW + (ya + r) * IW + xa + c;
             xo = STEM ? (((iy0 + ya + r) << 16) | (ix0 + xa + c))   // stem-output pixel (y, x), gathered below
                       : ((sl * d.H + iy0 + ya + r) * d.W + ix0 + xa + c) * Cin;
@@ -153,7 +163,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
         xoff[m] = xo;
     }
     for (int p = tid; p < POUT_PAD; p += 256) {
-        const int sl = p / THTW, pp = p - sl * THTW;
+        const int sl = (p >= THTW ? 1 : 0) + (p >= 2 * THTW ? 1 : 0), pp = p - sl * THTW;  // SS <= 2
         const int ty = pp >> TWL, tx = pp & (TW - 1);
         int o = -1;
         if (sl < nsv && oy0 + ty < d.Ho && ox0 + tx < d.Wo) o = (sl * d.Ho + oy0 + ty) * d.Wo + ox0 + tx;
@@ -184,8 +194,9 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     const int k = 16 * g + 4 * kq + c;
-                    const int tap = k / d.stem_c, ch = k - tap * d.stem_c;
-                    const int dy = tap / d.stem_k, dx = tap - dy * d.stem_k;
+                    // STEM = number of spectrogram channels (compile time); 3x3 stem kernel
+                    const int tap = k / STEM, ch = k - tap * STEM;
+                    const int dy = tap / 3, dx = tap - dy * 3;
                     const int y = sy + dy, x = sx + dx;
                     const bool ok = rv && k < Cin && y >= 0 && y < d.stem_h && x >= 0 && x < d.stem_w;
                     v[c] = ok ? Xb[((size_t)ch * d.stem_h + y) * d.stem_w + x] : 0.0f;
@@ -450,7 +461,7 @@ const MbCfg kCfgs[] = {
     MB_ENTRY(5, 1, 16, 7, 3, 1, 4, 1, 3, 7, 5, 2, 6, 1, 2),    // 18: as 7
     MB_ENTRY(5, 2, 16, 7, 3, 1, 1, 4, 3, 3, 4, 0, 3, 1, 2),    // 19: as 8
     // stem conv (im2col gather from the planar spectrogram) -> depthwise 3x3 -> project: the first block
-    MB_ENTRY_S(3, 1, 16, 2, 3, 1, 4, 1, 2, 1, 4, 1, 8, 1, 3, 1),  // 20: 2-channel spectrogram, 3x3 stem (K = 18)
+    MB_ENTRY_S(3, 1, 16, 2, 3, 1, 4, 1, 2, 1, 4, 1, 8, 1, 3, 2),  // 20: 2-channel spectrogram, 3x3 stem (K = 18)
     MB_ENTRY_S(3, 1, 16, 1, 3, 1, 4, 1, 2, 1, 4, 1, 8, 1, 3, 1),  // 21: 1-channel spectrogram (K = 9)
 };
 constexpr int kNCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
@@ -460,7 +471,8 @@ constexpr int kNCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 double mb_try_th(MbDesc &d, int ci, int th) {
     const MbCfg &c = kCfgs[ci];
     if (c.KS != d.KS || c.ST != d.ST || d.Cexp % c.CE || (!d.stem && d.Cin % 4) || d.Cexp % 4) return -1;
-    if ((c.STEM != 0) != (d.stem != 0)) return -1;
+    if (c.STEM != (d.stem ? d.stem_c : 0)) return -1;
+    if (d.stem && d.stem_k != 3) return -1;
     if ((d.Cin + 15) / 16 != c.KG) return -1;
     if (d.act_e != MB_ACT || d.act_d != MB_ACT || d.act_p != ACT_NONE) return -1;
     const int nto = (d.Cout + 15) / 16;
