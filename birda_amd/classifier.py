@@ -88,10 +88,11 @@ class BatchInferenceContext:
 
 class BirdClassifier:
     def __init__(self, model_path: str, labels_path: Optional[str] = None, top_k: int = DEFAULT_TOP_K,
-                 min_confidence: float = DEFAULT_MIN_CONFIDENCE, device: int = 0):
+                 min_confidence: float = DEFAULT_MIN_CONFIDENCE, device: int = 0, precision: str = "f32"):
         self._L = _lib.load()
         self._keep = (model_path.encode(), labels_path.encode() if labels_path else None)
-        cfg = BhConfig(self._keep[0], self._keep[1], top_k, min_confidence, device, 0)
+        flags = {"f32": 0, "f16x3": 1, "f16": 2}[precision]   # BH_FLAG_* (include/birda_hip.h)
+        cfg = BhConfig(self._keep[0], self._keep[1], top_k, min_confidence, device, flags)
         h = C.c_void_p()
         check(self._L.bh_classifier_create(C.byref(cfg), C.byref(h)))
         self._h = h

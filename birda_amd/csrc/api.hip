@@ -62,6 +62,7 @@ struct bh_classifier {
     bh::FrontendParams *d_fe = nullptr;      // device copy read by the mel kernel
     std::vector<int> fused_at;               // per layer: index into mb (expand layer of a fused block) or -1
     std::vector<bh::MbDesc> mb;              // fused MBConv blocks (kernels_mbconv.hip)
+    int precision = 0;                       // GEMM operands of the fused blocks: 0 f32, 3 f16 hi/lo split, 1 f16
     unsigned long long *d_stamps = nullptr;  // BIRDA_HIP_MB_STAMPS=1: [mb.size()][8] phase counters
     uint64_t mel_flops = 0;
     std::mutex warm_mu;
@@ -386,6 +387,36 @@ int predict_slices(bh_classifier *c, bh_batch_context *ctx, const float *const *
     return BH_OK;
 }
 
+// IEEE binary16 round-to-nearest-even of a float, and back (host side of the hi/lo operand split)
+uint16_t f32_to_f16(float f) {
+    uint32_t x; memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x47800000u) return (uint16_t)(sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u));   // overflow / nan
+    if (x < 0x38800000u) {                                                                     // subnormal half
+        if (x < 0x33000000u) return (uint16_t)sign;
+        const int shift = 113 - (int)(x >> 23);
+        uint32_t m = (x & 0x7fffffu) | 0x800000u;
+        const uint32_t half = m >> (shift + 13), rem = m & ((1u << (shift + 13)) - 1), mid = 1u << (shift + 12);
+        return (uint16_t)(sign | (half + ((rem > mid || (rem == mid && (half & 1))) ? 1 : 0)));
+    }
+    const uint32_t e = ((x >> 23) - 112) << 10, m = (x >> 13) & 0x3ffu, rem = x & 0x1fffu;
+    uint32_t h = e | m;
+    if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) h++;
+    return (uint16_t)(sign | h);
+}
+float f16_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1f, m = h & 0x3ffu;
+    uint32_t x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else { int k = 0; uint32_t mm = m; while (!(mm & 0x400u)) { mm <<= 1; k++; } x = sign | ((uint32_t)(113 - k) << 23) | ((mm & 0x3ffu) << 13); }
+    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e + 112) << 23) | (m << 13);
+    float f; memcpy(&f, &x, 4);
+    return f;
+}
+
 // Finds expand(1x1) -> depthwise -> project(1x1) triples whose intermediates have no other reader
 // and prepares a fused launch for each (weights re-laid fragment-major for the picked tile config).
 int plan_fusion(bh_classifier *c) {
@@ -420,32 +451,62 @@ int plan_fusion(bh_classifier *c) {
         d.KS = (int)D.kh; d.ST = (int)D.sh;
         d.act_e = (int)E.act; d.act_d = (int)D.act; d.act_p = (int)P.act;
         if (const char *dbg = getenv("BIRDA_HIP_MB_DBG")) d.dbg = atoi(dbg);
+        d.prec = c->precision;
         if (!bh::mb_plan(d, force_cfg)) continue;
         // per-chunk weight blocks (kernels.hpp MbDesc)
         const int CE = d.CE, NTE = CE / 16, KG = d.KG, NTOP = d.NTOP, nch = d.nchunks, KK = d.KS * d.KS;
         const float *We = m.blob.data() + E.w_off, *Wp = m.blob.data() + P.w_off, *Wd = m.blob.data() + D.w_off;
         const float *be = m.blob.data() + E.b_off, *bd = m.blob.data() + D.b_off;
-        const size_t we_fl = (size_t)KG * NTE * 256 + CE, wp_fl = (size_t)NTE * NTOP * 256, wd_fl = (size_t)KK * CE + CE;
+        const bool h16 = d.prec != 0;
+        const size_t frag = h16 ? 512 : 256, psteps = h16 ? CE / 32 : NTE;
+        const size_t we_fl = (size_t)KG * NTE * frag + CE, wp_fl = psteps * NTOP * frag, wd_fl = (size_t)KK * CE + CE;
         std::vector<float> wef(nch * we_fl, 0.0f), wpf(nch * wp_fl, 0.0f), wdf(nch * wd_fl, 0.0f);
+        auto we_at = [&](int k, int n) { return (k < d.Cin && n < d.Cexp) ? We[(size_t)k * d.Cexp + n] : 0.0f; };
+        auto wp_at = [&](int k, int n) { return (k < d.Cexp && n < d.Cout) ? Wp[(size_t)k * d.Cout + n] : 0.0f; };
+        // f16: element jj of lane's 8-half fragment = k = 32 g + 8 (lane >> 4) + jj; hi plane then lo plane
+        auto put16 = [&](std::vector<float> &dst, size_t base_fl, int plane, int lane, int jj, float v) {
+            uint16_t *h = reinterpret_cast<uint16_t *>(dst.data() + base_fl) + ((size_t)plane * 64 + lane) * 8 + jj;
+            const uint16_t hi = f32_to_f16(v);
+            *h = plane == 0 ? hi : f32_to_f16(v - f16_to_f32(hi));
+        };
         for (int ch = 0; ch < nch; ch++) {
             for (int g = 0; g < KG; g++)
                 for (int j = 0; j < NTE; j++)
-                    for (int lane = 0; lane < 64; lane++)
-                        for (int cc = 0; cc < 4; cc++) {
-                            const int k = 16 * g + 4 * (lane >> 4) + cc, n = ch * CE + 16 * j + (lane & 15);
-                            if (k < d.Cin) wef[ch * we_fl + (((size_t)g * NTE + j) * 64 + lane) * 4 + cc] = We[(size_t)k * d.Cexp + n];
+                    for (int lane = 0; lane < 64; lane++) {
+                        const int n = ch * CE + 16 * j + (lane & 15);
+                        if (h16) {
+                            for (int jj = 0; jj < 8; jj++) {
+                                const float v = we_at(32 * g + 8 * (lane >> 4) + jj, n);
+                                const size_t base = ch * we_fl + ((size_t)g * NTE + j) * 512;
+                                put16(wef, base, 0, lane, jj, v);
+                                put16(wef, base, 1, lane, jj, v);
+                            }
+                        } else {
+                            for (int cc = 0; cc < 4; cc++)
+                                wef[ch * we_fl + (((size_t)g * NTE + j) * 64 + lane) * 4 + cc] = we_at(16 * g + 4 * (lane >> 4) + cc, n);
                         }
-            for (int n = 0; n < CE; n++) wef[ch * we_fl + (size_t)KG * NTE * 256 + n] = be[ch * CE + n];
-            for (int g = 0; g < NTE; g++)
+                    }
+            for (int n = 0; n < CE; n++) wef[ch * we_fl + (size_t)KG * NTE * frag + n] = ch * CE + n < d.Cexp ? be[ch * CE + n] : 0.0f;
+            for (int g = 0; g < (int)psteps; g++)
                 for (int j = 0; j < NTOP; j++)
-                    for (int lane = 0; lane < 64; lane++)
-                        for (int cc = 0; cc < 4; cc++) {
-                            const int k = ch * CE + 16 * g + 4 * (lane >> 4) + cc, n = 16 * j + (lane & 15);
-                            if (n < d.Cout) wpf[ch * wp_fl + (((size_t)g * NTOP + j) * 64 + lane) * 4 + cc] = Wp[(size_t)k * d.Cout + n];
+                    for (int lane = 0; lane < 64; lane++) {
+                        const int n = 16 * j + (lane & 15);
+                        if (h16) {
+                            for (int jj = 0; jj < 8; jj++) {
+                                const float v = wp_at(ch * CE + 32 * g + 8 * (lane >> 4) + jj, n);
+                                const size_t base = ch * wp_fl + ((size_t)g * NTOP + j) * 512;
+                                put16(wpf, base, 0, lane, jj, v);
+                                put16(wpf, base, 1, lane, jj, v);
+                            }
+                        } else {
+                            for (int cc = 0; cc < 4; cc++)
+                                wpf[ch * wp_fl + (((size_t)g * NTOP + j) * 64 + lane) * 4 + cc] = wp_at(ch * CE + 16 * g + 4 * (lane >> 4) + cc, n);
                         }
+                    }
             for (int tap = 0; tap < KK; tap++)
-                for (int n = 0; n < CE; n++) wdf[ch * wd_fl + (size_t)tap * CE + n] = Wd[(size_t)tap * d.Cexp + ch * CE + n];
-            for (int n = 0; n < CE; n++) wdf[ch * wd_fl + (size_t)KK * CE + n] = bd[ch * CE + n];
+                for (int n = 0; n < CE; n++)
+                    wdf[ch * wd_fl + (size_t)tap * CE + n] = ch * CE + n < d.Cexp ? Wd[(size_t)tap * d.Cexp + ch * CE + n] : 0.0f;
+            for (int n = 0; n < CE; n++) wdf[ch * wd_fl + (size_t)KK * CE + n] = ch * CE + n < d.Cexp ? bd[ch * CE + n] : 0.0f;
         }
         float *dwe = nullptr, *dwp = nullptr, *dwd = nullptr;
         int rc = upload(wef.data(), wef.size() * sizeof(float), &dwe);
@@ -575,6 +636,13 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) {
     }
     if (m.layers.empty() || m.layers.back().cout != m.h.n_classes)
         return fail(BH_ERR_IO, "model: last layer width != n_classes");
+    c->precision = (cfg->flags & BH_FLAG_PRECISION_MASK) == BH_FLAG_F16X3 ? 3 : (cfg->flags & BH_FLAG_PRECISION_MASK) == BH_FLAG_F16 ? 1 : 0;
+    if (const char *pe = getenv("BIRDA_HIP_PRECISION")) {
+        if (!strcmp(pe, "f32")) c->precision = 0;
+        else if (!strcmp(pe, "f16x3")) c->precision = 3;
+        else if (!strcmp(pe, "f16")) c->precision = 1;
+        else return fail(BH_ERR_INVALID, "BIRDA_HIP_PRECISION must be f32, f16x3 or f16");
+    }
     rc = plan_fusion(c.get());
     if (rc != BH_OK) return rc;
     if (const char *st = getenv("BIRDA_HIP_MB_STAMPS"); st && st[0] == '1' && !c->mb.empty()) {

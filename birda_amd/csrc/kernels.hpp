@@ -107,6 +107,7 @@ struct MbDesc {
     const float *We, *Wd, *Wp, *bp;
     int H, W, Cin, Cexp, Cout, Ho, Wo, pad_t, pad_l, KS, ST;
     int act_e, act_d, act_p;
+    int prec;  // 0: f32 MFMA; 3: f16 hi/lo split (three f16 MFMAs per product, f32-grade); 1: plain f16 MFMA
     // stem variant (first block): "expand" = the k x k stride-s stem conv gathered from the planar
     // spectrogram X [n][stem_c][stem_h][stem_w]; then H, W are the stem's OUTPUT size and
     // Cin = stem_k * stem_k * stem_c im2col columns (We rows in [kh][kw][cin] order)

@@ -27,6 +27,8 @@ namespace bh {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -99,19 +101,38 @@ __device__ __forceinline__ void mb_dma(const float *gsrc, float *lds_dst, int wa
 }
 __device__ __forceinline__ void mb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// a = hi + lo with hi, lo in f16 (22 significant bits): products hi*hi + hi*lo + lo*hi on the f16
+// MFMA with f32 accumulation reproduce an f32 fmaf chain to ~1e-7 of sum|a b|
+// (tools/microbench/mfma_f16_overlap.hip) at 4.4x the f32 MFMA rate, and leave the vector pipe
+// half free while they run.  Valid while |a| < 65504 (f16 range).
+__device__ __forceinline__ void mb_split8(const float (&v)[8], f16x8 &hi, f16x8 &lo) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        hi[j] = (_Float16)v[j];
+        lo[j] = (_Float16)(v[j] - (float)hi[j]);
+    }
+}
+
+//   PREC        0: f32 MFMA (16x16x4, KG counts 16-deep groups); 3: f16 hi/lo split, three 16x16x32 MFMAs
+//               per product (KG counts 32-deep steps); 1: plain f16 operands (one MFMA, ~1e-3 relative)
 template <int KS, int ST, int CE, int KG, int RT_W, int NCS, int WM, int WN, int MT_W, int NT_W, int TWL, int XBL,
-          int SS, int OCC, int STEM>
+          int SS, int OCC, int STEM, int PREC>
 __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const int n_seg) {
     static_assert(!STEM || SS == 1, "the stem variant handles one segment per workgroup");
+    static_assert(PREC == 0 || CE % 32 == 0, "f16 MFMA steps are 32 deep");
     static_assert(WM * WN == 4, "4 waves");
     constexpr int NT_E = CE / 16, NT_U = NT_E / NCS, CES = CE + 4, C4N = CE / 4, TW = 1 << TWL;
     constexpr int POUT_PAD = WM * MT_W * 16, NTOP = WN * NT_W;
     constexpr int XB = 1 << XBL, XBN = TW / XB, NCOL = (XB - 1) * ST + KS;
     constexpr int RSTEP = 4 / NCS;  // row-tile stride between a wave's P1 tiles
     constexpr int RG = (RT_W * NT_U <= 8) ? RT_W : (8 / NT_U >= 1 ? 8 / NT_U : 1);  // row tiles in flight
-    constexpr int WE_FLOATS = KG * NT_E * 256 + CE;   // We fragments + be
-    constexpr int WP_FLOATS = NT_E * NTOP * 256;
-    constexpr int WD_FLOATS = KS * KS * CE + CE;      // Wd [tap][CE] + bd
+    constexpr int FRAG = PREC ? 512 : 256;             // floats per (k step, column tile): f16 = hi + lo planes
+    constexpr int PSTEPS = PREC ? CE / 32 : NT_E;      // k steps of the project GEMM per chunk
+    constexpr int WE_FLOATS = KG * NT_E * FRAG + CE;   // We fragments + be
+    constexpr int WP_FLOATS = PSTEPS * NTOP * FRAG;
+    constexpr int WD_FLOATS = KS * KS * CE + CE;       // Wd [tap][CE] + bd
+    constexpr int DSH = CE + 8;                        // f16 D planes: row stride in halves (80 B: conflict-free b128)
+    constexpr int DS_FLOATS = PREC ? POUT_PAD * DSH : POUT_PAD * CES;
     static_assert(NT_U * NCS == NT_E, "column split");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -121,13 +142,14 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
     const int egrid = SS * IH * IW;
     float *Es = smem;
     float *Ds = Es + (size_t)(egrid + 1) * CES;  // + 1: trash row that padding source rows write to
-    float *WeS = Ds + POUT_PAD * CES;
+    float *WeS = Ds + DS_FLOATS;
+    _Float16 *DsH = reinterpret_cast<_Float16 *>(Ds), *DsL = DsH + POUT_PAD * DSH;   // PREC != 0
     float *WpS = WeS + WE_FLOATS;
     float *Wds = WpS + WP_FLOATS;
     int *emap = reinterpret_cast<int *>(Wds + WD_FLOATS);
     int *xoff = emap + d.mpad_max;
     int *omap = xoff + d.mpad_max;
-    const float *bes = WeS + KG * NT_E * 256, *bds = Wds + KS * KS * CE;
+    const float *bes = WeS + KG * NT_E * FRAG, *bds = Wds + KS * KS * CE;
 
     MbClock t_last{};
     if (d.stamps) t_last.last = __builtin_readcyclecounter();
@@ -178,37 +200,45 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
     __syncthreads();
 
     // ---- the wave's rows of X: A fragments of the expand GEMM, resident for the whole kernel ----
-    float4 afr[RT_W][KG];
+    // f32: afr[i][g] = 4 k values of one 16-deep group; f16: ah/al[i][g] = 8 k values of one 32-deep step
+    float4 afr[PREC ? 1 : RT_W][PREC ? 1 : KG];
+    f16x8 ah[PREC ? RT_W : 1][PREC ? KG : 1], al[PREC ? RT_W : 1][PREC ? KG : 1];
 #pragma unroll
     for (int i = 0; i < RT_W; i++) {
         const int rt = rw + RSTEP * i;
         const bool rv = rt < nrt;
-        if constexpr (STEM) {
-            // im2col gather of the stem conv (k x k, stride s, planar input): column
-            // k = (dy * kw + dx) * C + ch, exactly the row order of the [kh][kw][cin][cout] weights
-            const int pk = rv ? xoff[rt * 16 + li] : 0;
-            const int sy = (pk >> 16) * d.stem_s - d.stem_pt, sx = (pk & 0xffff) * d.stem_s - d.stem_pl;
+        const int xo = rv ? xoff[rt * 16 + li] : 0;
+        constexpr int NV = PREC ? 8 : 4;   // consecutive k per lane and step
 #pragma unroll
-            for (int g = 0; g < KG; g++) {
-                float v[4];
+        for (int g = 0; g < KG; g++) {
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const int k0 = (PREC ? 32 * g + 8 * kq : 16 * g + 4 * kq);
+            if constexpr (STEM != 0) {
+                // im2col gather of the 3x3 stem conv (stride s, planar input): column
+                // k = (dy * 3 + dx) * C + ch, exactly the row order of the [kh][kw][cin][cout] weights
+                const int sy = (xo >> 16) * d.stem_s - d.stem_pt, sx = (xo & 0xffff) * d.stem_s - d.stem_pl;
 #pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const int k = 16 * g + 4 * kq + c;
-                    // STEM = number of spectrogram channels (compile time); 3x3 stem kernel
-                    const int tap = k / STEM, ch = k - tap * STEM;
+                for (int c = 0; c < NV; c++) {
+                    const int k = k0 + c;
+                    const int tap = k / (STEM ? STEM : 1), ch = k - tap * STEM;   // STEM = spectrogram channels
                     const int dy = tap / 3, dx = tap - dy * 3;
                     const int y = sy + dy, x = sx + dx;
                     const bool ok = rv && k < Cin && y >= 0 && y < d.stem_h && x >= 0 && x < d.stem_w;
                     v[c] = ok ? Xb[((size_t)ch * d.stem_h + y) * d.stem_w + x] : 0.0f;
                 }
+            } else {
+#pragma unroll
+                for (int q = 0; q < NV / 4; q++) {
+                    const float4 t = (rv && k0 + 4 * q < Cin) ? *reinterpret_cast<const float4 *>(Xb + xo + k0 + 4 * q)
+                                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+                    v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+                }
+            }
+            if constexpr (PREC != 0) {
+                mb_split8(v, ah[i][g], al[i][g]);
+            } else {
                 afr[i][g] = make_float4(v[0], v[1], v[2], v[3]);
             }
-        } else {
-            const float *xp = Xb + (rv ? xoff[rt * 16 + li] : 0) + 4 * kq;
-#pragma unroll
-            for (int g = 0; g < KG; g++)
-                afr[i][g] = (rv && 16 * g + 4 * kq < Cin) ? *reinterpret_cast<const float4 *>(xp + 16 * g)
-                                                          : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     mb_stamp(d.stamps, t_last, 0);
@@ -233,6 +263,34 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
 #pragma unroll
                     for (int j = 0; j < NT_U; j++) acc[ii][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (!(d.dbg & 8)) {
+                    if constexpr (PREC != 0) {
+                        // fragment planes: [step][column tile]{hi: 64 lanes x 8 halves, lo: same}
+                        const f16x8 *wf = reinterpret_cast<const f16x8 *>(WeS);
+#pragma unroll
+                        for (int g = 0; g < KG; g++) {
+                            f16x8 bh[NT_U], bl[NT_U];
+#pragma unroll
+                            for (int j = 0; j < NT_U; j++) {
+                                bh[j] = wf[((g * NT_E + cs * NT_U + j) * 2 + 0) * 64 + lane];
+                                if (PREC == 3) bl[j] = wf[((g * NT_E + cs * NT_U + j) * 2 + 1) * 64 + lane];
+                            }
+#pragma unroll
+                            for (int ii = 0; ii < RG; ii++) {
+                                if (i0 + ii >= RT_W) continue;
+                                constexpr int dummy = 0; (void)dummy;
+                                const int ir = i0 + ii < RT_W ? i0 + ii : 0;
+#pragma unroll
+                                for (int j = 0; j < NT_U; j++) {
+                                    acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ir][g], bh[j], acc[ii][j], 0, 0, 0);
+                                    if (PREC == 3) {
+                                        acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ir][g], bl[j], acc[ii][j], 0, 0, 0);
+                                        acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ir][g], bh[j], acc[ii][j], 0, 0, 0);
+                                    }
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    } else {
                     // B fragments double-buffered by hand, and a scheduling fence per k group: left
                     // alone, hipcc hoists every group's LDS loads to the top of the unrolled loop and
                     // spills the resident A fragments
@@ -266,6 +324,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                    }  // PREC == 0
                 }
 #pragma unroll
                 for (int ii = 0; ii < RG; ii++) {
@@ -332,7 +391,19 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                     float4 v = make_float4(acc[x][0][0], acc[x][0][1], acc[x][1][0], acc[x][1][1]);
                     v.x = mb_act<MB_ACT>(v.x); v.y = mb_act<MB_ACT>(v.y);
                     v.z = mb_act<MB_ACT>(v.z); v.w = mb_act<MB_ACT>(v.w);
-                    *reinterpret_cast<float4 *>(&Ds[(sl * THTW + (ty << TWL) + tx0 + x) * CES + 4 * c4]) = v;
+                    const int prow = sl * THTW + (ty << TWL) + tx0 + x;
+                    if constexpr (PREC != 0) {   // the project GEMM's A operand: f16 hi (+ lo) planes
+                        f16x4 h, l;
+                        h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+                        *reinterpret_cast<f16x4 *>(&DsH[prow * DSH + 4 * c4]) = h;
+                        if (PREC == 3) {
+                            l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
+                            l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
+                            *reinterpret_cast<f16x4 *>(&DsL[prow * DSH + 4 * c4]) = l;
+                        }
+                    } else {
+                        *reinterpret_cast<float4 *>(&Ds[prow * CES + 4 * c4]) = v;
+                    }
                 }
             }
         }
@@ -344,6 +415,35 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
 
         // ---- P3: project -----------------------------------------------------------------
         if (!(d.dbg & 4)) {
+            if constexpr (PREC != 0) {
+                const f16x8 *wf = reinterpret_cast<const f16x8 *>(WpS);
+#pragma unroll
+                for (int g = 0; g < PSTEPS; g++) {
+                    f16x8 a_h[MT_W], a_l[MT_W], b_h[NT_W], b_l[NT_W];
+#pragma unroll
+                    for (int i = 0; i < MT_W; i++) {
+                        const int row = (wm * MT_W + i) * 16 + li;
+                        a_h[i] = *reinterpret_cast<const f16x8 *>(&DsH[row * DSH + 32 * g + 8 * kq]);
+                        if (PREC == 3) a_l[i] = *reinterpret_cast<const f16x8 *>(&DsL[row * DSH + 32 * g + 8 * kq]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < NT_W; j++) {
+                        b_h[j] = wf[((g * NTOP + wn * NT_W + j) * 2 + 0) * 64 + lane];
+                        if (PREC == 3) b_l[j] = wf[((g * NTOP + wn * NT_W + j) * 2 + 1) * 64 + lane];
+                    }
+#pragma unroll
+                    for (int i = 0; i < MT_W; i++)
+#pragma unroll
+                        for (int j = 0; j < NT_W; j++) {
+                            acco[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[i], b_h[j], acco[i][j], 0, 0, 0);
+                            if (PREC == 3) {
+                                acco[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[i], b_l[j], acco[i][j], 0, 0, 0);
+                                acco[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l[i], b_h[j], acco[i][j], 0, 0, 0);
+                            }
+                        }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
             const float *dsb = Ds + ((wm * MT_W) * 16 + li) * CES + 4 * kq;
             float4 a[MT_W], b[NT_W], an[MT_W], bn[NT_W];
 #pragma unroll
@@ -378,6 +478,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            }  // PREC == 0
         }
         mb_stamp(d.stamps, t_last, 6);
         // no barrier here: the next chunk's P1 touches Es / WeS (landed before B2) only; its P2
@@ -412,14 +513,14 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
 }
 
 struct MbCfg {
-    int KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC;
+    int KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC;
     void (*launch)(const MbDesc &, int, hipStream_t);
 };
 
 template <int KS, int ST, int CE, int KG, int RT_W, int NCS, int WM, int WN, int MT_W, int NT_W, int TWL, int XBL,
-          int SS, int OCC, int STEM>
+          int SS, int OCC, int STEM, int PREC>
 void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
-    auto kern = mbconv_kernel<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, SS, OCC, STEM>;
+    auto kern = mbconv_kernel<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, SS, OCC, STEM, PREC>;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -429,11 +530,17 @@ void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
     hipLaunchKernelGGL(kern, grid, block, d.lds_bytes, s, d, n_seg);
 }
 
+#define MB_ENTRY_P(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, PREC) \
+    {KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC,                 \
+     mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC, STEM, PREC>}
 #define MB_ENTRY_S(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM) \
-    {KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC,                 \
-     mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC, STEM>}
+    MB_ENTRY_P(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, 0)
 #define MB_ENTRY(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC) \
     MB_ENTRY_S(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, 0)
+// split-f16 (PREC 3) and plain-f16 (PREC 1) twins of one tile configuration; KG counts 32-deep steps
+#define MB_ENTRY_H(KS, ST, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM)             \
+    MB_ENTRY_P(KS, ST, 32, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, 3),          \
+    MB_ENTRY_P(KS, ST, 32, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, 1)
 
 // The instantiations cover the BirdNET-v2.4 / Perch-shaped stacks (EfficientNet-B0 stages);
 // mb_plan() picks, per block, the valid entry with the least MFMA work.
@@ -463,6 +570,21 @@ const MbCfg kCfgs[] = {
     // stem conv (im2col gather from the planar spectrogram) -> depthwise 3x3 -> project: the first block
     MB_ENTRY_S(3, 1, 16, 2, 3, 1, 4, 1, 2, 1, 4, 1, 8, 1, 3, 2),  // 20: 2-channel spectrogram, 3x3 stem (K = 18)
     MB_ENTRY_S(3, 1, 16, 1, 3, 1, 4, 1, 2, 1, 4, 1, 8, 1, 3, 1),  // 21: 1-channel spectrogram (K = 9)
+    // f16 MFMA twins (even index: split hi/lo x3, odd: plain f16), 32-channel chunks
+    //         KS ST KG RT NCS WM WN MT NT TWL XBL TH S OCC STEM
+    MB_ENTRY_H(3, 2, 1, 5, 1, 4, 1, 1, 2, 4, 1, 4, 1, 2, 0),    // 22/23: Cin <= 32, 3x3 s2 (16 -> 96 -> 24)
+    MB_ENTRY_H(3, 1, 1, 3, 1, 4, 1, 2, 2, 4, 2, 8, 1, 2, 0),    // 24/25: Cin <= 32, 3x3 s1
+    MB_ENTRY_H(5, 2, 1, 7, 1, 4, 1, 1, 3, 4, 1, 4, 1, 2, 0),    // 26/27: Cin <= 32, 5x5 s2
+    MB_ENTRY_H(5, 1, 2, 4, 1, 4, 1, 3, 3, 4, 3, 12, 1, 1, 0),   // 28/29: Cin <= 64, 5x5 s1, 12x64
+    MB_ENTRY_H(3, 2, 2, 7, 1, 2, 2, 3, 3, 4, 0, 6, 1, 1, 0),    // 30/31: Cin <= 64, 3x3 s2
+    MB_ENTRY_H(3, 1, 3, 3, 1, 4, 1, 3, 5, 5, 3, 6, 1, 2, 0),    // 32/33: 80 -> 480 -> 80, 6x32
+    MB_ENTRY_H(5, 1, 3, 3, 1, 4, 1, 3, 7, 5, 3, 6, 1, 1, 0),    // 34/35: 80 -> 480 -> 112
+    MB_ENTRY_H(5, 1, 4, 3, 1, 4, 1, 3, 7, 5, 3, 6, 1, 1, 0),    // 36/37: 112 -> 672 -> 112
+    MB_ENTRY_H(5, 2, 4, 3, 1, 1, 4, 3, 3, 4, 1, 3, 1, 1, 0),    // 38/39: 112 -> 672 -> 192 stride 2
+    MB_ENTRY_H(5, 1, 6, 3, 2, 2, 2, 3, 6, 4, 2, 3, 2, 1, 0),    // 40/41: 192 -> 1152 -> 192, 3x16 x 2
+    MB_ENTRY_H(3, 1, 6, 3, 2, 2, 2, 3, 10, 4, 2, 3, 2, 1, 0),   // 42/43: 192 -> 1152 -> 320
+    MB_ENTRY_H(3, 1, 1, 3, 1, 4, 1, 2, 1, 4, 2, 8, 1, 2, 2),    // 44/45: stem (2-channel spectrogram) block
+    MB_ENTRY_H(3, 1, 1, 3, 1, 4, 1, 2, 1, 4, 2, 8, 1, 2, 1),    // 46/47: stem (1-channel spectrogram) block
 };
 constexpr int kNCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
@@ -470,10 +592,12 @@ constexpr int kNCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 // per segment (in 16x16x4 steps), or -1 when the entry cannot run this block at that height
 double mb_try_th(MbDesc &d, int ci, int th) {
     const MbCfg &c = kCfgs[ci];
-    if (c.KS != d.KS || c.ST != d.ST || d.Cexp % c.CE || (!d.stem && d.Cin % 4) || d.Cexp % 4) return -1;
+    // f16 configurations take any Cexp: the last chunk's missing channels are zero weights and biases
+    if (c.KS != d.KS || c.ST != d.ST || (c.PREC == 0 && d.Cexp % c.CE) || (!d.stem && d.Cin % 4) || d.Cexp % 4) return -1;
     if (c.STEM != (d.stem ? d.stem_c : 0)) return -1;
     if (d.stem && d.stem_k != 3) return -1;
-    if ((d.Cin + 15) / 16 != c.KG) return -1;
+    if (c.PREC != d.prec) return -1;
+    if ((d.Cin + (c.PREC ? 31 : 15)) / (c.PREC ? 32 : 16) != c.KG) return -1;
     if (d.act_e != MB_ACT || d.act_d != MB_ACT || d.act_p != ACT_NONE) return -1;
     const int nto = (d.Cout + 15) / 16;
     if (nto > c.WN * c.NT_W) return -1;
@@ -484,13 +608,15 @@ double mb_try_th(MbDesc &d, int ci, int th) {
     t.cfg = ci; t.TH = th; t.S = c.S;
     t.tiles_y = (d.Ho + th - 1) / th; t.tiles_x = (d.Wo + TW - 1) / TW;
     t.IH = (th - 1) * c.ST + c.KS; t.IW = (TW - 1) * c.ST + c.KS;
-    t.KG = (d.Cin + 15) / 16; t.nchunks = d.Cexp / c.CE; t.NTOP = c.WN * c.NT_W; t.CE = c.CE;
+    t.KG = c.KG; t.nchunks = (d.Cexp + c.CE - 1) / c.CE; t.NTOP = c.WN * c.NT_W; t.CE = c.CE;
     const int mseg = std::min(t.IH, d.H) * std::min(t.IW, d.W);
     t.mpad_max = (c.S * mseg + 15) / 16 * 16;
     if (t.mpad_max / 16 > c.RT_W * (4 / c.NCS)) return -1;  // a wave keeps all its rows of X in registers
-    const size_t we_fl = (size_t)c.KG * (c.CE / 16) * 256 + c.CE, wp_fl = (size_t)(c.CE / 16) * t.NTOP * 256;
+    const size_t frag = c.PREC ? 512 : 256, psteps = c.PREC ? c.CE / 32 : c.CE / 16;
+    const size_t we_fl = (size_t)c.KG * (c.CE / 16) * frag + c.CE, wp_fl = psteps * t.NTOP * frag;
     const size_t wd_fl = (size_t)c.KS * c.KS * c.CE + c.CE;
-    t.lds_bytes = (((size_t)c.S * t.IH * t.IW + 1) * ces + (size_t)pout_pad * ces + we_fl + wp_fl + wd_fl) * 4 +
+    const size_t ds_fl = c.PREC ? (size_t)pout_pad * (c.CE + 8) : (size_t)pout_pad * ces;
+    t.lds_bytes = (((size_t)c.S * t.IH * t.IW + 1) * ces + ds_fl + we_fl + wp_fl + wd_fl) * 4 +
                   ((size_t)2 * t.mpad_max + pout_pad) * 4;
     if (t.lds_bytes > 160 * 1024) return -1;
     d = t;
@@ -516,8 +642,8 @@ int mb_config_count() { return kNCfgs; }
 int mb_config_name(int ci, char *out, size_t cap) {
     if (ci < 0 || ci >= kNCfgs) return 0;
     const MbCfg &c = kCfgs[ci];
-    return snprintf(out, cap, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", c.KS, c.ST, c.CE, c.KG, c.RT_W, c.NCS, c.WM,
-                    c.WN, c.MT_W, c.NT_W, c.TWL, c.XBL, c.S, c.OCC, c.STEM);
+    return snprintf(out, cap, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", c.KS, c.ST, c.CE, c.KG, c.RT_W, c.NCS, c.WM,
+                    c.WN, c.MT_W, c.NT_W, c.TWL, c.XBL, c.S, c.OCC, c.STEM, c.PREC);
 }
 
 bool mb_plan(MbDesc &d, int force_cfg) {
@@ -541,10 +667,11 @@ bool mb_plan(MbDesc &d, int force_cfg) {
     // measured on MI355X (profiles/): 16-channel chunks (2-4 workgroups per CU) win wherever an
     // instantiation exists; the 192-channel 3x16 blocks need two column-split waves and stay at 32
     static const int kPreferred[] = {11, 12, 13, 14, 15, 16, 17, 18, 19, 9, 10, 20, 21};
-    for (int ci : kPreferred) {  // at the entry's own tile height: the shapes it was measured on
-        MbDesc t = d;
-        if (mb_try_th(t, ci, kCfgs[ci].TH) >= 0) { d = t; return true; }
-    }
+    if (d.prec == 0)
+        for (int ci : kPreferred) {  // at the entry's own tile height: the shapes it was measured on
+            MbDesc t = d;
+            if (mb_try_th(t, ci, kCfgs[ci].TH) >= 0) { d = t; return true; }
+        }
     double best = -1;
     MbDesc bestd = d;
     for (int ci = 0; ci < kNCfgs; ci++) {

@@ -48,8 +48,19 @@ typedef struct {
     uint32_t top_k;          /* DEFAULT_TOP_K = 5, constants.rs:178 */
     float min_confidence;    /* DEFAULT_MIN_CONFIDENCE = 0.1, constants.rs:25 */
     int32_t device;          /* HIP device ordinal (one process per GPU) */
-    uint32_t flags;          /* reserved, 0 */
+    uint32_t flags;          /* BH_FLAG_* below; 0 = f32 */
 } bh_config;
+
+/* GEMM operand precision of the fused conv blocks (accumulation is always f32):
+ *   BH_FLAG_F32    v_mfma_f32_16x16x4_f32: exact f32 fmaf chains (default)
+ *   BH_FLAG_F16X3  every f32 operand split into f16 hi + lo, three f16 MFMAs per product:
+ *                  ~1e-7 of sum|a b| like the f32 chain, 4.4x its MFMA rate; operands < 65504
+ *   BH_FLAG_F16    operands rounded to f16 once (BASELINE config 5): ~1e-3 relative
+ * The environment variable BIRDA_HIP_PRECISION = f32 | f16x3 | f16 overrides the flag. */
+#define BH_FLAG_PRECISION_MASK 0x3u
+#define BH_FLAG_F32 0x0u
+#define BH_FLAG_F16X3 0x1u
+#define BH_FLAG_F16 0x2u
 
 /* birdnet_onnx::ModelConfig{sample_rate, segment_duration, sample_count} + labels().len()
  * (classifier.rs:295-297,306,360-377) */
