@@ -26,6 +26,30 @@ __device__ __forceinline__ float gelu_erf_fast(float v) {
     return __builtin_fmaf(-0.5f * ax * p, e, __builtin_fmaxf(v, 0.0f));
 }
 
+// Two GELUs at once with the f32 packed ops (v_pk_fma_f32 / v_pk_mul_f32): 17 instructions per
+// pair against 13 per value.  max(v, 0) is written 0.5 v + 0.5 |v| so the tail stays packed:
+// GELU(v) = 0.5 v + |v| (0.5 - 0.5 P(t) e), same polynomial and the same rcp / exp2 as above
+// (|difference| from gelu_erf_fast <= 3e-8 |v|: one extra rounding in the tail).
+typedef float bh_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bh_f32x2 gelu_erf_fast2(bh_f32x2 v) {
+    bh_f32x2 ax;
+    ax[0] = __builtin_fabsf(v[0]); ax[1] = __builtin_fabsf(v[1]);
+    const bh_f32x2 one = {1.0f, 1.0f};
+    const bh_f32x2 den = __builtin_elementwise_fma(ax, (bh_f32x2){0.3275911f * 0.70710678118654752440f, 0.3275911f * 0.70710678118654752440f}, one);
+    bh_f32x2 t;
+    t[0] = __builtin_amdgcn_rcpf(den[0]); t[1] = __builtin_amdgcn_rcpf(den[1]);
+    bh_f32x2 p = __builtin_elementwise_fma(t, (bh_f32x2){1.061405429f, 1.061405429f}, (bh_f32x2){-1.453152027f, -1.453152027f});
+    p = __builtin_elementwise_fma(p, t, (bh_f32x2){1.421413741f, 1.421413741f});
+    p = __builtin_elementwise_fma(p, t, (bh_f32x2){-0.284496736f, -0.284496736f});
+    p = __builtin_elementwise_fma(p, t, (bh_f32x2){0.254829592f, 0.254829592f});
+    p = p * t;
+    const bh_f32x2 q = (v * (bh_f32x2){-0.5f * 1.4426950408889634f, -0.5f * 1.4426950408889634f}) * v;
+    bh_f32x2 e;
+    e[0] = __builtin_amdgcn_exp2f(q[0]); e[1] = __builtin_amdgcn_exp2f(q[1]);
+    const bh_f32x2 s = __builtin_elementwise_fma(p * (bh_f32x2){-0.5f, -0.5f}, e, (bh_f32x2){0.5f, 0.5f});
+    return __builtin_elementwise_fma(v, (bh_f32x2){0.5f, 0.5f}, ax * s);
+}
+
 __device__ __forceinline__ float act_apply_slow(float v, int act) {
     switch (act) {
     case ACT_RELU: return fmaxf(v, 0.f);

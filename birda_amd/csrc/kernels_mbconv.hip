@@ -41,6 +41,11 @@ __device__ __forceinline__ float mb_act(float v) {
     else if constexpr (ACT == ACT_RELU) return fmaxf(v, 0.f);
     else return act_apply_slow(v, ACT);
 }
+template <int ACT>
+__device__ __forceinline__ f32x2 mb_act2(f32x2 v) {
+    if constexpr (ACT == ACT_GELU_ERF) return gelu_erf_fast2(v);
+    else { f32x2 r; r[0] = mb_act<ACT>(v[0]); r[1] = mb_act<ACT>(v[1]); return r; }
+}
 constexpr int MB_ACT = ACT_GELU_ERF;  // expand + depthwise activation of every instantiation below
 
 // n / d for 0 <= n < 2^22, d > 0 through the float reciprocal (one multiply, a convert and a
@@ -243,11 +248,24 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
     }
     mb_stamp(d.stamps, t_last, 0);
 
+    // The project accumulators start at bias + residual: those loads overlap the first chunk
+    // instead of stalling the epilogue, which is then nothing but stores.
+    float *Yb = d.Y + (size_t)seg0 * d.Ho * d.Wo * Cout;
+    const float *Rb = d.R ? d.R + (size_t)seg0 * d.Ho * d.Wo * Cout : nullptr;
     f32x4 acco[MT_W][NT_W];
 #pragma unroll
-    for (int i = 0; i < MT_W; i++)
+    for (int i = 0; i < MT_W; i++) {
+        const int4 o4 = *reinterpret_cast<const int4 *>(&omap[(wm * MT_W + i) * 16 + 4 * kq]);
+        const int orow[4] = {o4.x, o4.y, o4.z, o4.w};
 #pragma unroll
-        for (int j = 0; j < NT_W; j++) acco[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NT_W; j++) {
+            const int col = (wn * NT_W + j) * 16 + li;
+            const float bias = col < Cout ? d.bp[col] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                acco[i][j][r] = bias + ((Rb && col < Cout && orow[r] >= 0) ? Rb[(size_t)orow[r] * Cout + col] : 0.0f);
+        }
+    }
 
     for (int ch = 0; ch < nchunks; ch++) {
         const int chn = min(ch + 1, nchunks - 1);
@@ -337,9 +355,10 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                         for (int j = 0; j < NT_U; j++) {
                             const int col = (cs * NT_U + j) * 16 + li;
                             const float bias = bes[col];
-#pragma unroll
-                            for (int r = 0; r < 4; r++)
-                                Es[er[r] * CES + col] = (d.dbg & 1) ? acc[ii][j][r] + bias : mb_act<MB_ACT>(acc[ii][j][r] + bias);
+                            f32x2 v01 = {acc[ii][j][0] + bias, acc[ii][j][1] + bias}, v23 = {acc[ii][j][2] + bias, acc[ii][j][3] + bias};
+                            if (!(d.dbg & 1)) { v01 = mb_act2<MB_ACT>(v01); v23 = mb_act2<MB_ACT>(v23); }
+                            Es[er[0] * CES + col] = v01[0]; Es[er[1] * CES + col] = v01[1];
+                            Es[er[2] * CES + col] = v23[0]; Es[er[3] * CES + col] = v23[1];
                         }
                     }
                 }
@@ -388,9 +407,8 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                 }
 #pragma unroll
                 for (int x = 0; x < XB; x++) {
-                    float4 v = make_float4(acc[x][0][0], acc[x][0][1], acc[x][1][0], acc[x][1][1]);
-                    v.x = mb_act<MB_ACT>(v.x); v.y = mb_act<MB_ACT>(v.y);
-                    v.z = mb_act<MB_ACT>(v.z); v.w = mb_act<MB_ACT>(v.w);
+                    const f32x2 g0 = mb_act2<MB_ACT>(acc[x][0]), g1 = mb_act2<MB_ACT>(acc[x][1]);
+                    const float4 v = make_float4(g0[0], g0[1], g1[0], g1[1]);
                     const int prow = sl * THTW + (ty << TWL) + tx0 + x;
                     if constexpr (PREC != 0) {   // the project GEMM's A operand: f16 hi (+ lo) planes
                         f16x4 h, l;
@@ -485,9 +503,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
         // (which rewrites Ds) sits behind B1, which also drains the Wd DMA issued above.
     }
 
-    // ---- epilogue: bias, activation, residual, store -----------------------------------------
-    float *Yb = d.Y + (size_t)seg0 * d.Ho * d.Wo * Cout;
-    const float *Rb = d.R ? d.R + (size_t)seg0 * d.Ho * d.Wo * Cout : nullptr;
+    // ---- epilogue: store (bias and residual are already in the accumulators) -------------------
 #pragma unroll
     for (int i = 0; i < MT_W; i++) {
         const int4 o4 = *reinterpret_cast<const int4 *>(&omap[(wm * MT_W + i) * 16 + 4 * kq]);
@@ -496,15 +512,9 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
         for (int j = 0; j < NT_W; j++) {
             const int col = (wn * NT_W + j) * 16 + li;
             if (col >= Cout) continue;
-            const float bias = d.bp[col];
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                if (orow[r] >= 0) {
-                    const size_t idx = (size_t)orow[r] * Cout + col;
-                    float v = acco[i][j][r] + bias;
-                    if (Rb) v += Rb[idx];
-                    if (!(d.dbg & 32)) Yb[idx] = v;
-                }
+                if (orow[r] >= 0 && !(d.dbg & 32)) Yb[(size_t)orow[r] * Cout + col] = acco[i][j][r];
         }
     }
     mb_stamp(d.stamps, t_last, 7);
