@@ -452,7 +452,20 @@ int plan_fusion(bh_classifier *c) {
         d.act_e = (int)E.act; d.act_d = (int)D.act; d.act_p = (int)P.act;
         if (const char *dbg = getenv("BIRDA_HIP_MB_DBG")) d.dbg = atoi(dbg);
         d.prec = c->precision;
-        if (!bh::mb_plan(d, force_cfg)) continue;
+        if (c->precision == 3) {
+            // The split-f16 MFMA and the f32 MFMA agree to ~1e-7 of sum|a b|, so the choice per block is
+            // purely speed (profiles/): f16x3 wins where the GEMMs dominate (Cin >= 80, and the 3x3 s1
+            // blocks), the f32 kernels with 16-channel chunks win on the large early images, where the
+            // vector work (GELU, depthwise) dominates and residency matters more than MFMA rate.
+            const bool f16_faster = d.Cin >= 80 || (!d.stem && d.KS == 3 && d.ST == 1);
+            const char *mix = getenv("BIRDA_HIP_F16X3_ALL");
+            if (!f16_faster && !(mix && mix[0] == '1')) d.prec = 0;
+        }
+        if (!bh::mb_plan(d, force_cfg)) {
+            if (d.prec == 0) continue;
+            d.prec = 0;                       // no f16 instantiation for this shape: f32 one, if any
+            if (!bh::mb_plan(d, force_cfg)) continue;
+        }
         // per-chunk weight blocks (kernels.hpp MbDesc)
         const int CE = d.CE, NTE = CE / 16, KG = d.KG, NTOP = d.NTOP, nch = d.nchunks, KK = d.KS * d.KS;
         const float *We = m.blob.data() + E.w_off, *Wp = m.blob.data() + P.w_off, *Wd = m.blob.data() + D.w_off;

@@ -152,8 +152,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
     float *WpS = WeS + WE_FLOATS;
     float *Wds = WpS + WP_FLOATS;
     int *emap = reinterpret_cast<int *>(Wds + WD_FLOATS);
-    int *xoff = emap + d.mpad_max;
-    int *omap = xoff + d.mpad_max;
+    int *omap = emap + d.mpad_max;
     const float *bes = WeS + KG * NT_E * FRAG, *bds = Wds + KS * KS * CE;
 
     MbClock t_last{};
@@ -177,33 +176,6 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
     const int wm = wave / WN, wn = wave - wm * WN;    // P3
 
     const float rcp_vw = 1.0f / (float)max(vw, 1);
-    for (int m = tid; m < nrt * 16; m += 256) {
-        int e = egrid, xo = 0;
-        if (m < M) {
-            const int sl = SS > 1 ? (m >= Mseg ? 1 : 0) : 0, mm = m - sl * Mseg;
-            const int r = mb_div(mm, vw, rcp_vw), c = mm - r * vw;
-            e = sl * IH * IW + (ya + r) * IW + xa + c;
-            xo = STEM ? (((iy0 + ya + r) << 16) | (ix0 + xa + c))   // stem-output pixel (y, x), gathered below
-                      : ((sl * d.H + iy0 + ya + r) * d.W + ix0 + xa + c) * Cin;
-        }
-        emap[m] = e;
-        xoff[m] = xo;
-    }
-    for (int p = tid; p < POUT_PAD; p += 256) {
-        const int sl = (p >= THTW ? 1 : 0) + (p >= 2 * THTW ? 1 : 0), pp = p - sl * THTW;  // SS <= 2
-        const int ty = pp >> TWL, tx = pp & (TW - 1);
-        int o = -1;
-        if (sl < nsv && oy0 + ty < d.Ho && ox0 + tx < d.Wo) o = (sl * d.Ho + oy0 + ty) * d.Wo + ox0 + tx;
-        omap[p] = o;
-    }
-    if (M != egrid) {  // some of the grid lies outside the image (or a segment is missing): zero padding
-        float4 *z = reinterpret_cast<float4 *>(Es);
-        const int n4 = egrid * CES / 4;
-        for (int i = tid; i < n4; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    mb_dma_wait();
-    __syncthreads();
-
     // ---- the wave's rows of X: A fragments of the expand GEMM, resident for the whole kernel ----
     // f32: afr[i][g] = 4 k values of one 16-deep group; f16: ah/al[i][g] = 8 k values of one 32-deep step
     float4 afr[PREC ? 1 : RT_W][PREC ? 1 : KG];
@@ -212,7 +184,16 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
     for (int i = 0; i < RT_W; i++) {
         const int rt = rw + RSTEP * i;
         const bool rv = rt < nrt;
-        const int xo = rv ? xoff[rt * 16 + li] : 0;
+        int xo = 0;   // row offset computed in registers: the loads go out before the table barrier
+        {
+            const int m = rt * 16 + li;
+            if (rv && m < M) {
+                const int sl = SS > 1 ? (m >= Mseg ? 1 : 0) : 0, mm = m - sl * Mseg;
+                const int r = mb_div(mm, vw, rcp_vw), c = mm - r * vw;
+                xo = STEM ? (((iy0 + ya + r) << 16) | (ix0 + xa + c))   // stem-output pixel (y, x), gathered below
+                          : ((sl * d.H + iy0 + ya + r) * d.W + ix0 + xa + c) * Cin;
+            }
+        }
         constexpr int NV = PREC ? 8 : 4;   // consecutive k per lane and step
 #pragma unroll
         for (int g = 0; g < KG; g++) {
@@ -246,6 +227,30 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
             }
         }
     }
+    for (int m = tid; m < nrt * 16; m += 256) {
+        int e = egrid;
+        if (m < M) {
+            const int sl = SS > 1 ? (m >= Mseg ? 1 : 0) : 0, mm = m - sl * Mseg;
+            const int r = mb_div(mm, vw, rcp_vw), c = mm - r * vw;
+            e = sl * IH * IW + (ya + r) * IW + xa + c;
+        }
+        emap[m] = e;
+    }
+    for (int p = tid; p < POUT_PAD; p += 256) {
+        const int sl = (p >= THTW ? 1 : 0) + (p >= 2 * THTW ? 1 : 0), pp = p - sl * THTW;  // SS <= 2
+        const int ty = pp >> TWL, tx = pp & (TW - 1);
+        int o = -1;
+        if (sl < nsv && oy0 + ty < d.Ho && ox0 + tx < d.Wo) o = (sl * d.Ho + oy0 + ty) * d.Wo + ox0 + tx;
+        omap[p] = o;
+    }
+    if (M != egrid) {  // some of the grid lies outside the image (or a segment is missing): zero padding
+        float4 *z = reinterpret_cast<float4 *>(Es);
+        const int n4 = egrid * CES / 4;
+        for (int i = tid; i < n4; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    mb_dma_wait();
+    __syncthreads();
+
     mb_stamp(d.stamps, t_last, 0);
 
     // The project accumulators start at bias + residual: those loads overlap the first chunk
@@ -627,7 +632,7 @@ double mb_try_th(MbDesc &d, int ci, int th) {
     const size_t wd_fl = (size_t)c.KS * c.KS * c.CE + c.CE;
     const size_t ds_fl = c.PREC ? (size_t)pout_pad * (c.CE + 8) : (size_t)pout_pad * ces;
     t.lds_bytes = (((size_t)c.S * t.IH * t.IW + 1) * ces + ds_fl + we_fl + wp_fl + wd_fl) * 4 +
-                  ((size_t)2 * t.mpad_max + pout_pad) * 4;
+                  ((size_t)t.mpad_max + pout_pad) * 4;
     if (t.lds_bytes > 160 * 1024) return -1;
     d = t;
     const double tiles = (double)t.tiles_y * t.tiles_x / c.S;
