@@ -454,10 +454,9 @@ int plan_fusion(bh_classifier *c) {
         d.prec = c->precision;
         if (c->precision == 3) {
             // The split-f16 MFMA and the f32 MFMA agree to ~1e-7 of sum|a b|, so the choice per block is
-            // purely speed (profiles/): f16x3 wins where the GEMMs dominate (Cin >= 80, and the 3x3 s1
-            // blocks), the f32 kernels with 16-channel chunks win on the large early images, where the
-            // vector work (GELU, depthwise) dominates and residency matters more than MFMA rate.
-            const bool f16_faster = d.Cin >= 80 || (!d.stem && d.KS == 3 && d.ST == 1);
+            // purely speed (profiles/): f16x3 wins everywhere except the stem block, whose 18-column
+            // im2col GEMM is tiny and whose vector work dominates.
+            const bool f16_faster = !d.stem;
             const char *mix = getenv("BIRDA_HIP_F16X3_ALL");
             if (!f16_faster && !(mix && mix[0] == '1')) d.prec = 0;
         }
@@ -471,7 +470,7 @@ int plan_fusion(bh_classifier *c) {
         const float *We = m.blob.data() + E.w_off, *Wp = m.blob.data() + P.w_off, *Wd = m.blob.data() + D.w_off;
         const float *be = m.blob.data() + E.b_off, *bd = m.blob.data() + D.b_off;
         const bool h16 = d.prec != 0;
-        const size_t frag = h16 ? 512 : 256, psteps = h16 ? CE / 32 : NTE;
+        const size_t frag = h16 ? 512 : 256, psteps = h16 ? (CE + 31) / 32 : NTE;
         const size_t we_fl = (size_t)KG * NTE * frag + CE, wp_fl = psteps * NTOP * frag, wd_fl = (size_t)KK * CE + CE;
         std::vector<float> wef(nch * we_fl, 0.0f), wpf(nch * wp_fl, 0.0f), wdf(nch * wd_fl, 0.0f);
         auto we_at = [&](int k, int n) { return (k < d.Cin && n < d.Cexp) ? We[(size_t)k * d.Cexp + n] : 0.0f; };
@@ -506,7 +505,8 @@ int plan_fusion(bh_classifier *c) {
                         const int n = 16 * j + (lane & 15);
                         if (h16) {
                             for (int jj = 0; jj < 8; jj++) {
-                                const float v = wp_at(ch * CE + 32 * g + 8 * (lane >> 4) + jj, n);
+                                const int kk = 32 * g + 8 * (lane >> 4) + jj;          // k inside the chunk (zero padding past CE)
+                                const float v = kk < CE ? wp_at(ch * CE + kk, n) : 0.0f;
                                 const size_t base = ch * wp_fl + ((size_t)g * NTOP + j) * 512;
                                 put16(wpf, base, 0, lane, jj, v);
                                 put16(wpf, base, 1, lane, jj, v);

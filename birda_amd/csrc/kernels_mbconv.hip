@@ -124,7 +124,7 @@ template <int KS, int ST, int CE, int KG, int RT_W, int NCS, int WM, int WN, int
           int SS, int OCC, int STEM, int PREC>
 __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const int n_seg) {
     static_assert(!STEM || SS == 1, "the stem variant handles one segment per workgroup");
-    static_assert(PREC == 0 || CE % 32 == 0, "f16 MFMA steps are 32 deep");
+    static_assert(PREC == 0 || CE % 32 == 0 || CE == 16, "f16 MFMA steps are 32 deep (16-channel chunks: zero-padded)");
     static_assert(WM * WN == 4, "4 waves");
     constexpr int NT_E = CE / 16, NT_U = NT_E / NCS, CES = CE + 4, C4N = CE / 4, TW = 1 << TWL;
     constexpr int POUT_PAD = WM * MT_W * 16, NTOP = WN * NT_W;
@@ -132,11 +132,11 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
     constexpr int RSTEP = 4 / NCS;  // row-tile stride between a wave's P1 tiles
     constexpr int RG = (RT_W * NT_U <= 8) ? RT_W : (8 / NT_U >= 1 ? 8 / NT_U : 1);  // row tiles in flight
     constexpr int FRAG = PREC ? 512 : 256;             // floats per (k step, column tile): f16 = hi + lo planes
-    constexpr int PSTEPS = PREC ? CE / 32 : NT_E;      // k steps of the project GEMM per chunk
+    constexpr int PSTEPS = PREC ? (CE + 31) / 32 : NT_E;  // k steps of the project GEMM per chunk
     constexpr int WE_FLOATS = KG * NT_E * FRAG + CE;   // We fragments + be
     constexpr int WP_FLOATS = PSTEPS * NTOP * FRAG;
     constexpr int WD_FLOATS = KS * KS * CE + CE;       // Wd [tap][CE] + bd
-    constexpr int DSH = CE + 8;                        // f16 D planes: row stride in halves (80 B: conflict-free b128)
+    constexpr int DSH = PSTEPS * 32 + 8;               // f16 D planes: row stride in halves (80 B: conflict-free b128)
     constexpr int DS_FLOATS = PREC ? POUT_PAD * DSH : POUT_PAD * CES;
     static_assert(NT_U * NCS == NT_E, "column split");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -242,6 +242,10 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
         int o = -1;
         if (sl < nsv && oy0 + ty < d.Ho && ox0 + tx < d.Wo) o = (sl * d.Ho + oy0 + ty) * d.Wo + ox0 + tx;
         omap[p] = o;
+    }
+    if constexpr (PREC != 0 && CE % 32 != 0) {   // the k padding of the project GEMM's A operand
+        float4 *z = reinterpret_cast<float4 *>(Ds);
+        for (int i = tid; i < DS_FLOATS / 4; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (M != egrid) {  // some of the grid lies outside the image (or a segment is missing): zero padding
         float4 *z = reinterpret_cast<float4 *>(Es);
@@ -600,6 +604,15 @@ const MbCfg kCfgs[] = {
     MB_ENTRY_H(3, 1, 6, 3, 2, 2, 2, 3, 10, 4, 2, 3, 2, 1, 0),   // 42/43: 192 -> 1152 -> 320
     MB_ENTRY_H(3, 1, 1, 3, 1, 4, 1, 2, 1, 4, 2, 8, 1, 2, 2),    // 44/45: stem (2-channel spectrogram) block
     MB_ENTRY_H(3, 1, 1, 3, 1, 4, 1, 2, 1, 4, 2, 8, 1, 2, 1),    // 46/47: stem (1-channel spectrogram) block
+    // split-f16 with 16-channel chunks (k of the project GEMM zero-padded to 32): the large early images
+    //         KS ST CE KG RT NCS WM WN MT NT TWL XBL TH S OCC STEM PREC
+    MB_ENTRY_P(3, 2, 16, 1, 5, 1, 4, 1, 1, 2, 4, 0, 4, 1, 4, 0, 3),    // 48: as 11
+    MB_ENTRY_P(3, 1, 16, 1, 3, 1, 4, 1, 2, 2, 4, 1, 8, 1, 3, 0, 3),    // 49: as 12
+    MB_ENTRY_P(5, 2, 16, 1, 7, 1, 4, 1, 1, 3, 4, 0, 4, 1, 2, 0, 3),    // 50: as 13
+    MB_ENTRY_P(5, 1, 16, 2, 4, 1, 4, 1, 3, 3, 4, 2, 12, 1, 2, 0, 3),   // 51: as 14
+    MB_ENTRY_P(3, 2, 16, 2, 7, 1, 2, 2, 3, 3, 4, 1, 6, 1, 2, 0, 3),    // 52: as 15
+    MB_ENTRY_P(3, 1, 16, 1, 3, 1, 4, 1, 2, 1, 4, 1, 8, 1, 3, 2, 3),    // 53: as 20 (2-channel stem)
+    MB_ENTRY_P(3, 1, 16, 1, 3, 1, 4, 1, 2, 1, 4, 1, 8, 1, 3, 1, 3),    // 54: as 21 (1-channel stem)
 };
 constexpr int kNCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
@@ -627,10 +640,10 @@ double mb_try_th(MbDesc &d, int ci, int th) {
     const int mseg = std::min(t.IH, d.H) * std::min(t.IW, d.W);
     t.mpad_max = (c.S * mseg + 15) / 16 * 16;
     if (t.mpad_max / 16 > c.RT_W * (4 / c.NCS)) return -1;  // a wave keeps all its rows of X in registers
-    const size_t frag = c.PREC ? 512 : 256, psteps = c.PREC ? c.CE / 32 : c.CE / 16;
+    const size_t frag = c.PREC ? 512 : 256, psteps = c.PREC ? (c.CE + 31) / 32 : c.CE / 16;
     const size_t we_fl = (size_t)c.KG * (c.CE / 16) * frag + c.CE, wp_fl = psteps * t.NTOP * frag;
     const size_t wd_fl = (size_t)c.KS * c.KS * c.CE + c.CE;
-    const size_t ds_fl = c.PREC ? (size_t)pout_pad * (c.CE + 8) : (size_t)pout_pad * ces;
+    const size_t ds_fl = c.PREC ? (size_t)pout_pad * (psteps * 32 + 8) : (size_t)pout_pad * ces;
     t.lds_bytes = (((size_t)c.S * t.IH * t.IW + 1) * ces + ds_fl + we_fl + wp_fl + wd_fl) * 4 +
                   ((size_t)t.mpad_max + pout_pad) * 4;
     if (t.lds_bytes > 160 * 1024) return -1;
@@ -682,8 +695,14 @@ bool mb_plan(MbDesc &d, int force_cfg) {
     // measured on MI355X (profiles/): 16-channel chunks (2-4 workgroups per CU) win wherever an
     // instantiation exists; the 192-channel 3x16 blocks need two column-split waves and stay at 32
     static const int kPreferred[] = {11, 12, 13, 14, 15, 16, 17, 18, 19, 9, 10, 20, 21};
+    static const int kPreferred16[] = {48, 49, 50, 51, 52};   // split-f16, 16-channel chunks: the early blocks
     if (d.prec == 0)
         for (int ci : kPreferred) {  // at the entry's own tile height: the shapes it was measured on
+            MbDesc t = d;
+            if (mb_try_th(t, ci, kCfgs[ci].TH) >= 0) { d = t; return true; }
+        }
+    if (d.prec == 3)
+        for (int ci : kPreferred16) {
             MbDesc t = d;
             if (mb_try_th(t, ci, kCfgs[ci].TH) >= 0) { d = t; return true; }
         }

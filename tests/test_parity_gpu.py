@@ -22,6 +22,7 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 LOGIT_RTOL = 2e-5
+F16_LOGIT_RTOL = 1e-2      # plain f16 MFMA operands (BH_FLAG_F16): measured 9e-4 on the full model
 DEGENERATE_RTOL = 1e-2
 SPEC_MAX_ATOL = 2e-3
 SPEC_MEAN_ATOL = 1e-5
@@ -341,32 +342,64 @@ def test_fused_blocks_match_unfused_and_oracle_on_small_images(model_dir, oracle
 
 
 def test_every_fused_tile_configuration(model_dir, oracle_lib, monkeypatch):
-    """Force each tile configuration in turn; blocks it cannot run fall back to the layer kernels."""
-    from birda_amd import _lib, synth
+    """Force each tile configuration in turn (f32 MFMA: 0-21; split-f16 x3: even 22-46 and 48-54; plain
+    f16: odd 23-47); blocks it cannot run fall back to the layer kernels."""
+    from birda_amd import synth
     from birda_amd.classifier import BirdClassifier
     path, _, m, _ = model_dir["mini_b0"]
     segs = synth.synth_segments(3, m.sample_count, m.sample_rate, start=7)
     ref = oracle_lib.OracleModel(path).forward(segs)
+    scale = max(1.0, float(np.abs(ref).max()))
+    monkeypatch.setenv("BIRDA_HIP_F16X3_ALL", "1")
     used = set()
-    for cfg in range(32):
+    for cfg in range(55):
+        prec = "f32" if cfg < 22 else ("f16x3" if (cfg % 2 == 0 or cfg >= 48) else "f16")
         monkeypatch.setenv("BIRDA_HIP_MB_CFG", str(cfg))
-        clf = BirdClassifier(path)
+        clf = BirdClassifier(path, precision=prec)
         blocks = clf.fused_blocks()
         if not blocks:
             clf.close()
-            if cfg >= 22:
-                break
             continue
         assert set(blocks) == {cfg}
         used.add(cfg)
         ctx = clf.create_batch_context(4)
-        _logit_close(clf.predict_logits(ctx, segs), ref)
+        got = clf.predict_logits(ctx, segs)
+        if prec == "f16":
+            assert np.isfinite(got).all() and np.abs(got - ref).max() <= F16_LOGIT_RTOL * scale, cfg
+        else:
+            _logit_close(got, ref)
         ctx.close(); clf.close()
-    assert used == set(range(21)), used       # 21 = 1-channel stem: the Perch-shaped test
+    # 21 and 46/47 are the 1-channel stem variants: exercised by the Perch-shaped test
+    assert used == set(range(55)) - {21, 46, 47, 54}, sorted(set(range(55)) - used)
+
+
+def test_precision_modes_on_the_full_model(full_model, oracle_lib):
+    """BH_FLAG_F16X3 (split hi/lo f16 operands, three MFMAs per product) must meet the SAME fp32 logit
+    tolerance as the f32 MFMA path; BH_FLAG_F16 (BASELINE config 5: fp16 MFMA conv) its own."""
+    from birda_amd import synth
+    from birda_amd.classifier import BirdClassifier
+    path, labels, m, _ = full_model
+    segs = synth.synth_segments(4, m.sample_count, m.sample_rate, start=200)
+    ref = oracle_lib.OracleModel(path).forward(segs)
+    scale = max(1.0, float(np.abs(ref).max()))
+    out = {}
+    for prec in ("f32", "f16x3", "f16"):
+        clf = BirdClassifier(path, labels, precision=prec)
+        assert len(clf.fused_blocks()) == 16
+        ctx = clf.create_batch_context(4)
+        out[prec] = clf.predict_logits(ctx, segs)
+        ctx.close(); clf.close()
+    e32 = _logit_close(out["f32"], ref)
+    e163 = _logit_close(out["f16x3"], ref)
+    e16 = float(np.abs(out["f16"] - ref).max())
+    print(f"max|dlogit| / scale: f32 {e32 / scale:.2e}  f16x3 {e163 / scale:.2e}  f16 {e16 / scale:.2e}")
+    assert np.isfinite(out["f16"]).all() and e16 <= F16_LOGIT_RTOL * scale
+    # same top-1 class in every mode
+    assert (out["f16"].argmax(1) == ref.argmax(1)).all() and (out["f16x3"].argmax(1) == ref.argmax(1)).all()
 
 
 # ---- C4: Perch-shaped model (5 s / 32 kHz, one 128-mel branch, 14 795 classes, softmax) --------
-def test_perch_shaped_model_matches_oracle(oracle_lib, tmp_path):
+def test_perch_shaped_model_matches_oracle(oracle_lib, tmp_path, monkeypatch):
     from birda_amd import modelfile as mf, synth
     from birda_amd.classifier import BirdClassifier
     m = synth.build_model("perch_v2")
@@ -384,6 +417,14 @@ def test_perch_shaped_model_matches_oracle(oracle_lib, tmp_path):
     ref = oracle_lib.OracleModel(path).forward(segs)
     err = _logit_close(logits, ref)
     print(f"perch-shaped max|dlogit| = {err:.3e} on max|logit| {np.abs(ref).max():.2f}")
+    monkeypatch.setenv("BIRDA_HIP_F16X3_ALL", "1")      # also the early blocks on the f16 kernels
+    for prec, cfg, tol in (("f16x3", 46, LOGIT_RTOL), ("f16", 47, F16_LOGIT_RTOL)):
+        c2 = BirdClassifier(path, None, precision=prec)
+        assert cfg in c2.fused_blocks(), (prec, c2.fused_blocks())   # the 1-channel stem, f16 variants
+        x2 = c2.create_batch_context(4)
+        got = c2.predict_logits(x2, segs)
+        assert np.isfinite(got).all() and np.abs(got - ref).max() <= tol * max(1.0, float(np.abs(ref).max())), prec
+        x2.close(); c2.close()
     res = clf.predict_batch_with_context(ctx, list(segs))
     for i, r in enumerate(res):                      # softmax confidences of the kept top-5
         idx, conf = oracle_lib.topk(ref[i], 2, 5, 0.0)
