@@ -104,8 +104,12 @@ struct bh_batch_context {
 
 namespace {
 
+uint16_t f32_to_f16(float f);
+float f16_to_f32(uint16_t h);
+
 // Gf for one branch (see kernels_frontend.hip): double precision on the host, once.
-std::vector<float> build_gf(const bh::BranchRec &b, const float *W, int nm_pad) {
+// prec 0: f32 fragment-major; prec 3: f16 hi / lo planes for the split MFMA (same byte count).
+std::vector<float> build_gf(const bh::BranchRec &b, const float *W, int nm_pad, int prec) {
     const int L = (int)b.frame_length, K = L / 2, nb = (int)b.n_bins, nm = (int)b.n_mels;
     std::vector<double> ct(L);
     for (int i = 0; i < L; i++) ct[i] = std::cos(2.0 * M_PI * (double)i / (double)L);
@@ -132,6 +136,20 @@ std::vector<float> build_gf(const bh::BranchRec &b, const float *W, int nm_pad) 
     // MFMA-fragment-major relayout (kernels.hpp BranchParams::gf)
     const int mt_n = nm_pad / 16;
     std::vector<float> frag((size_t)K * nm_pad);
+    if (prec != 0) {  // [step of 32 k][mel tile][plane hi, lo][64 lanes][8 halves]: k = 32 s + 8 (lane >> 4) + jj
+        uint16_t *h = reinterpret_cast<uint16_t *>(frag.data());
+        for (int st = 0; st < K / 32; st++)
+            for (int mt = 0; mt < mt_n; mt++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int jj = 0; jj < 8; jj++) {
+                        const float v = gf[(size_t)(32 * st + 8 * (lane >> 4) + jj) * nm_pad + 16 * mt + (lane & 15)];
+                        const uint16_t hi = f32_to_f16(v);
+                        const size_t base = (((size_t)st * mt_n + mt) * 2) * 64 * 8;
+                        h[base + (size_t)lane * 8 + jj] = hi;
+                        h[base + 64 * 8 + (size_t)lane * 8 + jj] = f32_to_f16(v - f16_to_f32(hi));
+                    }
+        return frag;
+    }
     for (int g = 0; g < K / 16; g++)
         for (int mt = 0; mt < mt_n; mt++)
             for (int lane = 0; lane < 64; lane++)
@@ -584,6 +602,19 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) {
     HIPCHK(hipSetDevice(c->device));
     if (m.h.n_branches > bh::MAX_BRANCHES) return fail(BH_ERR_UNSUPPORTED, "too many front-end branches");
     // front-end operators
+    // GEMM operand precision (decided here: the front-end operator layout depends on it)
+    // the spectrogram front-end keeps f32-grade products in every mode: f32 MFMA, or split f16 in f16x3
+    c->precision = (cfg->flags & BH_FLAG_PRECISION_MASK) == BH_FLAG_F16X3 ? 3 : (cfg->flags & BH_FLAG_PRECISION_MASK) == BH_FLAG_F16 ? 1 : 0;
+    if (const char *pe = getenv("BIRDA_HIP_PRECISION")) {
+        if (!strcmp(pe, "f32")) c->precision = 0;
+        else if (!strcmp(pe, "f16x3")) c->precision = 3;
+        else if (!strcmp(pe, "f16")) c->precision = 1;
+        else return fail(BH_ERR_INVALID, "BIRDA_HIP_PRECISION must be f32, f16x3 or f16");
+    }
+    int fe_prec = (c->precision == 3 && !(getenv("BIRDA_HIP_MEL_F32") && getenv("BIRDA_HIP_MEL_F32")[0] == '1')) ? 3 : 0;
+    for (uint32_t b = 0; b < m.h.n_branches; b++)
+        if (m.branches[b].frame_length % 256) fe_prec = 0;   // 32-deep steps split over 4 waves
+    c->fe.prec = fe_prec;
     c->fe.n_branches = (int)m.h.n_branches;
     c->fe.sample_count = (int)m.h.sample_count;
     c->fe.norm_eps = m.h.norm_eps;
@@ -596,7 +627,7 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) {
         if (br.frame_length % 128 || br.fft_length != br.frame_length)
             return fail(BH_ERR_UNSUPPORTED, "front-end: frame_length %u must be a multiple of 128 and equal fft_length", br.frame_length);
         if ((64 * br.frame_step) % 4) return fail(BH_ERR_UNSUPPORTED, "front-end: hop %u unsupported", br.frame_step);
-        std::vector<float> gf = build_gf(br, m.blob.data() + br.mel_w_off, nm_pad);
+        std::vector<float> gf = build_gf(br, m.blob.data() + br.mel_w_off, nm_pad, fe_prec);
         float *d = nullptr;
         int rc = upload(gf.data(), gf.size() * sizeof(float), &d);
         if (rc != BH_OK) return rc;
@@ -649,13 +680,6 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) {
     }
     if (m.layers.empty() || m.layers.back().cout != m.h.n_classes)
         return fail(BH_ERR_IO, "model: last layer width != n_classes");
-    c->precision = (cfg->flags & BH_FLAG_PRECISION_MASK) == BH_FLAG_F16X3 ? 3 : (cfg->flags & BH_FLAG_PRECISION_MASK) == BH_FLAG_F16 ? 1 : 0;
-    if (const char *pe = getenv("BIRDA_HIP_PRECISION")) {
-        if (!strcmp(pe, "f32")) c->precision = 0;
-        else if (!strcmp(pe, "f16x3")) c->precision = 3;
-        else if (!strcmp(pe, "f16")) c->precision = 1;
-        else return fail(BH_ERR_INVALID, "BIRDA_HIP_PRECISION must be f32, f16x3 or f16");
-    }
     rc = plan_fusion(c.get());
     if (rc != BH_OK) return rc;
     if (const char *st = getenv("BIRDA_HIP_MB_STAMPS"); st && st[0] == '1' && !c->mb.empty()) {

@@ -76,6 +76,7 @@ struct BranchParams {
 };
 struct FrontendParams {
     BranchParams br[MAX_BRANCHES];
+    int prec;  // 0: gf in f32 fragments (f32 MFMA); 3: gf as f16 hi / lo planes (split-f16 MFMA, 32-deep steps)
     int n_branches;
     int sample_count;
     float norm_eps;

@@ -19,6 +19,7 @@ namespace bh {
 constexpr int MM_SPLIT = 8;  // partial min/max blocks per segment
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ inline float wave_min(float v) {
 #pragma unroll
@@ -84,7 +85,7 @@ void launch_minmax(const float *x, float *minmax, int n_seg, int sample_count, h
 constexpr int MEL_FT = 3;           // 16-frame tiles per block: 3 keeps the span at 60 KB -> two blocks per CU
 constexpr int MEL_TN = 16 * MEL_FT;
 
-template <int MT>
+template <int MT, int PREC>
 __global__ __launch_bounds__(256, 2) void mel_kernel(const float *__restrict__ x, const float *__restrict__ mm,
                                                       float *__restrict__ spec, const FrontendParams *__restrict__ pp,
                                                       const float *__restrict__ gf0, const float *__restrict__ gf1,
@@ -168,6 +169,54 @@ __global__ __launch_bounds__(256, 2) void mel_kernel(const float *__restrict__ x
     const int gpw = K / 64;          // 16-k groups per wave
     const int gbeg = wave * gpw;
     const float4 *gA = reinterpret_cast<const float4 *>(gfp) + lane;
+    if constexpr (PREC == 3) {
+        // Split-f16 MFMA (v_mfma_f32_16x16x32_f16 x 3 per product: hi*hi + hi*lo + lo*hi, f32 accumulate):
+        // f32-grade sums at 4.4x the f32 MFMA rate.  The operator arrives pre-split (hi / lo planes);
+        // the folded frame samples are split here, 8 consecutive k per lane and 32-deep step.
+        const int spw = K / 128, sbeg = wave * spw;              // steps per wave (even: K % 256 == 0)
+        const f16x8 *gA = reinterpret_cast<const f16x8 *>(gfp) + lane;
+        f16x8 a0h[MT], a0l[MT], a1h[MT], a1l[MT];
+        auto load = [&](int st, f16x8 (&ah)[MT], f16x8 (&al)[MT]) {
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                ah[m] = gA[(((size_t)st * MT + m) * 2 + 0) * 64];
+                al[m] = gA[(((size_t)st * MT + m) * 2 + 1) * 64];
+            }
+        };
+        const float *xf = xs + li * H;
+        auto step = [&](int st, const f16x8 (&ah)[MT], const f16x8 (&al)[MT]) {
+            const int j0 = st * 32 + 8 * kq;
+            f16x8 bh[MEL_FT], bl[MEL_FT];
+#pragma unroll
+            for (int f = 0; f < MEL_FT; f++)
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++) {
+                    const float y = xf[f * 16 * H + j0 + jj + 1] + xf[f * 16 * H + L - 1 - j0 - jj];
+                    bh[f][jj] = (_Float16)y;
+                    bl[f][jj] = (_Float16)(y - (float)bh[f][jj]);
+                }
+#pragma unroll
+            for (int m = 0; m < MT; m++)
+#pragma unroll
+                for (int f = 0; f < MEL_FT; f++) {
+                    acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh[f], acc[f][m], 0, 0, 0);
+                    acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl[f], acc[f][m], 0, 0, 0);
+                    acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh[f], acc[f][m], 0, 0, 0);
+                }
+        };
+        load(sbeg, a0h, a0l);
+        if (!(dbg & 1))
+        for (int si = 0; si < spw; si += 2) {
+            if (si + 1 < spw) load(sbeg + si + 1, a1h, a1l);
+            __builtin_amdgcn_sched_barrier(0);
+            step(sbeg + si, a0h, a0l);
+            __builtin_amdgcn_sched_barrier(0);
+            if (si + 2 < spw) load(sbeg + si + 2, a0h, a0l);
+            __builtin_amdgcn_sched_barrier(0);
+            if (si + 1 < spw) step(sbeg + si + 1, a1h, a1l);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
     // Two operator register sets, used alternately (no copies): set B is loaded while set A feeds
     // the MFMAs and vice versa.  The scheduling fences keep each load a full group (96 MFMAs)
     // ahead of its use; left to itself hipcc re-loads the operator right in front of the MFMAs.
@@ -201,14 +250,18 @@ __global__ __launch_bounds__(256, 2) void mel_kernel(const float *__restrict__ x
         __builtin_amdgcn_sched_barrier(0);
         group(gbeg + gi, a0);
         __builtin_amdgcn_sched_barrier(0);
-        const int gn = gbeg + min(gi + 2, gpw - 1);
+        // (never issue a prefetch nobody consumes: hipcc re-used the destination registers of such
+        // dangling loads after the loop and the late data clobbered live values)
+        if (gi + 2 < gpw) {
 #pragma unroll
-        for (int m = 0; m < MT; m++) a0[m] = gA[((size_t)gn * MT + m) * 64];
+            for (int m = 0; m < MT; m++) a0[m] = gA[((size_t)(gbeg + gi + 2) * MT + m) * 64];
+        }
         __builtin_amdgcn_sched_barrier(0);
         group(gbeg + gi + 1, a1);
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    }  // PREC
     // cross-wave reduction: wave s parks its partials for the frame tiles it does not own
     __syncthreads();  // every wave is done reading xs
     float4 *red = reinterpret_cast<float4 *>(smem);
@@ -277,12 +330,18 @@ void launch_mel(const float *x, const float *minmax, float *spec, const Frontend
     case MTV: {                                                                                            \
         static bool attr_set = false;                                                                      \
         if (!attr_set) {                                                                                   \
-            (void)hipFuncSetAttribute((const void *)mel_kernel<MTV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute((const void *)mel_kernel<MTV, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                160 * 1024);                                                              \
+            (void)hipFuncSetAttribute((const void *)mel_kernel<MTV, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 160 * 1024);                                                              \
             attr_set = true;                                                                               \
         }                                                                                                  \
-        hipLaunchKernelGGL(mel_kernel<MTV>, grid, block, smem, s, x, minmax, spec, d_p, p.br[0].gf, p.br[1].gf,  \
-                           p.br[2].gf, p.br[3].gf, dbg);                                                   \
+        if (p.prec == 3)                                                                                   \
+            hipLaunchKernelGGL((mel_kernel<MTV, 3>), grid, block, smem, s, x, minmax, spec, d_p, p.br[0].gf,   \
+                               p.br[1].gf, p.br[2].gf, p.br[3].gf, dbg);                                   \
+        else                                                                                               \
+            hipLaunchKernelGGL((mel_kernel<MTV, 0>), grid, block, smem, s, x, minmax, spec, d_p, p.br[0].gf,   \
+                               p.br[1].gf, p.br[2].gf, p.br[3].gf, dbg);                                   \
     } break;
     switch (mt) {
         BH_MEL_CASE(2)

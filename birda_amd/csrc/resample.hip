@@ -233,14 +233,17 @@ __global__ __launch_bounds__(256) void resample_kernel(const float *__restrict__
             }
     };
     for (int gi = 0; gi < gpw; gi += 2) {   // gpw even: K % 128 == 0
+        if (gi + 1 < gpw) {   // never issue a prefetch nobody consumes (see mel_kernel)
 #pragma unroll
-        for (int m = 0; m < RS_MT; m++) a1[m] = gA[((size_t)(gbeg + min(gi + 1, gpw - 1)) * RS_MT + m) * 64];
+            for (int m = 0; m < RS_MT; m++) a1[m] = gA[((size_t)(gbeg + gi + 1) * RS_MT + m) * 64];
+        }
         __builtin_amdgcn_sched_barrier(0);
         group(gbeg + gi, a0);
         __builtin_amdgcn_sched_barrier(0);
-        const int gn = gbeg + min(gi + 2, gpw - 1);
+        if (gi + 2 < gpw) {
 #pragma unroll
-        for (int m = 0; m < RS_MT; m++) a0[m] = gA[((size_t)gn * RS_MT + m) * 64];
+            for (int m = 0; m < RS_MT; m++) a0[m] = gA[((size_t)(gbeg + gi + 2) * RS_MT + m) * 64];
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (gi + 1 < gpw) group(gbeg + gi + 1, a1);
         __builtin_amdgcn_sched_barrier(0);
