@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 SEGMENTS_PER_GPU = 1000
 MEL_BYTES_PER_SEGMENT = 968_448          # 576 000 B read + 392 448 B written
 PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
+PEAK_F16_MFMA_TFLOPS = 2500.0            # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -80,6 +81,80 @@ def pmc_traffic(kernel_prefix):
     return None
 
 
+def analyse(clf, m, info, fused, stage_tot, layer_tot, segs_done, steps, slices_per_step, precision):
+    """Roofline objects from the HIP-event timings of one timed region."""
+    from birda_amd import modelfile as mf
+
+    def macs(L):
+        px = L.out_h * L.out_w
+        if L.op == mf.OP_CONV:
+            return px * L.kh * L.kw * L.cin * L.cout
+        if L.op == mf.OP_DWCONV:
+            return px * L.kh * L.kw * L.cout
+        if L.op in (mf.OP_PWCONV, mf.OP_DENSE):
+            return px * L.cin * L.cout
+        return 0
+
+    # launches grouped by kernel: fused blocks of equal shape share one instantiation
+    groups = {}
+    layers = m.layers
+    n_stem_blocks = 1 if (fused and layers_have_fused_stem(m, layer_tot)) else 0
+    bi, i = 0, 0
+    while fused and i + 2 < len(layers) and bi + n_stem_blocks < len(fused):
+        E, D, P = layers[i], layers[i + 1], layers[i + 2]
+        if (E.op == mf.OP_PWCONV and D.op == mf.OP_DWCONV and P.op == mf.OP_PWCONV and D.in_tensor == i + 1
+                and P.in_tensor == i + 2 and layer_tot[i][1] > 0 and layer_tot[i + 1][1] == 0):
+            key = (E.cin, E.cout, P.cout, D.kh, D.sh, E.in_h, E.in_w)
+            g = groups.setdefault(key, {"ms": 0.0, "launches": 0, "macs": macs(E) + macs(D) + macs(P),
+                                        "kernel": clf.fused_kernel_name(fused[bi + n_stem_blocks])})
+            g["ms"] += layer_tot[i][0]
+            g["launches"] += layer_tot[i][1]
+            bi += 1
+            i += 3
+        else:
+            i += 1
+    out = {}
+    mb_ms, mb_launches = stage_tot.get("mbconv", (0.0, 0))
+    if groups:
+        dom_key, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
+        # this kernel runs n_blocks equal-shaped blocks per slice; every block sees every segment once
+        n_blocks = max(1, dom["launches"] // (steps * slices_per_step))
+        # the instantiation's last template argument is its MFMA type: 0 = f32, 3 = split f16 (x3), 1 = f16
+        dom_prec = int(dom["kernel"].rstrip(">").split(",")[-1])
+        if dom_prec == 0:
+            peak, note, insn = PEAK_F32_MFMA_TFLOPS, "dense f32 MFMA peak (runs at the vector rate)", "v_mfma_f32_16x16x4_f32"
+        elif dom_prec == 3:
+            peak, note, insn = (PEAK_F16_MFMA_TFLOPS / 3.0, "dense f16 MFMA peak / 3: three MFMAs per f32-grade product; the "
+                                "kernel is bound by its vector work (GELU, depthwise taps), see DESIGN.md",
+                                "3 x v_mfma_f32_16x16x32_f16 per product")
+        else:
+            peak, note, insn = PEAK_F16_MFMA_TFLOPS, "dense f16 MFMA peak", "v_mfma_f32_16x16x32_f16"
+        total_flops = 2.0 * dom["macs"] * segs_done * n_blocks
+        tflops = total_flops / (dom["ms"] * 1e-3) / 1e12
+        out["roofline"] = {
+            "kernel": "mbconv_kernel (fused expand 1x1 -> depthwise %dx%d s%d -> project 1x1, Cin %d -> %d -> %d at %dx%d, %s)"
+                      % (dom_key[3], dom_key[3], dom_key[4], dom_key[0], dom_key[1], dom_key[2], dom_key[5], dom_key[6], insn),
+            "bound": "mfma", "achieved": round(tflops, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+            "frac": round(tflops / peak, 4), "peak_note": note, "traffic": pmc_traffic(dom["kernel"]),
+            "rocprof_name": "bh::mbconv_kernel<" + dom["kernel"][len("mbconv<"):],
+            "launches": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2),
+            "algorithmic_gflop_per_launch": round(total_flops / max(dom["launches"], 1) / 1e9, 3)}
+        if mb_ms > 0:
+            flops = 2.0 * sum(g["macs"] * max(1, g["launches"] // (steps * slices_per_step)) for g in groups.values()) * segs_done
+            out["all_fused_blocks"] = {"achieved": round(flops / (mb_ms * 1e-3) / 1e12, 2), "unit": "TFLOP/s (algorithmic)",
+                                       "launches": mb_launches, "us_per_segment": round(mb_ms * 1e3 / segs_done, 3)}
+    mel_ms, mel_launches = stage_tot["mel"]
+    mel_gbps = MEL_BYTES_PER_SEGMENT * segs_done / (mel_ms * 1e-3) / 1e9
+    out["roofline_mel"] = {"kernel": "mel_kernel (folded STFT x mel, %s)" % (
+                               "split f16 x3 MFMA" if precision == "f16x3" else "v_mfma_f32_16x16x4_f32"), "bound": "hbm",
+                           "achieved": round(mel_gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                           "frac": round(mel_gbps / PEAK_HBM_GBPS, 4), "traffic": pmc_traffic("bh::mel_kernel"),
+                           "launches": mel_launches, "avg_launch_us": round(mel_ms * 1e3 / max(mel_launches, 1), 2),
+                           "mfma_tflops": round(info.mel_flops_per_segment * segs_done / (mel_ms * 1e-3) / 1e12, 2)}
+    out["stage_us_per_segment"] = {k: round(v[0] * 1e3 / segs_done, 3) for k, v in stage_tot.items()}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,6 +162,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--micro-batch", type=int, default=int(os.environ.get("BIRDA_HIP_MICRO_BATCH", "1000")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default=os.environ.get("BIRDA_HIP_BENCH_PRECISION", "f16x3"),
+                    choices=["f32", "f16x3", "f16"],
+                    help="GEMM operands: f16x3 = f32 values split into f16 hi + lo, three f16 MFMAs per product, "
+                         "f32 accumulate (same fp32 logit tolerance as f32); f32 = v_mfma_f32_16x16x4_f32 everywhere")
     args = ap.parse_args()
 
     import numpy as np
@@ -111,7 +190,7 @@ def main():
     model_path = os.path.join(tmp, "birdnet_v24_synth.bhm")
     m = synth.build_model("birdnet_v24")
     mf.write_model(model_path, m)
-    clf = BirdClassifier(model_path, None, top_k=5, min_confidence=0.1, device=local_rank)
+    clf = BirdClassifier(model_path, None, top_k=5, min_confidence=0.1, device=local_rank, precision=args.precision)
     ctx = clf.create_batch_context(args.micro_batch)
     info = clf.info
     fused = clf.fused_blocks()
@@ -167,45 +246,7 @@ def main():
 
     value = n_total * args.steps / elapsed
     segs_done = n_local * args.steps
-
-    def macs(L):
-        px = L.out_h * L.out_w
-        if L.op == mf.OP_CONV:
-            return px * L.kh * L.kw * L.cin * L.cout
-        if L.op == mf.OP_DWCONV:
-            return px * L.kh * L.kw * L.cout
-        if L.op in (mf.OP_PWCONV, mf.OP_DENSE):
-            return px * L.cin * L.cout
-        return 0
-
-    # launches grouped by kernel: fused blocks of equal shape share one instantiation
-    groups = {}
-    li, bi = 0, 0
-    n_stem_blocks = 1 if (fused and layers_have_fused_stem(m, layer_tot)) else 0
-    layers = m.layers
-    fused_layers = set()
-    if fused:
-        # fused blocks start at the expand layer of every pw -> dw -> pw triple the library fused
-        i = 0
-        while i + 2 < len(layers) and bi < len(fused):
-            E, D, P = layers[i], layers[i + 1], layers[i + 2]
-            if (E.op == mf.OP_PWCONV and D.op == mf.OP_DWCONV and P.op == mf.OP_PWCONV and D.in_tensor == i + 1
-                    and P.in_tensor == i + 2 and layer_tot[i][1] > 0 and layer_tot[i + 1][1] == 0):
-                key = ("mbconv", E.cin, E.cout, P.cout, D.kh, D.sh, E.in_h, E.in_w)
-                g = groups.setdefault(key, {"ms": 0.0, "launches": 0, "macs": macs(E) + macs(D) + macs(P),
-                                            "kernel": clf.fused_kernel_name(fused[bi + n_stem_blocks])})
-                g["ms"] += layer_tot[i][0]
-                g["launches"] += layer_tot[i][1]
-                fused_layers.add(i)
-                bi += 1
-                i += 3
-            else:
-                i += 1
-    dom_key, dom = (max(groups.items(), key=lambda kv: kv[1]["ms"]) if groups else (None, None))
-    mel_ms, mel_launches = stage_tot["mel"]
-    mel_gbps = MEL_BYTES_PER_SEGMENT * segs_done / (mel_ms * 1e-3) / 1e9
-    mb_ms, mb_launches = stage_tot.get("mbconv", (0.0, 0))
-    mb_macs = sum(g["macs"] * g["launches"] for g in groups.values())   # per segment x launches (launch = n_local segs)
+    slices_per_step = max(1, -(-n_local // args.micro_batch))
     out = {
         "metric": "3s/48kHz segments/sec (BirdNET v2.4)", "value": round(value, 1), "unit": "segments/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -215,34 +256,43 @@ def main():
                                "seeded synthetic BirdNET-v2.4-shaped model (EfficientNet-B0-like, 6522 classes)",
                    "segments_per_gpu": n_local, "micro_batch": args.micro_batch,
                    "gflop_per_segment": round((2 * info.macs_per_segment + info.mel_flops_per_segment) / 1e9, 3),
-                   "fused_blocks": len(fused)},
+                   "fused_blocks": len(fused), "precision": args.precision,
+                   "gemm": {"f32": "v_mfma_f32_16x16x4_f32 (exact f32 fmaf chains)",
+                            "f16x3": "f32 operands split into f16 hi + lo, 3 x v_mfma_f32_16x16x32_f16 per product, f32 "
+                                     "accumulate (|err| ~1e-7 of sum|a b|, same fp32 logit tolerance as the f32 MFMA path, "
+                                     "tests/test_parity_gpu.py); stem block on the f32 MFMA",
+                            "f16": "operands rounded to f16, v_mfma_f32_16x16x32_f16, f32 accumulate"}[args.precision]},
     }
-    if dom:
-        # this kernel runs n_blocks equal-shaped blocks per slice; every block sees every segment once
-        n_blocks = dom["launches"] // (args.steps * max(1, -(-n_local // args.micro_batch)))
-        total_flops = 2.0 * dom["macs"] * segs_done * n_blocks
-        tflops = total_flops / (dom["ms"] * 1e-3) / 1e12
-        out["roofline"] = {
-            "kernel": "mbconv_kernel (fused expand 1x1 -> depthwise %dx%d s%d -> project 1x1, Cin %d -> %d -> %d at %dx%d, "
-                      "v_mfma_f32_16x16x4_f32)" % (dom_key[4], dom_key[4], dom_key[5], dom_key[1], dom_key[2], dom_key[3],
-                                                   dom_key[6], dom_key[7]),
-            "bound": "mfma", "achieved": round(tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(dom["kernel"]),
-            "rocprof_name": "bh::mbconv_kernel<" + dom["kernel"][len("mbconv<"):],
-            "launches": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2),
-            "algorithmic_gflop_per_launch": round(total_flops / max(dom["launches"], 1) / 1e9, 3)}
-        if mb_ms > 0:
-            out["roofline_all_fused_blocks"] = {
-                "achieved": round(2.0 * sum(g["macs"] * (g["launches"] // (args.steps * max(1, -(-n_local // args.micro_batch))))
-                                            for g in groups.values()) * segs_done / (mb_ms * 1e-3) / 1e12, 2),
-                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "launches": mb_launches}
-            out["roofline_all_fused_blocks"]["frac"] = round(out["roofline_all_fused_blocks"]["achieved"] / PEAK_F32_MFMA_TFLOPS, 4)
-    out["roofline_mel"] = {"kernel": "mel_kernel (folded STFT x mel, v_mfma_f32_16x16x4_f32)", "bound": "hbm",
-                           "achieved": round(mel_gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                           "frac": round(mel_gbps / PEAK_HBM_GBPS, 4), "traffic": pmc_traffic("bh::mel_kernel"),
-                           "launches": mel_launches, "avg_launch_us": round(mel_ms * 1e3 / max(mel_launches, 1), 2),
-                           "mfma_tflops": round(info.mel_flops_per_segment * segs_done / (mel_ms * 1e-3) / 1e12, 2)}
-    out["stage_us_per_segment"] = {k: round(v[0] * 1e3 / segs_done, 3) for k, v in stage_tot.items()}
+    out.update(analyse(clf, m, info, fused, stage_tot, layer_tot, segs_done, args.steps, slices_per_step, args.precision))
+    if rank == 0 and world == 1 and args.precision != "f32":
+        # the exact-f32 MFMA path, measured beside it on the same inputs (a few steps; not the headline)
+        ctx.close()
+        clf.close()
+        clf = BirdClassifier(model_path, None, top_k=5, min_confidence=0.1, device=local_rank, precision="f32")
+        ctx = clf.create_batch_context(args.micro_batch)
+        for _ in range(2):
+            step()
+        sync_all()
+        ctx.set_profiling(True)
+        st2, ly2 = {}, [[0.0, 0] for _ in range(int(info.n_layers))]
+        k2 = max(3, min(args.steps, 5))
+        t2 = time.perf_counter()
+        for _ in range(k2):
+            step()
+            for k, (ms, n) in ctx.stage_ms().items():
+                a = st2.setdefault(k, [0.0, 0])
+                a[0] += ms
+                a[1] += n
+            for i, (ms, n) in enumerate(ctx.layer_ms()):
+                ly2[i][0] += ms
+                ly2[i][1] += n
+        sync_all()
+        e2 = time.perf_counter() - t2
+        ctx.set_profiling(False)
+        f32 = {"value": round(n_local * k2 / e2, 1), "unit": "segments/s", "steps": k2,
+               "gemm": "v_mfma_f32_16x16x4_f32 in every kernel"}
+        f32.update(analyse(clf, m, info, clf.fused_blocks(), st2, ly2, n_local * k2, k2, slices_per_step, "f32"))
+        out["f32_mfma_path"] = f32
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(model_path, m.sample_count, m.sample_rate)
     elif rank == 0:
