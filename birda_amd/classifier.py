@@ -203,6 +203,32 @@ class BirdClassifier:
         check(self._L.bh_forward_device(self._h, ctx._h, d_segments, n, d_logits, d_topk_index or None,
                                         d_topk_conf or None))
 
+    # ---- decoded PCM16 stream in, per-segment results out (device-side front-end) ----
+    def segment_starts(self, n_frames: int, segment_samples: int, overlap_samples: int) -> List[int]:
+        n = int(self._L.bh_segment_starts(n_frames, segment_samples, overlap_samples, None, 0))
+        buf = (C.c_uint64 * max(n, 1))()
+        self._L.bh_segment_starts(n_frames, segment_samples, overlap_samples, buf, n)
+        return [int(buf[i]) for i in range(n)]
+
+    def predict_pcm16(self, ctx: BatchInferenceContext, pcm: np.ndarray, source_rate: int, overlap_samples: int = 0):
+        """pcm: int16 [frames] or [frames, channels].  Returns (results, start_samples)."""
+        a = np.ascontiguousarray(pcm, np.int16)
+        channels = 1 if a.ndim == 1 else a.shape[1]
+        n_frames = a.shape[0]
+        cap = n_frames // max(1, self.sample_count() // 4) + 8   # generous: overlap < segment
+        cap = max(cap, 8)
+        while True:
+            res = (BhResult * cap)()
+            starts = (C.c_uint64 * cap)()
+            n = C.c_size_t()
+            rc = self._L.bh_predict_pcm16(self._h, ctx._h, a.ctypes.data, n_frames, channels, source_rate, overlap_samples,
+                                          res, cap, C.byref(n), starts)
+            if rc != 0 and int(n.value) > cap:
+                cap = int(n.value)
+                continue
+            check(rc)
+            return self._results(res, int(n.value)), [int(starts[i]) for i in range(int(n.value))]
+
     # ---- resampler (reference src/audio/resample.rs:10-105) ----
     def resample(self, samples: np.ndarray, from_rate: int, to_rate: int) -> np.ndarray:
         x = np.ascontiguousarray(samples, np.float32)

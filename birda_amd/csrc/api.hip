@@ -950,6 +950,97 @@ int bh_predict_batch_source_rate(bh_classifier *c, bh_batch_context *ctx, const 
     return BH_OK;
 }
 
+size_t bh_segment_starts(size_t n_frames, size_t segment_samples, size_t overlap_samples, uint64_t *starts, size_t cap) {
+    // StreamingDecoder::next_segment over a stream of n_frames (decode.rs:150-202): take = min(seg, left);
+    // emit at the running start; advance take - overlap, or stop when that is <= 0 (the buffer is cleared)
+    if (overlap_samples >= segment_samples || segment_samples == 0) return 0;
+    size_t n = 0, pos = 0;
+    while (pos < n_frames) {
+        const size_t take = std::min(segment_samples, n_frames - pos);
+        if (starts && n < cap) starts[n] = pos;
+        n++;
+        if (take <= overlap_samples) break;
+        pos += take - overlap_samples;
+    }
+    return n;
+}
+
+int bh_predict_pcm16(bh_classifier *c, bh_batch_context *ctx, const int16_t *pcm, size_t n_frames, uint32_t channels,
+                     uint32_t source_rate, size_t overlap_samples, bh_result *out, size_t out_cap, size_t *n_segments,
+                     uint64_t *start_samples) {
+    int rc = check_ctx(c, ctx);
+    if (rc != BH_OK) return rc;
+    if (!pcm || !out || !n_segments || channels == 0) return fail(BH_ERR_INVALID, "predict_pcm16: bad arguments");
+    const auto &h = c->model.h;
+    const bool resampling = source_rate != h.sample_rate;
+    // segment and overlap lengths at the source rate (processor.rs:67-82)
+    const size_t seg = resampling ? (size_t)std::ceil((double)h.sample_count * source_rate / h.sample_rate) : h.sample_count;
+    const size_t ovl = resampling ? (size_t)std::ceil((double)overlap_samples * source_rate / h.sample_rate) : overlap_samples;
+    if (ovl >= seg) return fail(BH_ERR_INVALID, "overlap (%zu) must be shorter than the segment (%zu)", ovl, seg);
+    const size_t nseg = bh_segment_starts(n_frames, seg, ovl, nullptr, 0);
+    *n_segments = nseg;
+    if (nseg > out_cap) return fail(BH_ERR_INVALID, "predict_pcm16: %zu segments, room for %zu", nseg, out_cap);
+    if (nseg == 0) return BH_OK;
+    std::vector<uint64_t> starts(nseg);
+    bh_segment_starts(n_frames, seg, ovl, starts.data(), nseg);
+    if (start_samples) memcpy(start_samples, starts.data(), nseg * sizeof(uint64_t));
+    HIPCHK(hipSetDevice(c->device));
+    // the whole stream travels once, as int16 (a quarter of the f32 segments when they overlap by half)
+    int16_t *d_pcm = nullptr;
+    unsigned long long *d_starts = nullptr;
+    const size_t pcm_bytes = n_frames * channels * sizeof(int16_t);
+    HIPCHK(hipMalloc((void **)&d_pcm, pcm_bytes));
+    if (hipMalloc((void **)&d_starts, nseg * sizeof(unsigned long long)) != hipSuccess) { (void)hipFree(d_pcm); return fail(BH_ERR_HIP, "hipMalloc failed"); }
+    auto cleanup = [&]() { (void)hipFree(d_pcm); (void)hipFree(d_starts); };
+    if (hipMemcpyAsync(d_pcm, pcm, pcm_bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(d_starts, starts.data(), nseg * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        cleanup();
+        return fail(BH_ERR_HIP, "predict_pcm16: upload failed");
+    }
+    if (resampling && ctx->raw_len < seg) {
+        (void)hipFree(ctx->d_raw); (void)hipHostFree(ctx->h_raw);
+        ctx->d_raw = nullptr; ctx->h_raw = nullptr; ctx->raw_len = 0;
+        if (hipMalloc((void **)&ctx->d_raw, ctx->max_batch * seg * sizeof(float)) != hipSuccess ||
+            hipHostMalloc((void **)&ctx->h_raw, ctx->max_batch * seg * sizeof(float), hipHostMallocDefault) != hipSuccess) {
+            cleanup();
+            return fail(BH_ERR_HIP, "predict_pcm16: scratch allocation failed");
+        }
+        ctx->raw_len = seg;
+    }
+    for (size_t b0 = 0; b0 < nseg; b0 += ctx->max_batch) {
+        const size_t nb = std::min(ctx->max_batch, nseg - b0);
+        if (resampling) {
+            bh::launch_segment_pcm16(d_pcm, n_frames, (int)channels, d_starts + b0, (int)nb, (int)seg, ctx->d_raw, seg, ctx->stream);
+            rc = bh_resample_device(c, ctx, ctx->d_raw, seg, seg, source_rate, h.sample_rate, ctx->d_input, h.sample_count,
+                                    h.sample_count, nb);
+            if (rc != BH_OK) { cleanup(); return rc; }
+        } else {
+            bh::launch_segment_pcm16(d_pcm, n_frames, (int)channels, d_starts + b0, (int)nb, (int)seg, ctx->d_input, seg, ctx->stream);
+        }
+        rc = forward_slice(c, ctx, ctx->d_input, nb, ctx->d_logits, ctx->d_topk_idx, ctx->d_topk_conf);
+        if (rc != BH_OK) { cleanup(); return rc; }
+        if (hipMemcpyAsync(ctx->h_topk_idx, ctx->d_topk_idx, nb * c->top_k * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(ctx->h_topk_conf, ctx->d_topk_conf, nb * c->top_k * sizeof(float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            cleanup();
+            return fail(BH_ERR_HIP, "predict_pcm16: result download failed");
+        }
+        for (size_t i = 0; i < nb; i++) {
+            bh_result &r = out[b0 + i];
+            r.n_pred = 0;
+            for (uint32_t k = 0; k < c->top_k; k++) {
+                const int32_t id = ctx->h_topk_idx[i * c->top_k + k];
+                if (id < 0) break;
+                r.index[r.n_pred] = id;
+                r.confidence[r.n_pred] = ctx->h_topk_conf[i * c->top_k + k];
+                r.n_pred++;
+            }
+        }
+    }
+    cleanup();
+    return BH_OK;
+}
+
 int bh_resample_output_len(size_t n_in, uint32_t from_rate, uint32_t to_rate, size_t *n_out) {
     if (!n_out || from_rate == 0 || to_rate == 0) return fail(BH_ERR_INVALID, "resample_output_len: bad arguments");
     *n_out = bh::resample_output_len(n_in, from_rate, to_rate);

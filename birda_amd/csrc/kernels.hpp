@@ -82,6 +82,9 @@ struct FrontendParams {
     float norm_eps;
 };
 
+// interleaved PCM16 on the device -> mono f32 segments starting at d_starts[i] (zero-padded tail)
+void launch_segment_pcm16(const int16_t *d_pcm, size_t n_frames, int channels, const unsigned long long *d_starts,
+                          int n_seg, int seg_len, float *d_out, size_t out_stride, hipStream_t s);
 void launch_minmax(const float *x, float *minmax, int n_seg, int sample_count, hipStream_t s);
 void launch_mel(const float *x, const float *minmax, float *spec, const FrontendParams &p,
                 const FrontendParams *d_p, int n_seg, hipStream_t s);

@@ -10,6 +10,7 @@
 //   y_t[j] = x[tH + j + 1] + x[tH + L - 1 - j]      (j = 0..K-1; last row of Gf halved)
 // and spec_t = Gf^T y_t: a [n_mels x K] x [K x n_frames] GEMM per segment and branch, run on
 // the f32 MFMA (v_mfma_f32_16x16x4_f32, exact f32 fmaf chains).
+#include <algorithm>
 #include <cstdlib>
 
 #include "kernels.hpp"
@@ -66,6 +67,40 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ x
 
 void launch_minmax(const float *x, float *minmax, int n_seg, int sample_count, hipStream_t s) {
     hipLaunchKernelGGL(minmax_kernel, dim3(MM_SPLIT, n_seg), dim3(256), 0, s, x, minmax, sample_count);
+}
+
+// ---------------------------------------------------------------------------------------
+// PCM16 -> mono f32 segments on the device (reference src/audio/decode.rs:353-411 append_samples:
+// s / 32768.0 per channel, channels summed then divided by their count; :150-202 next_segment: the
+// segment is zero-padded past the end of the stream).  grid (blocks over the segment, n_seg).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void segment_pcm16_kernel(const int16_t *__restrict__ pcm, long n_frames, int channels,
+                                                             const unsigned long long *__restrict__ starts,
+                                                             int seg_len, float *__restrict__ out, long out_stride) {
+    const int seg = blockIdx.y;
+    const long s0 = (long)starts[seg];
+    float *o = out + (long)seg * out_stride;
+    for (int j = blockIdx.x * 256 + threadIdx.x; j < seg_len; j += gridDim.x * 256) {
+        const long f = s0 + j;
+        float v = 0.0f;
+        if (f < n_frames) {
+            if (channels == 1) {
+                v = (float)pcm[f] / 32768.0f;
+            } else {
+                float sum = 0.0f;
+                for (int c = 0; c < channels; c++) sum += (float)pcm[f * channels + c] / 32768.0f;
+                v = sum / (float)channels;
+            }
+        }
+        o[j] = v;
+    }
+}
+
+void launch_segment_pcm16(const int16_t *d_pcm, size_t n_frames, int channels, const unsigned long long *d_starts,
+                          int n_seg, int seg_len, float *d_out, size_t out_stride, hipStream_t s) {
+    dim3 grid((unsigned)std::min<size_t>(((size_t)seg_len + 255) / 256, 64), n_seg), block(256);
+    hipLaunchKernelGGL(segment_pcm16_kernel, grid, block, 0, s, d_pcm, (long)n_frames, channels, d_starts, seg_len, d_out,
+                       (long)out_stride);
 }
 
 // ---------------------------------------------------------------------------------------

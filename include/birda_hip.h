@@ -188,6 +188,21 @@ BH_API int bh_debug_mb_stamps(bh_classifier *c, uint64_t *out, size_t cap);
 BH_API int bh_predict_batch_source_rate(bh_classifier *c, bh_batch_context *ctx, const float *const *segments,
                                         size_t n, size_t n_src_samples, uint32_t source_rate, bh_result *out);
 
+/* ---- decoded PCM in, detections out (the file front-end on the device) -------
+ * StreamingDecoder::next_segment over a stream of n_frames (decode.rs:150-202): start sample of
+ * every segment, including the short trailing one an overlap leaves behind.  Returns the count;
+ * starts (nullable) receives min(count, cap) entries. */
+BH_API size_t bh_segment_starts(size_t n_frames, size_t segment_samples, size_t overlap_samples, uint64_t *starts,
+                                size_t cap);
+/* One decoded stream of interleaved PCM16 (host): uploaded once as int16, then on the device
+ * append_samples' scaling and mono mix (decode.rs:353-411), next_segment's windows and zero padding,
+ * resample_chunk + resize when source_rate differs from the model rate (processor.rs:84-87), and the
+ * classifier.  overlap_samples is counted at the model rate (processor.rs:520).  out receives one
+ * result per segment; start_samples (nullable) their start positions at the source rate. */
+BH_API int bh_predict_pcm16(bh_classifier *c, bh_batch_context *ctx, const int16_t *pcm, size_t n_frames,
+                            uint32_t channels, uint32_t source_rate, size_t overlap_samples, bh_result *out,
+                            size_t out_cap, size_t *n_segments, uint64_t *start_samples);
+
 /* ---- resampler (reference src/audio/resample.rs:10-105; rubato Fft<f32>, FixedSync::Both,
  * chunk 1024, one new resampler per segment).  The device kernel applies rubato's block
  * operator as a polyphase GEMM (birda_amd/csrc/resample.hip); identity when the rates are equal.

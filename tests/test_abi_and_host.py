@@ -230,3 +230,21 @@ def test_resample_output_length_matches_the_block_rule(L, oracle_lib):
             assert L.bh_resample_output_len(n, frm, to, C.byref(out)) == 0
             want = len(oracle_lib.resample(np.zeros(n, np.float32), frm, to)) if n else 0
             assert out.value == want, (frm, to, n)
+
+
+def test_segment_starts_match_reference_traces_and_the_oracle_segmenter(L, cases, oracle_lib):
+    """bh_segment_starts = StreamingDecoder::next_segment's start positions (decode.rs:150-202), including
+    the trailing tail segment an overlap leaves behind; pure host arithmetic, no GPU needed."""
+    def starts(n, seg, ovl):
+        cnt = L.bh_segment_starts(n, seg, ovl, None, 0)
+        buf = (C.c_uint64 * max(cnt, 1))()
+        assert L.bh_segment_starts(n, seg, ovl, buf, cnt) == cnt
+        return [int(buf[i]) for i in range(cnt)]
+    for c in cases["segmenter"]:
+        assert starts(c["n_samples"], c["seg"], c["ovl"]) == c["starts"], c["src"]
+    rng = np.random.default_rng(5)
+    for _ in range(40):
+        seg = int(rng.integers(2, 60)); ovl = int(rng.integers(0, seg)); n = int(rng.integers(0, 400))
+        want = [s for _, s in oracle_lib.segment_stream(np.zeros(n, np.float32), seg, ovl, packet=int(rng.integers(1, 50)))]
+        assert starts(n, seg, ovl) == want, (n, seg, ovl)
+    assert starts(100, 10, 10) == [] and starts(100, 10, 12) == []     # overlap >= segment: Error::Internal upstream

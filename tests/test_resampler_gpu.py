@@ -156,3 +156,41 @@ def test_c5_mixed_rate_files_through_the_pipeline(oracle_lib, model_dir, tmp_pat
             fa, fb = a.rsplit(",", 2), b.rsplit(",", 2)
             assert fa[0] == fb[0] and fa[2] == fb[2] and abs(float(fa[1]) - float(fb[1])) <= 2e-4, (rate, a, b)
     clf.close()
+
+
+def test_pcm16_stream_is_segmented_scaled_and_mixed_on_the_device(oracle_lib, model_dir):
+    """bh_predict_pcm16: one int16 upload, then append_samples + next_segment (+ resample) on the GPU.
+    Against the oracle's host restatement of the same steps feeding the oracle's forward."""
+    from birda_amd.classifier import BirdClassifier
+    path, labels, m, names = model_dir["birdnet_v24_tiny"]
+    om = oracle_lib.OracleModel(path)
+    clf = BirdClassifier(path, labels, top_k=5, min_confidence=0.0)
+    ctx = clf.create_batch_context(3)           # smaller than the segment count: several slices
+    rng = np.random.default_rng(11)
+    for rate, channels, overlap_s in ((48000, 1, 0.0), (48000, 2, 1.0), (44100, 1, 0.5), (22050, 2, 0.0)):
+        n = int(8.3 * rate)
+        t = np.arange(n) / rate
+        x = 0.2 * rng.standard_normal((n, channels)) + 0.4 * np.sin(2 * np.pi * 2100 * t)[:, None]
+        pcm = np.clip(np.round(x * 32767.0), -32768, 32767).astype(np.int16)
+        ovl = int(np.float32(overlap_s) * np.float32(m.sample_rate))
+        res, starts = clf.predict_pcm16(ctx, pcm if channels > 1 else pcm[:, 0], rate, ovl)
+        # oracle: PCM scaling + mono mix, segmenter at the source rate, resample + resize, forward, top-k
+        mono = np.zeros(n, np.float32)
+        oracle_lib.lib().bo_pcm16_to_mono(pcm.ctypes.data, n, channels, mono)
+        seg_src = int(oracle_lib.lib().bo_source_samples(m.sample_count, rate, m.sample_rate))
+        ovl_src = int(oracle_lib.lib().bo_source_samples(ovl, rate, m.sample_rate))
+        want = oracle_lib.segment_stream(mono, seg_src, ovl_src)
+        assert starts == [s for _, s in want], (rate, channels, overlap_s)
+        segs = np.zeros((len(want), m.sample_count), np.float32)
+        for i, (raw, _) in enumerate(want):
+            r = oracle_lib.resample(raw, rate, m.sample_rate)
+            segs[i, : min(len(r), m.sample_count)] = r[: m.sample_count]
+        ref = om.forward(segs)
+        assert len(res) == len(want)
+        for i, r in enumerate(res):
+            conf = 1.0 / (1.0 + np.exp(-ref[i].astype(np.float64)))
+            for p in r.predictions:                     # every reported class carries the oracle's confidence
+                assert abs(p.confidence - conf[p.index]) <= 2e-4, (rate, channels, i, p.index)
+            top = np.sort(conf)[::-1]
+            assert abs(r.predictions[0].confidence - top[0]) <= 2e-4
+    ctx.close(); clf.close()
