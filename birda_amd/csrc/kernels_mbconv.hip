@@ -613,6 +613,10 @@ const MbCfg kCfgs[] = {
     MB_ENTRY_P(3, 2, 16, 2, 7, 1, 2, 2, 3, 3, 4, 1, 6, 1, 2, 0, 3),    // 52: as 15
     MB_ENTRY_P(3, 1, 16, 1, 3, 1, 4, 1, 2, 1, 4, 1, 8, 1, 3, 2, 3),    // 53: as 20 (2-channel stem)
     MB_ENTRY_P(3, 1, 16, 1, 3, 1, 4, 1, 2, 1, 4, 1, 8, 1, 3, 1, 3),    // 54: as 21 (1-channel stem)
+    MB_ENTRY_P(3, 1, 16, 3, 3, 1, 4, 1, 3, 5, 5, 2, 6, 1, 2, 0, 3),    // 55: as 16 (80 -> 480 -> 80, 6x32)
+    MB_ENTRY_P(5, 1, 16, 3, 3, 1, 4, 1, 3, 7, 5, 2, 6, 1, 2, 0, 3),    // 56: as 17
+    MB_ENTRY_P(5, 1, 16, 4, 3, 1, 4, 1, 3, 7, 5, 2, 6, 1, 2, 0, 3),    // 57: as 18 (112 -> 672 -> 112)
+    MB_ENTRY_P(5, 2, 16, 4, 3, 1, 1, 4, 3, 3, 4, 0, 3, 1, 2, 0, 3),    // 58: as 19
 };
 constexpr int kNCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
@@ -695,7 +699,9 @@ bool mb_plan(MbDesc &d, int force_cfg) {
     // measured on MI355X (profiles/): 16-channel chunks (2-4 workgroups per CU) win wherever an
     // instantiation exists; the 192-channel 3x16 blocks need two column-split waves and stay at 32
     static const int kPreferred[] = {11, 12, 13, 14, 15, 16, 17, 18, 19, 9, 10, 20, 21};
-    static const int kPreferred16[] = {48, 49, 50, 51, 52};   // split-f16, 16-channel chunks: the early blocks
+    // split-f16 with 16-channel chunks (two or more workgroups per CU): the early blocks, and the 6x32
+    // blocks whose depthwise phase is light enough (3x3, and the stride-2 5x5)
+    static const int kPreferred16[] = {48, 49, 50, 51, 52, 55, 58};
     if (d.prec == 0)
         for (int ci : kPreferred) {  // at the entry's own tile height: the shapes it was measured on
             MbDesc t = d;

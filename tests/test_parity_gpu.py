@@ -352,7 +352,7 @@ def test_every_fused_tile_configuration(model_dir, oracle_lib, monkeypatch):
     scale = max(1.0, float(np.abs(ref).max()))
     monkeypatch.setenv("BIRDA_HIP_F16X3_ALL", "1")
     used = set()
-    for cfg in range(55):
+    for cfg in range(59):
         prec = "f32" if cfg < 22 else ("f16x3" if (cfg % 2 == 0 or cfg >= 48) else "f16")
         monkeypatch.setenv("BIRDA_HIP_MB_CFG", str(cfg))
         clf = BirdClassifier(path, precision=prec)
@@ -370,7 +370,7 @@ def test_every_fused_tile_configuration(model_dir, oracle_lib, monkeypatch):
             _logit_close(got, ref)
         ctx.close(); clf.close()
     # 21 and 46/47 are the 1-channel stem variants: exercised by the Perch-shaped test
-    assert used == set(range(55)) - {21, 46, 47, 54}, sorted(set(range(55)) - used)
+    assert used == set(range(59)) - {21, 46, 47, 54}, sorted(set(range(59)) - used)
 
 
 def test_precision_modes_on_the_full_model(full_model, oracle_lib):
