@@ -617,6 +617,10 @@ const MbCfg kCfgs[] = {
     MB_ENTRY_P(5, 1, 16, 3, 3, 1, 4, 1, 3, 7, 5, 2, 6, 1, 2, 0, 3),    // 56: as 17
     MB_ENTRY_P(5, 1, 16, 4, 3, 1, 4, 1, 3, 7, 5, 2, 6, 1, 2, 0, 3),    // 57: as 18 (112 -> 672 -> 112)
     MB_ENTRY_P(5, 2, 16, 4, 3, 1, 1, 4, 3, 3, 4, 0, 3, 1, 2, 0, 3),    // 58: as 19
+    // half-image tiles (3x32 of a 6x32 image) for the 5x5 blocks: 1.67x the expand work (cheap on the f16
+    // MFMA) buys two or three workgroups per CU, whose phases then overlap
+    MB_ENTRY_P(5, 1, 16, 4, 3, 1, 2, 2, 3, 4, 5, 2, 3, 1, 2, 0, 3),    // 59: 112 -> 672 -> 112
+    MB_ENTRY_P(5, 1, 16, 3, 3, 1, 2, 2, 3, 4, 5, 2, 3, 1, 2, 0, 3),    // 60: 80 -> 480 -> 112
 };
 constexpr int kNCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
