@@ -14,8 +14,26 @@ def timeit(fn, sync, n=5):
     return (time.perf_counter() - t) / n
 
 N = 1000
+PREC = os.environ.get("BIRDA_HIP_BENCH_PRECISION", "f16x3")
 m = synth.build_model("birdnet_v24"); p = "/tmp/v24.bhm"; mf.write_model(p, m)
-clf = BirdClassifier(p); ctx = clf.create_batch_context(N)
+clf = BirdClassifier(p, precision=PREC); ctx = clf.create_batch_context(N)
+# PCIe-inclusive: host f32 segments -> pinned staging -> device -> classify -> top-k back (bh_predict_batch_contig)
+import ctypes as C
+from birda_amd._lib import BhResult
+hseg = np.tile(synth.synth_segments(8, m.sample_count, m.sample_rate), (N // 8, 1))
+res = (BhResult * N)()
+def host_path():
+    rc = clf._L.bh_predict_batch_contig(clf._h, ctx._h, hseg.ctypes.data, N, res)
+    assert rc == 0
+dt = timeit(host_path, lambda: None, 3)
+print(f"host f32 segments in, top-k out (PCIe inclusive, bh_predict_batch_contig): {N/dt:.0f} seg/s ({hseg.nbytes/dt/1e9:.1f} GB/s of PCM)")
+pcm = np.clip(np.round(hseg.reshape(-1) * 32767), -32768, 32767).astype(np.int16)
+cap = N + 8; res2 = (BhResult * cap)(); nseg = C.c_size_t()
+def pcm_path():
+    rc = clf._L.bh_predict_pcm16(clf._h, ctx._h, pcm.ctypes.data, pcm.size, 1, m.sample_rate, 0, res2, cap, C.byref(nseg), None)
+    assert rc == 0 and nseg.value == N
+dt = timeit(pcm_path, lambda: None, 3)
+print(f"host int16 stream in (bh_predict_pcm16, device-side segmenting): {N/dt:.0f} seg/s ({pcm.nbytes/dt/1e9:.1f} GB/s of PCM)")
 out = torch.empty((N, m.sample_count), device="cuda")
 logits = torch.empty((N, m.n_classes), device="cuda")
 for rate in (44100, 22050):
@@ -30,7 +48,7 @@ for rate in (44100, 22050):
     print(f"  resample + classify: {N/dt:.0f} seg/s")
 ctx.close(); clf.close()
 m = synth.build_model("perch_v2"); p = "/tmp/perch.bhm"; mf.write_model(p, m)
-clf = BirdClassifier(p); ctx = clf.create_batch_context(N)
+clf = BirdClassifier(p, precision=PREC); ctx = clf.create_batch_context(N)
 print("perch fused blocks:", clf.fused_blocks())
 x = torch.from_numpy(np.tile(synth.synth_segments(8, m.sample_count, m.sample_rate), (N // 8, 1))).cuda()
 logits = torch.empty((N, m.n_classes), device="cuda")
