@@ -621,6 +621,10 @@ const MbCfg kCfgs[] = {
     // MFMA) buys two or three workgroups per CU, whose phases then overlap
     MB_ENTRY_P(5, 1, 16, 4, 3, 1, 2, 2, 3, 4, 5, 2, 3, 1, 2, 0, 3),    // 59: 112 -> 672 -> 112
     MB_ENTRY_P(5, 1, 16, 3, 3, 1, 2, 2, 3, 4, 5, 2, 3, 1, 2, 0, 3),    // 60: 80 -> 480 -> 112
+    // 32-wide tiles for the large early images: half the workgroups, half the per-workgroup set-up
+    MB_ENTRY_P(3, 2, 16, 1, 10, 1, 4, 1, 2, 2, 5, 1, 4, 1, 2, 0, 3),   // 61: as 48, tile 4x32
+    MB_ENTRY_P(3, 1, 16, 1, 6, 1, 4, 1, 4, 2, 5, 2, 8, 1, 2, 0, 3),    // 62: as 49, tile 8x32
+    MB_ENTRY_S(3, 1, 16, 2, 6, 1, 4, 1, 4, 1, 5, 2, 8, 1, 2, 2),       // 63: as 20 (stem, f32), tile 8x32
 };
 constexpr int kNCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
