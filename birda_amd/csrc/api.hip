@@ -57,6 +57,7 @@ struct bh_classifier {
     float *d_blob = nullptr;                 // raw model blob (dw / conv weights, biases)
     std::vector<float *> d_w;                // per layer: weights as the kernels want them
     std::vector<int> ldw;                    // per layer: padded row length of d_w (pw / dense)
+    std::vector<void *> d_w16;               // per layer: f16 hi / lo fragment planes (pw / dense outside fused blocks), or null
     std::vector<float *> d_owned;            // re-laid buffers to free
     bh::FrontendParams fe{};
     bh::FrontendParams *d_fe = nullptr;      // device copy read by the mel kernel
@@ -329,11 +330,19 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
             ctx_mark(ctx, ST_DW, (int)i);
             break;
         case bh::OP_PWCONV:
+            if (!ctx->keep_tensors && c->d_w16[i])
+                bh::launch_pw_gemm16(in, c->d_w16[i], bias, res, out, (int)(n * L.out_h * L.out_w), (int)L.cin, (int)L.cout,
+                                     (int)L.act, c->precision == 3 ? 3 : 1, s);
+            else
             bh::launch_pw_gemm(in, c->d_w[i], bias, res, out, (int)(n * L.out_h * L.out_w), (int)L.cin,
                                (int)L.cout, c->ldw[i], (int)L.act, s);
             ctx_mark(ctx, ST_PW, (int)i);
             break;
         case bh::OP_DENSE:
+            if (!ctx->keep_tensors && c->d_w16[i])
+                bh::launch_pw_gemm16(in, c->d_w16[i], bias, res, out, (int)n, (int)L.cin, (int)L.cout, (int)L.act,
+                                     c->precision == 3 ? 3 : 1, s);
+            else
             bh::launch_pw_gemm(in, c->d_w[i], bias, res, out, (int)n, (int)L.cin, (int)L.cout, c->ldw[i],
                                (int)L.act, s);
             ctx_mark(ctx, ST_DENSE, (int)i);
@@ -682,6 +691,36 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) {
         return fail(BH_ERR_IO, "model: last layer width != n_classes");
     rc = plan_fusion(c.get());
     if (rc != BH_OK) return rc;
+    // f16 operand planes for the GEMM layers that stay outside the fused blocks (head conv, dense)
+    c->d_w16.assign(m.layers.size(), nullptr);
+    if (c->precision != 0) {
+        std::vector<char> in_block(m.layers.size(), 0);
+        for (size_t i = 0; i < m.layers.size(); i++)
+            if (c->fused_at[i] >= 0) in_block[i] = in_block[i + 1] = in_block[i + 2] = 1;
+        for (size_t i = 0; i < m.layers.size(); i++) {
+            const auto &L = m.layers[i];
+            if (in_block[i] || (L.op != bh::OP_PWCONV && L.op != bh::OP_DENSE) || !bh::pw_gemm16_supports((int)L.cin, (int)L.act)) continue;
+            const int K = (int)L.cin, N = (int)L.cout, nt = (N + 15) / 16;
+            std::vector<uint16_t> planes((size_t)(K / 32) * nt * 2 * 64 * 8, 0);
+            const float *W = m.blob.data() + L.w_off;
+            for (int st = 0; st < K / 32; st++)
+                for (int t = 0; t < nt; t++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int jj = 0; jj < 8; jj++) {
+                            const int k = 32 * st + 8 * (lane >> 4) + jj, n = 16 * t + (lane & 15);
+                            const float v = n < N ? W[(size_t)k * N + n] : 0.0f;
+                            const uint16_t hi = f32_to_f16(v);
+                            const size_t base = (((size_t)st * nt + t) * 2) * 64 * 8;
+                            planes[base + (size_t)lane * 8 + jj] = hi;
+                            planes[base + 64 * 8 + (size_t)lane * 8 + jj] = f32_to_f16(v - f16_to_f32(hi));
+                        }
+            float *d = nullptr;
+            rc = upload(planes.data(), planes.size() * sizeof(uint16_t), &d);
+            if (rc != BH_OK) return rc;
+            c->d_owned.push_back(d);
+            c->d_w16[i] = d;
+        }
+    }
     if (const char *st = getenv("BIRDA_HIP_MB_STAMPS"); st && st[0] == '1' && !c->mb.empty()) {
         HIPCHK(hipMalloc((void **)&c->d_stamps, c->mb.size() * 8 * sizeof(unsigned long long)));
         HIPCHK(hipMemset(c->d_stamps, 0, c->mb.size() * 8 * sizeof(unsigned long long)));

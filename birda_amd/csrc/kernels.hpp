@@ -101,6 +101,11 @@ void launch_dwconv(const float *in, const float *w, const float *b, float *out, 
 // C[M][N] = act(A[M][K] . W[K][ldw] + bias) (+ R); W rows padded to ldw (multiple of 4)
 void launch_pw_gemm(const float *A, const float *W, const float *bias, const float *R, float *C, int M, int K,
                     int N, int ldw, int act, hipStream_t s);
+// the same product on the f16 MFMA (terms = 3: hi / lo split operands, f32-grade; 1: plain f16); K % 32 == 0;
+// Wf: fragment-major planes [K / 32][ceil(N / 16)]{hi, lo}[64 lanes][8 halves]
+bool pw_gemm16_supports(int K, int act);
+void launch_pw_gemm16(const float *A, const void *Wf, const float *bias, const float *R, float *C, int M, int K, int N,
+                      int act, int terms, hipStream_t s);
 // global average pool [n][P][C] -> [n][C]
 void launch_gap(const float *in, float *out, int n_seg, int P, int C, hipStream_t s);
 // activation + top-k over logits [n][n_classes] -> idx/conf [n][top_k]

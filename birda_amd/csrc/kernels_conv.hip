@@ -176,6 +176,118 @@ void launch_pw_gemm(const float *A, const float *W, const float *bias, const flo
 }
 
 // ---------------------------------------------------------------------------------------
+// Split-f16 GEMM (BH_FLAG_F16X3 / BH_FLAG_F16) for the layers outside the fused blocks (head 1x1 conv,
+// dense): C[M][N] = act(A[M][K] W[K][N] + bias) (+ R), K % 32 == 0.  Block = 4 waves as 2 x 2, wave
+// tile 64 x 64 (4 x 4 MFMA tiles), block tile 128 x 128.  A rows go global -> registers -> hi / lo
+// f16 fragments (8 consecutive k per lane); W is pre-split on the host in fragment-major planes
+// [k step][column tile]{hi, lo}[64 lanes][8 halves] and streams from L2.  Two register sets alternate
+// so that every load is a full k step (48 MFMAs) ahead of its use.
+// ---------------------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <int TERMS, int ACT>
+__global__ __launch_bounds__(256) void pw_gemm16_kernel(const float *__restrict__ A, const f16x8 *__restrict__ Wf,
+                                                         const float *__restrict__ bias, const float *__restrict__ R,
+                                                         float *__restrict__ C, int M, int K, int N, int n_tiles) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * 128 + wm * 64, t0 = blockIdx.x * 8 + wn * 4;   // first row, first column tile
+    const int steps = K / 32;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const float *arow[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) arow[i] = A + (size_t)min(m0 + i * 16 + li, M - 1) * K + 8 * kq;   // rows past M: clamped, never stored
+
+    float4 ra0[4][2], ra1[4][2];
+    f16x8 bh0[4], bl0[4], bh1[4], bl1[4];
+    auto load = [&](int st, float4 (&ra)[4][2], f16x8 (&bh)[4], f16x8 (&bl)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            ra[i][0] = *reinterpret_cast<const float4 *>(arow[i] + 32 * st);
+            ra[i][1] = *reinterpret_cast<const float4 *>(arow[i] + 32 * st + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int t = min(t0 + j, n_tiles - 1);
+            bh[j] = Wf[(((size_t)st * n_tiles + t) * 2 + 0) * 64 + lane];
+            if (TERMS == 3) bl[j] = Wf[(((size_t)st * n_tiles + t) * 2 + 1) * 64 + lane];
+        }
+    };
+    auto step = [&](const float4 (&ra)[4][2], const f16x8 (&bh)[4], const f16x8 (&bl)[4]) {
+        f16x8 ah[4], al[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float v[8] = {ra[i][0].x, ra[i][0].y, ra[i][0].z, ra[i][0].w, ra[i][1].x, ra[i][1].y, ra[i][1].z, ra[i][1].w};
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                ah[i][q] = (_Float16)v[q];
+                al[i][q] = (_Float16)(v[q] - (float)ah[i][q]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                if (TERMS == 3) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+            }
+    };
+    load(0, ra0, bh0, bl0);
+    for (int st = 0; st < steps; st += 2) {
+        if (st + 1 < steps) load(st + 1, ra1, bh1, bl1);   // (never a prefetch nobody consumes)
+        __builtin_amdgcn_sched_barrier(0);
+        step(ra0, bh0, bl0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 2 < steps) load(st + 2, ra0, bh0, bl0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 1 < steps) step(ra1, bh1, bl1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int col = (t0 + j) * 16 + li;
+        if (col >= N) continue;
+        const float bv = bias[col];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = m0 + i * 16 + kq * 4 + r;
+                if (row < M) {
+                    // the activation is a template argument: a run-time switch inlined 64 times bloats
+                    // the kernel past the instruction cache
+                    float v = acc[i][j][r] + bv;
+                    if (ACT == ACT_GELU_ERF) v = gelu_erf_fast(v);
+                    if (R) v += R[(size_t)row * N + col];
+                    C[(size_t)row * N + col] = v;
+                }
+            }
+    }
+}
+
+bool pw_gemm16_supports(int K, int act) { return K % 32 == 0 && (act == ACT_NONE || act == ACT_GELU_ERF); }
+
+void launch_pw_gemm16(const float *A, const void *Wf, const float *bias, const float *R, float *C, int M, int K, int N,
+                      int act, int terms, hipStream_t s) {
+    const int n_tiles = (N + 15) / 16;
+    dim3 grid((n_tiles + 7) / 8, (M + 127) / 128), block(256);
+#define BH_G16(T, ACTV) hipLaunchKernelGGL((pw_gemm16_kernel<T, ACTV>), grid, block, 0, s, A, (const f16x8 *)Wf, bias, R, C, M, K, N, n_tiles)
+    if (terms == 3) { if (act == ACT_GELU_ERF) BH_G16(3, ACT_GELU_ERF); else BH_G16(3, ACT_NONE); }
+    else { if (act == ACT_GELU_ERF) BH_G16(1, ACT_GELU_ERF); else BH_G16(1, ACT_NONE); }
+#undef BH_G16
+}
+
+// ---------------------------------------------------------------------------------------
 // Depthwise conv, NHWC.  One lane = one output pixel x 4 channels; lanes run over the
 // channel groups first, so a wave reads/writes contiguous 16-B pieces of NHWC rows.
 // ---------------------------------------------------------------------------------------
