@@ -9,45 +9,53 @@ enum Act : int { ACT_NONE = 0, ACT_RELU, ACT_RELU6, ACT_SWISH, ACT_GELU_ERF, ACT
 
 constexpr int MAX_BRANCHES = 4;
 
-// GELU(v) = 0.5 v (1 + erf(v / sqrt 2)) with erf from Abramowitz & Stegun 7.1.26
-// (|err(erf)| <= 1.5e-7): GELU(v) = max(v, 0) - 0.5 |v| P(t) exp(-v^2 / 2), t = 1 / (1 + p |v| / sqrt 2).
-// 13 VALU instructions, two of them transcendental (v_rcp_f32, v_exp_f32), against ~30 for
-// ocml erff; max |err| 5e-7 absolute (~1 ulp of v for |v| in [4, 8)), the same as the f32
-// rounding of the erff form itself.
+// exact-erf GELU, GELU(v) = v Phi(v), without erff and without a division:
+//     GELU(v) = 0.5 v + |v| (0.5 - Phi(-|v|)),   Phi(-a) = exp2(Q(a)),
+// Q = -1 + a (c1 + ... + c8 a^7) a weighted minimax fit of log2 Phi(-a) on [0, 6.2] (Q(0) = -1
+// exactly, so GELU(0) = 0; Q decreases monotonically to -inf beyond the fit range, where
+// Phi(-a) < 3e-10 rounds away).  |Phi error| <= 5.3e-8, |GELU error| <= 1.7e-7 max(|v|, 1) with
+// the f32 evaluation included: at the rounding level of the erff form itself.  11 VALU
+// instructions, ONE of them transcendental (v_exp_f32, quarter rate), against ~30 for ocml erff.
+#define BH_GELU_C1 -1.1511051654815674f
+#define BH_GELU_C2 -0.4592081904411316f
+#define BH_GELU_C3 -0.052496183663606644f
+#define BH_GELU_C4 0.007063428405672312f
+#define BH_GELU_C5 -0.00013694142398890108f
+#define BH_GELU_C6 -0.00018617883324623108f
+#define BH_GELU_C7 3.93775844713673e-05f
+#define BH_GELU_C8 -2.834923634509323e-06f
 __device__ __forceinline__ float gelu_erf_fast(float v) {
-    const float ax = __builtin_fabsf(v);
-    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
-    float p = __builtin_fmaf(t, 1.061405429f, -1.453152027f);
-    p = __builtin_fmaf(p, t, 1.421413741f);
-    p = __builtin_fmaf(p, t, -0.284496736f);
-    p = __builtin_fmaf(p, t, 0.254829592f);
-    p = p * t;
-    const float e = __builtin_amdgcn_exp2f((-0.5f * 1.4426950408889634f) * v * v);
-    return __builtin_fmaf(-0.5f * ax * p, e, __builtin_fmaxf(v, 0.0f));
+    const float a = __builtin_fabsf(v);
+    float q = __builtin_fmaf(a, BH_GELU_C8, BH_GELU_C7);
+    q = __builtin_fmaf(q, a, BH_GELU_C6);
+    q = __builtin_fmaf(q, a, BH_GELU_C5);
+    q = __builtin_fmaf(q, a, BH_GELU_C4);
+    q = __builtin_fmaf(q, a, BH_GELU_C3);
+    q = __builtin_fmaf(q, a, BH_GELU_C2);
+    q = __builtin_fmaf(q, a, BH_GELU_C1);
+    q = __builtin_fmaf(q, a, -1.0f);
+    const float e = __builtin_amdgcn_exp2f(q);
+    return __builtin_fmaf(a, 0.5f - e, 0.5f * v);
 }
 
-// Two GELUs at once with the f32 packed ops (v_pk_fma_f32 / v_pk_mul_f32): 17 instructions per
-// pair against 13 per value.  max(v, 0) is written 0.5 v + 0.5 |v| so the tail stays packed:
-// GELU(v) = 0.5 v + |v| (0.5 - 0.5 P(t) e), same polynomial and the same rcp / exp2 as above
-// (|difference| from gelu_erf_fast <= 3e-8 |v|: one extra rounding in the tail).
+// Two GELUs at once with the f32 packed ops (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): 13
+// instructions + 2 v_exp_f32 per pair; same arithmetic, bit-identical to gelu_erf_fast.
 typedef float bh_f32x2 __attribute__((ext_vector_type(2)));
+#define BH_PK(c) ((bh_f32x2){(c), (c)})
 __device__ __forceinline__ bh_f32x2 gelu_erf_fast2(bh_f32x2 v) {
-    bh_f32x2 ax;
-    ax[0] = __builtin_fabsf(v[0]); ax[1] = __builtin_fabsf(v[1]);
-    const bh_f32x2 one = {1.0f, 1.0f};
-    const bh_f32x2 den = __builtin_elementwise_fma(ax, (bh_f32x2){0.3275911f * 0.70710678118654752440f, 0.3275911f * 0.70710678118654752440f}, one);
-    bh_f32x2 t;
-    t[0] = __builtin_amdgcn_rcpf(den[0]); t[1] = __builtin_amdgcn_rcpf(den[1]);
-    bh_f32x2 p = __builtin_elementwise_fma(t, (bh_f32x2){1.061405429f, 1.061405429f}, (bh_f32x2){-1.453152027f, -1.453152027f});
-    p = __builtin_elementwise_fma(p, t, (bh_f32x2){1.421413741f, 1.421413741f});
-    p = __builtin_elementwise_fma(p, t, (bh_f32x2){-0.284496736f, -0.284496736f});
-    p = __builtin_elementwise_fma(p, t, (bh_f32x2){0.254829592f, 0.254829592f});
-    p = p * t;
-    const bh_f32x2 q = (v * (bh_f32x2){-0.5f * 1.4426950408889634f, -0.5f * 1.4426950408889634f}) * v;
+    bh_f32x2 a;
+    a[0] = __builtin_fabsf(v[0]); a[1] = __builtin_fabsf(v[1]);
+    bh_f32x2 q = __builtin_elementwise_fma(a, BH_PK(BH_GELU_C8), BH_PK(BH_GELU_C7));
+    q = __builtin_elementwise_fma(q, a, BH_PK(BH_GELU_C6));
+    q = __builtin_elementwise_fma(q, a, BH_PK(BH_GELU_C5));
+    q = __builtin_elementwise_fma(q, a, BH_PK(BH_GELU_C4));
+    q = __builtin_elementwise_fma(q, a, BH_PK(BH_GELU_C3));
+    q = __builtin_elementwise_fma(q, a, BH_PK(BH_GELU_C2));
+    q = __builtin_elementwise_fma(q, a, BH_PK(BH_GELU_C1));
+    q = __builtin_elementwise_fma(q, a, BH_PK(-1.0f));
     bh_f32x2 e;
     e[0] = __builtin_amdgcn_exp2f(q[0]); e[1] = __builtin_amdgcn_exp2f(q[1]);
-    const bh_f32x2 s = __builtin_elementwise_fma(p * (bh_f32x2){-0.5f, -0.5f}, e, (bh_f32x2){0.5f, 0.5f});
-    return __builtin_elementwise_fma(v, (bh_f32x2){0.5f, 0.5f}, ax * s);
+    return __builtin_elementwise_fma(a, BH_PK(0.5f) - e, v * BH_PK(0.5f));
 }
 
 __device__ __forceinline__ float act_apply_slow(float v, int act) {
