@@ -11,9 +11,11 @@
 //   in-tile   IH x IW = ((TH-1)s + k) x ((TW-1)s + k) input positions; the part inside the image is
 //             the "valid rect", M = S * vh * vw source rows.
 //   per chunk of CE expanded channels:
-//     P1  E[M x CE]   = act(X[M x Cin] . We[Cin x CE] + be)   f32 MFMA; A resident in registers,
-//                       B fragment-major in LDS; rows scattered into the LDS grid Es (the grid's
-//                       out-of-image border stays zero = the depthwise conv's zero padding)
+//     P1  E[M x CE]   = act(X[M x Cin] . We[Cin x CE] + be)   MFMA, computed as E^T = We^T X^T so that a
+//                       lane holds 4 consecutive channels of one row (one 16-byte LDS write); X resident
+//                       in registers, We fragment-major in LDS, be the accumulators' start value; rows go
+//                       to their slots of the LDS grid Es (the grid's out-of-image border stays zero =
+//                       the depthwise conv's zero padding)
 //     P2  D[P x CE]   = act(dw_kxk(Es) + bd)                  VALU + LDS, 4 channels per lane
 //     P3  acc[P x Co] += D[P x CE] . Wp[CE x Co]              f32 MFMA, accumulators live across chunks
 //   epilogue: + bp, activation, + residual, NHWC store.
@@ -151,8 +153,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
     _Float16 *DsH = reinterpret_cast<_Float16 *>(Ds), *DsL = DsH + POUT_PAD * DSH;   // PREC != 0
     float *WpS = WeS + WE_FLOATS;
     float *Wds = WpS + WP_FLOATS;
-    int *emap = reinterpret_cast<int *>(Wds + WD_FLOATS);
-    int *omap = emap + d.mpad_max;
+    int *omap = reinterpret_cast<int *>(Wds + WD_FLOATS);
     const float *bes = WeS + KG * NT_E * FRAG, *bds = Wds + KS * KS * CE;
 
     MbClock t_last{};
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
     const int xa = max(0, -ix0), xb = min(IW, d.W - ix0);
     const int vh = max(yb - ya, 0), vw = max(xb - xa, 0);
     const int Mseg = vh * vw, M = Mseg * nsv, nrt = (M + 15) >> 4;
-    const int Cin = d.Cin, Cout = d.Cout, nchunks = d.nchunks;
+    const int Cin = d.Cin, Cout = d.Cout, nchunks = (d.dbg & 128) ? 0 : d.nchunks;
     // STEM: X is the planar spectrogram [n][C][SH][SW]; "Cin" = kh*kw*C im2col columns
     const float *Xb = STEM ? d.X + (size_t)seg0 * d.stem_c * d.stem_h * d.stem_w : d.X + (size_t)seg0 * d.H * d.W * Cin;
     const int rw = wave / NCS, cs = wave - rw * NCS;  // P1: row-tile lane of the wave, column split
@@ -180,16 +181,22 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
     // f32: afr[i][g] = 4 k values of one 16-deep group; f16: ah/al[i][g] = 8 k values of one 32-deep step
     float4 afr[PREC ? 1 : RT_W][PREC ? 1 : KG];
     f16x8 ah[PREC ? RT_W : 1][PREC ? KG : 1], al[PREC ? RT_W : 1][PREC ? KG : 1];
+    // the expand GEMM is computed transposed (E^T = We^T X^T): a lane ends up with 4 consecutive
+    // channels of ONE source row, li of its row tile, and writes them with one ds_write_b128 at
+    // eoff[i] = that row's slot in the LDS grid (padding rows: the trash slot)
+    int eoff[RT_W];
 #pragma unroll
     for (int i = 0; i < RT_W; i++) {
         const int rt = rw + RSTEP * i;
-        const bool rv = rt < nrt;
+        const bool rv = rt < nrt && !(d.dbg & 64);
         int xo = 0;   // row offset computed in registers: the loads go out before the table barrier
+        eoff[i] = egrid * CES + 4 * kq;
         {
             const int m = rt * 16 + li;
-            if (rv && m < M) {
+            if (rt < nrt && m < M) {
                 const int sl = SS > 1 ? (m >= Mseg ? 1 : 0) : 0, mm = m - sl * Mseg;
                 const int r = mb_div(mm, vw, rcp_vw), c = mm - r * vw;
+                eoff[i] = (sl * IH * IW + (ya + r) * IW + xa + c) * CES + 4 * kq;
                 xo = STEM ? (((iy0 + ya + r) << 16) | (ix0 + xa + c))   // stem-output pixel (y, x), gathered below
                           : ((sl * d.H + iy0 + ya + r) * d.W + ix0 + xa + c) * Cin;
             }
@@ -226,15 +233,6 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                 afr[i][g] = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
-    }
-    for (int m = tid; m < nrt * 16; m += 256) {
-        int e = egrid;
-        if (m < M) {
-            const int sl = SS > 1 ? (m >= Mseg ? 1 : 0) : 0, mm = m - sl * Mseg;
-            const int r = mb_div(mm, vw, rcp_vw), c = mm - r * vw;
-            e = sl * IH * IW + (ya + r) * IW + xa + c;
-        }
-        emap[m] = e;
     }
     for (int p = tid; p < POUT_PAD; p += 256) {
         const int sl = (p >= THTW ? 1 : 0) + (p >= 2 * THTW ? 1 : 0), pp = p - sl * THTW;  // SS <= 2
@@ -284,11 +282,13 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
 #pragma unroll
         for (int i0 = 0; i0 < RT_W; i0 += RG) {
             if (rw + RSTEP * i0 < nrt) {  // wave-uniform
-                f32x4 acc[RG][NT_U];
+                f32x4 acc[RG][NT_U];   // [channel 4 kq + r][source row li], seeded with the bias
 #pragma unroll
-                for (int ii = 0; ii < RG; ii++)
+                for (int j = 0; j < NT_U; j++) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(&bes[(cs * NT_U + j) * 16 + 4 * kq]);
 #pragma unroll
-                    for (int j = 0; j < NT_U; j++) acc[ii][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    for (int ii = 0; ii < RG; ii++) acc[ii][j] = b4;
+                }
                 if (!(d.dbg & 8)) {
                     if constexpr (PREC != 0) {
                         // fragment planes: [step][column tile]{hi: 64 lanes x 8 halves, lo: same}
@@ -308,10 +308,10 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                                 const int ir = i0 + ii < RT_W ? i0 + ii : 0;
 #pragma unroll
                                 for (int j = 0; j < NT_U; j++) {
-                                    acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ir][g], bh[j], acc[ii][j], 0, 0, 0);
+                                    acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[ir][g], acc[ii][j], 0, 0, 0);
                                     if (PREC == 3) {
-                                        acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ir][g], bl[j], acc[ii][j], 0, 0, 0);
-                                        acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ir][g], bh[j], acc[ii][j], 0, 0, 0);
+                                        acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[ir][g], acc[ii][j], 0, 0, 0);
+                                        acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[ir][g], acc[ii][j], 0, 0, 0);
                                     }
                                 }
                             }
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
 #pragma unroll
                                 for (int j = 0; j < NT_U; j++) {
                                     const float b = c == 0 ? bv[j].x : c == 1 ? bv[j].y : c == 2 ? bv[j].z : bv[j].w;
-                                    acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[ii][j], 0, 0, 0);
+                                    acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, acc[ii][j], 0, 0, 0);
                                 }
                             }
                         if (g + 1 < KG) {
@@ -358,16 +358,12 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                     if (i0 + ii >= RT_W) continue;
                     const int rt = rw + RSTEP * (i0 + ii);
                     if (rt < nrt) {
-                        const int4 e4 = *reinterpret_cast<const int4 *>(&emap[rt * 16 + 4 * kq]);
-                        const int er[4] = {e4.x, e4.y, e4.z, e4.w};
+                        float *erow = Es + eoff[i0 + ii < RT_W ? i0 + ii : 0] + cs * NT_U * 16;
 #pragma unroll
                         for (int j = 0; j < NT_U; j++) {
-                            const int col = (cs * NT_U + j) * 16 + li;
-                            const float bias = bes[col];
-                            f32x2 v01 = {acc[ii][j][0] + bias, acc[ii][j][1] + bias}, v23 = {acc[ii][j][2] + bias, acc[ii][j][3] + bias};
+                            f32x2 v01 = {acc[ii][j][0], acc[ii][j][1]}, v23 = {acc[ii][j][2], acc[ii][j][3]};
                             if (!(d.dbg & 1)) { v01 = mb_act2<MB_ACT>(v01); v23 = mb_act2<MB_ACT>(v23); }
-                            Es[er[0] * CES + col] = v01[0]; Es[er[1] * CES + col] = v01[1];
-                            Es[er[2] * CES + col] = v23[0]; Es[er[3] * CES + col] = v23[1];
+                            *reinterpret_cast<f32x4 *>(erow + j * 16) = (f32x4){v01[0], v01[1], v23[0], v23[1]};
                         }
                     }
                 }
@@ -657,7 +653,7 @@ double mb_try_th(MbDesc &d, int ci, int th) {
     const size_t wd_fl = (size_t)c.KS * c.KS * c.CE + c.CE;
     const size_t ds_fl = c.PREC ? (size_t)pout_pad * (psteps * 32 + 8) : (size_t)pout_pad * ces;
     t.lds_bytes = (((size_t)c.S * t.IH * t.IW + 1) * ces + ds_fl + we_fl + wp_fl + wd_fl) * 4 +
-                  ((size_t)t.mpad_max + pout_pad) * 4;
+                  (size_t)pout_pad * 4;
     if (t.lds_bytes > 160 * 1024) return -1;
     d = t;
     const double tiles = (double)t.tiles_y * t.tiles_x / c.S;
