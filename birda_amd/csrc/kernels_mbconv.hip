@@ -274,6 +274,20 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
         }
     }
 
+    // P2 tasks: XB output pixels x 4 channels each.  The 16-channel-chunk instantiations have at most 256
+    // = one per thread, so the first task's decomposition is done once here, not once per chunk.
+    const int p2_ntask = nsv * TH * XBN * C4N;
+    int p2_c4, p2_eoff, p2_prow;
+    auto p2_task = [&](int t) {
+        const int q = t / C4N;
+        p2_c4 = t - q * C4N;
+        const int r = q >> (TWL - XBL), sl = (SS > 1 && r >= TH) ? 1 : 0, ty = r - sl * TH;
+        const int tx0 = (q & (XBN - 1)) * XB;
+        p2_eoff = (sl * IH * IW + (ty * ST) * IW + tx0 * ST) * CES + 4 * p2_c4;
+        p2_prow = sl * THTW + (ty << TWL) + tx0;
+    };
+    p2_task(tid);
+
     for (int ch = 0; ch < nchunks; ch++) {
         const int chn = min(ch + 1, nchunks - 1);
         mb_stamp(d.stamps, t_last, 1);
@@ -362,7 +376,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
 #pragma unroll
                         for (int j = 0; j < NT_U; j++) {
                             f32x2 v01 = {acc[ii][j][0], acc[ii][j][1]}, v23 = {acc[ii][j][2], acc[ii][j][3]};
-                            if (!(d.dbg & 1)) { v01 = mb_act2<MB_ACT>(v01); v23 = mb_act2<MB_ACT>(v23); }
+                            v01 = mb_act2<MB_ACT>(v01); v23 = mb_act2<MB_ACT>(v23);
                             *reinterpret_cast<f32x4 *>(erow + j * 16) = (f32x4){v01[0], v01[1], v23[0], v23[1]};
                         }
                     }
@@ -380,13 +394,10 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
 
         // ---- P2: depthwise, XB output pixels x 4 channels per lane ---------------------------
         if (!(d.dbg & 2)) {
-            const int ntask = nsv * TH * XBN * C4N;
-            for (int t = tid; t < ntask; t += 256) {
-                const int q = t / C4N, c4 = t - q * C4N;
-                const int xbi = q & (XBN - 1), r = q >> (TWL - XBL);
-                const int sl = (SS > 1 && r >= TH) ? 1 : 0, ty = r - sl * TH;
-                const int tx0 = xbi * XB;
-                const float *eb = Es + ((size_t)sl * IH * IW + (ty * ST) * IW + tx0 * ST) * CES + 4 * c4;
+            for (int t = tid; t < p2_ntask; t += 256) {
+                if (p2_ntask > 256) p2_task(t);   // wave-uniform
+                const int c4 = p2_c4;
+                const float *eb = Es + p2_eoff;
                 const float4 bd4 = *reinterpret_cast<const float4 *>(&bds[4 * c4]);
                 // two-wide vectors so the taps become v_pk_fma_f32 (2 FMAs per instruction)
                 f32x2 acc[XB][2];
@@ -414,7 +425,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                 for (int x = 0; x < XB; x++) {
                     const f32x2 g0 = mb_act2<MB_ACT>(acc[x][0]), g1 = mb_act2<MB_ACT>(acc[x][1]);
                     const float4 v = make_float4(g0[0], g0[1], g1[0], g1[1]);
-                    const int prow = sl * THTW + (ty << TWL) + tx0 + x;
+                    const int prow = p2_prow + x;
                     if constexpr (PREC != 0) {   // the project GEMM's A operand: f16 hi (+ lo) planes
                         f16x4 h, l;
                         h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
