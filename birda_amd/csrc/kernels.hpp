@@ -14,7 +14,7 @@ constexpr int MAX_BRANCHES = 4;
 // Q = -1 + a (c1 + ... + c8 a^7) a weighted minimax fit of log2 Phi(-a) on [0, 6.2] (Q(0) = -1
 // exactly, so GELU(0) = 0; Q decreases monotonically to -inf beyond the fit range, where
 // Phi(-a) < 3e-10 rounds away).  |Phi error| <= 5.3e-8, |GELU error| <= 1.7e-7 max(|v|, 1) with
-// the f32 evaluation included: at the rounding level of the erff form itself.  11 VALU
+// the f32 evaluation included: at the rounding level of the erff form itself.  12 VALU
 // instructions, ONE of them transcendental (v_exp_f32, quarter rate), against ~30 for ocml erff.
 #define BH_GELU_C1 -1.1511051654815674f
 #define BH_GELU_C2 -0.4592081904411316f
@@ -24,8 +24,15 @@ constexpr int MAX_BRANCHES = 4;
 #define BH_GELU_C6 -0.00018617883324623108f
 #define BH_GELU_C7 3.93775844713673e-05f
 #define BH_GELU_C8 -2.834923634509323e-06f
+// max(v, 0) as ONE v_max_f32: fmaxf() in IEEE mode first canonicalises its operand (a second v_max)
+__device__ __forceinline__ float bh_relu1(float v) {
+    float m;
+    asm("v_max_f32_e32 %0, 0, %1" : "=v"(m) : "v"(v));
+    return m;
+}
 __device__ __forceinline__ float gelu_erf_fast(float v) {
-    const float a = __builtin_fabsf(v);
+    const float m = bh_relu1(v);
+    const float a = __builtin_fmaf(m, 2.0f, -v);   // |v|, exactly
     float q = __builtin_fmaf(a, BH_GELU_C8, BH_GELU_C7);
     q = __builtin_fmaf(q, a, BH_GELU_C6);
     q = __builtin_fmaf(q, a, BH_GELU_C5);
@@ -35,16 +42,45 @@ __device__ __forceinline__ float gelu_erf_fast(float v) {
     q = __builtin_fmaf(q, a, BH_GELU_C1);
     q = __builtin_fmaf(q, a, -1.0f);
     const float e = __builtin_amdgcn_exp2f(q);
-    return __builtin_fmaf(a, 0.5f - e, 0.5f * v);
+    return __builtin_fmaf(-a, e, m);   // 0.5 v + |v| (0.5 - e) with 0.5 v + 0.5 |v| = max(v, 0)
 }
 
-// Two GELUs at once with the f32 packed ops (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32): 13
-// instructions + 2 v_exp_f32 per pair; same arithmetic, bit-identical to gelu_erf_fast.
+// |v| = 2 max(v, 0) - v for a pair, one packed FMA (written out: hipcc otherwise negates v with v_xor first)
 typedef float bh_f32x2 __attribute__((ext_vector_type(2)));
-#define BH_PK(c) ((bh_f32x2){(c), (c)})
-__device__ __forceinline__ bh_f32x2 gelu_erf_fast2(bh_f32x2 v) {
+__device__ __forceinline__ bh_f32x2 bh_abs_from_relu2(bh_f32x2 m, bh_f32x2 v) {
     bh_f32x2 a;
-    a[0] = __builtin_fabsf(v[0]); a[1] = __builtin_fabsf(v[1]);
+    asm("v_pk_fma_f32 %0, %1, 2.0, %2 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(a) : "v"(m), "v"(v));
+    return a;
+}
+
+// Four GELUs at once with the f32 packed ops (v_pk_fma_f32): 12 packed instructions + 2 v_max_f32 +
+// 2 v_exp_f32 per pair; same arithmetic, bit-identical to gelu_erf_fast.  The two pairs' Horner chains
+// are interleaved by hand: back-to-back dependent packed ops cost a wait state each on gfx950.
+#define BH_PK(c) ((bh_f32x2){(c), (c)})
+__device__ __forceinline__ void gelu_erf_fast4(bh_f32x2 &v0, bh_f32x2 &v1) {
+    bh_f32x2 m0, m1;
+    m0[0] = bh_relu1(v0[0]); m0[1] = bh_relu1(v0[1]);
+    m1[0] = bh_relu1(v1[0]); m1[1] = bh_relu1(v1[1]);
+    const bh_f32x2 a0 = bh_abs_from_relu2(m0, v0);
+    const bh_f32x2 a1 = bh_abs_from_relu2(m1, v1);
+    bh_f32x2 q0 = __builtin_elementwise_fma(a0, BH_PK(BH_GELU_C8), BH_PK(BH_GELU_C7));
+    bh_f32x2 q1 = __builtin_elementwise_fma(a1, BH_PK(BH_GELU_C8), BH_PK(BH_GELU_C7));
+#define BH_GELU_STEP(c)                                       \
+    q0 = __builtin_elementwise_fma(q0, a0, BH_PK(c));         \
+    q1 = __builtin_elementwise_fma(q1, a1, BH_PK(c));
+    BH_GELU_STEP(BH_GELU_C6) BH_GELU_STEP(BH_GELU_C5) BH_GELU_STEP(BH_GELU_C4) BH_GELU_STEP(BH_GELU_C3)
+    BH_GELU_STEP(BH_GELU_C2) BH_GELU_STEP(BH_GELU_C1) BH_GELU_STEP(-1.0f)
+#undef BH_GELU_STEP
+    bh_f32x2 e0, e1;
+    e0[0] = __builtin_amdgcn_exp2f(q0[0]); e0[1] = __builtin_amdgcn_exp2f(q0[1]);
+    e1[0] = __builtin_amdgcn_exp2f(q1[0]); e1[1] = __builtin_amdgcn_exp2f(q1[1]);
+    v0 = __builtin_elementwise_fma(-a0, e0, m0);
+    v1 = __builtin_elementwise_fma(-a1, e1, m1);
+}
+__device__ __forceinline__ bh_f32x2 gelu_erf_fast2(bh_f32x2 v) {
+    bh_f32x2 m;
+    m[0] = bh_relu1(v[0]); m[1] = bh_relu1(v[1]);
+    const bh_f32x2 a = bh_abs_from_relu2(m, v);
     bh_f32x2 q = __builtin_elementwise_fma(a, BH_PK(BH_GELU_C8), BH_PK(BH_GELU_C7));
     q = __builtin_elementwise_fma(q, a, BH_PK(BH_GELU_C6));
     q = __builtin_elementwise_fma(q, a, BH_PK(BH_GELU_C5));
@@ -55,7 +91,7 @@ __device__ __forceinline__ bh_f32x2 gelu_erf_fast2(bh_f32x2 v) {
     q = __builtin_elementwise_fma(q, a, BH_PK(-1.0f));
     bh_f32x2 e;
     e[0] = __builtin_amdgcn_exp2f(q[0]); e[1] = __builtin_amdgcn_exp2f(q[1]);
-    return __builtin_elementwise_fma(a, BH_PK(0.5f) - e, v * BH_PK(0.5f));
+    return __builtin_elementwise_fma(-a, e, m);
 }
 
 __device__ __forceinline__ float act_apply_slow(float v, int act) {

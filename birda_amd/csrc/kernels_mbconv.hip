@@ -48,6 +48,11 @@ __device__ __forceinline__ f32x2 mb_act2(f32x2 v) {
     if constexpr (ACT == ACT_GELU_ERF) return gelu_erf_fast2(v);
     else { f32x2 r; r[0] = mb_act<ACT>(v[0]); r[1] = mb_act<ACT>(v[1]); return r; }
 }
+template <int ACT>
+__device__ __forceinline__ void mb_act4(f32x2 &v0, f32x2 &v1) {
+    if constexpr (ACT == ACT_GELU_ERF) gelu_erf_fast4(v0, v1);
+    else { v0 = mb_act2<ACT>(v0); v1 = mb_act2<ACT>(v1); }
+}
 constexpr int MB_ACT = ACT_GELU_ERF;  // expand + depthwise activation of every instantiation below
 
 // n / d for 0 <= n < 2^22, d > 0 through the float reciprocal (one multiply, a convert and a
@@ -376,7 +381,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
 #pragma unroll
                         for (int j = 0; j < NT_U; j++) {
                             f32x2 v01 = {acc[ii][j][0], acc[ii][j][1]}, v23 = {acc[ii][j][2], acc[ii][j][3]};
-                            v01 = mb_act2<MB_ACT>(v01); v23 = mb_act2<MB_ACT>(v23);
+                            mb_act4<MB_ACT>(v01, v23);
                             *reinterpret_cast<f32x4 *>(erow + j * 16) = (f32x4){v01[0], v01[1], v23[0], v23[1]};
                         }
                     }
@@ -423,7 +428,8 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                 }
 #pragma unroll
                 for (int x = 0; x < XB; x++) {
-                    const f32x2 g0 = mb_act2<MB_ACT>(acc[x][0]), g1 = mb_act2<MB_ACT>(acc[x][1]);
+                    f32x2 g0 = acc[x][0], g1 = acc[x][1];
+                    mb_act4<MB_ACT>(g0, g1);
                     const float4 v = make_float4(g0[0], g0[1], g1[0], g1[1]);
                     const int prow = p2_prow + x;
                     if constexpr (PREC != 0) {   // the project GEMM's A operand: f16 hi (+ lo) planes
