@@ -94,6 +94,29 @@ __device__ __forceinline__ bh_f32x2 gelu_erf_fast2(bh_f32x2 v) {
     return __builtin_elementwise_fma(-a, e, m);
 }
 
+// a = hi + lo with hi, lo in f16 (22 significant bits between them), for a pair: products
+// hi*hi + hi*lo + lo*hi on the f16 MFMA with f32 accumulation reproduce an f32 fmaf chain to ~1e-7 of
+// sum|a b| (tools/microbench/mfma_f16_overlap.hip).  Valid while |a| < 65504 (f16 range).
+// 4 instructions per pair: v_cvt_pk_f16_f32 (RNE), two v_fma_mix_f32 (lo = a - hi, the f16 operand
+// widened inside the FMA, exact) and a second v_cvt_pk_f16_f32.
+typedef _Float16 bh_f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void bh_split2(float v0, float v1, bh_f16x2 &hi, bh_f16x2 &lo) {
+    hi = __builtin_convertvector((bh_f32x2){v0, v1}, bh_f16x2);
+    float l0, l1;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l0) : "v"(hi), "v"(v0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(l1) : "v"(hi), "v"(v1));
+    lo = __builtin_convertvector((bh_f32x2){l0, l1}, bh_f16x2);
+}
+typedef _Float16 bh_f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void bh_split8(const float (&v)[8], bh_f16x8 &hi, bh_f16x8 &lo) {
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        bh_f16x2 h, l;
+        bh_split2(v[j], v[j + 1], h, l);
+        hi[j] = h[0]; hi[j + 1] = h[1]; lo[j] = l[0]; lo[j + 1] = l[1];
+    }
+}
+
 __device__ __forceinline__ float act_apply_slow(float v, int act) {
     switch (act) {
     case ACT_RELU: return fmaxf(v, 0.f);

@@ -225,11 +225,7 @@ __global__ __launch_bounds__(256) void pw_gemm16_kernel(const float *__restrict_
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const float v[8] = {ra[i][0].x, ra[i][0].y, ra[i][0].z, ra[i][0].w, ra[i][1].x, ra[i][1].y, ra[i][1].z, ra[i][1].w};
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                ah[i][q] = (_Float16)v[q];
-                al[i][q] = (_Float16)(v[q] - (float)ah[i][q]);
-            }
+            bh_split8(v, ah[i], al[i]);
         }
 #pragma unroll
         for (int i = 0; i < 4; i++)

@@ -224,12 +224,12 @@ __global__ __launch_bounds__(256, 2) void mel_kernel(const float *__restrict__ x
             f16x8 bh[MEL_FT], bl[MEL_FT];
 #pragma unroll
             for (int f = 0; f < MEL_FT; f++)
+            {
+                float y[8];
 #pragma unroll
-                for (int jj = 0; jj < 8; jj++) {
-                    const float y = xf[f * 16 * H + j0 + jj + 1] + xf[f * 16 * H + L - 1 - j0 - jj];
-                    bh[f][jj] = (_Float16)y;
-                    bl[f][jj] = (_Float16)(y - (float)bh[f][jj]);
-                }
+                for (int jj = 0; jj < 8; jj++) y[jj] = xf[f * 16 * H + j0 + jj + 1] + xf[f * 16 * H + L - 1 - j0 - jj];
+                bh_split8(y, bh[f], bl[f]);
+            }
 #pragma unroll
             for (int m = 0; m < MT; m++)
 #pragma unroll

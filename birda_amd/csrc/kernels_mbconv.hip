@@ -113,18 +113,6 @@ __device__ __forceinline__ void mb_dma(const float *gsrc, float *lds_dst, int wa
 }
 __device__ __forceinline__ void mb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// a = hi + lo with hi, lo in f16 (22 significant bits): products hi*hi + hi*lo + lo*hi on the f16
-// MFMA with f32 accumulation reproduce an f32 fmaf chain to ~1e-7 of sum|a b|
-// (tools/microbench/mfma_f16_overlap.hip) at 4.4x the f32 MFMA rate, and leave the vector pipe
-// half free while they run.  Valid while |a| < 65504 (f16 range).
-__device__ __forceinline__ void mb_split8(const float (&v)[8], f16x8 &hi, f16x8 &lo) {
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        hi[j] = (_Float16)v[j];
-        lo[j] = (_Float16)(v[j] - (float)hi[j]);
-    }
-}
-
 //   PREC        0: f32 MFMA (16x16x4, KG counts 16-deep groups); 3: f16 hi/lo split, three 16x16x32 MFMAs
 //               per product (KG counts 32-deep steps); 1: plain f16 operands (one MFMA, ~1e-3 relative)
 template <int KS, int ST, int CE, int KG, int RT_W, int NCS, int WM, int WN, int MT_W, int NT_W, int TWL, int XBL,
@@ -233,7 +221,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                 }
             }
             if constexpr (PREC != 0) {
-                mb_split8(v, ah[i][g], al[i][g]);
+                bh_split8(v, ah[i][g], al[i][g]);
             } else {
                 afr[i][g] = make_float4(v[0], v[1], v[2], v[3]);
             }
@@ -433,13 +421,16 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                     const float4 v = make_float4(g0[0], g0[1], g1[0], g1[1]);
                     const int prow = p2_prow + x;
                     if constexpr (PREC != 0) {   // the project GEMM's A operand: f16 hi (+ lo) planes
-                        f16x4 h, l;
-                        h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
-                        *reinterpret_cast<f16x4 *>(&DsH[prow * DSH + 4 * c4]) = h;
                         if (PREC == 3) {
-                            l[0] = (_Float16)(v.x - (float)h[0]); l[1] = (_Float16)(v.y - (float)h[1]);
-                            l[2] = (_Float16)(v.z - (float)h[2]); l[3] = (_Float16)(v.w - (float)h[3]);
-                            *reinterpret_cast<f16x4 *>(&DsL[prow * DSH + 4 * c4]) = l;
+                            bh_f16x2 h0, l0, h1, l1;
+                            bh_split2(v.x, v.y, h0, l0);
+                            bh_split2(v.z, v.w, h1, l1);
+                            *reinterpret_cast<f16x4 *>(&DsH[prow * DSH + 4 * c4]) = (f16x4){h0[0], h0[1], h1[0], h1[1]};
+                            *reinterpret_cast<f16x4 *>(&DsL[prow * DSH + 4 * c4]) = (f16x4){l0[0], l0[1], l1[0], l1[1]};
+                        } else {
+                            f16x4 h;
+                            h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+                            *reinterpret_cast<f16x4 *>(&DsH[prow * DSH + 4 * c4]) = h;
                         }
                     } else {
                         *reinterpret_cast<float4 *>(&Ds[prow * CES + 4 * c4]) = v;
