@@ -479,14 +479,9 @@ int plan_fusion(bh_classifier *c) {
         d.act_e = (int)E.act; d.act_d = (int)D.act; d.act_p = (int)P.act;
         if (const char *dbg = getenv("BIRDA_HIP_MB_DBG")) d.dbg = atoi(dbg);
         d.prec = c->precision;
-        if (c->precision == 3) {
-            // The split-f16 MFMA and the f32 MFMA agree to ~1e-7 of sum|a b|, so the choice per block is
-            // purely speed (profiles/): f16x3 wins everywhere except the stem block, whose 18-column
-            // im2col GEMM is tiny and whose vector work dominates.
-            const bool f16_faster = !d.stem;
-            const char *mix = getenv("BIRDA_HIP_F16X3_ALL");
-            if (!f16_faster && !(mix && mix[0] == '1')) d.prec = 0;
-        }
+        // The split-f16 MFMA and the f32 MFMA agree to ~1e-7 of sum|a b|; measured (profiles/), f16x3 is
+        // the faster one on every block, the stem's 18-column im2col GEMM included.
+        if (d.stem && c->precision == 3 && getenv("BIRDA_HIP_STEM_F32")) d.prec = 0;   // A/B aid
         if (!bh::mb_plan(d, force_cfg)) {
             if (d.prec == 0) continue;
             d.prec = 0;                       // no f16 instantiation for this shape: f32 one, if any

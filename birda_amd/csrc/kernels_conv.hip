@@ -227,6 +227,7 @@ __global__ __launch_bounds__(256) void pw_gemm16_kernel(const float *__restrict_
             const float v[8] = {ra[i][0].x, ra[i][0].y, ra[i][0].z, ra[i][0].w, ra[i][1].x, ra[i][1].y, ra[i][1].z, ra[i][1].w};
             bh_split8(v, ah[i], al[i]);
         }
+        __builtin_amdgcn_sched_barrier(0);   // no VALU split between the MFMAs (see mel_kernel)
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void mel_kernel(const float *__restrict__ x
         // Split-f16 MFMA (v_mfma_f32_16x16x32_f16 x 3 per product: hi*hi + hi*lo + lo*hi, f32 accumulate):
         // f32-grade sums at 4.4x the f32 MFMA rate.  The operator arrives pre-split (hi / lo planes);
         // the folded frame samples are split here, 8 consecutive k per lane and 32-deep step.
-        const int spw = K / 128, sbeg = wave * spw;              // steps per wave (even: K % 256 == 0)
+        const int spw = K / 128, sbeg = wave * spw;              // 32-deep steps per wave (L % 256 == 0, checked at create)
         const f16x8 *gA = reinterpret_cast<const f16x8 *>(gfp) + lane;
         f16x8 a0h[MT], a0l[MT], a1h[MT], a1l[MT];
         auto load = [&](int st, f16x8 (&ah)[MT], f16x8 (&al)[MT]) {
@@ -230,6 +230,11 @@ __global__ __launch_bounds__(256, 2) void mel_kernel(const float *__restrict__ x
                 for (int jj = 0; jj < 8; jj++) y[jj] = xf[f * 16 * H + j0 + jj + 1] + xf[f * 16 * H + L - 1 - j0 - jj];
                 bh_split8(y, bh[f], bl[f]);
             }
+            // Keep the VALU split out of the MFMA sequence.  Left to interleave them (v_cvt_pk_f16_f32 /
+            // v_fma_mix_f32 between back-to-back MFMAs), hipcc produced a kernel whose B operands were
+            // sporadically corrupt when two workgroups shared a CU: whole 16-frame tiles wrong in ~1 % of
+            // the tiles, different ones on every run (tools/gpu_determinism.py, tools/gpu_mel_twins.py).
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < MT; m++)
 #pragma unroll
@@ -239,17 +244,31 @@ __global__ __launch_bounds__(256, 2) void mel_kernel(const float *__restrict__ x
                     acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh[f], acc[f][m], 0, 0, 0);
                 }
         };
+        // The last one or two steps are peeled so that no load inside the loop is conditional: with
+        // `if (si + 2 < spw) load(...)` in the loop, hipcc turned the register sets into loop-carried
+        // selects and waited for every load right after issuing it.
         load(sbeg, a0h, a0l);
-        if (!(dbg & 1))
-        for (int si = 0; si < spw; si += 2) {
-            if (si + 1 < spw) load(sbeg + si + 1, a1h, a1l);
-            __builtin_amdgcn_sched_barrier(0);
-            step(sbeg + si, a0h, a0l);
-            __builtin_amdgcn_sched_barrier(0);
-            if (si + 2 < spw) load(sbeg + si + 2, a0h, a0l);
-            __builtin_amdgcn_sched_barrier(0);
-            if (si + 1 < spw) step(sbeg + si + 1, a1h, a1l);
-            __builtin_amdgcn_sched_barrier(0);
+        if (!(dbg & 1)) {
+            int si = 0;
+            for (; si + 2 < spw; si += 2) {
+                load(sbeg + si + 1, a1h, a1l);
+                __builtin_amdgcn_sched_barrier(0);
+                step(sbeg + si, a0h, a0l);
+                __builtin_amdgcn_sched_barrier(0);
+                load(sbeg + si + 2, a0h, a0l);
+                __builtin_amdgcn_sched_barrier(0);
+                step(sbeg + si + 1, a1h, a1l);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (si + 1 < spw) {
+                load(sbeg + si + 1, a1h, a1l);
+                __builtin_amdgcn_sched_barrier(0);
+                step(sbeg + si, a0h, a0l);
+                __builtin_amdgcn_sched_barrier(0);
+                step(sbeg + si + 1, a1h, a1l);
+            } else {
+                step(sbeg + si, a0h, a0l);
+            }
         }
     } else {
     // Two operator register sets, used alternately (no copies): set B is loaded while set A feeds
@@ -278,22 +297,30 @@ __global__ __launch_bounds__(256, 2) void mel_kernel(const float *__restrict__ x
                     acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[c][f], acc[f][m], 0, 0, 0);
             }
     };
-    if (!(dbg & 1))
-    for (int gi = 0; gi < gpw; gi += 2) {   // gpw is even: K % 128 == 0 (checked at create)
+    if (!(dbg & 1)) {   // last one or two groups peeled: no conditional loads inside the loop
+        int gi = 0;
+        for (; gi + 2 < gpw; gi += 2) {
 #pragma unroll
-        for (int m = 0; m < MT; m++) a1[m] = gA[((size_t)(gbeg + gi + 1) * MT + m) * 64];
-        __builtin_amdgcn_sched_barrier(0);
-        group(gbeg + gi, a0);
-        __builtin_amdgcn_sched_barrier(0);
-        // (never issue a prefetch nobody consumes: hipcc re-used the destination registers of such
-        // dangling loads after the loop and the late data clobbered live values)
-        if (gi + 2 < gpw) {
+            for (int m = 0; m < MT; m++) a1[m] = gA[((size_t)(gbeg + gi + 1) * MT + m) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+            group(gbeg + gi, a0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < MT; m++) a0[m] = gA[((size_t)(gbeg + gi + 2) * MT + m) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+            group(gbeg + gi + 1, a1);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        group(gbeg + gi + 1, a1);
-        __builtin_amdgcn_sched_barrier(0);
+        if (gi + 1 < gpw) {
+#pragma unroll
+            for (int m = 0; m < MT; m++) a1[m] = gA[((size_t)(gbeg + gi + 1) * MT + m) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+            group(gbeg + gi, a0);
+            __builtin_amdgcn_sched_barrier(0);
+            group(gbeg + gi + 1, a1);
+        } else {
+            group(gbeg + gi, a0);
+        }
     }
 
     }  // PREC

@@ -629,6 +629,10 @@ const MbCfg kCfgs[] = {
     MB_ENTRY_P(3, 2, 16, 1, 10, 1, 4, 1, 2, 2, 5, 1, 4, 1, 2, 0, 3),   // 61: as 48, tile 4x32
     MB_ENTRY_P(3, 1, 16, 1, 6, 1, 4, 1, 4, 2, 5, 2, 8, 1, 2, 0, 3),    // 62: as 49, tile 8x32
     MB_ENTRY_S(3, 1, 16, 2, 6, 1, 4, 1, 4, 1, 5, 2, 8, 1, 2, 2),       // 63: as 20 (stem, f32), tile 8x32
+    // four workgroups per CU for the gather-latency-bound stem block
+    MB_ENTRY_S(3, 1, 16, 2, 3, 1, 4, 1, 2, 1, 4, 1, 8, 1, 4, 2),       // 64: as 20, 4 waves per SIMD
+    MB_ENTRY_P(3, 1, 16, 1, 3, 1, 4, 1, 2, 1, 4, 1, 8, 1, 4, 2, 3),    // 65: as 53, 4 waves per SIMD
+    MB_ENTRY_P(3, 1, 16, 1, 3, 1, 4, 1, 2, 1, 4, 1, 8, 1, 4, 1, 3),    // 66: as 54, 4 waves per SIMD
 };
 constexpr int kNCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
@@ -713,7 +717,7 @@ bool mb_plan(MbDesc &d, int force_cfg) {
     static const int kPreferred[] = {11, 12, 13, 14, 15, 16, 17, 18, 19, 9, 10, 20, 21};
     // split-f16 with 16-channel chunks (two or more workgroups per CU): the early blocks, and the 6x32
     // blocks whose depthwise phase is light enough (3x3, and the stride-2 5x5)
-    static const int kPreferred16[] = {48, 49, 50, 51, 52, 55, 58};
+    static const int kPreferred16[] = {48, 49, 50, 51, 52, 55, 58, 65, 66};
     if (d.prec == 0)
         for (int ci : kPreferred) {  // at the entry's own tile height: the shapes it was measured on
             MbDesc t = d;

@@ -13,9 +13,8 @@ m = synth.build_model(kind)
 path = f"/tmp/{kind}.bhm"; mf.write_model(path, m)
 segs = synth.synth_segments(n, m.sample_count, m.sample_rate, start=7)
 ref = O.OracleModel(path).forward(segs)
-os.environ["BIRDA_HIP_F16X3_ALL"] = "1"
 for cfg in range(lo, hi):
-    prec = "f32" if cfg < 22 else ("f16x3" if (cfg % 2 == 0 or cfg >= 48) else "f16")
+    prec = "f32" if cfg < 22 or cfg in (63, 64) else ("f16x3" if (cfg % 2 == 0 or cfg >= 48) else "f16")
     os.environ["BIRDA_HIP_MB_CFG"] = str(cfg)
     clf = BirdClassifier(path, precision=prec)
     blocks = clf.fused_blocks()
