@@ -260,7 +260,7 @@ def main():
                    "gemm": {"f32": "v_mfma_f32_16x16x4_f32 (exact f32 fmaf chains)",
                             "f16x3": "f32 operands split into f16 hi + lo, 3 x v_mfma_f32_16x16x32_f16 per product, f32 "
                                      "accumulate (|err| ~1e-7 of sum|a b|, same fp32 logit tolerance as the f32 MFMA path, "
-                                     "tests/test_parity_gpu.py); stem block on the f32 MFMA",
+                                     "tests/test_parity_gpu.py)",
                             "f16": "operands rounded to f16, v_mfma_f32_16x16x32_f16, f32 accumulate"}[args.precision]},
     }
     out.update(analyse(clf, m, info, fused, stage_tot, layer_tot, segs_done, args.steps, slices_per_step, args.precision))
