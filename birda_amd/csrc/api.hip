@@ -58,6 +58,7 @@ struct bh_classifier {
     std::vector<float *> d_w;                // per layer: weights as the kernels want them
     std::vector<int> ldw;                    // per layer: padded row length of d_w (pw / dense)
     std::vector<void *> d_w16;               // per layer: f16 hi / lo fragment planes (pw / dense outside fused blocks), or null
+    std::vector<char> head_gap;              // per layer: 1 = this 1x1 conv + GELU and the global average pool after it run as one launch
     std::vector<float *> d_owned;            // re-laid buffers to free
     bh::FrontendParams fe{};
     bh::FrontendParams *d_fe = nullptr;      // device copy read by the mel kernel
@@ -330,6 +331,14 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
             ctx_mark(ctx, ST_DW, (int)i);
             break;
         case bh::OP_PWCONV:
+            if (!ctx->keep_tensors && c->head_gap[i]) {
+                float *pooled = (i + 1 == nl - 1) ? d_logits : T(i + 2);
+                bh::launch_head_gap16(in, c->d_w16[i], bias, pooled, (int)n, (int)(L.out_h * L.out_w), (int)L.cin, (int)L.cout,
+                                      c->precision == 3 ? 3 : 1, s);
+                ctx_mark(ctx, ST_PW, (int)i);
+                i += 1;   // the pool layer is done
+                break;
+            }
             if (!ctx->keep_tensors && c->d_w16[i])
                 bh::launch_pw_gemm16(in, c->d_w16[i], bias, res, out, (int)(n * L.out_h * L.out_w), (int)L.cin, (int)L.cout,
                                      (int)L.act, c->precision == 3 ? 3 : 1, s);
@@ -714,6 +723,21 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) {
             if (rc != BH_OK) return rc;
             c->d_owned.push_back(d);
             c->d_w16[i] = d;
+        }
+    }
+    // head conv + GELU followed by the global average pool (and read by nothing else): one launch
+    c->head_gap.assign(m.layers.size(), 0);
+    {
+        const char *hg = getenv("BIRDA_HIP_HEAD_GAP");
+        for (size_t i = 0; i + 1 < m.layers.size() && !(hg && hg[0] == '0'); i++) {
+            const auto &L = m.layers[i], &G = m.layers[i + 1];
+            if (!c->d_w16[i] || L.op != bh::OP_PWCONV || L.res_tensor != bh::NO_TENSOR || G.op != bh::OP_GAP ||
+                G.in_tensor != i + 1 || !bh::head_gap16_supports((int)(L.out_h * L.out_w), (int)L.cin, (int)L.cout, (int)L.act))
+                continue;
+            bool other_reader = m.h.embedding_tensor == i + 1;
+            for (size_t j = 0; j < m.layers.size(); j++)
+                if (j != i + 1 && (m.layers[j].in_tensor == i + 1 || m.layers[j].res_tensor == i + 1)) other_reader = true;
+            if (!other_reader) c->head_gap[i] = 1;
         }
     }
     if (const char *st = getenv("BIRDA_HIP_MB_STAMPS"); st && st[0] == '1' && !c->mb.empty()) {

@@ -175,6 +175,10 @@ void launch_pw_gemm16(const float *A, const void *Wf, const float *bias, const f
                       int act, int terms, hipStream_t s);
 // global average pool [n][P][C] -> [n][C]
 void launch_gap(const float *in, float *out, int n_seg, int P, int C, hipStream_t s);
+// head 1x1 conv + GELU + global average pool fused (f16 hi / lo weight planes as for launch_pw_gemm16)
+bool head_gap16_supports(int P, int K, int N, int act);
+void launch_head_gap16(const float *A, const void *Wf, const float *bias, float *out, int n_seg, int P, int K, int N,
+                       int terms, hipStream_t s);
 // activation + top-k over logits [n][n_classes] -> idx/conf [n][top_k]
 void launch_topk(const float *logits, int n_seg, int n_classes, int out_act, int top_k, float min_conf,
                  int32_t *idx, float *conf, hipStream_t s);

@@ -285,6 +285,153 @@ void launch_pw_gemm16(const float *A, const void *Wf, const float *bias, const f
 }
 
 // ---------------------------------------------------------------------------------------
+// Head 1x1 conv + GELU + global average pool in one launch (split-f16 / f16 MFMA):
+//     out[seg][n] = (1 / P) sum_p GELU(X[seg][p][:] . W[:][n] + b[n])
+// The unfused pair writes the [n_seg * P][N] activation (196 MB per 1000 BirdNET segments) and reads it
+// straight back to average it; here it never exists.  (reference: the last Conv + Mul/Erf + GlobalAveragePool
+// nodes of the ONNX graph behind birdnet_onnx::Classifier::predict_batch, src/inference/classifier.rs:478-488.)
+//
+// Block = 4 waves, 4 * SW segments x 128 output channels; wave w owns SW whole segments (PT row tiles of
+// 16 pixels each) x the block's 8 column tiles: its accumulators hold every pixel of its segments, so
+// the pool is an in-register sum plus two cross-lane adds.  A (f32 rows, 8 consecutive k per lane) goes
+// global -> registers one k step ahead and is split into f16 hi / lo there; the block's 16-KB slice of
+// the pre-split weights (kernels.hpp: [k step][column tile]{hi, lo}[64 lanes][8 halves]) is shared by
+// the four waves through LDS, filled by LDS-DMA one step ahead (double-buffered).
+// Blocks that share their rows of X are placed on the same XCD (blockIdx % 8) back to back, so X is
+// fetched from HBM once and re-read from that XCD's L2 by the other column blocks.
+// ---------------------------------------------------------------------------------------
+template <int PT, int SW, int TERMS>
+__global__ __launch_bounds__(256, 1) void head_gap16_kernel(const float *__restrict__ A, const f16x8 *__restrict__ Wf,
+                                                             const float *__restrict__ bias, float *__restrict__ out,
+                                                             int n_seg, int P, int K, int N, int n_tiles, int n_cb) {
+    constexpr int RT = PT * SW, CT = 8;
+    __shared__ __attribute__((aligned(16))) f16x8 Bs[2][CT * 2 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int xcd = blockIdx.x & 7, bi = blockIdx.x >> 3;
+    const int cb = bi % n_cb, mb = (bi / n_cb) * 8 + xcd;
+    const int seg0 = (mb * 4 + wave) * SW;
+    if (mb * 4 * SW >= n_seg) return;   // whole block
+    const int steps = K / 32;
+
+    // B slice of step st -> Bs[buf]: 16 pieces of 1 KiB, four per wave (M0 = LDS address of the piece)
+    auto dma = [&](int st, int buf) {
+        const f16x8 *src = Wf + ((size_t)st * n_tiles + cb * CT) * 2 * 64;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int piece = q * 4 + wave;
+            const unsigned la = (unsigned)(size_t)(&Bs[buf][piece * 64]);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                         :: "v"(src + piece * 64 + lane), "s"(__builtin_amdgcn_readfirstlane(la)) : "memory", "m0");
+        }
+    };
+    // element offset of the lane's row in A; padding rows (pixel >= P, segment >= n_seg) read a valid row
+    // instead and are left out of the pool below  (a conditional load here crashes hipcc 7.2's machine
+    // copy propagation pass)
+    int aoff[RT];
+#pragma unroll
+    for (int i = 0; i < RT; i++) {
+        const int seg = min(seg0 + i / PT, n_seg - 1), px = min((i % PT) * 16 + li, P - 1);
+        aoff[i] = (seg * P + px) * K + 8 * kq;
+    }
+    float4 ra[RT][2];
+    auto load_a = [&](int st) {
+#pragma unroll
+        for (int i = 0; i < RT; i++) {
+            ra[i][0] = *reinterpret_cast<const float4 *>(A + (size_t)aoff[i] + 32 * st);
+            ra[i][1] = *reinterpret_cast<const float4 *>(A + (size_t)aoff[i] + 32 * st + 4);
+        }
+    };
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int j = 0; j < CT; j++)
+#pragma unroll
+        for (int i = 0; i < RT; i++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f16x8 ah[RT], al[RT];
+    auto split_a = [&]() {
+#pragma unroll
+        for (int i = 0; i < RT; i++) {
+            const float v[8] = {ra[i][0].x, ra[i][0].y, ra[i][0].z, ra[i][0].w, ra[i][1].x, ra[i][1].y, ra[i][1].z, ra[i][1].w};
+            bh_split8(v, ah[i], al[i]);
+        }
+    };
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < CT; j++) {
+            const f16x8 bh = Bs[buf][(j * 2 + 0) * 64 + lane];
+            f16x8 bl;
+            if (TERMS == 3) bl = Bs[buf][(j * 2 + 1) * 64 + lane];
+#pragma unroll
+            for (int i = 0; i < RT; i++) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh, acc[i][j], 0, 0, 0);
+                if (TERMS == 3) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh, acc[i][j], 0, 0, 0);
+                }
+            }
+        }
+    };
+    dma(0, 0);
+    load_a(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int st = 0; st + 1 < steps; st++) {   // the last step is peeled: no conditional loads in the loop
+        dma(st + 1, (st + 1) & 1);
+        split_a();
+        __builtin_amdgcn_sched_barrier(0);    // the split stays out of the MFMA sequence (see mel_kernel)
+        load_a(st + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(st & 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    split_a();
+    __builtin_amdgcn_sched_barrier(0);
+    compute((steps - 1) & 1);
+
+    // GELU, then the mean over the segment's pixels: rows 4 kq + r of PT tiles in registers, kq across lanes
+    const float inv_p = 1.0f / (float)P;
+#pragma unroll
+    for (int sg = 0; sg < SW; sg++) {
+        const int seg = seg0 + sg;
+#pragma unroll
+        for (int j = 0; j < CT; j++) {
+            float sum = 0.0f;
+            const float b = bias[(cb * CT + j) * 16 + li];
+#pragma unroll
+            for (int t = 0; t < PT; t++) {
+                bh_f32x2 v01 = {acc[sg * PT + t][j][0] + b, acc[sg * PT + t][j][1] + b}, v23 = {acc[sg * PT + t][j][2] + b, acc[sg * PT + t][j][3] + b};
+                gelu_erf_fast4(v01, v23);
+                const int px = t * 16 + 4 * kq;
+                if (PT * 16 == P || px + 3 < P) sum += (v01[0] + v01[1]) + (v23[0] + v23[1]);
+                else sum += (px < P ? v01[0] : 0.f) + (px + 1 < P ? v01[1] : 0.f) + (px + 2 < P ? v23[0] : 0.f);
+            }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            if (kq == 0 && seg < n_seg) out[(size_t)seg * N + (cb * CT + j) * 16 + li] = sum * inv_p;
+        }
+    }
+}
+
+// P pixels per segment; the instantiations cover P <= 48 (two segments per wave) and P <= 80 (one)
+bool head_gap16_supports(int P, int K, int N, int act) {
+    return act == ACT_GELU_ERF && K % 32 == 0 && N % 128 == 0 && P >= 1 && P <= 80;
+}
+
+void launch_head_gap16(const float *A, const void *Wf, const float *bias, float *out, int n_seg, int P, int K, int N,
+                       int terms, hipStream_t s) {
+    const int n_tiles = N / 16, n_cb = N / 128;
+    const int pt = (P + 15) / 16, sw = pt <= 3 ? 2 : 1;
+    const int n_mb = (n_seg + 4 * sw - 1) / (4 * sw);
+    dim3 grid((unsigned)(((n_mb + 7) / 8) * n_cb * 8)), block(256);
+#define BH_HG(PTV, SWV, T) hipLaunchKernelGGL((head_gap16_kernel<PTV, SWV, T>), grid, block, 0, s, A, (const f16x8 *)Wf, bias, out, \
+                                              n_seg, P, K, N, n_tiles, n_cb)
+    if (pt <= 3) { if (terms == 3) BH_HG(3, 2, 3); else BH_HG(3, 2, 1); }
+    else { if (terms == 3) BH_HG(5, 1, 3); else BH_HG(5, 1, 1); }
+#undef BH_HG
+}
+
+// ---------------------------------------------------------------------------------------
 // Depthwise conv, NHWC.  One lane = one output pixel x 4 channels; lanes run over the
 // channel groups first, so a wave reads/writes contiguous 16-B pieces of NHWC rows.
 // ---------------------------------------------------------------------------------------
