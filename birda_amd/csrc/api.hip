@@ -502,7 +502,8 @@ int plan_fusion(bh_classifier *c) {
         const float *be = m.blob.data() + E.b_off, *bd = m.blob.data() + D.b_off;
         const bool h16 = d.prec != 0;
         const size_t frag = h16 ? 512 : 256, psteps = h16 ? (CE + 31) / 32 : NTE;
-        const size_t we_fl = (size_t)KG * NTE * frag + CE, wp_fl = psteps * NTOP * frag, wd_fl = (size_t)KK * CE + CE;
+        const bool p16 = h16 && CE == 16;   // project GEMM as one 16-deep step: [column tile]{hi, lo}[64 lanes][4 halves]
+        const size_t we_fl = (size_t)KG * NTE * frag + CE, wp_fl = p16 ? (size_t)NTOP * 256 : psteps * NTOP * frag, wd_fl = (size_t)KK * CE + CE;
         std::vector<float> wef(nch * we_fl, 0.0f), wpf(nch * wp_fl, 0.0f), wdf(nch * wd_fl, 0.0f);
         auto we_at = [&](int k, int n) { return (k < d.Cin && n < d.Cexp) ? We[(size_t)k * d.Cexp + n] : 0.0f; };
         auto wp_at = [&](int k, int n) { return (k < d.Cexp && n < d.Cout) ? Wp[(size_t)k * d.Cout + n] : 0.0f; };
@@ -530,7 +531,18 @@ int plan_fusion(bh_classifier *c) {
                         }
                     }
             for (int n = 0; n < CE; n++) wef[ch * we_fl + (size_t)KG * NTE * frag + n] = ch * CE + n < d.Cexp ? be[ch * CE + n] : 0.0f;
-            for (int g = 0; g < (int)psteps; g++)
+            if (p16) {
+                for (int j = 0; j < NTOP; j++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int jj = 0; jj < 4; jj++) {
+                            const float v = wp_at(ch * CE + 4 * (lane >> 4) + jj, 16 * j + (lane & 15));
+                            uint16_t *h = reinterpret_cast<uint16_t *>(wpf.data() + ch * wp_fl + (size_t)j * 256);
+                            const uint16_t hi = f32_to_f16(v);
+                            h[(size_t)lane * 4 + jj] = hi;
+                            h[(size_t)(64 + lane) * 4 + jj] = f32_to_f16(v - f16_to_f32(hi));
+                        }
+            }
+            for (int g = 0; g < (int)psteps && !p16; g++)
                 for (int j = 0; j < NTOP; j++)
                     for (int lane = 0; lane < 64; lane++) {
                         const int n = 16 * j + (lane & 15);

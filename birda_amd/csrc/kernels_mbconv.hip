@@ -120,7 +120,7 @@ template <int KS, int ST, int CE, int KG, int RT_W, int NCS, int WM, int WN, int
           int SS, int OCC, int STEM, int PREC>
 __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const int n_seg) {
     static_assert(!STEM || SS == 1, "the stem variant handles one segment per workgroup");
-    static_assert(PREC == 0 || CE % 32 == 0 || CE == 16, "f16 MFMA steps are 32 deep (16-channel chunks: zero-padded)");
+    static_assert(PREC == 0 || CE % 32 == 0 || CE == 16, "f16 project GEMM: 32-deep steps, or one 16-deep step for 16-channel chunks");
     static_assert(WM * WN == 4, "4 waves");
     constexpr int NT_E = CE / 16, NT_U = NT_E / NCS, CES = CE + 4, C4N = CE / 4, TW = 1 << TWL;
     constexpr int POUT_PAD = WM * MT_W * 16, NTOP = WN * NT_W;
@@ -129,10 +129,11 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
     constexpr int RG = (RT_W * NT_U <= 8) ? RT_W : (8 / NT_U >= 1 ? 8 / NT_U : 1);  // row tiles in flight
     constexpr int FRAG = PREC ? 512 : 256;             // floats per (k step, column tile): f16 = hi + lo planes
     constexpr int PSTEPS = PREC ? (CE + 31) / 32 : NT_E;  // k steps of the project GEMM per chunk
+    constexpr bool P16 = PREC != 0 && CE == 16;        // 16-channel chunks: ONE v_mfma_f32_16x16x16_f16 step, no k padding
     constexpr int WE_FLOATS = KG * NT_E * FRAG + CE;   // We fragments + be
-    constexpr int WP_FLOATS = PSTEPS * NTOP * FRAG;
+    constexpr int WP_FLOATS = P16 ? NTOP * 256 : PSTEPS * NTOP * FRAG;
     constexpr int WD_FLOATS = KS * KS * CE + CE;       // Wd [tap][CE] + bd
-    constexpr int DSH = PSTEPS * 32 + 8;               // f16 D planes: row stride in halves (80 B: conflict-free b128)
+    constexpr int DSH = P16 ? 24 : PSTEPS * 32 + 8;    // f16 D planes: row stride in halves (48 / 80 B: conflict-free reads)
     constexpr int DS_FLOATS = PREC ? POUT_PAD * DSH : POUT_PAD * CES;
     static_assert(NT_U * NCS == NT_E, "column split");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -234,10 +235,6 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
         int o = -1;
         if (sl < nsv && oy0 + ty < d.Ho && ox0 + tx < d.Wo) o = (sl * d.Ho + oy0 + ty) * d.Wo + ox0 + tx;
         omap[p] = o;
-    }
-    if constexpr (PREC != 0 && CE % 32 != 0) {   // the k padding of the project GEMM's A operand
-        float4 *z = reinterpret_cast<float4 *>(Ds);
-        for (int i = tid; i < DS_FLOATS / 4; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (M != egrid) {  // some of the grid lies outside the image (or a segment is missing): zero padding
         float4 *z = reinterpret_cast<float4 *>(Es);
@@ -447,7 +444,32 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
 
         // ---- P3: project -----------------------------------------------------------------
         if (!(d.dbg & 4)) {
-            if constexpr (PREC != 0) {
+            if constexpr (P16) {
+                // fragment planes: [column tile]{hi: 64 lanes x 4 halves, lo: same}; k = 4 (lane >> 4) + 0..3
+                const f16x4 *wf = reinterpret_cast<const f16x4 *>(WpS);
+                f16x4 a_h[MT_W], a_l[MT_W], b_h[NT_W], b_l[NT_W];
+#pragma unroll
+                for (int i = 0; i < MT_W; i++) {
+                    const int row = (wm * MT_W + i) * 16 + li;
+                    a_h[i] = *reinterpret_cast<const f16x4 *>(&DsH[row * DSH + 4 * kq]);
+                    if (PREC == 3) a_l[i] = *reinterpret_cast<const f16x4 *>(&DsL[row * DSH + 4 * kq]);
+                }
+#pragma unroll
+                for (int j = 0; j < NT_W; j++) {
+                    b_h[j] = wf[((wn * NT_W + j) * 2 + 0) * 64 + lane];
+                    if (PREC == 3) b_l[j] = wf[((wn * NT_W + j) * 2 + 1) * 64 + lane];
+                }
+#pragma unroll
+                for (int i = 0; i < MT_W; i++)
+#pragma unroll
+                    for (int j = 0; j < NT_W; j++) {
+                        acco[i][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(a_h[i], b_h[j], acco[i][j], 0, 0, 0);
+                        if (PREC == 3) {
+                            acco[i][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(a_h[i], b_l[j], acco[i][j], 0, 0, 0);
+                            acco[i][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(a_l[i], b_h[j], acco[i][j], 0, 0, 0);
+                        }
+                    }
+            } else if constexpr (PREC != 0) {
                 const f16x8 *wf = reinterpret_cast<const f16x8 *>(WpS);
 #pragma unroll
                 for (int g = 0; g < PSTEPS; g++) {
@@ -634,6 +656,10 @@ const MbCfg kCfgs[] = {
     MB_ENTRY_S(3, 1, 16, 2, 3, 1, 4, 1, 2, 1, 4, 1, 8, 1, 4, 2),       // 64: as 20, 4 waves per SIMD
     MB_ENTRY_P(3, 1, 16, 1, 3, 1, 4, 1, 2, 1, 4, 1, 8, 1, 4, 2, 3),    // 65: as 53, 4 waves per SIMD
     MB_ENTRY_P(3, 1, 16, 1, 3, 1, 4, 1, 2, 1, 4, 1, 8, 1, 4, 1, 3),    // 66: as 54, 4 waves per SIMD
+    // 16-channel chunks for the 3x16 blocks: with the 16-deep project step the workgroup needs < 80 KB of LDS,
+    // so two share a CU
+    MB_ENTRY_P(5, 1, 16, 6, 2, 1, 2, 2, 3, 6, 4, 2, 3, 2, 2, 0, 3),    // 67: as 40 (192 -> 1152 -> 192, 3x16 x 2)
+    MB_ENTRY_P(3, 1, 16, 6, 2, 1, 2, 2, 3, 10, 4, 2, 3, 2, 2, 0, 3),   // 68: as 42 (192 -> 1152 -> 320)
 };
 constexpr int kNCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
@@ -662,9 +688,10 @@ double mb_try_th(MbDesc &d, int ci, int th) {
     t.mpad_max = (c.S * mseg + 15) / 16 * 16;
     if (t.mpad_max / 16 > c.RT_W * (4 / c.NCS)) return -1;  // a wave keeps all its rows of X in registers
     const size_t frag = c.PREC ? 512 : 256, psteps = c.PREC ? (c.CE + 31) / 32 : c.CE / 16;
-    const size_t we_fl = (size_t)c.KG * (c.CE / 16) * frag + c.CE, wp_fl = psteps * t.NTOP * frag;
+    const bool p16 = c.PREC && c.CE == 16;   // one 16-deep project step, half-size fragments and D rows
+    const size_t we_fl = (size_t)c.KG * (c.CE / 16) * frag + c.CE, wp_fl = p16 ? (size_t)t.NTOP * 256 : psteps * t.NTOP * frag;
     const size_t wd_fl = (size_t)c.KS * c.KS * c.CE + c.CE;
-    const size_t ds_fl = c.PREC ? (size_t)pout_pad * (psteps * 32 + 8) : (size_t)pout_pad * ces;
+    const size_t ds_fl = c.PREC ? (size_t)pout_pad * (p16 ? 24 : psteps * 32 + 8) : (size_t)pout_pad * ces;
     t.lds_bytes = (((size_t)c.S * t.IH * t.IW + 1) * ces + ds_fl + we_fl + wp_fl + wd_fl) * 4 +
                   (size_t)pout_pad * 4;
     if (t.lds_bytes > 160 * 1024) return -1;
