@@ -402,6 +402,29 @@ def test_precision_modes_on_the_full_model(full_model, oracle_lib):
     assert (out["f16"].argmax(1) == ref.argmax(1)).all() and (out["f16x3"].argmax(1) == ref.argmax(1)).all()
 
 
+def test_fused_head_pool_matches_the_layer_kernels(full_model, oracle_lib, monkeypatch):
+    """Head 1x1 conv + GELU + global average pool in one launch (f16 modes) against the same layers run
+    one by one (BIRDA_HIP_HEAD_GAP=0) and against the oracle; a ragged batch (n not a multiple of the 8
+    segments a workgroup owns) exercises the clamped padding rows."""
+    from birda_amd import synth
+    from birda_amd.classifier import BirdClassifier
+    path, labels, m, _ = full_model
+    segs = synth.synth_segments(11, m.sample_count, m.sample_rate, start=300)
+    ref = oracle_lib.OracleModel(path).forward(segs[:3])
+    scale = max(1.0, float(np.abs(ref).max()))
+    for prec, tol in (("f16x3", LOGIT_RTOL), ("f16", F16_LOGIT_RTOL)):
+        got = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("BIRDA_HIP_HEAD_GAP", flag)
+            clf = BirdClassifier(path, labels, precision=prec)
+            ctx = clf.create_batch_context(16)
+            got[flag] = clf.predict_logits(ctx, segs)
+            ctx.close(); clf.close()
+        assert np.isfinite(got["1"]).all()
+        assert np.abs(got["1"] - got["0"]).max() <= tol * scale, prec
+        assert np.abs(got["1"][:3] - ref).max() <= tol * scale, prec
+
+
 # ---- C4: Perch-shaped model (5 s / 32 kHz, one 128-mel branch, 14 795 classes, softmax) --------
 def test_perch_shaped_model_matches_oracle(oracle_lib, tmp_path, monkeypatch):
     from birda_amd import modelfile as mf, synth
