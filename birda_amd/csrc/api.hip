@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -15,6 +16,7 @@
 #include <mutex>
 #include <set>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/birda_hip.h"
@@ -78,6 +80,8 @@ struct bh_batch_context {
     size_t max_batch = 0;
     bool keep_tensors = false;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;       // H2D of host batches, ahead of the compute stream
+    std::vector<hipEvent_t> copy_ev;         // one per sub-slice in flight
     float *d_input = nullptr;    // [max_batch][sample_count]
     float *d_minmax = nullptr;   // [max_batch][8][2]
     float *d_arena = nullptr;
@@ -258,6 +262,7 @@ int ctx_create(bh_classifier *c, size_t max_batch, bool keep, bh_batch_context *
     ctx->keep_tensors = keep;
     const auto &m = c->model;
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
     const size_t in_bytes = max_batch * (size_t)m.h.sample_count * sizeof(float);
     HIPCHK(hipMalloc((void **)&ctx->d_input, in_bytes));
     HIPCHK(hipMalloc((void **)&ctx->d_minmax, max_batch * 16 * sizeof(float)));
@@ -280,6 +285,8 @@ void ctx_destroy(bh_batch_context *ctx) {
     (void)hipSetDevice(ctx->c->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto e : ctx->ev) (void)hipEventDestroy(e);
+    for (auto e : ctx->copy_ev) (void)hipEventDestroy(e);
+    if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
     (void)hipFree(ctx->d_input); (void)hipFree(ctx->d_minmax); (void)hipFree(ctx->d_arena);
     (void)hipFree(ctx->d_logits); (void)hipFree(ctx->d_topk_idx); (void)hipFree(ctx->d_topk_conf);
     (void)hipHostFree(ctx->h_input); (void)hipHostFree(ctx->h_topk_idx); (void)hipHostFree(ctx->h_topk_conf);
@@ -380,29 +387,86 @@ int check_ctx(bh_classifier *c, bh_batch_context *ctx) {
     return BH_OK;
 }
 
-// host slices -> results through ctx
+// Host threads that gather the caller's segment slices into the pinned staging buffer
+// (BIRDA_HIP_COPY_THREADS; default min(8, hardware threads / 2)).  One thread moves ~10 GB/s, a fifth of
+// what the PCIe link takes.
+unsigned copy_threads() {
+    static const unsigned n = [] {
+        if (const char *e = getenv("BIRDA_HIP_COPY_THREADS")) return (unsigned)std::max(1, atoi(e));
+        const unsigned hw = std::thread::hardware_concurrency();
+        return std::max(1u, std::min(8u, hw / 2));
+    }();
+    return n;
+}
+
+// host slices -> results through ctx.
+// A slice of up to max_batch segments is pipelined three ways: worker threads gather 32-segment chunks into
+// pinned memory; each chunk's H2D copy is enqueued on the copy stream as soon as it is complete; and the
+// slice is computed in up to four sub-slices on the compute stream, each waiting only for its own copies
+// (reference: the decode thread filling the channel while the main thread runs batches,
+// src/pipeline/processor.rs:647-671).
 int predict_slices(bh_classifier *c, bh_batch_context *ctx, const float *const *segments, const float *contig,
                    size_t n, bh_result *out, float *logits_out, float *emb_out) {
     const auto &m = c->model;
-    const size_t S = m.h.sample_count;
+    const size_t S = m.h.sample_count, NC = m.h.n_classes, TK = c->top_k;
     HIPCHK(hipSetDevice(c->device));
+    if (segments)
+        for (size_t i = 0; i < n; i++)
+            if (!segments[i]) return fail(BH_ERR_INVALID, "segment %zu is null", i);
     for (size_t b0 = 0; b0 < n; b0 += ctx->max_batch) {
         const size_t nb = std::min(ctx->max_batch, n - b0);
-        for (size_t i = 0; i < nb; i++) {
-            const float *src = segments ? segments[b0 + i] : contig + (b0 + i) * S;
-            if (!src) return fail(BH_ERR_INVALID, "segment %zu is null", b0 + i);
-            memcpy(ctx->h_input + i * S, src, S * sizeof(float));
+        constexpr size_t CH = 32;
+        const size_t nchunks = (nb + CH - 1) / CH;
+        // sub-slices: a quarter of the slice, in whole chunks, never below 128 segments (the late blocks
+        // need that many to fill the GPU); debug contexts keep one (bh_debug_read_tensor reads the last)
+        size_t sub = nb;
+        if (nb >= 512 && !ctx->keep_tensors && !emb_out) sub = std::max<size_t>(128, ((nb + 3) / 4 + CH - 1) / CH * CH);
+        const size_t nsub = (nb + sub - 1) / sub;
+        while (ctx->copy_ev.size() < nsub) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->copy_ev.push_back(e);
         }
-        HIPCHK(hipMemcpyAsync(ctx->d_input, ctx->h_input, nb * S * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-        int rc = forward_slice(c, ctx, ctx->d_input, nb, ctx->d_logits, ctx->d_topk_idx, ctx->d_topk_conf);
-        if (rc != BH_OK) return rc;
+        auto gather = [&](size_t j) {
+            const size_t i1 = std::min(nb, (j + 1) * CH);
+            for (size_t i = j * CH; i < i1; i++) {
+                const float *src = segments ? segments[b0 + i] : contig + (b0 + i) * S;
+                memcpy(ctx->h_input + i * S, src, S * sizeof(float));
+            }
+        };
+        const unsigned nthreads = (unsigned)std::min<size_t>(copy_threads(), nchunks);
+        std::vector<std::atomic<int>> done(nchunks);
+        for (auto &d : done) d.store(0, std::memory_order_relaxed);
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> workers;
+        if (nthreads > 1)
+            for (unsigned t = 0; t < nthreads; t++)
+                workers.emplace_back([&] {
+                    for (size_t j; (j = next.fetch_add(1)) < nchunks;) { gather(j); done[j].store(1, std::memory_order_release); }
+                });
+        int rc = BH_OK;
+        for (size_t j = 0; j < nchunks && rc == BH_OK; j++) {
+            if (nthreads > 1) while (!done[j].load(std::memory_order_acquire)) std::this_thread::yield();
+            else gather(j);
+            const size_t i0 = j * CH, i1 = std::min(nb, (j + 1) * CH);
+            if (hipMemcpyAsync(ctx->d_input + i0 * S, ctx->h_input + i0 * S, (i1 - i0) * S * sizeof(float), hipMemcpyHostToDevice,
+                               ctx->copy_stream) != hipSuccess) { rc = fail(BH_ERR_HIP, "H2D copy failed"); break; }
+            if (i1 % sub == 0 || i1 == nb) {   // a sub-slice is complete on the copy stream: compute it
+                const size_t si = (i1 - 1) / sub, s0 = si * sub, ns = i1 - s0;
+                if (hipEventRecord(ctx->copy_ev[si], ctx->copy_stream) != hipSuccess ||
+                    hipStreamWaitEvent(ctx->stream, ctx->copy_ev[si], 0) != hipSuccess) { rc = fail(BH_ERR_HIP, "stream event failed"); break; }
+                rc = forward_slice(c, ctx, ctx->d_input + s0 * S, ns, ctx->d_logits + s0 * NC, ctx->d_topk_idx + s0 * TK,
+                                   ctx->d_topk_conf + s0 * TK);
+            }
+        }
+        for (auto &w : workers) w.join();
+        if (rc != BH_OK) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamSynchronize(ctx->stream); return rc; }
         if (out) {
-            HIPCHK(hipMemcpyAsync(ctx->h_topk_idx, ctx->d_topk_idx, nb * c->top_k * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(hipMemcpyAsync(ctx->h_topk_conf, ctx->d_topk_conf, nb * c->top_k * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipMemcpyAsync(ctx->h_topk_idx, ctx->d_topk_idx, nb * TK * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipMemcpyAsync(ctx->h_topk_conf, ctx->d_topk_conf, nb * TK * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
         }
         if (logits_out)
-            HIPCHK(hipMemcpyAsync(logits_out + b0 * m.h.n_classes, ctx->d_logits, nb * (size_t)m.h.n_classes * sizeof(float),
-                                  hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipMemcpyAsync(logits_out + b0 * NC, ctx->d_logits, nb * NC * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
         if (emb_out)
             HIPCHK(hipMemcpyAsync(emb_out + b0 * m.h.embedding_dim, ctx->d_arena + ctx->t_off[m.h.embedding_tensor],
                                   nb * (size_t)m.h.embedding_dim * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
