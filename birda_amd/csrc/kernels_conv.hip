@@ -575,81 +575,85 @@ void launch_gap(const float *in, float *out, int n_seg, int P, int C, hipStream_
 // activation + top-k (block per segment).  Ranks on the logit (monotone in the confidence,
 // immune to saturated-sigmoid ties), ties to the lower class index -- same rule as the
 // oracle's bo_topk.  idx = -1 / conf = 0 pad the unused slots.
+// The row is read from HBM once into LDS; a selection pass is a per-thread scan of LDS, a wave
+// reduction through lane shuffles and one barrier; a chosen class is struck out by overwriting its
+// LDS entry with NaN (NaN logits are never chosen).
 // ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void topk_better(float &bv, int &bi, float ov, int oi) {
+    if (oi >= 0 && (bi < 0 || ov > bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
+}
+
 __global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ logits, int n_classes, int out_act,
                                                     int top_k, float min_conf, int32_t *__restrict__ idx,
                                                     float *__restrict__ conf) {
-    const int seg = blockIdx.x;
+    extern __shared__ float row[];   // n_classes logits
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    __shared__ float red[1];
+    const int seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *lg = logits + (size_t)seg * n_classes;
-    __shared__ float sv[256];
-    __shared__ int si[256];
-    __shared__ int chosen[32];
-    __shared__ float red[2];
-    const int tid = threadIdx.x;
+    float m = -INFINITY;
+    for (int i = tid; i < n_classes; i += 256) { const float v = lg[i]; row[i] = v; m = fmaxf(m, v); }
     // softmax statistics
     float mx = -INFINITY, sum = 0.f;
     if (out_act == 2) {
-        float m = -INFINITY;
-        for (int i = tid; i < n_classes; i += 256) m = fmaxf(m, lg[i]);
-        sv[tid] = m;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) sv[wave] = m;
         __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) { if (tid < s) sv[tid] = fmaxf(sv[tid], sv[tid + s]); __syncthreads(); }
-        mx = sv[0];
-        __syncthreads();
+        mx = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
         // the oracle sums exp() in class order; do the same on one lane for bit-stable sums
         if (tid == 0) {
             float sacc = 0.f;
-            for (int i = 0; i < n_classes; i++) sacc += expf(lg[i] - mx);
+            for (int i = 0; i < n_classes; i++) sacc += expf(row[i] - mx);
             red[0] = sacc;
         }
         __syncthreads();
         sum = red[0];
     }
-    int kept = 0;
+    __syncthreads();
     bool stop = false;
     for (int k = 0; k < top_k; k++) {
         float bv = -INFINITY; int bi = -1;
         if (!stop) {
             for (int i = tid; i < n_classes; i += 256) {
-                const float v = lg[i];
-                if (v != v) continue;
-                bool taken = false;
-                for (int j = 0; j < kept; j++) taken |= (chosen[j] == i);
-                if (taken) continue;
-                if (bi < 0 || v > bv) { bv = v; bi = i; }
+                const float v = row[i];
+                if (v != v) continue;          // NaN logit, or a class already chosen
+                if (bi < 0 || v > bv) { bv = v; bi = i; }   // ascending i: ties keep the lower index
             }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) topk_better(bv, bi, __shfl_xor(bv, o, 64), __shfl_xor(bi, o, 64));
         }
-        sv[tid] = bv; si[tid] = bi;
+        if (lane == 0) { sv[wave] = bv; si[wave] = bi; }
         __syncthreads();
-        for (int s = 128; s > 0; s >>= 1) {
-            if (tid < s) {
-                const float ov = sv[tid + s]; const int oi = si[tid + s];
-                const bool take = oi >= 0 && (si[tid] < 0 || ov > sv[tid] || (ov == sv[tid] && oi < si[tid]));
-                if (take) { sv[tid] = ov; si[tid] = oi; }
-            }
-            __syncthreads();
-        }
-        const int best = si[0];
+        bv = sv[0]; bi = si[0];
+        topk_better(bv, bi, sv[1], si[1]);
+        topk_better(bv, bi, sv[2], si[2]);
+        topk_better(bv, bi, sv[3], si[3]);
         float p = 0.f;
-        if (best >= 0) {
-            const float v = sv[0];
-            p = out_act == 1 ? 1.0f / (1.0f + expf(-v)) : out_act == 2 ? expf(v - mx) / sum : v;
-        }
-        const bool ok = !stop && best >= 0 && p >= min_conf;
+        if (bi >= 0) p = out_act == 1 ? 1.0f / (1.0f + expf(-bv)) : out_act == 2 ? expf(bv - mx) / sum : bv;
+        const bool ok = !stop && bi >= 0 && p >= min_conf;
         if (!ok) stop = true;
         if (tid == 0) {
-            idx[(size_t)seg * top_k + k] = ok ? best : -1;
+            idx[(size_t)seg * top_k + k] = ok ? bi : -1;
             conf[(size_t)seg * top_k + k] = ok ? p : 0.f;
-            if (ok) chosen[kept] = best;
+            if (ok) row[bi] = __builtin_nanf("");
         }
-        if (ok) kept++;
         __syncthreads();
     }
 }
 
 void launch_topk(const float *logits, int n_seg, int n_classes, int out_act, int top_k, float min_conf,
                  int32_t *idx, float *conf, hipStream_t s) {
-    hipLaunchKernelGGL(topk_kernel, dim3(n_seg), dim3(256), 0, s, logits, n_classes, out_act, top_k, min_conf, idx, conf);
+    static bool attr_set = false;
+    if (!attr_set) {
+        // (the kernel also has a few static __shared__ words: ask for less than the full 160 KB)
+        if (hipFuncSetAttribute((const void *)topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
+            (void)hipGetLastError();
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(topk_kernel, dim3(n_seg), dim3(256), (size_t)n_classes * sizeof(float), s, logits, n_classes, out_act, top_k,
+                       min_conf, idx, conf);
 }
 
 }  // namespace bh
