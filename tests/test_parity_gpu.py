@@ -182,6 +182,32 @@ def test_predict_entry_points_agree_and_preserve_order(clf_tiny, model_dir):
     ctx.close(); ctx5.close()
 
 
+def test_host_batch_pipeline_matches_the_device_path(clf_mini, model_dir):
+    """The host entry points gather 32-segment chunks on worker threads, copy each chunk on a second
+    stream and compute the slice in sub-slices (n >= 512): rows must come back in order and bit-identical
+    to one device-resident forward of the same batch, for scattered slices as well as a contiguous block."""
+    import torch
+    _, _, m, _ = model_dir["mini"]
+    from birda_amd import synth
+    n = 700                                            # 4 sub-slices of 192 (last 124), 22 chunks
+    uniq = synth.synth_segments(50, m.sample_count, m.sample_rate, start=900)
+    segs = uniq[np.arange(n) % 50]
+    ctx = clf_mini.create_batch_context(n)
+    x = torch.from_numpy(segs).cuda()
+    dev = torch.empty((n, m.n_classes), device="cuda")
+    clf_mini.forward_device(ctx, x.data_ptr(), n, dev.data_ptr()); ctx.synchronize()
+    want = dev.cpu().numpy()
+    assert np.array_equal(clf_mini.predict_logits(ctx, segs), want)
+    res = clf_mini.predict_batch_with_context(ctx, [segs[i] for i in range(n)])      # scattered host slices
+    top1 = want.argmax(1)
+    for i, r in enumerate(res):
+        if r.predictions:
+            assert r.predictions[0].index == top1[i]
+    small = clf_mini.create_batch_context(96)          # slices of 96 < n: several slices, one sub-slice each
+    assert np.array_equal(clf_mini.predict_logits(small, segs), want)
+    ctx.close(); small.close()
+
+
 def test_error_behaviour(clf_tiny, model_dir):
     from birda_amd._lib import BirdaHipError
     _, _, m, _ = model_dir["birdnet_v24_tiny"]
