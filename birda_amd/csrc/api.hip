@@ -79,6 +79,7 @@ struct bh_batch_context {
     bh_classifier *c = nullptr;
     size_t max_batch = 0;
     bool keep_tensors = false;
+    bool keep_fused = false;   // BIRDA_HIP_KEEP_FUSED=1: a debug context still runs the fused blocks (their outputs are readable)
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;       // H2D of host batches, ahead of the compute stream
     std::vector<hipEvent_t> copy_ev;         // one per sub-slice in flight
@@ -260,6 +261,7 @@ int ctx_create(bh_classifier *c, size_t max_batch, bool keep, bh_batch_context *
     ctx->c = c;
     ctx->max_batch = max_batch;
     ctx->keep_tensors = keep;
+    if (const char *kf = getenv("BIRDA_HIP_KEEP_FUSED")) ctx->keep_fused = kf[0] == '1';
     const auto &m = c->model;
     HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
@@ -316,7 +318,7 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
         bh::ConvParams p{(int)L.in_h, (int)L.in_w, (int)L.out_h, (int)L.out_w, (int)L.cin, (int)L.cout,
                          (int)L.kh, (int)L.kw, (int)L.sh, (int)L.sw, (int)L.pad_t, (int)L.pad_l,
                          (int)L.in_layout, (int)L.act};
-        if (!ctx->keep_tensors && c->fused_at[i] >= 0) {
+        if ((!ctx->keep_tensors || ctx->keep_fused) && c->fused_at[i] >= 0) {
             // expand (i) -> depthwise (i+1) -> project (i+2) in one launch
             bh::MbDesc d = c->mb[c->fused_at[i]];
             const auto &LP = m.layers[i + 2];

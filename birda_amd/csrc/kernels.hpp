@@ -24,12 +24,12 @@ constexpr int MAX_BRANCHES = 4;
 #define BH_GELU_C6 -0.00018617883324623108f
 #define BH_GELU_C7 3.93775844713673e-05f
 #define BH_GELU_C8 -2.834923634509323e-06f
-// max(v, 0) as ONE v_max_f32: fmaxf() in IEEE mode first canonicalises its operand (a second v_max)
-__device__ __forceinline__ float bh_relu1(float v) {
-    float m;
-    asm("v_max_f32_e32 %0, 0, %1" : "=v"(m) : "v"(v));
-    return m;
-}
+// max(v, 0) as ONE instruction (v_med3_f32 v, 0, 3e38: the finite bound keeps hipcc from rewriting it as a canonicalise + max pair): fmaxf() in IEEE mode first canonicalises its operand
+// (a second v_max).  NOT inline asm: the operand is usually an MFMA result, and hipcc places the wait
+// states an MFMA -> VALU read needs only in front of instructions it knows -- an inline-asm v_max_f32
+// here read stale accumulators whenever fewer than ~10 instructions separated it from the last MFMA
+// (single-tile groups of the expand GEMM).
+__device__ __forceinline__ float bh_relu1(float v) { return __builtin_amdgcn_fmed3f(v, 0.0f, 3.0e38f); }
 __device__ __forceinline__ float gelu_erf_fast(float v) {
     const float m = bh_relu1(v);
     const float a = __builtin_fmaf(m, 2.0f, -v);   // |v|, exactly

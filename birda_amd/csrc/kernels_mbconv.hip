@@ -660,6 +660,7 @@ const MbCfg kCfgs[] = {
     // so two share a CU
     MB_ENTRY_P(5, 1, 16, 6, 2, 1, 2, 2, 3, 6, 4, 2, 3, 2, 2, 0, 3),    // 67: as 40 (192 -> 1152 -> 192, 3x16 x 2)
     MB_ENTRY_P(3, 1, 16, 6, 2, 1, 2, 2, 3, 10, 4, 2, 3, 2, 2, 0, 3),   // 68: as 42 (192 -> 1152 -> 320)
+    MB_ENTRY_P(3, 2, 16, 1, 9, 1, 4, 1, 2, 2, 4, 1, 8, 1, 2, 0, 3),    // 69: as 48, tile 8x16 (17x33 source rows: 10 % halo; the one entry whose last expand group is a single row tile)
 };
 constexpr int kNCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
