@@ -370,6 +370,34 @@ def test_fused_blocks_match_unfused_and_oracle_on_small_images(model_dir, oracle
     assert np.array_equal(fused, sliced)
 
 
+def test_fused_block_outputs_match_oracle_tensor_by_tensor(model_dir, oracle_lib, monkeypatch):
+    """Every fused block's OUTPUT tensor against the oracle's (BIRDA_HIP_KEEP_FUSED=1: a debug context that
+    still runs the fused kernels), both precisions: a wrong tile or row group shows up here even when the
+    logits would average it away."""
+    from birda_amd import modelfile as mf, synth
+    from birda_amd.classifier import BirdClassifier
+    monkeypatch.setenv("BIRDA_HIP_KEEP_TENSORS", "1")
+    monkeypatch.setenv("BIRDA_HIP_KEEP_FUSED", "1")
+    path, _, m, _ = model_dir["mini_b0"]
+    n = 3
+    segs = synth.synth_segments(n, m.sample_count, m.sample_rate, start=21)
+    om = oracle_lib.OracleModel(path)
+    outs = [li + 1 for li, L in enumerate(m.layers) if L.op == mf.OP_PWCONV and L.act == mf.ACT_NONE]   # project layers
+    refs = {t: om.forward(segs, dump_tensor=t)[1] for t in outs}
+    for prec in ("f32", "f16x3"):
+        clf = BirdClassifier(path, precision=prec)
+        assert len(clf.fused_blocks()) == 16
+        ctx = clf.create_batch_context(n)
+        clf.predict_logits(ctx, segs)
+        for t in outs:
+            got, ref = clf.read_tensor(ctx, t, n), refs[t]
+            scale = max(1.0, float(np.abs(ref).max()))
+            d = np.abs(got - ref)
+            assert np.isfinite(got).all(), (prec, t)
+            assert d.max() <= SPEC_MAX_ATOL * scale and d.mean() <= SPEC_MEAN_ATOL * scale, (prec, t, d.max(), d.mean())
+        ctx.close(); clf.close()
+
+
 def test_every_fused_tile_configuration(model_dir, oracle_lib, monkeypatch):
     """Force each tile configuration in turn (f32 MFMA: 0-21; split-f16 x3: even 22-46 and 48-54; plain
     f16: odd 23-47; 48-69: split-f16 x3 variants, 63 / 64 f32); blocks it cannot run fall back to the layer kernels."""
