@@ -9,7 +9,8 @@ from birda_amd.classifier import BirdClassifier
 from oracle import oracle as O
 
 kind, cfg, prec = sys.argv[1], int(sys.argv[2]), sys.argv[3]
-os.environ["BIRDA_HIP_MB_CFG"] = str(cfg)
+if cfg >= 0:
+    os.environ["BIRDA_HIP_MB_CFG"] = str(cfg)   # < 0: the planner's own choice per block
 m = synth.build_model(kind)
 path = f"/tmp/{kind}.bhm"; mf.write_model(path, m)
 n = 2
