@@ -32,9 +32,10 @@ PEAK_F16_MFMA_TFLOPS = 2500.0            # MI355X_MICROARCH.md: dense bf16/f16 M
 PEAK_HBM_GBPS = 8000.0
 
 
-def cpu_baseline(model_path, sample_count, sample_rate):
+def cpu_baseline(model_path, sample_count, sample_rate, hip_logits=None):
     """The oracle (a port, not the reference: the reference's ORT path cannot run here) timed
-    on this box's host cores over a bounded sample of the same synthetic workload."""
+    on this box's host cores over a bounded sample of the same synthetic workload.  As the checker it
+    also gives BASELINE's second figure, max |dlogit| of the timed HIP path on the first segments."""
     import numpy as np
     from birda_amd import synth
     from oracle import oracle as O
@@ -43,7 +44,16 @@ def cpu_baseline(model_path, sample_count, sample_rate):
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     om = O.OracleModel(model_path)
     base = synth.synth_segments(min(cores, 16), sample_count, sample_rate)
-    om.forward(base[: min(cores, base.shape[0])])  # touch code / pages once
+    ref = om.forward(base[: min(cores, base.shape[0])])  # touch code / pages once; reference logits of segments 0..
+    parity = None
+    if hip_logits:
+        parity = {}
+        for name, got in hip_logits.items():
+            k = min(len(ref), len(got))
+            scale = float(max(1.0, np.abs(ref[:k]).max()))
+            d = float(np.abs(got[:k] - ref[:k]).max())
+            parity[name] = {"max_abs_dlogit": round(d, 6), "max_abs_logit": round(scale, 3), "relative": float(f"{d / scale:.3e}"),
+                            "segments": k, "top1_agree": bool((got[:k].argmax(1) == ref[:k].argmax(1)).all())}
     n = int(min(1024, max(64, 4 * cores)))         # ~10-30 s of CPU work on 8 ... 256 cores
     segs = np.tile(base, (n // base.shape[0] + 1, 1))[:n]
     t = time.perf_counter()
@@ -51,7 +61,8 @@ def cpu_baseline(model_path, sample_count, sample_rate):
     dt = time.perf_counter() - t
     return {"value": round(n / dt, 2), "unit": "segments/s", "cores": cores, "kind": "port",
             "sample": f"{n} synthetic 3 s/48 kHz segments, oracle/birda_oracle.c, OpenMP across segments "
-                      f"({cores} threads), fp32, {dt:.1f} s"}
+                      f"({cores} threads), fp32, {dt:.1f} s",
+            "max_abs_dlogit_vs_oracle": parity}
 
 
 def layers_have_fused_stem(m, layer_tot):
@@ -244,6 +255,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    hip_logits = {args.precision: logits[:16].cpu().numpy()} if rank == 0 else None   # segments 0..15 of the global list
     value = n_total * args.steps / elapsed
     segs_done = n_local * args.steps
     slices_per_step = max(1, -(-n_local // args.micro_batch))
@@ -293,8 +305,9 @@ def main():
                "gemm": "v_mfma_f32_16x16x4_f32 in every kernel"}
         f32.update(analyse(clf, m, info, clf.fused_blocks(), st2, ly2, n_local * k2, k2, slices_per_step, "f32"))
         out["f32_mfma_path"] = f32
+        hip_logits["f32"] = logits[:16].cpu().numpy()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(model_path, m.sample_count, m.sample_rate)
+        out["cpu_baseline"] = cpu_baseline(model_path, m.sample_count, m.sample_rate, hip_logits)
     elif rank == 0:
         out["cpu_baseline"] = None
     ctx.close()
