@@ -471,9 +471,12 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                     }
             } else if constexpr (PREC != 0) {
                 const f16x8 *wf = reinterpret_cast<const f16x8 *>(WpS);
+                // the weight fragments of a step are taken JB column tiles at a time: all NT_W (up to 10 hi +
+                // 10 lo quads) at once cost 80 registers and spilled the 320-channel blocks
+                constexpr int JB = NT_W <= 6 ? NT_W : (NT_W + 1) / 2;
 #pragma unroll
                 for (int g = 0; g < PSTEPS; g++) {
-                    f16x8 a_h[MT_W], a_l[MT_W], b_h[NT_W], b_l[NT_W];
+                    f16x8 a_h[MT_W], a_l[MT_W];
 #pragma unroll
                     for (int i = 0; i < MT_W; i++) {
                         const int row = (wm * MT_W + i) * 16 + li;
@@ -481,21 +484,28 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                         if (PREC == 3) a_l[i] = *reinterpret_cast<const f16x8 *>(&DsL[row * DSH + 32 * g + 8 * kq]);
                     }
 #pragma unroll
-                    for (int j = 0; j < NT_W; j++) {
-                        b_h[j] = wf[((g * NTOP + wn * NT_W + j) * 2 + 0) * 64 + lane];
-                        if (PREC == 3) b_l[j] = wf[((g * NTOP + wn * NT_W + j) * 2 + 1) * 64 + lane];
-                    }
+                    for (int j0 = 0; j0 < NT_W; j0 += JB) {
+                        f16x8 b_h[JB], b_l[JB];
 #pragma unroll
-                    for (int i = 0; i < MT_W; i++)
-#pragma unroll
-                        for (int j = 0; j < NT_W; j++) {
-                            acco[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[i], b_h[j], acco[i][j], 0, 0, 0);
-                            if (PREC == 3) {
-                                acco[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[i], b_l[j], acco[i][j], 0, 0, 0);
-                                acco[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l[i], b_h[j], acco[i][j], 0, 0, 0);
-                            }
+                        for (int jj = 0; jj < JB; jj++) {
+                            if (j0 + jj >= NT_W) continue;
+                            b_h[jj] = wf[((g * NTOP + wn * NT_W + j0 + jj) * 2 + 0) * 64 + lane];
+                            if (PREC == 3) b_l[jj] = wf[((g * NTOP + wn * NT_W + j0 + jj) * 2 + 1) * 64 + lane];
                         }
-                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int i = 0; i < MT_W; i++)
+#pragma unroll
+                            for (int jj = 0; jj < JB; jj++) {
+                                if (j0 + jj >= NT_W) continue;
+                                const int j = j0 + jj < NT_W ? j0 + jj : 0;
+                                acco[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[i], b_h[jj], acco[i][j], 0, 0, 0);
+                                if (PREC == 3) {
+                                    acco[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[i], b_l[jj], acco[i][j], 0, 0, 0);
+                                    acco[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l[i], b_h[jj], acco[i][j], 0, 0, 0);
+                                }
+                            }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             } else {
             const float *dsb = Ds + ((wm * MT_W) * 16 + li) * CES + 4 * kq;
@@ -661,6 +671,14 @@ const MbCfg kCfgs[] = {
     MB_ENTRY_P(5, 1, 16, 6, 2, 1, 2, 2, 3, 6, 4, 2, 3, 2, 2, 0, 3),    // 67: as 40 (192 -> 1152 -> 192, 3x16 x 2)
     MB_ENTRY_P(3, 1, 16, 6, 2, 1, 2, 2, 3, 10, 4, 2, 3, 2, 2, 0, 3),   // 68: as 42 (192 -> 1152 -> 320)
     MB_ENTRY_P(3, 2, 16, 1, 9, 1, 4, 1, 2, 2, 4, 1, 8, 1, 2, 0, 3),    // 69: as 48, tile 8x16 (17x33 source rows: 10 % halo; the one entry whose last expand group is a single row tile)
+    // whole-image tiles for the Perch-shaped stack (128 mel x 497 frames -> 8x32 and 4x16 images in the late stages)
+    //         KS ST CE KG RT NCS WM WN MT NT TWL XBL TH S OCC STEM PREC
+    MB_ENTRY_P(3, 1, 16, 3, 4, 1, 4, 1, 4, 5, 5, 2, 8, 1, 1, 0, 3),    // 70: 80 -> 480 -> 80, 8x32
+    //         KS ST KG RT NCS WM WN MT NT TWL XBL TH S OCC STEM
+    MB_ENTRY_H(5, 1, 3, 4, 1, 4, 1, 4, 7, 5, 3, 8, 1, 1, 0),           // 71/72: 80 -> 480 -> 112, 8x32
+    MB_ENTRY_H(5, 1, 4, 4, 1, 4, 1, 4, 7, 5, 3, 8, 1, 1, 0),           // 73/74: 112 -> 672 -> 112, 8x32
+    MB_ENTRY_H(5, 1, 6, 2, 2, 2, 2, 2, 6, 4, 2, 4, 1, 1, 0),           // 75/76: 192 -> 1152 -> 192, 4x16 (one segment: no spills)
+    MB_ENTRY_H(3, 1, 6, 2, 2, 2, 2, 2, 10, 4, 2, 4, 1, 1, 0),          // 77/78: 192 -> 1152 -> 320, 4x16
 };
 constexpr int kNCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 

@@ -400,7 +400,7 @@ def test_fused_block_outputs_match_oracle_tensor_by_tensor(model_dir, oracle_lib
 
 def test_every_fused_tile_configuration(model_dir, oracle_lib, monkeypatch):
     """Force each tile configuration in turn (f32 MFMA: 0-21; split-f16 x3: even 22-46 and 48-54; plain
-    f16: odd 23-47; 48-69: split-f16 x3 variants, 63 / 64 f32); blocks it cannot run fall back to the layer kernels."""
+    f16: odd 23-47; 48-78: split-f16 x3 variants, except 63 / 64 f32 and 72 / 74 / 76 / 78 plain f16); blocks it cannot run fall back to the layer kernels."""
     from birda_amd import synth
     from birda_amd.classifier import BirdClassifier
     path, _, m, _ = model_dir["mini_b0"]
@@ -408,8 +408,9 @@ def test_every_fused_tile_configuration(model_dir, oracle_lib, monkeypatch):
     ref = oracle_lib.OracleModel(path).forward(segs)
     scale = max(1.0, float(np.abs(ref).max()))
     used = set()
-    for cfg in range(70):
-        prec = "f32" if cfg < 22 or cfg in (63, 64) else ("f16x3" if (cfg % 2 == 0 or cfg >= 48) else "f16")
+    for cfg in range(79):
+        prec = ("f32" if cfg < 22 or cfg in (63, 64) else "f16" if (23 <= cfg <= 47 and cfg % 2) or cfg in (72, 74, 76, 78)
+                else "f16x3")
         monkeypatch.setenv("BIRDA_HIP_MB_CFG", str(cfg))
         clf = BirdClassifier(path, precision=prec)
         blocks = clf.fused_blocks()
@@ -491,7 +492,7 @@ def test_perch_shaped_model_matches_oracle(oracle_lib, tmp_path, monkeypatch):
     clf = BirdClassifier(path, None, top_k=5, min_confidence=0.0)
     assert clf.sample_rate() == 32000 and clf.sample_count() == 160000 and abs(clf.segment_duration() - 5.0) < 1e-6
     print("perch-shaped fused blocks:", clf.fused_blocks())
-    assert len(clf.fused_blocks()) >= 8       # blocks whose tiles do not fit a configuration run layer by layer
+    assert len(clf.fused_blocks()) >= 8       # f32: blocks whose tiles do not fit a configuration run layer by layer
     assert 21 in clf.fused_blocks()           # the 1-channel stem variant
     ctx = clf.create_batch_context(4)
     logits = clf.predict_logits(ctx, segs)
@@ -501,6 +502,7 @@ def test_perch_shaped_model_matches_oracle(oracle_lib, tmp_path, monkeypatch):
     for prec, cfg, tol in (("f16x3", 66, LOGIT_RTOL), ("f16", 47, F16_LOGIT_RTOL)):
         c2 = BirdClassifier(path, None, precision=prec)
         assert cfg in c2.fused_blocks(), (prec, c2.fused_blocks())   # the 1-channel stem, f16 variants
+        assert len(c2.fused_blocks()) == 16, c2.fused_blocks()       # whole-image configurations 70-78 cover the 8x32 / 4x16 stages
         x2 = c2.create_batch_context(4)
         got = c2.predict_logits(x2, segs)
         assert np.isfinite(got).all() and np.abs(got - ref).max() <= tol * max(1.0, float(np.abs(ref).max())), prec
