@@ -317,9 +317,10 @@ def test_full_size_batch_properties(full_model, precision):
         assert (rows == rows[0]).all()
     ctx2 = clf.create_batch_context(96)                  # different micro-batch slicing, same answers
     logits2 = torch.empty_like(logits)
-    clf.forward_device(ctx2, x.data_ptr(), 1000, logits2.data_ptr())
-    ctx2.synchronize()
-    assert torch.equal(logits, logits2)
+    for _ in range(6):                                   # (a rare hazard shows up in one pass of a few: repeat)
+        clf.forward_device(ctx2, x.data_ptr(), 1000, logits2.data_ptr())
+        ctx2.synchronize()
+        assert torch.equal(logits, logits2)
     ii = idx.cpu().numpy(); cc = conf.cpu().numpy()
     assert ((ii >= -1) & (ii < m.n_classes)).all()
     valid = ii >= 0

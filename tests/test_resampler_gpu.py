@@ -194,3 +194,35 @@ def test_pcm16_stream_is_segmented_scaled_and_mixed_on_the_device(oracle_lib, mo
             top = np.sort(conf)[::-1]
             assert abs(r.predictions[0].confidence - top[0]) <= 2e-4
     ctx.close(); clf.close()
+
+
+def test_pcm16_pipeline_with_sub_slices_matches_the_f32_entry_point(model_dir):
+    """A stream long enough for the pipelined upload (8-MiB pieces, four sub-slices, overlap between
+    slices): bh_predict_pcm16 must report what bh_predict_batch reports for the same segments cut and
+    scaled on the host."""
+    from birda_amd.classifier import BirdClassifier
+    path, labels, m, _ = model_dir["mini"]
+    clf = BirdClassifier(path, labels, top_k=5, min_confidence=0.0)
+    S = m.sample_count
+    ovl = S // 4
+    nseg = 1100                                     # two slices of a 600-segment context, second one ragged
+    n = (S - ovl) * (nseg - 1) + S - 37             # last segment short: zero-padded tail
+    rng = np.random.default_rng(5)
+    t = np.arange(n) / m.sample_rate
+    x = 0.2 * rng.standard_normal((n, 2)) + 0.4 * np.sin(2 * np.pi * (900 + 0.05 * np.arange(n) % 2000) * t)[:, None]
+    pcm = np.clip(np.round(x * 32767.0), -32768, 32767).astype(np.int16)
+    ctx = clf.create_batch_context(600)
+    res, starts = clf.predict_pcm16(ctx, pcm, m.sample_rate, ovl)
+    assert starts == clf.segment_starts(n, S, ovl) and len(res) == len(starts) >= nseg   # (the segmenter itself: test_abi_and_host)
+    nseg = len(starts)
+    mono = ((pcm[:, 0].astype(np.float32) / np.float32(32768.0)) + (pcm[:, 1].astype(np.float32) / np.float32(32768.0))) / np.float32(2.0)
+    segs = np.zeros((nseg, S), np.float32)
+    for i, s in enumerate(starts):
+        piece = mono[s: s + S]
+        segs[i, : len(piece)] = piece
+    want = clf.predict_batch_with_context(ctx, [segs[i] for i in range(600)]) + \
+        clf.predict_batch_with_context(ctx, [segs[i] for i in range(600, nseg)])
+    for i, (a, b) in enumerate(zip(res, want)):
+        assert [p.index for p in a.predictions] == [p.index for p in b.predictions], i
+        assert np.allclose([p.confidence for p in a.predictions], [p.confidence for p in b.predictions], atol=2e-6), i
+    ctx.close(); clf.close()

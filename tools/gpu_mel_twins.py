@@ -17,7 +17,8 @@ x = torch.from_numpy(uniq[order]).cuda()
 logits = torch.empty((n, m.n_classes), device="cuda")
 ctx = clf.create_batch_context(n)
 nb = len(m.branches)
-for rep in range(2):
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+for rep in range(reps):
     clf.forward_device(ctx, x.data_ptr(), n, logits.data_ptr()); ctx.synchronize()
     sp = clf.read_tensor(ctx, 0, n).reshape(n, nb, m.spec_h, m.spec_w)
     for k in range(8):
