@@ -707,13 +707,8 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) {
         else if (!strcmp(pe, "f16")) c->precision = 1;
         else return fail(BH_ERR_INVALID, "BIRDA_HIP_PRECISION must be f32, f16x3 or f16");
     }
-    // The front-end runs on the f32 MFMA in EVERY mode.  A split-f16 variant of mel_kernel exists (0.94 us per
-    // segment instead of 1.58) and meets the parity tolerance, but it is not deterministic: about one 16-frame
-    // spectrogram tile in ~10^6 comes out wrong, different ones on every run, only when two workgroups share
-    // a CU, at a rate that changes with unrelated code-placement changes ("hazards"); until that is
-    // understood it is opt-in for experiments only (BIRDA_HIP_MEL_F16X3=1).
-    const char *mel16 = getenv("BIRDA_HIP_MEL_F16X3");
-    int fe_prec = (c->precision == 3 && mel16 && mel16[0] == '1') ? 3 : 0;
+    // f16x3: the front-end GEMM on the split-f16 MFMA too (BIRDA_HIP_MEL_F32=1 keeps it on the f32 MFMA: A/B aid)
+    int fe_prec = (c->precision == 3 && !(getenv("BIRDA_HIP_MEL_F32") && getenv("BIRDA_HIP_MEL_F32")[0] == '1')) ? 3 : 0;
     for (uint32_t b = 0; b < m.h.n_branches; b++)
         if (m.branches[b].frame_length % 256) fe_prec = 0;   // 32-deep steps split over 4 waves
     c->fe.prec = fe_prec;

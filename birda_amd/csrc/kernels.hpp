@@ -94,6 +94,19 @@ __device__ __forceinline__ bh_f32x2 gelu_erf_fast2(bh_f32x2 v) {
     return __builtin_elementwise_fma(-a, e, m);
 }
 
+// a + b as a plain v_add_f32 that hipcc cannot fuse with its neighbour.  Written as `fwd[j] + rev[-j]`
+// in C, the folded-frame sums of the split-f16 mel kernel were SLP-vectorised into
+// `v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` (the second operand's halves swapped), and that kernel
+// then produced a wrong 16-frame tile once in 10^5 ... 10^6 when two workgroups shared a CU -- in 5 of
+// 6 placements of the identical code in the code object, never with one workgroup per CU.  With the adds
+// kept scalar: 0 wrong tiles in 2.6e7 (6 placements, tools/gpu_slice_invariance.py).  No other kernel
+// of this library contains that instruction form.
+__device__ __forceinline__ float bh_add_unpacked(float a, float b) {
+    float r;
+    asm("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // a = hi + lo with hi, lo in f16 (22 significant bits between them), for a pair: products
 // hi*hi + hi*lo + lo*hi on the f16 MFMA with f32 accumulation reproduce an f32 fmaf chain to ~1e-7 of
 // sum|a b| (tools/microbench/mfma_f16_overlap.hip).  Valid while |a| < 65504 (f16 range).

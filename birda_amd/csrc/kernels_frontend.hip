@@ -227,7 +227,8 @@ __global__ __launch_bounds__(256, 2) void mel_kernel(const float *__restrict__ x
             {
                 float y[8];
 #pragma unroll
-                for (int jj = 0; jj < 8; jj++) y[jj] = xf[f * 16 * H + j0 + jj + 1] + xf[f * 16 * H + L - 1 - j0 - jj];
+                for (int jj = 0; jj < 8; jj++)   // (one v_add_f32 each, on purpose: see bh_add_unpacked)
+                    y[jj] = bh_add_unpacked(xf[f * 16 * H + j0 + jj + 1], xf[f * 16 * H + L - 1 - j0 - jj]);
                 bh_split8(y, bh[f], bl[f]);
             }
             // Keep the VALU split out of the MFMA sequence.  Left to interleave them (v_cvt_pk_f16_f32 /
