@@ -248,3 +248,32 @@ def test_segment_starts_match_reference_traces_and_the_oracle_segmenter(L, cases
         want = [s for _, s in oracle_lib.segment_stream(np.zeros(n, np.float32), seg, ovl, packet=int(rng.integers(1, 50)))]
         assert starts(n, seg, ovl) == want, (n, seg, ovl)
     assert starts(100, 10, 10) == [] and starts(100, 10, 12) == []     # overlap >= segment: Error::Internal upstream
+
+
+def test_device_code_has_no_half_swapped_packed_f32_ops(tmp_path):
+    """Regression guard for a measured hazard: hipcc's SLP-vectorised
+    `v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` (operand halves swapped) made the split-f16 mel kernel
+    nondeterministic on gfx950.  No packed-f32 instruction of the library may select operand halves
+    with `op_sel:` (the `op_sel_hi:` broadcast forms are fine); sums that the compiler would pack that
+    way are written with `bh_add_unpacked`."""
+    import re
+    import shutil
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "birda_amd", "csrc")
+
+    def asm(name):
+        out = str(tmp_path / (name + ".s"))
+        subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-inline-asm", "--cuda-device-only", "-S",
+                        os.path.join(src, name + ".hip"), "-o", out], check=True, capture_output=True, timeout=900)
+        return open(out).read()
+
+    names = ["kernels_frontend", "kernels_conv", "kernels_mbconv", "resample"]
+    with ThreadPoolExecutor(4) as ex:
+        texts = dict(zip(names, ex.map(asm, names)))
+    for name, text in texts.items():
+        bad = [l.strip() for l in text.splitlines() if re.search(r"v_pk_(add|mul|fma)_f32\b.*\bop_sel:\[", l)]
+        assert not bad, (name, bad[:3])
