@@ -193,9 +193,17 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # (dry-run aid for a 1-GPU box: BIRDA_BENCH_DRYRUN_ONE_DEVICE=1 puts every rank on cuda:0 and uses gloo,
+    #  which exercises the launch / sharding / timing / reporting flow; the driver's runs use RCCL)
+    dryrun = world > 1 and os.environ.get("BIRDA_BENCH_DRYRUN_ONE_DEVICE") == "1"
+    if dryrun:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dryrun:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # seeded synthetic BirdNET-v2.4-shaped model (no real weights exist offline)
     tmp = tempfile.mkdtemp(prefix=f"birda_bench_r{rank}_")
@@ -223,7 +231,7 @@ def main():
         if world > 1:
             ctx.synchronize()
             packed = torch.cat([tk_idx.to(torch.float32), tk_conf], 1)
-            sharding.gather_results(packed, n_total, rank, world)
+            sharding.gather_results(packed.cpu() if dryrun else packed, n_total, rank, world)
 
     def sync_all():
         ctx.synchronize()
@@ -252,7 +260,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ctx.set_profiling(False)
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if dryrun else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
