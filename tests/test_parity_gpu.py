@@ -514,3 +514,23 @@ def test_perch_shaped_model_matches_oracle(oracle_lib, tmp_path, monkeypatch):
         assert len(r.predictions) == 5
         assert np.allclose([p.confidence for p in r.predictions], conf, rtol=2e-3, atol=1e-7)
     ctx.close(); clf.close()
+
+
+def test_model_converted_from_onnx_runs_identically(model_dir, tmp_path):
+    """model -> ONNX bytes -> birda_amd.convert -> BHM1: the library must plan the same fused blocks and return
+    bit-identical logits for the converted file (same weights, layer table rebuilt from the ONNX graph)."""
+    from birda_amd import convert, modelfile as mf, onnx_io as ox, synth
+    from birda_amd.classifier import BirdClassifier
+    path, labels, m, _ = model_dir["mini_b0"]
+    m2 = convert.model_from_graph(ox.load(ox.dump(convert.graph_from_model(m))), m)
+    p2 = str(tmp_path / "converted.bhm")
+    mf.write_model(p2, m2)
+    segs = synth.synth_segments(5, m.sample_count, m.sample_rate, start=70)
+    out = []
+    for p in (path, p2):
+        clf = BirdClassifier(p, labels, precision="f16x3")
+        ctx = clf.create_batch_context(8)
+        out.append((clf.fused_blocks(), clf.predict_logits(ctx, segs)))
+        ctx.close(); clf.close()
+    assert out[0][0] == out[1][0] and len(out[0][0]) == 16
+    assert np.array_equal(out[0][1], out[1][1])
