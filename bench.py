@@ -157,7 +157,7 @@ def analyse(clf, m, info, fused, stage_tot, layer_tot, segs_done, steps, slices_
     mel_ms, mel_launches = stage_tot["mel"]
     mel_gbps = MEL_BYTES_PER_SEGMENT * segs_done / (mel_ms * 1e-3) / 1e9
     out["roofline_mel"] = {"kernel": "mel_kernel (folded STFT x mel, %s)" % (
-                               "split f16 x3 MFMA" if (precision == "f16x3" and os.environ.get("BIRDA_HIP_MEL_F32") != "1")
+                               "split f16 x3 MFMA" if (precision != "f32" and os.environ.get("BIRDA_HIP_MEL_F32") != "1")
                                else "v_mfma_f32_16x16x4_f32"), "bound": "hbm",
                            "achieved": round(mel_gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
                            "frac": round(mel_gbps / PEAK_HBM_GBPS, 4), "traffic": pmc_traffic("bh::mel_kernel"),

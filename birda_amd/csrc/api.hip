@@ -699,7 +699,7 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) {
     if (m.h.n_branches > bh::MAX_BRANCHES) return fail(BH_ERR_UNSUPPORTED, "too many front-end branches");
     // front-end operators
     // GEMM operand precision (decided here: the front-end operator layout depends on it)
-    // the spectrogram front-end keeps f32-grade products in every mode: f32 MFMA, or split f16 in f16x3
+    // the spectrogram front-end keeps f32-grade products in every mode: f32 MFMA, or split f16 in the f16 modes
     c->precision = (cfg->flags & BH_FLAG_PRECISION_MASK) == BH_FLAG_F16X3 ? 3 : (cfg->flags & BH_FLAG_PRECISION_MASK) == BH_FLAG_F16 ? 1 : 0;
     if (const char *pe = getenv("BIRDA_HIP_PRECISION")) {
         if (!strcmp(pe, "f32")) c->precision = 0;
@@ -707,8 +707,9 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) {
         else if (!strcmp(pe, "f16")) c->precision = 1;
         else return fail(BH_ERR_INVALID, "BIRDA_HIP_PRECISION must be f32, f16x3 or f16");
     }
-    // f16x3: the front-end GEMM on the split-f16 MFMA too (BIRDA_HIP_MEL_F32=1 keeps it on the f32 MFMA: A/B aid)
-    int fe_prec = (c->precision == 3 && !(getenv("BIRDA_HIP_MEL_F32") && getenv("BIRDA_HIP_MEL_F32")[0] == '1')) ? 3 : 0;
+    // f16x3 and f16: the front-end GEMM on the split-f16 MFMA (f32-grade products, faster than the f32 MFMA;
+    // BIRDA_HIP_MEL_F32=1 keeps it on the f32 MFMA: A/B aid)
+    int fe_prec = (c->precision != 0 && !(getenv("BIRDA_HIP_MEL_F32") && getenv("BIRDA_HIP_MEL_F32")[0] == '1')) ? 3 : 0;
     for (uint32_t b = 0; b < m.h.n_branches; b++)
         if (m.branches[b].frame_length % 256) fe_prec = 0;   // 32-deep steps split over 4 waves
     c->fe.prec = fe_prec;
