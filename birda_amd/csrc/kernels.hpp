@@ -95,12 +95,11 @@ __device__ __forceinline__ bh_f32x2 gelu_erf_fast2(bh_f32x2 v) {
 }
 
 // a + b as a plain v_add_f32 that hipcc cannot fuse with its neighbour.  Written as `fwd[j] + rev[-j]`
-// in C, the folded-frame sums of the split-f16 mel kernel were SLP-vectorised into
-// `v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` (the second operand's halves swapped), and that kernel
-// then produced a wrong 16-frame tile once in 10^5 ... 10^6 when two workgroups shared a CU -- in 5 of
-// 6 placements of the identical code in the code object, never with one workgroup per CU.  With the adds
-// kept scalar: 0 wrong tiles in 2.6e7 (6 placements, tools/gpu_slice_invariance.py).  No other kernel
-// of this library contains that instruction form.
+// in C, the folded-frame sums of the split-f16 mel kernel are SLP-vectorised into
+// `v_pk_add_f32 ... op_sel:[0,1] op_sel_hi:[1,0]` (the second operand's halves swapped), and on gfx950 that
+// form returns wrong sums while the same wave has v_mfma_f32_16x16x32_f16 in flight
+// (tools/microbench/pk_add_opsel.hip: 7 % of the lanes, different ones every run; never without the MFMAs,
+// never for two v_add_f32).  In the mel kernel that was one wrong 16-frame tile in 10^5 ... 10^6.
 __device__ __forceinline__ float bh_add_unpacked(float a, float b) {
     float r;
     asm("v_add_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
