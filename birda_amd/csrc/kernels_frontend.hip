@@ -231,10 +231,9 @@ __global__ __launch_bounds__(256, 2) void mel_kernel(const float *__restrict__ x
                     y[jj] = bh_add_unpacked(xf[f * 16 * H + j0 + jj + 1], xf[f * 16 * H + L - 1 - j0 - jj]);
                 bh_split8(y, bh[f], bl[f]);
             }
-            // Keep the VALU split out of the MFMA sequence.  Left to interleave them (v_cvt_pk_f16_f32 /
-            // v_fma_mix_f32 between back-to-back MFMAs), hipcc produced a kernel whose B operands were
-            // sporadically corrupt when two workgroups shared a CU: whole 16-frame tiles wrong in ~1 % of
-            // the tiles, different ones on every run (tools/gpu_determinism.py, tools/gpu_mel_twins.py).
+            // The split stays out of the MFMA sequence.  (Not needed for correctness any more: the wrong tiles this
+            // fence first reduced came from hipcc's v_pk_add_f32 op_sel form of the sums above -- bh_add_unpacked,
+            // DESIGN.md section 3; without the fence the kernel is as fast and as deterministic, 200 soak runs.)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < MT; m++)
