@@ -14,6 +14,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 //      3: after s_nop 3      4: mode 1 without MFMA traffic                        5: v_pk_add_f32 on a register copy (v_mov first)
 //      6: v_pk_add_f32 WITHOUT op_sel on pre-swapped operands (same sums)          7: mode 1, MFMAs only in the OTHER waves (odd waves)
 //      8: mode 1 with f32 MFMAs (16x16x4) as the traffic                            9: v_pk_fma_f32 y = u * 1 + w, op_sel as mode 1
+//     10: the broadcast forms the GELU uses (op_sel_hi only): v_pk_mul_f32 op_sel_hi:[1,0], v_pk_fma_f32 op_sel_hi:[1,0,1] neg;
+//         its reference is mode 11 = the same instructions with no MFMA in flight
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void k(float *out, int iters) {
     extern __shared__ float xs[];   // ~60 KB so that two workgroups share a CU, like the mel kernel
@@ -60,12 +62,18 @@ __global__ __launch_bounds__(256, 2) void k(float *out, int iters) {
                 asm volatile("v_mov_b32_e32 %0, %1" : "=v"(w2[1]) : "v"(w[1]));
                 asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(y) : "v"(u2), "v"(w2));
             }
+            if (MODE == 10 || MODE == 11) {   // the GELU's forms: t = u * c (c broadcast from the low half), y = t * 2 - w
+                const f32x2 c = {0.75f, 123.0f};
+                f32x2 t;
+                asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(u), "v"(c));
+                asm volatile("v_pk_fma_f32 %0, %1, 2.0, %2 op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(y) : "v"(t), "v"(w));
+            }
             sum += y[0] * 0.5f + y[1] * 0.25f;
         }
         if (MODE == 8) {
 #pragma unroll
             for (int q = 0; q < 6; q++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, 0.001f * lane, acc, 0, 0, 0);
-        } else if (MODE != 4 && (MODE != 7 || ((tid >> 6) & 1))) {   // MFMA traffic (as the mel kernel's main loop has between the sums)
+        } else if (MODE != 4 && MODE != 11 && (MODE != 7 || ((tid >> 6) & 1))) {   // MFMA traffic (as the mel kernel's main loop has between the sums)
 #pragma unroll
             for (int q = 0; q < 6; q++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
         }
@@ -111,5 +119,7 @@ int main() {
     report<8>("  ... with f32 MFMAs (16x16x4) as the traffic", ref, blocks, iters);
     report<6>("v_pk_add_f32 without op_sel (operands pre-swapped)", ref, blocks, iters);
     report<9>("v_pk_fma_f32 u * 1 + w, op_sel:[0,0,1] op_sel_hi:[1,1,0]", ref, blocks, iters);
+    const std::vector<float> ref2 = run<11>(blocks, iters);   // the same packed instructions with no MFMA in flight
+    report<10>("GELU's forms (v_pk_mul op_sel_hi:[1,0]; v_pk_fma op_sel_hi:[1,0,1] neg) vs no-MFMA run", ref2, blocks, iters);
     return 0;
 }
