@@ -712,6 +712,7 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) {
     int fe_prec = (c->precision != 0 && !(getenv("BIRDA_HIP_MEL_F32") && getenv("BIRDA_HIP_MEL_F32")[0] == '1')) ? 3 : 0;
     for (uint32_t b = 0; b < m.h.n_branches; b++)
         if (m.branches[b].frame_length % 256) fe_prec = 0;   // 32-deep steps split over 4 waves
+    if (m.h.sample_count % 4) return fail(BH_ERR_UNSUPPORTED, "front-end: sample_count %u must be a multiple of 4 (16-byte span loads)", m.h.sample_count);
     c->fe.prec = fe_prec;
     c->fe.n_branches = (int)m.h.n_branches;
     c->fe.sample_count = (int)m.h.sample_count;
