@@ -122,7 +122,8 @@ void launch_segment_pcm16(const int16_t *d_pcm, size_t n_frames, int channels, c
 constexpr int MEL_FT = 3;           // 16-frame tiles per block: 3 keeps the span at 60 KB -> two blocks per CU
 constexpr int MEL_TN = 16 * MEL_FT;
 
-constexpr int MEL_SU = 16;          // prefetched 16-B loads per thread: 64 KB of span, enough for every built front-end
+// prefetched 16-B loads per thread: 15 cover the 60-KB spans of the 96-mel (v2.4) front-ends in 60 registers, 16 the
+// 64-KB span of the 128-mel one, whose workgroups have the whole register file
 
 // (128-mel front-ends need 98 KB of LDS for the reduction: one workgroup per CU, so they get the whole register file)
 template <int MT, int PREC>
@@ -144,6 +145,7 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void mel_kernel(const float *
     // it started (two per CU) exposed one HBM round trip per tile, 0.37 of this kernel's 0.95 us per segment.
     // item = (seg * n_branches + branch) * n_tiles + tile
     static_assert(MM_SPLIT == 8, "16 floats of min / max partials per segment");
+    constexpr int MEL_SU = MT <= 6 ? 15 : 16;
     float4 q[MEL_SU], mmq[4];
     auto issue = [&](int it) {
         const int tl = it % n_tiles, sb = it / n_tiles, sg = sb / n_branches, br = sb - sg * n_branches;
