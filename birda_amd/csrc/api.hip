@@ -147,6 +147,22 @@ std::vector<float> build_gf(const bh::BranchRec &b, const float *W, int nm_pad, 
     // MFMA-fragment-major relayout (kernels.hpp BranchParams::gf)
     const int mt_n = nm_pad / 16;
     std::vector<float> frag((size_t)K * nm_pad);
+    if (prec == 32) {  // mel32_kernel: [step of 16 k][mel tile of 32][plane hi, lo][64 lanes][8 halves]; within a chunk of 64 k the
+        // staged Y rows pair k with k + 32 in one dword, so element jj of step s holds k = 64 (s / 4) + 8 (s % 4) + 4 (lane >> 5) + jj / 2 + 32 (jj % 2)
+        uint16_t *h = reinterpret_cast<uint16_t *>(frag.data());
+        const int mt32 = nm_pad / 32;
+        for (int st = 0; st < K / 16; st++)
+            for (int mt = 0; mt < mt32; mt++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int jj = 0; jj < 8; jj++) {
+                        const float v = gf[(size_t)(64 * (st >> 2) + 8 * (st & 3) + 4 * (lane >> 5) + (jj >> 1) + 32 * (jj & 1)) * nm_pad + 32 * mt + (lane & 31)];
+                        const uint16_t hi = f32_to_f16(v);
+                        const size_t base = (((size_t)st * mt32 + mt) * 2) * 64 * 8;
+                        h[base + (size_t)lane * 8 + jj] = hi;
+                        h[base + 64 * 8 + (size_t)lane * 8 + jj] = f32_to_f16(v - f16_to_f32(hi));
+                    }
+        return frag;
+    }
     if (prec != 0) {  // [step of 32 k][mel tile][plane hi, lo][64 lanes][8 halves]: k = 32 s + 8 (lane >> 4) + jj
         uint16_t *h = reinterpret_cast<uint16_t *>(frag.data());
         for (int st = 0; st < K / 32; st++)
@@ -712,6 +728,19 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) {
     int fe_prec = (c->precision != 0 && !(getenv("BIRDA_HIP_MEL_F32") && getenv("BIRDA_HIP_MEL_F32")[0] == '1')) ? 3 : 0;
     for (uint32_t b = 0; b < m.h.n_branches; b++)
         if (m.branches[b].frame_length % 256) fe_prec = 0;   // 32-deep steps split over 4 waves
+    if (fe_prec == 3) {
+        // mel32_kernel (Y rows staged along k: no LDS bank conflicts whatever the hop) where mel_kernel's frame-strided
+        // reads collapse onto a few banks: hops that are multiples of 16 samples (Perch: 320 -> every frame on one bank;
+        // 483 -> 258 us per 600 segments).  BirdNET's hops (278 / 280) stay on mel_kernel (790 vs 1006 us per 1000).
+        // BIRDA_HIP_MEL32=0/1 forces the choice (A/B aid).
+        bool want = false, can = true;
+        for (uint32_t b = 0; b < m.h.n_branches; b++) {
+            if (m.branches[b].frame_step % 16 == 0) want = true;
+            if (align_up(m.branches[b].n_mels, 16) % 32 || m.branches[b].frame_length % 512) can = false;   // 32-mel tiles, 64-k chunks per wave
+        }
+        if (const char *e = getenv("BIRDA_HIP_MEL32")) want = e[0] == '1';
+        if (want && can) fe_prec = 32;
+    }
     if (m.h.sample_count % 4) return fail(BH_ERR_UNSUPPORTED, "front-end: sample_count %u must be a multiple of 4 (16-byte span loads)", m.h.sample_count);
     c->fe.prec = fe_prec;
     c->fe.n_branches = (int)m.h.n_branches;

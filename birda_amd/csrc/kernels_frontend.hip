@@ -396,6 +396,199 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void mel_kernel(const float *
     }   // items
 }
 
+// ---------------------------------------------------------------------------------------
+// mel32 kernel (split-f16, FrontendParams::prec == 32): the same folded GEMM on v_mfma_f32_32x32x16_f16.
+// 32-frame tiles: 32 frames x 2 k-halves tile the 64 LDS banks exactly two deep (16 frames x 4 k-groups
+// at a stride of 278 / 280 samples hit them three deep, which bounded mel_kernel's main loop); the
+// 43-KB span lets three workgroups share a CU; a wave's store covers two 128-byte rows of the output.
+// K is split across the 4 waves as before; wave m owns MEL tile m (32 mels) in the epilogue.
+// Operator planes: [step of 16 k][mel tile of 32]{hi, lo}[64 lanes][8 halves], k = 16 s + 8 (lane >> 5) + jj,
+// mel = 32 mt + (lane & 31).
+// ---------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int MEL32_TN = 32;
+constexpr int MEL32_YP = 36;   // dwords per staged Y row (32 + 4: 16-byte row pieces of 16 frames tile the 64 banks)
+
+template <int MT32>
+__global__ __launch_bounds__(256, 2) void mel32_kernel(const float *__restrict__ x, const float *__restrict__ mm,
+                                                        float *__restrict__ spec, const FrontendParams *__restrict__ pp,
+                                                        const float *__restrict__ gf0, const float *__restrict__ gf1,
+                                                        const float *__restrict__ gf2, const float *__restrict__ gf3,
+                                                        const int dbg, const int ybuf_off, const int n_tiles, const int n_items) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n_branches = pp->n_branches;
+    const int S = pp->sample_count;
+    float *xs = smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fn = lane & 31, kh = lane >> 5;
+    constexpr int SU = 11;   // prefetched 16-B pieces per thread (44 KB of span)
+    float4 q[SU], mmq[4];
+    auto issue = [&](int it) {
+        const int tl = it % n_tiles, sb = it / n_tiles, sg = sb / n_branches, br = sb - sg * n_branches;
+        const int g0 = tl * MEL32_TN * pp->br[br].H;
+        const float *xg = x + (size_t)sg * S;
+#pragma unroll
+        for (int u = 0; u < SU; u++) q[u] = *reinterpret_cast<const float4 *>(xg + min(g0 + tid * 4 + u * 1024, S - 4));
+        const float4 *mv = reinterpret_cast<const float4 *>(mm + (size_t)sg * MM_SPLIT * 2);
+        mmq[0] = mv[0]; mmq[1] = mv[1]; mmq[2] = mv[2]; mmq[3] = mv[3];
+    };
+    int item = blockIdx.x;
+    if (item < n_items) issue(item);
+    while (item < n_items) {
+        const int tile = item % n_tiles, sbr = item / n_tiles, seg = sbr / n_branches, branch = sbr - seg * n_branches;
+        BranchParams bp = pp->br[branch];
+        const float *__restrict__ gfp = branch == 0 ? gf0 : branch == 1 ? gf1 : branch == 2 ? gf2 : gf3;
+        const int t0 = tile * MEL32_TN;
+        const int L = bp.L, H = bp.H, K = bp.K;
+        const int span_pad = ((MEL32_TN - 1) * H + L + 3) & ~3;
+        const float mn = fminf(fminf(fminf(mmq[0].x, mmq[0].z), fminf(mmq[1].x, mmq[1].z)), fminf(fminf(mmq[2].x, mmq[2].z), fminf(mmq[3].x, mmq[3].z)));
+        const float mx = fmaxf(fmaxf(fmaxf(mmq[0].y, mmq[0].w), fmaxf(mmq[1].y, mmq[1].w)), fmaxf(fmaxf(mmq[2].y, mmq[2].w), fmaxf(mmq[3].y, mmq[3].w)));
+        const float sc = 2.0f / ((mx - mn) + pp->norm_eps);
+        const float *xseg = x + (size_t)seg * S;
+        const int g0s = t0 * H;
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+            const int i = tid * 4 + u * 1024;
+            if (i < span_pad) {
+                float4 v = q[u];
+                v.x = (g0s + i + 0 < S) ? fmaf(v.x - mn, sc, -1.0f) : -1.0f;
+                v.y = (g0s + i + 1 < S) ? fmaf(v.y - mn, sc, -1.0f) : -1.0f;
+                v.z = (g0s + i + 2 < S) ? fmaf(v.z - mn, sc, -1.0f) : -1.0f;
+                v.w = (g0s + i + 3 < S) ? fmaf(v.w - mn, sc, -1.0f) : -1.0f;
+                *reinterpret_cast<float4 *>(xs + i) = v;
+            }
+        }
+        for (int i = SU * 1024 + tid * 4; i < span_pad; i += 1024) {   // spans beyond the prefetch capacity
+            float4 v;
+            v.x = (g0s + i + 0 < S) ? fmaf(xseg[g0s + i + 0] - mn, sc, -1.0f) : -1.0f;
+            v.y = (g0s + i + 1 < S) ? fmaf(xseg[g0s + i + 1] - mn, sc, -1.0f) : -1.0f;
+            v.z = (g0s + i + 2 < S) ? fmaf(xseg[g0s + i + 2] - mn, sc, -1.0f) : -1.0f;
+            v.w = (g0s + i + 3 < S) ? fmaf(xseg[g0s + i + 3] - mn, sc, -1.0f) : -1.0f;
+            *reinterpret_cast<float4 *>(xs + i) = v;
+        }
+        __syncthreads();
+
+        const int next = item + (int)gridDim.x;
+        issue(min(next, n_items - 1));   // the next span flies under the main loop; unconditional (see mel_kernel)
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc[MT32];
+#pragma unroll
+        for (int m = 0; m < MT32; m++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[m][r] = 0.0f;
+        // Per wave: K / 4 of the reduction, in chunks of 64 k.  Phase A stages the chunk's Y = x[t H + k + 1] + x[t H + L - 1 - k]
+        // as split-f16 rows ([plane][frame][32 dwords, dword d = {k0 + d, k0 + d + 32}], pitch 36) with the lanes along k, so both span
+        // reads and the row writes walk consecutive banks whatever the hop is (frames along the lanes put H mod 64 between
+        // neighbours: 8 banks for a hop of 280, one for 320); the two lane halves take frames pair_dist apart, chosen so that
+        // pair_dist * H = 32 (mod 64) when the hop allows it.  Phase B reads the operand fragments back as 16-byte row pieces
+        // (pitch 36: conflict-free) and runs the MFMAs.  Both phases are wave-private: LDS executes a wave's accesses in order.
+        const int nch = K / 256, kw = wave * (K / 4);
+        int dd = 16;
+#pragma unroll
+        for (int c = 1; c <= 16; c *= 2)
+            if (((c * H) & 63) == 32) dd = c;
+        uint32_t *yb = reinterpret_cast<uint32_t *>(smem) + ybuf_off + wave * (2 * 32 * MEL32_YP);
+        const int dl = lane & 31;
+        const f16x8 *gA = reinterpret_cast<const f16x8 *>(gfp) + lane;
+        f16x8 a0h[MT32], a0l[MT32], a1h[MT32], a1l[MT32];
+        auto load = [&](int st, f16x8 (&ah)[MT32], f16x8 (&al)[MT32]) {
+#pragma unroll
+            for (int m = 0; m < MT32; m++) {
+                ah[m] = gA[(((size_t)st * MT32 + m) * 2 + 0) * 64];
+                al[m] = gA[(((size_t)st * MT32 + m) * 2 + 1) * 64];
+            }
+        };
+        const f16x8 *yr = reinterpret_cast<const f16x8 *>(yb + fn * MEL32_YP + 4 * kh);   // row = frame, 4 dwords of this half
+        auto step = [&](int sl, const f16x8 (&ah)[MT32], const f16x8 (&al)[MT32]) {
+            const f16x8 bh = yr[2 * sl], bl = yr[2 * sl + (32 * MEL32_YP) / 4];
+#pragma unroll
+            for (int m = 0; m < MT32; m++) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh, acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT32; m++) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl, acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT32; m++) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh, acc[m], 0, 0, 0);
+        };
+        const int st0 = kw / 16;
+        if (!(dbg & 1)) {
+            load(st0, a0h, a0l);
+            for (int c = 0; c < nch; c++) {
+                const int kc = kw + 64 * c;
+                const float *pf = xs + (kh * dd) * H + kc + dl + 1;
+                const float *pb = xs + (kh * dd) * H + (L - 1 - kc - dl);
+                uint32_t *yw = yb + (kh * dd) * MEL32_YP + dl;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const int fs = ((i & ~(dd - 1)) << 1) | (i & (dd - 1));   // wave-uniform; the upper half adds dd
+                    const float y0 = bh_add_unpacked(pf[fs * H], pb[fs * H]);            // single v_add_f32s on purpose
+                    const float y1 = bh_add_unpacked(pf[fs * H + 32], pb[fs * H - 32]);
+                    bh_f16x2 hi, lo;
+                    bh_split2(y0, y1, hi, lo);
+                    yw[fs * MEL32_YP] = __builtin_bit_cast(uint32_t, hi);
+                    yw[fs * MEL32_YP + 32 * MEL32_YP] = __builtin_bit_cast(uint32_t, lo);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                const int sc0 = st0 + 4 * c;
+                const bool last = c + 1 == nch;
+                load(sc0 + 1, a1h, a1l);
+                step(0, a0h, a0l);
+                load(sc0 + 2, a0h, a0l);
+                step(1, a1h, a1l);
+                load(sc0 + 3, a1h, a1l);
+                step(2, a0h, a0l);
+                load(last ? sc0 + 3 : sc0 + 4, a0h, a0l);   // unconditional: the last chunk re-reads its own last step
+                step(3, a1h, a1l);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+
+        // cross-wave reduction: every wave parks its partial of every MEL tile ([wave][tile][4 x float4][64 lanes]); wave m
+        // sums tile m in wave order (no register selection by wave index: that would put the accumulators on the stack)
+        __syncthreads();
+        float4 *red = reinterpret_cast<float4 *>(smem);
+#pragma unroll
+        for (int m = 0; m < MT32; m++)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++)
+                red[((wave * MT32 + m) * 4 + r4) * 64 + lane] = make_float4(acc[m][4 * r4], acc[m][4 * r4 + 1], acc[m][4 * r4 + 2], acc[m][4 * r4 + 3]);
+        __syncthreads();
+        if (wave < MT32) {
+            f32x16 tot;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; r4++) {
+                float4 v = red[((0 * MT32 + wave) * 4 + r4) * 64 + lane];
+#pragma unroll
+                for (int sw = 1; sw < 4; sw++) {
+                    const float4 w = red[((sw * MT32 + wave) * 4 + r4) * 64 + lane];
+                    v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+                }
+                tot[4 * r4] = v.x; tot[4 * r4 + 1] = v.y; tot[4 * r4 + 2] = v.z; tot[4 * r4 + 3] = v.w;
+            }
+            // epilogue: square, power law, folded-BN affine, mel flip; lanes 0-31 / 32-63 each write a 128-byte row piece
+            const int t = t0 + fn;
+            if (t < bp.n_frames) {
+                float *out = spec + ((size_t)seg * n_branches + branch) * bp.n_mels * bp.n_frames;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int mel = 32 * wave + (r & 3) + 4 * kh + 8 * (r >> 2);
+                    if (mel < bp.n_mels) {
+                        const float v = tot[r];
+                        float o = __builtin_amdgcn_exp2f(bp.expo * __builtin_amdgcn_logf(v * v));
+                        o = o * bp.out_scale + bp.out_shift;
+                        const int row = bp.flip ? (bp.n_mels - 1 - mel) : mel;
+                        out[(size_t)row * bp.n_frames + t] = o;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        item = next;
+    }
+}
+
 void launch_mel(const float *x, const float *minmax, float *spec, const FrontendParams &p,
                 const FrontendParams *d_p, int n_seg, hipStream_t s) {
     int max_span = 0, max_frames = 0, nmp = p.br[0].nm_pad;
@@ -405,6 +598,35 @@ void launch_mel(const float *x, const float *minmax, float *spec, const Frontend
         max_frames = p.br[b].n_frames > max_frames ? p.br[b].n_frames : max_frames;
     }
     static const int dbg = getenv("BIRDA_HIP_MEL_DBG") ? atoi(getenv("BIRDA_HIP_MEL_DBG")) : 0;  // tuning ablations
+    if (p.prec == 32) {
+        int span32 = 0;
+        for (int b = 0; b < p.n_branches; b++) span32 = std::max(span32, (MEL32_TN - 1) * p.br[b].H + p.br[b].L);
+        const int mt32 = nmp / 32;
+        const int ybuf_off = (span32 + 3) & ~3;   // floats; the staged Y rows follow the span, the reduction buffer overlays both
+        const size_t smem32 = std::max((size_t)(ybuf_off + 4 * 2 * 32 * MEL32_YP) * sizeof(float), (size_t)4 * mt32 * 4 * 64 * sizeof(float4));
+        const int nt32 = (max_frames + MEL32_TN - 1) / MEL32_TN, ni32 = nt32 * p.n_branches * n_seg;
+        static int n_cu32 = 0;
+        if (!n_cu32) {
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu32, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu32 <= 0)
+                n_cu32 = 256;
+        }
+        dim3 g32((unsigned)std::min(ni32, 2 * n_cu32)), b32(256);
+#define BH_MEL32(MTV)                                                                                                          \
+    case MTV: {                                                                                                                \
+        static bool set32 = false;                                                                                             \
+        if (!set32) { (void)hipFuncSetAttribute((const void *)mel32_kernel<MTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set32 = true; } \
+        hipLaunchKernelGGL((mel32_kernel<MTV>), g32, b32, smem32, s, x, minmax, spec, d_p, p.br[0].gf, p.br[1].gf, p.br[2].gf, p.br[3].gf, dbg, ybuf_off, nt32, ni32); \
+    } break;
+        switch (mt32) {
+            BH_MEL32(1)
+            BH_MEL32(3)
+            BH_MEL32(4)
+        default: break;
+        }
+#undef BH_MEL32
+        return;
+    }
     const int mt = nmp / 16;
     const size_t span_bytes = (size_t)((max_span + 3) & ~3) * sizeof(float);
     const size_t red_bytes = (size_t)4 * 3 * mt * 64 * sizeof(float4);

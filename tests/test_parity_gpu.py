@@ -516,6 +516,33 @@ def test_perch_shaped_model_matches_oracle(oracle_lib, tmp_path, monkeypatch):
     ctx.close(); clf.close()
 
 
+@pytest.mark.parametrize("mel32", ["0", "1"])
+def test_both_front_end_kernels_match_oracle(full_model, oracle_lib, monkeypatch, mel32):
+    """mel_kernel (16-frame tiles) and mel32_kernel (32-frame tiles, Y rows staged along k) are chosen by hop; force each
+    on the BirdNET front-end (96 mels, two branches) and hold it to the same logit tolerance and slicing invariance."""
+    import torch
+    from birda_amd import synth
+    from birda_amd.classifier import BirdClassifier
+    path, _, m, _ = full_model
+    monkeypatch.setenv("BIRDA_HIP_MEL32", mel32)
+    clf = BirdClassifier(path, precision="f16x3")
+    segs = synth.synth_segments(5, m.sample_count, m.sample_rate, start=300)
+    ctx = clf.create_batch_context(8)
+    got = clf.predict_logits(ctx, segs)
+    ref = oracle_lib.OracleModel(path).forward(segs)
+    print(f"BIRDA_HIP_MEL32={mel32}: max|dlogit| = {_logit_close(got, ref):.3e}")
+    x = torch.from_numpy(segs[np.arange(300) % 5]).cuda()
+    la = torch.empty((300, m.n_classes), device="cuda"); lb = torch.empty_like(la)
+    ctx2 = clf.create_batch_context(96)
+    big = clf.create_batch_context(300)
+    clf.forward_device(big, x.data_ptr(), 300, la.data_ptr()); big.synchronize()
+    for _ in range(3):
+        clf.forward_device(ctx2, x.data_ptr(), 300, lb.data_ptr()); ctx2.synchronize()
+        assert torch.equal(la, lb)
+    assert np.array_equal(la[:5].cpu().numpy(), got)
+    ctx.close(); ctx2.close(); big.close(); clf.close()
+
+
 def test_model_converted_from_onnx_runs_identically(model_dir, tmp_path):
     """model -> ONNX bytes -> birda_amd.convert -> BHM1: the library must plan the same fused blocks and return
     bit-identical logits for the converted file (same weights, layer table rebuilt from the ONNX graph)."""
