@@ -70,6 +70,10 @@ SYMBOLS = [
     ("bh_resample", C.c_int, [_VP, _VP, _SZ, C.c_uint32, C.c_uint32, _VP, _SZ, C.POINTER(_SZ)]),
     ("bh_resample_output_len", C.c_int, [_SZ, C.c_uint32, C.c_uint32, C.POINTER(_SZ)]),
     ("bh_resample_device", C.c_int, [_VP, _VP, _VP, _SZ, _SZ, C.c_uint32, C.c_uint32, _VP, _SZ, _SZ, _SZ]),
+    ("bh_classifier_set_range_filter", C.c_int, [_VP, _VP, _SZ, C.c_float, C.c_int, C.c_int]),
+    ("bh_classifier_set_species_list", C.c_int, [_VP, _VP, _SZ]),
+    ("bh_classifier_clear_filters", C.c_int, [_VP]),
+    ("bh_topk_from_logits", C.c_int, [_VP, _VP, _SZ, C.POINTER(BhResult)]),
 ]
 
 
@@ -104,6 +108,8 @@ HOST_SYMBOLS = [
     ("bhh_csv_header", _SZ, [C.c_int, C.c_char_p, _SZ]),
     ("bhh_csv_row", _SZ, [C.c_char_p, C.c_float, C.c_float, C.c_float, C.c_char_p, C.c_char_p, _SZ]),
     ("bhh_process_file", C.c_int, [_VP, C.POINTER(BhhProcessingConfig), C.POINTER(BhhProcessResult)]),
+    ("bhh_scientific_name_len", _SZ, [C.c_char_p]),
+    ("bhh_project_scores", C.c_int, [_VP, _SZ, _VP, _VP, _SZ, _VP, _SZ, C.c_float, _VP, C.POINTER(_SZ), C.POINTER(_SZ)]),
 ]
 
 _lib = None

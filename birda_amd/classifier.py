@@ -250,6 +250,28 @@ class BirdClassifier:
         check(self._L.bh_debug_read_tensor(self._h, ctx._h, tensor, out.ctypes.data, out.size))
         return out
 
+    # ---- range filter / species list (classifier.rs:587-645), applied on the device to the kept top-k -------
+    def set_range_filter(self, scores: np.ndarray, threshold: float, unmatched: str = "keep", rerank: bool = False):
+        """scores[c]: geomodel occurrence score of class c, NaN where the species has no geomodel entry
+        (pipeline.project_scores builds it).  unmatched: "keep" | "drop" (config UnmatchedPolicy)."""
+        if unmatched not in ("keep", "drop"):
+            raise ValueError("unmatched must be 'keep' or 'drop'")
+        a = np.ascontiguousarray(scores, np.float32)
+        check(self._L.bh_classifier_set_range_filter(self._h, a.ctypes.data, a.size, threshold, int(unmatched == "keep"), int(rerank)))
+
+    def set_species_list(self, keep: np.ndarray):
+        a = np.ascontiguousarray(np.asarray(keep) != 0, np.uint8)
+        check(self._L.bh_classifier_set_species_list(self._h, a.ctypes.data, a.size))
+
+    def clear_filters(self):
+        check(self._L.bh_classifier_clear_filters(self._h))
+
+    def topk_from_logits(self, logits: np.ndarray) -> List[PredictionResult]:
+        a = np.ascontiguousarray(logits, np.float32).reshape(-1, self.n_classes())
+        arr = (BhResult * max(1, a.shape[0]))()
+        check(self._L.bh_topk_from_logits(self._h, a.ctypes.data, a.shape[0], arr))
+        return self._results(arr, a.shape[0])
+
     def close(self):
         if getattr(self, "_h", None):
             self._L.bh_classifier_destroy(self._h)

@@ -69,6 +69,9 @@ struct bh_classifier {
     int precision = 0;                       // GEMM operands of the fused blocks: 0 f32, 3 f16 hi/lo split, 1 f16
     unsigned long long *d_stamps = nullptr;  // BIRDA_HIP_MB_STAMPS=1: [mb.size()][8] phase counters
     uint64_t mel_flops = 0;
+    bh::TopkFilter filter;                   // range filter / species list applied to the kept top-k (device tables below)
+    float *d_class_score = nullptr;
+    unsigned char *d_species_keep = nullptr;
     std::mutex warm_mu;
     std::set<size_t> warmed;                 // WarmupRegistry, classifier.rs:221-246
     bh_batch_context *internal_ctx = nullptr;
@@ -395,7 +398,7 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
     }
     if (d_idx && d_conf) {
         bh::launch_topk(d_logits, (int)n, (int)m.h.n_classes, (int)m.h.output_activation, (int)c->top_k,
-                        c->min_conf, d_idx, d_conf, s);
+                        c->min_conf, c->filter, d_idx, d_conf, s);
         ctx_mark(ctx, ST_TOPK);
     }
     HIPCHK(hipGetLastError());
@@ -871,7 +874,80 @@ void bh_classifier_destroy(bh_classifier *c) {
     for (float *d : c->d_owned) (void)hipFree(d);
     (void)hipFree(c->d_blob);
     (void)hipFree(c->d_stamps);
+    (void)hipFree(c->d_class_score);
+    (void)hipFree(c->d_species_keep);
     delete c;
+}
+
+// ---- range filter / species list (reference classifier.rs:587-645) -------------------------
+int bh_classifier_set_range_filter(bh_classifier *c, const float *scores, size_t n_classes, float threshold,
+                                   int keep_unmatched, int rerank) {
+    if (!c || !scores) return fail(BH_ERR_INVALID, "set_range_filter: null argument");
+    if (n_classes != c->model.h.n_classes)
+        return fail(BH_ERR_INVALID, "set_range_filter: %zu scores for %u classes", n_classes, c->model.h.n_classes);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());   // no launch may still read the table being replaced
+    if (!c->d_class_score) HIPCHK(hipMalloc((void **)&c->d_class_score, n_classes * sizeof(float)));
+    HIPCHK(hipMemcpy(c->d_class_score, scores, n_classes * sizeof(float), hipMemcpyHostToDevice));
+    c->filter.class_score = c->d_class_score;
+    c->filter.threshold = threshold;
+    c->filter.keep_unmatched = keep_unmatched ? 1 : 0;
+    c->filter.rerank = rerank ? 1 : 0;
+    return BH_OK;
+}
+
+int bh_classifier_set_species_list(bh_classifier *c, const uint8_t *keep, size_t n_classes) {
+    if (!c || !keep) return fail(BH_ERR_INVALID, "set_species_list: null argument");
+    if (n_classes != c->model.h.n_classes)
+        return fail(BH_ERR_INVALID, "set_species_list: %zu flags for %u classes", n_classes, c->model.h.n_classes);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    if (!c->d_species_keep) HIPCHK(hipMalloc((void **)&c->d_species_keep, n_classes));
+    HIPCHK(hipMemcpy(c->d_species_keep, keep, n_classes, hipMemcpyHostToDevice));
+    c->filter.species_keep = c->d_species_keep;
+    return BH_OK;
+}
+
+int bh_topk_from_logits(bh_classifier *c, const float *logits, size_t n, bh_result *out) {
+    if (!c || (n && (!logits || !out))) return fail(BH_ERR_INVALID, "topk_from_logits: null argument");
+    if (!n) return BH_OK;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t nc = c->model.h.n_classes, tk = c->top_k;
+    float *d_l = nullptr, *d_c = nullptr;
+    int32_t *d_i = nullptr;
+    std::vector<int32_t> hi(n * tk);
+    std::vector<float> hc(n * tk);
+    hipError_t e = hipMalloc((void **)&d_l, n * nc * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_i, n * tk * sizeof(int32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_c, n * tk * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(d_l, logits, n * nc * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        bh::launch_topk(d_l, (int)n, (int)nc, (int)c->model.h.output_activation, (int)tk, c->min_conf, c->filter, d_i, d_c, nullptr);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(hi.data(), d_i, n * tk * sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(hc.data(), d_c, n * tk * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d_l); (void)hipFree(d_i); (void)hipFree(d_c);
+    if (e != hipSuccess) return fail(BH_ERR_HIP, "topk_from_logits: %s", hipGetErrorString(e));
+    for (size_t i = 0; i < n; i++) {
+        bh_result &r = out[i];
+        r.n_pred = 0;
+        for (size_t k = 0; k < tk; k++) {
+            if (hi[i * tk + k] < 0) break;
+            r.index[r.n_pred] = hi[i * tk + k];
+            r.confidence[r.n_pred] = hc[i * tk + k];
+            r.n_pred++;
+        }
+    }
+    return BH_OK;
+}
+
+int bh_classifier_clear_filters(bh_classifier *c) {
+    if (!c) return fail(BH_ERR_INVALID, "clear_filters: null classifier");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    c->filter = bh::TopkFilter{};
+    return BH_OK;
 }
 
 int bh_classifier_info(const bh_classifier *c, bh_model_info *info) {

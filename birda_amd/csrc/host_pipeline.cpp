@@ -24,6 +24,8 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
+#include <limits>
 #include <vector>
 
 #include "../../include/birda_hip.h"
@@ -535,3 +537,51 @@ int bhh_process_file(bh_classifier *clf, const bhh_processing_config *cfg, bhh_p
 }
 
 }  // extern "C"
+
+
+// ---- range filter tables (reference src/inference/geomodel.rs) ---------------------------------------------
+extern "C" BH_API size_t bhh_scientific_name_len(const char *label) {
+    if (!label) return 0;
+    const char *us = std::strchr(label, '_');
+    if (!us) return std::strlen(label);
+    // the prefix is a scientific name only when it contains a space (binomials do, FSD50K classes do not): :28-33
+    return std::memchr(label, ' ', (size_t)(us - label)) ? (size_t)(us - label) : std::strlen(label);
+}
+
+static std::string species_key(const char *label) {   // :36-38
+    std::string k(label, bhh_scientific_name_len(label));
+    for (char &ch : k)
+        if (ch >= 'A' && ch <= 'Z') ch = (char)(ch + 32);
+    return k;
+}
+
+extern "C" BH_API int bhh_project_scores(const char *const *geomodel_labels, size_t n_geomodel, const char *const *score_species,
+                                         const float *score_values, size_t n_scores, const char *const *classifier_labels,
+                                         size_t n_classes, float threshold, float *out_scores, size_t *mapped, size_t *in_range) {
+    if ((n_geomodel && !geomodel_labels) || (n_scores && (!score_species || !score_values)) || (n_classes && (!classifier_labels || !out_scores))) {
+        return hfail(BH_ERR_INVALID, "project_scores: null argument");
+    }
+    std::unordered_map<std::string, size_t> cls_by_key;   // first classifier label of a scientific name wins (:62-74)
+    cls_by_key.reserve(n_classes);
+    for (size_t c = 0; c < n_classes; c++) {
+        cls_by_key.emplace(species_key(classifier_labels[c]), c);
+        out_scores[c] = std::numeric_limits<float>::quiet_NaN();
+    }
+    size_t n_mapped = 0;
+    for (size_t g = 0; g < n_geomodel; g++) {              // mapped species start at 0 = "out of range" (:146-149)
+        auto it = cls_by_key.find(species_key(geomodel_labels[g]));
+        if (it != cls_by_key.end() && std::isnan(out_scores[it->second])) { out_scores[it->second] = 0.0f; n_mapped++; }
+    }
+    for (size_t i = 0; i < n_scores; i++) {                // :151-158; species outside the mapping are dropped
+        auto it = cls_by_key.find(species_key(score_species[i]));
+        if (it != cls_by_key.end() && !std::isnan(out_scores[it->second])) out_scores[it->second] = score_values[i];
+    }
+    if (mapped) *mapped = n_mapped;
+    if (in_range) {                                        // :173-178
+        size_t n = 0;
+        for (size_t c = 0; c < n_classes; c++)
+            if (out_scores[c] >= threshold) n++;
+        *in_range = n;
+    }
+    return BH_OK;
+}

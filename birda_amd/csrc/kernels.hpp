@@ -192,8 +192,17 @@ bool head_gap16_supports(int P, int K, int N, int act);
 void launch_head_gap16(const float *A, const void *Wf, const float *bias, float *out, int n_seg, int P, int K, int N,
                        int terms, hipStream_t s);
 // activation + top-k over logits [n][n_classes] -> idx/conf [n][top_k]
+// Post-filter of the kept top-k (reference apply_range_filter, classifier.rs:587-645): class_score (NaN = species without
+// geomodel entry) selects geomodel_filter.rs:46-82, else species_keep the species-list retain (:617-640); both null = off.
+struct TopkFilter {
+    const float *class_score = nullptr;
+    const unsigned char *species_keep = nullptr;
+    float threshold = 0.f;
+    int keep_unmatched = 1;
+    int rerank = 0;
+};
 void launch_topk(const float *logits, int n_seg, int n_classes, int out_act, int top_k, float min_conf,
-                 int32_t *idx, float *conf, hipStream_t s);
+                 const TopkFilter &filter, int32_t *idx, float *conf, hipStream_t s);
 
 // Polyphase resampler (resample.hip): rubato's FFT resampler as one dense operator on the MFMA.
 struct ResamplePlan {

@@ -584,12 +584,14 @@ __device__ __forceinline__ void topk_better(float &bv, int &bi, float ov, int oi
 }
 
 __global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ logits, int n_classes, int out_act,
-                                                    int top_k, float min_conf, int32_t *__restrict__ idx,
-                                                    float *__restrict__ conf) {
+                                                    int top_k, float min_conf, const TopkFilter flt,
+                                                    int32_t *__restrict__ idx, float *__restrict__ conf) {
     extern __shared__ float row[];   // n_classes logits
     __shared__ float sv[4];
     __shared__ int si[4];
     __shared__ float red[1];
+    __shared__ int koi[32];          // kept predictions (top_k <= BH_MAX_TOP_K = 32)
+    __shared__ float koc[32];
     const int seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *lg = logits + (size_t)seg * n_classes;
     float m = -INFINITY;
@@ -635,16 +637,52 @@ __global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ log
         const bool ok = !stop && bi >= 0 && p >= min_conf;
         if (!ok) stop = true;
         if (tid == 0) {
-            idx[(size_t)seg * top_k + k] = ok ? bi : -1;
-            conf[(size_t)seg * top_k + k] = ok ? p : 0.f;
+            koi[k] = ok ? bi : -1;
+            koc[k] = ok ? p : 0.f;
             if (ok) row[bi] = __builtin_nanf("");
         }
         __syncthreads();
     }
+    if (tid == 0) {
+        int n = 0;
+        while (n < top_k && koi[n] >= 0) n++;
+        if (flt.class_score) {
+            // geomodel_filter.rs:46-82: in range -> keep (scaled when reranking), out of range -> drop,
+            // no geomodel entry -> keep only under the keep policy without rerank; rerank re-sorts descending
+            const bool keeps = flt.keep_unmatched && !flt.rerank;
+            int w = 0;
+            for (int i = 0; i < n; i++) {
+                const int ci = koi[i];
+                const float c0 = koc[i], sc = flt.class_score[ci];
+                if (sc != sc) {
+                    if (keeps) { koi[w] = ci; koc[w] = c0; w++; }
+                } else if (sc >= flt.threshold) {
+                    koi[w] = ci; koc[w] = flt.rerank ? c0 * sc : c0; w++;
+                }
+            }
+            if (flt.rerank)
+                for (int i = 1; i < w; i++) {   // stable insertion sort, descending
+                    const int ti = koi[i]; const float tc = koc[i];
+                    int j = i;
+                    while (j > 0 && koc[j - 1] < tc) { koi[j] = koi[j - 1]; koc[j] = koc[j - 1]; j--; }
+                    koi[j] = ti; koc[j] = tc;
+                }
+            for (int i = w; i < n; i++) { koi[i] = -1; koc[i] = 0.f; }
+        } else if (flt.species_keep) {   // classifier.rs:617-640
+            int w = 0;
+            for (int i = 0; i < n; i++)
+                if (flt.species_keep[koi[i]]) { const int ci = koi[i]; const float c0 = koc[i]; koi[w] = ci; koc[w] = c0; w++; }
+            for (int i = w; i < n; i++) { koi[i] = -1; koc[i] = 0.f; }
+        }
+        for (int k = 0; k < top_k; k++) {
+            idx[(size_t)seg * top_k + k] = koi[k];
+            conf[(size_t)seg * top_k + k] = koc[k];
+        }
+    }
 }
 
 void launch_topk(const float *logits, int n_seg, int n_classes, int out_act, int top_k, float min_conf,
-                 int32_t *idx, float *conf, hipStream_t s) {
+                 const TopkFilter &filter, int32_t *idx, float *conf, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         // (the kernel also has a few static __shared__ words: ask for less than the full 160 KB)
@@ -653,7 +691,7 @@ void launch_topk(const float *logits, int n_seg, int n_classes, int out_act, int
         attr_set = true;
     }
     hipLaunchKernelGGL(topk_kernel, dim3(n_seg), dim3(256), (size_t)n_classes * sizeof(float), s, logits, n_classes, out_act, top_k,
-                       min_conf, idx, conf);
+                       min_conf, filter, idx, conf);
 }
 
 }  // namespace bh

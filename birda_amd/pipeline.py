@@ -81,6 +81,39 @@ def csv_row(label: str, start: float, end: float, conf: float, path: str) -> byt
     return buf.raw[:n]
 
 
+def scientific_name(label: str) -> str:
+    """geomodel.rs:28-33."""
+    raw = label.encode("utf-8")
+    return raw[:_lib.load().bhh_scientific_name_len(raw)].decode("utf-8")
+
+
+@dataclass
+class MappingSummary:   # classifier.rs:128-131 (MappingSummary::new)
+    mapped: int
+    total: int
+    unmatched: int
+    in_range: int
+
+
+def project_scores(geomodel_labels: List[str], reported: List[Tuple[str, float]], classifier_labels: List[str],
+                   threshold: float = 0.0) -> Tuple[np.ndarray, MappingSummary]:
+    """SpeciesMapping::build + GeomodelScores::project (geomodel.rs:58-162) onto class indices: the table
+    BirdClassifier.set_range_filter takes (NaN = no geomodel entry)."""
+    def arr(items):
+        raw = [s.encode("utf-8") for s in items]
+        return (C.c_char_p * max(1, len(raw)))(*raw), raw
+    g, _g = arr(geomodel_labels)
+    sp, _s = arr([r[0] for r in reported])
+    c, _c = arr(classifier_labels)
+    vals = np.asarray([r[1] for r in reported] or [0.0], np.float32)
+    out = np.zeros(max(1, len(classifier_labels)), np.float32)
+    mapped, in_range = C.c_size_t(), C.c_size_t()
+    _hcheck(_lib.load().bhh_project_scores(g, len(geomodel_labels), sp, vals.ctypes.data, len(reported), c,
+                                           len(classifier_labels), threshold, out.ctypes.data, C.byref(mapped), C.byref(in_range)))
+    n = len(classifier_labels)
+    return out[:n].copy(), MappingSummary(mapped.value, n, n - mapped.value, in_range.value)
+
+
 @dataclass
 class ProcessResult:
     detections: int

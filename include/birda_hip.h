@@ -137,6 +137,28 @@ BH_API int bh_predict_batch_contig(bh_classifier *c, bh_batch_context *ctx, cons
 BH_API int bh_predict_batch_logits(bh_classifier *c, bh_batch_context *ctx, const float *base,
                                    size_t n, float *logits, float *embeddings);
 
+/* ---- range filter / species list on the kept top-k --------------------- */
+/* BirdClassifier::apply_range_filter (classifier.rs:587-645) runs on every PredictionResult between the
+ * classifier call and detection extraction (processor.rs:320); here it is the tail of the top-k kernel, so
+ * every entry point (bh_predict*, bh_forward_device's d_topk_*) returns filtered predictions.
+ * set_range_filter = filter_predictions (geomodel_filter.rs:46-82) with GeomodelScores flattened onto class
+ * indices: scores[c] is the occurrence score of classifier label c, NaN where score_of() is None (no
+ * geomodel entry; birda_host.h bhh_project_scores builds the table as geomodel.rs:58-162 does).
+ *   score >= threshold: keep (confidence * score when rerank);  score < threshold: drop;
+ *   NaN: keep only when keep_unmatched and not rerank (:33-35).  rerank re-sorts by confidence descending.
+ * Dropped slots close up; the tail is -1 / 0 padded.  set_species_list = the species-list retain
+ * (classifier.rs:617-640), used only while no range filter is set (:587, :617), keep[c] != 0 keeps class c.
+ * The caller still applies `confidence >= min_confidence` per detection (processor.rs:375): rerank lowers
+ * confidences after the classifier's own threshold.  Call between batches, from the predicting thread. */
+BH_API int bh_classifier_set_range_filter(bh_classifier *c, const float *scores, size_t n_classes,
+                                          float threshold, int keep_unmatched, int rerank);
+BH_API int bh_classifier_set_species_list(bh_classifier *c, const uint8_t *keep, size_t n_classes);
+BH_API int bh_classifier_clear_filters(bh_classifier *c);
+/* Output activation + top-k + min-confidence + the filter above on caller-held logits (host [n][n_classes], e.g. kept
+ * from bh_predict_batch_logits): the stage birdnet_onnx runs after Session::run, on the same kernel the predict entry
+ * points use.  Lets a caller change filters / thresholds without re-running the network. */
+BH_API int bh_topk_from_logits(bh_classifier *c, const float *logits, size_t n, bh_result *out);
+
 /* ---- device-resident path (bench / multi-GPU sharding: inputs already in HBM) -------- */
 /* d_segments: device f32 [n][sample_count]; d_logits: device f32 [n][n_classes];
  * d_topk_index/d_topk_conf (nullable): device [n][top_k], -1 / 0 padded.

@@ -67,6 +67,19 @@ typedef struct {
 
 BH_API int bhh_process_file(bh_classifier *clf, const bhh_processing_config *cfg, bhh_process_result *res);
 
+/* ---- range filter tables (geomodel.rs; pure host logic, once per run) ------------------ */
+/* scientific_name (geomodel.rs:28-33): length of the scientific-name prefix of a label. */
+BH_API size_t bhh_scientific_name_len(const char *label);
+/* SpeciesMapping::build (geomodel.rs:58-93) + GeomodelScores::project (:140-162) flattened onto class indices for
+ * bh_classifier_set_range_filter: out_scores[c] = NaN when classifier label c has no geomodel entry, else the reported
+ * score of its species (0 when the report omits it).  Matching is on the lower-cased scientific name (ASCII case
+ * folding); of two classifier labels sharing one the first is mapped.  score_species / score_values are the geomodel's
+ * LocationScores (birdnet_onnx RangeFilter::predict output, queried with threshold 0: classifier.rs:117-145).
+ * mapped / in_range (nullable) receive MappingSummary's counts (mapped_count, in_range_count(threshold)). */
+BH_API int bhh_project_scores(const char *const *geomodel_labels, size_t n_geomodel, const char *const *score_species,
+                              const float *score_values, size_t n_scores, const char *const *classifier_labels,
+                              size_t n_classes, float threshold, float *out_scores, size_t *mapped, size_t *in_range);
+
 #ifdef __cplusplus
 }
 #endif

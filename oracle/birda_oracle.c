@@ -817,3 +817,108 @@ BO_API size_t bo_process_stream(const bo_model *m, const char *const *labels, co
     free(det); free(batch); free(logits); free(idx); free(conf); free(segs); free(st); free(en);
     return o;
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* Range filter / species list                                     */
+/* ------------------------------------------------------------------------------------ */
+
+/* scientific_name -- reference src/inference/geomodel.rs:28-33: the part before the first '_'
+ * when that part contains a space, else the whole label.  Returns its length (a prefix of label). */
+BO_API size_t bo_scientific_name_len(const char *label) {
+    const char *us = strchr(label, '_');
+    if (!us) return strlen(label);
+    for (const char *p = label; p < us; p++)
+        if (*p == ' ') return (size_t)(us - label);
+    return strlen(label);
+}
+
+/* species_key -- geomodel.rs:36-38: scientific name, lower-cased (ASCII here: binomials are Latin). */
+static char *bo_species_key(const char *label) {
+    size_t n = bo_scientific_name_len(label);
+    char *k = malloc(n + 1);
+    for (size_t i = 0; i < n; i++) {
+        unsigned char ch = (unsigned char)label[i];
+        k[i] = (char)((ch >= 'A' && ch <= 'Z') ? ch + 32 : ch);
+    }
+    k[n] = 0;
+    return k;
+}
+
+/* SpeciesMapping::build + GeomodelScores::project -- geomodel.rs:58-93 and :140-162, flattened onto
+ * class indices: out[c] = NaN when classifier label c has no geomodel entry (score_of -> None), else the
+ * geomodel's score for that species, 0 when the score list omits it.  Of two classifier labels with one
+ * scientific name the first is mapped (:62-74), the second stays unmatched.  geo_scores / score_species
+ * list the reported LocationScores (species label, score) in order; later entries overwrite earlier ones
+ * (HashMap::insert, :154-157).  Returns mapped_count (:103-105).  O(n^2): an oracle. */
+BO_API size_t bo_project_scores(const char *const *geo_labels, size_t n_geo, const char *const *score_species,
+                                const float *score_values, size_t n_scores, const char *const *cls_labels,
+                                size_t n_cls, float *out) {
+    char **ck = malloc(sizeof(char *) * (n_cls ? n_cls : 1));
+    int *first = malloc(sizeof(int) * (n_cls ? n_cls : 1));
+    for (size_t c = 0; c < n_cls; c++) {
+        ck[c] = bo_species_key(cls_labels[c]);
+        first[c] = 1;
+        for (size_t d = 0; d < c; d++)
+            if (!strcmp(ck[d], ck[c])) { first[c] = 0; break; }
+        out[c] = NAN;
+    }
+    size_t mapped = 0;
+    for (size_t g = 0; g < n_geo; g++) {
+        char *gk = bo_species_key(geo_labels[g]);
+        for (size_t c = 0; c < n_cls; c++)
+            if (first[c] && !strcmp(ck[c], gk)) {
+                if (isnan(out[c])) { out[c] = 0.0f; mapped++; }
+                break;
+            }
+        free(gk);
+    }
+    for (size_t s = 0; s < n_scores; s++) {
+        char *sk = bo_species_key(score_species[s]);
+        for (size_t c = 0; c < n_cls; c++)
+            if (first[c] && !strcmp(ck[c], sk)) {
+                if (!isnan(out[c])) out[c] = score_values[s];   /* classifier_label_for: only mapped species */
+                break;
+            }
+        free(sk);
+    }
+    for (size_t c = 0; c < n_cls; c++) free(ck[c]);
+    free(ck); free(first);
+    return mapped;
+}
+
+/* filter_predictions -- reference src/inference/geomodel_filter.rs:46-82 on one PredictionResult:
+ *   score >= threshold: keep (confidence * score when rerank); score < threshold: drop;
+ *   no entry (NaN): keep only under the keep policy without rerank (:33-35).
+ * With rerank the survivors are re-sorted by confidence descending under f32 total order (:77-79; the
+ * reference's sort is unstable: equal confidences keep their input order here).  Returns the count. */
+BO_API int bo_filter_predictions(const int *idx, const float *conf, int n, const float *scores, float threshold,
+                                 int keep_unmatched, int rerank, int *out_idx, float *out_conf) {
+    const int keeps = keep_unmatched && !rerank;
+    int k = 0;
+    for (int i = 0; i < n; i++) {
+        const float s = scores[idx[i]];
+        if (isnan(s)) {
+            if (keeps) { out_idx[k] = idx[i]; out_conf[k] = conf[i]; k++; }
+        } else if (s >= threshold) {
+            out_idx[k] = idx[i]; out_conf[k] = rerank ? conf[i] * s : conf[i]; k++;
+        }
+    }
+    if (rerank)
+        for (int i = 1; i < k; i++) {   /* insertion sort, descending, stable */
+            const int ti = out_idx[i]; const float tc = out_conf[i];
+            int j = i;
+            while (j > 0 && out_conf[j - 1] < tc) { out_idx[j] = out_idx[j - 1]; out_conf[j] = out_conf[j - 1]; j--; }
+            out_idx[j] = ti; out_conf[j] = tc;
+        }
+    return k;
+}
+
+/* species-list filter -- reference src/inference/classifier.rs:617-640: retain predictions whose species is
+ * in the list (keep[class] != 0); applies only when no range filter is configured (:587, :617). */
+BO_API int bo_species_retain(const int *idx, const float *conf, int n, const unsigned char *keep, int *out_idx,
+                             float *out_conf) {
+    int k = 0;
+    for (int i = 0; i < n; i++)
+        if (keep[idx[i]]) { out_idx[k] = idx[i]; out_conf[k] = conf[i]; k++; }
+    return k;
+}

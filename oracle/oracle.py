@@ -49,6 +49,14 @@ def lib():
     L.bo_topk.restype = C.c_int
     L.bo_topk.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
     L.bo_fft.argtypes = [C.c_void_p] * 4 + [C.c_int, C.c_int]
+    L.bo_scientific_name_len.restype = C.c_size_t
+    L.bo_scientific_name_len.argtypes = [C.c_char_p]
+    L.bo_project_scores.restype = C.c_size_t
+    L.bo_project_scores.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    L.bo_filter_predictions.restype = C.c_int
+    L.bo_filter_predictions.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.bo_species_retain.restype = C.c_int
+    L.bo_species_retain.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.bo_pcm16_to_mono.argtypes = [C.c_void_p, C.c_size_t, C.c_int, f32p]
     L.bo_pcm32_to_mono.argtypes = [C.c_void_p, C.c_size_t, C.c_int, f32p]
     L.bo_f32_to_mono.argtypes = [f32p, C.c_size_t, C.c_int, f32p]
@@ -174,6 +182,47 @@ def topk(logits: np.ndarray, out_act: int, top_k: int, min_conf: float) -> Tuple
     conf = np.zeros(top_k, np.float32)
     k = L.bo_topk(logits, logits.size, out_act, top_k, min_conf, idx.ctypes.data, conf.ctypes.data)
     return idx[:k].copy(), conf[:k].copy()
+
+
+def scientific_name(label: str) -> str:
+    raw = label.encode("utf-8")
+    return raw[:lib().bo_scientific_name_len(raw)].decode("utf-8")
+
+
+def _cstrs(items):
+    raw = [s.encode("utf-8") for s in items]
+    return (C.c_char_p * max(1, len(raw)))(*raw), raw
+
+
+def project_scores(geo_labels, reported, cls_labels) -> Tuple[np.ndarray, int]:
+    """reported: [(geomodel species label, score)].  Returns (per-class scores with NaN = no geomodel entry, mapped count)."""
+    L = lib()
+    g, _g = _cstrs(geo_labels)
+    sp, _s = _cstrs([r[0] for r in reported])
+    c, _c = _cstrs(cls_labels)
+    vals = np.asarray([r[1] for r in reported] or [0.0], np.float32)
+    out = np.zeros(max(1, len(cls_labels)), np.float32)
+    mapped = L.bo_project_scores(g, len(geo_labels), sp, vals.ctypes.data, len(reported), c, len(cls_labels), out.ctypes.data)
+    return out[:len(cls_labels)].copy(), int(mapped)
+
+
+def filter_predictions(idx, conf, scores, threshold: float, keep_unmatched: bool, rerank: bool):
+    L = lib()
+    idx = np.ascontiguousarray(idx, np.int32); conf = np.ascontiguousarray(conf, np.float32)
+    scores = np.ascontiguousarray(scores, np.float32)
+    oi = np.zeros(max(1, idx.size), np.int32); oc = np.zeros(max(1, idx.size), np.float32)
+    k = L.bo_filter_predictions(idx.ctypes.data, conf.ctypes.data, idx.size, scores.ctypes.data, threshold,
+                                int(keep_unmatched), int(rerank), oi.ctypes.data, oc.ctypes.data)
+    return oi[:k].copy(), oc[:k].copy()
+
+
+def species_retain(idx, conf, keep):
+    L = lib()
+    idx = np.ascontiguousarray(idx, np.int32); conf = np.ascontiguousarray(conf, np.float32)
+    keep = np.ascontiguousarray(keep, np.uint8)
+    oi = np.zeros(max(1, idx.size), np.int32); oc = np.zeros(max(1, idx.size), np.float32)
+    k = L.bo_species_retain(idx.ctypes.data, conf.ctypes.data, idx.size, keep.ctypes.data, oi.ctypes.data, oc.ctypes.data)
+    return oi[:k].copy(), oc[:k].copy()
 
 
 def fft(x: np.ndarray, sign: int = -1) -> np.ndarray:

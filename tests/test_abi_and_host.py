@@ -277,3 +277,34 @@ def test_device_code_has_no_half_swapped_packed_f32_ops(tmp_path):
     for name, text in texts.items():
         bad = [l.strip() for l in text.splitlines() if re.search(r"v_pk_(add|mul|fma)_f32\b.*\bop_sel:\[", l)]
         assert not bad, (name, bad[:3])
+
+
+# ---------------- range filter tables (host logic, include/birda_host.h) ----------------
+def test_species_mapping_and_projection_match_reference_cases_and_oracle(L, cases, oracle_lib):
+    from birda_amd import pipeline
+    for c in cases["scientific_name"]:
+        assert pipeline.scientific_name(c["label"]) == c["expect"], c["src"]
+    for c in cases["geomodel_projection"]:
+        reported = [tuple(r) for r in c["reported"]]
+        got, summary = pipeline.project_scores(c["geomodel"], reported, c["classifier"], 0.01)
+        want = np.asarray([np.nan if v is None else v for v in c["scores"]], np.float32)
+        assert (summary.mapped, summary.unmatched, summary.total) == (c["mapped"], c["unmatched"], len(c["classifier"])), c["src"]
+        assert np.array_equal(got, want, equal_nan=True), c["src"]
+        ref, mapped = oracle_lib.project_scores(c["geomodel"], reported, c["classifier"])
+        assert np.array_equal(got, ref, equal_nan=True) and mapped == summary.mapped, c["src"]
+        for thr, n in c.get("in_range", []):
+            assert pipeline.project_scores(c["geomodel"], reported, c["classifier"], thr)[1].in_range == n, c["src"]
+    # a label set at the real scale (6 522 classes against 12 012 geomodel species), host against oracle
+    rng = np.random.default_rng(5)
+    genus = [f"G{g:03d}" for g in range(400)]
+    pool = [f"{genus[i % 400]} s{i // 400:02d}" for i in range(13000)]
+    cls = [f"{pool[i]}_Common {i}" for i in rng.permutation(13000)[:6522]]
+    cls[10] = cls[3].split("_")[0] + "_Duplicate"            # collision: the first label wins
+    cls[20] = "Dog_Dog"; cls[21] = "Accelerating_and_revving_and_vroom"
+    geo = [f"{pool[i].upper() if i % 7 == 0 else pool[i]}_English {i}" for i in rng.permutation(13000)[:12012]]
+    reported = [(g, float(rng.random())) for g in geo[::3]]
+    got, summary = pipeline.project_scores(geo, reported, cls, 0.03)
+    ref, mapped = oracle_lib.project_scores(geo, reported, cls)
+    assert np.array_equal(got, ref, equal_nan=True) and summary.mapped == mapped
+    assert np.isnan(got[10]) and np.isnan(got[20]) and np.isnan(got[21])
+    assert summary.in_range == int((ref >= np.float32(0.03)).sum()) and 0 < summary.mapped < 6522

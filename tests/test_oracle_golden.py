@@ -267,3 +267,49 @@ def test_process_stream_csv_is_sorted_and_thresholded(oracle_lib, model_dir):
     assert all(float(r[1]) >= 0.05 for r in rows)
     assert st.n_segments == 7 and logits.shape == (7, m.n_classes)
     assert st.n_detections == len(rows) and st.n_detections <= 7 * 5
+
+
+# ---------------- range filter: oracle against the reference's unit-test expectations ----------------
+def test_scientific_name_matches_reference_tests(oracle_lib, cases):
+    for c in cases["scientific_name"]:
+        assert oracle_lib.scientific_name(c["label"]) == c["expect"], c["src"]
+
+
+def _expected_scores(c):
+    return np.asarray([np.nan if v is None else v for v in c["scores"]], np.float32)
+
+
+def test_geomodel_projection_matches_reference_tests(oracle_lib, cases):
+    for c in cases["geomodel_projection"]:
+        got, mapped = oracle_lib.project_scores(c["geomodel"], [tuple(r) for r in c["reported"]], c["classifier"])
+        want = _expected_scores(c)
+        assert mapped == c["mapped"] and len(c["classifier"]) - mapped == c["unmatched"], c["src"]
+        assert np.array_equal(np.isnan(got), np.isnan(want)) and np.array_equal(got[~np.isnan(got)], want[~np.isnan(want)]), c["src"]
+        for thr, n in c.get("in_range", []):
+            assert int((got >= np.float32(thr)).sum()) == n, c["src"]
+
+
+def filter_case_tables(c):
+    """Species of a filter_predictions case -> class indices, score table (NaN = no entry), inputs."""
+    species = sorted(set(c["table"]) | {s for s, _ in c["in"]})
+    index = {s: i for i, s in enumerate(species)}
+    scores = np.asarray([c["table"].get(s, np.nan) for s in species] or [np.nan], np.float32)
+    idx = np.asarray([index[s] for s, _ in c["in"]], np.int32)
+    conf = np.asarray([p for _, p in c["in"]], np.float32)
+    return species, index, scores, idx, conf
+
+
+def test_filter_predictions_matches_reference_tests(oracle_lib, cases):
+    for c in cases["filter_predictions"]:
+        species, index, scores, idx, conf = filter_case_tables(c)
+        oi, oc = oracle_lib.filter_predictions(idx, conf, scores, 0.01, c["policy"] == "keep", c["rerank"])
+        assert [species[i] for i in oi] == [s for s, _ in c["out"]], c["src"]
+        assert np.allclose(oc, [p for _, p in c["out"]], atol=1e-6), c["src"]     # the reference's own tolerance (:205)
+        if not c["rerank"]:
+            assert np.array_equal(oc, [np.float32(p) for _, p in c["out"]]), c["src"]   # confidence untouched: exact (:137-140)
+
+
+def test_species_list_retain(oracle_lib):
+    # classifier.rs:617-640: retain(|p| species_list.contains(&p.species)), order preserved
+    oi, oc = oracle_lib.species_retain([4, 1, 3, 0], [0.9, 0.8, 0.7, 0.6], [1, 0, 0, 1, 1])
+    assert oi.tolist() == [4, 3, 0] and np.array_equal(oc, np.asarray([0.9, 0.7, 0.6], np.float32))

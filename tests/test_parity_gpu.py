@@ -561,3 +561,83 @@ def test_model_converted_from_onnx_runs_identically(model_dir, tmp_path):
         ctx.close(); clf.close()
     assert out[0][0] == out[1][0] and len(out[0][0]) == 16
     assert np.array_equal(out[0][1], out[1][1])
+
+
+# ---- range filter / species list on the kept top-k --------------------------------------------
+def test_device_range_filter_reproduces_the_reference_unit_tests(clf_mini, model_dir):
+    """geomodel_filter.rs:126-300 as data (tests/golden/reference_unit_cases.json): each case's predictions are
+    planted as logits, pass through the top-k kernel and its filter tail, and must come out as the reference asserts."""
+    import json
+    from test_oracle_golden import filter_case_tables
+    with open(os.path.join(GOLDEN, "reference_unit_cases.json")) as f:
+        cases = json.load(f)["filter_predictions"]
+    _, _, m, _ = model_dir["mini"]
+    try:
+        for c in cases:
+            species, index, scores, idx, conf = filter_case_tables(c)
+            table = np.full(m.n_classes, np.nan, np.float32)
+            table[:len(species)] = scores[:len(species)]
+            logits = np.full((1, m.n_classes), -20.0, np.float32)            # sigmoid 2e-9: below min_confidence
+            for i, p in zip(idx, conf):
+                logits[0, i] = np.log(np.float64(p) / (1.0 - np.float64(p)))
+            clf_mini.set_range_filter(table, 0.01, c["policy"], c["rerank"])
+            got = clf_mini.topk_from_logits(logits)[0].predictions
+            assert [species[p.index] for p in got] == [s for s, _ in c["out"]], c["src"]
+            assert np.allclose([p.confidence for p in got], [p for _, p in c["out"]], atol=1e-6), c["src"]
+    finally:
+        clf_mini.clear_filters()
+
+
+@pytest.mark.parametrize("policy,rerank", [("keep", False), ("drop", False), ("keep", True), ("drop", True)])
+def test_device_range_filter_matches_oracle_on_every_entry_point(clf_tiny, model_dir, oracle_lib, policy, rerank):
+    import torch
+    from birda_amd import synth
+    _, _, m, _ = model_dir["birdnet_v24_tiny"]
+    rng = np.random.default_rng(11)
+    segs = synth.synth_segments(12, m.sample_count, m.sample_rate, start=70)
+    ctx = clf_tiny.create_batch_context(12)
+    plain = clf_tiny.predict_batch_with_context(ctx, list(segs))
+    assert sum(len(r.predictions) for r in plain) >= 12          # the tiny model's sigmoid outputs cluster near 0.5
+    table = rng.random(m.n_classes).astype(np.float32)
+    table[rng.random(m.n_classes) < 0.3] = np.nan                # species without geomodel entry
+    table[rng.random(m.n_classes) < 0.3] = 0.001                 # out of range
+    try:
+        clf_tiny.set_range_filter(table, 0.03, policy, rerank)
+        got = clf_tiny.predict_batch_with_context(ctx, list(segs))
+        one = clf_tiny.predict(segs[0])
+        x = torch.from_numpy(segs).cuda()
+        lg = torch.empty((12, m.n_classes), device="cuda")
+        di = torch.empty((12, 5), dtype=torch.int32, device="cuda"); dc = torch.empty((12, 5), device="cuda")
+        clf_tiny.forward_device(ctx, x.data_ptr(), 12, lg.data_ptr(), di.data_ptr(), dc.data_ptr()); ctx.synchronize()
+        di, dc = di.cpu().numpy(), dc.cpu().numpy()
+        dropped = 0
+        for i, (p, g) in enumerate(zip(plain, got)):
+            oi, oc = oracle_lib.filter_predictions([q.index for q in p.predictions], [q.confidence for q in p.predictions],
+                                                   table, 0.03, policy == "keep", rerank)
+            assert [q.index for q in g.predictions] == oi.tolist()
+            assert np.array_equal(np.asarray([q.confidence for q in g.predictions], np.float32), oc)   # one f32 multiply: exact
+            k = len(oi)
+            assert di[i, :k].tolist() == oi.tolist() and (di[i, k:] == -1).all() and (dc[i, k:] == 0).all()
+            assert np.array_equal(dc[i, :k], oc)
+            dropped += len(p.predictions) - k
+        assert [q.index for q in one.predictions] == [q.index for q in got[0].predictions]
+        assert dropped > 0
+        # species list: ignored while a range filter is set (classifier.rs:587, :617), applied once it is cleared
+        keep = rng.random(m.n_classes) < 0.5
+        clf_tiny.set_species_list(keep)
+        again = clf_tiny.predict_batch_with_context(ctx, list(segs))
+        assert [[q.index for q in r.predictions] for r in again] == [[q.index for q in r.predictions] for r in got]
+        clf_tiny.clear_filters()
+        clf_tiny.set_species_list(keep)
+        listed = clf_tiny.predict_batch_with_context(ctx, list(segs))
+        for p, g in zip(plain, listed):
+            oi, oc = oracle_lib.species_retain([q.index for q in p.predictions], [q.confidence for q in p.predictions], keep)
+            assert [q.index for q in g.predictions] == oi.tolist()
+            assert np.array_equal(np.asarray([q.confidence for q in g.predictions], np.float32), oc)
+    finally:
+        clf_tiny.clear_filters()
+    after = clf_tiny.predict_batch_with_context(ctx, list(segs))
+    assert [[q.index for q in r.predictions] for r in after] == [[q.index for q in r.predictions] for r in plain]
+    with pytest.raises(Exception):
+        clf_tiny.set_range_filter(table[:-1], 0.03)
+    ctx.close()

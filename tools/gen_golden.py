@@ -174,6 +174,73 @@ REFERENCE_UNIT_CASES = {
         {"batch_size": 16, "estimated": 10, "effective": 10, "segments": 10, "batches": 1, "padded_rows": 0},
         {"batch_size": 8, "estimated": 0, "effective": 8, "segments": 0, "batches": 0, "padded_rows": 0},
     ],
+    "scientific_name": [  # reference src/inference/geomodel.rs:198-238
+        {"src": "geomodel.rs:199", "label": "Parus major_Great Tit", "expect": "Parus major"},
+        {"src": "geomodel.rs:204", "label": "Parus major_Talitiainen", "expect": "Parus major"},
+        {"src": "geomodel.rs:209", "label": "Parus major", "expect": "Parus major"},
+        {"src": "geomodel.rs:214-217", "label": "Accelerating_and_revving_and_vroom", "expect": "Accelerating_and_revving_and_vroom"},
+        {"src": "geomodel.rs:222", "label": "Accordion", "expect": "Accordion"},
+        {"src": "geomodel.rs:223", "label": "Dog_Dog", "expect": "Dog_Dog"},
+        {"src": "geomodel.rs:228", "label": "Parus major_Great_Tit", "expect": "Parus major"},
+        {"src": "geomodel.rs:233", "label": "", "expect": ""},
+    ],
+    # SpeciesMapping::build + GeomodelScores::project (geomodel.rs:240-409).  "scores": expected score_of() per
+    # classifier label, null = None (no geomodel entry).
+    "geomodel_projection": [
+        {"src": "geomodel.rs:241-256 localized labels", "geomodel": ["Parus major_Great Tit"], "classifier": ["Parus major_Talitiainen"],
+         "reported": [], "mapped": 1, "unmatched": 0, "scores": [0.0]},
+        {"src": "geomodel.rs:259-266 bare binomial (Perch)", "geomodel": ["Parus major_Great Tit"], "classifier": ["Parus major"],
+         "reported": [], "mapped": 1, "unmatched": 0, "scores": [0.0]},
+        {"src": "geomodel.rs:269-276 case-insensitive", "geomodel": ["parus major_Great Tit"], "classifier": ["Parus Major_Talitiainen"],
+         "reported": [], "mapped": 1, "unmatched": 0, "scores": [0.0]},
+        {"src": "geomodel.rs:279-296 unmatched count", "geomodel": ["Parus major_Great Tit"],
+         "classifier": ["Parus major_Great Tit", "Accipiter gentilis_Northern Goshawk", "Dog_Dog"],
+         "reported": [], "mapped": 1, "unmatched": 2, "scores": [0.0, None, None]},
+        {"src": "geomodel.rs:299-312 geomodel-only species ignored",
+         "geomodel": ["Parus major_Great Tit", "Petaurista albiventer_White-bellied Giant Flying Squirrel"],
+         "classifier": ["Parus major_Great Tit"], "reported": [], "mapped": 1, "unmatched": 0, "scores": [0.0]},
+        {"src": "geomodel.rs:315-326 first of two colliding classifier labels", "geomodel": ["Parus major_Great Tit"],
+         "classifier": ["Parus major_First", "Parus major_Second"], "reported": [], "mapped": 1, "unmatched": 1, "scores": [0.0, None]},
+        {"src": "geomodel.rs:329-335 empty sets", "geomodel": [], "classifier": [], "reported": [], "mapped": 0, "unmatched": 0, "scores": []},
+        {"src": "geomodel.rs:338-353 keyed by classifier label", "geomodel": ["Parus major_Great Tit"], "classifier": ["Parus major_Talitiainen"],
+         "reported": [["Parus major_Great Tit", 0.8]], "mapped": 1, "unmatched": 0, "scores": [0.8]},
+        {"src": "geomodel.rs:356-367 omitted species reads 0", "geomodel": ["Parus major_Great Tit"], "classifier": ["Parus major_Great Tit"],
+         "reported": [], "mapped": 1, "unmatched": 0, "scores": [0.0]},
+        {"src": "geomodel.rs:370-378 unmatched omitted", "geomodel": ["Parus major_Great Tit"], "classifier": ["Dog_Dog"],
+         "reported": [], "mapped": 0, "unmatched": 1, "scores": [None]},
+        {"src": "geomodel.rs:381-397 species without classifier match dropped",
+         "geomodel": ["Parus major_Great Tit", "Vulpes vulpes_Red Fox"], "classifier": ["Parus major_Great Tit"],
+         "reported": [["Parus major_Great Tit", 0.8], ["Vulpes vulpes_Red Fox", 0.9]], "mapped": 1, "unmatched": 0, "scores": [0.8]},
+        {"src": "geomodel.rs:400-417 in_range_count", "geomodel": ["Aaa aaa_X", "Bbb bbb_Y", "Ccc ccc_Z"],
+         "classifier": ["Aaa aaa_X", "Bbb bbb_Y", "Ccc ccc_Z"],
+         "reported": [["Aaa aaa_X", 0.9], ["Bbb bbb_Y", 0.005], ["Ccc ccc_Z", 0.02]], "mapped": 3, "unmatched": 0,
+         "scores": [0.9, 0.005, 0.02], "in_range": [[0.01, 2], [0.5, 1], [0.99, 0]]},
+    ],
+    # filter_predictions (geomodel_filter.rs:84-294).  "table": score per species that has a geomodel entry;
+    # "in" / "out": [species, confidence] in order.  threshold 0.01 throughout (:117-123).
+    "filter_predictions": [
+        {"src": "geomodel_filter.rs:126-140", "table": {"Parus major_x": 0.5}, "policy": "keep", "rerank": False,
+         "in": [["Parus major_x", 0.8]], "out": [["Parus major_x", 0.8]]},
+        {"src": "geomodel_filter.rs:143-153", "table": {"Parus major_x": 0.005}, "policy": "keep", "rerank": False,
+         "in": [["Parus major_x", 0.9]], "out": []},
+        {"src": "geomodel_filter.rs:156-166 inclusive threshold", "table": {"Parus major_x": 0.01}, "policy": "keep", "rerank": False,
+         "in": [["Parus major_x", 0.9]], "out": [["Parus major_x", 0.9]]},
+        {"src": "geomodel_filter.rs:169-180", "table": {"Parus major_x": 0.5}, "policy": "keep", "rerank": False,
+         "in": [["Dog_Dog", 0.7]], "out": [["Dog_Dog", 0.7]]},
+        {"src": "geomodel_filter.rs:183-193", "table": {"Parus major_x": 0.5}, "policy": "drop", "rerank": False,
+         "in": [["Dog_Dog", 0.7]], "out": []},
+        {"src": "geomodel_filter.rs:196-206", "table": {"Parus major_x": 0.5}, "policy": "keep", "rerank": True,
+         "in": [["Parus major_x", 0.8]], "out": [["Parus major_x", 0.4]]},
+        {"src": "geomodel_filter.rs:209-222", "table": {"Parus major_x": 0.5}, "policy": "keep", "rerank": True,
+         "in": [["Parus major_x", 0.8], ["Dog_Dog", 0.9]], "out": [["Parus major_x", 0.4]]},
+        {"src": "geomodel_filter.rs:225-245", "table": {"Parus major_x": 0.9, "Rara avis_y": 0.02}, "policy": "keep", "rerank": True,
+         "in": [["Rara avis_y", 0.80], ["Parus major_x", 0.70]], "out": [["Parus major_x", 0.63], ["Rara avis_y", 0.016]]},
+        {"src": "geomodel_filter.rs:248-259", "table": {"Aaa aaa_x": 0.2, "Bbb bbb_y": 0.9}, "policy": "keep", "rerank": False,
+         "in": [["Aaa aaa_x", 0.5], ["Bbb bbb_y", 0.4]], "out": [["Aaa aaa_x", 0.5], ["Bbb bbb_y", 0.4]]},
+        {"src": "geomodel_filter.rs:278-284", "table": {"Aaa aaa_x": 0.9}, "policy": "keep", "rerank": True, "in": [], "out": []},
+        {"src": "geomodel_filter.rs:287-300", "table": {}, "policy": "keep", "rerank": False,
+         "in": [["Dog_Dog", 0.7], ["Siren_Siren", 0.6]], "out": [["Dog_Dog", 0.7], ["Siren_Siren", 0.6]]},
+    ],
     "pcm": [  # reference src/audio/decode.rs:353-411
         {"src": "decode.rs:372-374 S16 mono", "fmt": "s16", "channels": 1, "in": [0, 16384, -32768, 32767], "out": [0.0, 0.5, -1.0, 0.999969482421875]},
         {"src": "decode.rs:376-385 S16 stereo mean", "fmt": "s16", "channels": 2, "in": [16384, -16384, 32767, 32767], "out": [0.0, 0.999969482421875]},
