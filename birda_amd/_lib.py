@@ -108,6 +108,8 @@ HOST_SYMBOLS = [
     ("bhh_csv_header", _SZ, [C.c_int, C.c_char_p, _SZ]),
     ("bhh_csv_row", _SZ, [C.c_char_p, C.c_float, C.c_float, C.c_float, C.c_char_p, C.c_char_p, _SZ]),
     ("bhh_process_file", C.c_int, [_VP, C.POINTER(BhhProcessingConfig), C.POINTER(BhhProcessResult)]),
+    ("bhh_is_audio_file", C.c_int, [C.c_char_p]),
+    ("bhh_collect_input_files", _SZ, [_VP, _SZ, C.c_char_p, _SZ, C.POINTER(_SZ)]),
     ("bhh_scientific_name_len", _SZ, [C.c_char_p]),
     ("bhh_project_scores", C.c_int, [_VP, _SZ, _VP, _VP, _SZ, _VP, _SZ, C.c_float, _VP, C.POINTER(_SZ), C.POINTER(_SZ)]),
 ]

@@ -585,3 +585,63 @@ extern "C" BH_API int bhh_project_scores(const char *const *geomodel_labels, siz
     }
     return BH_OK;
 }
+
+
+// ---- directory mode (reference src/pipeline/coordinator.rs:146-190) ------------------------------------------
+#include <dirent.h>
+#include <sys/stat.h>
+
+extern "C" BH_API int bhh_is_audio_file(const char *path) {   // :179-190
+    if (!path) return 0;
+    const char *base = std::strrchr(path, '/');
+    base = base ? base + 1 : path;
+    const char *dot = std::strrchr(base, '.');
+    if (!dot || dot == base) return 0;                         // Path::extension(): ".wav" alone has none
+    std::string ext(dot + 1);
+    for (char &ch : ext)
+        if (ch >= 'A' && ch <= 'Z') ch = (char)(ch + 32);
+    for (const char *e : {"wav", "flac", "mp3", "m4a", "aac"})
+        if (ext == e) return 1;
+    return 0;
+}
+
+static bool walk_audio_files(const std::string &dir, std::vector<std::string> &files) {   // :164-176
+    DIR *d = opendir(dir.c_str());
+    if (!d) return false;
+    std::vector<std::string> names;
+    while (dirent *e = readdir(d)) {
+        if (!std::strcmp(e->d_name, ".") || !std::strcmp(e->d_name, "..")) continue;
+        names.emplace_back(e->d_name);
+    }
+    closedir(d);
+    std::sort(names.begin(), names.end());
+    for (const std::string &n : names) {
+        const std::string p = dir + "/" + n;
+        struct stat st;
+        if (stat(p.c_str(), &st) != 0) continue;
+        if (S_ISDIR(st.st_mode)) {
+            if (!walk_audio_files(p, files)) return false;
+        } else if (bhh_is_audio_file(p.c_str())) {
+            files.push_back(p);
+        }
+    }
+    return true;
+}
+
+extern "C" BH_API size_t bhh_collect_input_files(const char *const *paths, size_t n_paths, char *out, size_t cap, size_t *n_files) {
+    std::vector<std::string> files;
+    for (size_t i = 0; i < n_paths; i++) {                    // :146-161
+        struct stat st;
+        if (!paths || !paths[i] || stat(paths[i], &st) != 0) continue;   // "Skipping non-existent path"
+        if (S_ISREG(st.st_mode)) {
+            if (bhh_is_audio_file(paths[i])) files.emplace_back(paths[i]);
+        } else if (S_ISDIR(st.st_mode)) {
+            if (!walk_audio_files(paths[i], files)) { hfail(BH_ERR_IO, std::string("cannot read directory ") + paths[i]); return (size_t)-1; }
+        }
+    }
+    std::string joined;
+    for (size_t i = 0; i < files.size(); i++) { if (i) joined += '\n'; joined += files[i]; }
+    if (n_files) *n_files = files.size();
+    if (out && cap > joined.size()) std::memcpy(out, joined.c_str(), joined.size() + 1);
+    return joined.size() + 1;
+}

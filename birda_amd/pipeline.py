@@ -139,3 +139,34 @@ def process_file(classifier, input_path: str, output_dir: Optional[str] = None, 
     return ProcessResult(res.detections, res.segments, res.duration_secs, res.audio_duration_secs,
                          res.segments_per_sec, res.effective_batch, res.batches, res.padded_rows,
                          res.output_path.decode())
+
+
+def collect_input_files(paths: List[str]) -> List[str]:
+    """coordinator.rs:146-176: audio files given directly or found under the given directories."""
+    L = _lib.load()
+    raw = [p.encode() for p in paths]
+    arr = (C.c_char_p * max(1, len(raw)))(*raw)
+    n = C.c_size_t()
+    need = L.bhh_collect_input_files(arr, len(raw), None, 0, C.byref(n))
+    if need == C.c_size_t(-1).value:
+        _hcheck(-2)
+    buf = C.create_string_buffer(need)
+    L.bhh_collect_input_files(arr, len(raw), buf, need, C.byref(n))
+    return buf.value.decode().split("\n") if n.value else []
+
+
+def process_files(classifier, files: List[str], rank: int = 0, world: int = 1, durations: Optional[List[float]] = None,
+                  **kwargs) -> List[ProcessResult]:
+    """Directory mode on `world` processes (one per GPU): rank g takes the files `sharding.assign_by_duration` gives
+    it (the reference scales out as N processes over one directory with lock files, file_lock.rs:36-88)
+    and runs them through `process_file` one after another on its own classifier, as `process_files_sequential`
+    does (lib.rs:1003-1100)."""
+    from . import sharding
+    if durations is None:
+        durations = []
+        for f in files:
+            d = StreamingDecoder(f)
+            durations.append(d.duration_hint() or 0.0)
+            d.close()
+    mine = sharding.assign_by_duration(durations, world)[rank]
+    return [process_file(classifier, files[i], **kwargs) for i in mine]

@@ -21,6 +21,24 @@ def shard_range(n_total: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, hi
 
 
+def assign_by_duration(durations, world: int):
+    """Directory mode: contiguous runs of the file list per rank, cut where the cumulative audio duration crosses
+    g/world of the total, so output order = file order and every GPU gets about the same audio.
+    Returns world lists of file indices (some may be empty)."""
+    total = float(sum(durations))
+    out = [[] for _ in range(world)]
+    if total <= 0.0:
+        for i in range(len(durations)):               # no duration hints: equal file counts
+            out[(i * world) // len(durations)].append(i)
+        return out
+    acc = 0.0
+    for i, d in enumerate(durations):
+        mid = acc + 0.5 * float(d)                    # a file goes where its midpoint falls
+        out[min(world - 1, int(mid * world / total))].append(i)
+        acc += float(d)
+    return out
+
+
 def gather_results(local: torch.Tensor, n_total: int, rank: int, world: int) -> Optional[torch.Tensor]:
     """Gather per-segment rows ([n_local, ...]) to rank 0 in segment order.  Shards may differ
     by one row, so every rank pads to the largest shard for the collective."""

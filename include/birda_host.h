@@ -67,6 +67,15 @@ typedef struct {
 
 BH_API int bhh_process_file(bh_classifier *clf, const bhh_processing_config *cfg, bhh_process_result *res);
 
+/* ---- directory mode (coordinator.rs:146-190) ------------------------------------------ */
+/* is_audio_file (:179-190): extension in {wav, flac, mp3, m4a, aac}, ASCII case-insensitive. */
+BH_API int bhh_is_audio_file(const char *path);
+/* collect_input_files (:146-176): files are taken when they are audio files, directories are walked recursively, paths
+ * that do not exist are skipped.  Writes the '\n'-separated list into out (nul-terminated) and returns the byte count
+ * needed (call with cap = 0 to size the buffer), (size_t)-1 on an I/O error.  The reference keeps read_dir order, which
+ * is unspecified; entries of one directory come back sorted by name here so that runs are repeatable. */
+BH_API size_t bhh_collect_input_files(const char *const *paths, size_t n_paths, char *out, size_t cap, size_t *n_files);
+
 /* ---- range filter tables (geomodel.rs; pure host logic, once per run) ------------------ */
 /* scientific_name (geomodel.rs:28-33): length of the scientific-name prefix of a label. */
 BH_API size_t bhh_scientific_name_len(const char *label);

@@ -308,3 +308,39 @@ def test_species_mapping_and_projection_match_reference_cases_and_oracle(L, case
     assert np.array_equal(got, ref, equal_nan=True) and summary.mapped == mapped
     assert np.isnan(got[10]) and np.isnan(got[20]) and np.isnan(got[21])
     assert summary.in_range == int((ref >= np.float32(0.03)).sum()) and 0 < summary.mapped < 6522
+
+
+# ---------------- directory mode (coordinator.rs:146-190) ----------------
+def test_collect_input_files_walks_directories_like_the_reference(L, tmp_path):
+    from birda_amd import pipeline
+    root = tmp_path / "rec"
+    (root / "a" / "deep").mkdir(parents=True)
+    (root / "b").mkdir()
+    made = ["a/one.wav", "a/deep/two.FLAC", "b/three.Mp3", "b/four.m4a", "five.aac"]
+    for rel in made + ["a/notes.txt", "b/wav", "a/.wav", "b/clip.wav.bak", "six.ogg"]:
+        (root / rel).write_bytes(b"x")
+    single = tmp_path / "solo.WAV"; single.write_bytes(b"x")
+    other = tmp_path / "readme.md"; other.write_bytes(b"x")
+    got = pipeline.collect_input_files([str(root), str(single), str(other), str(tmp_path / "missing")])
+    assert sorted(got) == sorted([str(root / r) for r in made] + [str(single)])
+    assert got == pipeline.collect_input_files([str(root), str(single)])          # repeatable order
+    assert got[-1] == str(single)                                                  # argument order is kept (:149-160)
+    assert pipeline.collect_input_files([]) == [] and pipeline.collect_input_files([str(other)]) == []
+    for name, want in (("x.wav", 1), ("x.WaV", 1), ("x.flac", 1), ("x.mp3", 1), ("x.m4a", 1), ("x.aac", 1),
+                       ("x.ogg", 0), ("wav", 0), (".wav", 0), ("dir.wav/x", 0), ("x.wav.txt", 0)):
+        assert L.bhh_is_audio_file(name.encode()) == want, name
+
+
+def test_directory_mode_assignment_by_duration():
+    from birda_amd import sharding
+    rng = np.random.default_rng(3)
+    for world in (1, 2, 4, 8):
+        for n in (0, 1, 5, 40):
+            d = (rng.random(n) * 600 + 5).tolist()
+            parts = sharding.assign_by_duration(d, world)
+            assert len(parts) == world and sum(parts, []) == list(range(n))      # contiguous runs, file order kept
+            if n >= 8 * world:
+                loads = [sum(d[i] for i in p) for p in parts]
+                assert max(loads) - min(loads) <= 2 * max(d)
+    assert sharding.assign_by_duration([0.0, 0.0, 0.0, 0.0], 2) == [[0, 1], [2, 3]]
+    assert sharding.assign_by_duration([100.0, 1.0, 1.0, 100.0], 2) == [[0, 1], [2, 3]]

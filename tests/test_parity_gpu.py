@@ -641,3 +641,31 @@ def test_device_range_filter_matches_oracle_on_every_entry_point(clf_tiny, model
     with pytest.raises(Exception):
         clf_tiny.set_range_filter(table[:-1], 0.03)
     ctx.close()
+
+
+def test_directory_mode_two_ranks_cover_every_file_once(clf_tiny, model_dir, tmp_path):
+    """coordinator.rs:146-190 + SURVEY 8e directory mode: the walk finds the audio files, two ranks split them by
+    cumulative duration, each file is processed exactly once and gives the same CSV as a single-rank run."""
+    from birda_amd import pipeline, synth
+    _, _, m, _ = model_dir["birdnet_v24_tiny"]
+    rec = tmp_path / "recordings"; (rec / "night").mkdir(parents=True)
+    lengths = {"a.wav": 2, "night/b.WAV": 5, "night/c.wav": 1, "d.wav": 3}
+    for k, (rel, n) in enumerate(lengths.items()):
+        x = synth.synth_segments(n, m.sample_count, m.sample_rate, start=10 * k).reshape(-1)
+        synth.write_wav_pcm16(str(rec / rel), x, m.sample_rate)
+    (rec / "night" / "log.txt").write_text("not audio")
+    files = pipeline.collect_input_files([str(rec)])
+    assert sorted(files) == sorted(str(rec / r) for r in lengths)
+    single = tmp_path / "single"; single.mkdir()
+    ref = pipeline.process_files(clf_tiny, files, output_dir=str(single), min_confidence=0.05, batch_size=4)
+    assert [r.segments for r in ref] == [lengths[os.path.relpath(f, rec)] for f in files]
+    seen = []
+    for rank in range(2):
+        out = tmp_path / f"rank{rank}"; out.mkdir()
+        res = pipeline.process_files(clf_tiny, files, rank=rank, world=2, output_dir=str(out), min_confidence=0.05, batch_size=4)
+        assert res, "11 segments over two ranks: neither share is empty"
+        for r in res:
+            name = os.path.basename(r.output_path)
+            seen.append(name)
+            assert open(r.output_path, "rb").read() == open(single / name, "rb").read()
+    assert sorted(seen) == sorted(os.path.basename(r.output_path) for r in ref)
