@@ -59,7 +59,14 @@ def cpu_baseline(model_path, sample_count, sample_rate, hip_logits=None):
     t = time.perf_counter()
     om.forward(segs)
     dt = time.perf_counter() - t
-    return {"value": round(n / dt, 2), "unit": "segments/s", "cores": cores, "kind": "port",
+    # the true reference is ONNX Runtime (ORT_DYLIB_PATH, constants.rs:547) running the published birdnet.onnx.
+    ort, onnx = os.environ.get("ORT_DYLIB_PATH", ""), os.environ.get("BIRDA_REFERENCE_ONNX", "")
+    if ort and onnx and os.path.exists(ort) and os.path.exists(onnx):
+        ref_note = ("ONNX Runtime and a reference model are present on this box, but this build carries no ORT binding yet "
+                    "(DESIGN.md section 8, lead 4): compared against the CPU restatement")
+    else:
+        ref_note = "reference ORT path unavailable (no ORT_DYLIB_PATH / birdnet.onnx on this box): compared against the CPU restatement"
+    return {"value": round(n / dt, 2), "unit": "segments/s", "cores": cores, "kind": "port", "reference": ref_note,
             "sample": f"{n} synthetic 3 s/48 kHz segments, oracle/birda_oracle.c, OpenMP across segments "
                       f"({cores} threads), fp32, {dt:.1f} s",
             "max_abs_dlogit_vs_oracle": parity}

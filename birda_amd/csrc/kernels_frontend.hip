@@ -397,13 +397,15 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void mel_kernel(const float *
 }
 
 // ---------------------------------------------------------------------------------------
-// mel32 kernel (split-f16, FrontendParams::prec == 32): the same folded GEMM on v_mfma_f32_32x32x16_f16.
-// 32-frame tiles: 32 frames x 2 k-halves tile the 64 LDS banks exactly two deep (16 frames x 4 k-groups
-// at a stride of 278 / 280 samples hit them three deep, which bounded mel_kernel's main loop); the
-// 43-KB span lets three workgroups share a CU; a wave's store covers two 128-byte rows of the output.
-// K is split across the 4 waves as before; wave m owns MEL tile m (32 mels) in the epilogue.
-// Operator planes: [step of 16 k][mel tile of 32]{hi, lo}[64 lanes][8 halves], k = 16 s + 8 (lane >> 5) + jj,
-// mel = 32 mt + (lane & 31).
+// mel32 kernel (split-f16, FrontendParams::prec == 32): the same folded GEMM on v_mfma_f32_32x32x16_f16, for
+// front-ends whose hop collapses mel_kernel's frame-strided LDS reads onto a few banks (a hop of 320 samples puts
+// every frame of a fragment on ONE bank).  32-frame items; per wave and chunk of 64 k, phase A builds the folded
+// samples y with the LANES ALONG k (conflict-free for any hop) and parks them as split-f16 rows, phase B reads the
+// rows back as MFMA operands (see the comment in the main loop).  K is split across the 4 waves as in mel_kernel;
+// every wave parks its partials in LDS and wave m sums and stores MEL tile m (32 mels x 32 frames: two 128-byte
+// row pieces per store instruction).  The next item's span is fetched BEFORE the main loop.
+// Operator planes: [step of 16 k][mel tile of 32]{hi, lo}[64 lanes][8 halves]; element jj of step s holds
+// k = 64 (s / 4) + 8 (s % 4) + 4 (lane >> 5) + jj / 2 + 32 (jj % 2), mel = 32 mt + (lane & 31) (api.hip build_gf).
 // ---------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int MEL32_TN = 32;

@@ -669,3 +669,27 @@ def test_directory_mode_two_ranks_cover_every_file_once(clf_tiny, model_dir, tmp
             seen.append(name)
             assert open(r.output_path, "rb").read() == open(single / name, "rb").read()
     assert sorted(seen) == sorted(os.path.basename(r.output_path) for r in ref)
+
+
+def test_non_finite_samples_stay_in_their_own_rows(clf_tiny, model_dir):
+    """A corrupt decode (NaN / Inf samples) must not leak into the other rows of a batch, hang a kernel or produce
+    predictions from NaN logits: rows are independent (processor.rs:363-367)."""
+    from birda_amd import synth
+    _, _, m, _ = model_dir["birdnet_v24_tiny"]
+    segs = synth.synth_segments(6, m.sample_count, m.sample_rate, start=500)
+    ctx = clf_tiny.create_batch_context(6)
+    clean = clf_tiny.predict_logits(ctx, segs)
+    bad = segs.copy()
+    bad[1, 1000] = np.nan
+    bad[3, 77777] = np.inf
+    bad[4, 5] = -np.inf
+    got = clf_tiny.predict_logits(ctx, bad)
+    for i in (0, 2, 5):
+        assert np.array_equal(got[i], clean[i])
+    res = clf_tiny.predict_batch_with_context(ctx, list(bad))
+    ref = clf_tiny.predict_batch_with_context(ctx, list(segs))
+    for i in (0, 2, 5):
+        assert [(p.index, p.confidence) for p in res[i].predictions] == [(p.index, p.confidence) for p in ref[i].predictions]
+    for i in (1, 3, 4):
+        assert all(np.isfinite(p.confidence) for p in res[i].predictions)
+    ctx.close()
