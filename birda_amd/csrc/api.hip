@@ -1046,10 +1046,6 @@ int bh_forward_device(bh_classifier *c, bh_batch_context *ctx, const float *d_se
     if (rc != BH_OK) return rc;
     if (!d_segments || !d_logits) return fail(BH_ERR_INVALID, "forward_device: null device pointer");
     HIPCHK(hipSetDevice(c->device));
-    if (ctx->profiling) {
-        for (auto e : ctx->ev) (void)hipEventDestroy(e);
-        ctx->ev.clear(); ctx->ev_stage.clear(); ctx->ev_layer.clear();
-    }
     const auto &h = c->model.h;
     for (size_t b0 = 0; b0 < n; b0 += ctx->max_batch) {
         const size_t nb = std::min(ctx->max_batch, n - b0);
@@ -1120,6 +1116,11 @@ int bh_debug_mb_stamps(bh_classifier *c, uint64_t *out, size_t cap) {
 
 int bh_batch_context_set_profiling(bh_batch_context *ctx, int enabled) {
     if (!ctx) return fail(BH_ERR_INVALID, "set_profiling: null context");
+    if (enabled) {   // a new measurement: drop the events of the previous one (after they have fired)
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (auto e : ctx->ev) (void)hipEventDestroy(e);
+        ctx->ev.clear(); ctx->ev_stage.clear(); ctx->ev_layer.clear();
+    }
     ctx->profiling = enabled != 0;
     return BH_OK;
 }

@@ -176,7 +176,9 @@ BH_API int bh_debug_read_tensor(bh_classifier *c, bh_batch_context *ctx, uint32_
                                 float *host, size_t max_floats);
 BH_API uint64_t bh_tensor_floats(const bh_classifier *c, uint32_t tensor);
 
-/* Per-stage kernel timing of the last bh_forward_device call when profiling is enabled:
+/* Per-stage kernel timing, summed over every bh_forward_device call since profiling was last switched ON
+ * (set_profiling(ctx, 1) starts a new measurement; the events are recorded on the context stream around every
+ * launch and read here, after a stream synchronise: nothing inside a forward waits for them):
  * stage 0 = min/max, 1 = mel front-end, 2 = stem conv, 3 = depthwise, 4 = pointwise,
  * 5 = pool, 6 = dense, 7 = top-k, 8 = fused MBConv blocks (expand + depthwise + project in
  * one launch).  ms[] receives BH_N_STAGES floats (HIP-event times). */
@@ -184,9 +186,8 @@ BH_API uint64_t bh_tensor_floats(const bh_classifier *c, uint32_t tensor);
 BH_API int bh_batch_context_set_profiling(bh_batch_context *ctx, int enabled);
 BH_API int bh_batch_context_stage_ms(bh_batch_context *ctx, float *ms, uint32_t *launches);
 
-/* Per-launch timing of the last profiled bh_forward_device call, indexed by the layer a launch
- * starts at (a fused block is booked on its expand layer); slices of one forward are summed and
- * counted in launches[]. */
+/* Per-launch timing of the same measurement, indexed by the layer a launch starts at (a fused block is booked
+ * on its expand layer); every launch since set_profiling(ctx, 1) is summed and counted in launches[]. */
 BH_API int bh_batch_context_layer_ms(bh_batch_context *ctx, float *ms, uint32_t *launches, size_t n_layers);
 
 /* Number of expand -> depthwise -> project triples that run as one fused launch; cfgs
