@@ -233,11 +233,30 @@ def main():
     tk_idx = torch.empty((n_local, 5), dtype=torch.int32, device="cuda")
     tk_conf = torch.empty((n_local, 5), device="cuda")
 
+    # The result gather runs on torch's stream; the forward runs on the context's own HIP stream.  Order them with
+    # events (stream-to-stream, no host synchronise inside a step) when torch can wrap the context stream.
+    ctx_stream = None
+    if world > 1:
+        try:
+            ctx_stream = torch.cuda.ExternalStream(ctx.stream(), device=torch.device("cuda", local_rank))
+        except Exception:   # noqa: BLE001 -- fall back to a host synchronise per step
+            ctx_stream = None
+
     def step():
         clf.forward_device(ctx, x.data_ptr(), n_local, logits.data_ptr(), tk_idx.data_ptr(), tk_conf.data_ptr())
         if world > 1:
-            ctx.synchronize()
+            cur = torch.cuda.current_stream()
+            if ctx_stream is not None:
+                done = torch.cuda.Event()
+                done.record(ctx_stream)
+                cur.wait_event(done)                      # the gather's inputs are complete
+            else:
+                ctx.synchronize()
             packed = torch.cat([tk_idx.to(torch.float32), tk_conf], 1)
+            if ctx_stream is not None:
+                read = torch.cuda.Event()
+                read.record(cur)
+                ctx_stream.wait_event(read)               # the next forward's top-k must not overwrite them earlier
             sharding.gather_results(packed.cpu() if dryrun else packed, n_total, rank, world)
 
     def sync_all():
