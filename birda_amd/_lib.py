@@ -2,6 +2,10 @@
 
 Fails loudly when the HIP library is missing: there is no CPU fallback anywhere in the
 product path.
+
+Sharing a process with PyTorch (bench.py, the tests): the PyTorch ROCm wheel carries its own copy of the HIP / HSA
+runtime, and the copy that is mapped first serves both.  PyTorch finds no GPU when that is not its own, so import
+torch BEFORE the first classifier is created; the library itself is indifferent to which copy it runs on.
 """
 from __future__ import annotations
 

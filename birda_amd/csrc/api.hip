@@ -1375,7 +1375,8 @@ int bh_resample_device(bh_classifier *c, bh_batch_context *ctx, const float *d_i
     const char *err = nullptr;
     const bh::ResamplePlan *pl = bh::resample_plan(from_rate, to_rate, &err);
     if (!pl) return fail(BH_ERR_UNSUPPORTED, "%s (%u -> %u Hz)", err ? err : "resampler", from_rate, to_rate);
-    bh::launch_resample(*pl, d_in, in_stride, (int)src_len, d_out, out_stride, (int)out_len, (int)n_seg, ctx->stream);
+    bh::launch_resample(*pl, d_in, in_stride, (int)src_len, d_out, out_stride, (int)out_len, (int)n_seg,
+                        c->precision != 0 && !(getenv("BIRDA_HIP_RESAMPLE_F32") && getenv("BIRDA_HIP_RESAMPLE_F32")[0] == '1'), ctx->stream);
     HIPCHK(hipGetLastError());
     return BH_OK;
 }

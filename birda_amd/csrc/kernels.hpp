@@ -209,6 +209,7 @@ struct ResamplePlan {
     uint32_t from, to;
     int hop, N, nblk, K, dmin;  // y[N m + p] = sum_{k < K} x[hop m + dmin + k] G[k][p]
     const float *d_op;          // device, fragment-major [nblk][K/16][10][64][4]
+    const void *d_op16;         // the same operator as f16 hi / lo planes [nblk][K/32][10]{hi, lo}[64 lanes][8 halves], k = 32 s + 8 (lane >> 4) + j
 };
 void resample_sizes(uint32_t from, uint32_t to, int *fft_in, int *fft_out);
 size_t resample_output_len(size_t n, uint32_t from, uint32_t to);  // rubato's output length for n inputs
@@ -216,8 +217,9 @@ const ResamplePlan *resample_plan(uint32_t from, uint32_t to, const char **err);
 // d_in [n_seg][in_stride] (src_len valid samples each) -> d_out [n_seg][out_stride]: the first
 // min(out_len, rubato length) samples are the resampled signal, the rest up to out_len zeros
 // (`samples.resize(segment_samples, 0.0)`, reference src/pipeline/processor.rs:87)
+// split_f16: the GEMM on the split-f16 MFMA (three v_mfma_f32_16x16x32_f16 per product, f32-grade sums) instead of the f32 MFMA
 void launch_resample(const ResamplePlan &pl, const float *d_in, size_t in_stride, int src_len, float *d_out,
-                     size_t out_stride, int out_len, int n_seg, hipStream_t s);
+                     size_t out_stride, int out_len, int n_seg, bool split_f16, hipStream_t s);
 
 // Fused MBConv block (kernels_mbconv.hip): expand 1x1 -> depthwise -> project 1x1 (+ residual).
 struct MbDesc {

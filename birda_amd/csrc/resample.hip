@@ -167,6 +167,27 @@ const ResamplePlan *resample_plan(uint32_t from, uint32_t to, const char **err) 
         return nullptr;
     }
     pl.d_op = dptr;
+    // the same operator pre-split into f16 hi + lo planes for the split-f16 kernel (32-deep steps)
+    std::vector<_Float16> frag16((size_t)pl.nblk * pl.K * 160 * 2);
+    for (int cb = 0; cb < pl.nblk; cb++)
+        for (int st = 0; st < pl.K / 32; st++)
+            for (int mt = 0; mt < 10; mt++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int j = 0; j < 8; j++) {
+                        const int k = 32 * st + 8 * (lane >> 4) + j, p = cb * 160 + 16 * mt + (lane & 15);
+                        const float v = (float)tap(p, dmin + k);
+                        const _Float16 hi = (_Float16)v;
+                        const size_t base = ((((size_t)cb * (pl.K / 32) + st) * 10 + mt) * 2) * 64 * 8;
+                        frag16[base + (size_t)lane * 8 + j] = hi;
+                        frag16[base + 64 * 8 + (size_t)lane * 8 + j] = (_Float16)(v - (float)hi);
+                    }
+    void *dptr16 = nullptr;
+    if (hipMalloc(&dptr16, frag16.size() * sizeof(_Float16)) != hipSuccess ||
+        hipMemcpy(dptr16, frag16.data(), frag16.size() * sizeof(_Float16), hipMemcpyHostToDevice) != hipSuccess) {
+        *err = "resampler: device upload failed";
+        return nullptr;
+    }
+    pl.d_op16 = dptr16;
     return &g_plans.emplace(key, pl).first->second;
 }
 
@@ -283,8 +304,133 @@ __global__ __launch_bounds__(256) void resample_kernel(const float *__restrict__
     }
 }
 
+// The same kernel on the split-f16 MFMA (classifier precision f16x3 / f16): the operator arrives as f16 hi / lo planes,
+// the input samples are split in registers (8 consecutive k per lane and 32-deep step), three
+// v_mfma_f32_16x16x32_f16 per product (hi*hi + hi*lo + lo*hi, f32 accumulate): the f32 MFMA runs at the vector rate
+// (157 TFLOP/s), this one at 2.5 PFLOP/s / 3.  Same staging, K split, reduction and stores as above.
+typedef _Float16 rs_f16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(256) void resample16_kernel(const float *__restrict__ in, size_t in_stride, int src_len,
+                                                         float *__restrict__ out, size_t out_stride, int out_len,
+                                                         int n_valid, const rs_f16x8 *__restrict__ op, int hop, int N,
+                                                         int K, int dmin) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int seg = blockIdx.z, cb = blockIdx.y, t0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const float *xseg = in + (size_t)seg * in_stride;
+    const int span = 63 * hop + K;
+    const int g0 = t0 * hop + dmin;
+    for (int i0 = tid; i0 < span; i0 += 256 * 8) {   // 8 independent loads in flight per thread
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int gi = g0 + i0 + u * 256;
+            v[u] = (i0 + u * 256 < span && gi >= 0 && gi < src_len) ? xseg[gi] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if (i0 + u * 256 < span) smem[i0 + u * 256] = v[u];
+    }
+    __syncthreads();
+
+    f32x4 acc[4][RS_MT];
+#pragma unroll
+    for (int f = 0; f < 4; f++)
+#pragma unroll
+        for (int m = 0; m < RS_MT; m++) acc[f][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int spw = K / 128, sbeg = wave * spw;   // 32-deep steps per wave (K % 128 == 0)
+    const rs_f16x8 *gA = op + (size_t)cb * (K / 32) * RS_MT * 2 * 64 + lane;
+    rs_f16x8 a0h[RS_MT], a0l[RS_MT], a1h[RS_MT], a1l[RS_MT];
+    auto load = [&](int st, rs_f16x8 (&ah)[RS_MT], rs_f16x8 (&al)[RS_MT]) {
+#pragma unroll
+        for (int m = 0; m < RS_MT; m++) {
+            ah[m] = gA[(((size_t)st * RS_MT + m) * 2 + 0) * 64];
+            al[m] = gA[(((size_t)st * RS_MT + m) * 2 + 1) * 64];
+        }
+    };
+    const float *xf = smem + li * hop;
+    auto step = [&](int st, const rs_f16x8 (&ah)[RS_MT], const rs_f16x8 (&al)[RS_MT]) {
+        const int j0 = st * 32 + 8 * kq;
+        bh_f16x8 bh[4], bl[4];
+#pragma unroll
+        for (int f = 0; f < 4; f++) {
+            float y[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) y[jj] = xf[f * 16 * hop + j0 + jj];
+            bh_split8(y, bh[f], bl[f]);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // the split stays out of the MFMA sequence (see mel_kernel)
+#pragma unroll
+        for (int m = 0; m < RS_MT; m++)
+#pragma unroll
+            for (int f = 0; f < 4; f++) {
+                acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh[f], acc[f][m], 0, 0, 0);
+                acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl[f], acc[f][m], 0, 0, 0);
+                acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh[f], acc[f][m], 0, 0, 0);
+            }
+    };
+    // the last one or two steps are peeled: no conditional load inside the loop (see mel_kernel)
+    load(sbeg, a0h, a0l);
+    {
+        int si = 0;
+        for (; si + 2 < spw; si += 2) {
+            load(sbeg + si + 1, a1h, a1l);
+            __builtin_amdgcn_sched_barrier(0);
+            step(sbeg + si, a0h, a0l);
+            __builtin_amdgcn_sched_barrier(0);
+            load(sbeg + si + 2, a0h, a0l);
+            __builtin_amdgcn_sched_barrier(0);
+            step(sbeg + si + 1, a1h, a1l);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (si + 1 < spw) {
+            load(sbeg + si + 1, a1h, a1l);
+            __builtin_amdgcn_sched_barrier(0);
+            step(sbeg + si, a0h, a0l);
+            __builtin_amdgcn_sched_barrier(0);
+            step(sbeg + si + 1, a1h, a1l);
+        } else {
+            step(sbeg + si, a0h, a0l);
+        }
+    }
+
+    __syncthreads();  // every wave is done reading the span
+    float4 *red = reinterpret_cast<float4 *>(smem);
+#pragma unroll
+    for (int f = 0; f < 4; f++) {
+        if (f == wave) continue;
+        const int slot = f - (f > wave ? 1 : 0);
+#pragma unroll
+        for (int m = 0; m < RS_MT; m++)
+            red[((wave * 3 + slot) * RS_MT + m) * 64 + lane] = make_float4(acc[f][m][0], acc[f][m][1], acc[f][m][2], acc[f][m][3]);
+    }
+    __syncthreads();
+    const int t = t0 + wave * 16 + li;
+    float *oseg = out + (size_t)seg * out_stride;
+#pragma unroll
+    for (int m = 0; m < RS_MT; m++) {
+        f32x4 v = wave == 0 ? acc[0][m] : wave == 1 ? acc[1][m] : wave == 2 ? acc[2][m] : acc[3][m];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            if (s == wave) continue;
+            const int slot = wave - (wave > s ? 1 : 0);
+            const float4 q = red[((s * 3 + slot) * RS_MT + m) * 64 + lane];
+            v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+        }
+        const long o = (long)t * N + cb * 160 + m * 16 + kq * 4;  // 4 consecutive output samples
+        if (o + 3 < out_len && o + 3 < n_valid) {
+            *reinterpret_cast<float4 *>(oseg + o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (o + r < out_len) oseg[o + r] = (o + r < n_valid) ? v[r] : 0.0f;  // resize(.., 0.0) pads
+        }
+    }
+}
+
 void launch_resample(const ResamplePlan &pl, const float *d_in, size_t in_stride, int src_len, float *d_out,
-                     size_t out_stride, int out_len, int n_seg, hipStream_t s) {
+                     size_t out_stride, int out_len, int n_seg, bool split_f16, hipStream_t s) {
     const int n_valid = (int)std::min<size_t>((size_t)out_len, resample_output_len((size_t)src_len, pl.from, pl.to));
     const int frames = (out_len + pl.N - 1) / pl.N;
     const size_t span_bytes = ((size_t)63 * pl.hop + pl.K) * sizeof(float);
@@ -296,6 +442,16 @@ void launch_resample(const ResamplePlan &pl, const float *d_in, size_t in_stride
         attr_set = true;
     }
     dim3 grid((frames + 63) / 64, pl.nblk, n_seg), block(256);
+    if (split_f16) {
+        static bool attr16_set = false;
+        if (!attr16_set) {
+            (void)hipFuncSetAttribute((const void *)resample16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr16_set = true;
+        }
+        hipLaunchKernelGGL(resample16_kernel, grid, block, smem, s, d_in, in_stride, src_len, d_out, out_stride, out_len,
+                           n_valid, (const rs_f16x8 *)pl.d_op16, pl.hop, pl.N, pl.K, pl.dmin);
+        return;
+    }
     hipLaunchKernelGGL(resample_kernel, grid, block, smem, s, d_in, in_stride, src_len, d_out, out_stride, out_len,
                        n_valid, pl.d_op, pl.hop, pl.N, pl.K, pl.dmin);
 }

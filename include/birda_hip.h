@@ -195,7 +195,7 @@ BH_API int bh_batch_context_layer_ms(bh_batch_context *ctx, float *ms, uint32_t 
  * create): BIRDA_HIP_FUSE=0 disables fusion, BIRDA_HIP_MB_CFG=<i> forces configuration i where it is
  * valid, BIRDA_HIP_MB_PREFER=<i,j,...> tries those first, BIRDA_HIP_HEAD_GAP=0 keeps the head conv and
  * the global average pool as two launches, BIRDA_HIP_STEM_F32=1 keeps the stem block on the f32 MFMA in
- * f16x3 mode, BIRDA_HIP_MEL_F32=1 the front-end; BIRDA_HIP_MEL32=0/1 forces the 16-frame-fragment /
+ * f16x3 mode, BIRDA_HIP_MEL_F32=1 the front-end, BIRDA_HIP_RESAMPLE_F32=1 the resampler; BIRDA_HIP_MEL32=0/1 forces the 16-frame-fragment /
  * 32-frame-fragment front-end kernel (default: by hop).  BIRDA_HIP_COPY_THREADS=<n> (default min(8, hardware
  * threads / 2)) sets the host threads that gather the caller's segments into pinned memory in the
  * bh_predict_batch* entry points. */

@@ -22,11 +22,12 @@ RESAMPLE_ATOL = 2e-5
 PAIRS = [(44100, 48000), (22050, 48000), (48000, 32000), (44100, 32000)]
 
 
-@pytest.fixture(scope="module")
-def clf(model_dir):
+@pytest.fixture(scope="module", params=["f32", "f16x3"])
+def clf(model_dir, request):
+    """f32: the resampler GEMM on the f32 MFMA; f16x3: on the split-f16 MFMA (resample16_kernel).  Same tolerance."""
     from birda_amd.classifier import BirdClassifier
     path, labels, m, _ = model_dir["mini"]
-    c = BirdClassifier(path, labels)
+    c = BirdClassifier(path, labels, precision=request.param)
     yield c
     c.close()
 
