@@ -209,7 +209,7 @@ struct ResamplePlan {
     uint32_t from, to;
     int hop, N, nblk, K, dmin;  // y[N m + p] = sum_{k < K} x[hop m + dmin + k] G[k][p]
     const float *d_op;          // device, fragment-major [nblk][K/16][10][64][4]
-    const void *d_op16;         // the same operator as f16 hi / lo planes [nblk][K/32][10]{hi, lo}[64 lanes][8 halves], k = 32 s + 8 (lane >> 4) + j
+    const void *d_op16;         // the same operator as f16 hi / lo planes [2 nblk (80 phases each)][K/32][5]{hi, lo}[64 lanes][8 halves], k = 32 s + 8 (lane >> 4) + j
 };
 void resample_sizes(uint32_t from, uint32_t to, int *fft_in, int *fft_out);
 size_t resample_output_len(size_t n, uint32_t from, uint32_t to);  // rubato's output length for n inputs

@@ -169,15 +169,15 @@ const ResamplePlan *resample_plan(uint32_t from, uint32_t to, const char **err) 
     pl.d_op = dptr;
     // the same operator pre-split into f16 hi + lo planes for the split-f16 kernel (32-deep steps)
     std::vector<_Float16> frag16((size_t)pl.nblk * pl.K * 160 * 2);
-    for (int cb = 0; cb < pl.nblk; cb++)
+    for (int cb = 0; cb < 2 * pl.nblk; cb++)   // column blocks of 80 phases (5 tiles) for this kernel
         for (int st = 0; st < pl.K / 32; st++)
-            for (int mt = 0; mt < 10; mt++)
+            for (int mt = 0; mt < 5; mt++)
                 for (int lane = 0; lane < 64; lane++)
                     for (int j = 0; j < 8; j++) {
-                        const int k = 32 * st + 8 * (lane >> 4) + j, p = cb * 160 + 16 * mt + (lane & 15);
+                        const int k = 32 * st + 8 * (lane >> 4) + j, p = cb * 80 + 16 * mt + (lane & 15);
                         const float v = (float)tap(p, dmin + k);
                         const _Float16 hi = (_Float16)v;
-                        const size_t base = ((((size_t)cb * (pl.K / 32) + st) * 10 + mt) * 2) * 64 * 8;
+                        const size_t base = ((((size_t)cb * (pl.K / 32) + st) * 5 + mt) * 2) * 64 * 8;
                         frag16[base + (size_t)lane * 8 + j] = hi;
                         frag16[base + 64 * 8 + (size_t)lane * 8 + j] = (_Float16)(v - (float)hi);
                     }
@@ -309,7 +309,8 @@ __global__ __launch_bounds__(256) void resample_kernel(const float *__restrict__
 // v_mfma_f32_16x16x32_f16 per product (hi*hi + hi*lo + lo*hi, f32 accumulate): the f32 MFMA runs at the vector rate
 // (157 TFLOP/s), this one at 2.5 PFLOP/s / 3.  Same staging, K split, reduction and stores as above.
 typedef _Float16 rs_f16x8 __attribute__((ext_vector_type(8)));
-__global__ __launch_bounds__(256) void resample16_kernel(const float *__restrict__ in, size_t in_stride, int src_len,
+constexpr int RS16_MT = 5;   // column blocks of 80 phases: 80 accumulator + 80 operator registers, two workgroups per CU
+__global__ __launch_bounds__(256, 2) void resample16_kernel(const float *__restrict__ in, size_t in_stride, int src_len,
                                                          float *__restrict__ out, size_t out_stride, int out_len,
                                                          int n_valid, const rs_f16x8 *__restrict__ op, int hop, int N,
                                                          int K, int dmin) {
@@ -333,24 +334,24 @@ __global__ __launch_bounds__(256) void resample16_kernel(const float *__restrict
     }
     __syncthreads();
 
-    f32x4 acc[4][RS_MT];
+    f32x4 acc[4][RS16_MT];
 #pragma unroll
     for (int f = 0; f < 4; f++)
 #pragma unroll
-        for (int m = 0; m < RS_MT; m++) acc[f][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < RS16_MT; m++) acc[f][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int spw = K / 128, sbeg = wave * spw;   // 32-deep steps per wave (K % 128 == 0)
-    const rs_f16x8 *gA = op + (size_t)cb * (K / 32) * RS_MT * 2 * 64 + lane;
-    rs_f16x8 a0h[RS_MT], a0l[RS_MT], a1h[RS_MT], a1l[RS_MT];
-    auto load = [&](int st, rs_f16x8 (&ah)[RS_MT], rs_f16x8 (&al)[RS_MT]) {
+    const rs_f16x8 *gA = op + (size_t)cb * (K / 32) * RS16_MT * 2 * 64 + lane;
+    rs_f16x8 a0h[RS16_MT], a0l[RS16_MT], a1h[RS16_MT], a1l[RS16_MT];
+    auto load = [&](int st, rs_f16x8 (&ah)[RS16_MT], rs_f16x8 (&al)[RS16_MT]) {
 #pragma unroll
-        for (int m = 0; m < RS_MT; m++) {
-            ah[m] = gA[(((size_t)st * RS_MT + m) * 2 + 0) * 64];
-            al[m] = gA[(((size_t)st * RS_MT + m) * 2 + 1) * 64];
+        for (int m = 0; m < RS16_MT; m++) {
+            ah[m] = gA[(((size_t)st * RS16_MT + m) * 2 + 0) * 64];
+            al[m] = gA[(((size_t)st * RS16_MT + m) * 2 + 1) * 64];
         }
     };
     const float *xf = smem + li * hop;
-    auto step = [&](int st, const rs_f16x8 (&ah)[RS_MT], const rs_f16x8 (&al)[RS_MT]) {
+    auto step = [&](int st, const rs_f16x8 (&ah)[RS16_MT], const rs_f16x8 (&al)[RS16_MT]) {
         const int j0 = st * 32 + 8 * kq;
         bh_f16x8 bh[4], bl[4];
 #pragma unroll
@@ -362,7 +363,7 @@ __global__ __launch_bounds__(256) void resample16_kernel(const float *__restrict
         }
         __builtin_amdgcn_sched_barrier(0);   // the split stays out of the MFMA sequence (see mel_kernel)
 #pragma unroll
-        for (int m = 0; m < RS_MT; m++)
+        for (int m = 0; m < RS16_MT; m++)
 #pragma unroll
             for (int f = 0; f < 4; f++) {
                 acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh[f], acc[f][m], 0, 0, 0);
@@ -402,23 +403,23 @@ __global__ __launch_bounds__(256) void resample16_kernel(const float *__restrict
         if (f == wave) continue;
         const int slot = f - (f > wave ? 1 : 0);
 #pragma unroll
-        for (int m = 0; m < RS_MT; m++)
-            red[((wave * 3 + slot) * RS_MT + m) * 64 + lane] = make_float4(acc[f][m][0], acc[f][m][1], acc[f][m][2], acc[f][m][3]);
+        for (int m = 0; m < RS16_MT; m++)
+            red[((wave * 3 + slot) * RS16_MT + m) * 64 + lane] = make_float4(acc[f][m][0], acc[f][m][1], acc[f][m][2], acc[f][m][3]);
     }
     __syncthreads();
     const int t = t0 + wave * 16 + li;
     float *oseg = out + (size_t)seg * out_stride;
 #pragma unroll
-    for (int m = 0; m < RS_MT; m++) {
+    for (int m = 0; m < RS16_MT; m++) {
         f32x4 v = wave == 0 ? acc[0][m] : wave == 1 ? acc[1][m] : wave == 2 ? acc[2][m] : acc[3][m];
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             if (s == wave) continue;
             const int slot = wave - (wave > s ? 1 : 0);
-            const float4 q = red[((s * 3 + slot) * RS_MT + m) * 64 + lane];
+            const float4 q = red[((s * 3 + slot) * RS16_MT + m) * 64 + lane];
             v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
         }
-        const long o = (long)t * N + cb * 160 + m * 16 + kq * 4;  // 4 consecutive output samples
+        const long o = (long)t * N + cb * 80 + m * 16 + kq * 4;  // 4 consecutive output samples
         if (o + 3 < out_len && o + 3 < n_valid) {
             *reinterpret_cast<float4 *>(oseg + o) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
@@ -448,7 +449,9 @@ void launch_resample(const ResamplePlan &pl, const float *d_in, size_t in_stride
             (void)hipFuncSetAttribute((const void *)resample16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr16_set = true;
         }
-        hipLaunchKernelGGL(resample16_kernel, grid, block, smem, s, d_in, in_stride, src_len, d_out, out_stride, out_len,
+        const size_t smem16 = std::max(span_bytes, (size_t)4 * 3 * RS16_MT * 64 * sizeof(float4));
+        dim3 grid16((frames + 63) / 64, 2 * pl.nblk, n_seg);
+        hipLaunchKernelGGL(resample16_kernel, grid16, block, smem16, s, d_in, in_stride, src_len, d_out, out_stride, out_len,
                            n_valid, (const rs_f16x8 *)pl.d_op16, pl.hop, pl.N, pl.K, pl.dmin);
         return;
     }
