@@ -153,18 +153,11 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
 
     MbClock t_last{};
     if (d.stamps) t_last.last = __builtin_readcyclecounter();
-    // PERSIST (the early, many-tile blocks: OCC >= 3, split-f16): the workgroup walks the tiles
-    // (x fastest, then y, then segment group) with stride gridDim.x instead of owning one
-    constexpr bool PERSIST = PREC == 3 && OCC >= 3;
-    const int tiles_xy = d.tiles_x * d.tiles_y;
-    const int n_tl = PERSIST ? tiles_xy * ((n_seg + SS - 1) / SS) : 1;
-    for (int tl = PERSIST ? (int)blockIdx.x : 0; tl < n_tl; tl += PERSIST ? (int)gridDim.x : 1) {
     mb_dma<WE_FLOATS>(d.We, WeS, wave, lane);
     mb_dma<WD_FLOATS>(d.Wd, Wds, wave, lane);
 
-    const int tz = PERSIST ? tl / tiles_xy : (int)blockIdx.z, txy = tl - tz * tiles_xy;
-    const int tyi = PERSIST ? txy / d.tiles_x : (int)blockIdx.y, txi = PERSIST ? txy - tyi * d.tiles_x : (int)blockIdx.x;
-    const int seg0 = tz * SS;
+    const int tyi = blockIdx.y, txi = blockIdx.x;
+    const int seg0 = blockIdx.z * SS;
     const int nsv = min(SS, n_seg - seg0);
     const int oy0 = tyi * TH, ox0 = txi * TW;
     const int iy0 = oy0 * ST - d.pad_t, ix0 = ox0 * ST - d.pad_l;
@@ -571,8 +564,6 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
         }
     }
     mb_stamp(d.stamps, t_last, 7);
-    if constexpr (PERSIST) __syncthreads();   // the next tile's set-up rewrites omap, the weight buffers and the grid
-    }   // tiles
     if (d.stamps && lane == 0)
         for (int i = 0; i < 8; i++) atomicAdd(&d.stamps[i], t_last.acc[i]);
 }
@@ -592,28 +583,6 @@ void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
         attr_set = true;
     }
     dim3 grid(d.tiles_x, d.tiles_y, (n_seg + d.S - 1) / d.S), block(256);
-    if (PREC == 3 && OCC >= 3) {   // persistent instantiations: as many workgroups as are resident at once
-        static int n_cu = 0;
-        if (!n_cu) {
-            int dev = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-                n_cu = 256;
-        }
-        static int occ = 0;
-        static size_t occ_lds = 0;
-        if (!occ || occ_lds != d.lds_bytes) {   // what the hardware really co-schedules (registers, LDS granules)
-            int nb = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, 256, d.lds_bytes) != hipSuccess || nb <= 0) {
-                (void)hipGetLastError();
-                nb = (int)std::max<size_t>(1, std::min<size_t>(OCC, (160 * 1024) / std::max<size_t>(d.lds_bytes, 1)));
-            }
-            occ = nb; occ_lds = d.lds_bytes;
-            if (getenv("BIRDA_HIP_MB_VERBOSE")) fprintf(stderr, "mbconv persistent: %d workgroups per CU (LDS %zu B)\n", occ, d.lds_bytes);
-        }
-        const size_t per_cu = (size_t)occ;
-        const size_t total = (size_t)grid.x * grid.y * grid.z;
-        grid = dim3((unsigned)std::min(total, per_cu * (size_t)n_cu), 1, 1);
-    }
     hipLaunchKernelGGL(kern, grid, block, d.lds_bytes, s, d, n_seg);
 }
 
