@@ -28,7 +28,15 @@ class BhModelInfo(C.Structure):
     _fields_ = [("sample_rate", C.c_uint32), ("segment_duration", C.c_float), ("sample_count", C.c_uint32),
                 ("n_classes", C.c_uint32), ("embedding_dim", C.c_uint32), ("output_activation", C.c_uint32),
                 ("spec_channels", C.c_uint32), ("spec_h", C.c_uint32), ("spec_w", C.c_uint32),
-                ("n_layers", C.c_uint32), ("macs_per_segment", C.c_uint64), ("mel_flops_per_segment", C.c_uint64)]
+                ("n_layers", C.c_uint32), ("macs_per_segment", C.c_uint64), ("mel_flops_per_segment", C.c_uint64),
+                ("model_type", C.c_uint32), ("precision", C.c_uint32)]
+
+
+class BhProviderStatus(C.Structure):
+    """ExecutionProviderStatus (classifier.rs:23-30) + device facts."""
+    _fields_ = [("requested", C.c_char * 32), ("actual", C.c_char * 32), ("fallback_reason", C.c_char * 256),
+                ("device", C.c_int32), ("device_count", C.c_uint32), ("device_name", C.c_char * 128),
+                ("arch", C.c_char * 32), ("compute_units", C.c_uint32), ("hbm_bytes", C.c_uint64)]
 
 
 class BhResult(C.Structure):
@@ -41,6 +49,10 @@ SYMBOLS = [
     ("bh_device_count", C.c_int, []),
     ("bh_backend_name", C.c_char_p, []),
     ("bh_last_error", C.c_char_p, []),
+    ("bh_select_provider", C.c_int, [C.c_char_p, C.c_int32, C.POINTER(BhProviderStatus)]),
+    ("bh_classifier_provider_status", C.c_int, [_VP, C.POINTER(BhProviderStatus)]),
+    ("bh_default_batch_size", _SZ, [C.c_uint32, C.c_char_p]),
+    ("bh_classifier_default_batch_size", _SZ, [_VP]),
     ("bh_classifier_create", C.c_int, [C.POINTER(BhConfig), C.POINTER(_VP)]),
     ("bh_classifier_destroy", None, [_VP]),
     ("bh_classifier_info", C.c_int, [_VP, C.POINTER(BhModelInfo)]),
@@ -81,17 +93,37 @@ SYMBOLS = [
 ]
 
 
+FORMATS = {"csv": 1, "raven": 2, "table": 2, "audacity": 4, "kaleidoscope": 8, "json": 16, "parquet": 32}   # OutputFormat::from_str
+FRONT_ENDS = {"auto": 0, "host": 1, "device": 2}
+REPORT_NDJSON, REPORT_JSON = 1, 2
+FLOAT_DISPLAY_F32, FLOAT_DISPLAY_F64, FLOAT_JSON_F32, FLOAT_JSON_F64 = 0, 1, 2, 3
+
+
+class BhhWriterOptions(C.Structure):
+    _fields_ = [("csv_bom", C.c_int), ("csv_columns", C.c_char_p), ("source_file", C.c_char_p), ("model", C.c_char_p),
+                ("min_confidence", C.c_float), ("overlap", C.c_float), ("audio_duration", C.c_float),
+                ("has_lat", C.c_int), ("has_lon", C.c_int), ("lat", C.c_double), ("lon", C.c_double), ("week", C.c_int)]
+
+
+class BhhRangeFilterInfo(C.Structure):
+    _fields_ = [("geomodel_version", C.c_char_p), ("species_in_range", C.c_size_t), ("total_species", C.c_size_t),
+                ("mapped_species", C.c_size_t), ("unmatched_species", C.c_size_t), ("unmatched_policy", C.c_char_p),
+                ("threshold", C.c_float)]
+
+
 class BhhProcessingConfig(C.Structure):
     _fields_ = [("input_path", C.c_char_p), ("output_dir", C.c_char_p), ("display_path", C.c_char_p),
                 ("min_confidence", C.c_float), ("overlap", C.c_float), ("batch_size", C.c_size_t),
-                ("csv_bom", C.c_int)]
+                ("csv_bom", C.c_int), ("formats", C.c_uint32), ("front_end", C.c_uint32), ("csv_columns", C.c_char_p),
+                ("model_name", C.c_char_p), ("has_lat", C.c_int), ("has_lon", C.c_int), ("lat", C.c_double),
+                ("lon", C.c_double), ("week", C.c_int), ("reporter", C.c_void_p), ("dual_output", C.c_int)]
 
 
 class BhhProcessResult(C.Structure):
     _fields_ = [("detections", C.c_size_t), ("segments", C.c_size_t), ("duration_secs", C.c_double),
                 ("audio_duration_secs", C.c_double), ("segments_per_sec", C.c_double),
                 ("effective_batch", C.c_size_t), ("batches", C.c_size_t), ("padded_rows", C.c_size_t),
-                ("output_path", C.c_char * 1024)]
+                ("output_path", C.c_char * 1024), ("front_end", C.c_uint32), ("formats_written", C.c_uint32)]
 
 
 # every symbol include/birda_host.h declares
@@ -112,6 +144,24 @@ HOST_SYMBOLS = [
     ("bhh_csv_header", _SZ, [C.c_int, C.c_char_p, _SZ]),
     ("bhh_csv_row", _SZ, [C.c_char_p, C.c_float, C.c_float, C.c_float, C.c_char_p, C.c_char_p, _SZ]),
     ("bhh_process_file", C.c_int, [_VP, C.POINTER(BhhProcessingConfig), C.POINTER(BhhProcessResult)]),
+    ("bhh_writer_open", C.c_int, [C.c_uint32, C.c_char_p, C.POINTER(BhhWriterOptions), C.POINTER(_VP)]),
+    ("bhh_writer_write_header", C.c_int, [_VP]),
+    ("bhh_writer_write_detection", C.c_int, [_VP, C.c_char_p, C.c_float, C.c_float, C.c_float, C.c_char_p]),
+    ("bhh_writer_finalize", C.c_int, [_VP]),
+    ("bhh_output_path_for", _SZ, [C.c_char_p, C.c_char_p, C.c_uint32, C.c_char_p, _SZ]),
+    ("bhh_species_code", _SZ, [C.c_char_p, C.c_char_p, _SZ]),
+    ("bhh_format_float", _SZ, [C.c_int, C.c_double, C.c_char_p, _SZ]),
+    ("bhh_reporter_open", C.c_int, [C.c_int, C.c_char_p, C.POINTER(_VP)]),
+    ("bhh_reporter_close", None, [_VP]),
+    ("bhh_reporter_pipeline_started", None, [_VP, _SZ, C.c_char_p, C.c_float, C.c_char_p, C.c_char_p, C.c_char_p,
+                                             C.POINTER(BhhRangeFilterInfo)]),
+    ("bhh_reporter_file_started", None, [_VP, C.c_char_p, _SZ, _SZ, C.c_int, C.c_double]),
+    ("bhh_reporter_file_progress", C.c_int, [_VP, C.c_char_p, _SZ, _SZ, C.c_float]),
+    ("bhh_reporter_batch_progress", None, [_VP, _SZ, _SZ, C.c_float]),
+    ("bhh_reporter_file_completed", None, [_VP, C.c_char_p, C.c_int, _SZ, C.c_uint64, C.c_char_p, C.c_char_p]),
+    ("bhh_reporter_detections", None, [_VP, C.c_char_p, _VP, _VP, _VP, _VP, _SZ]),
+    ("bhh_reporter_pipeline_completed", None, [_VP, _SZ, _SZ, _SZ, _SZ, _SZ, C.c_uint64, C.c_double]),
+    ("bhh_reporter_error", None, [_VP, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p]),
     ("bhh_is_audio_file", C.c_int, [C.c_char_p]),
     ("bhh_collect_input_files", _SZ, [_VP, _SZ, C.c_char_p, _SZ, C.POINTER(_SZ)]),
     ("bhh_scientific_name_len", _SZ, [C.c_char_p]),

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <set>
 #include <string>
 #include <thread>
@@ -35,6 +36,15 @@ int fail(int code, const char *fmt, ...) {
     va_end(ap);
     g_err = buf;
     return code;
+}
+
+// Called from the catch (...) of every extern "C" entry point: no C++ exception (bad_alloc from a vector sized by the
+// caller, system_error from std::thread) may cross the C ABI.
+int on_exception() noexcept {
+    try { throw; }
+    catch (const std::bad_alloc &) { return fail(BH_ERR_INTERNAL, "out of host memory"); }
+    catch (const std::exception &e) { return fail(BH_ERR_INTERNAL, "internal error: %s", e.what()); }
+    catch (...) { return fail(BH_ERR_INTERNAL, "internal error (unknown exception)"); }
 }
 
 #define HIPCHK(expr)                                                                             \
@@ -233,8 +243,8 @@ void ctx_mark(bh_batch_context *ctx, int stage, int layer = -1) {
 
 // liveness-based arena plan: tensor t is born at step t (tensor 0 = front-end) and dies after
 // the last layer that reads it; the embedding tensor and the logits live to the end.
-void plan_arena(const bh::Model &m, const std::vector<int> &fused_at, size_t max_batch, bool keep,
-                std::vector<size_t> &off, size_t &total) {
+void plan_arena(const bh::Model &m, const std::vector<int> &fused_at, const std::vector<char> &head_gap, size_t max_batch,
+                bool keep, std::vector<size_t> &off, size_t &total) {
     const size_t nt = m.layers.size() + 1;
     std::vector<size_t> last(nt, 0), sz(nt);
     for (size_t t = 0; t < nt; t++) { last[t] = t; sz[t] = align_up(m.tensor_floats[t] * max_batch, 64); }
@@ -250,6 +260,14 @@ void plan_arena(const bh::Model &m, const std::vector<int> &fused_at, size_t max
                 // tensors i+1, i+2 stay in LDS and take no arena space
                 last[m.layers[i].in_tensor] = std::max(last[m.layers[i].in_tensor], i + 3);
                 sz[i + 1] = sz[i + 2] = 0;
+            }
+    if (!keep)
+        for (size_t i = 0; i + 1 < head_gap.size(); i++)
+            if (head_gap[i]) {
+                // head conv + pool in one launch: workgroups still read the conv's input while finished ones store
+                // pooled rows (tensor i+2), so the input lives through step i+2; the conv's output never exists
+                last[m.layers[i].in_tensor] = std::max(last[m.layers[i].in_tensor], i + 2);
+                sz[i + 1] = 0;
             }
     last[m.h.embedding_tensor] = nt;
     last[nt - 1] = nt;
@@ -291,7 +309,7 @@ int ctx_create(bh_classifier *c, size_t max_batch, bool keep, bh_batch_context *
     const size_t in_bytes = max_batch * (size_t)m.h.sample_count * sizeof(float);
     HIPCHK(hipMalloc((void **)&ctx->d_input, in_bytes));
     HIPCHK(hipMalloc((void **)&ctx->d_minmax, max_batch * 16 * sizeof(float)));
-    plan_arena(m, c->fused_at, max_batch, keep, ctx->t_off, ctx->arena_floats);
+    plan_arena(m, c->fused_at, c->head_gap, max_batch, keep, ctx->t_off, ctx->arena_floats);
     HIPCHK(hipMalloc((void **)&ctx->d_arena, ctx->arena_floats * sizeof(float)));
     HIPCHK(hipMalloc((void **)&ctx->d_logits, max_batch * (size_t)m.h.n_classes * sizeof(float)));
     HIPCHK(hipMalloc((void **)&ctx->d_topk_idx, max_batch * c->top_k * sizeof(int32_t)));
@@ -692,9 +710,73 @@ int bh_device_count(void) {
 }
 
 const char *bh_backend_name(void) { return "HIP (gfx950)"; }
+
+// ---- provider arm + default batch size (reference classifier.rs:662-1089, lib.rs:256-288) ---------------
+static void fill_device_facts(int32_t ordinal, bh_provider_status *o) {
+    hipDeviceProp_t prop;
+    if (ordinal < 0 || hipGetDeviceProperties(&prop, ordinal) != hipSuccess) { (void)hipGetLastError(); return; }
+    snprintf(o->device_name, sizeof o->device_name, "%s", prop.name);
+    snprintf(o->arch, sizeof o->arch, "%s", prop.gcnArchName);
+    o->compute_units = (uint32_t)prop.multiProcessorCount;
+    o->hbm_bytes = (uint64_t)prop.totalGlobalMem;
+}
+
+int bh_select_provider(const char *requested, int32_t device_ordinal, bh_provider_status *out) try {
+    if (!requested || !out) return fail(BH_ERR_INVALID, "select_provider: null argument");
+    memset(out, 0, sizeof *out);
+    std::string req(requested);
+    for (char &ch : req) if (ch >= 'A' && ch <= 'Z') ch = (char)(ch + 32);
+    snprintf(out->requested, sizeof out->requested, "%s", req.c_str());
+    const int ndev = bh_device_count();
+    out->device_count = (uint32_t)std::max(ndev, 0);
+    out->device = -1;
+    auto use_hip = [&]() {
+        out->device = device_ordinal < 0 ? 0 : device_ordinal;
+        snprintf(out->actual, sizeof out->actual, "HIP");
+        fill_device_facts(out->device, out);
+    };
+    if (req == "cpu") { snprintf(out->actual, sizeof out->actual, "CPU"); return BH_OK; }
+    if (req == "auto" || req == "gpu") {
+        if (ndev > 0 && device_ordinal < ndev) { use_hip(); return BH_OK; }
+        snprintf(out->actual, sizeof out->actual, "CPU");
+        snprintf(out->fallback_reason, sizeof out->fallback_reason, "No GPU providers available");
+        return BH_OK;
+    }
+    if (req == "hip" || req == "rocm") {
+        if (ndev <= 0) return fail(BH_ERR_NO_DEVICE, "HIP provider requested but no HIP device is available");
+        if (device_ordinal >= ndev) return fail(BH_ERR_NO_DEVICE, "device %d out of range (0..%d)", device_ordinal, ndev - 1);
+        use_hip();
+        return BH_OK;
+    }
+    return fail(BH_ERR_INVALID, "select_provider: '%s' is not served by this backend (auto, gpu, hip, rocm, cpu)", requested);
+} catch (...) { return on_exception(); }
+
+int bh_classifier_provider_status(const bh_classifier *c, bh_provider_status *out) try {
+    if (!c || !out) return fail(BH_ERR_INVALID, "provider_status: null argument");
+    memset(out, 0, sizeof *out);
+    snprintf(out->requested, sizeof out->requested, "hip");
+    snprintf(out->actual, sizeof out->actual, "HIP");
+    out->device = c->device;
+    out->device_count = (uint32_t)std::max(bh_device_count(), 0);
+    fill_device_facts(c->device, out);
+    return BH_OK;
+} catch (...) { return on_exception(); }
+
+size_t bh_default_batch_size(uint32_t model_type, const char *provider_actual) {
+    const char *p = provider_actual ? provider_actual : "HIP";
+    if (!strcmp(p, "CPU")) return 8;                                                                  // batch_size::CPU
+    if (!strcmp(p, "CUDA")) return (model_type == BH_MODEL_BIRDNET_V24 || model_type == BH_MODEL_BSG_FINLAND) ? 64 : 32;
+    if (!strcmp(p, "TensorRT")) return 32;
+    if (!strcmp(p, "HIP")) return 256;
+    return 16;                                                                                        // batch_size::OTHER_GPU
+}
+
+size_t bh_classifier_default_batch_size(const bh_classifier *c) {
+    return c ? bh_default_batch_size(c->model.h.family, "HIP") : 0;
+}
 const char *bh_last_error(void) { return g_err.c_str(); }
 
-int bh_classifier_create(const bh_config *cfg, bh_classifier **out) {
+int bh_classifier_create(const bh_config *cfg, bh_classifier **out) try {
     if (!cfg || !out || !cfg->model_path) return fail(BH_ERR_INVALID, "classifier_create: null config/model_path");
     *out = nullptr;
     if (cfg->top_k == 0 || cfg->top_k > BH_MAX_TOP_K) return fail(BH_ERR_INVALID, "top_k must be 1..%d", BH_MAX_TOP_K);
@@ -865,7 +947,7 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) {
     }
     *out = c.release();
     return BH_OK;
-}
+} catch (...) { return on_exception(); }
 
 void bh_classifier_destroy(bh_classifier *c) {
     if (!c) return;
@@ -881,7 +963,7 @@ void bh_classifier_destroy(bh_classifier *c) {
 
 // ---- range filter / species list (reference classifier.rs:587-645) -------------------------
 int bh_classifier_set_range_filter(bh_classifier *c, const float *scores, size_t n_classes, float threshold,
-                                   int keep_unmatched, int rerank) {
+                                   int keep_unmatched, int rerank) try {
     if (!c || !scores) return fail(BH_ERR_INVALID, "set_range_filter: null argument");
     if (n_classes != c->model.h.n_classes)
         return fail(BH_ERR_INVALID, "set_range_filter: %zu scores for %u classes", n_classes, c->model.h.n_classes);
@@ -894,9 +976,9 @@ int bh_classifier_set_range_filter(bh_classifier *c, const float *scores, size_t
     c->filter.keep_unmatched = keep_unmatched ? 1 : 0;
     c->filter.rerank = rerank ? 1 : 0;
     return BH_OK;
-}
+} catch (...) { return on_exception(); }
 
-int bh_classifier_set_species_list(bh_classifier *c, const uint8_t *keep, size_t n_classes) {
+int bh_classifier_set_species_list(bh_classifier *c, const uint8_t *keep, size_t n_classes) try {
     if (!c || !keep) return fail(BH_ERR_INVALID, "set_species_list: null argument");
     if (n_classes != c->model.h.n_classes)
         return fail(BH_ERR_INVALID, "set_species_list: %zu flags for %u classes", n_classes, c->model.h.n_classes);
@@ -906,9 +988,9 @@ int bh_classifier_set_species_list(bh_classifier *c, const uint8_t *keep, size_t
     HIPCHK(hipMemcpy(c->d_species_keep, keep, n_classes, hipMemcpyHostToDevice));
     c->filter.species_keep = c->d_species_keep;
     return BH_OK;
-}
+} catch (...) { return on_exception(); }
 
-int bh_topk_from_logits(bh_classifier *c, const float *logits, size_t n, bh_result *out) {
+int bh_topk_from_logits(bh_classifier *c, const float *logits, size_t n, bh_result *out) try {
     if (!c || (n && (!logits || !out))) return fail(BH_ERR_INVALID, "topk_from_logits: null argument");
     if (!n) return BH_OK;
     HIPCHK(hipSetDevice(c->device));
@@ -940,15 +1022,15 @@ int bh_topk_from_logits(bh_classifier *c, const float *logits, size_t n, bh_resu
         }
     }
     return BH_OK;
-}
+} catch (...) { return on_exception(); }
 
-int bh_classifier_clear_filters(bh_classifier *c) {
+int bh_classifier_clear_filters(bh_classifier *c) try {
     if (!c) return fail(BH_ERR_INVALID, "clear_filters: null classifier");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipDeviceSynchronize());
     c->filter = bh::TopkFilter{};
     return BH_OK;
-}
+} catch (...) { return on_exception(); }
 
 int bh_classifier_info(const bh_classifier *c, bh_model_info *info) {
     if (!c || !info) return fail(BH_ERR_INVALID, "classifier_info: null argument");
@@ -958,6 +1040,8 @@ int bh_classifier_info(const bh_classifier *c, bh_model_info *info) {
     info->spec_channels = h.n_branches; info->spec_h = h.spec_h; info->spec_w = h.spec_w;
     info->n_layers = h.n_layers; info->macs_per_segment = c->model.macs_per_segment();
     info->mel_flops_per_segment = c->mel_flops;
+    info->model_type = h.family;
+    info->precision = c->precision == 3 ? BH_FLAG_F16X3 : c->precision == 1 ? BH_FLAG_F16 : BH_FLAG_F32;
     return BH_OK;
 }
 
@@ -973,7 +1057,7 @@ int bh_classifier_is_warm(const bh_classifier *c, size_t batch_size) {
     return cc->warmed.count(batch_size) ? 1 : 0;
 }
 
-int bh_classifier_ensure_warm(bh_classifier *c, size_t batch_size) {
+int bh_classifier_ensure_warm(bh_classifier *c, size_t batch_size) try {
     if (!c || batch_size == 0) return fail(BH_ERR_INVALID, "ensure_warm: bad arguments");
     if (bh_classifier_is_warm(c, batch_size)) return BH_OK;
     // warmup(batch_size): all-zero segments through the real path (classifier.rs:443-466)
@@ -985,24 +1069,24 @@ int bh_classifier_ensure_warm(bh_classifier *c, size_t batch_size) {
     std::lock_guard<std::mutex> g(c->warm_mu);
     c->warmed.insert(batch_size);
     return BH_OK;
-}
+} catch (...) { return on_exception(); }
 
-int bh_batch_context_create(bh_classifier *c, size_t max_batch, bh_batch_context **out) {
+int bh_batch_context_create(bh_classifier *c, size_t max_batch, bh_batch_context **out) try {
     const char *keep = getenv("BIRDA_HIP_KEEP_TENSORS");
     return ctx_create(c, max_batch, keep && keep[0] == '1', out);
-}
+} catch (...) { return on_exception(); }
 void bh_batch_context_destroy(bh_batch_context *ctx) { ctx_destroy(ctx); }
 size_t bh_batch_context_bytes(const bh_batch_context *ctx) {
     return ctx ? ctx->max_batch * (size_t)ctx->c->model.h.sample_count * sizeof(float) : 0;
 }
 size_t bh_batch_context_device_bytes(const bh_batch_context *ctx) { return ctx ? ctx->device_bytes : 0; }
 
-int bh_predict(bh_classifier *c, const float *segment, size_t n_samples, bh_result *out) {
+int bh_predict(bh_classifier *c, const float *segment, size_t n_samples, bh_result *out) try {
     const float *segs[1] = {segment};
     return bh_predict_batch(c, segs, 1, n_samples, out);
-}
+} catch (...) { return on_exception(); }
 
-int bh_predict_batch(bh_classifier *c, const float *const *segments, size_t n, size_t n_samples, bh_result *out) {
+int bh_predict_batch(bh_classifier *c, const float *const *segments, size_t n, size_t n_samples, bh_result *out) try {
     if (!c || !segments || !out) return fail(BH_ERR_INVALID, "predict_batch: null argument");
     if (n == 0) return BH_OK;
     if (n_samples != c->model.h.sample_count)
@@ -1012,10 +1096,10 @@ int bh_predict_batch(bh_classifier *c, const float *const *segments, size_t n, s
     int rc = internal_ctx(c, n, &ctx);
     if (rc != BH_OK) return rc;
     return predict_slices(c, ctx, segments, nullptr, n, out, nullptr, nullptr);
-}
+} catch (...) { return on_exception(); }
 
 int bh_predict_batch_with_context(bh_classifier *c, bh_batch_context *ctx, const float *const *segments, size_t n,
-                                  size_t n_samples, bh_result *out) {
+                                  size_t n_samples, bh_result *out) try {
     int rc = check_ctx(c, ctx);
     if (rc != BH_OK) return rc;
     if (!segments || !out) return fail(BH_ERR_INVALID, "predict_batch_with_context: null argument");
@@ -1023,25 +1107,25 @@ int bh_predict_batch_with_context(bh_classifier *c, bh_batch_context *ctx, const
     if (n_samples != c->model.h.sample_count)
         return fail(BH_ERR_INVALID, "segment has %zu samples, model expects %u", n_samples, c->model.h.sample_count);
     return predict_slices(c, ctx, segments, nullptr, n, out, nullptr, nullptr);
-}
+} catch (...) { return on_exception(); }
 
-int bh_predict_batch_contig(bh_classifier *c, bh_batch_context *ctx, const float *base, size_t n, bh_result *out) {
+int bh_predict_batch_contig(bh_classifier *c, bh_batch_context *ctx, const float *base, size_t n, bh_result *out) try {
     int rc = check_ctx(c, ctx);
     if (rc != BH_OK) return rc;
     if (!base || !out) return fail(BH_ERR_INVALID, "predict_batch_contig: null argument");
     return predict_slices(c, ctx, nullptr, base, n, out, nullptr, nullptr);
-}
+} catch (...) { return on_exception(); }
 
 int bh_predict_batch_logits(bh_classifier *c, bh_batch_context *ctx, const float *base, size_t n, float *logits,
-                            float *embeddings) {
+                            float *embeddings) try {
     int rc = check_ctx(c, ctx);
     if (rc != BH_OK) return rc;
     if (!base || !logits) return fail(BH_ERR_INVALID, "predict_batch_logits: null argument");
     return predict_slices(c, ctx, nullptr, base, n, nullptr, logits, embeddings);
-}
+} catch (...) { return on_exception(); }
 
 int bh_forward_device(bh_classifier *c, bh_batch_context *ctx, const float *d_segments, size_t n, float *d_logits,
-                      int32_t *d_topk_index, float *d_topk_conf) {
+                      int32_t *d_topk_index, float *d_topk_conf) try {
     int rc = check_ctx(c, ctx);
     if (rc != BH_OK) return rc;
     if (!d_segments || !d_logits) return fail(BH_ERR_INVALID, "forward_device: null device pointer");
@@ -1055,7 +1139,7 @@ int bh_forward_device(bh_classifier *c, bh_batch_context *ctx, const float *d_se
         if (rc != BH_OK) return rc;
     }
     return BH_OK;
-}
+} catch (...) { return on_exception(); }
 
 int bh_batch_context_synchronize(bh_batch_context *ctx) {
     if (!ctx) return fail(BH_ERR_INVALID, "synchronize: null context");
@@ -1069,7 +1153,7 @@ uint64_t bh_tensor_floats(const bh_classifier *c, uint32_t tensor) {
     return c->model.tensor_floats[tensor];
 }
 
-int bh_debug_read_tensor(bh_classifier *c, bh_batch_context *ctx, uint32_t tensor, float *host, size_t max_floats) {
+int bh_debug_read_tensor(bh_classifier *c, bh_batch_context *ctx, uint32_t tensor, float *host, size_t max_floats) try {
     int rc = check_ctx(c, ctx);
     if (rc != BH_OK) return rc;
     if (!ctx->keep_tensors) return fail(BH_ERR_INVALID, "context was not created with BIRDA_HIP_KEEP_TENSORS=1");
@@ -1081,9 +1165,9 @@ int bh_debug_read_tensor(bh_classifier *c, bh_batch_context *ctx, uint32_t tenso
     const float *src = (tensor == c->model.layers.size()) ? ctx->last_logits : ctx->d_arena + ctx->t_off[tensor];
     HIPCHK(hipMemcpy(host, src, nfl * sizeof(float), hipMemcpyDeviceToHost));
     return BH_OK;
-}
+} catch (...) { return on_exception(); }
 
-int bh_batch_context_layer_ms(bh_batch_context *ctx, float *ms, uint32_t *launches, size_t n_layers) {
+int bh_batch_context_layer_ms(bh_batch_context *ctx, float *ms, uint32_t *launches, size_t n_layers) try {
     if (!ctx || !ms) return fail(BH_ERR_INVALID, "layer_ms: null argument");
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (size_t i = 0; i < n_layers; i++) { ms[i] = 0.f; if (launches) launches[i] = 0; }
@@ -1094,7 +1178,7 @@ int bh_batch_context_layer_ms(bh_batch_context *ctx, float *ms, uint32_t *launch
         if (hipEventElapsedTime(&t, ctx->ev[i - 1], ctx->ev[i]) == hipSuccess) { ms[ly] += t; if (launches) launches[ly]++; }
     }
     return BH_OK;
-}
+} catch (...) { return on_exception(); }
 
 int bh_classifier_fused_blocks(const bh_classifier *c, int32_t *cfgs, size_t cap) {
     if (!c) return 0;
@@ -1114,7 +1198,7 @@ int bh_debug_mb_stamps(bh_classifier *c, uint64_t *out, size_t cap) {
     return (int)(n / 8);
 }
 
-int bh_batch_context_set_profiling(bh_batch_context *ctx, int enabled) {
+int bh_batch_context_set_profiling(bh_batch_context *ctx, int enabled) try {
     if (!ctx) return fail(BH_ERR_INVALID, "set_profiling: null context");
     if (enabled) {   // a new measurement: drop the events of the previous one (after they have fired)
         HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -1123,9 +1207,9 @@ int bh_batch_context_set_profiling(bh_batch_context *ctx, int enabled) {
     }
     ctx->profiling = enabled != 0;
     return BH_OK;
-}
+} catch (...) { return on_exception(); }
 
-int bh_batch_context_stage_ms(bh_batch_context *ctx, float *ms, uint32_t *launches) {
+int bh_batch_context_stage_ms(bh_batch_context *ctx, float *ms, uint32_t *launches) try {
     if (!ctx || !ms) return fail(BH_ERR_INVALID, "stage_ms: null argument");
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < BH_N_STAGES; i++) { ctx->stage_ms[i] = 0.f; ctx->stage_launches[i] = 0; }
@@ -1140,10 +1224,10 @@ int bh_batch_context_stage_ms(bh_batch_context *ctx, float *ms, uint32_t *launch
     }
     for (int i = 0; i < BH_N_STAGES; i++) { ms[i] = ctx->stage_ms[i]; if (launches) launches[i] = ctx->stage_launches[i]; }
     return BH_OK;
-}
+} catch (...) { return on_exception(); }
 
 int bh_predict_batch_source_rate(bh_classifier *c, bh_batch_context *ctx, const float *const *segments, size_t n,
-                                 size_t n_src_samples, uint32_t source_rate, bh_result *out) {
+                                 size_t n_src_samples, uint32_t source_rate, bh_result *out) try {
     if (!c || !segments || !out) return fail(BH_ERR_INVALID, "predict_batch_source_rate: null argument");
     if (n == 0) return BH_OK;
     const auto &h = c->model.h;
@@ -1198,7 +1282,7 @@ int bh_predict_batch_source_rate(bh_classifier *c, bh_batch_context *ctx, const 
         }
     }
     return BH_OK;
-}
+} catch (...) { return on_exception(); }
 
 size_t bh_segment_starts(size_t n_frames, size_t segment_samples, size_t overlap_samples, uint64_t *starts, size_t cap) {
     // StreamingDecoder::next_segment over a stream of n_frames (decode.rs:150-202): take = min(seg, left);
@@ -1217,7 +1301,7 @@ size_t bh_segment_starts(size_t n_frames, size_t segment_samples, size_t overlap
 
 int bh_predict_pcm16(bh_classifier *c, bh_batch_context *ctx, const int16_t *pcm, size_t n_frames, uint32_t channels,
                      uint32_t source_rate, size_t overlap_samples, bh_result *out, size_t out_cap, size_t *n_segments,
-                     uint64_t *start_samples) {
+                     uint64_t *start_samples) try {
     int rc = check_ctx(c, ctx);
     if (rc != BH_OK) return rc;
     if (!pcm || !out || !n_segments || channels == 0) return fail(BH_ERR_INVALID, "predict_pcm16: bad arguments");
@@ -1346,17 +1430,17 @@ int bh_predict_pcm16(bh_classifier *c, bh_batch_context *ctx, const int16_t *pcm
         }
     }
     return BH_OK;
-}
+} catch (...) { return on_exception(); }
 
-int bh_resample_output_len(size_t n_in, uint32_t from_rate, uint32_t to_rate, size_t *n_out) {
+int bh_resample_output_len(size_t n_in, uint32_t from_rate, uint32_t to_rate, size_t *n_out) try {
     if (!n_out || from_rate == 0 || to_rate == 0) return fail(BH_ERR_INVALID, "resample_output_len: bad arguments");
     *n_out = bh::resample_output_len(n_in, from_rate, to_rate);
     return BH_OK;
-}
+} catch (...) { return on_exception(); }
 
 int bh_resample_device(bh_classifier *c, bh_batch_context *ctx, const float *d_in, size_t in_stride, size_t src_len,
                        uint32_t from_rate, uint32_t to_rate, float *d_out, size_t out_stride, size_t out_len,
-                       size_t n_seg) {
+                       size_t n_seg) try {
     int rc = check_ctx(c, ctx);
     if (rc != BH_OK) return rc;
     if (!d_in || !d_out || from_rate == 0 || to_rate == 0 || src_len > in_stride || out_len > out_stride)
@@ -1379,10 +1463,10 @@ int bh_resample_device(bh_classifier *c, bh_batch_context *ctx, const float *d_i
                         c->precision != 0 && !(getenv("BIRDA_HIP_RESAMPLE_F32") && getenv("BIRDA_HIP_RESAMPLE_F32")[0] == '1'), ctx->stream);
     HIPCHK(hipGetLastError());
     return BH_OK;
-}
+} catch (...) { return on_exception(); }
 
 int bh_resample(bh_classifier *c, const float *in, size_t n_in, uint32_t from_rate, uint32_t to_rate, float *out,
-                size_t out_cap, size_t *n_out) {
+                size_t out_cap, size_t *n_out) try {
     if (!c || !in || !out || !n_out) return fail(BH_ERR_INVALID, "resample: null argument");
     const size_t need = bh::resample_output_len(n_in, from_rate, to_rate);
     if (need > out_cap) return fail(BH_ERR_INVALID, "resample: output buffer too small (%zu < %zu)", out_cap, need);
@@ -1403,6 +1487,6 @@ int bh_resample(bh_classifier *c, const float *in, size_t n_in, uint32_t from_ra
     if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == BH_OK) rc = fail(BH_ERR_HIP, "resample: stream sync failed");
     (void)hipFree(d_in); (void)hipFree(d_out);
     return rc;
-}
+} catch (...) { return on_exception(); }
 
 }  // extern "C"

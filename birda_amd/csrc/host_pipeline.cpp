@@ -28,13 +28,33 @@
 #include <limits>
 #include <vector>
 
-#include "../../include/birda_hip.h"
-#include "../../include/birda_host.h"
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include "host_internal.hpp"
+
+using bhh::Detection;
+using bhh::detection_from_label;
+using bhh::escape_csv;
 
 namespace {
 
 thread_local std::string h_err;
 int hfail(int code, const std::string &msg) { h_err = msg; return code; }
+}  // namespace
+void bhh::set_host_error(const std::string &msg) { h_err = msg; }
+namespace {
+// catch (...) handler of the extern "C" entry points: exceptions never cross the C ABI
+int h_on_exception() noexcept {
+    try {
+        try { throw; }
+        catch (const std::bad_alloc &) { return hfail(BH_ERR_INTERNAL, "out of host memory"); }
+        catch (const std::exception &e) { return hfail(BH_ERR_INTERNAL, std::string("internal error: ") + e.what()); }
+        catch (...) { return hfail(BH_ERR_INTERNAL, "internal error (unknown exception)"); }
+    } catch (...) { return BH_ERR_INTERNAL; }   // building the message failed as well
+}
 
 // ---------------------------------------------------------------------------------------
 // WAV container -> interleaved PCM packets (the symphonia role, WAV only)
@@ -53,7 +73,7 @@ struct bh_decoder {
     int channels = 1;
     SampleFmt fmt = FMT_NONE;
     int bytes_per_sample = 2;
-    uint64_t data_bytes = 0, data_read = 0;
+    uint64_t data_bytes = 0, data_read = 0, data_offset = 0;
     bool has_duration = false;
     double duration_secs = 0.0;
     // StreamingDecoder state (decode.rs:34-50)
@@ -107,7 +127,7 @@ extern "C" {
 const char *bhh_last_error(void) { return h_err.c_str(); }
 
 // StreamingDecoder::open -- decode.rs:54-128
-int bhh_decoder_open(const char *path, bh_decoder **out) {
+int bhh_decoder_open(const char *path, bh_decoder **out) try {
     if (!path || !out) return hfail(BH_ERR_INVALID, "decoder_open: null argument");
     *out = nullptr;
     FILE *f = fopen(path, "rb");
@@ -126,8 +146,11 @@ int bhh_decoder_open(const char *path, bh_decoder **out) {
         if (fread(ch, 1, 8, f) != 8) break;
         uint32_t sz = rd32(ch + 4);
         if (memcmp(ch, "fmt ", 4) == 0) {
-            std::vector<unsigned char> b(sz);
-            if (fread(b.data(), 1, sz, f) != sz || sz < 16) break;
+            // the chunk size comes from an untrusted header: read the 40 bytes WAVE_FORMAT_EXTENSIBLE defines at most
+            unsigned char b[40] = {0};
+            const uint32_t take = sz < sizeof b ? sz : (uint32_t)sizeof b;
+            if (sz < 16 || fread(b, 1, take, f) != take) break;
+            if (sz > take && fseek(f, (long)(sz - take), SEEK_CUR) != 0) break;
             uint16_t tag = rd16(&b[0]);
             d->channels = rd16(&b[2]);
             d->sample_rate = rd32(&b[4]);
@@ -141,14 +164,17 @@ int bhh_decoder_open(const char *path, bh_decoder **out) {
             if (sz & 1) fseek(f, 1, SEEK_CUR);
         } else if (memcmp(ch, "data", 4) == 0) {
             long pos = ftell(f);
+            d->data_offset = (uint64_t)pos;
             fseek(f, 0, SEEK_END);
             long end = ftell(f);
             fseek(f, pos, SEEK_SET);
             uint64_t avail = (uint64_t)(end - pos);
-            d->data_bytes = (sz == 0xFFFFFFFFu || sz == 0 || sz > avail) ? avail : sz;
+            // a streaming writer leaves 0xFFFFFFFF (or a length past the end of the file): take what is there.
+            // A zero-length data chunk is an empty stream, not "to end of file".
+            d->data_bytes = (sz == 0xFFFFFFFFu || sz > avail) ? avail : sz;
             have_data = true;
         } else {
-            fseek(f, (long)sz + (sz & 1), SEEK_CUR);
+            if (fseek(f, (long)sz + (sz & 1), SEEK_CUR) != 0) break;
         }
     }
     if (!have_fmt || !have_data || d->channels <= 0)
@@ -161,7 +187,7 @@ int bhh_decoder_open(const char *path, bh_decoder **out) {
     d->duration_secs = (double)n_frames / (double)d->sample_rate;
     *out = d.release();
     return BH_OK;
-}
+} catch (...) { return h_on_exception(); }
 
 void bhh_decoder_close(bh_decoder *d) {
     if (!d) return;
@@ -178,7 +204,7 @@ int bhh_decoder_duration_hint(const bh_decoder *d, double *secs) {
 
 // StreamingDecoder::next_segment -- decode.rs:150-202.  returns 1 segment / 0 exhausted / <0 error
 int bhh_decoder_next_segment(bh_decoder *d, size_t segment_samples, size_t overlap_samples, float *out,
-                             size_t *start_sample) {
+                             size_t *start_sample) try {
     if (!d || !out || !start_sample) return hfail(BH_ERR_INVALID, "next_segment: null argument");
     if (overlap_samples >= segment_samples)  // :156-162
         return hfail(BH_ERR_INVALID, "overlap_samples (" + std::to_string(overlap_samples) + ") must be less than segment_samples (" +
@@ -198,7 +224,7 @@ int bhh_decoder_next_segment(bh_decoder *d, size_t segment_samples, size_t overl
         d->samples_emitted += take;
     }
     return 1;
-}
+} catch (...) { return h_on_exception(); }
 
 // estimate_segment_count -- src/output/progress.rs:80-92 (-1 = None)
 int64_t bhh_estimate_segment_count(int has_duration, double duration_secs, float segment_duration, float overlap) {
@@ -232,30 +258,7 @@ size_t bhh_duration_to_samples(float seconds, uint32_t rate) {
 
 namespace {
 
-// escape_csv -- csv.rs:126-132
-std::string escape_csv(const std::string &v) {
-    if (v.find(',') != std::string::npos || v.find('"') != std::string::npos || v.find('\n') != std::string::npos) {
-        std::string o = "\"";
-        for (char c : v) { if (c == '"') o += '"'; o += c; }
-        return o + "\"";
-    }
-    return v;
-}
-
-struct Detection {  // output/types.rs:8-23
-    float start_time, end_time, confidence;
-    std::string scientific_name, common_name;
-};
-
-// Detection::from_label -- types.rs:58-79
-Detection detection_from_label(const std::string &label, float conf, float start, float end) {
-    Detection d{start, end, conf, label, label};
-    const size_t us = label.find('_');
-    if (us != std::string::npos) { d.scientific_name = label.substr(0, us); d.common_name = label.substr(us + 1); }
-    return d;
-}
-
-std::string csv_row(const Detection &d, const std::string &path) {  // csv.rs:55-66, DECIMAL_PLACES = 4
+std::string csv_row(const Detection &d, const std::string &path) {  // csv.rs:55-66, DECIMAL_PLACES = 4 (bhh_csv_row; files go through host_output.cpp)
     char num[96];
     snprintf(num, sizeof num, "%.1f,%.1f,", (double)d.start_time, (double)d.end_time);
     std::string row = num;
@@ -269,9 +272,60 @@ std::string csv_row(const Detection &d, const std::string &path) {  // csv.rs:55
 const char *CSV_HEADER = "Start (s),End (s),Scientific name,Common name,Confidence,File\n";  // csv.rs:41-52
 
 // ---- watchdog (gpu/watchdog.rs:22-66) ----
-struct Watchdog {
-    std::shared_ptr<std::atomic<bool>> cancelled;
+// The reference spawns one detached thread per batch that sleeps the whole timeout whether or not the guard was
+// dropped; at ORT batch rates that is a handful of threads.  A batch takes well under a millisecond here, so ONE
+// process-wide thread serves every guard: start arms a deadline, cancel disarms it and wakes the thread, which
+// terminates the process (exit code 1, the reference's message) only for a deadline that passes while still armed.
+struct WatchdogHub {
+    struct Armed { std::chrono::steady_clock::time_point deadline; uint64_t timeout_ms; size_t batch_size; };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::unordered_map<uint64_t, Armed> armed;
+    uint64_t next_id = 1;
+    bool thread_started = false;
+
+    void loop() {
+        std::unique_lock<std::mutex> l(mu);
+        for (;;) {
+            if (armed.empty()) { cv.wait(l); continue; }
+            auto first = armed.begin();
+            for (auto it = armed.begin(); it != armed.end(); ++it)
+                if (it->second.deadline < first->second.deadline) first = it;
+            const Armed a = first->second;
+            if (std::chrono::steady_clock::now() >= a.deadline) {
+                const size_t suggested = std::max<size_t>(a.batch_size / 2, 1);
+                fprintf(stderr, "\nFATAL: Inference timeout after %llus (batch size: %zu)\n\n"
+                                "The GPU inference operation did not complete within the expected time.\n"
+                                "Recommendations:\n  1. Reduce batch size: birda -b %zu <input>\n"
+                                "  2. Close other GPU applications and try again\n\n"
+                                "Terminating process to prevent system lockup.\n",
+                        (unsigned long long)(a.timeout_ms / 1000), a.batch_size, suggested);
+                _Exit(1);
+            }
+            cv.wait_until(l, a.deadline);
+        }
+    }
+    uint64_t arm(uint64_t timeout_ms, size_t batch_size) {
+        std::lock_guard<std::mutex> l(mu);
+        if (!thread_started) {   // created once; never per batch
+            std::thread([this] { loop(); }).detach();
+            thread_started = true;
+        }
+        const uint64_t id = next_id++;
+        armed[id] = Armed{std::chrono::steady_clock::now() + std::chrono::milliseconds(timeout_ms), timeout_ms, batch_size};
+        cv.notify_all();
+        return id;
+    }
+    void disarm(uint64_t id) {
+        std::lock_guard<std::mutex> l(mu);
+        armed.erase(id);
+        cv.notify_all();
+    }
 };
+WatchdogHub &watchdog_hub() {
+    static WatchdogHub *hub = new WatchdogHub();   // never destroyed: the detached thread may outlive static destructors
+    return *hub;
+}
 
 // inference_watchdog_timeout -- processor.rs:194-211
 uint64_t watchdog_timeout_secs() {
@@ -333,179 +387,299 @@ extern "C" {
 uint64_t bhh_watchdog_timeout_secs(void) { return watchdog_timeout_secs(); }
 
 // start_inference_watchdog -- gpu/watchdog.rs:22-52.  The returned handle is the WatchdogGuard;
-// bhh_watchdog_cancel == drop(guard) (:61-65).
+// bhh_watchdog_cancel == drop(guard) (:61-65).  NULL when the guard could not be armed (out of memory / threads):
+// the batch then runs unguarded instead of taking the process down.
 void *bhh_watchdog_start(uint64_t timeout_ms, size_t batch_size) {
-    auto *w = new Watchdog{std::make_shared<std::atomic<bool>>(false)};
-    auto flag = w->cancelled;
-    std::thread([flag, timeout_ms, batch_size] {
-        std::this_thread::sleep_for(std::chrono::milliseconds(timeout_ms));
-        if (!flag->load(std::memory_order_seq_cst)) {
-            const size_t suggested = std::max<size_t>(batch_size / 2, 1);
-            fprintf(stderr, "\nFATAL: Inference timeout after %llus (batch size: %zu)\n\n"
-                            "The GPU inference operation did not complete within the expected time.\n"
-                            "Recommendations:\n  1. Reduce batch size: birda -b %zu <input>\n"
-                            "  2. Close other GPU applications and try again\n\n"
-                            "Terminating process to prevent system lockup.\n",
-                    (unsigned long long)(timeout_ms / 1000), batch_size, suggested);
-            _Exit(1);
-        }
-    }).detach();
-    return w;
+    try {
+        return new uint64_t(watchdog_hub().arm(timeout_ms, batch_size));
+    } catch (...) {
+        return nullptr;
+    }
 }
 void bhh_watchdog_cancel(void *guard) {
-    auto *w = static_cast<Watchdog *>(guard);
-    if (!w) return;
-    w->cancelled->store(true, std::memory_order_seq_cst);
-    delete w;
+    auto *id = static_cast<uint64_t *>(guard);
+    if (!id) return;
+    watchdog_hub().disarm(*id);
+    delete id;
 }
 
-size_t bhh_csv_header(int bom, char *out, size_t cap) {
+size_t bhh_csv_header(int bom, char *out, size_t cap) try {
     std::string s;
     if (bom) s = "\xEF\xBB\xBF";  // UTF8_BOM, constants.rs:437
     s += CSV_HEADER;
     if (s.size() + 1 > cap) return 0;
     memcpy(out, s.c_str(), s.size() + 1);
     return s.size();
-}
+} catch (...) { return (h_on_exception(), (size_t)0); }
 
-size_t bhh_csv_row(const char *label, float start, float end, float conf, const char *path, char *out, size_t cap) {
-    std::string s = csv_row(detection_from_label(label, conf, start, end), path);
+size_t bhh_csv_row(const char *label, float start, float end, float conf, const char *path, char *out, size_t cap) try {
+    std::string s = csv_row(detection_from_label(label, conf, start, end, path ? path : ""), path ? path : "");
     if (s.size() + 1 > cap) return 0;
     memcpy(out, s.c_str(), s.size() + 1);
     return s.size();
+} catch (...) { return (h_on_exception(), (size_t)0); }
+
+}  // extern "C"
+
+// ---- process_file -- processor.rs:418-796 ---------------------------------------------------------------
+namespace {
+
+struct FilePlan {
+    std::string path, shown;
+    uint32_t source_rate = 0, target_rate = 0;
+    float segment_duration = 0.f;
+    size_t segment_samples = 0, overlap_samples = 0, src_segment_samples = 0, src_overlap_samples = 0;
+    size_t effective = 0;
+    int64_t estimated = -1;
+    bool resampling = false;
+    float min_confidence = 0.1f;
+    bhh_reporter *reporter = nullptr;
+};
+
+// (start_sample / source_rate as f32, start + segment_samples / target_rate) -- processor.rs:91-94
+void chunk_times(const FilePlan &pl, size_t start_sample, float &start_time, float &end_time) {
+    start_time = (float)start_sample / (float)pl.source_rate;
+    end_time = start_time + (float)pl.segment_samples / (float)pl.target_rate;
 }
 
-// output_path_for(csv): <output_dir>/<stem>.BirdNET.results.csv (constants.rs:265; coordinator.rs:63-94)
-static std::string csv_output_path(const std::string &input, const std::string &out_dir) {
-    size_t slash = input.find_last_of('/');
-    std::string name = slash == std::string::npos ? input : input.substr(slash + 1);
-    size_t dot = name.find_last_of('.');
-    std::string stem = (dot == std::string::npos || dot == 0) ? name : name.substr(0, dot);
-    for (char &c : stem) if (c == '/' || c == '\\') c = '_';  // coordinator.rs:55-57
-    std::string dir = out_dir.empty() ? (slash == std::string::npos ? "." : input.substr(0, slash)) : out_dir;
-    return dir + "/" + stem + ".BirdNET.results.csv";
-}
-
-// process_file -- processor.rs:418-796 (CSV format, no lock files / progress bars / reporters)
-int bhh_process_file(bh_classifier *clf, const bhh_processing_config *cfg, bhh_process_result *res) {
-    if (!clf || !cfg || !cfg->input_path || !res) return hfail(BH_ERR_INVALID, "process_file: null argument");
-    memset(res, 0, sizeof *res);
-    const auto t_start = std::chrono::steady_clock::now();
-    bh_model_info info;
-    if (bh_classifier_info(clf, &info) != BH_OK) return hfail(BH_ERR_INVALID, bh_last_error());
-
-    // open once for metadata (:457-459)
-    bh_decoder *probe = nullptr;
-    int rc = bhh_decoder_open(cfg->input_path, &probe);
-    if (rc != BH_OK) return rc;
-    const uint32_t source_rate = bhh_decoder_sample_rate(probe);
-    double duration = 0.0;
-    const int has_duration = bhh_decoder_duration_hint(probe, &duration);
-    bhh_decoder_close(probe);
-
-    const uint32_t target_rate = info.sample_rate;          // :474
-    const float segment_duration = info.segment_duration;
-    const size_t segment_samples = bhh_duration_to_samples(segment_duration, target_rate);   // :514
-    const size_t overlap_samples = bhh_duration_to_samples(cfg->overlap, target_rate);       // :520
-    const int64_t estimated = bhh_estimate_segment_count(has_duration, duration, segment_duration, cfg->overlap);  // :525
-    const size_t batch_size = cfg->batch_size ? cfg->batch_size : 8;
-    const size_t effective = bhh_effective_batch_size(batch_size, estimated);                // :531-545
-    res->effective_batch = effective;
-
-    if (segment_samples != info.sample_count)
-        return hfail(BH_ERR_INVALID, "segment_duration * sample_rate != model sample_count");
-    const bool resampling = source_rate != target_rate;   // raw source-rate segments go to the device resampler
-    const size_t src_segment_samples = bhh_source_samples(segment_samples, source_rate, target_rate);
-
-    rc = bh_classifier_ensure_warm(clf, effective);                                          // :577
-    if (rc != BH_OK) return hfail(rc, bh_last_error());
-    bh_batch_context *ctx = nullptr;                                                         // :582-603
-    if (effective > 1) {
-        rc = bh_batch_context_create(clf, effective, &ctx);
-        if (rc != BH_OK) ctx = nullptr;  // fall back to predict_batch like the reference does for Perch
-    }
-
-    Channel chan(std::max<size_t>(4, effective * 2));                                        // :640-641
-    const std::string path = cfg->input_path;
-    const float overlap = cfg->overlap;
-    (void)overlap;
-    std::thread producer([&chan, path, source_rate, target_rate, segment_samples, overlap_samples] {  // :23-108
-        bh_decoder *dec = nullptr;
-        int r = bhh_decoder_open(path.c_str(), &dec);                                        // :59
-        if (r != BH_OK) { chan.close(r, h_err); return; }
-        const size_t src_seg = bhh_source_samples(segment_samples, source_rate, target_rate);   // :67-71
-        const size_t src_ovl = bhh_source_samples(overlap_samples, source_rate, target_rate);   // :78-82
-        std::vector<float> raw(src_seg);
-        size_t start_sample = 0;
-        while ((r = bhh_decoder_next_segment(dec, src_seg, src_ovl, raw.data(), &start_sample)) == 1) {  // :84
-            AudioChunk c;
-            // equal rates: resample_chunk is the identity (resample.rs:98-100) and resize pads (:87);
-            // otherwise the raw segment travels on and both steps run on the device (bh_resample_device)
-            c.samples.assign(raw.begin(), raw.end());
-            if (source_rate == target_rate) c.samples.resize(segment_samples, 0.0f);
-            c.start_time = (float)start_sample / (float)source_rate;                         // :91
-            const float seg_dur = (float)segment_samples / (float)target_rate;               // :93
-            c.end_time = c.start_time + seg_dur;                                             // :94
-            if (!chan.send(std::move(c))) break;                                             // :103
+// threshold + Detection::from_label for one segment's predictions -- processor.rs:363-385
+void collect_detections(bh_classifier *clf, const FilePlan &pl, const bh_result &r, float start_time, float end_time,
+                        std::vector<Detection> &detections) {
+    for (uint32_t k = 0; k < r.n_pred; k++)
+        if (r.confidence[k] >= pl.min_confidence) {                                          // :375
+            const char *label = bh_classifier_label(clf, (uint32_t)r.index[k]);
+            detections.push_back(detection_from_label(label ? label : std::to_string(r.index[k]), r.confidence[k], start_time, end_time, pl.shown));
         }
-        bhh_decoder_close(dec);
-        chan.close(r < 0 ? r : 0, r < 0 ? h_err : "");
+}
+
+// reporter.progress(None, Some(file_progress)) after every segment -- processor.rs:388-406
+void report_progress(const FilePlan &pl, size_t &segments_done) {
+    if (!pl.reporter) return;
+    segments_done++;
+    const size_t total = pl.estimated > 0 ? (size_t)pl.estimated : 0;   // unwrap_or(0)
+    const float percent = total > 0 ? std::min((float)segments_done / (float)total * 100.0f, 100.0f) : 0.0f;
+    bhh_reporter_file_progress(pl.reporter, pl.path.c_str(), segments_done, total, percent);
+}
+
+struct RunStats { size_t segments = 0, batches = 0, padded_rows = 0; };
+
+// HOST front end: decode thread -> bounded channel -> batcher (processor.rs:23-190, 220-410)
+int run_host_front_end(bh_classifier *clf, const FilePlan &pl, const bh_model_info &info, bh_batch_context *ctx,
+                       std::vector<Detection> &detections, RunStats &st, std::string &fail_msg) {
+    const size_t effective = pl.effective;
+    Channel chan(std::max<size_t>(4, effective * 2));                                        // :640-641
+    std::thread producer([&chan, &pl] {                                                      // :23-108
+        try {
+            bh_decoder *dec = nullptr;
+            int r = bhh_decoder_open(pl.path.c_str(), &dec);                                 // :59
+            if (r != BH_OK) { chan.close(r, h_err); return; }
+            std::vector<float> raw(pl.src_segment_samples);
+            size_t start_sample = 0;
+            while ((r = bhh_decoder_next_segment(dec, pl.src_segment_samples, pl.src_overlap_samples, raw.data(), &start_sample)) == 1) {  // :84
+                AudioChunk c;
+                // equal rates: resample_chunk is the identity (resample.rs:98-100) and resize pads (:87);
+                // otherwise the raw segment travels on and both steps run on the device (bh_resample_device)
+                c.samples.assign(raw.begin(), raw.end());
+                if (!pl.resampling) c.samples.resize(pl.segment_samples, 0.0f);
+                chunk_times(pl, start_sample, c.start_time, c.end_time);
+                if (!chan.send(std::move(c))) break;                                         // :103
+            }
+            bhh_decoder_close(dec);
+            chan.close(r < 0 ? r : 0, r < 0 ? h_err : "");
+        } catch (...) {   // an exception must not leave the thread (std::terminate)
+            chan.close(BH_ERR_INTERNAL, "decode thread: out of memory or internal error");
+        }
     });
 
-    // run_streaming_inference -- :114-190
-    std::vector<Detection> detections;
     std::vector<AudioChunk> batch;
     batch.reserve(effective);
-    size_t segment_count = 0;
     std::vector<float> padding;
     std::vector<bh_result> results(effective);
-    std::string fail_msg;
     int fail_code = 0;
+    size_t segments_done = 0;
 
     auto process_batch = [&](std::vector<AudioChunk> &b) -> int {                            // :220-410
         const size_t valid = b.size();
         std::vector<const float *> segs;
         for (auto &c : b) segs.push_back(c.samples.data());
         if (valid < effective) {                                                             // :240-258
-            if (padding.empty()) padding.assign(resampling ? src_segment_samples : (size_t)info.sample_count, 0.0f);
-            res->padded_rows += effective - valid;
+            if (padding.empty()) padding.assign(pl.resampling ? pl.src_segment_samples : (size_t)info.sample_count, 0.0f);
+            st.padded_rows += effective - valid;
             while (segs.size() < effective) segs.push_back(padding.data());
         }
         const size_t bs = segs.size();
         void *guard = bhh_watchdog_start(watchdog_timeout_secs() * 1000, bs);                // :263-266
         int r;
-        if (resampling) r = bh_predict_batch_source_rate(clf, ctx, segs.data(), bs, src_segment_samples, source_rate, results.data());
+        if (pl.resampling) r = bh_predict_batch_source_rate(clf, ctx, segs.data(), bs, pl.src_segment_samples, pl.source_rate, results.data());
         else if (bs == 1) r = bh_predict(clf, segs[0], info.sample_count, &results[0]);       // :269-277
         else if (ctx) r = bh_predict_batch_with_context(clf, ctx, segs.data(), bs, info.sample_count, results.data());
         else r = bh_predict_batch(clf, segs.data(), bs, info.sample_count, results.data());
         bhh_watchdog_cancel(guard);
         if (r != BH_OK) { fail_msg = std::string("Inference: ") + bh_last_error(); return r; }
-        res->batches++;
-        for (size_t i = 0; i < valid; i++)                                                   // :363-385
-            for (uint32_t k = 0; k < results[i].n_pred; k++)
-                if (results[i].confidence[k] >= cfg->min_confidence) {                       // :375
-                    const char *label = bh_classifier_label(clf, (uint32_t)results[i].index[k]);
-                    detections.push_back(detection_from_label(label ? label : std::to_string(results[i].index[k]),
-                                                              results[i].confidence[k], b[i].start_time, b[i].end_time));
-                }
+        st.batches++;
+        for (size_t i = 0; i < valid; i++) {                                                 // :363-385
+            collect_detections(clf, pl, results[i], b[i].start_time, b[i].end_time, detections);
+            report_progress(pl, segments_done);
+        }
         return BH_OK;
     };
 
     AudioChunk chunk;
     int r;
-    while ((r = chan.recv(chunk)) == 1) {                                                    // :132-155
-        batch.push_back(std::move(chunk));
-        segment_count++;
-        if (batch.size() >= effective) {
-            if ((fail_code = process_batch(batch)) != BH_OK) break;
-            batch.clear();
+    try {
+        while ((r = chan.recv(chunk)) == 1) {                                                // :132-155
+            batch.push_back(std::move(chunk));
+            st.segments++;
+            if (batch.size() >= effective) {
+                if ((fail_code = process_batch(batch)) != BH_OK) break;
+                batch.clear();
+            }
         }
+        if (r < 0 && !fail_code) { fail_code = r; fail_msg = chan.err; }
+        if (!fail_code && !batch.empty()) fail_code = process_batch(batch);                  // :158-174
+    } catch (...) {
+        chan.drop_receiver();
+        producer.join();
+        throw;
     }
-    if (r < 0 && !fail_code) { fail_code = r; fail_msg = chan.err; }
-    if (!fail_code && !batch.empty()) fail_code = process_batch(batch);                      // :158-174
     chan.drop_receiver();
     producer.join();                                                                         // :676
-    if (ctx) bh_batch_context_destroy(ctx);
+    return fail_code;
+}
+
+// DEVICE front end: the PCM16 frames of the file are mapped and handed to bh_predict_pcm16 span by span.
+// A span starts on a multiple of the segment step, so its windows are the stream's windows (decode.rs:150-202); all
+// but the last span end on a full segment, whose trailing overlap remainder belongs to the next span and is dropped here.
+int run_device_front_end(bh_classifier *clf, const FilePlan &pl, const bh_model_info &info, bh_batch_context *ctx, const int16_t *pcm,
+                         size_t n_frames, uint32_t channels, std::vector<Detection> &detections, RunStats &st, std::string &fail_msg) {
+    (void)info;
+    const size_t seg = pl.src_segment_samples, ovl = pl.src_overlap_samples;
+    if (ovl >= seg) {   // next_segment's check, decode.rs:156-162
+        fail_msg = "overlap_samples (" + std::to_string(ovl) + ") must be less than segment_samples (" + std::to_string(seg) + ")";
+        return BH_ERR_INVALID;
+    }
+    const size_t step = seg - ovl;
+    const size_t span_segments = std::max<size_t>(pl.effective, 4096 / pl.effective * pl.effective);   // whole batches, ~4096 segments
+    std::vector<bh_result> results(span_segments + 1);
+    std::vector<uint64_t> starts(span_segments + 1);
+    size_t segments_done = 0;
+    for (size_t f0 = 0; f0 < n_frames;) {
+        const size_t full_span = (span_segments - 1) * step + seg;
+        const bool last = n_frames - f0 <= full_span;
+        const size_t frames = last ? n_frames - f0 : full_span;
+        size_t n_seg = 0;
+        void *guard = bhh_watchdog_start(watchdog_timeout_secs() * 1000, std::min(pl.effective, span_segments));
+        const int r = bh_predict_pcm16(clf, ctx, pcm + f0 * channels, frames, channels, pl.source_rate, pl.overlap_samples, results.data(),
+                                       results.size(), &n_seg, starts.data());
+        bhh_watchdog_cancel(guard);
+        if (r != BH_OK) { fail_msg = std::string("Inference: ") + bh_last_error(); return r; }
+        const size_t keep = last ? n_seg : std::min(n_seg, span_segments);
+        for (size_t i = 0; i < keep; i++) {
+            float t0, t1;
+            chunk_times(pl, f0 + (size_t)starts[i], t0, t1);
+            collect_detections(clf, pl, results[i], t0, t1, detections);
+            report_progress(pl, segments_done);
+        }
+        st.segments += keep;
+        st.batches += (keep + pl.effective - 1) / pl.effective;
+        if (last) break;
+        f0 += span_segments * step;
+    }
+    return BH_OK;
+}
+
+// a read-only mapping of a WAV file's PCM16 data chunk
+struct PcmMapping {
+    void *base = MAP_FAILED;
+    size_t length = 0;
+    const int16_t *pcm = nullptr;
+    size_t n_frames = 0;
+    ~PcmMapping() { if (base != MAP_FAILED) munmap(base, length); }
+    bool open(const bh_decoder &d) {
+        if (d.fmt != FMT_S16 || (d.data_offset & 1)) return false;
+        const int fd = ::open(d.path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        length = (size_t)(d.data_offset + d.data_bytes);
+        if (d.data_bytes) base = mmap(nullptr, length, PROT_READ, MAP_PRIVATE, fd, 0);
+        ::close(fd);
+        if (d.data_bytes && base == MAP_FAILED) return false;
+        if (base != MAP_FAILED) (void)madvise(base, length, MADV_SEQUENTIAL);
+        pcm = base != MAP_FAILED ? reinterpret_cast<const int16_t *>(static_cast<const char *>(base) + d.data_offset) : nullptr;
+        n_frames = (size_t)(d.data_bytes / ((uint64_t)d.channels * 2));
+        return true;
+    }
+};
+
+}  // namespace
+
+extern "C" int bhh_process_file(bh_classifier *clf, const bhh_processing_config *cfg, bhh_process_result *res) try {
+    if (!clf || !cfg || !cfg->input_path || !res) return hfail(BH_ERR_INVALID, "process_file: null argument");
+    memset(res, 0, sizeof *res);
+    const auto t_start = std::chrono::steady_clock::now();
+    bh_model_info info;
+    if (bh_classifier_info(clf, &info) != BH_OK) return hfail(BH_ERR_INVALID, bh_last_error());
+    const uint32_t formats = cfg->formats ? cfg->formats : BHH_FORMAT_CSV;
+    if (formats & ~BHH_FORMAT_ALL) return hfail(BH_ERR_INVALID, "InvalidOutputFormat: unknown bit in the format mask");
+    if (cfg->front_end > BHH_FRONT_END_DEVICE) return hfail(BH_ERR_INVALID, "process_file: unknown front_end");
+
+    // open once for metadata (:457-459)
+    bh_decoder *probe = nullptr;
+    int rc = bhh_decoder_open(cfg->input_path, &probe);
+    if (rc != BH_OK) return rc;
+    std::unique_ptr<bh_decoder, void (*)(bh_decoder *)> probe_own(probe, bhh_decoder_close);
+    FilePlan pl;
+    pl.path = cfg->input_path;
+    pl.shown = cfg->display_path ? cfg->display_path : pl.path;
+    pl.source_rate = bhh_decoder_sample_rate(probe);
+    double duration = 0.0;
+    const int has_duration = bhh_decoder_duration_hint(probe, &duration);
+
+    pl.target_rate = info.sample_rate;                                                       // :474
+    pl.segment_duration = info.segment_duration;
+    pl.segment_samples = bhh_duration_to_samples(pl.segment_duration, pl.target_rate);       // :514
+    pl.overlap_samples = bhh_duration_to_samples(cfg->overlap, pl.target_rate);              // :520
+    pl.estimated = bhh_estimate_segment_count(has_duration, duration, pl.segment_duration, cfg->overlap);  // :525
+    const size_t batch_size = cfg->batch_size ? cfg->batch_size : bh_classifier_default_batch_size(clf);   // lib.rs:1035
+    pl.effective = bhh_effective_batch_size(batch_size, pl.estimated);                       // :531-545
+    pl.min_confidence = cfg->min_confidence;
+    pl.reporter = cfg->reporter;
+    res->effective_batch = pl.effective;
+    if (pl.segment_samples != info.sample_count)
+        return hfail(BH_ERR_INVALID, "segment_duration * sample_rate != model sample_count");
+    pl.resampling = pl.source_rate != pl.target_rate;   // raw source-rate segments go to the device resampler
+    pl.src_segment_samples = bhh_source_samples(pl.segment_samples, pl.source_rate, pl.target_rate);   // :67-71
+    pl.src_overlap_samples = bhh_source_samples(pl.overlap_samples, pl.source_rate, pl.target_rate);   // :78-82
+
+    // front end: the device takes PCM16 WAV (any channel count); everything else decodes on the host
+    PcmMapping map;
+    bool device = false;
+    if (cfg->front_end != BHH_FRONT_END_HOST) {
+        device = map.open(*probe);
+        if (!device && cfg->front_end == BHH_FRONT_END_DEVICE)
+            return hfail(BH_ERR_UNSUPPORTED, "process_file: the device front end takes PCM16 WAV files only: " + pl.path);
+    }
+    const uint32_t channels = (uint32_t)probe->channels;
+    probe_own.reset();
+
+    rc = bh_classifier_ensure_warm(clf, pl.effective);                                       // :577
+    if (rc != BH_OK) return hfail(rc, bh_last_error());
+    bh_batch_context *ctx = nullptr;                                                         // :582-603
+    if (pl.effective > 1 || device) {
+        rc = bh_batch_context_create(clf, pl.effective, &ctx);
+        if (rc != BH_OK) {
+            if (device) return hfail(rc, bh_last_error());
+            ctx = nullptr;  // fall back to predict_batch like the reference does for Perch
+        }
+    }
+    std::unique_ptr<bh_batch_context, void (*)(bh_batch_context *)> ctx_own(ctx, bh_batch_context_destroy);
+
+    // run_streaming_inference -- :114-190
+    std::vector<Detection> detections;
+    RunStats st;
+    std::string fail_msg;
+    const int fail_code = device ? run_device_front_end(clf, pl, info, ctx, map.pcm, map.n_frames, channels, detections, st, fail_msg)
+                                 : run_host_front_end(clf, pl, info, ctx, detections, st, fail_msg);
+    ctx_own.reset();
     if (fail_code) return hfail(fail_code, fail_msg);
 
     // sort: start_time asc then confidence desc (:178-187); stable here (ties keep batch order)
@@ -515,28 +689,41 @@ int bhh_process_file(bh_classifier *clf, const bhh_processing_config *cfg, bhh_p
         return a.confidence > b.confidence;
     });
 
-    // write_output(csv) -- :819-873
-    const std::string out_path = csv_output_path(path, cfg->output_dir ? cfg->output_dir : "");
-    FILE *o = fopen(out_path.c_str(), "wb");
-    if (!o) return hfail(BH_ERR_IO, "cannot create " + out_path);
-    if (cfg->csv_bom) fwrite("\xEF\xBB\xBF", 1, 3, o);
-    fputs(CSV_HEADER, o);
-    const std::string shown = cfg->display_path ? cfg->display_path : path;
-    for (const auto &d : detections) { const std::string row = csv_row(d, shown); fwrite(row.data(), 1, row.size(), o); }
-    fclose(o);
+    const double audio_duration = has_duration ? duration
+                                  : (st.segments ? (double)pl.segment_duration + (st.segments - 1.0) * ((double)pl.segment_duration - cfg->overlap) : 0.0);  // :692-703
+
+    // write_output per format (:721-736) unless a reporter owns stdout-only mode
+    const bool should_write = cfg->dual_output || !cfg->reporter;
+    if (should_write) {
+        bhh::WriterOptions wo;
+        wo.csv_bom = cfg->csv_bom != 0;
+        if (cfg->csv_columns) wo.csv_columns = cfg->csv_columns;
+        if (cfg->model_name) wo.model = cfg->model_name;
+        wo.min_confidence = cfg->min_confidence; wo.overlap = cfg->overlap;
+        wo.audio_duration = (float)audio_duration;                                           // :706-714
+        wo.has_lat = cfg->has_lat != 0; wo.has_lon = cfg->has_lon != 0; wo.lat = cfg->lat; wo.lon = cfg->lon; wo.week = cfg->week;
+        for (uint32_t bit = 1; bit <= BHH_FORMAT_PARQUET; bit <<= 1) {
+            if (!(formats & bit)) continue;
+            std::string out_path, err;
+            rc = bhh::write_output(pl.path, cfg->output_dir ? cfg->output_dir : "", bit, detections, wo, out_path, err);
+            if (rc != BH_OK) return hfail(rc, err);
+            if (!res->formats_written) snprintf(res->output_path, sizeof res->output_path, "%s", out_path.c_str());
+            res->formats_written |= bit;
+        }
+    }
+    if (!cfg->dual_output && cfg->reporter) bhh::reporter_detections(cfg->reporter, pl.path, detections);   // :739-769
 
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     res->detections = detections.size();
-    res->segments = segment_count;
+    res->segments = st.segments;
+    res->batches = st.batches;
+    res->padded_rows = st.padded_rows;
     res->duration_secs = wall;
-    res->audio_duration_secs = has_duration ? duration
-                               : (segment_count ? (double)segment_duration + (segment_count - 1.0) * ((double)segment_duration - cfg->overlap) : 0.0);  // :692-703
-    res->segments_per_sec = wall > 0 && segment_count ? (double)segment_count / wall : 0.0;  // :771-778
-    snprintf(res->output_path, sizeof res->output_path, "%s", out_path.c_str());
+    res->audio_duration_secs = audio_duration;
+    res->segments_per_sec = wall > 0 && st.segments ? (double)st.segments / wall : 0.0;      // :771-778
+    res->front_end = device ? BHH_FRONT_END_DEVICE : BHH_FRONT_END_HOST;
     return BH_OK;
-}
-
-}  // extern "C"
+} catch (...) { return h_on_exception(); }
 
 
 // ---- range filter tables (reference src/inference/geomodel.rs) ---------------------------------------------
@@ -557,7 +744,7 @@ static std::string species_key(const char *label) {   // :36-38
 
 extern "C" BH_API int bhh_project_scores(const char *const *geomodel_labels, size_t n_geomodel, const char *const *score_species,
                                          const float *score_values, size_t n_scores, const char *const *classifier_labels,
-                                         size_t n_classes, float threshold, float *out_scores, size_t *mapped, size_t *in_range) {
+                                         size_t n_classes, float threshold, float *out_scores, size_t *mapped, size_t *in_range) try {
     if ((n_geomodel && !geomodel_labels) || (n_scores && (!score_species || !score_values)) || (n_classes && (!classifier_labels || !out_scores))) {
         return hfail(BH_ERR_INVALID, "project_scores: null argument");
     }
@@ -584,7 +771,7 @@ extern "C" BH_API int bhh_project_scores(const char *const *geomodel_labels, siz
         *in_range = n;
     }
     return BH_OK;
-}
+} catch (...) { return h_on_exception(); }
 
 
 // ---- directory mode (reference src/pipeline/coordinator.rs:146-190) ------------------------------------------
@@ -628,7 +815,7 @@ static bool walk_audio_files(const std::string &dir, std::vector<std::string> &f
     return true;
 }
 
-extern "C" BH_API size_t bhh_collect_input_files(const char *const *paths, size_t n_paths, char *out, size_t cap, size_t *n_files) {
+extern "C" BH_API size_t bhh_collect_input_files(const char *const *paths, size_t n_paths, char *out, size_t cap, size_t *n_files) try {
     std::vector<std::string> files;
     for (size_t i = 0; i < n_paths; i++) {                    // :146-161
         struct stat st;
@@ -644,4 +831,4 @@ extern "C" BH_API size_t bhh_collect_input_files(const char *const *paths, size_
     if (n_files) *n_files = files.size();
     if (out && cap > joined.size()) std::memcpy(out, joined.c_str(), joined.size() + 1);
     return joined.size() + 1;
-}
+} catch (...) { return (h_on_exception(), (size_t)-1); }

@@ -3,7 +3,38 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+#include <mutex>
+
 namespace bh {
+
+// One-time launcher set-up (kernel attributes, CU count) is per DEVICE, not per process: one process may hold
+// classifiers on several GPUs (bh_multi_*, one host thread per device).
+constexpr int MAX_DEVICES = 64;
+inline int current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= MAX_DEVICES) d = 0;
+    return d;
+}
+struct DeviceOnce {
+    std::mutex mu;
+    std::atomic<unsigned char> done[MAX_DEVICES] = {};
+    template <class F> void run(F &&f) {
+        const int d = current_device();
+        if (done[d].load(std::memory_order_acquire)) return;
+        std::lock_guard<std::mutex> g(mu);
+        if (!done[d].load(std::memory_order_relaxed)) { f(); done[d].store(1, std::memory_order_release); }
+    }
+};
+inline int device_cu_count() {
+    static std::atomic<int> n_cu[MAX_DEVICES] = {};
+    const int d = current_device();
+    int n = n_cu[d].load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256;
+    n_cu[d].store(n, std::memory_order_relaxed);
+    return n;
+}
 
 enum Act : int { ACT_NONE = 0, ACT_RELU, ACT_RELU6, ACT_SWISH, ACT_GELU_ERF, ACT_GELU_TANH, ACT_SIGMOID };
 

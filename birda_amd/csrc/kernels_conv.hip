@@ -683,13 +683,12 @@ __global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ log
 
 void launch_topk(const float *logits, int n_seg, int n_classes, int out_act, int top_k, float min_conf,
                  const TopkFilter &filter, int32_t *idx, float *conf, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce once;
+    once.run([] {
         // (the kernel also has a few static __shared__ words: ask for less than the full 160 KB)
         if (hipFuncSetAttribute((const void *)topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess)
             (void)hipGetLastError();
-        attr_set = true;
-    }
+    });
     hipLaunchKernelGGL(topk_kernel, dim3(n_seg), dim3(256), (size_t)n_classes * sizeof(float), s, logits, n_classes, out_act, top_k,
                        min_conf, filter, idx, conf);
 }

@@ -607,17 +607,12 @@ void launch_mel(const float *x, const float *minmax, float *spec, const Frontend
         const int ybuf_off = (span32 + 3) & ~3;   // floats; the staged Y rows follow the span, the reduction buffer overlays both
         const size_t smem32 = std::max((size_t)(ybuf_off + 4 * 2 * 32 * MEL32_YP) * sizeof(float), (size_t)4 * mt32 * 4 * 64 * sizeof(float4));
         const int nt32 = (max_frames + MEL32_TN - 1) / MEL32_TN, ni32 = nt32 * p.n_branches * n_seg;
-        static int n_cu32 = 0;
-        if (!n_cu32) {
-            int dev = 0;
-            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu32, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu32 <= 0)
-                n_cu32 = 256;
-        }
+        const int n_cu32 = device_cu_count();
         dim3 g32((unsigned)std::min(ni32, 2 * n_cu32)), b32(256);
 #define BH_MEL32(MTV)                                                                                                          \
     case MTV: {                                                                                                                \
-        static bool set32 = false;                                                                                             \
-        if (!set32) { (void)hipFuncSetAttribute((const void *)mel32_kernel<MTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); set32 = true; } \
+        static DeviceOnce set32;                                                                                               \
+        set32.run([] { (void)hipFuncSetAttribute((const void *)mel32_kernel<MTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
         hipLaunchKernelGGL((mel32_kernel<MTV>), g32, b32, smem32, s, x, minmax, spec, d_p, p.br[0].gf, p.br[1].gf, p.br[2].gf, p.br[3].gf, dbg, ybuf_off, nt32, ni32); \
     } break;
         switch (mt32) {
@@ -634,23 +629,17 @@ void launch_mel(const float *x, const float *minmax, float *spec, const Frontend
     const size_t red_bytes = (size_t)4 * 3 * mt * 64 * sizeof(float4);
     const size_t smem = span_bytes > red_bytes ? span_bytes : red_bytes;
     const int n_tiles = (max_frames + MEL_TN - 1) / MEL_TN, n_items = n_tiles * p.n_branches * n_seg;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-            n_cu = 256;
-    }
+    const int n_cu = device_cu_count();
     dim3 grid((unsigned)std::min(n_items, (mt <= 6 ? 2 : 1) * n_cu)), block(256);   // persistent: as many workgroups as fit at once
 #define BH_MEL_CASE(MTV)                                                                                   \
     case MTV: {                                                                                            \
-        static bool attr_set = false;                                                                      \
-        if (!attr_set) {                                                                                   \
+        static DeviceOnce attr_set;                                                                        \
+        attr_set.run([] {                                                                                  \
             (void)hipFuncSetAttribute((const void *)mel_kernel<MTV, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 160 * 1024);                                                              \
             (void)hipFuncSetAttribute((const void *)mel_kernel<MTV, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 160 * 1024);                                                              \
-            attr_set = true;                                                                               \
-        }                                                                                                  \
+        });                                                                                                \
         if (p.prec == 3)                                                                                   \
             hipLaunchKernelGGL((mel_kernel<MTV, 3>), grid, block, smem, s, x, minmax, spec, d_p, p.br[0].gf,   \
                                p.br[1].gf, p.br[2].gf, p.br[3].gf, dbg, n_tiles, n_items);                 \

@@ -577,11 +577,8 @@ template <int KS, int ST, int CE, int KG, int RT_W, int NCS, int WM, int WN, int
           int SS, int OCC, int STEM, int PREC>
 void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
     auto kern = mbconv_kernel<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, SS, OCC, STEM, PREC>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    static DeviceOnce attr_set;
+    attr_set.run([&] { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     dim3 grid(d.tiles_x, d.tiles_y, (n_seg + d.S - 1) / d.S), block(256);
     hipLaunchKernelGGL(kern, grid, block, d.lds_bytes, s, d, n_seg);
 }

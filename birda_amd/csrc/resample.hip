@@ -19,6 +19,7 @@
 #include <map>
 #include <mutex>
 #include <numeric>
+#include <tuple>
 #include <vector>
 
 #include "kernels.hpp"
@@ -64,7 +65,7 @@ double blackman_harris2(int i, int n) {
 }
 
 std::mutex g_plan_mu;
-std::map<std::pair<uint32_t, uint32_t>, ResamplePlan> g_plans;  // per device pointer set; one device per process
+std::map<std::tuple<int, uint32_t, uint32_t>, ResamplePlan> g_plans;  // the operator lives in ONE device's memory: keyed by device ordinal too
 
 }  // namespace
 
@@ -89,7 +90,7 @@ size_t resample_output_len(size_t n, uint32_t from, uint32_t to) {
 // Builds (or returns the cached) plan; *err receives a message on failure.
 const ResamplePlan *resample_plan(uint32_t from, uint32_t to, const char **err) {
     std::lock_guard<std::mutex> lock(g_plan_mu);
-    auto key = std::make_pair(from, to);
+    auto key = std::make_tuple(current_device(), from, to);
     auto it = g_plans.find(key);
     if (it != g_plans.end()) return &it->second;
     int ni, no;
@@ -437,18 +438,12 @@ void launch_resample(const ResamplePlan &pl, const float *d_in, size_t in_stride
     const size_t span_bytes = ((size_t)63 * pl.hop + pl.K) * sizeof(float);
     const size_t red_bytes = (size_t)4 * 3 * RS_MT * 64 * sizeof(float4);
     const size_t smem = std::max(span_bytes, red_bytes);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)resample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    static DeviceOnce attr_set;
+    attr_set.run([] { (void)hipFuncSetAttribute((const void *)resample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     dim3 grid((frames + 63) / 64, pl.nblk, n_seg), block(256);
     if (split_f16) {
-        static bool attr16_set = false;
-        if (!attr16_set) {
-            (void)hipFuncSetAttribute((const void *)resample16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr16_set = true;
-        }
+        static DeviceOnce attr16_set;
+        attr16_set.run([] { (void)hipFuncSetAttribute((const void *)resample16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
         const size_t smem16 = std::max(span_bytes, (size_t)4 * 3 * RS16_MT * 64 * sizeof(float4));
         dim3 grid16((frames + 63) / 64, 2 * pl.nblk, n_seg);
         hipLaunchKernelGGL(resample16_kernel, grid16, block, smem16, s, d_in, in_stride, src_len, d_out, out_stride, out_len,

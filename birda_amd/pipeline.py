@@ -5,7 +5,7 @@ from __future__ import annotations
 
 import ctypes as C
 from dataclasses import dataclass
-from typing import List, Optional, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -114,6 +114,137 @@ def project_scores(geomodel_labels: List[str], reported: List[Tuple[str, float]]
     return out[:n].copy(), MappingSummary(mapped.value, n, n - mapped.value, in_range.value)
 
 
+def format_mask(formats: Sequence[str]) -> int:
+    """OutputFormat::from_str (config/types.rs:354-370) onto the BHH_FORMAT_* bits."""
+    mask = 0
+    for f in formats:
+        if f.lower() not in _lib.FORMATS:
+            raise ValueError(f"InvalidOutputFormat: {f}")
+        mask |= _lib.FORMATS[f.lower()]
+    return mask
+
+
+def output_path_for(input_path: str, output_dir: Optional[str], fmt: str) -> str:
+    """coordinator.rs:41-94."""
+    buf = C.create_string_buffer(4096)
+    _lib.load().bhh_output_path_for(input_path.encode(), output_dir.encode() if output_dir else None,
+                                    _lib.FORMATS[fmt], buf, 4096)
+    return buf.value.decode()
+
+
+def species_code(common_name: str) -> str:
+    """generate_species_code (raven.rs:72-84)."""
+    buf = C.create_string_buffer(64)
+    _lib.load().bhh_species_code(common_name.encode("utf-8"), buf, 64)
+    return buf.value.decode("utf-8")
+
+
+def format_float(kind: int, value: float) -> str:
+    buf = C.create_string_buffer(512)
+    _lib.load().bhh_format_float(kind, value, buf, 512)
+    return buf.value.decode()
+
+
+class OutputWriter:
+    """One of the six writers behind write_output (processor.rs:819-873): write_header / write_detection / finalize."""
+
+    def __init__(self, fmt: str, path: str, csv_bom: bool = True, csv_columns: Optional[Sequence[str]] = None,
+                 source_file: str = "", model: str = "", min_confidence: float = 0.1, overlap: float = 0.0,
+                 audio_duration: float = 0.0, lat: Optional[float] = None, lon: Optional[float] = None,
+                 week: Optional[int] = None):
+        self._L = _lib.load()
+        self._keep = [",".join(csv_columns).encode() if csv_columns else None, source_file.encode(), model.encode()]
+        opt = _lib.BhhWriterOptions(int(csv_bom), self._keep[0], self._keep[1], self._keep[2], min_confidence, overlap,
+                                    audio_duration, int(lat is not None), int(lon is not None), lat or 0.0, lon or 0.0,
+                                    -1 if week is None else week)
+        h = C.c_void_p()
+        _hcheck(self._L.bhh_writer_open(_lib.FORMATS[fmt], path.encode(), C.byref(opt), C.byref(h)))
+        self._h = h
+
+    def write_header(self):
+        _hcheck(self._L.bhh_writer_write_header(self._h))
+
+    def write_detection(self, label: str, confidence: float, start_time: float, end_time: float, file_path: str):
+        _hcheck(self._L.bhh_writer_write_detection(self._h, label.encode("utf-8"), confidence, start_time, end_time,
+                                                   file_path.encode("utf-8")))
+
+    def finalize(self):
+        h, self._h = self._h, None
+        if h:
+            _hcheck(self._L.bhh_writer_finalize(h))
+
+
+class ProgressReporter:
+    """JsonProgressReporter (reporter.rs:170-420): NDJSON (a line per event) or JSON (one array at the end)."""
+
+    def __init__(self, mode: str = "ndjson", path: Optional[str] = None):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        _hcheck(self._L.bhh_reporter_open({"ndjson": _lib.REPORT_NDJSON, "json": _lib.REPORT_JSON}[mode],
+                                          path.encode() if path else None, C.byref(h)))
+        self._h = h
+
+    def pipeline_started(self, total_files, model, min_confidence, requested, actual, fallback_reason=None, range_filter=None):
+        rf = None
+        if range_filter is not None:
+            rf = _lib.BhhRangeFilterInfo(range_filter["geomodel_version"].encode(), range_filter["species_in_range"],
+                                         range_filter["total_species"], range_filter["mapped_species"],
+                                         range_filter["unmatched_species"], range_filter["unmatched_policy"].encode(),
+                                         range_filter["threshold"])
+        self._L.bhh_reporter_pipeline_started(self._h, total_files, model.encode(), min_confidence, requested.encode(),
+                                              actual.encode(), fallback_reason.encode() if fallback_reason else None,
+                                              C.byref(rf) if rf is not None else None)
+
+    def file_started(self, file, index, estimated_segments, duration_seconds=None):
+        self._L.bhh_reporter_file_started(self._h, file.encode(), index, estimated_segments,
+                                          int(duration_seconds is not None), duration_seconds or 0.0)
+
+    def file_progress(self, path, segments_done, segments_total, percent) -> bool:
+        return bool(self._L.bhh_reporter_file_progress(self._h, path.encode(), segments_done, segments_total, percent))
+
+    def batch_progress(self, current, total, percent):
+        self._L.bhh_reporter_batch_progress(self._h, current, total, percent)
+
+    def file_completed_success(self, file, detections, duration_ms):
+        self._L.bhh_reporter_file_completed(self._h, file.encode(), 0, detections, duration_ms, None, None)
+
+    def file_completed_failure(self, file, error_code, error_message):
+        self._L.bhh_reporter_file_completed(self._h, file.encode(), 1, 0, 0, error_code.encode(), error_message.encode())
+
+    def file_skipped(self, file, locked=False):
+        self._L.bhh_reporter_file_completed(self._h, file.encode(), 3 if locked else 2, 0, 0, None, None)
+
+    def detections(self, file, dets):
+        """dets: (label, confidence, start_time, end_time) tuples."""
+        n = len(dets)
+        raw = [d[0].encode("utf-8") for d in dets]
+        labels = (C.c_char_p * max(1, n))(*raw)
+        conf = np.asarray([d[1] for d in dets] or [0.0], np.float32)
+        st = np.asarray([d[2] for d in dets] or [0.0], np.float32)
+        en = np.asarray([d[3] for d in dets] or [0.0], np.float32)
+        self._L.bhh_reporter_detections(self._h, file.encode(), labels, conf.ctypes.data, st.ctypes.data, en.ctypes.data, n)
+
+    def pipeline_completed(self, files_processed, files_failed, files_skipped, total_detections, total_segments,
+                           duration_ms, realtime_factor):
+        self._L.bhh_reporter_pipeline_completed(self._h, files_processed, files_failed, files_skipped, total_detections,
+                                                total_segments, duration_ms, realtime_factor)
+
+    def error(self, code, fatal, message, suggestion=None):
+        self._L.bhh_reporter_error(self._h, code.encode(), int(fatal), message.encode(),
+                                   suggestion.encode() if suggestion else None)
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._L.bhh_reporter_close(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 @dataclass
 class ProcessResult:
     detections: int
@@ -125,20 +256,32 @@ class ProcessResult:
     batches: int
     padded_rows: int
     output_path: str
+    front_end: str = "host"
+    formats_written: int = 0
 
 
 def process_file(classifier, input_path: str, output_dir: Optional[str] = None, min_confidence: float = 0.1,
-                 overlap: float = 0.0, batch_size: int = 8, csv_bom: bool = True,
-                 display_path: Optional[str] = None) -> ProcessResult:
+                 overlap: float = 0.0, batch_size: int = 0, csv_bom: bool = True,
+                 display_path: Optional[str] = None, formats: Sequence[str] = ("csv",), front_end: str = "auto",
+                 csv_columns: Optional[Sequence[str]] = None, model_name: str = "", lat: Optional[float] = None,
+                 lon: Optional[float] = None, week: Optional[int] = None, reporter: Optional[ProgressReporter] = None,
+                 dual_output: bool = False) -> ProcessResult:
+    """process_file (processor.rs:418-796).  batch_size 0 = the backend's default (determine_default_batch_size);
+    front_end "host" keeps the reference's decode-thread + padded-batch structure, "device" / "auto" run decode
+    scaling, mono mix, segmentation and resampling on the GPU for PCM16 WAV input."""
     L = _lib.load()
     cfg = BhhProcessingConfig(input_path.encode(), output_dir.encode() if output_dir else None,
                               display_path.encode() if display_path else None, min_confidence, overlap, batch_size,
-                              int(csv_bom))
+                              int(csv_bom), format_mask(formats), _lib.FRONT_ENDS[front_end],
+                              ",".join(csv_columns).encode() if csv_columns else None, model_name.encode(),
+                              int(lat is not None), int(lon is not None), lat or 0.0, lon or 0.0,
+                              -1 if week is None else week, reporter._h if reporter is not None else None,
+                              int(dual_output))
     res = BhhProcessResult()
     _hcheck(L.bhh_process_file(classifier._h, C.byref(cfg), C.byref(res)))
     return ProcessResult(res.detections, res.segments, res.duration_secs, res.audio_duration_secs,
                          res.segments_per_sec, res.effective_batch, res.batches, res.padded_rows,
-                         res.output_path.decode())
+                         res.output_path.decode(), "device" if res.front_end == 2 else "host", res.formats_written)
 
 
 def collect_input_files(paths: List[str]) -> List[str]:

@@ -35,7 +35,9 @@ typedef enum {
     BH_ERR_NO_DEVICE = -3, /* no HIP device / device index out of range */
     BH_ERR_HIP = -4,       /* a HIP runtime call failed; message carries hipGetErrorString */
     BH_ERR_LABELS = -5,    /* label count != model output width (inference/mod.rs:34-37) */
-    BH_ERR_UNSUPPORTED = -6
+    BH_ERR_UNSUPPORTED = -6,
+    BH_ERR_INTERNAL = -7,  /* host allocation failure or another C++ exception stopped at the ABI boundary */
+    BH_ERR_NONFINITE = -8  /* an f16-operand forward produced inf / NaN logits (operand outside the f16 range) */
 } bh_status;
 
 #define BH_MAX_TOP_K 32
@@ -75,6 +77,8 @@ typedef struct {
     uint32_t n_layers;
     uint64_t macs_per_segment;  /* conv stack multiply-accumulates (for MFMA utilisation) */
     uint64_t mel_flops_per_segment;
+    uint32_t model_type;        /* BH_MODEL_* */
+    uint32_t precision;         /* BH_FLAG_F32 / F16X3 / F16 the classifier was built with */
 } bh_model_info;
 
 /* birdnet_onnx::PredictionResult{predictions: Vec<Prediction{species, confidence, index}>}
@@ -92,6 +96,46 @@ typedef struct bh_batch_context bh_batch_context;
 BH_API int bh_device_count(void);
 BH_API const char *bh_backend_name(void); /* "HIP (gfx950)" */
 BH_API const char *bh_last_error(void);
+
+/* ---- execution-provider arm (classifier.rs:662-1089) and default batch size (lib.rs:256-288) ----------
+ * ExecutionProviderStatus{requested, actual, fallback_reason} (classifier.rs:23-30), plus what
+ * `birda providers` prints about a backend (lib.rs:1173-1247). */
+typedef struct {
+    char requested[32];        /* the device text the caller asked for, lower-cased: "auto", "gpu", "hip", "rocm", "cpu" */
+    char actual[32];           /* "HIP" when a gfx950 device serves the run, else "CPU" (= this library is not used) */
+    char fallback_reason[256]; /* "" = None */
+    int32_t device;            /* HIP ordinal that would serve, -1 when actual is "CPU" */
+    uint32_t device_count;
+    char device_name[128];     /* hipDeviceProp_t::name */
+    char arch[32];             /* gcnArchName, e.g. "gfx950:sramecc+:xnack-" */
+    uint32_t compute_units;
+    uint64_t hbm_bytes;
+} bh_provider_status;
+/* select_execution_provider's arm for this backend.  requested (ASCII, any case):
+ *   "cpu"            -> actual "CPU", no reason (InferenceDevice::Cpu, :696-705): the caller keeps its ORT CPU path
+ *   "auto" / "gpu"   -> "HIP" when a device exists (this backend goes first in gpu_priority), else actual "CPU" with
+ *                       fallback_reason "No GPU providers available" (:742-754, :843-854)
+ *   "hip" / "rocm"   -> explicit (configure_explicit_provider, :924-984): "HIP", or BH_ERR_NO_DEVICE when no device
+ *                       exists (provider_unavailable_error); nothing else is accepted (BH_ERR_INVALID).
+ * device_ordinal < 0 picks ordinal 0. */
+BH_API int bh_select_provider(const char *requested, int32_t device_ordinal, bh_provider_status *out);
+/* The status a built classifier runs under (BirdClassifier::execution_provider_status). */
+BH_API int bh_classifier_provider_status(const bh_classifier *c, bh_provider_status *out);
+
+/* ModelType (config/types.rs:375-388) as carried in the model container's header */
+#define BH_MODEL_BIRDNET_V24 0u
+#define BH_MODEL_PERCH_V2 1u
+#define BH_MODEL_BIRDNET_V30 2u
+#define BH_MODEL_BSG_FINLAND 3u
+#define BH_MIN_BATCH_SIZE 1   /* constants.rs:44 */
+#define BH_MAX_BATCH_SIZE 512 /* constants.rs:55 */
+/* determine_default_batch_size(model_type, ep_status) (lib.rs:256-288; constants.rs:58-73) with this backend's arm:
+ * (_, "CPU") 8; (v2.4 | BSG, "CUDA") 64; (v3.0 | Perch, "CUDA") 32; (_, "TensorRT") 32; (_, "HIP") 256; else 16.
+ * 256 = half of MAX_BATCH_SIZE: every launch of the late blocks then has >= 128 workgroups and one batch context
+ * holds ~1 GB.  provider_actual NULL = "HIP". */
+BH_API size_t bh_default_batch_size(uint32_t model_type, const char *provider_actual);
+/* the same for a built classifier (its model family, provider "HIP") */
+BH_API size_t bh_classifier_default_batch_size(const bh_classifier *c);
 
 /* ClassifierBuilder::build() (classifier.rs:281-283).  Loads the model, uploads weights,
  * precomputes the folded STFT*mel operators, validates the label count. */

@@ -46,6 +46,92 @@ BH_API size_t bhh_csv_header(int bom, char *out, size_t cap);
 BH_API size_t bhh_csv_row(const char *label, float start, float end, float conf, const char *path,
                           char *out, size_t cap);
 
+/* ---- result writers (reference src/output/{csv,raven,...}.rs behind write_output, processor.rs:819-873) ------------ */
+/* OutputFormat (config/types.rs:326-339) as a bit mask */
+#define BHH_FORMAT_CSV 1u          /* <stem>.BirdNET.results.csv               csv.rs */
+#define BHH_FORMAT_RAVEN 2u        /* <stem>.BirdNET.selection.table.txt       raven.rs */
+#define BHH_FORMAT_AUDACITY 4u     /* <stem>.BirdNET.results.txt               audacity.rs */
+#define BHH_FORMAT_KALEIDOSCOPE 8u /* <stem>.BirdNET.results.kaleidoscope.csv  kaleidoscope.rs */
+#define BHH_FORMAT_JSON 16u        /* <stem>.BirdNET.json                      json.rs */
+#define BHH_FORMAT_PARQUET 32u     /* <stem>.BirdNET.results.parquet           parquet.rs */
+#define BHH_FORMAT_ALL 63u
+
+typedef struct {
+    int csv_bom;              /* CsvWriter::new include_bom */
+    const char *csv_columns;  /* comma-separated additional columns (CSV header + empty cells; Parquet nullable columns) or NULL */
+    const char *source_file;  /* JsonResultWriter::new(output_path, source_file, audio_duration, model, min_confidence, */
+    const char *model;        /*                       overlap, lat, lon, week), json.rs:107-131 */
+    float min_confidence, overlap, audio_duration;
+    int has_lat, has_lon;
+    double lat, lon;
+    int week;                 /* -1 = None */
+} bhh_writer_options;
+
+typedef struct bhh_writer bhh_writer;
+/* OutputWriter (writer.rs:7-18): new / write_header / write_detection / finalize; finalize also frees the handle.
+ * write_detection takes what Detection::from_label takes (types.rs:58-79). */
+BH_API int bhh_writer_open(uint32_t format, const char *path, const bhh_writer_options *opt, bhh_writer **out);
+BH_API int bhh_writer_write_header(bhh_writer *w);
+BH_API int bhh_writer_write_detection(bhh_writer *w, const char *label, float confidence, float start_time, float end_time,
+                                      const char *file_path);
+BH_API int bhh_writer_finalize(bhh_writer *w);
+/* output_dir_for + output_path_for (coordinator.rs:41-94): stem sanitised, extension by format; output_dir NULL / "" = next
+ * to the input.  Returns the length (0 = unknown format); out receives the text when cap allows. */
+BH_API size_t bhh_output_path_for(const char *input_path, const char *output_dir, uint32_t format, char *out, size_t cap);
+/* generate_species_code (raven.rs:72-84) */
+BH_API size_t bhh_species_code(const char *common_name, char *out, size_t cap);
+/* float formatting the writers rely on: Rust `{}` (core::fmt, shortest digits, no exponent) and serde_json (ryu) */
+#define BHH_FLOAT_DISPLAY_F32 0
+#define BHH_FLOAT_DISPLAY_F64 1
+#define BHH_FLOAT_JSON_F32 2
+#define BHH_FLOAT_JSON_F64 3
+BH_API size_t bhh_format_float(int kind, double value, char *out, size_t cap);
+
+/* ---- progress reporter (reference src/output/reporter.rs:22-420: JsonProgressReporter) ------------------
+ * One JSON envelope {spec_version "1.1", timestamp, event, payload} per event (json_envelope.rs:13-61).  NDJSON mode
+ * writes and flushes a line per event; JSON mode buffers and prints one array at pipeline_completed. */
+#define BHH_REPORT_NDJSON 1
+#define BHH_REPORT_JSON 2
+typedef struct bhh_reporter bhh_reporter;
+typedef struct {   /* RangeFilterInfo (json_envelope.rs:176-193) */
+    const char *geomodel_version;
+    size_t species_in_range, total_species, mapped_species, unmatched_species;
+    const char *unmatched_policy;   /* "keep" | "drop" */
+    float threshold;
+} bhh_range_filter_info;
+BH_API int bhh_reporter_open(int mode, const char *path /* NULL = stdout */, bhh_reporter **out);
+BH_API void bhh_reporter_close(bhh_reporter *r);
+BH_API void bhh_reporter_pipeline_started(bhh_reporter *r, size_t total_files, const char *model, float min_confidence,
+                                          const char *requested, const char *actual, const char *fallback_reason /* NULL = None */,
+                                          const bhh_range_filter_info *range_filter /* NULL = None */);
+BH_API void bhh_reporter_file_started(bhh_reporter *r, const char *file, size_t index, size_t estimated_segments, int has_duration,
+                                      double duration_seconds);
+/* progress(None, Some(file)) is throttled (10 % or 500 ms; always at 0 % and 100 %): returns 1 when the event was written */
+BH_API int bhh_reporter_file_progress(bhh_reporter *r, const char *path, size_t segments_done, size_t segments_total, float percent);
+BH_API void bhh_reporter_batch_progress(bhh_reporter *r, size_t current, size_t total, float percent);
+#define BHH_FILE_PROCESSED 0
+#define BHH_FILE_FAILED 1
+#define BHH_FILE_SKIPPED 2
+#define BHH_FILE_LOCKED 3
+BH_API void bhh_reporter_file_completed(bhh_reporter *r, const char *file, int status, size_t detections, uint64_t duration_ms,
+                                        const char *error_code, const char *error_message);
+BH_API void bhh_reporter_detections(bhh_reporter *r, const char *file, const char *const *labels, const float *confidence,
+                                    const float *start_time, const float *end_time, size_t n);
+BH_API void bhh_reporter_pipeline_completed(bhh_reporter *r, size_t files_processed, size_t files_failed, size_t files_skipped,
+                                            size_t total_detections, size_t total_segments, uint64_t duration_ms, double realtime_factor);
+BH_API void bhh_reporter_error(bhh_reporter *r, const char *code, int fatal, const char *message, const char *suggestion /* NULL = None */);
+
+/* ---- per-file pipeline --------------------------------------------------------------------------- */
+/* Where decode + segmentation run:
+ *   HOST    the reference's structure: a decode thread (decode_and_stream, processor.rs:49-108) feeds AudioChunks through a
+ *           bounded channel to the batcher (run_streaming_inference, :114-190), which zero-pads the last batch (:240-258).
+ *   DEVICE   the file's PCM16 frames are mapped, uploaded as int16 and scaled / mixed / windowed / resampled on
+ *           the GPU (bh_predict_pcm16); the same detections, no padding rows, no per-segment host work.
+ *   AUTO    DEVICE when the file is PCM16 WAV, else HOST. */
+#define BHH_FRONT_END_AUTO 0u
+#define BHH_FRONT_END_HOST 1u
+#define BHH_FRONT_END_DEVICE 2u
+
 /* ProcessingConfig (reference src/pipeline/config.rs:32-66), the fields this path uses */
 typedef struct {
     const char *input_path;
@@ -53,8 +139,17 @@ typedef struct {
     const char *display_path; /* path text written in the File column; NULL = input_path */
     float min_confidence;     /* 0.1 */
     float overlap;            /* seconds, 0.0 */
-    size_t batch_size;        /* CLI -b; 0 = 8 */
+    size_t batch_size;        /* CLI -b; 0 = bh_classifier_default_batch_size() (determine_default_batch_size, lib.rs:1035) */
     int csv_bom;              /* default on, lib.rs:1078 */
+    uint32_t formats;         /* BHH_FORMAT_* mask; 0 = CSV (config default [csv], config/types.rs:185-205) */
+    uint32_t front_end;       /* BHH_FRONT_END_* */
+    const char *csv_columns;  /* config.csv_columns (config.rs:46) or NULL */
+    const char *model_name;   /* JsonOutputConfig.model (processor.rs:800-815) */
+    int has_lat, has_lon;     /* JsonOutputConfig lat / lon / week */
+    double lat, lon;
+    int week;                 /* -1 = None */
+    bhh_reporter *reporter;   /* config.reporter (processor.rs:438): progress + detections events; NULL = none */
+    int dual_output;          /* dual_output_mode (:721): with a reporter, also write the result files */
 } bhh_processing_config;
 
 /* ProcessResult (processor.rs:877-886) + batching counters */
@@ -62,7 +157,9 @@ typedef struct {
     size_t detections, segments;
     double duration_secs, audio_duration_secs, segments_per_sec;
     size_t effective_batch, batches, padded_rows;
-    char output_path[1024];
+    char output_path[1024];   /* the first format written (lowest bit) */
+    uint32_t front_end;       /* BHH_FRONT_END_HOST or BHH_FRONT_END_DEVICE: the one that ran */
+    uint32_t formats_written;
 } bhh_process_result;
 
 BH_API int bhh_process_file(bh_classifier *clf, const bhh_processing_config *cfg, bhh_process_result *res);

@@ -244,10 +244,18 @@ def test_c1_wav_to_csv_matches_oracle(full_model, oracle_lib, tmp_path):
     wav = str(tmp_path / "rec30s.wav")
     synth.write_wav_pcm16(wav, x, m.sample_rate)
     clf = BirdClassifier(path, labels, top_k=5, min_confidence=0.1)
-    res = pipeline.process_file(clf, wav, str(tmp_path), min_confidence=0.1, overlap=0.0, batch_size=8)
-    assert res.segments == 10 and res.effective_batch == 8 and res.batches == 2 and res.padded_rows == 6
+    # the reference's structure (decode thread, batches of 8 with zero-padded rows) ...
+    res = pipeline.process_file(clf, wav, str(tmp_path), min_confidence=0.1, overlap=0.0, batch_size=8, front_end="host")
+    assert res.segments == 10 and res.effective_batch == 8 and res.batches == 2 and res.padded_rows == 6 and res.front_end == "host"
     assert res.output_path.endswith("rec30s.BirdNET.results.csv")
     got = open(res.output_path, "rb").read()
+    # ... and the device front end at the backend's default batch size (256, capped to the 10 estimated segments): the
+    # PCM16 frames are scaled and windowed on the GPU, nothing is padded, the CSV is byte-identical
+    dev_dir = tmp_path / "dev"
+    dev_dir.mkdir()
+    rd = pipeline.process_file(clf, wav, str(dev_dir), min_confidence=0.1, overlap=0.0)
+    assert rd.front_end == "device" and rd.segments == 10 and rd.effective_batch == 10 and rd.batches == 1 and rd.padded_rows == 0
+    assert open(rd.output_path, "rb").read() == got
     # oracle on the PCM16-quantised samples, exactly what the decoder produces
     pcm = np.clip(np.round(x.astype(np.float64) * 32767.0), -32768, 32767).astype(np.int16)
     mono = np.zeros(pcm.size, np.float32)
@@ -278,16 +286,21 @@ def test_overlap_and_short_file_batching(clf_tiny, model_dir, oracle_lib, tmp_pa
     mono = np.zeros(pcm.size, np.float32)
     oracle_lib.lib().bo_pcm16_to_mono(pcm.ctypes.data, pcm.size, 1, mono)
     for overlap, batch, n_seg in ((0.0, 16, 4), (1.0, 4, 6), (1.5, 1, 7)):
-        res = pipeline.process_file(clf_tiny, wav, str(tmp_path), min_confidence=0.05, overlap=overlap, batch_size=batch)
+        res = pipeline.process_file(clf_tiny, wav, str(tmp_path), min_confidence=0.05, overlap=overlap, batch_size=batch, front_end="host")
         want, st = om.process_stream(names, mono, m.sample_rate, overlap, 0.05, 5, batch, True, wav)
         assert res.segments == st.n_segments == n_seg
         assert res.effective_batch == st.effective_batch and res.batches == st.n_batches
         assert res.padded_rows == st.n_padded_rows
-        g, w = open(res.output_path, "rb").read().decode().splitlines(), want.decode().splitlines()
+        host_csv = open(res.output_path, "rb").read()
+        g, w = host_csv.decode().splitlines(), want.decode().splitlines()
         assert len(g) == len(w)
         for a, b in zip(g[1:], w[1:]):
             fa, fb = a.rsplit(",", 2), b.rsplit(",", 2)
             assert fa[0] == fb[0] and abs(float(fa[1]) - float(fb[1])) <= 1.01e-4
+        # the device front end (same windows, the trailing overlap remainder included), spans cut at a batch of `batch`
+        rd = pipeline.process_file(clf_tiny, wav, str(tmp_path), min_confidence=0.05, overlap=overlap, batch_size=batch, front_end="device")
+        assert rd.front_end == "device" and rd.segments == n_seg and rd.padded_rows == 0
+        assert open(rd.output_path, "rb").read() == host_csv
 
 
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])

@@ -145,7 +145,7 @@ def test_c5_mixed_rate_files_through_the_pipeline(oracle_lib, model_dir, tmp_pat
         x = np.clip(0.1 * rng.standard_normal(n) + 0.3 * np.sin(2 * np.pi * 1500 * t) + 0.3 * np.sin(2 * np.pi * 4200 * t), -1, 1)
         wav = str(tmp_path / f"rec_{rate}.wav")
         synth.write_wav_pcm16(wav, x, rate)
-        res = pipeline.process_file(clf, wav, str(tmp_path), min_confidence=0.05, overlap=0.0, batch_size=4)
+        res = pipeline.process_file(clf, wav, str(tmp_path), min_confidence=0.05, overlap=0.0, batch_size=4, front_end="host")
         pcm = np.clip(np.round(x * 32767.0), -32768, 32767).astype(np.int16)
         mono = np.zeros(pcm.size, np.float32)
         oracle_lib.lib().bo_pcm16_to_mono(pcm.ctypes.data, pcm.size, 1, mono)
@@ -156,6 +156,15 @@ def test_c5_mixed_rate_files_through_the_pipeline(oracle_lib, model_dir, tmp_pat
         for a, b in zip(g[1:], w[1:]):
             fa, fb = a.rsplit(",", 2), b.rsplit(",", 2)
             assert fa[0] == fb[0] and fa[2] == fb[2] and abs(float(fa[1]) - float(fb[1])) <= 2e-4, (rate, a, b)
+        # device front end: PCM16 upload, scaling + windows + resampling on the GPU; same rows
+        dev = tmp_path / f"dev_{rate}"
+        dev.mkdir()
+        rd = pipeline.process_file(clf, wav, str(dev), min_confidence=0.05, overlap=0.0, batch_size=4, front_end="device")
+        gd = open(rd.output_path, "rb").read().decode().splitlines()
+        assert rd.front_end == "device" and rd.segments == 3 and len(gd) == len(g)
+        for a, b in zip(gd[1:], g[1:]):
+            fa, fb = a.rsplit(",", 2), b.rsplit(",", 2)
+            assert fa[0] == fb[0] and fa[2] == fb[2] and abs(float(fa[1]) - float(fb[1])) <= 1e-4, (rate, a, b)
     clf.close()
 
 
