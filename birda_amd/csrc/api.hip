@@ -1064,7 +1064,15 @@ int bh_classifier_ensure_warm(bh_classifier *c, size_t batch_size) try {
     std::vector<float> zero(c->model.h.sample_count, 0.0f);
     std::vector<const float *> segs(batch_size, zero.data());
     std::vector<bh_result> res(batch_size);
+    bool had_ctx;
+    { std::lock_guard<std::mutex> g(c->internal_mu); had_ctx = c->internal_ctx != nullptr; }
     int rc = bh_predict_batch(c, segs.data(), batch_size, zero.size(), res.data());
+    if (!had_ctx) {
+        // the warm-up's context is not kept: callers that batch create their own (process_file does, right after this
+        // call), and a second full-size arena for the classifier's lifetime would only double the memory
+        std::lock_guard<std::mutex> g(c->internal_mu);
+        if (c->internal_ctx) { ctx_destroy(c->internal_ctx); c->internal_ctx = nullptr; }
+    }
     if (rc != BH_OK) return rc;  // recorded only after success (classifier.rs:424)
     std::lock_guard<std::mutex> g(c->warm_mu);
     c->warmed.insert(batch_size);

@@ -131,6 +131,7 @@ def build_model(kind: str = "birdnet_v24", seed: int = WEIGHT_SEED,
     """kind: 'birdnet_v24' (full shape), 'birdnet_v24_tiny' (same front-end, toy stack),
     'mini' (short segments + toy stack, for second-scale CPU tests),
     'mini_b0' (short segments + the full EfficientNet-B0 channel plan),
+    'mini_hg' (toy stack ending in 32 channels + a 128-wide head: fused head conv + pool on a small arena),
     'perch_v2' (5 s / 32 kHz, Perch-shaped: one 128-mel branch, 14 795 classes)."""
     rng = np.random.default_rng(seed)
     b = _Builder(rng)
@@ -142,7 +143,7 @@ def build_model(kind: str = "birdnet_v24", seed: int = WEIGHT_SEED,
         stages = _B0_STAGES if kind == "birdnet_v24" else _TINY_STAGES
         stem, head, ncls, family = (32, 1024, 6522, 0) if kind == "birdnet_v24" else (8, 64, 50, 0)
         out_act = mf.OUT_SIGMOID
-    elif kind in ("mini", "mini_b0"):
+    elif kind in ("mini", "mini_b0", "mini_hg"):
         sr, n, dur = 48000, 12000, 0.25
         branches = [mf.Branch(512, 100, 32, (n - 512) // 100 + 1, 0.0, 3000.0, 1.23),
                     mf.Branch(256, 103, 32, (n - 256) // 103 + 1, 500.0, 15000.0, 1.23)]
@@ -150,6 +151,8 @@ def build_model(kind: str = "birdnet_v24", seed: int = WEIGHT_SEED,
         stages, stem, head, ncls, family, out_act = _TINY_STAGES, 8, 64, 50, 0, mf.OUT_SIGMOID
         if kind == "mini_b0":  # the full B0 channel plan on a short segment: every fused-block shape, small images
             stages, stem, head = _B0_STAGES, 32, 256
+        if kind == "mini_hg":  # toy stack whose last stage has 32 channels and a 128-wide head: the head conv + pool run as
+            stages, head = [(1, 3, 1, 8, 1), (4, 5, 2, 16, 2), (4, 3, 2, 32, 1)], 128   # one launch in the f16 modes
     elif kind == "perch_v2":
         # Perch v2: 5 s @ 32 kHz, 14 795 classes, softmax (manifests/Perch-v2-*).
         sr, n, dur = 32000, 160000, 5.0

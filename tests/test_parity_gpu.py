@@ -22,7 +22,7 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 LOGIT_RTOL = 2e-5
-F16_LOGIT_RTOL = 1e-2      # plain f16 MFMA operands (BH_FLAG_F16): measured 9e-4 on the full model
+F16_LOGIT_RTOL = 3e-3      # plain f16 MFMA operands (BH_FLAG_F16, BASELINE config 5): measured 9e-4 of the logit scale on the full model
 DEGENERATE_RTOL = 1e-2
 SPEC_MAX_ATOL = 2e-3
 SPEC_MEAN_ATOL = 1e-5
@@ -469,6 +469,25 @@ def test_precision_modes_on_the_full_model(full_model, oracle_lib):
     assert np.isfinite(out["f16"]).all() and e16 <= F16_LOGIT_RTOL * scale
     # same top-1 class in every mode
     assert (out["f16"].argmax(1) == ref.argmax(1)).all() and (out["f16x3"].argmax(1) == ref.argmax(1)).all()
+
+
+def test_fused_head_pool_on_a_small_arena(model_dir, oracle_lib):
+    """The head conv + GELU + pool launch reads the conv's input while finished workgroups already store pooled rows:
+    the arena plan must keep the two apart (on this toy stack first-fit used to put both at offset 0).  Many
+    segments, so that workgroups of the launch really overlap in time; every row against the oracle."""
+    from birda_amd import synth
+    from birda_amd.classifier import BirdClassifier
+    path, labels, m, _ = model_dir["mini_hg"]
+    segs = synth.synth_segments(96, m.sample_count, m.sample_rate, start=40)
+    ref = oracle_lib.OracleModel(path).forward(segs)
+    scale = max(1.0, float(np.abs(ref).max()))
+    for prec, tol in (("f16x3", LOGIT_RTOL), ("f16", F16_LOGIT_RTOL), ("f32", LOGIT_RTOL)):
+        clf = BirdClassifier(path, labels, precision=prec)
+        ctx = clf.create_batch_context(96)
+        for _ in range(3):
+            got = clf.predict_logits(ctx, segs)
+            assert np.abs(got - ref).max() <= tol * scale, (prec, float(np.abs(got - ref).max()), scale)
+        ctx.close(); clf.close()
 
 
 def test_fused_head_pool_matches_the_layer_kernels(full_model, oracle_lib, monkeypatch):
