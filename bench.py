@@ -6,18 +6,27 @@ under torch.distributed.run, one rank per GPU over RCCL.  One "step" = one pass 
 path (min/max -> STFT*mel -> stem -> fused MBConv blocks -> head -> logits -> sigmoid/top-k)
 over 1 000 synthetic segments per GPU that are already resident in HBM (BASELINE.json
 configs[1]); with N > 1 each rank owns its own 1 000-segment shard (weak scaling) and the only
-collective is the gather of the top-k results to rank 0.  Prints ONE JSON line on rank 0.
+collective is the gather of the packed top-k rows to rank 0.  Prints ONE JSON line on rank 0.
 
+`value` is the first timed region of exactly K steps (barrier + synchronise on both sides, max over ranks);
+`repeats` holds four more K-step regions and the median of the five.
 `roofline` is the dominant kernel (largest total time in the timed region): one of the fused
 MBConv kernels, priced in ALGORITHMIC flops (2 x MACs of the block's expand + depthwise +
-project convolutions, no halo / padding work) against the f32 MFMA peak; its launch duration
-comes from HIP events recorded on the context stream around every launch of the timed steps.
+project convolutions, no halo / padding work) against the MFMA peak of the instruction it uses; its launch
+duration comes from HIP events recorded on the context stream around every launch of the timed steps.
 `roofline_mel` is the front-end kernel against the HBM roofline (968 448 B per
-segment).  `cpu_baseline` is the oracle timed on this box's host cores over a bounded sample.
+segment).  `h2d_inclusive` and `end_to_end` (rank 0, N = 1) are the host-buffer entry points and the whole
+per-file pipeline (`bhh_process_file`: WAV in, CSV out), which pay the host copy and PCIe and are never `value`.
+`cpu_baseline` is the oracle timed on this box's host cores over a bounded sample.
+
+Other workloads: --config c3 (10 000 segments as 8 shards through the C ABI's bh_multi_*; on a 1-GPU box the shards
+are logical devices on ordinal 0), c4 (Perch-shaped model, 5 s / 32 kHz), c5 (22.05 / 44.1 / 48 kHz round-robin ->
+device resampler -> v2.4-shaped model with f16 MFMA operands).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import tempfile
 import time
@@ -26,10 +35,32 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 SEGMENTS_PER_GPU = 1000
-MEL_BYTES_PER_SEGMENT = 968_448          # 576 000 B read + 392 448 B written
 PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0            # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak
 PEAK_HBM_GBPS = 8000.0
+DTYPE = {"f32": "f32", "f16x3": "f16x3 (f32 operands split into f16 hi + lo, f32 accumulate)", "f16": "f16 (f32 accumulate)"}
+
+
+def mel_bytes_per_segment(m):
+    """the segment read once + the spectrogram written once (v2.4: 576 000 + 392 448 = 968 448 B)."""
+    return 4 * (m.sample_count + sum(b.n_mels * b.n_frames for b in m.branches))
+
+
+def reference_ort_leg(model_path, hip_logits_first, sample_count):
+    """SURVEY 8c / BASELINE.md 3.2: the true reference is ONNX Runtime (ORT_DYLIB_PATH, reference src/constants.rs:547)
+    running the published birdnet.onnx on the CPU EP.  When both are on the box (and the model on disk was converted
+    from that ONNX file: BIRDA_REFERENCE_ONNX), tools/ort_reference.py binds the ORT C API through ctypes and this
+    returns its throughput and max |dlogit|; otherwise a note saying which piece is missing."""
+    ort, onnx = os.environ.get("ORT_DYLIB_PATH", ""), os.environ.get("BIRDA_REFERENCE_ONNX", "")
+    if not (ort and os.path.exists(ort)):
+        return {"available": False, "note": "reference ORT path unavailable (no ORT_DYLIB_PATH on this box): compared against the CPU restatement"}
+    if not (onnx and os.path.exists(onnx)):
+        return {"available": False, "note": "libonnxruntime found but no BIRDA_REFERENCE_ONNX model: compared against the CPU restatement"}
+    try:
+        from tools import ort_reference
+        return ort_reference.run(ort, onnx, sample_count)
+    except Exception as e:   # noqa: BLE001 -- the opportunistic leg must never take the bench down
+        return {"available": False, "note": f"ORT reference leg failed: {e!r}"}
 
 
 def cpu_baseline(model_path, sample_count, sample_rate, hip_logits=None):
@@ -59,15 +90,10 @@ def cpu_baseline(model_path, sample_count, sample_rate, hip_logits=None):
     t = time.perf_counter()
     om.forward(segs)
     dt = time.perf_counter() - t
-    # the true reference is ONNX Runtime (ORT_DYLIB_PATH, constants.rs:547) running the published birdnet.onnx.
-    ort, onnx = os.environ.get("ORT_DYLIB_PATH", ""), os.environ.get("BIRDA_REFERENCE_ONNX", "")
-    if ort and onnx and os.path.exists(ort) and os.path.exists(onnx):
-        ref_note = ("ONNX Runtime and a reference model are present on this box, but this build carries no ORT binding yet "
-                    "(DESIGN.md section 8, lead 4): compared against the CPU restatement")
-    else:
-        ref_note = "reference ORT path unavailable (no ORT_DYLIB_PATH / birdnet.onnx on this box): compared against the CPU restatement"
-    return {"value": round(n / dt, 2), "unit": "segments/s", "cores": cores, "kind": "port", "reference": ref_note,
-            "sample": f"{n} synthetic 3 s/48 kHz segments, oracle/birda_oracle.c, OpenMP across segments "
+    return {"value": round(n / dt, 2), "unit": "segments/s", "cores": cores, "kind": "port",
+            "reference": reference_ort_leg(model_path, hip_logits, sample_count),
+            "readme_context": "reference README: 183 segments/s for BirdNET v2.4 on a 24-thread i7-13700K (ORT CPU EP, batch 8)",
+            "sample": f"{n} synthetic segments, oracle/birda_oracle.c, OpenMP across segments "
                       f"({cores} threads), fp32, {dt:.1f} s",
             "max_abs_dlogit_vs_oracle": parity}
 
@@ -80,22 +106,21 @@ def layers_have_fused_stem(m, layer_tot):
             and layer_tot[0][1] > 0 and layer_tot[1][1] == 0 and layer_tot[2][1] == 0)
 
 
-def pmc_traffic(kernel_prefix):
+def pmc_traffic(kernel_key):
     """HBM bytes per launch of a kernel from the newest committed PMC summary (profiles/*_traffic.json,
     collected with tools/profile_round.sh on this same command: two rocprofv3 --pmc passes, FETCH_SIZE
-    doubled for gfx950 as MI355X_MICROARCH.md prescribes).  None when no summary is committed."""
+    doubled for gfx950 as MI355X_MICROARCH.md prescribes).  kernel_key names the EXACT instantiation
+    (e.g. "bh::mel_kernel<6, 3>", "mbconv<3,2,16,...>"); None when no summary holds it."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
-    if not files:
-        return None
-    try:
-        d = json.load(open(files[-1]))
-    except (OSError, ValueError):
-        return None
-    for k, v in d.items():
-        if k.startswith(kernel_prefix):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        v = d.get(kernel_key)
+        if v:
             return {"bytes_per_launch": v["hbm_bytes_per_launch"], "read": v["read_bytes_per_launch"],
-                    "write": v["write_bytes_per_launch"], "source": os.path.basename(files[-1])}
+                    "write": v["write_bytes_per_launch"], "source": os.path.basename(path)}
     return None
 
 
@@ -118,13 +143,19 @@ def analyse(clf, m, info, fused, stage_tot, layer_tot, segs_done, steps, slices_
     layers = m.layers
     n_stem_blocks = 1 if (fused and layers_have_fused_stem(m, layer_tot)) else 0
     bi, i = 0, 0
+    if n_stem_blocks:
+        E, D, P = layers[0], layers[1], layers[2]
+        groups[("stem", E.cin, E.cout, P.cout, D.kh, D.sh, E.out_h, E.out_w)] = {
+            "ms": layer_tot[0][0], "launches": layer_tot[0][1], "macs": macs(E) + macs(D) + macs(P),
+            "kernel": clf.fused_kernel_name(fused[0]), "stem": True}
+        i = 3
     while fused and i + 2 < len(layers) and bi + n_stem_blocks < len(fused):
         E, D, P = layers[i], layers[i + 1], layers[i + 2]
         if (E.op == mf.OP_PWCONV and D.op == mf.OP_DWCONV and P.op == mf.OP_PWCONV and D.in_tensor == i + 1
                 and P.in_tensor == i + 2 and layer_tot[i][1] > 0 and layer_tot[i + 1][1] == 0):
             key = (E.cin, E.cout, P.cout, D.kh, D.sh, E.in_h, E.in_w)
             g = groups.setdefault(key, {"ms": 0.0, "launches": 0, "macs": macs(E) + macs(D) + macs(P),
-                                        "kernel": clf.fused_kernel_name(fused[bi + n_stem_blocks])})
+                                        "kernel": clf.fused_kernel_name(fused[bi + n_stem_blocks]), "stem": False})
             g["ms"] += layer_tot[i][0]
             g["launches"] += layer_tot[i][1]
             bi += 1
@@ -149,9 +180,14 @@ def analyse(clf, m, info, fused, stage_tot, layer_tot, segs_done, steps, slices_
             peak, note, insn = PEAK_F16_MFMA_TFLOPS, "dense f16 MFMA peak", "v_mfma_f32_16x16x32_f16"
         total_flops = 2.0 * dom["macs"] * segs_done * n_blocks
         tflops = total_flops / (dom["ms"] * 1e-3) / 1e12
+        if dom["stem"]:
+            desc = "stem conv %dx%d s%d (im2col GEMM) -> depthwise -> project 1x1, %d -> %d -> %d at %dx%d" % (
+                3, 3, 2, dom_key[1], dom_key[2], dom_key[3], dom_key[6], dom_key[7])
+        else:
+            desc = "expand 1x1 -> depthwise %dx%d s%d -> project 1x1, Cin %d -> %d -> %d at %dx%d" % (
+                dom_key[3], dom_key[3], dom_key[4], dom_key[0], dom_key[1], dom_key[2], dom_key[5], dom_key[6])
         out["roofline"] = {
-            "kernel": "mbconv_kernel (fused expand 1x1 -> depthwise %dx%d s%d -> project 1x1, Cin %d -> %d -> %d at %dx%d, %s)"
-                      % (dom_key[3], dom_key[3], dom_key[4], dom_key[0], dom_key[1], dom_key[2], dom_key[5], dom_key[6], insn),
+            "kernel": "mbconv_kernel (fused %s, %s)" % (desc, insn),
             "bound": "mfma", "achieved": round(tflops, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(tflops / peak, 4), "peak_note": note, "traffic": pmc_traffic(dom["kernel"]),
             "rocprof_name": "bh::mbconv_kernel<" + dom["kernel"][len("mbconv<"):],
@@ -161,16 +197,93 @@ def analyse(clf, m, info, fused, stage_tot, layer_tot, segs_done, steps, slices_
             flops = 2.0 * sum(g["macs"] * max(1, g["launches"] // (steps * slices_per_step)) for g in groups.values()) * segs_done
             out["all_fused_blocks"] = {"achieved": round(flops / (mb_ms * 1e-3) / 1e12, 2), "unit": "TFLOP/s (algorithmic)",
                                        "launches": mb_launches, "us_per_segment": round(mb_ms * 1e3 / segs_done, 3)}
+            out["fused_block_us_per_1000_segments"] = {g["kernel"]: round(g["ms"] * 1e3 / segs_done * 1000 / max(1, g["launches"] // (steps * slices_per_step)), 1)
+                                                       for g in groups.values()}
     mel_ms, mel_launches = stage_tot["mel"]
-    mel_gbps = MEL_BYTES_PER_SEGMENT * segs_done / (mel_ms * 1e-3) / 1e9
-    out["roofline_mel"] = {"kernel": "mel_kernel (folded STFT x mel, %s)" % (
-                               "split f16 x3 MFMA" if (precision != "f32" and os.environ.get("BIRDA_HIP_MEL_F32") != "1")
-                               else "v_mfma_f32_16x16x4_f32"), "bound": "hbm",
-                           "achieved": round(mel_gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
-                           "frac": round(mel_gbps / PEAK_HBM_GBPS, 4), "traffic": pmc_traffic("bh::mel_kernel"),
+    mel_b = mel_bytes_per_segment(m)
+    mel_gbps = mel_b * segs_done / (mel_ms * 1e-3) / 1e9
+    f16_fe = precision != "f32" and os.environ.get("BIRDA_HIP_MEL_F32") != "1"
+    mel_key = clf.mel_kernel_name() if hasattr(clf, "mel_kernel_name") else None
+    out["roofline_mel"] = {"kernel": "%s (folded STFT x mel, %s)" % (mel_key or "mel_kernel", "split f16 x3 MFMA" if f16_fe else "v_mfma_f32_16x16x4_f32"),
+                           "bound": "hbm", "achieved": round(mel_gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s",
+                           "frac": round(mel_gbps / PEAK_HBM_GBPS, 4), "algorithmic_bytes_per_segment": mel_b,
+                           "traffic": pmc_traffic(mel_key) if mel_key else None,
                            "launches": mel_launches, "avg_launch_us": round(mel_ms * 1e3 / max(mel_launches, 1), 2),
                            "mfma_tflops": round(info.mel_flops_per_segment * segs_done / (mel_ms * 1e-3) / 1e12, 2)}
     out["stage_us_per_segment"] = {k: round(v[0] * 1e3 / segs_done, 3) for k, v in stage_tot.items()}
+    return out
+
+
+def torch_gather_rows(rows, n_total, rank, world, on_host):
+    """The one collective of the path: packed int32 top-k rows of every rank to rank 0, in segment order
+    (all_gather_into_tensor over RCCL; gloo gather in the CPU tests and the 1-GPU dry run)."""
+    import torch
+    import torch.distributed as dist
+    from birda_amd import sharding
+    if world == 1:
+        return rows
+    sizes = [sharding.shard_range(n_total, r, world) for r in range(world)]
+    max_n = max(hi - lo for lo, hi in sizes)
+    pad = torch.zeros((max_n, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+    pad[: rows.shape[0]] = rows
+    if not on_host and dist.get_backend() == "nccl":
+        out = torch.empty((world * max_n, rows.shape[1]), dtype=rows.dtype, device=rows.device)
+        dist.all_gather_into_tensor(out, pad)
+        if rank != 0:
+            return None
+        return torch.cat([out[r * max_n: r * max_n + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], 0)
+    bufs = [torch.empty_like(pad) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad, bufs, dst=0)
+    if rank != 0:
+        return None
+    return torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], 0)
+
+
+def host_legs(clf, m, model_path, precision, tmp):
+    """H2D-inclusive entry points and the end-to-end per-file pipeline (rank 0, N = 1; BASELINE.md 3.5 (b), reference metric
+    definition processor.rs:771-788).  Bounded: three calls each on 1 000 segments."""
+    import numpy as np
+    from birda_amd import pipeline, synth
+    n = SEGMENTS_PER_GPU
+    uniq = synth.synth_segments(16, m.sample_count, m.sample_rate)
+    host = np.ascontiguousarray(np.tile(uniq, (n // 16 + 1, 1))[:n])
+    ctx = clf.create_batch_context(n)
+    out = {}
+    import ctypes as C
+    from birda_amd._lib import BhResult, check
+    arr = (BhResult * n)()
+
+    def timed(fn, reps=3):
+        fn()
+        ts = []
+        for _ in range(reps):
+            t = time.perf_counter(); fn(); ts.append(time.perf_counter() - t)
+        return statistics.median(ts)
+    t = timed(lambda: check(clf._L.bh_predict_batch_contig(clf._h, ctx._h, host.ctypes.data, n, arr)))
+    out["bh_predict_batch_contig"] = {"value": round(n / t, 1), "unit": "segments/s", "input": "pageable f32 host segments",
+                                      "pcm_gb_per_s": round(n * m.sample_count * 4 / t / 1e9, 2)}
+    pcm = np.clip(np.round(host.reshape(-1).astype(np.float64) * 32767.0), -32768, 32767).astype(np.int16)
+    t = timed(lambda: clf.predict_pcm16(ctx, pcm, m.sample_rate, 0))
+    out["bh_predict_pcm16"] = {"value": round(n / t, 1), "unit": "segments/s", "input": "decoded int16 stream, scaled / windowed on the device",
+                               "pcm_gb_per_s": round(pcm.nbytes / t / 1e9, 2)}
+    ctx.close()
+    # end to end: WAV file in, CSV out (decode + segment + classify + threshold + sort + write), device front end
+    wav = os.path.join(tmp, "bench_1000_segments.wav")
+    synth.write_wav_pcm16(wav, host.reshape(-1), m.sample_rate)
+    labels = os.path.join(tmp, "bench_labels.txt")
+    synth.write_labels(labels, m.n_classes)
+    from birda_amd.classifier import BirdClassifier
+    c2 = BirdClassifier(model_path, labels, top_k=5, min_confidence=0.1, device=clf.device, precision=precision)
+    e2e = {}
+    for fe, reps in (("device", 3), ("host", 1)):
+        pipeline.process_file(c2, wav, tmp, front_end=fe)
+        rs = [pipeline.process_file(c2, wav, tmp, front_end=fe) for _ in range(reps)]
+        r = sorted(rs, key=lambda x: x.segments_per_sec)[len(rs) // 2]
+        e2e[fe] = {"value": round(r.segments_per_sec, 1), "unit": "segments/s", "segments": r.segments, "detections": r.detections,
+                   "batch": r.effective_batch, "realtime_factor": round(r.audio_duration_secs / r.duration_secs, 1)}
+    c2.close()
+    out["end_to_end"] = {"what": "bhh_process_file on a synthetic %d-segment PCM16 WAV -> CSV (reference metric: segments / wall seconds, "
+                                 "processor.rs:771-788), default batch size" % n, **e2e}
     return out
 
 
@@ -181,11 +294,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--micro-batch", type=int, default=int(os.environ.get("BIRDA_HIP_MICRO_BATCH", "1000")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default=os.environ.get("BIRDA_HIP_BENCH_PRECISION", "f16x3"),
-                    choices=["f32", "f16x3", "f16"],
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the f32, H2D-inclusive and end-to-end legs (profiling runs)")
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
+                    help="BASELINE.json configs: c2 = configs[1] (the bench line), c3 = 10 000 segments as 8 shards through bh_multi_*, "
+                         "c4 = Perch-shaped model, c5 = mixed-rate input -> resampler -> f16 MFMA")
+    ap.add_argument("--precision", default=os.environ.get("BIRDA_HIP_BENCH_PRECISION", ""),
+                    choices=["", "f32", "f16x3", "f16"],
                     help="GEMM operands: f16x3 = f32 values split into f16 hi + lo, three f16 MFMAs per product, "
                          "f32 accumulate (same fp32 logit tolerance as f32); f32 = v_mfma_f32_16x16x4_f32 everywhere")
     args = ap.parse_args()
+    if not args.precision:
+        args.precision = "f16" if args.config == "c5" else "f16x3"
 
     import numpy as np
     import torch
@@ -212,26 +331,51 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    # seeded synthetic BirdNET-v2.4-shaped model (no real weights exist offline)
+    # seeded synthetic model (no real weights exist offline)
     tmp = tempfile.mkdtemp(prefix=f"birda_bench_r{rank}_")
-    model_path = os.path.join(tmp, "birdnet_v24_synth.bhm")
-    m = synth.build_model("birdnet_v24")
+    kind = "perch_v2" if args.config == "c4" else "birdnet_v24"
+    model_path = os.path.join(tmp, f"{kind}_synth.bhm")
+    m = synth.build_model(kind)
     mf.write_model(model_path, m)
+
+    if args.config == "c3" and world == 1:
+        return bench_c3_multi(args, m, model_path, tmp)
+
     clf = BirdClassifier(model_path, None, top_k=5, min_confidence=0.1, device=local_rank, precision=args.precision)
     ctx = clf.create_batch_context(args.micro_batch)
     info = clf.info
     fused = clf.fused_blocks()
 
-    n_local = SEGMENTS_PER_GPU
+    n_local = 10000 // world if args.config == "c3" else SEGMENTS_PER_GPU
     n_total = n_local * world
     lo, hi = sharding.shard_range(n_total, rank, world)
-    # segment i of the global list; 64 distinct seeds tiled keeps host prep short
-    uniq = synth.synth_segments(64, m.sample_count, m.sample_rate, start=0)
-    host = np.stack([uniq[(lo + j) % 64] for j in range(n_local)])
-    x = torch.from_numpy(host).cuda()
-    logits = torch.empty((n_local, m.n_classes), device="cuda")
+    logits = torch.empty((min(n_local, args.micro_batch) if args.config == "c3" else n_local, m.n_classes), device="cuda")
     tk_idx = torch.empty((n_local, 5), dtype=torch.int32, device="cuda")
     tk_conf = torch.empty((n_local, 5), device="cuda")
+    rates = [m.sample_rate]
+    if args.config == "c5":
+        # the same signal synthesised at 22 050 / 44 100 / 48 000 Hz round-robin over the global list; on the
+        # device the segments of one rate sit together (one resampler launch per rate), results return in list order
+        from birda_amd import pipeline
+        rates = [22050, 44100, 48000]
+        groups = []
+        for r in rates:
+            ids = [j for j in range(n_local) if (lo + j) % 3 == rates.index(r)]
+            src_len = pipeline.source_samples(m.sample_count, r, m.sample_rate)
+            uniq = synth.synth_segments(16, src_len, r, start=0)
+            host = np.stack([uniq[(lo + j) % 16] for j in ids])
+            groups.append({"rate": r, "src_len": src_len, "ids": torch.tensor(ids, device="cuda"), "x": torch.from_numpy(host).cuda(),
+                           "n": len(ids)})
+        x48 = torch.empty((n_local, m.sample_count), device="cuda")      # resampled (or copied) segments, grouped by rate
+        order = torch.cat([g["ids"] for g in groups])
+        inv = torch.empty_like(order)
+        inv[order] = torch.arange(n_local, device="cuda")
+        x = None
+    else:
+        # segment i of the global list; 64 distinct seeds tiled keeps host prep short
+        uniq = synth.synth_segments(64, m.sample_count, m.sample_rate, start=0)
+        host = np.stack([uniq[(lo + j) % 64] for j in range(n_local)])
+        x = torch.from_numpy(host).cuda()
 
     # The result gather runs on torch's stream; the forward runs on the context's own HIP stream.  Order them with
     # events (stream-to-stream, no host synchronise inside a step) when torch can wrap the context stream.
@@ -242,8 +386,24 @@ def main():
         except Exception:   # noqa: BLE001 -- fall back to a host synchronise per step
             ctx_stream = None
 
+    def forward_all(src_ptr):
+        if args.config == "c3":      # logits are scratch here: one micro-batch of rows
+            for b0 in range(0, n_local, args.micro_batch):
+                nb = min(args.micro_batch, n_local - b0)
+                clf.forward_device(ctx, src_ptr + b0 * m.sample_count * 4, nb, logits.data_ptr(), tk_idx.data_ptr() + b0 * 20, tk_conf.data_ptr() + b0 * 20)
+        else:
+            clf.forward_device(ctx, src_ptr, n_local, logits.data_ptr(), tk_idx.data_ptr(), tk_conf.data_ptr())
+
     def step():
-        clf.forward_device(ctx, x.data_ptr(), n_local, logits.data_ptr(), tk_idx.data_ptr(), tk_conf.data_ptr())
+        if args.config == "c5":
+            off = 0
+            for g in groups:     # decode_and_stream's resample_chunk + resize per segment (processor.rs:84-87), on the context stream
+                clf.resample_device(ctx, g["x"].data_ptr(), g["src_len"], g["src_len"], g["rate"], m.sample_rate,
+                                    x48.data_ptr() + off * m.sample_count * 4, m.sample_count, m.sample_count, g["n"])
+                off += g["n"]
+            forward_all(x48.data_ptr())
+        else:
+            forward_all(x.data_ptr())
         if world > 1:
             cur = torch.cuda.current_stream()
             if ctx_stream is not None:
@@ -252,12 +412,12 @@ def main():
                 cur.wait_event(done)                      # the gather's inputs are complete
             else:
                 ctx.synchronize()
-            packed = torch.cat([tk_idx.to(torch.float32), tk_conf], 1)
+            packed = torch.cat([tk_idx, tk_conf.view(torch.int32)], 1)     # indices stay integers; confidences travel as bit patterns
             if ctx_stream is not None:
                 read = torch.cuda.Event()
                 read.record(cur)
                 ctx_stream.wait_event(read)               # the next forward's top-k must not overwrite them earlier
-            sharding.gather_results(packed.cpu() if dryrun else packed, n_total, rank, world)
+            torch_gather_rows(packed.cpu() if dryrun else packed, n_total, rank, world, dryrun)
 
     def sync_all():
         ctx.synchronize()
@@ -265,78 +425,96 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def timed_region(k):
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()           # nothing in the timed region waits for the profiling events: they are read after it
+        sync_all()
+        e = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([e], device="cpu" if dryrun else "cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e = float(t.item())
+        return e
+
     for _ in range(args.warmup):
         step()
     sync_all()
 
     ctx.set_profiling(True)     # HIP events around every launch, on the context stream
-    stage_tot = {}
-    layer_tot = [[0.0, 0] for _ in range(int(info.n_layers))]
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()           # nothing in the timed region waits for the events: they are read after it
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    for k, (ms, n) in ctx.stage_ms().items():
-        stage_tot[k] = [ms, n]
-    for i, (ms, n) in enumerate(ctx.layer_ms()):
-        layer_tot[i] = [ms, n]
+    elapsed = timed_region(args.steps)
+    stage_tot = {k: [ms, n] for k, (ms, n) in ctx.stage_ms().items()}
+    layer_tot = [[ms, n] for (ms, n) in ctx.layer_ms()]
     ctx.set_profiling(False)
-    if world > 1:
-        t = torch.tensor([elapsed], device="cpu" if dryrun else "cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    # four more K-step regions: median of 5; `value` stays the first, the contract's region
+    more = [timed_region(args.steps) for _ in range(4)]
+    all_values = [n_total * args.steps / e for e in [elapsed] + more]
 
-    hip_logits = {args.precision: logits[:16].cpu().numpy()} if rank == 0 else None   # segments 0..15 of the global list
+    if args.config == "c5":
+        first = logits[inv[:16]].cpu().numpy()            # list order
+    else:
+        first = logits[:16].cpu().numpy()
+    hip_logits = {args.precision: first} if rank == 0 else None   # segments 0..15 of the global list
     value = n_total * args.steps / elapsed
     segs_done = n_local * args.steps
     slices_per_step = max(1, -(-n_local // args.micro_batch))
+    workloads = {
+        "c2": "configs[1]: 1000 synthetic 3 s/48 kHz segments per GPU per step, HBM-resident, seeded synthetic BirdNET-v2.4-shaped "
+              "model (EfficientNet-B0-like, 6522 classes)",
+        "c3": "configs[2]: 10 000 synthetic 3 s/48 kHz segments sharded over the ranks (contiguous blocks), HBM-resident, top-k gather to rank 0",
+        "c4": "configs[3]: 1000 synthetic 5 s/32 kHz segments per GPU per step, HBM-resident, seeded synthetic Perch-v2-shaped model "
+              "(one 128-mel branch, EfficientNet-B0-like, 14 795 classes, softmax)",
+        "c5": "configs[4]: 1000 segments per GPU per step synthesised at 22.05/44.1/48 kHz round-robin, HBM-resident at the SOURCE rate -> "
+              "device polyphase resampler -> BirdNET-v2.4-shaped model with f16 MFMA operands"}
+    metric = {"c4": "5s/32kHz segments/sec (Perch-v2-shaped)"}.get(args.config, "3s/48kHz segments/sec (BirdNET v2.4)")
     out = {
-        "metric": "3s/48kHz segments/sec (BirdNET v2.4)", "value": round(value, 1), "unit": "segments/s",
+        "metric": metric, "value": round(value, 1), "unit": "segments/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: 1000 synthetic 3 s/48 kHz segments per GPU per step, HBM-resident, "
-                               "seeded synthetic BirdNET-v2.4-shaped model (EfficientNet-B0-like, 6522 classes)",
+        "vs_baseline": None, "dtype": DTYPE[args.precision].split(" ")[0], "data": "synthetic",
+        "config": {"workload": workloads[args.config],
                    "segments_per_gpu": n_local, "micro_batch": args.micro_batch,
                    "gflop_per_segment": round((2 * info.macs_per_segment + info.mel_flops_per_segment) / 1e9, 3),
-                   "fused_blocks": len(fused), "precision": args.precision,
+                   "fused_blocks": len(fused), "precision": args.precision, "dtype_note": DTYPE[args.precision],
                    "gemm": {"f32": "v_mfma_f32_16x16x4_f32 (exact f32 fmaf chains)",
                             "f16x3": "f32 operands split into f16 hi + lo, 3 x v_mfma_f32_16x16x32_f16 per product, f32 "
                                      "accumulate (|err| ~1e-7 of sum|a b|, same fp32 logit tolerance as the f32 MFMA path, "
                                      "tests/test_parity_gpu.py)",
                             "f16": "operands rounded to f16, v_mfma_f32_16x16x32_f16, f32 accumulate"}[args.precision]},
+        "repeats": {"values": [round(v, 1) for v in all_values], "median_of_5": round(statistics.median(all_values), 1),
+                    "note": "five regions of exactly --steps steps each; `value` is the first"},
     }
     out.update(analyse(clf, m, info, fused, stage_tot, layer_tot, segs_done, args.steps, slices_per_step, args.precision))
-    if rank == 0 and world == 1 and args.precision != "f32":
-        # the exact-f32 MFMA path, measured beside it on the same inputs (a few steps; not the headline)
+    extra = rank == 0 and world == 1 and not args.no_extra_legs
+    if extra and args.config == "c2":
+        out.update(h2d_inclusive=None)
+        legs = host_legs(clf, m, model_path, args.precision, tmp)
+        out["end_to_end"] = legs.pop("end_to_end")
+        out["h2d_inclusive"] = legs
+    if extra and args.precision != "f32" and args.config in ("c2", "c4"):
+        # the exact-f32 MFMA path, measured beside it on the same inputs for the same number of steps (not the headline)
         ctx.close()
         clf.close()
         clf = BirdClassifier(model_path, None, top_k=5, min_confidence=0.1, device=local_rank, precision="f32")
         ctx = clf.create_batch_context(args.micro_batch)
         for _ in range(2):
             step()
-        sync_all()
         ctx.set_profiling(True)
-        st2, ly2 = {}, [[0.0, 0] for _ in range(int(info.n_layers))]
-        k2 = max(3, min(args.steps, 5))
-        t2 = time.perf_counter()
-        for _ in range(k2):
-            step()
-        sync_all()
-        e2 = time.perf_counter() - t2
-        for k, (ms, n) in ctx.stage_ms().items():
-            st2[k] = [ms, n]
-        for i, (ms, n) in enumerate(ctx.layer_ms()):
-            ly2[i] = [ms, n]
+        e2 = timed_region(args.steps)
+        st2 = {k: [ms, n] for k, (ms, n) in ctx.stage_ms().items()}
+        ly2 = [[ms, n] for (ms, n) in ctx.layer_ms()]
         ctx.set_profiling(False)
-        f32 = {"value": round(n_local * k2 / e2, 1), "unit": "segments/s", "steps": k2,
+        f32 = {"value": round(n_local * args.steps / e2, 1), "unit": "segments/s", "steps": args.steps,
                "gemm": "v_mfma_f32_16x16x4_f32 in every kernel"}
-        f32.update(analyse(clf, m, info, clf.fused_blocks(), st2, ly2, n_local * k2, k2, slices_per_step, "f32"))
+        f32.update(analyse(clf, m, info, clf.fused_blocks(), st2, ly2, n_local * args.steps, args.steps, slices_per_step, "f32"))
         out["f32_mfma_path"] = f32
         hip_logits["f32"] = logits[:16].cpu().numpy()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(model_path, m.sample_count, m.sample_rate, hip_logits)
+        if args.config == "c5":       # the checker's path for this workload: oracle resampler -> oracle forward on the first segments
+            out["cpu_baseline"] = cpu_baseline_c5(model_path, m, hip_logits)
+        else:
+            out["cpu_baseline"] = cpu_baseline(model_path, m.sample_count, m.sample_rate, hip_logits)
     elif rank == 0:
         out["cpu_baseline"] = None
     ctx.close()
@@ -346,6 +524,86 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def cpu_baseline_c5(model_path, m, hip_logits):
+    """Config 5's CPU leg: the oracle's block-FFT resampler (rubato restatement) + forward on a bounded sample, and
+    max |dlogit| of the f16-MFMA HIP path against it (tolerance 3e-3 of the logit scale, tests/test_parity_gpu.py)."""
+    import numpy as np
+    from birda_amd import pipeline, synth
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    om = O.OracleModel(model_path)
+    rates = [22050, 44100, 48000]
+    n = int(min(384, max(48, 2 * cores)))
+    segs = np.zeros((n, m.sample_count), np.float32)
+    t = time.perf_counter()
+    for i in range(n):
+        r = rates[i % 3]
+        src = synth.synth_segments(1, pipeline.source_samples(m.sample_count, r, m.sample_rate), r, start=i % 16)[0]
+        y = src if r == m.sample_rate else O.resample(src, r, m.sample_rate)
+        segs[i, : min(len(y), m.sample_count)] = y[: m.sample_count]
+    ref = om.forward(segs)
+    dt = time.perf_counter() - t
+    parity = {}
+    for name, got in (hip_logits or {}).items():
+        k = min(len(got), n)
+        scale = float(max(1.0, np.abs(ref[:k]).max()))
+        d = float(np.abs(got[:k] - ref[:k]).max())
+        parity[name] = {"max_abs_dlogit": round(d, 6), "max_abs_logit": round(scale, 3), "relative": float(f"{d / scale:.3e}"), "segments": k,
+                        "top1_agree": bool((got[:k].argmax(1) == ref[:k].argmax(1)).all())}
+    return {"value": round(n / dt, 2), "unit": "segments/s", "cores": cores, "kind": "port",
+            "sample": f"{n} mixed-rate segments: oracle resampler (serial) + oracle forward (OpenMP, {cores} threads), {dt:.1f} s",
+            "max_abs_dlogit_vs_oracle": parity}
+
+
+def bench_c3_multi(args, m, model_path, tmp):
+    """BASELINE configs[2] on one process through the C ABI: 10 000 HBM-resident segments as 8 contiguous shards
+    (bh_multi_forward_device).  With fewer than 8 GPUs visible the shards are logical devices on the GPUs that exist
+    (SURVEY.md section 0), which measures the sharding / gather machinery, not 8-GPU scaling."""
+    import numpy as np
+    import torch
+    from birda_amd import sharding, synth
+    from birda_amd.multi import MultiClassifier
+    n_dev = torch.cuda.device_count()
+    G = 8
+    devices = [g * n_dev // G for g in range(G)]
+    n_total = 10000
+    mc = MultiClassifier(model_path, None, devices=devices, top_k=5, min_confidence=0.1, precision=args.precision,
+                         max_batch=min(args.micro_batch, 625))
+    uniq = synth.synth_segments(64, m.sample_count, m.sample_rate, start=0)
+    xs, counts = [], []
+    for g in range(G):
+        lo, hi = sharding.shard_range(n_total, g, G)
+        host = np.stack([uniq[j % 64] for j in range(lo, hi)])
+        xs.append(torch.from_numpy(host).to(f"cuda:{devices[g]}"))
+        counts.append(hi - lo)
+    ptrs = [x.data_ptr() for x in xs]
+
+    def step():
+        return mc.forward_device(ptrs, counts)
+    for _ in range(max(1, args.warmup)):
+        res = step()
+    vals = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        vals.append(n_total * args.steps / (time.perf_counter() - t0))
+    out = {"metric": "3s/48kHz segments/sec (BirdNET v2.4)", "value": round(vals[0], 1), "unit": "segments/s", "n_gpus": n_dev,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(n_total / vals[0] * 1e3, 3), "higher_is_better": True,
+           "scaling": "strong", "vs_baseline": None, "dtype": DTYPE[args.precision].split(" ")[0], "data": "synthetic",
+           "config": {"workload": "configs[2]: 10 000 synthetic 3 s/48 kHz segments as 8 contiguous shards in ONE process through bh_multi_forward_device "
+                                  "(host threads, one context + stream per shard, packed top-k gather); results include the unpack into bh_result rows",
+                      "shards": G, "shard_devices": devices, "gather": mc.gather_backend(), "precision": args.precision,
+                      "note": "shards that share a GPU are logical devices: this measures the sharding machinery, not multi-GPU scaling"},
+           "repeats": {"values": [round(v, 1) for v in vals], "median_of_5": round(statistics.median(vals), 1)},
+           "checks": {"results": len(res), "segments_with_predictions": sum(1 for r in res if r.predictions)},
+           "cpu_baseline": None}
+    mc.close()
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

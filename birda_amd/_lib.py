@@ -39,6 +39,12 @@ class BhProviderStatus(C.Structure):
                 ("arch", C.c_char * 32), ("compute_units", C.c_uint32), ("hbm_bytes", C.c_uint64)]
 
 
+class BhMultiConfig(C.Structure):
+    _fields_ = [("model_path", C.c_char_p), ("labels_path", C.c_char_p), ("top_k", C.c_uint32), ("min_confidence", C.c_float),
+                ("flags", C.c_uint32), ("devices", C.POINTER(C.c_int32)), ("n_devices", C.c_uint32), ("max_batch", C.c_uint32),
+                ("gather", C.c_uint32)]
+
+
 class BhResult(C.Structure):
     _fields_ = [("n_pred", C.c_uint32), ("index", C.c_int32 * BH_MAX_TOP_K), ("confidence", C.c_float * BH_MAX_TOP_K)]
 
@@ -78,6 +84,7 @@ SYMBOLS = [
     ("bh_batch_context_layer_ms", C.c_int, [_VP, _VP, _VP, _SZ]),
     ("bh_classifier_fused_blocks", C.c_int, [_VP, _VP, _SZ]),
     ("bh_mb_config_name", C.c_int, [C.c_int32, C.c_char_p, _SZ]),
+    ("bh_classifier_frontend_kernel", C.c_int, [_VP, C.c_char_p, _SZ]),
     ("bh_debug_mb_stamps", C.c_int, [_VP, _VP, _SZ]),
     ("bh_predict_batch_source_rate", C.c_int, [_VP, _VP, C.POINTER(_VP), _SZ, _SZ, C.c_uint32, C.POINTER(BhResult)]),
     ("bh_segment_starts", _SZ, [_SZ, _SZ, _SZ, _VP, _SZ]),
@@ -90,6 +97,19 @@ SYMBOLS = [
     ("bh_classifier_set_species_list", C.c_int, [_VP, _VP, _SZ]),
     ("bh_classifier_clear_filters", C.c_int, [_VP]),
     ("bh_topk_from_logits", C.c_int, [_VP, _VP, _SZ, C.POINTER(BhResult)]),
+    ("bh_multi_create", C.c_int, [C.POINTER(BhMultiConfig), C.POINTER(_VP)]),
+    ("bh_multi_destroy", None, [_VP]),
+    ("bh_multi_last_error", C.c_char_p, []),
+    ("bh_multi_shards", C.c_uint32, [_VP]),
+    ("bh_multi_shard_device", C.c_int, [_VP, C.c_uint32]),
+    ("bh_multi_gather_backend", C.c_char_p, [_VP]),
+    ("bh_multi_classifier", _VP, [_VP, C.c_uint32]),
+    ("bh_multi_context", _VP, [_VP, C.c_uint32]),
+    ("bh_shard_range", None, [_SZ, C.c_uint32, C.c_uint32, C.POINTER(_SZ), C.POINTER(_SZ)]),
+    ("bh_shard_ranges_weighted", C.c_int, [_VP, _SZ, C.c_uint32, _VP]),
+    ("bh_multi_predict_batch_contig", C.c_int, [_VP, _VP, _SZ, C.POINTER(BhResult)]),
+    ("bh_multi_predict_batch_source_rate", C.c_int, [_VP, C.POINTER(_VP), _VP, _VP, _SZ, C.POINTER(BhResult), _VP]),
+    ("bh_multi_forward_device", C.c_int, [_VP, C.POINTER(_VP), _VP, C.POINTER(BhResult)]),
 ]
 
 

@@ -131,6 +131,22 @@ class BirdClassifier:
         self._L.bh_mb_config_name(cfg, buf, 128)
         return "mbconv<" + buf.value.decode() + ">"
 
+    def mel_kernel_name(self) -> str:
+        """The front-end kernel instantiation as a profiler prints it (e.g. "bh::mel_kernel<6, 3>")."""
+        buf = C.create_string_buffer(128)
+        self._L.bh_classifier_frontend_kernel(self._h, buf, 128)
+        return buf.value.decode()
+
+    def provider_status(self):
+        """ExecutionProviderStatus{requested, actual, fallback_reason} (classifier.rs:23-30) + device facts."""
+        st = _lib.BhProviderStatus()
+        check(self._L.bh_classifier_provider_status(self._h, C.byref(st)))
+        return st
+
+    def default_batch_size(self) -> int:
+        """determine_default_batch_size (lib.rs:256-288) for this backend."""
+        return int(self._L.bh_classifier_default_batch_size(self._h))
+
     # ---- warm-up (classifier.rs:414-466) ----
     def ensure_warm(self, batch_size: int):
         check(self._L.bh_classifier_ensure_warm(self._h, batch_size))

@@ -1196,6 +1196,17 @@ int bh_classifier_fused_blocks(const bh_classifier *c, int32_t *cfgs, size_t cap
 
 int bh_mb_config_name(int32_t cfg, char *out, size_t cap) { return bh::mb_config_name(cfg, out, cap); }
 
+int bh_classifier_frontend_kernel(const bh_classifier *c, char *out, size_t cap) {
+    if (!c) return 0;
+    char buf[64];
+    const int nmp = c->fe.br[0].nm_pad;
+    if (c->fe.prec == 32) snprintf(buf, sizeof buf, "bh::mel32_kernel<%d>", nmp / 32);
+    else snprintf(buf, sizeof buf, "bh::mel_kernel<%d, %d>", nmp / 16, c->fe.prec);
+    const int n = (int)strlen(buf);
+    if (out && cap > (size_t)n) memcpy(out, buf, (size_t)n + 1);
+    return n;
+}
+
 int bh_debug_mb_stamps(bh_classifier *c, uint64_t *out, size_t cap) {
     if (!c || !c->d_stamps) return 0;
     const size_t n = std::min(cap, c->mb.size() * 8);

@@ -245,6 +245,11 @@ BH_API int bh_batch_context_layer_ms(bh_batch_context *ctx, float *ms, uint32_t 
  * bh_predict_batch* entry points. */
 BH_API int bh_classifier_fused_blocks(const bh_classifier *c, int32_t *cfgs, size_t cap);
 
+/* Name of the front-end (STFT x mel) kernel instantiation this classifier launches, as a profiler prints it
+ * (e.g. "bh::mel_kernel<6, 3>"): lets the bench match its HIP-event timings and the committed PMC counters to the exact
+ * kernel.  Returns the string length. */
+BH_API int bh_classifier_frontend_kernel(const bh_classifier *c, char *out, size_t cap);
+
 /* Template arguments of tile configuration `cfg` as a profiler prints them after
  * "mbconv_kernel<" (to match bench timings with rocprofv3 rows); returns the string length. */
 BH_API int bh_mb_config_name(int32_t cfg, char *out, size_t cap);
@@ -292,6 +297,51 @@ BH_API int bh_resample_output_len(size_t n_in, uint32_t from_rate, uint32_t to_r
 BH_API int bh_resample_device(bh_classifier *c, bh_batch_context *ctx, const float *d_in, size_t in_stride,
                               size_t src_len, uint32_t from_rate, uint32_t to_rate, float *d_out,
                               size_t out_stride, size_t out_len, size_t n_seg);
+
+/* ---- several shards in one process (birda_amd/csrc/multi.hip) -----------------------------------
+ * Segments are independent through every stage (processor.rs:363-367): shard g of G owns a contiguous block of the
+ * global list and nothing is exchanged but the results.  The reference has no counterpart (it scales out as N
+ * processes over one directory with lock files, src/locking/file_lock.rs:36-88); a Rust host drives all the GPUs of a
+ * node through these calls from one BirdClassifier. */
+typedef struct bh_multi bh_multi;
+#define BH_GATHER_AUTO 0u /* RCCL all-gather of the packed top-k rows when every shard has its own device and the
+                             communicator comes up, else hipMemcpyDtoH per device */
+#define BH_GATHER_HOST 1u
+#define BH_GATHER_RCCL 2u /* fail at create when RCCL cannot serve */
+typedef struct {
+    const char *model_path, *labels_path;
+    uint32_t top_k;
+    float min_confidence;
+    uint32_t flags;         /* BH_FLAG_* */
+    const int32_t *devices; /* HIP ordinal of every shard; an ordinal may repeat (logical devices: several shards, each with
+                               its own context, stream and host thread, on one GPU) */
+    uint32_t n_devices;     /* 0 = one shard per visible device */
+    uint32_t max_batch;     /* micro-batch of every shard's context; 0 = bh_default_batch_size */
+    uint32_t gather;        /* BH_GATHER_* */
+} bh_multi_config;
+BH_API int bh_multi_create(const bh_multi_config *cfg, bh_multi **out);
+BH_API void bh_multi_destroy(bh_multi *m);
+BH_API const char *bh_multi_last_error(void);
+BH_API uint32_t bh_multi_shards(const bh_multi *m);
+BH_API int bh_multi_shard_device(const bh_multi *m, uint32_t shard);
+BH_API const char *bh_multi_gather_backend(const bh_multi *m); /* "rccl" or "host (<why>)" */
+BH_API bh_classifier *bh_multi_classifier(bh_multi *m, uint32_t shard); /* labels, info, filters (shared per device) */
+BH_API bh_batch_context *bh_multi_context(bh_multi *m, uint32_t shard);
+/* the partition: [lo, hi) = [shard * n / G, (shard + 1) * n / G); concatenating the shards restores the list */
+BH_API void bh_shard_range(size_t n_total, uint32_t shard, uint32_t n_shards, size_t *lo, size_t *hi);
+/* mixed-rate lists (BASELINE config 5) are balanced by SOURCE SAMPLES: item i goes to the shard its midpoint falls in
+ * on the cumulative-weight axis; bounds receives n_shards + 1 cut points (contiguous, order-preserving) */
+BH_API int bh_shard_ranges_weighted(const uint64_t *weights, size_t n, uint32_t n_shards, size_t *bounds);
+/* predict_batch over all shards: host segments [n][sample_count] in, one result per segment in list order */
+BH_API int bh_multi_predict_batch_contig(bh_multi *m, const float *base, size_t n, bh_result *out);
+/* decode_and_stream's resample step + predict_batch for a list whose items differ in rate / length: per shard one batch
+ * per (rate, length) present, results back in list order; bounds_out (nullable) receives the n_shards + 1 cut points */
+BH_API int bh_multi_predict_batch_source_rate(bh_multi *m, const float *const *segments, const uint32_t *source_rates,
+                                              const size_t *n_src_samples, size_t n, bh_result *out, size_t *bounds_out);
+/* device-resident input: d_segments[g] = shard g's [n_per_shard[g]][sample_count] f32 on ITS device; the packed top-k
+ * rows are gathered (RCCL all-gather onto shard 0's device + one download, or one download per device) and returned in
+ * shard order */
+BH_API int bh_multi_forward_device(bh_multi *m, const float *const *d_segments, const size_t *n_per_shard, bh_result *out);
 
 #ifdef __cplusplus
 }
