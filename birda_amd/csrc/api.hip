@@ -70,6 +70,7 @@ struct bh_classifier {
     std::vector<float *> d_w;                // per layer: weights as the kernels want them
     std::vector<int> ldw;                    // per layer: padded row length of d_w (pw / dense)
     std::vector<void *> d_w16;               // per layer: f16 hi / lo fragment planes (pw / dense outside fused blocks), or null
+    std::vector<float> w16_unscale;          // per layer: 2^-s of those planes (they hold W * 2^s, kernels.hpp f16_scale_exponent)
     std::vector<char> head_gap;              // per layer: 1 = this 1x1 conv + GELU and the global average pool after it run as one launch
     std::vector<float *> d_owned;            // re-laid buffers to free
     bh::FrontendParams fe{};
@@ -114,6 +115,8 @@ struct bh_batch_context {
     size_t raw_len = 0;
     int32_t *h_topk_idx = nullptr;
     float *h_topk_conf = nullptr;
+    unsigned *d_nonfinite = nullptr;   // segments whose logits came out inf / NaN from finite samples (top-k kernel), since the last check
+    unsigned *h_nonfinite = nullptr;   // pinned
     size_t device_bytes = 0;
     size_t last_n = 0;
     const float *last_logits = nullptr;
@@ -133,7 +136,7 @@ float f16_to_f32(uint16_t h);
 
 // Gf for one branch (see kernels_frontend.hip): double precision on the host, once.
 // prec 0: f32 fragment-major; prec 3: f16 hi / lo planes for the split MFMA (same byte count).
-std::vector<float> build_gf(const bh::BranchRec &b, const float *W, int nm_pad, int prec) {
+std::vector<float> build_gf(const bh::BranchRec &b, const float *W, int nm_pad, int prec, int *scale_exp) {
     const int L = (int)b.frame_length, K = L / 2, nb = (int)b.n_bins, nm = (int)b.n_mels;
     std::vector<double> ct(L);
     for (int i = 0; i < L; i++) ct[i] = std::cos(2.0 * M_PI * (double)i / (double)L);
@@ -156,6 +159,14 @@ std::vector<float> build_gf(const bh::BranchRec &b, const float *W, int nm_pad, 
         }
         const double scale = (j == K - 1) ? 0.5 * wn : wn;  // the centre sample is added to itself
         for (int m = 0; m < nm; m++) gf[(size_t)j * nm_pad + m] = (float)(scale * acc[m]);
+    }
+    // f16 planes hold Gf * 2^s (kernels.hpp f16_scale_exponent); the kernel's power law undoes it (BranchParams::log2_bias)
+    *scale_exp = 0;
+    if (prec != 0) {
+        float mx = 0.0f;
+        for (float v : gf) mx = std::max(mx, std::fabs(v));
+        *scale_exp = bh::f16_scale_exponent(mx);
+        for (float &v : gf) v = std::ldexp(v, *scale_exp);
     }
     // MFMA-fragment-major relayout (kernels.hpp BranchParams::gf)
     const int mt_n = nm_pad / 16;
@@ -317,6 +328,10 @@ int ctx_create(bh_classifier *c, size_t max_batch, bool keep, bh_batch_context *
     HIPCHK(hipHostMalloc((void **)&ctx->h_input, in_bytes, hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&ctx->h_topk_idx, max_batch * c->top_k * sizeof(int32_t), hipHostMallocDefault));
     HIPCHK(hipHostMalloc((void **)&ctx->h_topk_conf, max_batch * c->top_k * sizeof(float), hipHostMallocDefault));
+    HIPCHK(hipMalloc((void **)&ctx->d_nonfinite, sizeof(unsigned)));
+    HIPCHK(hipMemset(ctx->d_nonfinite, 0, sizeof(unsigned)));
+    HIPCHK(hipHostMalloc((void **)&ctx->h_nonfinite, sizeof(unsigned), hipHostMallocDefault));
+    *ctx->h_nonfinite = 0;
     ctx->device_bytes = in_bytes + max_batch * 16 * sizeof(float) + ctx->arena_floats * sizeof(float) +
                         max_batch * (size_t)m.h.n_classes * sizeof(float) + max_batch * c->top_k * 8;
     *out = ctx.release();
@@ -335,6 +350,7 @@ void ctx_destroy(bh_batch_context *ctx) {
     (void)hipHostFree(ctx->h_input); (void)hipHostFree(ctx->h_topk_idx); (void)hipHostFree(ctx->h_topk_conf);
     (void)hipFree(ctx->d_raw); (void)hipHostFree(ctx->h_raw);
     (void)hipFree(ctx->d_pcm); (void)hipFree(ctx->d_starts);
+    (void)hipFree(ctx->d_nonfinite); (void)hipHostFree(ctx->h_nonfinite);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -385,14 +401,14 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
             if (!ctx->keep_tensors && c->head_gap[i]) {
                 float *pooled = (i + 1 == nl - 1) ? d_logits : T(i + 2);
                 bh::launch_head_gap16(in, c->d_w16[i], bias, pooled, (int)n, (int)(L.out_h * L.out_w), (int)L.cin, (int)L.cout,
-                                      c->precision == 3 ? 3 : 1, s);
+                                      c->precision == 3 ? 3 : 1, c->w16_unscale[i], s);
                 ctx_mark(ctx, ST_PW, (int)i);
                 i += 1;   // the pool layer is done
                 break;
             }
             if (!ctx->keep_tensors && c->d_w16[i])
                 bh::launch_pw_gemm16(in, c->d_w16[i], bias, res, out, (int)(n * L.out_h * L.out_w), (int)L.cin, (int)L.cout,
-                                     (int)L.act, c->precision == 3 ? 3 : 1, s);
+                                     (int)L.act, c->precision == 3 ? 3 : 1, c->w16_unscale[i], s);
             else
             bh::launch_pw_gemm(in, c->d_w[i], bias, res, out, (int)(n * L.out_h * L.out_w), (int)L.cin,
                                (int)L.cout, c->ldw[i], (int)L.act, s);
@@ -401,7 +417,7 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
         case bh::OP_DENSE:
             if (!ctx->keep_tensors && c->d_w16[i])
                 bh::launch_pw_gemm16(in, c->d_w16[i], bias, res, out, (int)n, (int)L.cin, (int)L.cout, (int)L.act,
-                                     c->precision == 3 ? 3 : 1, s);
+                                     c->precision == 3 ? 3 : 1, c->w16_unscale[i], s);
             else
             bh::launch_pw_gemm(in, c->d_w[i], bias, res, out, (int)n, (int)L.cin, (int)L.cout, c->ldw[i],
                                (int)L.act, s);
@@ -416,13 +432,29 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
     }
     if (d_idx && d_conf) {
         bh::launch_topk(d_logits, (int)n, (int)m.h.n_classes, (int)m.h.output_activation, (int)c->top_k,
-                        c->min_conf, c->filter, d_idx, d_conf, s);
+                        c->min_conf, c->filter, d_idx, d_conf, ctx->d_minmax, ctx->d_nonfinite, s);
         ctx_mark(ctx, ST_TOPK);
     }
     HIPCHK(hipGetLastError());
     ctx->last_n = n;
     ctx->last_logits = d_logits;
     return BH_OK;
+}
+
+// The non-finite counter of the forwards enqueued so far: fetch_nonfinite() goes on the stream BEFORE the synchronise that
+// ends a call, nonfinite_status() after it.  A hit is an error, not a silent NaN row: in the f16 operand modes an activation
+// at or beyond 65 504 turns into inf inside bh_split2 / the f16 conversions (weights cannot: they are pre-scaled at create).
+hipError_t fetch_nonfinite(bh_batch_context *ctx) {
+    return hipMemcpyAsync(ctx->h_nonfinite, ctx->d_nonfinite, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream);
+}
+int nonfinite_status(bh_classifier *c, bh_batch_context *ctx) {
+    const unsigned bad = *ctx->h_nonfinite;
+    if (!bad) return BH_OK;
+    *ctx->h_nonfinite = 0;
+    (void)hipMemsetAsync(ctx->d_nonfinite, 0, sizeof(unsigned), ctx->stream);
+    return fail(BH_ERR_NONFINITE, "%u segment(s) with finite samples produced inf / NaN logits%s", bad,
+                c->precision != 0 ? ": an activation left the f16 operand range (|x| >= 65504); build the classifier with BH_FLAG_F32 for this model"
+                                  : " (f32 overflow inside the network)");
 }
 
 int check_ctx(bh_classifier *c, bh_batch_context *ctx) {
@@ -514,6 +546,7 @@ int predict_slices(bh_classifier *c, bh_batch_context *ctx, const float *const *
         if (emb_out)
             HIPCHK(hipMemcpyAsync(emb_out + b0 * m.h.embedding_dim, ctx->d_arena + ctx->t_off[m.h.embedding_tensor],
                                   nb * (size_t)m.h.embedding_dim * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(fetch_nonfinite(ctx));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         if (out)
             for (size_t i = 0; i < nb; i++) {
@@ -527,6 +560,8 @@ int predict_slices(bh_classifier *c, bh_batch_context *ctx, const float *const *
                     r.n_pred++;
                 }
             }
+        const int nf = nonfinite_status(c, ctx);   // the rows are filled (NaN logits are never chosen); the call still fails
+        if (nf != BH_OK) return nf;
     }
     return BH_OK;
 }
@@ -609,12 +644,22 @@ int plan_fusion(bh_classifier *c) {
         const float *We = m.blob.data() + E.w_off, *Wp = m.blob.data() + P.w_off, *Wd = m.blob.data() + D.w_off;
         const float *be = m.blob.data() + E.b_off, *bd = m.blob.data() + D.b_off;
         const bool h16 = d.prec != 0;
+        // f16 operand planes hold We * 2^se and Wp * 2^sp (kernels.hpp f16_scale_exponent); be / bp are multiplied alike
+        int se = 0, sp = 0;
+        if (h16) {
+            float me = 0.0f, mp = 0.0f;
+            for (size_t q = 0; q < (size_t)d.Cin * d.Cexp; q++) me = std::max(me, std::fabs(We[q]));
+            for (size_t q = 0; q < (size_t)d.Cexp * d.Cout; q++) mp = std::max(mp, std::fabs(Wp[q]));
+            se = bh::f16_scale_exponent(me);
+            sp = bh::f16_scale_exponent(mp);
+        }
+        d.e_unscale = std::ldexp(1.0f, -se); d.p_scale = std::ldexp(1.0f, sp); d.p_unscale = std::ldexp(1.0f, -sp);
         const size_t frag = h16 ? 512 : 256, psteps = h16 ? (CE + 31) / 32 : NTE;
         const bool p16 = h16 && CE == 16;   // project GEMM as one 16-deep step: [column tile]{hi, lo}[64 lanes][4 halves]
         const size_t we_fl = (size_t)KG * NTE * frag + CE, wp_fl = p16 ? (size_t)NTOP * 256 : psteps * NTOP * frag, wd_fl = (size_t)KK * CE + CE;
         std::vector<float> wef(nch * we_fl, 0.0f), wpf(nch * wp_fl, 0.0f), wdf(nch * wd_fl, 0.0f);
-        auto we_at = [&](int k, int n) { return (k < d.Cin && n < d.Cexp) ? We[(size_t)k * d.Cexp + n] : 0.0f; };
-        auto wp_at = [&](int k, int n) { return (k < d.Cexp && n < d.Cout) ? Wp[(size_t)k * d.Cout + n] : 0.0f; };
+        auto we_at = [&](int k, int n) { return (k < d.Cin && n < d.Cexp) ? std::ldexp(We[(size_t)k * d.Cexp + n], se) : 0.0f; };
+        auto wp_at = [&](int k, int n) { return (k < d.Cexp && n < d.Cout) ? std::ldexp(Wp[(size_t)k * d.Cout + n], sp) : 0.0f; };
         // f16: element jj of lane's 8-half fragment = k = 32 g + 8 (lane >> 4) + jj; hi plane then lo plane
         auto put16 = [&](std::vector<float> &dst, size_t base_fl, int plane, int lane, int jj, float v) {
             uint16_t *h = reinterpret_cast<uint16_t *>(dst.data() + base_fl) + ((size_t)plane * 64 + lane) * 8 + jj;
@@ -638,7 +683,7 @@ int plan_fusion(bh_classifier *c) {
                                 wef[ch * we_fl + (((size_t)g * NTE + j) * 64 + lane) * 4 + cc] = we_at(16 * g + 4 * (lane >> 4) + cc, n);
                         }
                     }
-            for (int n = 0; n < CE; n++) wef[ch * we_fl + (size_t)KG * NTE * frag + n] = ch * CE + n < d.Cexp ? be[ch * CE + n] : 0.0f;
+            for (int n = 0; n < CE; n++) wef[ch * we_fl + (size_t)KG * NTE * frag + n] = ch * CE + n < d.Cexp ? std::ldexp(be[ch * CE + n], se) : 0.0f;
             if (p16) {
                 for (int j = 0; j < NTOP; j++)
                     for (int lane = 0; lane < 64; lane++)
@@ -684,6 +729,15 @@ int plan_fusion(bh_classifier *c) {
         c->d_owned.push_back(dwd);
         d.We = dwe; d.Wp = dwp; d.Wd = dwd;
         d.bp = c->d_blob + P.b_off;
+        if (sp != 0) {   // bp * 2^sp: the project accumulators start there
+            std::vector<float> bps(d.Cout);
+            for (int n = 0; n < d.Cout; n++) bps[n] = std::ldexp(m.blob[P.b_off + n], sp);
+            float *dbp = nullptr;
+            rc = upload(bps.data(), bps.size() * sizeof(float), &dbp);
+            if (rc != BH_OK) return rc;
+            c->d_owned.push_back(dbp);
+            d.bp = dbp;
+        }
         c->fused_at[i] = (int)c->mb.size();
         c->mb.push_back(d);
         i += 2;
@@ -840,7 +894,8 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) try {
         if (br.frame_length % 128 || br.fft_length != br.frame_length)
             return fail(BH_ERR_UNSUPPORTED, "front-end: frame_length %u must be a multiple of 128 and equal fft_length", br.frame_length);
         if ((64 * br.frame_step) % 4) return fail(BH_ERR_UNSUPPORTED, "front-end: hop %u unsupported", br.frame_step);
-        std::vector<float> gf = build_gf(br, m.blob.data() + br.mel_w_off, nm_pad, fe_prec);
+        int gf_s = 0;
+        std::vector<float> gf = build_gf(br, m.blob.data() + br.mel_w_off, nm_pad, fe_prec, &gf_s);
         float *d = nullptr;
         int rc = upload(gf.data(), gf.size() * sizeof(float), &d);
         if (rc != BH_OK) return rc;
@@ -849,6 +904,7 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) try {
         p.gf = d; p.L = (int)br.frame_length; p.H = (int)br.frame_step; p.K = p.L / 2;
         p.n_mels = (int)br.n_mels; p.nm_pad = nm_pad; p.n_frames = (int)br.n_frames;
         p.expo = 1.0f / (1.0f + expf(br.mag_scale));
+        p.log2_bias = -2.0f * (float)gf_s * p.expo;
         p.out_scale = br.out_scale; p.out_shift = br.out_shift; p.flip = (int)(br.flags & 1u);
         c->mel_flops += 2ull * (uint64_t)p.K * nm_pad * br.n_frames;
     }
@@ -897,6 +953,7 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) try {
     if (rc != BH_OK) return rc;
     // f16 operand planes for the GEMM layers that stay outside the fused blocks (head conv, dense)
     c->d_w16.assign(m.layers.size(), nullptr);
+    c->w16_unscale.assign(m.layers.size(), 1.0f);
     if (c->precision != 0) {
         std::vector<char> in_block(m.layers.size(), 0);
         for (size_t i = 0; i < m.layers.size(); i++)
@@ -907,12 +964,16 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) try {
             const int K = (int)L.cin, N = (int)L.cout, nt = (N + 15) / 16;
             std::vector<uint16_t> planes((size_t)(K / 32) * nt * 2 * 64 * 8, 0);
             const float *W = m.blob.data() + L.w_off;
+            float wmax = 0.0f;
+            for (size_t q = 0; q < (size_t)K * N; q++) wmax = std::max(wmax, std::fabs(W[q]));
+            const int ws = bh::f16_scale_exponent(wmax);
+            c->w16_unscale[i] = std::ldexp(1.0f, -ws);
             for (int st = 0; st < K / 32; st++)
                 for (int t = 0; t < nt; t++)
                     for (int lane = 0; lane < 64; lane++)
                         for (int jj = 0; jj < 8; jj++) {
                             const int k = 32 * st + 8 * (lane >> 4) + jj, n = 16 * t + (lane & 15);
-                            const float v = n < N ? W[(size_t)k * N + n] : 0.0f;
+                            const float v = n < N ? std::ldexp(W[(size_t)k * N + n], ws) : 0.0f;
                             const uint16_t hi = f32_to_f16(v);
                             const size_t base = (((size_t)st * nt + t) * 2) * 64 * 8;
                             planes[base + (size_t)lane * 8 + jj] = hi;
@@ -1004,7 +1065,7 @@ int bh_topk_from_logits(bh_classifier *c, const float *logits, size_t n, bh_resu
     if (e == hipSuccess) e = hipMalloc((void **)&d_c, n * tk * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(d_l, logits, n * nc * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        bh::launch_topk(d_l, (int)n, (int)nc, (int)c->model.h.output_activation, (int)tk, c->min_conf, c->filter, d_i, d_c, nullptr);
+        bh::launch_topk(d_l, (int)n, (int)nc, (int)c->model.h.output_activation, (int)tk, c->min_conf, c->filter, d_i, d_c, nullptr, nullptr, nullptr);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(hi.data(), d_i, n * tk * sizeof(int32_t), hipMemcpyDeviceToHost);
@@ -1151,8 +1212,10 @@ int bh_forward_device(bh_classifier *c, bh_batch_context *ctx, const float *d_se
 
 int bh_batch_context_synchronize(bh_batch_context *ctx) {
     if (!ctx) return fail(BH_ERR_INVALID, "synchronize: null context");
+    HIPCHK(hipSetDevice(ctx->c->device));
+    HIPCHK(fetch_nonfinite(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    return BH_OK;
+    return nonfinite_status(ctx->c, ctx);   // BH_ERR_NONFINITE once per occurrence: the counter is cleared
 }
 void *bh_batch_context_stream(bh_batch_context *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
@@ -1287,6 +1350,7 @@ int bh_predict_batch_source_rate(bh_classifier *c, bh_batch_context *ctx, const 
         if (rc != BH_OK) return rc;
         HIPCHK(hipMemcpyAsync(ctx->h_topk_idx, ctx->d_topk_idx, nb * c->top_k * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipMemcpyAsync(ctx->h_topk_conf, ctx->d_topk_conf, nb * c->top_k * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(fetch_nonfinite(ctx));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         for (size_t i = 0; i < nb; i++) {
             bh_result &r = out[b0 + i];
@@ -1299,6 +1363,8 @@ int bh_predict_batch_source_rate(bh_classifier *c, bh_batch_context *ctx, const 
                 r.n_pred++;
             }
         }
+        const int nf = nonfinite_status(c, ctx);
+        if (nf != BH_OK) return nf;
     }
     return BH_OK;
 } catch (...) { return on_exception(); }
@@ -1434,7 +1500,7 @@ int bh_predict_pcm16(bh_classifier *c, bh_batch_context *ctx, const int16_t *pcm
         if (rc != BH_OK) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamSynchronize(ctx->stream); return rc; }
         if (hipMemcpyAsync(ctx->h_topk_idx, ctx->d_topk_idx, nb * c->top_k * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
             hipMemcpyAsync(ctx->h_topk_conf, ctx->d_topk_conf, nb * c->top_k * sizeof(float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(ctx->stream) != hipSuccess)
+            fetch_nonfinite(ctx) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
             return fail(BH_ERR_HIP, "predict_pcm16: result download failed");
         for (size_t i = 0; i < nb; i++) {
             bh_result &r = out[b0 + i];
@@ -1447,6 +1513,8 @@ int bh_predict_pcm16(bh_classifier *c, bh_batch_context *ctx, const int16_t *pcm
                 r.n_pred++;
             }
         }
+        const int nf = nonfinite_status(c, ctx);
+        if (nf != BH_OK) return nf;
     }
     return BH_OK;
 } catch (...) { return on_exception(); }

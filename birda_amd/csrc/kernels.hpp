@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <cmath>
 #include <mutex>
 
 namespace bh {
@@ -26,6 +27,17 @@ struct DeviceOnce {
         if (!done[d].load(std::memory_order_relaxed)) { f(); done[d].store(1, std::memory_order_release); }
     }
 };
+// Power-of-two pre-scale of an f16 operand tensor (host side): the exponent s with max |w| * 2^s in [2^13, 2^14) -- a factor
+// of four below the f16 maximum 65 504, and high enough that the lo half (w - f16(w), ~2^-11 of w) of every entry within
+// 2^-13 of the largest is a NORMAL f16.  Exact (a power of two) and undone exactly in the consumer's f32 epilogue.
+// 0 for an all-zero tensor; clamped so that biases multiplied alike stay far inside the f32 range.
+inline int f16_scale_exponent(float max_abs) {
+    if (!(max_abs > 0.0f) || !std::isfinite(max_abs)) return 0;
+    int e = 0;
+    (void)std::frexp(max_abs, &e);   // max_abs = f * 2^e, f in [0.5, 1)
+    const int s = 14 - e;
+    return s < -60 ? -60 : (s > 60 ? 60 : s);
+}
 inline int device_cu_count() {
     static std::atomic<int> n_cu[MAX_DEVICES] = {};
     const int d = current_device();
@@ -183,6 +195,9 @@ struct BranchParams {
     float expo;       // 1 / (1 + exp(mag_scale))
     float out_scale, out_shift;
     int flip;
+    float log2_bias;  // f16 operator planes hold Gf * 2^s (s puts max |Gf| in [2^13, 2^14): both f16 halves of every
+                      // entry that matters stay normal numbers); the power law undoes it inside its exp2:
+                      // (v^2)^expo = exp2(expo * log2((v 2^s)^2) + log2_bias), log2_bias = -2 s expo.  0 for the f32 operator.
 };
 struct FrontendParams {
     BranchParams br[MAX_BRANCHES];
@@ -213,15 +228,19 @@ void launch_pw_gemm(const float *A, const float *W, const float *bias, const flo
                     int N, int ldw, int act, hipStream_t s);
 // the same product on the f16 MFMA (terms = 3: hi / lo split operands, f32-grade; 1: plain f16); K % 32 == 0;
 // Wf: fragment-major planes [K / 32][ceil(N / 16)]{hi, lo}[64 lanes][8 halves]
+// The planes hold W * w_scale, w_scale = 1 / w_unscale an exact power of two chosen on the host (f16_weight_scale, api.hip)
+// so that max |W w_scale| lies in [2^13, 2^14): the lo half of every weight that matters is a normal f16 (an unscaled
+// He-normal weight at Cin 1152 is ~2^-5, its lo half a subnormal with 2^-24 absolute resolution); the epilogue computes
+// acc * w_unscale + bias in one FMA.
 bool pw_gemm16_supports(int K, int act);
 void launch_pw_gemm16(const float *A, const void *Wf, const float *bias, const float *R, float *C, int M, int K, int N,
-                      int act, int terms, hipStream_t s);
+                      int act, int terms, float w_unscale, hipStream_t s);
 // global average pool [n][P][C] -> [n][C]
 void launch_gap(const float *in, float *out, int n_seg, int P, int C, hipStream_t s);
 // head 1x1 conv + GELU + global average pool fused (f16 hi / lo weight planes as for launch_pw_gemm16)
 bool head_gap16_supports(int P, int K, int N, int act);
 void launch_head_gap16(const float *A, const void *Wf, const float *bias, float *out, int n_seg, int P, int K, int N,
-                       int terms, hipStream_t s);
+                       int terms, float w_unscale, hipStream_t s);
 // activation + top-k over logits [n][n_classes] -> idx/conf [n][top_k]
 // Post-filter of the kept top-k (reference apply_range_filter, classifier.rs:587-645): class_score (NaN = species without
 // geomodel entry) selects geomodel_filter.rs:46-82, else species_keep the species-list retain (:617-640); both null = off.
@@ -232,8 +251,10 @@ struct TopkFilter {
     int keep_unmatched = 1;
     int rerank = 0;
 };
+// minmax (nullable): the segments' min / max partials [n_seg][8][2]; nonfinite (nullable): counter that receives +1 for every
+// segment whose logits hold an inf / NaN although its samples were all finite (an operand left the f16 range on the way)
 void launch_topk(const float *logits, int n_seg, int n_classes, int out_act, int top_k, float min_conf,
-                 const TopkFilter &filter, int32_t *idx, float *conf, hipStream_t s);
+                 const TopkFilter &filter, int32_t *idx, float *conf, const float *minmax, unsigned *nonfinite, hipStream_t s);
 
 // Polyphase resampler (resample.hip): rubato's FFT resampler as one dense operator on the MFMA.
 struct ResamplePlan {
@@ -241,6 +262,7 @@ struct ResamplePlan {
     int hop, N, nblk, K, dmin;  // y[N m + p] = sum_{k < K} x[hop m + dmin + k] G[k][p]
     const float *d_op;          // device, fragment-major [nblk][K/16][10][64][4]
     const void *d_op16;         // the same operator as f16 hi / lo planes [2 nblk (80 phases each)][K/32][5]{hi, lo}[64 lanes][8 halves], k = 32 s + 8 (lane >> 4) + j
+    float op16_unscale;         // the planes hold G * 2^s (max in [2^13, 2^14)); the kernel's store multiplies by 2^-s
 };
 void resample_sizes(uint32_t from, uint32_t to, int *fft_in, int *fft_out);
 size_t resample_output_len(size_t n, uint32_t from, uint32_t to);  // rubato's output length for n inputs
@@ -266,6 +288,11 @@ struct MbDesc {
     int H, W, Cin, Cexp, Cout, Ho, Wo, pad_t, pad_l, KS, ST;
     int act_e, act_d, act_p;
     int prec;  // 0: f32 MFMA; 3: f16 hi/lo split (three f16 MFMAs per product, f32-grade); 1: plain f16 MFMA
+    // f16 modes: the expand / project planes hold We * 2^se and Wp * 2^sp (powers of two that put the largest weight in
+    // [2^13, 2^14), so both f16 halves of the weights are normal numbers), be and bp arrive multiplied alike;
+    // the expand result is multiplied by e_unscale = 2^-se before its activation, the project accumulators start at
+    // bp 2^sp + R p_scale and are stored times p_unscale.  All three are 1 in f32 mode.
+    float e_unscale, p_scale, p_unscale;
     // stem variant (first block): "expand" = the k x k stride-s stem conv gathered from the planar
     // spectrogram X [n][stem_c][stem_h][stem_w]; then H, W are the stem's OUTPUT size and
     // Cin = stem_k * stem_k * stem_c im2col columns (We rows in [kh][kw][cin] order)

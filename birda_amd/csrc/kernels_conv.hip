@@ -188,7 +188,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 template <int TERMS, int ACT>
 __global__ __launch_bounds__(256) void pw_gemm16_kernel(const float *__restrict__ A, const f16x8 *__restrict__ Wf,
                                                          const float *__restrict__ bias, const float *__restrict__ R,
-                                                         float *__restrict__ C, int M, int K, int N, int n_tiles) {
+                                                         float *__restrict__ C, int M, int K, int N, int n_tiles, float w_unscale) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void pw_gemm16_kernel(const float *__restrict_
                 if (row < M) {
                     // the activation is a template argument: a run-time switch inlined 64 times bloats
                     // the kernel past the instruction cache
-                    float v = acc[i][j][r] + bv;
+                    float v = __builtin_fmaf(acc[i][j][r], w_unscale, bv);   // the planes hold W / w_unscale
                     if (ACT == ACT_GELU_ERF) v = gelu_erf_fast(v);
                     if (R) v += R[(size_t)row * N + col];
                     C[(size_t)row * N + col] = v;
@@ -275,10 +275,10 @@ __global__ __launch_bounds__(256) void pw_gemm16_kernel(const float *__restrict_
 bool pw_gemm16_supports(int K, int act) { return K % 32 == 0 && (act == ACT_NONE || act == ACT_GELU_ERF); }
 
 void launch_pw_gemm16(const float *A, const void *Wf, const float *bias, const float *R, float *C, int M, int K, int N,
-                      int act, int terms, hipStream_t s) {
+                      int act, int terms, float w_unscale, hipStream_t s) {
     const int n_tiles = (N + 15) / 16;
     dim3 grid((n_tiles + 7) / 8, (M + 127) / 128), block(256);
-#define BH_G16(T, ACTV) hipLaunchKernelGGL((pw_gemm16_kernel<T, ACTV>), grid, block, 0, s, A, (const f16x8 *)Wf, bias, R, C, M, K, N, n_tiles)
+#define BH_G16(T, ACTV) hipLaunchKernelGGL((pw_gemm16_kernel<T, ACTV>), grid, block, 0, s, A, (const f16x8 *)Wf, bias, R, C, M, K, N, n_tiles, w_unscale)
     if (terms == 3) { if (act == ACT_GELU_ERF) BH_G16(3, ACT_GELU_ERF); else BH_G16(3, ACT_NONE); }
     else { if (act == ACT_GELU_ERF) BH_G16(1, ACT_GELU_ERF); else BH_G16(1, ACT_NONE); }
 #undef BH_G16
@@ -303,7 +303,7 @@ void launch_pw_gemm16(const float *A, const void *Wf, const float *bias, const f
 template <int PT, int SW, int TERMS>
 __global__ __launch_bounds__(256, 1) void head_gap16_kernel(const float *__restrict__ A, const f16x8 *__restrict__ Wf,
                                                              const float *__restrict__ bias, float *__restrict__ out,
-                                                             int n_seg, int P, int K, int N, int n_tiles, int n_cb) {
+                                                             int n_seg, int P, int K, int N, int n_tiles, int n_cb, float w_unscale) {
     constexpr int RT = PT * SW, CT = 8;
     __shared__ __attribute__((aligned(16))) f16x8 Bs[2][CT * 2 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -400,7 +400,9 @@ __global__ __launch_bounds__(256, 1) void head_gap16_kernel(const float *__restr
             const float b = bias[(cb * CT + j) * 16 + li];
 #pragma unroll
             for (int t = 0; t < PT; t++) {
-                bh_f32x2 v01 = {acc[sg * PT + t][j][0] + b, acc[sg * PT + t][j][1] + b}, v23 = {acc[sg * PT + t][j][2] + b, acc[sg * PT + t][j][3] + b};
+                const f32x4 a4 = acc[sg * PT + t][j];   // the planes hold W / w_unscale
+                bh_f32x2 v01 = {__builtin_fmaf(a4[0], w_unscale, b), __builtin_fmaf(a4[1], w_unscale, b)},
+                         v23 = {__builtin_fmaf(a4[2], w_unscale, b), __builtin_fmaf(a4[3], w_unscale, b)};
                 gelu_erf_fast4(v01, v23);
                 const int px = t * 16 + 4 * kq;
                 if (PT * 16 == P || px + 3 < P) sum += (v01[0] + v01[1]) + (v23[0] + v23[1]);
@@ -419,13 +421,13 @@ bool head_gap16_supports(int P, int K, int N, int act) {
 }
 
 void launch_head_gap16(const float *A, const void *Wf, const float *bias, float *out, int n_seg, int P, int K, int N,
-                       int terms, hipStream_t s) {
+                       int terms, float w_unscale, hipStream_t s) {
     const int n_tiles = N / 16, n_cb = N / 128;
     const int pt = (P + 15) / 16, sw = pt <= 3 ? 2 : 1;
     const int n_mb = (n_seg + 4 * sw - 1) / (4 * sw);
     dim3 grid((unsigned)(((n_mb + 7) / 8) * n_cb * 8)), block(256);
 #define BH_HG(PTV, SWV, T) hipLaunchKernelGGL((head_gap16_kernel<PTV, SWV, T>), grid, block, 0, s, A, (const f16x8 *)Wf, bias, out, \
-                                              n_seg, P, K, N, n_tiles, n_cb)
+                                              n_seg, P, K, N, n_tiles, n_cb, w_unscale)
     if (pt <= 3) { if (terms == 3) BH_HG(3, 2, 3); else BH_HG(3, 2, 1); }
     else { if (terms == 3) BH_HG(5, 1, 3); else BH_HG(5, 1, 1); }
 #undef BH_HG
@@ -585,7 +587,8 @@ __device__ __forceinline__ void topk_better(float &bv, int &bi, float ov, int oi
 
 __global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ logits, int n_classes, int out_act,
                                                     int top_k, float min_conf, const TopkFilter flt,
-                                                    int32_t *__restrict__ idx, float *__restrict__ conf) {
+                                                    int32_t *__restrict__ idx, float *__restrict__ conf,
+                                                    const float *__restrict__ minmax, unsigned *__restrict__ nonfinite) {
     extern __shared__ float row[];   // n_classes logits
     __shared__ float sv[4];
     __shared__ int si[4];
@@ -595,7 +598,17 @@ __global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ log
     const int seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *lg = logits + (size_t)seg * n_classes;
     float m = -INFINITY;
-    for (int i = tid; i < n_classes; i += 256) { const float v = lg[i]; row[i] = v; m = fmaxf(m, v); }
+    bool bad = false;   // an inf / NaN logit
+    for (int i = tid; i < n_classes; i += 256) { const float v = lg[i]; row[i] = v; m = fmaxf(m, v); bad |= !(fabsf(v) <= 3.4028235e38f); }
+    const int any_bad = __syncthreads_or(bad ? 1 : 0);
+    if (nonfinite && any_bad && tid == 0) {
+        // non-finite logits from FINITE samples: an operand overflowed on the way (f16 range); a segment that came in with
+        // NaN / inf samples is the caller's business and is not counted
+        bool in_ok = true;
+        if (minmax)
+            for (int q = 0; q < 16; q++) in_ok &= fabsf(minmax[(size_t)seg * 16 + q]) <= 3.4028235e38f;
+        if (in_ok) atomicAdd(nonfinite, 1u);
+    }
     // softmax statistics
     float mx = -INFINITY, sum = 0.f;
     if (out_act == 2) {
@@ -682,7 +695,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ log
 }
 
 void launch_topk(const float *logits, int n_seg, int n_classes, int out_act, int top_k, float min_conf,
-                 const TopkFilter &filter, int32_t *idx, float *conf, hipStream_t s) {
+                 const TopkFilter &filter, int32_t *idx, float *conf, const float *minmax, unsigned *nonfinite, hipStream_t s) {
     static DeviceOnce once;
     once.run([] {
         // (the kernel also has a few static __shared__ words: ask for less than the full 160 KB)
@@ -690,7 +703,7 @@ void launch_topk(const float *logits, int n_seg, int n_classes, int out_act, int
             (void)hipGetLastError();
     });
     hipLaunchKernelGGL(topk_kernel, dim3(n_seg), dim3(256), (size_t)n_classes * sizeof(float), s, logits, n_classes, out_act, top_k,
-                       min_conf, filter, idx, conf);
+                       min_conf, filter, idx, conf, minmax, nonfinite);
 }
 
 }  // namespace bh

@@ -383,7 +383,7 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void mel_kernel(const float *
                     const float v = tot[m][r];
                     // (v^2)^expo = exp2(expo * log2(v^2)): v_log_f32 + v_mul + v_exp_f32 instead of ocml powf
                     // (~70 instructions); relative error <= ~5e-7 for v^2 down to 1e-12, 0 -> 0
-                    float o = (dbg & 2) ? v : __builtin_amdgcn_exp2f(bp.expo * __builtin_amdgcn_logf(v * v));
+                    float o = (dbg & 2) ? v : __builtin_amdgcn_exp2f(__builtin_fmaf(bp.expo, __builtin_amdgcn_logf(v * v), bp.log2_bias));
                     o = o * bp.out_scale + bp.out_shift;
                     const int row = bp.flip ? (bp.n_mels - 1 - mel) : mel;
                     out[(size_t)row * bp.n_frames + t] = o;
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(256, 2) void mel32_kernel(const float *__restrict__
                     const int mel = 32 * wave + (r & 3) + 4 * kh + 8 * (r >> 2);
                     if (mel < bp.n_mels) {
                         const float v = tot[r];
-                        float o = __builtin_amdgcn_exp2f(bp.expo * __builtin_amdgcn_logf(v * v));
+                        float o = __builtin_amdgcn_exp2f(__builtin_fmaf(bp.expo, __builtin_amdgcn_logf(v * v), bp.log2_bias));
                         o = o * bp.out_scale + bp.out_shift;
                         const int row = bp.flip ? (bp.n_mels - 1 - mel) : mel;
                         out[(size_t)row * bp.n_frames + t] = o;

@@ -172,6 +172,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
     const int wm = wave / WN, wn = wave - wm * WN;    // P3
 
     const float rcp_vw = 1.0f / (float)max(vw, 1);
+    const float e_unscale = d.e_unscale, p_scale = d.p_scale, p_unscale = d.p_unscale;
     // ---- the wave's rows of X: A fragments of the expand GEMM, resident for the whole kernel ----
     // f32: afr[i][g] = 4 k values of one 16-deep group; f16: ah/al[i][g] = 8 k values of one 32-deep step
     float4 afr[PREC ? 1 : RT_W][PREC ? 1 : KG];
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
             const float bias = col < Cout ? d.bp[col] : 0.0f;
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                acco[i][j][r] = bias + ((Rb && col < Cout && orow[r] >= 0) ? Rb[(size_t)orow[r] * Cout + col] : 0.0f);
+                acco[i][j][r] = __builtin_fmaf((Rb && col < Cout && orow[r] >= 0) ? Rb[(size_t)orow[r] * Cout + col] : 0.0f, p_scale, bias);
         }
     }
 
@@ -367,6 +368,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
 #pragma unroll
                         for (int j = 0; j < NT_U; j++) {
                             f32x2 v01 = {acc[ii][j][0], acc[ii][j][1]}, v23 = {acc[ii][j][2], acc[ii][j][3]};
+                            if constexpr (PREC != 0) { v01 *= e_unscale; v23 *= e_unscale; }   // weights and bias carry 2^se
                             mb_act4<MB_ACT>(v01, v23);
                             *reinterpret_cast<f32x4 *>(erow + j * 16) = (f32x4){v01[0], v01[1], v23[0], v23[1]};
                         }
@@ -560,7 +562,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
             if (col >= Cout) continue;
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                if (orow[r] >= 0 && !(d.dbg & 32)) Yb[(size_t)orow[r] * Cout + col] = acco[i][j][r];
+                if (orow[r] >= 0 && !(d.dbg & 32)) Yb[(size_t)orow[r] * Cout + col] = PREC != 0 ? acco[i][j][r] * p_unscale : acco[i][j][r];
         }
     }
     mb_stamp(d.stamps, t_last, 7);

@@ -170,13 +170,17 @@ const ResamplePlan *resample_plan(uint32_t from, uint32_t to, const char **err) 
     pl.d_op = dptr;
     // the same operator pre-split into f16 hi + lo planes for the split-f16 kernel (32-deep steps)
     std::vector<_Float16> frag16((size_t)pl.nblk * pl.K * 160 * 2);
+    float op_max = 0.0f;
+    for (float v : frag) op_max = std::max(op_max, std::fabs(v));
+    const int op_s = f16_scale_exponent(op_max);   // planes hold G * 2^s; the kernel's store multiplies by 2^-s
+    pl.op16_unscale = std::ldexp(1.0f, -op_s);
     for (int cb = 0; cb < 2 * pl.nblk; cb++)   // column blocks of 80 phases (5 tiles) for this kernel
         for (int st = 0; st < pl.K / 32; st++)
             for (int mt = 0; mt < 5; mt++)
                 for (int lane = 0; lane < 64; lane++)
                     for (int j = 0; j < 8; j++) {
                         const int k = 32 * st + 8 * (lane >> 4) + j, p = cb * 80 + 16 * mt + (lane & 15);
-                        const float v = (float)tap(p, dmin + k);
+                        const float v = std::ldexp((float)tap(p, dmin + k), op_s);
                         const _Float16 hi = (_Float16)v;
                         const size_t base = ((((size_t)cb * (pl.K / 32) + st) * 5 + mt) * 2) * 64 * 8;
                         frag16[base + (size_t)lane * 8 + j] = hi;
@@ -314,7 +318,7 @@ constexpr int RS16_MT = 5;   // column blocks of 80 phases: 80 accumulator + 80 
 __global__ __launch_bounds__(256, 2) void resample16_kernel(const float *__restrict__ in, size_t in_stride, int src_len,
                                                          float *__restrict__ out, size_t out_stride, int out_len,
                                                          int n_valid, const rs_f16x8 *__restrict__ op, int hop, int N,
-                                                         int K, int dmin) {
+                                                         int K, int dmin, float op_unscale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int seg = blockIdx.z, cb = blockIdx.y, t0 = blockIdx.x * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -420,6 +424,8 @@ __global__ __launch_bounds__(256, 2) void resample16_kernel(const float *__restr
             const float4 q = red[((s * 3 + slot) * RS16_MT + m) * 64 + lane];
             v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
         }
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] *= op_unscale;   // the operator planes hold G * 2^s
         const long o = (long)t * N + cb * 80 + m * 16 + kq * 4;  // 4 consecutive output samples
         if (o + 3 < out_len && o + 3 < n_valid) {
             *reinterpret_cast<float4 *>(oseg + o) = make_float4(v[0], v[1], v[2], v[3]);
@@ -447,7 +453,7 @@ void launch_resample(const ResamplePlan &pl, const float *d_in, size_t in_stride
         const size_t smem16 = std::max(span_bytes, (size_t)4 * 3 * RS16_MT * 64 * sizeof(float4));
         dim3 grid16((frames + 63) / 64, 2 * pl.nblk, n_seg);
         hipLaunchKernelGGL(resample16_kernel, grid16, block, smem16, s, d_in, in_stride, src_len, d_out, out_stride, out_len,
-                           n_valid, (const rs_f16x8 *)pl.d_op16, pl.hop, pl.N, pl.K, pl.dmin);
+                           n_valid, (const rs_f16x8 *)pl.d_op16, pl.hop, pl.N, pl.K, pl.dmin, pl.op16_unscale);
         return;
     }
     hipLaunchKernelGGL(resample_kernel, grid, block, smem, s, d_in, in_stride, src_len, d_out, out_stride, out_len,

@@ -211,6 +211,10 @@ BH_API int bh_topk_from_logits(bh_classifier *c, const float *logits, size_t n, 
 BH_API int bh_forward_device(bh_classifier *c, bh_batch_context *ctx, const float *d_segments,
                              size_t n, float *d_logits, int32_t *d_topk_index,
                              float *d_topk_conf);
+/* Returns BH_ERR_NONFINITE (once; the counter is cleared) when a forward enqueued since the last check produced inf / NaN
+ * logits for a segment whose samples were all finite: in the f16 operand modes an activation reached 65 504.  The host
+ * entry points (bh_predict*) report the same after filling their results.  Counted by the top-k stage, i.e. only for
+ * forwards that were given top-k buffers. */
 BH_API int bh_batch_context_synchronize(bh_batch_context *ctx);
 BH_API void *bh_batch_context_stream(bh_batch_context *ctx); /* hipStream_t */
 

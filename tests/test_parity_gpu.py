@@ -471,6 +471,109 @@ def test_precision_modes_on_the_full_model(full_model, oracle_lib):
     assert (out["f16"].argmax(1) == ref.argmax(1)).all() and (out["f16x3"].argmax(1) == ref.argmax(1)).all()
 
 
+def _rescale_trunk(m, scales):
+    """A function-preserving re-parameterisation of a synthetic model: every residual-connected group of project outputs
+    (the linear 'trunk' tensors between blocks) is multiplied by a power of two -- project weights and bias times s -- and
+    every layer that reads such a tensor gets its weights divided by s.  Exact in f32 arithmetic (powers of two), so the
+    oracle's logits do not move; the f16 operand planes, though, see weights 2^-12 / 2^10 times their usual size and
+    activations up to 2^10 times larger."""
+    import copy
+    from birda_amd import modelfile as mf
+    m2 = copy.deepcopy(m)
+    blob = m2.blob.copy()
+    comp = {}          # tensor -> component id
+    order = []
+    for i, L in enumerate(m2.layers):
+        if L.op == mf.OP_PWCONV and L.act == mf.ACT_NONE:
+            c = comp[L.res_tensor] if L.res_tensor != mf.NO_TENSOR else len(order)
+            if c == len(order):
+                order.append(c)
+            comp[i + 1] = c
+    scale = {c: scales[c % len(scales)] for c in order}
+    for i, L in enumerate(m2.layers):
+        if L.op in (mf.OP_PWCONV, mf.OP_DENSE) and L.in_tensor in comp:      # a reader of a trunk tensor
+            blob[L.w_off:L.w_off + L.cin * L.cout] /= np.float32(scale[comp[L.in_tensor]])
+        else:
+            assert L.in_tensor not in comp, "only 1x1 layers read trunk tensors in the synthetic stacks"
+        if (i + 1) in comp:                                                     # a producer
+            s = np.float32(scale[comp[i + 1]])
+            blob[L.w_off:L.w_off + L.cin * L.cout] *= s
+            blob[L.b_off:L.b_off + L.cout] *= s
+    m2.blob = blob
+    return m2, len(order)
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f16"])
+def test_f16_operand_planes_survive_tiny_and_huge_weights(model_dir, oracle_lib, tmp_path, precision):
+    """the hi / lo f16 split must hold the fp32 tolerance when a layer's weights are 2^-12 or 2^10 times
+    their usual size (the lo half of an unscaled small weight is an f16 subnormal) and when block inputs are ~1e4.  Every
+    f16 weight plane is pre-scaled at create by an exact power of two into [2^13, 2^14) and the scale is undone in the
+    f32 epilogue, so the logits must agree with the oracle's -- which, the rescaling being exact, are also the ORIGINAL
+    model's logits."""
+    from birda_amd import modelfile as mf, synth
+    from birda_amd.classifier import BirdClassifier
+    path0, labels, m, _ = model_dir["mini_b0"]
+    m2, n_comp = _rescale_trunk(m, [2.0 ** -12, 2.0 ** 10])
+    assert n_comp >= 7
+    path = str(tmp_path / "rescaled.bhm")
+    mf.write_model(path, m2)
+    segs = synth.synth_segments(6, m.sample_count, m.sample_rate, start=70)
+    ref0 = oracle_lib.OracleModel(path0).forward(segs)
+    ref = oracle_lib.OracleModel(path).forward(segs)
+    scale = max(1.0, float(np.abs(ref0).max()))
+    assert np.abs(ref - ref0).max() <= 2e-6 * scale          # the re-parameterisation is exact up to f32 rounding order
+    clf = BirdClassifier(path, labels, precision=precision)
+    assert len(clf.fused_blocks()) == 16
+    ctx = clf.create_batch_context(8)
+    got = clf.predict_logits(ctx, segs)
+    err = float(np.abs(got - ref).max())
+    print(f"{precision}: rescaled model max|dlogit| = {err:.3e} of scale {scale:.2f}")
+    assert np.isfinite(got).all() and err <= (LOGIT_RTOL if precision == "f16x3" else F16_LOGIT_RTOL) * scale
+    ctx.close(); clf.close()
+
+
+def test_f16_activation_overflow_is_reported_not_silent(model_dir, oracle_lib, tmp_path):
+    """Trunk tensors multiplied by 2^14 (block inputs ~1e5 > 65 504): the f16 operand modes cannot represent them.  That must
+    come back as BH_ERR_NONFINITE -- from the host entry points and from bh_batch_context_synchronize after a device-side
+    forward -- while BH_FLAG_F32 still computes the right logits; and a segment that ARRIVES with NaN samples is not an error."""
+    import torch
+    from birda_amd import modelfile as mf, synth
+    from birda_amd._lib import BirdaHipError
+    from birda_amd.classifier import BirdClassifier
+    path0, labels, m, _ = model_dir["mini_b0"]
+    m2, _ = _rescale_trunk(m, [2.0 ** 14])
+    path = str(tmp_path / "overflow.bhm")
+    mf.write_model(path, m2)
+    segs = synth.synth_segments(5, m.sample_count, m.sample_rate, start=10)
+    ref = oracle_lib.OracleModel(path0).forward(segs)
+    scale = max(1.0, float(np.abs(ref).max()))
+    clf = BirdClassifier(path, labels, precision="f32")
+    ctx = clf.create_batch_context(8)
+    assert np.abs(clf.predict_logits(ctx, segs) - ref).max() <= LOGIT_RTOL * scale
+    ctx.close(); clf.close()
+    for prec in ("f16x3", "f16"):
+        clf = BirdClassifier(path, labels, precision=prec)
+        ctx = clf.create_batch_context(8)
+        with pytest.raises(BirdaHipError) as e:
+            clf.predict_batch_with_context(ctx, list(segs))
+        assert e.value.code == -8 and "f16 operand range" in str(e.value)
+        x = torch.from_numpy(segs).cuda()
+        lg = torch.empty((5, m.n_classes), device="cuda"); ti = torch.empty((5, 5), dtype=torch.int32, device="cuda"); tc = torch.empty((5, 5), device="cuda")
+        clf.forward_device(ctx, x.data_ptr(), 5, lg.data_ptr(), ti.data_ptr(), tc.data_ptr())
+        with pytest.raises(BirdaHipError) as e:
+            ctx.synchronize()
+        assert e.value.code == -8
+        ctx.synchronize()                                       # reported once: the counter is cleared
+        ctx.close(); clf.close()
+    # the healthy model: NaN samples in, NaN row out, no error
+    clf = BirdClassifier(path0, labels, precision="f16x3")
+    ctx = clf.create_batch_context(8)
+    bad = segs.copy(); bad[2, 100] = np.nan
+    res = clf.predict_batch_with_context(ctx, list(bad))
+    assert len(res) == 5 and res[2].predictions == []
+    ctx.close(); clf.close()
+
+
 def test_fused_head_pool_on_a_small_arena(model_dir, oracle_lib):
     """The head conv + GELU + pool launch reads the conv's input while finished workgroups already store pooled rows:
     the arena plan must keep the two apart (on this toy stack first-fit used to put both at offset 0).  Many
