@@ -99,6 +99,7 @@ struct bh_batch_context {
     std::vector<hipEvent_t> copy_ev;         // one per sub-slice in flight
     float *d_input = nullptr;    // [max_batch][sample_count]
     float *d_minmax = nullptr;   // [max_batch][8][2]
+    unsigned *d_inbad = nullptr; // [max_batch][8]: the slice of the segment holds an inf / NaN sample
     float *d_arena = nullptr;
     size_t arena_floats = 0;
     std::vector<size_t> t_off;   // per tensor offset (floats) into the arena
@@ -320,6 +321,7 @@ int ctx_create(bh_classifier *c, size_t max_batch, bool keep, bh_batch_context *
     const size_t in_bytes = max_batch * (size_t)m.h.sample_count * sizeof(float);
     HIPCHK(hipMalloc((void **)&ctx->d_input, in_bytes));
     HIPCHK(hipMalloc((void **)&ctx->d_minmax, max_batch * 16 * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&ctx->d_inbad, max_batch * 8 * sizeof(unsigned)));
     plan_arena(m, c->fused_at, c->head_gap, max_batch, keep, ctx->t_off, ctx->arena_floats);
     HIPCHK(hipMalloc((void **)&ctx->d_arena, ctx->arena_floats * sizeof(float)));
     HIPCHK(hipMalloc((void **)&ctx->d_logits, max_batch * (size_t)m.h.n_classes * sizeof(float)));
@@ -345,7 +347,7 @@ void ctx_destroy(bh_batch_context *ctx) {
     for (auto e : ctx->ev) (void)hipEventDestroy(e);
     for (auto e : ctx->copy_ev) (void)hipEventDestroy(e);
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
-    (void)hipFree(ctx->d_input); (void)hipFree(ctx->d_minmax); (void)hipFree(ctx->d_arena);
+    (void)hipFree(ctx->d_input); (void)hipFree(ctx->d_minmax); (void)hipFree(ctx->d_inbad); (void)hipFree(ctx->d_arena);
     (void)hipFree(ctx->d_logits); (void)hipFree(ctx->d_topk_idx); (void)hipFree(ctx->d_topk_conf);
     (void)hipHostFree(ctx->h_input); (void)hipHostFree(ctx->h_topk_idx); (void)hipHostFree(ctx->h_topk_conf);
     (void)hipFree(ctx->d_raw); (void)hipHostFree(ctx->h_raw);
@@ -363,7 +365,7 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
     auto T = [&](uint32_t t) { return ctx->d_arena + ctx->t_off[t]; };
     const uint32_t nl = (uint32_t)m.layers.size();
     ctx_mark(ctx, -1);
-    bh::launch_minmax(d_seg, ctx->d_minmax, (int)n, (int)m.h.sample_count, s);
+    bh::launch_minmax(d_seg, ctx->d_minmax, ctx->d_inbad, (int)n, (int)m.h.sample_count, s);
     ctx_mark(ctx, ST_MINMAX);
     bh::launch_mel(d_seg, ctx->d_minmax, T(0), c->fe, c->d_fe, (int)n, s);
     ctx_mark(ctx, ST_MEL);
@@ -432,7 +434,7 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
     }
     if (d_idx && d_conf) {
         bh::launch_topk(d_logits, (int)n, (int)m.h.n_classes, (int)m.h.output_activation, (int)c->top_k,
-                        c->min_conf, c->filter, d_idx, d_conf, ctx->d_minmax, ctx->d_nonfinite, s);
+                        c->min_conf, c->filter, d_idx, d_conf, ctx->d_inbad, ctx->d_nonfinite, s);
         ctx_mark(ctx, ST_TOPK);
     }
     HIPCHK(hipGetLastError());

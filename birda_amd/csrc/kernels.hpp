@@ -210,7 +210,8 @@ struct FrontendParams {
 // interleaved PCM16 on the device -> mono f32 segments starting at d_starts[i] (zero-padded tail)
 void launch_segment_pcm16(const int16_t *d_pcm, size_t n_frames, int channels, const unsigned long long *d_starts,
                           int n_seg, int seg_len, float *d_out, size_t out_stride, hipStream_t s);
-void launch_minmax(const float *x, float *minmax, int n_seg, int sample_count, hipStream_t s);
+// minmax [n_seg][8][2]: min / max of eight slices of every segment; in_bad (nullable) [n_seg][8]: 1 where the slice holds an inf / NaN
+void launch_minmax(const float *x, float *minmax, unsigned *in_bad, int n_seg, int sample_count, hipStream_t s);
 void launch_mel(const float *x, const float *minmax, float *spec, const FrontendParams &p,
                 const FrontendParams *d_p, int n_seg, hipStream_t s);
 
@@ -251,10 +252,10 @@ struct TopkFilter {
     int keep_unmatched = 1;
     int rerank = 0;
 };
-// minmax (nullable): the segments' min / max partials [n_seg][8][2]; nonfinite (nullable): counter that receives +1 for every
-// segment whose logits hold an inf / NaN although its samples were all finite (an operand left the f16 range on the way)
+// in_bad (nullable): launch_minmax's flags [n_seg][8]; nonfinite (nullable): counter that receives +1 for every segment whose
+// logits hold an inf / NaN although its samples were all finite (an operand left the f16 range on the way)
 void launch_topk(const float *logits, int n_seg, int n_classes, int out_act, int top_k, float min_conf,
-                 const TopkFilter &filter, int32_t *idx, float *conf, const float *minmax, unsigned *nonfinite, hipStream_t s);
+                 const TopkFilter &filter, int32_t *idx, float *conf, const unsigned *in_bad, unsigned *nonfinite, hipStream_t s);
 
 // Polyphase resampler (resample.hip): rubato's FFT resampler as one dense operator on the MFMA.
 struct ResamplePlan {

@@ -588,7 +588,7 @@ __device__ __forceinline__ void topk_better(float &bv, int &bi, float ov, int oi
 __global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ logits, int n_classes, int out_act,
                                                     int top_k, float min_conf, const TopkFilter flt,
                                                     int32_t *__restrict__ idx, float *__restrict__ conf,
-                                                    const float *__restrict__ minmax, unsigned *__restrict__ nonfinite) {
+                                                    const unsigned *__restrict__ in_bad, unsigned *__restrict__ nonfinite) {
     extern __shared__ float row[];   // n_classes logits
     __shared__ float sv[4];
     __shared__ int si[4];
@@ -605,8 +605,8 @@ __global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ log
         // non-finite logits from FINITE samples: an operand overflowed on the way (f16 range); a segment that came in with
         // NaN / inf samples is the caller's business and is not counted
         bool in_ok = true;
-        if (minmax)
-            for (int q = 0; q < 16; q++) in_ok &= fabsf(minmax[(size_t)seg * 16 + q]) <= 3.4028235e38f;
+        if (in_bad)
+            for (int q = 0; q < 8; q++) in_ok &= in_bad[(size_t)seg * 8 + q] == 0u;
         if (in_ok) atomicAdd(nonfinite, 1u);
     }
     // softmax statistics
@@ -695,7 +695,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ log
 }
 
 void launch_topk(const float *logits, int n_seg, int n_classes, int out_act, int top_k, float min_conf,
-                 const TopkFilter &filter, int32_t *idx, float *conf, const float *minmax, unsigned *nonfinite, hipStream_t s) {
+                 const TopkFilter &filter, int32_t *idx, float *conf, const unsigned *in_bad, unsigned *nonfinite, hipStream_t s) {
     static DeviceOnce once;
     once.run([] {
         // (the kernel also has a few static __shared__ words: ask for less than the full 160 KB)
@@ -703,7 +703,7 @@ void launch_topk(const float *logits, int n_seg, int n_classes, int out_act, int
             (void)hipGetLastError();
     });
     hipLaunchKernelGGL(topk_kernel, dim3(n_seg), dim3(256), (size_t)n_classes * sizeof(float), s, logits, n_classes, out_act, top_k,
-                       min_conf, filter, idx, conf, minmax, nonfinite);
+                       min_conf, filter, idx, conf, in_bad, nonfinite);
 }
 
 }  // namespace bh

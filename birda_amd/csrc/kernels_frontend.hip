@@ -35,24 +35,31 @@ __device__ inline float wave_max(float v) {
 
 // grid (MM_SPLIT, n_seg), block 256: partial min/max of one slice of a segment
 __global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ x, float *__restrict__ mm,
-                                                      int sample_count) {
+                                                      unsigned *__restrict__ in_bad, int sample_count) {
     const int seg = blockIdx.y, part = blockIdx.x;
     const int n4 = sample_count >> 2;
     const int per = (n4 + MM_SPLIT - 1) / MM_SPLIT;
     const int lo = part * per, hi = min(n4, lo + per);
     const float4 *p = reinterpret_cast<const float4 *>(x + (size_t)seg * sample_count);
     float mn = INFINITY, mx = -INFINITY;
+    // fminf / fmaxf skip NaN, so a corrupt decode would go unnoticed here: z accumulates v * 0, which is 0 for every finite
+    // sample and NaN for inf / NaN (two packed FMAs per 16 bytes)
+    float z0 = 0.0f, z1 = 0.0f;
     for (int i = lo + threadIdx.x; i < hi; i += 256) {
         float4 v = p[i];
         mn = fminf(fminf(mn, v.x), fminf(v.y, fminf(v.z, v.w)));
         mx = fmaxf(fmaxf(mx, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+        z0 = __builtin_fmaf(v.x, 0.0f, z0); z1 = __builtin_fmaf(v.y, 0.0f, z1);
+        z0 = __builtin_fmaf(v.z, 0.0f, z0); z1 = __builtin_fmaf(v.w, 0.0f, z1);
     }
     if (part == MM_SPLIT - 1)  // scalar tail when sample_count % 4 != 0
         for (int i = (n4 << 2) + threadIdx.x; i < sample_count; i += 256) {
             float v = x[(size_t)seg * sample_count + i];
             mn = fminf(mn, v); mx = fmaxf(mx, v);
+            z0 = __builtin_fmaf(v, 0.0f, z0);
         }
     mn = wave_min(mn); mx = wave_max(mx);
+    const int any_bad = __syncthreads_or((z0 + z1) != 0.0f ? 1 : 0);   // NaN != 0
     __shared__ float s[8];
     const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { s[w] = mn; s[4 + w] = mx; }
@@ -62,11 +69,12 @@ __global__ __launch_bounds__(256) void minmax_kernel(const float *__restrict__ x
         mx = fmaxf(fmaxf(s[4], s[5]), fmaxf(s[6], s[7]));
         mm[((size_t)seg * MM_SPLIT + part) * 2 + 0] = mn;
         mm[((size_t)seg * MM_SPLIT + part) * 2 + 1] = mx;
+        if (in_bad) in_bad[(size_t)seg * MM_SPLIT + part] = any_bad ? 1u : 0u;
     }
 }
 
-void launch_minmax(const float *x, float *minmax, int n_seg, int sample_count, hipStream_t s) {
-    hipLaunchKernelGGL(minmax_kernel, dim3(MM_SPLIT, n_seg), dim3(256), 0, s, x, minmax, sample_count);
+void launch_minmax(const float *x, float *minmax, unsigned *in_bad, int n_seg, int sample_count, hipStream_t s) {
+    hipLaunchKernelGGL(minmax_kernel, dim3(MM_SPLIT, n_seg), dim3(256), 0, s, x, minmax, in_bad, sample_count);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -326,6 +326,7 @@ __global__ __launch_bounds__(256, 2) void resample16_kernel(const float *__restr
     const float *xseg = in + (size_t)seg * in_stride;
     const int span = 63 * hop + K;
     const int g0 = t0 * hop + dmin;
+    float amax = 0.0f;   // largest |sample| of this workgroup's span
     for (int i0 = tid; i0 < span; i0 += 256 * 8) {   // 8 independent loads in flight per thread
         float v[8];
 #pragma unroll
@@ -335,7 +336,24 @@ __global__ __launch_bounds__(256, 2) void resample16_kernel(const float *__restr
         }
 #pragma unroll
         for (int u = 0; u < 8; u++)
-            if (i0 + u * 256 < span) smem[i0 + u * 256] = v[u];
+            if (i0 + u * 256 < span) { smem[i0 + u * 256] = v[u]; amax = fmaxf(amax, fabsf(v[u])); }
+    }
+    // Block floating point for the f16 operand split: the span is multiplied by the power of two that puts its largest
+    // sample in [2^13, 2^14) (quiet recordings -- |x| ~ 1e-4 is ordinary field audio -- would otherwise sit among the f16
+    // subnormals and lose their lo halves entirely), and the store multiplies by its inverse.  Exact (powers of two), local
+    // to the workgroup, independent of every other segment.  A span of zeros / denormals, or one holding inf, keeps scale 1.
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    float *amax_s = smem + ((span + 3) & ~3);
+    if (lane == 0) amax_s[wave] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(amax_s[0], amax_s[1]), fmaxf(amax_s[2], amax_s[3]));
+    const int ex = (int)((__float_as_uint(amax) >> 23) & 255u);        // amax = m 2^(ex - 127), m in [1, 2)
+    const bool rescale = ex >= 14 && ex <= 253 && ex != 140;           // 2^(140 - ex) and its inverse are normal floats
+    const float in_scale = rescale ? __uint_as_float((unsigned)(267 - ex) << 23) : 1.0f;     // 2^(140 - ex)
+    const float out_unscale = op_unscale * (rescale ? __uint_as_float((unsigned)(ex - 13) << 23) : 1.0f);   // x 2^(ex - 140)
+    if (rescale) {
+        for (int i = tid; i < span; i += 256) smem[i] *= in_scale;
     }
     __syncthreads();
 
@@ -425,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void resample16_kernel(const float *__restr
             v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
         }
 #pragma unroll
-        for (int r = 0; r < 4; r++) v[r] *= op_unscale;   // the operator planes hold G * 2^s
+        for (int r = 0; r < 4; r++) v[r] *= out_unscale;   // the operator planes hold G * 2^s, the span x * 2^(140 - ex)
         const long o = (long)t * N + cb * 80 + m * 16 + kq * 4;  // 4 consecutive output samples
         if (o + 3 < out_len && o + 3 < n_valid) {
             *reinterpret_cast<float4 *>(oseg + o) = make_float4(v[0], v[1], v[2], v[3]);
@@ -450,7 +468,7 @@ void launch_resample(const ResamplePlan &pl, const float *d_in, size_t in_stride
     if (split_f16) {
         static DeviceOnce attr16_set;
         attr16_set.run([] { (void)hipFuncSetAttribute((const void *)resample16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-        const size_t smem16 = std::max(span_bytes, (size_t)4 * 3 * RS16_MT * 64 * sizeof(float4));
+        const size_t smem16 = std::max(span_bytes + 32, (size_t)4 * 3 * RS16_MT * 64 * sizeof(float4));   // + the 4 wave maxima behind the span
         dim3 grid16((frames + 63) / 64, 2 * pl.nblk, n_seg);
         hipLaunchKernelGGL(resample16_kernel, grid16, block, smem16, s, d_in, in_stride, src_len, d_out, out_stride, out_len,
                            n_valid, (const rs_f16x8 *)pl.d_op16, pl.hop, pl.N, pl.K, pl.dmin, pl.op16_unscale);

@@ -77,6 +77,27 @@ def test_matches_block_fft_restatement(clf, oracle_lib, frm, to):
         assert err <= RESAMPLE_ATOL, (frm, to, n, err)
 
 
+@pytest.mark.parametrize("amplitude", [1e-4, 3e-7, 3.0e4, 1.0e9])
+def test_quiet_and_loud_audio_keep_the_relative_tolerance(clf, oracle_lib, amplitude):
+    """The resampler is linear, so its error must scale with the signal: field recordings with |x| ~ 1e-4 (or float WAVs far
+    above 1) keep RESAMPLE_ATOL RELATIVE to their amplitude.  In the split-f16 kernel this is the block floating point of
+    the staged span -- unscaled, samples of 1e-4 sit next to the f16 subnormals and the lo halves vanish."""
+    frm, to = 44100, 48000
+    rng = np.random.default_rng(11)
+    n = 132300
+    base = np.clip(0.3 * rng.standard_normal(n) + 0.5 * np.sin(2 * np.pi * 1234.5 * np.arange(n) / frm), -1, 1)
+    base[: n // 3] *= 1e-3                     # a much quieter passage inside the same segment: local spans scale locally
+    x = (base * amplitude).astype(np.float32)
+    want = oracle_lib.resample(x, frm, to)
+    got = clf.resample(x, frm, to)
+    assert np.isfinite(got).all()
+    err = float(np.abs(got - want).max())
+    assert err <= RESAMPLE_ATOL * amplitude, (amplitude, err / amplitude)
+    quiet = slice(2000, int(n // 3 * to / frm) - 4000)     # inside the quiet passage, away from its edges
+    errq = float(np.abs(got[quiet] - want[quiet]).max())
+    assert errq <= RESAMPLE_ATOL * amplitude * 1e-3 * 4, (amplitude, errq / (amplitude * 1e-3))
+
+
 def test_identity_and_empty(clf):
     x = np.array([0.1, 0.2, 0.3, 0.4, 0.5], np.float32)
     assert np.array_equal(clf.resample(x, 48000, 48000), x)      # resample.rs:11-13, :354-359
