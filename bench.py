@@ -169,7 +169,7 @@ def analyse(clf, m, info, fused, stage_tot, layer_tot, segs_done, steps, slices_
         # this kernel runs n_blocks equal-shaped blocks per slice; every block sees every segment once
         n_blocks = max(1, dom["launches"] // (steps * slices_per_step))
         # the instantiation's last template argument is its MFMA type: 0 = f32, 3 = split f16 (x3), 1 = f16
-        dom_prec = int(dom["kernel"].rstrip(">").split(",")[-1])
+        dom_prec = int(dom["kernel"].rstrip(">").split(",")[15])   # (a 17th argument marks a persistent instantiation)
         if dom_prec == 0:
             peak, note, insn = PEAK_F32_MFMA_TFLOPS, "dense f32 MFMA peak (runs at the vector rate)", "v_mfma_f32_16x16x4_f32"
         elif dom_prec == 3:

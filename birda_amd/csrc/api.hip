@@ -188,13 +188,15 @@ std::vector<float> build_gf(const bh::BranchRec &b, const float *W, int nm_pad, 
                     }
         return frag;
     }
-    if (prec != 0) {  // [step of 32 k][mel tile][plane hi, lo][64 lanes][8 halves]: k = 32 s + 8 (lane >> 4) + jj
+    if (prec != 0) {  // [step of 32 k][mel tile][plane hi, lo][64 lanes][8 halves]: k = 32 s + 4 jj + (lane >> 4)
+        // (the k of a step are dealt to the four lane groups round-robin, not in runs of 8: the kernel's frame-strided LDS
+        //  reads of the matching samples then fall on distinct banks -- kernels_frontend.hip, mel_kernel)
         uint16_t *h = reinterpret_cast<uint16_t *>(frag.data());
         for (int st = 0; st < K / 32; st++)
             for (int mt = 0; mt < mt_n; mt++)
                 for (int lane = 0; lane < 64; lane++)
                     for (int jj = 0; jj < 8; jj++) {
-                        const float v = gf[(size_t)(32 * st + 8 * (lane >> 4) + jj) * nm_pad + 16 * mt + (lane & 15)];
+                        const float v = gf[(size_t)(32 * st + 4 * jj + (lane >> 4)) * nm_pad + 16 * mt + (lane & 15)];
                         const uint16_t hi = f32_to_f16(v);
                         const size_t base = (((size_t)st * mt_n + mt) * 2) * 64 * 8;
                         h[base + (size_t)lane * 8 + jj] = hi;

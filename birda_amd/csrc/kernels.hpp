@@ -305,6 +305,7 @@ struct MbDesc {
               // 16 no weight DMA, 32 no output store.  Results are wrong when non-zero.
     // filled by mb_plan()
     int cfg, CE, TH, S, tiles_y, tiles_x, IH, IW, KG, nchunks, NTOP, mpad_max;
+    int ring;  // 1: the chunk weights go through rings of LDS buffers (We x 2, Wp x 3, Wd x 2), refilled a whole chunk ahead
     size_t lds_bytes;
 };
 int mb_config_count();

@@ -243,7 +243,13 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void mel_kernel(const float *
         };
         const float *xf = xs + li * H;
         auto step = [&](int st, const f16x8 (&ah)[MT], const f16x8 (&al)[MT]) {
-            const int j0 = st * 32 + 8 * kq;
+            // element jj of the lane's operand fragment is k = 32 st + 4 jj + kq (the operator planes are packed to match,
+            // api.hip build_gf): the four lane groups read NEIGHBOURING samples, so the 32 lanes of an LDS access spread over
+            // (16 frames x hop) + {0, 1}.  With runs of 8 k per group a hop of 278 put two lanes on every bank and 280 eight;
+            // now 278 is conflict-free and 280 four-way (a hop that is 24 mod 32 has only four distinct frame banks; padding
+            // the staged span so that frames sit hop + 2 apart removes that too on paper, but the scalar staging stores and
+            // the pad bookkeeping cost more than the conflicts: 0.83 against 0.67 us per segment)
+            const int j0 = st * 32 + kq;
             f16x8 bh[MEL_FT], bl[MEL_FT];
 #pragma unroll
             for (int f = 0; f < MEL_FT; f++)
@@ -251,7 +257,7 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void mel_kernel(const float *
                 float y[8];
 #pragma unroll
                 for (int jj = 0; jj < 8; jj++)   // (one v_add_f32 each, on purpose: see bh_add_unpacked)
-                    y[jj] = bh_add_unpacked(xf[f * 16 * H + j0 + jj + 1], xf[f * 16 * H + L - 1 - j0 - jj]);
+                    y[jj] = bh_add_unpacked(xf[f * 16 * H + j0 + 4 * jj + 1], xf[f * 16 * H + L - 1 - j0 - 4 * jj]);
                 bh_split8(y, bh[f], bl[f]);
             }
             // The split stays out of the MFMA sequence.  (Not needed for correctness any more: the wrong tiles this

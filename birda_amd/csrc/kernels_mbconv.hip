@@ -116,8 +116,13 @@ __device__ __forceinline__ void mb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)
 
 //   PREC        0: f32 MFMA (16x16x4, KG counts 16-deep groups); 3: f16 hi/lo split, three 16x16x32 MFMAs
 //               per product (KG counts 32-deep steps); 1: plain f16 operands (one MFMA, ~1e-3 relative)
+//   PERSIST     1: persistent workgroups (grid = workgroups that fit on the chip at once) walking the tiles, with the weights of
+//               EVERY chunk resident in LDS -- loaded once per workgroup, not once per tile and chunk.  For the early blocks
+//               (large images, few channels): a tile's compute is ~5k cycles, and 12 barriers each waiting for a freshly
+//               issued L2 -> LDS transfer plus the launch and set-up of 48-96 workgroups per segment were 70 % of their time
+//               (tools/abl2.sh: chunk loop without any compute 417 of 1061 us, set-up + epilogue 303).
 template <int KS, int ST, int CE, int KG, int RT_W, int NCS, int WM, int WN, int MT_W, int NT_W, int TWL, int XBL,
-          int SS, int OCC, int STEM, int PREC>
+          int SS, int OCC, int STEM, int PREC, int PERSIST = 0>
 __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const int n_seg) {
     static_assert(!STEM || SS == 1, "the stem variant handles one segment per workgroup");
     static_assert(PREC == 0 || CE % 32 == 0 || CE == 16, "f16 project GEMM: 32-deep steps, or one 16-deep step for 16-channel chunks");
@@ -138,26 +143,58 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
     static_assert(NT_U * NCS == NT_E, "column split");
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, kq = lane >> 4;
+    const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave0 = tid0 >> 6;
     const int IH = d.IH, IW = d.IW, TH = d.TH, THTW = d.TH << TWL;
     const int egrid = SS * IH * IW;
     float *Es = smem;
     float *Ds = Es + (size_t)(egrid + 1) * CES;  // + 1: trash row that padding source rows write to
+    // Weight buffers.  ring == 0: one buffer each, refilled one PHASE ahead of its reader (see above).  ring == 1 (blocks whose
+    // chunks are small: the early, large-image blocks): We x 2, Wp x 3, Wd x 2, refilled one whole CHUNK ahead -- a phase of
+    // those blocks is a few hundred cycles, shorter than an L2 -> LDS transfer, and the waits in front of both barriers were
+    // half of the kernel's wave-cycles (tools/gpu_mb_stamps.py); the ring costs 5-7 KB of LDS.
+    const bool ring = !PERSIST && d.ring != 0;
+    const int nbuf_e = PERSIST ? d.nchunks : (ring ? 2 : 1), nbuf_p = PERSIST ? d.nchunks : (ring ? 3 : 1);
     float *WeS = Ds + DS_FLOATS;
     _Float16 *DsH = reinterpret_cast<_Float16 *>(Ds), *DsL = DsH + POUT_PAD * DSH;   // PREC != 0
-    float *WpS = WeS + WE_FLOATS;
-    float *Wds = WpS + WP_FLOATS;
-    int *omap = reinterpret_cast<int *>(Wds + WD_FLOATS);
-    const float *bes = WeS + KG * NT_E * FRAG, *bds = Wds + KS * KS * CE;
+    float *WpS = WeS + nbuf_e * WE_FLOATS;
+    float *Wds = WpS + nbuf_p * WP_FLOATS;
+    int *omap = reinterpret_cast<int *>(Wds + nbuf_e * WD_FLOATS);
 
     MbClock t_last{};
     if (d.stamps) t_last.last = __builtin_readcyclecounter();
-    mb_dma<WE_FLOATS>(d.We, WeS, wave, lane);
-    mb_dma<WD_FLOATS>(d.Wd, Wds, wave, lane);
+    if constexpr (PERSIST != 0) {
+        for (int c = 0; c < d.nchunks; c++) {   // every chunk's weights, once
+            mb_dma<WE_FLOATS>(d.We + (size_t)c * WE_FLOATS, WeS + c * WE_FLOATS, wave0, lane0);
+            mb_dma<WD_FLOATS>(d.Wd + (size_t)c * WD_FLOATS, Wds + c * WD_FLOATS, wave0, lane0);
+            mb_dma<WP_FLOATS>(d.Wp + (size_t)c * WP_FLOATS, WpS + c * WP_FLOATS, wave0, lane0);
+        }
+    } else {
+        mb_dma<WE_FLOATS>(d.We, WeS, wave0, lane0);
+        mb_dma<WD_FLOATS>(d.Wd, Wds, wave0, lane0);
+        if (ring) {
+            mb_dma<WP_FLOATS>(d.Wp, WpS, wave0, lane0);
+            if (d.nchunks > 1) {
+                mb_dma<WE_FLOATS>(d.We + WE_FLOATS, WeS + WE_FLOATS, wave0, lane0);
+                mb_dma<WD_FLOATS>(d.Wd + WD_FLOATS, Wds + WD_FLOATS, wave0, lane0);
+                mb_dma<WP_FLOATS>(d.Wp + WP_FLOATS, WpS + WP_FLOATS, wave0, lane0);
+            }
+        }
+    }
 
-    const int tyi = blockIdx.y, txi = blockIdx.x;
-    const int seg0 = blockIdx.z * SS;
+    // PERSIST: tile = (segment group, tile row, tile column), linear; this workgroup takes every gridDim.x-th one
+    const int tiles_xy = d.tiles_x * d.tiles_y;
+    const int n_tiles = PERSIST ? tiles_xy * ((n_seg + SS - 1) / SS) : 1;
+    for (int tile = PERSIST ? (int)blockIdx.x : 0; tile < n_tiles; tile += PERSIST ? (int)gridDim.x : 1) {
+    // (everything below is per tile.  The thread index goes through an opaque copy so that hipcc does not hoist the
+    //  tile-invariant index arithmetic out of the tile loop and keep it in registers across it: a first persistent
+    //  version doubled its VGPRs and spilled SGPRs that way)
+    int tid = tid0;
+    if constexpr (PERSIST != 0) asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int tz = PERSIST ? tile / tiles_xy : (int)blockIdx.z, txy = tile - tz * tiles_xy;
+    const int tyi = PERSIST ? txy / d.tiles_x : (int)blockIdx.y, txi = PERSIST ? txy - tyi * d.tiles_x : (int)blockIdx.x;
+    const int seg0 = tz * SS;
     const int nsv = min(SS, n_seg - seg0);
     const int oy0 = tyi * TH, ox0 = txi * TW;
     const int iy0 = oy0 * ST - d.pad_t, ix0 = ox0 * ST - d.pad_l;
@@ -282,6 +319,10 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
 
     for (int ch = 0; ch < nchunks; ch++) {
         const int chn = min(ch + 1, nchunks - 1);
+        // this chunk's weights
+        const float *WeC = WeS + (PERSIST ? ch : ring ? (ch & 1) : 0) * WE_FLOATS, *WdC = Wds + (PERSIST ? ch : ring ? (ch & 1) : 0) * WD_FLOATS;
+        const float *WpC = WpS + (PERSIST ? ch : ring ? (ch % 3) : 0) * WP_FLOATS;
+        const float *bes = WeC + KG * NT_E * FRAG, *bds = WdC + KS * KS * CE;
         mb_stamp(d.stamps, t_last, 1);
 
         // ---- P1: expand ------------------------------------------------------------------
@@ -298,7 +339,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                 if (!(d.dbg & 8)) {
                     if constexpr (PREC != 0) {
                         // fragment planes: [step][column tile]{hi: 64 lanes x 8 halves, lo: same}
-                        const f16x8 *wf = reinterpret_cast<const f16x8 *>(WeS);
+                        const f16x8 *wf = reinterpret_cast<const f16x8 *>(WeC);
 #pragma unroll
                         for (int g = 0; g < KG; g++) {
                             f16x8 bh[NT_U], bl[NT_U];
@@ -330,13 +371,13 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                     float4 bv[NT_U], bn[NT_U];
 #pragma unroll
                     for (int j = 0; j < NT_U; j++)
-                        bv[j] = *reinterpret_cast<const float4 *>(&WeS[((cs * NT_U + j) * 64 + lane) * 4]);
+                        bv[j] = *reinterpret_cast<const float4 *>(&WeC[((cs * NT_U + j) * 64 + lane) * 4]);
 #pragma unroll
                     for (int g = 0; g < KG; g++) {
                         if (g + 1 < KG) {
 #pragma unroll
                             for (int j = 0; j < NT_U; j++)
-                                bn[j] = *reinterpret_cast<const float4 *>(&WeS[(((g + 1) * NT_E + cs * NT_U + j) * 64 + lane) * 4]);
+                                bn[j] = *reinterpret_cast<const float4 *>(&WeC[(((g + 1) * NT_E + cs * NT_U + j) * 64 + lane) * 4]);
                         }
 #pragma unroll
                         for (int c = 0; c < 4; c++)
@@ -377,9 +418,9 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
             }
         }
         mb_stamp(d.stamps, t_last, 2);
-        mb_dma_wait();
-        __syncthreads();  // B1: Es complete; WeS / WpS free; Wds (DMA issued after the last B2) landed
-        if (!(d.dbg & 16)) {
+        if (!ring && !PERSIST) mb_dma_wait();
+        __syncthreads();  // B1: Es complete; (ring == 0) WeS / WpS free; Wds (DMA issued after the last B2) landed
+        if (!ring && !PERSIST && !(d.dbg & 16)) {
             mb_dma<WE_FLOATS>(d.We + (size_t)chn * WE_FLOATS, WeS, wave, lane);
             mb_dma<WP_FLOATS>(d.Wp + (size_t)ch * WP_FLOATS, WpS, wave, lane);
         }
@@ -403,7 +444,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                     for (int j = 0; j < NCOL; j++) e[j] = *reinterpret_cast<const float4 *>(eb + (dy * IW + j) * CES);
 #pragma unroll
                     for (int dx = 0; dx < KS; dx++) {
-                        const float4 w = *reinterpret_cast<const float4 *>(&Wds[(dy * KS + dx) * CE + 4 * c4]);
+                        const float4 w = *reinterpret_cast<const float4 *>(&WdC[(dy * KS + dx) * CE + 4 * c4]);
                         const f32x2 w0 = (f32x2){w.x, w.y}, w1 = (f32x2){w.z, w.w};
 #pragma unroll
                         for (int x = 0; x < XB; x++) {
@@ -439,16 +480,25 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
             }
         }
         mb_stamp(d.stamps, t_last, 4);
-        mb_dma_wait();
-        __syncthreads();  // B2: Ds complete; WeS (next chunk) and WpS (this chunk) landed; Wds free
-        if (!(d.dbg & 16)) mb_dma<WD_FLOATS>(d.Wd + (size_t)chn * WD_FLOATS, Wds, wave, lane);
+        if (!PERSIST) mb_dma_wait();    // ring: the next chunk's weights, on their way since the previous B2
+        __syncthreads();  // B2: Ds complete; (ring == 0) WeS (next chunk) and WpS (this chunk) landed; Wds free
+        if (PERSIST) {
+        } else if (!ring) {
+            if (!(d.dbg & 16)) mb_dma<WD_FLOATS>(d.Wd + (size_t)chn * WD_FLOATS, Wds, wave, lane);
+        } else if (ch + 2 < nchunks && !(d.dbg & 16)) {
+            // chunk ch + 2 into the buffers chunk ch has just finished with (We, Wd: read before this barrier) and into the Wp
+            // buffer of chunk ch - 1 (its project phase ended before B1 of this chunk)
+            mb_dma<WE_FLOATS>(d.We + (size_t)(ch + 2) * WE_FLOATS, WeS + (ch & 1) * WE_FLOATS, wave, lane);
+            mb_dma<WD_FLOATS>(d.Wd + (size_t)(ch + 2) * WD_FLOATS, Wds + (ch & 1) * WD_FLOATS, wave, lane);
+            mb_dma<WP_FLOATS>(d.Wp + (size_t)(ch + 2) * WP_FLOATS, WpS + ((ch + 2) % 3) * WP_FLOATS, wave, lane);
+        }
         mb_stamp(d.stamps, t_last, 5);
 
         // ---- P3: project -----------------------------------------------------------------
         if (!(d.dbg & 4)) {
             if constexpr (P16) {
                 // fragment planes: [column tile]{hi: 64 lanes x 4 halves, lo: same}; k = 4 (lane >> 4) + 0..3
-                const f16x4 *wf = reinterpret_cast<const f16x4 *>(WpS);
+                const f16x4 *wf = reinterpret_cast<const f16x4 *>(WpC);
                 f16x4 a_h[MT_W], a_l[MT_W], b_h[NT_W], b_l[NT_W];
 #pragma unroll
                 for (int i = 0; i < MT_W; i++) {
@@ -472,7 +522,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                         }
                     }
             } else if constexpr (PREC != 0) {
-                const f16x8 *wf = reinterpret_cast<const f16x8 *>(WpS);
+                const f16x8 *wf = reinterpret_cast<const f16x8 *>(WpC);
                 // the weight fragments of a step are taken JB column tiles at a time: all NT_W (up to 10 hi +
                 // 10 lo quads) at once cost 80 registers and spilled the 320-channel blocks
                 constexpr int JB = NT_W <= 6 ? NT_W : (NT_W + 1) / 2;
@@ -513,7 +563,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
             const float *dsb = Ds + ((wm * MT_W) * 16 + li) * CES + 4 * kq;
             float4 a[MT_W], b[NT_W], an[MT_W], bn[NT_W];
 #pragma unroll
-            for (int j = 0; j < NT_W; j++) b[j] = *reinterpret_cast<const float4 *>(&WpS[((wn * NT_W + j) * 64 + lane) * 4]);
+            for (int j = 0; j < NT_W; j++) b[j] = *reinterpret_cast<const float4 *>(&WpC[((wn * NT_W + j) * 64 + lane) * 4]);
 #pragma unroll
             for (int i = 0; i < MT_W; i++) a[i] = *reinterpret_cast<const float4 *>(dsb + i * 16 * CES);
 #pragma unroll
@@ -521,7 +571,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                 if (g + 1 < NT_E) {
 #pragma unroll
                     for (int j = 0; j < NT_W; j++)
-                        bn[j] = *reinterpret_cast<const float4 *>(&WpS[(((g + 1) * NTOP + wn * NT_W + j) * 64 + lane) * 4]);
+                        bn[j] = *reinterpret_cast<const float4 *>(&WpC[(((g + 1) * NTOP + wn * NT_W + j) * 64 + lane) * 4]);
 #pragma unroll
                     for (int i = 0; i < MT_W; i++) an[i] = *reinterpret_cast<const float4 *>(dsb + i * 16 * CES + 16 * (g + 1));
                 }
@@ -566,28 +616,39 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
         }
     }
     mb_stamp(d.stamps, t_last, 7);
-    if (d.stamps && lane == 0)
+    if constexpr (PERSIST != 0) __syncthreads();   // the epilogue has read omap; the next tile's set-up rewrites it
+    }   // tiles
+    if (d.stamps && lane0 == 0)
         for (int i = 0; i < 8; i++) atomicAdd(&d.stamps[i], t_last.acc[i]);
 }
 
 struct MbCfg {
-    int KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC;
+    int KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC, PERSIST;
     void (*launch)(const MbDesc &, int, hipStream_t);
 };
 
 template <int KS, int ST, int CE, int KG, int RT_W, int NCS, int WM, int WN, int MT_W, int NT_W, int TWL, int XBL,
-          int SS, int OCC, int STEM, int PREC>
+          int SS, int OCC, int STEM, int PREC, int PERSIST = 0>
 void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
-    auto kern = mbconv_kernel<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, SS, OCC, STEM, PREC>;
+    auto kern = mbconv_kernel<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, SS, OCC, STEM, PREC, PERSIST>;
     static DeviceOnce attr_set;
     attr_set.run([&] { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     dim3 grid(d.tiles_x, d.tiles_y, (n_seg + d.S - 1) / d.S), block(256);
+    if (PERSIST) {   // as many workgroups as are resident at once: registers allow OCC per SIMD, LDS 160 KB per CU
+        const long total = (long)d.tiles_x * d.tiles_y * ((n_seg + d.S - 1) / d.S);
+        const long per_cu = std::max<long>(1, std::min<long>(OCC, (160 * 1024) / (long)(d.lds_bytes + 256)));
+        grid = dim3((unsigned)std::min<long>(total, per_cu * device_cu_count()));
+    }
     hipLaunchKernelGGL(kern, grid, block, d.lds_bytes, s, d, n_seg);
 }
 
 #define MB_ENTRY_P(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, PREC) \
-    {KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC,                 \
+    {KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC, 0,              \
      mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC, STEM, PREC>}
+// persistent workgroups, every chunk's weights resident in LDS (the early blocks)
+#define MB_ENTRY_PP(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, PREC) \
+    {KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC, 1,               \
+     mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC, STEM, PREC, 1>}
 #define MB_ENTRY_S(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM) \
     MB_ENTRY_P(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, 0)
 #define MB_ENTRY(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC) \
@@ -678,6 +739,14 @@ const MbCfg kCfgs[] = {
     MB_ENTRY_H(5, 1, 4, 4, 1, 4, 1, 4, 7, 5, 3, 8, 1, 1, 0),           // 73/74: 112 -> 672 -> 112, 8x32
     MB_ENTRY_H(5, 1, 6, 2, 2, 2, 2, 2, 6, 4, 2, 4, 1, 1, 0),           // 75/76: 192 -> 1152 -> 192, 4x16 (one segment: no spills)
     MB_ENTRY_H(3, 1, 6, 2, 2, 2, 2, 2, 10, 4, 2, 4, 1, 1, 0),          // 77/78: 192 -> 1152 -> 320, 4x16
+    // persistent twins of the early-block entries (48, 49, 65, 66, 50, 51): indices 79..84
+    //          KS ST CE KG RT NCS WM WN MT NT TWL XBL TH S OCC STEM PREC
+    MB_ENTRY_PP(3, 2, 16, 1, 5, 1, 4, 1, 1, 2, 4, 0, 4, 1, 4, 0, 3),    // 79: as 48 (16 -> 96 -> 24, 48x256 -> 24x128)
+    MB_ENTRY_PP(3, 1, 16, 1, 3, 1, 4, 1, 2, 2, 4, 1, 8, 1, 3, 0, 3),    // 80: as 49 (24 -> 144 -> 24, 24x128)
+    MB_ENTRY_PP(3, 1, 16, 1, 3, 1, 4, 1, 2, 1, 4, 1, 8, 1, 4, 2, 3),    // 81: as 65 (stem block, 2-channel spectrogram)
+    MB_ENTRY_PP(3, 1, 16, 1, 3, 1, 4, 1, 2, 1, 4, 1, 8, 1, 4, 1, 3),    // 82: as 66 (stem block, 1-channel spectrogram)
+    MB_ENTRY_PP(5, 2, 16, 1, 7, 1, 4, 1, 1, 3, 4, 0, 4, 1, 2, 0, 3),    // 83: as 50 (24 -> 144 -> 40, 5x5 s2)
+    MB_ENTRY_PP(5, 1, 16, 2, 4, 1, 4, 1, 3, 3, 4, 2, 12, 1, 2, 0, 3),   // 84: as 51 (40 -> 240 -> 40, 5x5 s1)
 };
 constexpr int kNCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
@@ -710,9 +779,22 @@ double mb_try_th(MbDesc &d, int ci, int th) {
     const size_t we_fl = (size_t)c.KG * (c.CE / 16) * frag + c.CE, wp_fl = p16 ? (size_t)t.NTOP * 256 : psteps * t.NTOP * frag;
     const size_t wd_fl = (size_t)c.KS * c.KS * c.CE + c.CE;
     const size_t ds_fl = c.PREC ? (size_t)pout_pad * (p16 ? 24 : psteps * 32 + 8) : (size_t)pout_pad * ces;
-    t.lds_bytes = (((size_t)c.S * t.IH * t.IW + 1) * ces + ds_fl + we_fl + wp_fl + wd_fl) * 4 +
-                  (size_t)pout_pad * 4;
+    const size_t lds_base = (((size_t)c.S * t.IH * t.IW + 1) * ces + ds_fl) * 4 + (size_t)pout_pad * 4;
+    t.lds_bytes = lds_base + (we_fl + wp_fl + wd_fl) * 4 * (c.PERSIST ? (size_t)t.nchunks : 1);   // persistent: every chunk resident
     if (t.lds_bytes > 160 * 1024) return -1;
+    if (c.PERSIST && t.lds_bytes > 80 * 1024) return -1;   // one workgroup per CU cannot hide its own set-up
+    // weight ring (We x 2, Wp x 3, Wd x 2, a whole chunk of prefetch distance): for 16-channel chunks, when the workgroups the
+    // entry's register budget allows per CU still fit in LDS with it.  BIRDA_HIP_MB_RING=0/1 forces it off / on where it fits.
+    t.ring = 0;
+    {
+        const size_t lds_ring = lds_base + (2 * we_fl + 3 * wp_fl + 2 * wd_fl) * 4;
+        const char *re = getenv("BIRDA_HIP_MB_RING");
+        // Measured (profiles/r2 notes): the ring removes the wait in front of B1 (22 % -> 3 % of a wave's
+        // cycles) but the time moves to B2 and the launch does not get shorter, and wherever it costs a workgroup per CU it is
+        // slower (7.31 -> 8.02 us per segment over all blocks when forced).  Off unless BIRDA_HIP_MB_RING=1.
+        const bool want = !c.PERSIST && re && re[0] == '1' && c.CE == 16 && t.nchunks > 2 && lds_ring <= 160 * 1024;
+        if (want) { t.ring = 1; t.lds_bytes = lds_ring; }
+    }
     d = t;
     const double tiles = (double)t.tiles_y * t.tiles_x / c.S;
     return tiles * ((double)t.mpad_max / 16 * t.KG * 4 * (d.Cexp / 16) + (double)pout_pad / 16 * t.NTOP * (d.Cexp / 4));
@@ -736,6 +818,9 @@ int mb_config_count() { return kNCfgs; }
 int mb_config_name(int ci, char *out, size_t cap) {
     if (ci < 0 || ci >= kNCfgs) return 0;
     const MbCfg &c = kCfgs[ci];
+    if (c.PERSIST)
+        return snprintf(out, cap, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", c.KS, c.ST, c.CE, c.KG, c.RT_W, c.NCS, c.WM,
+                        c.WN, c.MT_W, c.NT_W, c.TWL, c.XBL, c.S, c.OCC, c.STEM, c.PREC, c.PERSIST);
     return snprintf(out, cap, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", c.KS, c.ST, c.CE, c.KG, c.RT_W, c.NCS, c.WM,
                     c.WN, c.MT_W, c.NT_W, c.TWL, c.XBL, c.S, c.OCC, c.STEM, c.PREC);
 }
@@ -763,20 +848,34 @@ bool mb_plan(MbDesc &d, int force_cfg) {
     static const int kPreferred[] = {11, 12, 13, 14, 15, 16, 17, 18, 19, 9, 10, 20, 21};
     // split-f16 with 16-channel chunks (two or more workgroups per CU): the early blocks, and the 6x32
     // blocks whose depthwise phase is light enough (3x3, and the stride-2 5x5)
-    static const int kPreferred16[] = {48, 49, 50, 51, 52, 55, 58, 65, 66};
+    // 79..84: persistent twins of 48, 49, 65, 66, 50, 51.  Measured (us per 1000 segments, same box): the two 5x5 blocks gain
+    // (741 -> 686, 576 -> 536); the stem, 16 -> 96 -> 24 and 24 -> 144 -> 24 blocks LOSE (928 -> 1161, 1032 -> 1504, 737 -> 953):
+    // with every chunk's weights resident they fit two workgroups per CU instead of four, and without a prefetch of the next
+    // tile's rows nothing hides a tile's set-up.  Off by default; BIRDA_HIP_MB_PERSIST=1 all six, =2 the 5x5 pair.
+    static const int kPreferred16a[] = {79, 80, 81, 82, 83, 84, 48, 49, 50, 51, 52, 55, 58, 65, 66};
+    static const int kPreferred16p[] = {83, 84, 48, 49, 50, 51, 52, 55, 58, 65, 66};
+    static const int kPreferred16n[] = {48, 49, 50, 51, 52, 55, 58, 65, 66};
+    const char *pe = getenv("BIRDA_HIP_MB_PERSIST");
+    const int persist_mode = !pe ? 0 : pe[0] == '1' ? 2 : pe[0] == '2' ? 1 : 0;
     if (d.prec == 0)
         for (int ci : kPreferred) {  // at the entry's own tile height: the shapes it was measured on
             MbDesc t = d;
             if (mb_try_th(t, ci, kCfgs[ci].TH) >= 0) { d = t; return true; }
         }
-    if (d.prec == 3)
-        for (int ci : kPreferred16) {
+    if (d.prec == 3) {
+        const int *list = persist_mode == 2 ? kPreferred16a : persist_mode == 1 ? kPreferred16p : kPreferred16n;
+        const int nlist = persist_mode == 2 ? (int)(sizeof kPreferred16a / sizeof(int))
+                        : persist_mode == 1 ? (int)(sizeof kPreferred16p / sizeof(int)) : (int)(sizeof kPreferred16n / sizeof(int));
+        for (int q = 0; q < nlist; q++) {
+            const int ci = list[q];
             MbDesc t = d;
             if (mb_try_th(t, ci, kCfgs[ci].TH) >= 0) { d = t; return true; }
         }
+    }
     double best = -1;
     MbDesc bestd = d;
     for (int ci = 0; ci < kNCfgs; ci++) {
+        if (kCfgs[ci].PERSIST) continue;   // persistent entries only through the preferred list (measured shapes)
         MbDesc t = d;
         const double w = mb_try(t, ci);
         if (w < 0) continue;

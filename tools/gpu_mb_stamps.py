@@ -9,7 +9,7 @@ from birda_amd.classifier import BirdClassifier
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 m = synth.build_model("birdnet_v24")
 path = "/tmp/v24.bhm"; mf.write_model(path, m)
-clf = BirdClassifier(path)
+clf = BirdClassifier(path, precision=os.environ.get("PREC", "f16x3"))
 ctx = clf.create_batch_context(N)
 base = synth.synth_segments(8, m.sample_count, m.sample_rate)
 x = torch.from_numpy(np.tile(base, (N // 8 + 1, 1))[:N]).cuda()
