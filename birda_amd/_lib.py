@@ -97,6 +97,15 @@ SYMBOLS = [
     ("bh_classifier_set_species_list", C.c_int, [_VP, _VP, _SZ]),
     ("bh_classifier_clear_filters", C.c_int, [_VP]),
     ("bh_topk_from_logits", C.c_int, [_VP, _VP, _SZ, C.POINTER(BhResult)]),
+    ("bh_custom_classifier_create", C.c_int, [C.c_char_p, C.c_char_p, C.c_int32, C.c_uint32, C.POINTER(_VP)]),
+    ("bh_custom_classifier_destroy", None, [_VP]),
+    ("bh_custom_classifier_num_classes", C.c_uint32, [_VP]),
+    ("bh_custom_classifier_input_dim", C.c_uint32, [_VP]),
+    ("bh_custom_classifier_label", C.c_char_p, [_VP, C.c_uint32]),
+    ("bh_custom_classifier_predict_batch", C.c_int, [_VP, _VP, _SZ, C.POINTER(BhResult)]),
+    ("bh_predict_batch_two_stage", C.c_int, [_VP, _VP, _VP, C.POINTER(_VP), _SZ, _SZ, C.POINTER(BhResult), _VP]),
+    ("bh_classifier_set_bsg", C.c_int, [_VP, _VP, _VP, _VP, _SZ]),
+    ("bh_classifier_clear_bsg", C.c_int, [_VP]),
     ("bh_multi_create", C.c_int, [C.POINTER(BhMultiConfig), C.POINTER(_VP)]),
     ("bh_multi_destroy", None, [_VP]),
     ("bh_multi_last_error", C.c_char_p, []),
@@ -136,7 +145,8 @@ class BhhProcessingConfig(C.Structure):
                 ("min_confidence", C.c_float), ("overlap", C.c_float), ("batch_size", C.c_size_t),
                 ("csv_bom", C.c_int), ("formats", C.c_uint32), ("front_end", C.c_uint32), ("csv_columns", C.c_char_p),
                 ("model_name", C.c_char_p), ("has_lat", C.c_int), ("has_lon", C.c_int), ("lat", C.c_double),
-                ("lon", C.c_double), ("week", C.c_int), ("reporter", C.c_void_p), ("dual_output", C.c_int)]
+                ("lon", C.c_double), ("week", C.c_int), ("reporter", C.c_void_p), ("dual_output", C.c_int),
+                ("custom_classifier", C.c_void_p)]
 
 
 class BhhProcessResult(C.Structure):

@@ -282,6 +282,30 @@ class BirdClassifier:
     def clear_filters(self):
         check(self._L.bh_classifier_clear_filters(self._h))
 
+    # ---- BSG post-processing (classifier.rs:508-545) on the kept top-k, on the device ------------------------
+    def set_bsg(self, intercept: np.ndarray, slope: np.ndarray, prior: Optional[np.ndarray] = None):
+        """Per-class logistic calibration conf' = sigmoid(intercept + slope * logit(conf)), times the SDM occurrence prior
+        when one is given (has_bsg_processor / apply_bsg_postprocessing)."""
+        a = np.ascontiguousarray(intercept, np.float32)
+        b = np.ascontiguousarray(slope, np.float32)
+        p = np.ascontiguousarray(prior, np.float32) if prior is not None else None
+        check(self._L.bh_classifier_set_bsg(self._h, a.ctypes.data, b.ctypes.data, p.ctypes.data if p is not None else None, a.size))
+
+    def clear_bsg(self):
+        check(self._L.bh_classifier_clear_bsg(self._h))
+
+    # ---- two-stage inference (bat mode, processor.rs:319-360) -------------------------------------------
+    def predict_batch_two_stage(self, ctx: BatchInferenceContext, custom: "CustomClassifier", segments: Sequence[np.ndarray],
+                                want_logits: bool = False):
+        n = len(segments)
+        keep, ptrs, ns = self._ptrs(segments)
+        res = (BhResult * max(1, n))()
+        logits = np.empty((n, custom.num_classes()), np.float32) if want_logits else None
+        check(self._L.bh_predict_batch_two_stage(self._h, ctx._h, custom._h, ptrs, n, ns, res,
+                                                 logits.ctypes.data if want_logits else None))
+        out = custom._results(res, n)
+        return (out, logits) if want_logits else out
+
     def topk_from_logits(self, logits: np.ndarray) -> List[PredictionResult]:
         a = np.ascontiguousarray(logits, np.float32).reshape(-1, self.n_classes())
         arr = (BhResult * max(1, a.shape[0]))()
@@ -292,6 +316,52 @@ class BirdClassifier:
         if getattr(self, "_h", None):
             self._L.bh_classifier_destroy(self._h)
             self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CustomClassifier:
+    """birdnet_onnx::CustomClassifier (reference src/lib.rs:883-901): a small dense model on the backbone's embeddings."""
+
+    def __init__(self, model_path: str, labels_path: Optional[str] = None, device: int = 0, top_k: int = 0):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        check(self._L.bh_custom_classifier_create(model_path.encode(), labels_path.encode() if labels_path else None, device,
+                                                  top_k, C.byref(h)))
+        self._h = h
+
+    def num_classes(self) -> int:
+        return int(self._L.bh_custom_classifier_num_classes(self._h))
+
+    def input_dim(self) -> int:
+        return int(self._L.bh_custom_classifier_input_dim(self._h))
+
+    def label(self, index: int) -> Optional[str]:
+        raw = self._L.bh_custom_classifier_label(self._h, index)
+        return raw.decode("utf-8") if raw is not None else None
+
+    def _results(self, arr, n) -> List[PredictionResult]:
+        out = []
+        for i in range(n):
+            r = arr[i]
+            out.append(PredictionResult([Prediction(self.label(int(r.index[k])) or str(int(r.index[k])), float(r.confidence[k]),
+                                                    int(r.index[k])) for k in range(r.n_pred)]))
+        return out
+
+    def predict_batch(self, embeddings: np.ndarray) -> List[PredictionResult]:
+        e = np.ascontiguousarray(embeddings, np.float32).reshape(-1, self.input_dim())
+        res = (BhResult * max(1, e.shape[0]))()
+        check(self._L.bh_custom_classifier_predict_batch(self._h, e.ctypes.data, e.shape[0], res))
+        return self._results(res, e.shape[0])
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._L.bh_custom_classifier_destroy(h)
 
     def __del__(self):
         try:

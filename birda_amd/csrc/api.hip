@@ -83,6 +83,7 @@ struct bh_classifier {
     bh::TopkFilter filter;                   // range filter / species list applied to the kept top-k (device tables below)
     float *d_class_score = nullptr;
     unsigned char *d_species_keep = nullptr;
+    float *d_bsg = nullptr;                  // intercept | slope | prior, n_classes each
     std::mutex warm_mu;
     std::set<size_t> warmed;                 // WarmupRegistry, classifier.rs:221-246
     bh_batch_context *internal_ctx = nullptr;
@@ -486,7 +487,7 @@ unsigned copy_threads() {
 // (reference: the decode thread filling the channel while the main thread runs batches,
 // src/pipeline/processor.rs:647-671).
 int predict_slices(bh_classifier *c, bh_batch_context *ctx, const float *const *segments, const float *contig,
-                   size_t n, bh_result *out, float *logits_out, float *emb_out) {
+                   size_t n, bh_result *out, float *logits_out, float *emb_out, bool whole_slice = false) {
     const auto &m = c->model;
     const size_t S = m.h.sample_count, NC = m.h.n_classes, TK = c->top_k;
     HIPCHK(hipSetDevice(c->device));
@@ -500,7 +501,8 @@ int predict_slices(bh_classifier *c, bh_batch_context *ctx, const float *const *
         // sub-slices: a quarter of the slice, in whole chunks, never below 128 segments (the late blocks
         // need that many to fill the GPU); debug contexts keep one (bh_debug_read_tensor reads the last)
         size_t sub = nb;
-        if (nb >= 512 && !ctx->keep_tensors && !emb_out) sub = std::max<size_t>(128, ((nb + 3) / 4 + CH - 1) / CH * CH);
+        // (whole_slice: the caller reads an arena tensor of the slice afterwards -- the embeddings of the two-stage path)
+        if (nb >= 512 && !ctx->keep_tensors && !emb_out && !whole_slice) sub = std::max<size_t>(128, ((nb + 3) / 4 + CH - 1) / CH * CH);
         const size_t nsub = (nb + sub - 1) / sub;
         while (ctx->copy_ev.size() < nsub) {
             hipEvent_t e;
@@ -1023,6 +1025,7 @@ void bh_classifier_destroy(bh_classifier *c) {
     (void)hipFree(c->d_stamps);
     (void)hipFree(c->d_class_score);
     (void)hipFree(c->d_species_keep);
+    (void)hipFree(c->d_bsg);
     delete c;
 }
 
@@ -1093,7 +1096,35 @@ int bh_classifier_clear_filters(bh_classifier *c) try {
     if (!c) return fail(BH_ERR_INVALID, "clear_filters: null classifier");
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipDeviceSynchronize());
-    c->filter = bh::TopkFilter{};
+    {   // the range filter / species list only: BSG tables have their own clear
+        bh::TopkFilter f{};
+        f.bsg_intercept = c->filter.bsg_intercept; f.bsg_slope = c->filter.bsg_slope; f.bsg_prior = c->filter.bsg_prior;
+        c->filter = f;
+    }
+    return BH_OK;
+} catch (...) { return on_exception(); }
+
+// ---- BSG post-processing tables (reference classifier.rs:508-545) ------------------------------------------
+int bh_classifier_set_bsg(bh_classifier *c, const float *intercept, const float *slope, const float *prior, size_t n_classes) try {
+    if (!c || !intercept || !slope) return fail(BH_ERR_INVALID, "set_bsg: null argument");
+    if (n_classes != c->model.h.n_classes) return fail(BH_ERR_INVALID, "set_bsg: %zu entries for %u classes", n_classes, c->model.h.n_classes);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    if (!c->d_bsg) HIPCHK(hipMalloc((void **)&c->d_bsg, 3 * n_classes * sizeof(float)));
+    HIPCHK(hipMemcpy(c->d_bsg, intercept, n_classes * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_bsg + n_classes, slope, n_classes * sizeof(float), hipMemcpyHostToDevice));
+    if (prior) HIPCHK(hipMemcpy(c->d_bsg + 2 * n_classes, prior, n_classes * sizeof(float), hipMemcpyHostToDevice));
+    c->filter.bsg_intercept = c->d_bsg;
+    c->filter.bsg_slope = c->d_bsg + n_classes;
+    c->filter.bsg_prior = prior ? c->d_bsg + 2 * n_classes : nullptr;
+    return BH_OK;
+} catch (...) { return on_exception(); }
+
+int bh_classifier_clear_bsg(bh_classifier *c) try {
+    if (!c) return fail(BH_ERR_INVALID, "clear_bsg: null classifier");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    c->filter.bsg_intercept = c->filter.bsg_slope = c->filter.bsg_prior = nullptr;
     return BH_OK;
 } catch (...) { return on_exception(); }
 
@@ -1519,6 +1550,182 @@ int bh_predict_pcm16(bh_classifier *c, bh_batch_context *ctx, const int16_t *pcm
         }
         const int nf = nonfinite_status(c, ctx);
         if (nf != BH_OK) return nf;
+    }
+    return BH_OK;
+} catch (...) { return on_exception(); }
+
+// ---- custom classifier on embeddings (reference birdnet_onnx::CustomClassifier; lib.rs:883-901, processor.rs:319-360) ----
+}  // extern "C"
+
+struct bh_custom_classifier {
+    bh::CustomModel model;
+    int device = 0;
+    uint32_t top_k = 0;
+    std::vector<std::string> labels;
+    float *d_blob = nullptr;
+    std::vector<float *> d_w;     // per layer: W with rows padded to a multiple of 4 (or a pointer into d_blob)
+    std::vector<int> ldw;
+    std::vector<float *> d_owned;
+    // scratch, grown on demand: activations of the two widest layers, logits, top-k rows, host copies
+    float *d_act[2] = {nullptr, nullptr};
+    float *d_in = nullptr;
+    int32_t *d_idx = nullptr;
+    float *d_conf = nullptr;
+    size_t cap_rows = 0;
+    uint32_t max_width = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+};
+
+namespace {
+
+int cc_reserve(bh_custom_classifier *cc, size_t rows) {
+    if (rows <= cc->cap_rows) return BH_OK;
+    for (float *&p : cc->d_act) { (void)hipFree(p); p = nullptr; }
+    (void)hipFree(cc->d_in); (void)hipFree(cc->d_idx); (void)hipFree(cc->d_conf);
+    cc->d_in = nullptr; cc->d_idx = nullptr; cc->d_conf = nullptr; cc->cap_rows = 0;
+    for (float *&p : cc->d_act) HIPCHK(hipMalloc((void **)&p, rows * (size_t)cc->max_width * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&cc->d_in, rows * (size_t)cc->model.h.input_dim * sizeof(float)));
+    HIPCHK(hipMalloc((void **)&cc->d_idx, rows * (size_t)cc->top_k * sizeof(int32_t)));
+    HIPCHK(hipMalloc((void **)&cc->d_conf, rows * (size_t)cc->top_k * sizeof(float)));
+    cc->cap_rows = rows;
+    return BH_OK;
+}
+
+// dense stack + activation / top-k on device rows [n][input_dim] (row stride in_stride); results to the host
+int cc_run(bh_custom_classifier *cc, const float *d_emb, size_t in_stride, size_t n, hipStream_t s, bh_result *out, float *logits_out) {
+    const auto &m = cc->model;
+    int rc = cc_reserve(cc, n);
+    if (rc != BH_OK) return rc;
+    const float *cur = d_emb;
+    if (in_stride != m.h.input_dim) return fail(BH_ERR_INVALID, "custom classifier: embedding rows must be contiguous");
+    for (size_t i = 0; i < m.layers.size(); i++) {
+        const auto &L = m.layers[i];
+        float *dst = cc->d_act[i & 1];
+        bh::launch_pw_gemm(cur, cc->d_w[i], cc->d_blob + L.b_off, nullptr, dst, (int)n, (int)L.in_dim, (int)L.out_dim, cc->ldw[i], (int)L.act, s);
+        cur = dst;
+    }
+    const uint32_t TK = cc->top_k;
+    bh::launch_topk(cur, (int)n, (int)m.h.n_classes, (int)m.h.output_activation, (int)TK, 0.0f, bh::TopkFilter{}, cc->d_idx, cc->d_conf, nullptr, nullptr, s);
+    HIPCHK(hipGetLastError());
+    std::vector<int32_t> hi(n * TK);
+    std::vector<float> hc(n * TK);
+    HIPCHK(hipMemcpyAsync(hi.data(), cc->d_idx, n * TK * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hc.data(), cc->d_conf, n * TK * sizeof(float), hipMemcpyDeviceToHost, s));
+    if (logits_out) HIPCHK(hipMemcpyAsync(logits_out, cur, n * (size_t)m.h.n_classes * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    for (size_t i = 0; i < n; i++) {
+        bh_result &r = out[i];
+        r.n_pred = 0;
+        for (uint32_t k = 0; k < TK; k++) {
+            if (hi[i * TK + k] < 0) break;
+            r.index[r.n_pred] = hi[i * TK + k];
+            r.confidence[r.n_pred] = hc[i * TK + k];
+            r.n_pred++;
+        }
+    }
+    return BH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void bh_custom_classifier_destroy(bh_custom_classifier *cc) {
+    if (!cc) return;
+    (void)hipSetDevice(cc->device);
+    if (cc->stream) { (void)hipStreamSynchronize(cc->stream); (void)hipStreamDestroy(cc->stream); }
+    for (float *p : cc->d_owned) (void)hipFree(p);
+    for (float *p : cc->d_act) (void)hipFree(p);
+    (void)hipFree(cc->d_in); (void)hipFree(cc->d_idx); (void)hipFree(cc->d_conf); (void)hipFree(cc->d_blob);
+    delete cc;
+}
+
+int bh_custom_classifier_create(const char *model_path, const char *labels_path, int32_t device, uint32_t top_k,
+                                bh_custom_classifier **out) try {
+    if (!model_path || !out) return fail(BH_ERR_INVALID, "custom_classifier_create: null argument");
+    *out = nullptr;
+    std::unique_ptr<bh_custom_classifier, void (*)(bh_custom_classifier *)> cc(new bh_custom_classifier(), bh_custom_classifier_destroy);
+    std::string err;
+    if (!bh::load_custom_model(model_path, cc->model, err)) return fail(BH_ERR_IO, "%s", err.c_str());
+    const auto &m = cc->model;
+    if (labels_path) {
+        int rc = read_labels(labels_path, cc->labels);
+        if (rc != BH_OK) return rc;
+        if (cc->labels.size() != m.h.n_classes)
+            return fail(BH_ERR_LABELS, "label count %zu does not match custom classifier output width %u", cc->labels.size(), m.h.n_classes);
+    }
+    const int ndev = bh_device_count();
+    if (ndev <= 0) return fail(BH_ERR_NO_DEVICE, "no HIP device available (libbirda_hip has no CPU path)");
+    if (device < 0 || device >= ndev) return fail(BH_ERR_NO_DEVICE, "device %d out of range (0..%d)", device, ndev - 1);
+    cc->device = device;
+    cc->top_k = top_k ? std::min<uint32_t>(top_k, BH_MAX_TOP_K) : std::min<uint32_t>(m.h.n_classes, BH_MAX_TOP_K);
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipStreamCreateWithFlags(&cc->stream, hipStreamNonBlocking));
+    int rc = upload(m.blob.data(), m.blob.size() * sizeof(float), &cc->d_blob);
+    if (rc != BH_OK) return rc;
+    cc->max_width = m.h.input_dim;
+    for (const auto &L : m.layers) {
+        if (L.in_dim % 4) return fail(BH_ERR_UNSUPPORTED, "custom classifier: layer input width %u not a multiple of 4", L.in_dim);
+        cc->max_width = std::max(cc->max_width, L.out_dim);
+        const int ld = (int)align_up(L.out_dim, 4);
+        float *w = cc->d_blob + L.w_off;
+        if (ld != (int)L.out_dim || (L.w_off % 4)) {   // rows padded / 16-byte aligned for the GEMM's loads
+            std::vector<float> wp((size_t)L.in_dim * ld, 0.0f);
+            for (uint32_t k = 0; k < L.in_dim; k++) memcpy(&wp[(size_t)k * ld], m.blob.data() + L.w_off + (size_t)k * L.out_dim, L.out_dim * sizeof(float));
+            float *d = nullptr;
+            rc = upload(wp.data(), wp.size() * sizeof(float), &d);
+            if (rc != BH_OK) return rc;
+            cc->d_owned.push_back(d);
+            w = d;
+        }
+        cc->d_w.push_back(w);
+        cc->ldw.push_back(ld);
+    }
+    *out = cc.release();
+    return BH_OK;
+} catch (...) { return on_exception(); }
+
+uint32_t bh_custom_classifier_num_classes(const bh_custom_classifier *cc) { return cc ? cc->model.h.n_classes : 0; }
+uint32_t bh_custom_classifier_input_dim(const bh_custom_classifier *cc) { return cc ? cc->model.h.input_dim : 0; }
+const char *bh_custom_classifier_label(const bh_custom_classifier *cc, uint32_t index) {
+    if (!cc || index >= cc->labels.size()) return nullptr;
+    return cc->labels[index].c_str();
+}
+
+int bh_custom_classifier_predict_batch(bh_custom_classifier *cc, const float *embeddings, size_t n, bh_result *out) try {
+    if (!cc || (n && (!embeddings || !out))) return fail(BH_ERR_INVALID, "custom_classifier_predict_batch: null argument");
+    if (n == 0) return BH_OK;
+    std::lock_guard<std::mutex> g(cc->mu);
+    HIPCHK(hipSetDevice(cc->device));
+    int rc = cc_reserve(cc, n);
+    if (rc != BH_OK) return rc;
+    HIPCHK(hipMemcpyAsync(cc->d_in, embeddings, n * (size_t)cc->model.h.input_dim * sizeof(float), hipMemcpyHostToDevice, cc->stream));
+    return cc_run(cc, cc->d_in, cc->model.h.input_dim, n, cc->stream, out, nullptr);
+} catch (...) { return on_exception(); }
+
+int bh_predict_batch_two_stage(bh_classifier *c, bh_batch_context *ctx, bh_custom_classifier *cc, const float *const *segments,
+                               size_t n, size_t n_samples, bh_result *out, float *logits_out) try {
+    int rc = check_ctx(c, ctx);
+    if (rc != BH_OK) return rc;
+    if (!cc || !segments || !out) return fail(BH_ERR_INVALID, "predict_batch_two_stage: null argument");
+    const auto &h = c->model.h;
+    if (n_samples != h.sample_count) return fail(BH_ERR_INVALID, "segment has %zu samples, model expects %u", n_samples, h.sample_count);
+    if (cc->device != c->device) return fail(BH_ERR_INVALID, "two-stage: backbone and custom classifier live on different devices");
+    if (h.embedding_dim != cc->model.h.input_dim)
+        return fail(BH_ERR_INVALID, "bat mode requires %u-d embeddings from the backbone, the model exposes %u", cc->model.h.input_dim, h.embedding_dim);
+    std::lock_guard<std::mutex> g(cc->mu);
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<bh_result> backbone(std::min(n, ctx->max_batch));
+    for (size_t b0 = 0; b0 < n; b0 += ctx->max_batch) {
+        const size_t nb = std::min(ctx->max_batch, n - b0);
+        // the backbone on this slice (results discarded: the custom classifier's replace them, processor.rs:369-372); the
+        // embedding tensor of the slice then sits in the context's arena
+        rc = predict_slices(c, ctx, segments + b0, nullptr, nb, backbone.data(), nullptr, nullptr, true);
+        if (rc != BH_OK) return rc;
+        const float *d_emb = ctx->d_arena + ctx->t_off[h.embedding_tensor];
+        rc = cc_run(cc, d_emb, h.embedding_dim, nb, ctx->stream, out + b0, logits_out ? logits_out + b0 * cc->model.h.n_classes : nullptr);
+        if (rc != BH_OK) return rc;
     }
     return BH_OK;
 } catch (...) { return on_exception(); }

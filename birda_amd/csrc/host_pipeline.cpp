@@ -434,6 +434,7 @@ struct FilePlan {
     bool resampling = false;
     float min_confidence = 0.1f;
     bhh_reporter *reporter = nullptr;
+    bh_custom_classifier *custom = nullptr;   // bat mode
 };
 
 // (start_sample / source_rate as f32, start + segment_samples / target_rate) -- processor.rs:91-94
@@ -447,7 +448,8 @@ void collect_detections(bh_classifier *clf, const FilePlan &pl, const bh_result 
                         std::vector<Detection> &detections) {
     for (uint32_t k = 0; k < r.n_pred; k++)
         if (r.confidence[k] >= pl.min_confidence) {                                          // :375
-            const char *label = bh_classifier_label(clf, (uint32_t)r.index[k]);
+            // bat mode: the predictions (and their labels) are the custom classifier's (:369-372)
+            const char *label = pl.custom ? bh_custom_classifier_label(pl.custom, (uint32_t)r.index[k]) : bh_classifier_label(clf, (uint32_t)r.index[k]);
             detections.push_back(detection_from_label(label ? label : std::to_string(r.index[k]), r.confidence[k], start_time, end_time, pl.shown));
         }
 }
@@ -510,7 +512,8 @@ int run_host_front_end(bh_classifier *clf, const FilePlan &pl, const bh_model_in
         const size_t bs = segs.size();
         void *guard = bhh_watchdog_start(watchdog_timeout_secs() * 1000, bs);                // :263-266
         int r;
-        if (pl.resampling) r = bh_predict_batch_source_rate(clf, ctx, segs.data(), bs, pl.src_segment_samples, pl.source_rate, results.data());
+        if (pl.custom) r = bh_predict_batch_two_stage(clf, ctx, pl.custom, segs.data(), bs, info.sample_count, results.data(), nullptr);   // :319-360
+        else if (pl.resampling) r = bh_predict_batch_source_rate(clf, ctx, segs.data(), bs, pl.src_segment_samples, pl.source_rate, results.data());
         else if (bs == 1) r = bh_predict(clf, segs[0], info.sample_count, &results[0]);       // :269-277
         else if (ctx) r = bh_predict_batch_with_context(clf, ctx, segs.data(), bs, info.sample_count, results.data());
         else r = bh_predict_batch(clf, segs.data(), bs, info.sample_count, results.data());
@@ -634,11 +637,28 @@ extern "C" int bhh_process_file(bh_classifier *clf, const bhh_processing_config 
     double duration = 0.0;
     const int has_duration = bhh_decoder_duration_hint(probe, &duration);
 
-    pl.target_rate = info.sample_rate;                                                       // :474
-    pl.segment_duration = info.segment_duration;
-    pl.segment_samples = bhh_duration_to_samples(pl.segment_duration, pl.target_rate);       // :514
-    pl.overlap_samples = bhh_duration_to_samples(cfg->overlap, pl.target_rate);              // :520
-    pl.estimated = bhh_estimate_segment_count(has_duration, duration, pl.segment_duration, cfg->overlap);  // :525
+    pl.custom = cfg->custom_classifier;
+    const bool bat_mode = pl.custom != nullptr;                                              // lib.rs:774
+    float overlap_secs = cfg->overlap;
+    if (bat_mode) {
+        // no resampling: the model is fed source samples as if they were 48 kHz audio (:464-475); fixed 144 000-sample
+        // segments overlapping by a quarter (:502-508); durations derive from bat::SAMPLE_RATE = 256 kHz (constants.rs:525-542)
+        constexpr uint32_t BAT_SAMPLE_RATE = 256000;
+        constexpr size_t BAT_CHUNK_SAMPLES = 144000;
+        if (pl.source_rate != BAT_SAMPLE_RATE)
+            fprintf(stderr, "WARN Bat mode expects %ukHz audio, source is %ukHz. Results may be unreliable.\n", BAT_SAMPLE_RATE / 1000, pl.source_rate / 1000);
+        pl.target_rate = pl.source_rate;
+        pl.segment_duration = (float)BAT_CHUNK_SAMPLES / (float)BAT_SAMPLE_RATE;
+        pl.segment_samples = BAT_CHUNK_SAMPLES;
+        pl.overlap_samples = BAT_CHUNK_SAMPLES / 4;
+        overlap_secs = pl.segment_duration * 0.25f;                                          // bat::OVERLAP (lib.rs:734-738)
+    } else {
+        pl.target_rate = info.sample_rate;                                                   // :474
+        pl.segment_duration = info.segment_duration;
+        pl.segment_samples = bhh_duration_to_samples(pl.segment_duration, pl.target_rate);   // :514
+        pl.overlap_samples = bhh_duration_to_samples(cfg->overlap, pl.target_rate);          // :520
+    }
+    pl.estimated = bhh_estimate_segment_count(has_duration, duration, pl.segment_duration, overlap_secs);  // :525
     const size_t batch_size = cfg->batch_size ? cfg->batch_size : bh_classifier_default_batch_size(clf);   // lib.rs:1035
     pl.effective = bhh_effective_batch_size(batch_size, pl.estimated);                       // :531-545
     pl.min_confidence = cfg->min_confidence;
@@ -653,7 +673,9 @@ extern "C" int bhh_process_file(bh_classifier *clf, const bhh_processing_config 
     // front end: the device takes PCM16 WAV (any channel count); everything else decodes on the host
     PcmMapping map;
     bool device = false;
-    if (cfg->front_end != BHH_FRONT_END_HOST) {
+    if (bat_mode && cfg->front_end == BHH_FRONT_END_DEVICE)
+        return hfail(BH_ERR_UNSUPPORTED, "process_file: bat mode (custom classifier) runs on the host front end");
+    if (cfg->front_end != BHH_FRONT_END_HOST && !bat_mode) {
         device = map.open(*probe);
         if (!device && cfg->front_end == BHH_FRONT_END_DEVICE)
             return hfail(BH_ERR_UNSUPPORTED, "process_file: the device front end takes PCM16 WAV files only: " + pl.path);
@@ -664,10 +686,10 @@ extern "C" int bhh_process_file(bh_classifier *clf, const bhh_processing_config 
     rc = bh_classifier_ensure_warm(clf, pl.effective);                                       // :577
     if (rc != BH_OK) return hfail(rc, bh_last_error());
     bh_batch_context *ctx = nullptr;                                                         // :582-603
-    if (pl.effective > 1 || device) {
+    if (pl.effective > 1 || device || bat_mode) {
         rc = bh_batch_context_create(clf, pl.effective, &ctx);
         if (rc != BH_OK) {
-            if (device) return hfail(rc, bh_last_error());
+            if (device || bat_mode) return hfail(rc, bh_last_error());
             ctx = nullptr;  // fall back to predict_batch like the reference does for Perch
         }
     }
@@ -690,7 +712,7 @@ extern "C" int bhh_process_file(bh_classifier *clf, const bhh_processing_config 
     });
 
     const double audio_duration = has_duration ? duration
-                                  : (st.segments ? (double)pl.segment_duration + (st.segments - 1.0) * ((double)pl.segment_duration - cfg->overlap) : 0.0);  // :692-703
+                                  : (st.segments ? (double)pl.segment_duration + (st.segments - 1.0) * ((double)pl.segment_duration - overlap_secs) : 0.0);  // :692-703
 
     // write_output per format (:721-736) unless a reporter owns stdout-only mode
     const bool should_write = cfg->dual_output || !cfg->reporter;

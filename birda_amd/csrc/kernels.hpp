@@ -246,6 +246,9 @@ void launch_head_gap16(const float *A, const void *Wf, const float *bias, float 
 // Post-filter of the kept top-k (reference apply_range_filter, classifier.rs:587-645): class_score (NaN = species without
 // geomodel entry) selects geomodel_filter.rs:46-82, else species_keep the species-list retain (:617-640); both null = off.
 struct TopkFilter {
+    // BSG post-processing (reference classifier.rs:508-545): conf' = sigmoid(intercept[c] + slope[c] logit(conf)) (* prior[c]),
+    // then re-sorted; applied before the range filter / species list stage.  bsg_intercept null = off.
+    const float *bsg_intercept = nullptr, *bsg_slope = nullptr, *bsg_prior = nullptr;
     const float *class_score = nullptr;
     const unsigned char *species_keep = nullptr;
     float threshold = 0.f;

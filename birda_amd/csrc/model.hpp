@@ -95,4 +95,53 @@ inline bool load_model(const char *path, Model &m, std::string &err) {
     return true;
 }
 
+// BHC1: a custom classifier on embeddings (birda_amd/modelfile.py write_custom_classifier): dense layers + output activation
+#pragma pack(push, 1)
+struct CustomHeaderRec {
+    char magic[4];
+    uint32_t version, input_dim, n_layers, n_classes, output_activation;
+    uint64_t blob_offset, blob_floats;
+};
+struct CustomLayerRec {
+    uint32_t in_dim, out_dim, act, reserved;
+    uint64_t w_off, b_off;   // W [in][out] row-major, b [out]
+};
+#pragma pack(pop)
+
+struct CustomModel {
+    CustomHeaderRec h{};
+    std::vector<CustomLayerRec> layers;
+    std::vector<float> blob;
+};
+
+inline bool load_custom_model(const char *path, CustomModel &m, std::string &err) {
+    FILE *f = fopen(path, "rb");
+    if (!f) { err = std::string("cannot open custom classifier file ") + path; return false; }
+    auto bad = [&](const char *why) { err = std::string(path) + ": " + why; fclose(f); return false; };
+    unsigned char hdr[64];
+    if (fread(hdr, 1, 64, f) != 64) return bad("truncated header");
+    memcpy(&m.h, hdr, sizeof m.h);
+    if (memcmp(m.h.magic, "BHC1", 4) != 0 || m.h.version != 1) return bad("not a BHC1 v1 custom classifier");
+    if (m.h.n_layers == 0 || m.h.n_layers > 64 || m.h.input_dim == 0 || m.h.n_classes == 0) return bad("bad counts");
+    m.layers.resize(m.h.n_layers);
+    for (auto &L : m.layers) {
+        unsigned char rec[32];
+        if (fread(rec, 1, 32, f) != 32) return bad("truncated layer table");
+        memcpy(&L, rec, sizeof L);
+    }
+    if (m.h.blob_floats > (1ull << 32)) return bad("weights too large");
+    m.blob.resize(m.h.blob_floats);
+    if (fseek(f, (long)m.h.blob_offset, SEEK_SET) != 0) return bad("bad blob offset");
+    if (fread(m.blob.data(), sizeof(float), m.h.blob_floats, f) != m.h.blob_floats) return bad("truncated weights");
+    fclose(f);
+    uint32_t dim = m.h.input_dim;
+    for (const auto &L : m.layers) {
+        if (L.in_dim != dim || L.out_dim == 0) { err = "custom classifier: layer widths do not chain"; return false; }
+        if (L.w_off + (uint64_t)L.in_dim * L.out_dim > m.h.blob_floats || L.b_off + L.out_dim > m.h.blob_floats) { err = "custom classifier: weights outside blob"; return false; }
+        dim = L.out_dim;
+    }
+    if (dim != m.h.n_classes) { err = "custom classifier: last layer width != n_classes"; return false; }
+    return true;
+}
+
 }  // namespace bh

@@ -171,3 +171,57 @@ def read_model(path: str) -> Model:
         off += LAYER_SIZE
     m.blob = np.frombuffer(raw, dtype="<f4", count=bfl, offset=boff).copy()
     return m
+
+
+# --------------------------------------------------------------------------------------------------------
+# BHC1: custom classifier on embeddings (reference birdnet_onnx::CustomClassifier, src/lib.rs:883-901)
+# header 64 B: magic, version, input_dim, n_layers, n_classes, output_activation, blob_offset, blob_floats
+# layers n_layers x 32 B: in_dim, out_dim, act, reserved, w_off, b_off        (W [in][out] row-major, b [out])
+# --------------------------------------------------------------------------------------------------------
+CUSTOM_MAGIC = b"BHC1"
+CUSTOM_HEADER_FMT = "<4sIIIIIQQ"
+CUSTOM_LAYER_FMT = "<IIIIQQ"
+
+
+@dataclass
+class CustomLayer:
+    w: np.ndarray   # [in, out]
+    b: np.ndarray   # [out]
+    act: int = ACT_NONE
+
+
+@dataclass
+class CustomClassifierModel:
+    input_dim: int
+    output_activation: int
+    layers: List[CustomLayer] = field(default_factory=list)
+
+    @property
+    def n_classes(self) -> int:
+        return int(self.layers[-1].w.shape[1])
+
+
+def write_custom_classifier(path: str, m: CustomClassifierModel) -> None:
+    chunks, off, recs = [], 0, []
+    for L in m.layers:
+        w = np.ascontiguousarray(L.w, np.float32)
+        b = np.ascontiguousarray(L.b, np.float32)
+        pad = (-off) % 16
+        if pad:
+            chunks.append(np.zeros(pad, np.float32)); off += pad
+        w_off = off; chunks.append(w.ravel()); off += w.size
+        pad = (-off) % 16
+        if pad:
+            chunks.append(np.zeros(pad, np.float32)); off += pad
+        b_off = off; chunks.append(b.ravel()); off += b.size
+        recs.append(struct.pack(CUSTOM_LAYER_FMT, w.shape[0], w.shape[1], L.act, 0, w_off, b_off))
+    blob = np.concatenate(chunks) if chunks else np.zeros(0, np.float32)
+    blob_offset = (64 + 32 * len(recs) + 255) // 256 * 256
+    hdr = struct.pack(CUSTOM_HEADER_FMT, CUSTOM_MAGIC, 1, m.input_dim, len(recs), m.n_classes, m.output_activation,
+                      blob_offset, blob.size)
+    with open(path, "wb") as f:
+        f.write(hdr.ljust(64, b"\0"))
+        for r in recs:
+            f.write(r)
+        f.write(b"\0" * (blob_offset - 64 - 32 * len(recs)))
+        f.write(blob.astype("<f4").tobytes())

@@ -265,10 +265,12 @@ def process_file(classifier, input_path: str, output_dir: Optional[str] = None, 
                  display_path: Optional[str] = None, formats: Sequence[str] = ("csv",), front_end: str = "auto",
                  csv_columns: Optional[Sequence[str]] = None, model_name: str = "", lat: Optional[float] = None,
                  lon: Optional[float] = None, week: Optional[int] = None, reporter: Optional[ProgressReporter] = None,
-                 dual_output: bool = False) -> ProcessResult:
+                 dual_output: bool = False, custom_classifier=None) -> ProcessResult:
     """process_file (processor.rs:418-796).  batch_size 0 = the backend's default (determine_default_batch_size);
     front_end "host" keeps the reference's decode-thread + padded-batch structure, "device" / "auto" run decode
-    scaling, mono mix, segmentation and resampling on the GPU for PCM16 WAV input."""
+    scaling, mono mix, segmentation and resampling on the GPU for PCM16 WAV input.  custom_classifier: bat mode
+    (classifier.CustomClassifier): no resampling, 144 000-sample segments overlapping by a quarter, the custom
+    classifier's predictions on the backbone's embeddings."""
     L = _lib.load()
     cfg = BhhProcessingConfig(input_path.encode(), output_dir.encode() if output_dir else None,
                               display_path.encode() if display_path else None, min_confidence, overlap, batch_size,
@@ -276,7 +278,7 @@ def process_file(classifier, input_path: str, output_dir: Optional[str] = None, 
                               ",".join(csv_columns).encode() if csv_columns else None, model_name.encode(),
                               int(lat is not None), int(lon is not None), lat or 0.0, lon or 0.0,
                               -1 if week is None else week, reporter._h if reporter is not None else None,
-                              int(dual_output))
+                              int(dual_output), custom_classifier._h if custom_classifier is not None else None)
     res = BhhProcessResult()
     _hcheck(L.bhh_process_file(classifier._h, C.byref(cfg), C.byref(res)))
     return ProcessResult(res.detections, res.segments, res.duration_secs, res.audio_duration_secs,

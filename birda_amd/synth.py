@@ -192,6 +192,21 @@ def build_model(kind: str = "birdnet_v24", seed: int = WEIGHT_SEED,
     return m
 
 
+def build_custom_classifier(input_dim: int = 1024, n_classes: int = 30, hidden: Sequence[int] = (), seed: int = 77,
+                            out_act: int = mf.OUT_SIGMOID) -> "mf.CustomClassifierModel":
+    """Seeded BattyBirdNET-shaped classifier on the backbone's embedding (reference --bat <region>, src/lib.rs:862-901): Gemm
+    (+ ReLU) layers ending in a sigmoid.  The real regional classifiers are downloaded ONNX files; none is on disk."""
+    rng = np.random.default_rng(seed)
+    dims = [input_dim] + list(hidden) + [n_classes]
+    layers = []
+    for i in range(len(dims) - 1):
+        last = i == len(dims) - 2
+        w = (rng.standard_normal((dims[i], dims[i + 1])) * math.sqrt(2.0 / dims[i]) * (3.0 if last else 1.0)).astype(np.float32)
+        b = (rng.standard_normal(dims[i + 1]) * 0.5 - (1.0 if last else 0.0)).astype(np.float32)
+        layers.append(mf.CustomLayer(w, b, mf.ACT_NONE if last else mf.ACT_RELU))
+    return mf.CustomClassifierModel(input_dim, out_act, layers)
+
+
 def write_labels(path: str, n: int) -> List[str]:
     """`Scientific name_Common name` lines, the BirdNET label format split at the
     first '_' by `Detection::from_label` (reference src/output/types.rs:58-79)."""

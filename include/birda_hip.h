@@ -302,6 +302,44 @@ BH_API int bh_resample_device(bh_classifier *c, bh_batch_context *ctx, const flo
                               size_t src_len, uint32_t from_rate, uint32_t to_rate, float *d_out,
                               size_t out_stride, size_t out_len, size_t n_seg);
 
+/* ---- two-stage inference: a custom classifier on the backbone's embeddings ----------------
+ * birdnet_onnx::CustomClassifier (built at reference src/lib.rs:883-901 for `--bat <region>`, used at
+ * src/pipeline/processor.rs:319-360): a small model that maps the backbone's embedding (1024-d for BirdNET v2.4) to
+ * its own classes.  The reference runs it through ONNX Runtime on embeddings copied back to the host; here the
+ * embeddings stay in HBM and the dense layers run on the MFMA right behind the backbone.  [EXT] The published
+ * BattyBirdNET classifiers are Gemm (+ activation) stacks ending in a sigmoid; the container below (BHC1,
+ * birda_amd/modelfile.py write_custom_classifier) states exactly that: dense layers [in][out] + bias + activation, an
+ * output activation, labels. */
+typedef struct bh_custom_classifier bh_custom_classifier;
+/* CustomClassifier::builder().model_path().labels_path().build(); top_k = predictions kept per segment (0 = all classes
+ * up to BH_MAX_TOP_K), ordered by confidence; min_confidence is applied by the caller (processor.rs:375) */
+BH_API int bh_custom_classifier_create(const char *model_path, const char *labels_path, int32_t device, uint32_t top_k,
+                                       bh_custom_classifier **out);
+BH_API void bh_custom_classifier_destroy(bh_custom_classifier *cc);
+BH_API uint32_t bh_custom_classifier_num_classes(const bh_custom_classifier *cc); /* cc.num_classes() */
+BH_API uint32_t bh_custom_classifier_input_dim(const bh_custom_classifier *cc);   /* cc.input_dim() */
+BH_API const char *bh_custom_classifier_label(const bh_custom_classifier *cc, uint32_t index);
+/* cc.predict_batch(&embeddings): host embeddings [n][input_dim] in, one result per row */
+BH_API int bh_custom_classifier_predict_batch(bh_custom_classifier *cc, const float *embeddings, size_t n, bh_result *out);
+/* process_batch in bat mode (processor.rs:319-360): backbone forward on the segments, the embedding tensor handed to the
+ * custom classifier on the device, ITS predictions returned (they replace the backbone's, :369-372).  The backbone must
+ * expose an embedding of cc's input_dim.  logits_out (nullable): host [n][cc classes], for parity checks. */
+BH_API int bh_predict_batch_two_stage(bh_classifier *c, bh_batch_context *ctx, bh_custom_classifier *cc,
+                                      const float *const *segments, size_t n, size_t n_samples, bh_result *out, float *logits_out);
+
+/* ---- BSG post-processing of the kept predictions -------------------------------------------
+ * BirdClassifier::apply_bsg_postprocessing (classifier.rs:508-545) -> birdnet_onnx::BsgPostProcessor::{calibrate,
+ * process}: per-species calibration always, species-distribution-model (SDM) adjustment when latitude, longitude and day
+ * of year are known.  [EXT] The processor lives in birdnet-onnx; the form used here is the published BSG one, logistic
+ * calibration in logit space and a multiplicative occurrence prior:
+ *     conf' = sigmoid(intercept[c] + slope[c] * logit(conf)),   conf'' = conf' * prior[c]   (prior NULL = calibration only)
+ * applied to the kept top-k (as the reference applies it to PredictionResult), which are then re-sorted by confidence.
+ * Runs in the top-k kernel's tail, before the range filter stage (which BSG models skip, processor.rs:316-317).  The tables
+ * are per class index; reading the calibration CSV / SDM maps into them is host work outside this library. */
+BH_API int bh_classifier_set_bsg(bh_classifier *c, const float *intercept, const float *slope, const float *prior /* nullable */,
+                                 size_t n_classes);
+BH_API int bh_classifier_clear_bsg(bh_classifier *c);
+
 /* ---- several shards in one process (birda_amd/csrc/multi.hip) -----------------------------------
  * Segments are independent through every stage (processor.rs:363-367): shard g of G owns a contiguous block of the
  * global list and nothing is exchanged but the results.  The reference has no counterpart (it scales out as N

@@ -150,6 +150,11 @@ typedef struct {
     int week;                 /* -1 = None */
     bhh_reporter *reporter;   /* config.reporter (processor.rs:438): progress + detections events; NULL = none */
     int dual_output;          /* dual_output_mode (:721): with a reporter, also write the result files */
+    /* config.custom_classifier / bat_mode (config.rs:63, lib.rs:773-774): when set, no resampling (the source samples go to
+     * the model as they are: the "slow-down trick", processor.rs:464-475), segments of bat::CHUNK_SAMPLES = 144 000 samples
+     * overlapping by a quarter (:502-508, constants.rs:525-542), and the custom classifier's predictions on the backbone's
+     * embeddings replace the backbone's (:319-360, :369-372).  Runs on the HOST front end. */
+    bh_custom_classifier *custom_classifier;
 } bhh_processing_config;
 
 /* ProcessResult (processor.rs:877-886) + batching counters */

@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 import numpy as np
 
@@ -269,3 +269,38 @@ def segment_stream(samples: np.ndarray, seg: int, ovl: int, packet: int = 1152):
     finally:
         L.bo_segmenter_free(h)
     return out
+
+
+# --------------------------------------------------------------------------------------------------------
+# Two-stage inference and BSG post-processing, numpy restatements.  TEST INFRASTRUCTURE like the rest of
+# this package.  [EXT] Both live in birdnet-onnx (CustomClassifier, BsgPostProcessor), not in the reference tree: parity
+# unpinned; the forms below are the ones include/birda_hip.h states.
+# --------------------------------------------------------------------------------------------------------
+def custom_classifier_forward(model, embeddings: np.ndarray) -> np.ndarray:
+    """birdnet_onnx::CustomClassifier::predict_batch up to the logits (reference call site src/pipeline/processor.rs:341):
+    dense layers x W + b with the layer activation (0 none, 1 ReLU), float32 like ONNX Runtime's Gemm."""
+    x = np.asarray(embeddings, np.float32)
+    for L in model.layers:
+        x = (x.astype(np.float64) @ L.w.astype(np.float64) + L.b.astype(np.float64)).astype(np.float32)
+        if L.act == 1:
+            x = np.maximum(x, 0.0)
+        elif L.act != 0:
+            raise ValueError("activation not restated")
+    return x
+
+
+def bsg_postprocess(index: np.ndarray, confidence: np.ndarray, intercept: np.ndarray, slope: np.ndarray,
+                    prior: Optional[np.ndarray] = None):
+    """BirdClassifier::apply_bsg_postprocessing (reference src/inference/classifier.rs:508-545) on one segment's kept
+    predictions: conf' = sigmoid(intercept[c] + slope[c] * logit(conf)) (* prior[c]), stable re-sort descending."""
+    idx = [int(i) for i in index if i >= 0]
+    out = []
+    for c, p in zip(idx, confidence):
+        p = min(max(float(p), 1e-7), 1.0 - 1e-7)
+        lg = np.log(p / (1.0 - p))
+        q = 1.0 / (1.0 + np.exp(-(float(intercept[c]) + float(slope[c]) * lg)))
+        if prior is not None:
+            q *= float(prior[c])
+        out.append((c, q))
+    order = sorted(range(len(out)), key=lambda i: -out[i][1])     # sorted() is stable: ties keep their order
+    return [out[i][0] for i in order], [out[i][1] for i in order]
