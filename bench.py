@@ -57,8 +57,27 @@ def reference_ort_leg(model_path, hip_logits_first, sample_count):
     if not (onnx and os.path.exists(onnx)):
         return {"available": False, "note": "libonnxruntime found but no BIRDA_REFERENCE_ONNX model: compared against the CPU restatement"}
     try:
+        import numpy as np
         from tools import ort_reference
-        return ort_reference.run(ort, onnx, sample_count)
+        r = ort_reference.run(ort, onnx, sample_count)
+        ref = r.pop("logits_first16")
+        # max |dlogit| against the TRUE reference needs the HIP library to run the same weights: the BHM1 file converted from
+        # this ONNX file (tools/onnx_to_bhm.py), named by BIRDA_REFERENCE_BHM
+        bhm = os.environ.get("BIRDA_REFERENCE_BHM", "")
+        if bhm and os.path.exists(bhm):
+            from birda_amd import synth
+            from birda_amd.classifier import BirdClassifier
+            r["max_abs_dlogit_vs_reference"] = {}
+            for prec in ("f32", "f16x3"):
+                clf = BirdClassifier(bhm, None, precision=prec)
+                ctx = clf.create_batch_context(16)
+                got = clf.predict_logits(ctx, synth.synth_segments(16, clf.sample_count(), clf.sample_rate()))
+                ctx.close(); clf.close()
+                d, sc = float(np.abs(got - ref).max()), float(max(1.0, np.abs(ref).max()))
+                r["max_abs_dlogit_vs_reference"][prec] = {"max_abs_dlogit": round(d, 6), "max_abs_logit": round(sc, 3), "relative": float(f"{d / sc:.3e}")}
+        else:
+            r["note"] = "no BIRDA_REFERENCE_BHM (the model converted from this ONNX file): throughput only, no |dlogit|"
+        return r
     except Exception as e:   # noqa: BLE001 -- the opportunistic leg must never take the bench down
         return {"available": False, "note": f"ORT reference leg failed: {e!r}"}
 

@@ -88,6 +88,11 @@ struct bh_classifier {
     std::set<size_t> warmed;                 // WarmupRegistry, classifier.rs:221-246
     bh_batch_context *internal_ctx = nullptr;
     std::mutex internal_mu;
+    // One destroyed batch context is parked here and handed to the next bh_batch_context_create of the same size: the per-file
+    // pipeline creates and destroys a context per file (reference processor.rs:582-603), and a context is ~1 GB of hipMalloc
+    // plus pinned staging memory -- milliseconds per file at GPU throughput.
+    bh_batch_context *parked_ctx = nullptr;
+    std::mutex parked_mu;
 };
 
 struct bh_batch_context {
@@ -1020,6 +1025,7 @@ void bh_classifier_destroy(bh_classifier *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->internal_ctx) ctx_destroy(c->internal_ctx);
+    if (c->parked_ctx) ctx_destroy(c->parked_ctx);
     for (float *d : c->d_owned) (void)hipFree(d);
     (void)hipFree(c->d_blob);
     (void)hipFree(c->d_stamps);

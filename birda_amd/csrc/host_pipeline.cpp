@@ -603,7 +603,9 @@ struct PcmMapping {
         const int fd = ::open(d.path.c_str(), O_RDONLY);
         if (fd < 0) return false;
         length = (size_t)(d.data_offset + d.data_bytes);
-        if (d.data_bytes) base = mmap(nullptr, length, PROT_READ, MAP_PRIVATE, fd, 0);
+        // MAP_POPULATE: the page tables are filled in one pass here instead of one minor fault per 4-KB page inside the upload
+        // workers' copies (70 000 faults for a 1 000-segment file)
+        if (d.data_bytes) base = mmap(nullptr, length, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
         ::close(fd);
         if (d.data_bytes && base == MAP_FAILED) return false;
         if (base != MAP_FAILED) (void)madvise(base, length, MADV_SEQUENTIAL);
@@ -682,6 +684,13 @@ extern "C" int bhh_process_file(bh_classifier *clf, const bhh_processing_config 
     }
     const uint32_t channels = (uint32_t)probe->channels;
     probe_own.reset();
+    if (device && cfg->batch_size == 0) {
+        // No batch size asked for: the device front end slices the stream by 1 024 segments (4 GB of context), not by the 256 of
+        // determine_default_batch_size -- its rows are never padded, results do not depend on the slice, and the upload of one
+        // slice overlaps the compute of the previous sub-slice only within a slice (bh_predict_pcm16)
+        pl.effective = bhh_effective_batch_size(1024, pl.estimated);
+        res->effective_batch = pl.effective;
+    }
 
     rc = bh_classifier_ensure_warm(clf, pl.effective);                                       // :577
     if (rc != BH_OK) return hfail(rc, bh_last_error());

@@ -818,11 +818,9 @@ int mb_config_count() { return kNCfgs; }
 int mb_config_name(int ci, char *out, size_t cap) {
     if (ci < 0 || ci >= kNCfgs) return 0;
     const MbCfg &c = kCfgs[ci];
-    if (c.PERSIST)
-        return snprintf(out, cap, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", c.KS, c.ST, c.CE, c.KG, c.RT_W, c.NCS, c.WM,
-                        c.WN, c.MT_W, c.NT_W, c.TWL, c.XBL, c.S, c.OCC, c.STEM, c.PREC, c.PERSIST);
-    return snprintf(out, cap, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", c.KS, c.ST, c.CE, c.KG, c.RT_W, c.NCS, c.WM,
-                    c.WN, c.MT_W, c.NT_W, c.TWL, c.XBL, c.S, c.OCC, c.STEM, c.PREC);
+    // all 17 template arguments, as a profiler prints them (the last one marks a persistent instantiation)
+    return snprintf(out, cap, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", c.KS, c.ST, c.CE, c.KG, c.RT_W, c.NCS, c.WM,
+                    c.WN, c.MT_W, c.NT_W, c.TWL, c.XBL, c.S, c.OCC, c.STEM, c.PREC, c.PERSIST);
 }
 
 bool mb_plan(MbDesc &d, int force_cfg) {

@@ -118,3 +118,87 @@ def test_wire_format_scalars_and_attributes():
     assert (a["f"], a["i"], a["s"], a["ints"], a["floats"]) == (0.25, -3, "SAME_UPPER", [1, -2, 3], [0.5, 1.5])
     assert np.array_equal(a["t"], np.arange(6).reshape(2, 3)) and h.opset == 13 and h.inputs[0].shape == ["N", 3]
     assert h.initializers["w"].shape == () and float(h.initializers["w"]) == 2.5
+
+
+def test_hand_written_graph_matches_an_independent_torch_evaluation(tmp_path):
+    """A graph spelled the way a TF -> ONNX exporter spells it, written node by node HERE (not by graph_from_model) and
+    evaluated with torch.nn.functional on the oracle's own spectrogram: the converted model's oracle logits must agree.
+    Covers what the round trips cannot: un-folded BatchNormalization, asymmetric SAME padding of a stride-2 conv,
+    Clip(0, 6), Sigmoid * x, residual Add, ReduceMean over H, W, MatMul + Add, Gemm(transB = 1), a Softmax output."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import oracle as O
+    rng = np.random.default_rng(123)
+    base = synth.build_model("mini")                       # only its front-end is used
+    C0, H, W = len(base.branches), base.spec_h, base.spec_w
+    g = ox.Graph(name="hand_written", producer="tests")
+    g.inputs.append(ox.ValueInfo("spec", ox.FLOAT, ["N", C0, H, W]))
+    P = {}
+
+    def init(name, arr):
+        g.initializers[name] = np.asarray(arr, np.float32)
+        P[name] = torch.from_numpy(np.asarray(arr, np.float32))
+        return name
+
+    def bn(x, c, tag):
+        names = [init(f"{tag}_{k}", v) for k, v in (("g", rng.uniform(0.5, 1.5, c)), ("b", rng.normal(0, 0.1, c)),
+                                                    ("m", rng.normal(0, 0.1, c)), ("v", rng.uniform(0.5, 1.5, c)))]
+        g.nodes.append(ox.Node("BatchNormalization", [x] + names, [tag + "_o"], {"epsilon": 1e-3}))
+        return tag + "_o"
+
+    # stem: 3x3 stride 2, TF "SAME" on an even/odd size = pad only bottom/right as needed
+    oh, ow = -(-H // 2), -(-W // 2)
+    ph, pw = max((oh - 1) * 2 + 3 - H, 0), max((ow - 1) * 2 + 3 - W, 0)
+    pads = [ph // 2, pw // 2, ph - ph // 2, pw - pw // 2]
+    init("w0", rng.normal(0, 0.3, (8, C0, 3, 3)))
+    g.nodes.append(ox.Node("Conv", ["spec", "w0"], ["c0"], {"kernel_shape": [3, 3], "strides": [2, 2], "pads": pads}))
+    x = bn("c0", 8, "bn0")
+    g.nodes.append(ox.Node("Clip", [x, init("lo", 0.0), init("hi", 6.0)], ["a0"]))
+    # depthwise 3x3 + BN + swish
+    init("w1", rng.normal(0, 0.4, (8, 1, 3, 3)))
+    g.nodes.append(ox.Node("Conv", ["a0", "w1"], ["c1"], {"kernel_shape": [3, 3], "strides": [1, 1], "pads": [1, 1, 1, 1], "group": 8}))
+    x = bn("c1", 8, "bn1")
+    g.nodes.append(ox.Node("Sigmoid", [x], ["s1"]))
+    g.nodes.append(ox.Node("Mul", [x, "s1"], ["a1"]))
+    # project 1x1 (with bias) + residual
+    init("w2", rng.normal(0, 0.3, (8, 8, 1, 1))); init("b2", rng.normal(0, 0.1, 8))
+    g.nodes.append(ox.Node("Conv", ["a1", "w2", "b2"], ["c2"], {"kernel_shape": [1, 1]}))
+    g.nodes.append(ox.Node("Add", ["c2", "a0"], ["r2"]))
+    # head 1x1 + relu, mean over H, W, flatten, MatMul + Add, Gemm transB, softmax
+    init("w3", rng.normal(0, 0.3, (16, 8, 1, 1))); init("b3", rng.normal(0, 0.1, 16))
+    g.nodes.append(ox.Node("Conv", ["r2", "w3", "b3"], ["c3"], {"kernel_shape": [1, 1]}))
+    g.nodes.append(ox.Node("Relu", ["c3"], ["a3"]))
+    g.nodes.append(ox.Node("ReduceMean", ["a3"], ["p3"], {"axes": [2, 3], "keepdims": 1}))
+    g.nodes.append(ox.Node("Flatten", ["p3"], ["f3"], {"axis": 1}))
+    init("w4", rng.normal(0, 0.3, (16, 12))); init("b4", rng.normal(0, 0.1, 12))
+    g.nodes.append(ox.Node("MatMul", ["f3", "w4"], ["m4"]))
+    g.nodes.append(ox.Node("Add", ["m4", "b4"], ["d4"]))
+    g.nodes.append(ox.Node("Relu", ["d4"], ["a4"]))
+    init("w5", rng.normal(0, 0.5, (7, 12))); init("b5", rng.normal(0, 0.1, 7))
+    g.nodes.append(ox.Node("Gemm", ["a4", "w5", "b5"], ["logits"], {"transB": 1}))
+    g.nodes.append(ox.Node("Softmax", ["logits"], ["prob"], {"axis": -1}))
+    g.outputs.append(ox.ValueInfo("prob", ox.FLOAT, ["N", 7]))
+
+    m = convert.model_from_graph(ox.load(ox.dump(g)), base)
+    assert m.n_classes == 7 and m.output_activation == mf.OUT_SOFTMAX and m.embedding_dim == 16
+    assert [L.op for L in m.layers] == [mf.OP_CONV, mf.OP_DWCONV, mf.OP_PWCONV, mf.OP_PWCONV, mf.OP_GAP, mf.OP_DENSE, mf.OP_DENSE]
+    assert [L.act for L in m.layers[:4]] == [mf.ACT_RELU6, mf.ACT_SWISH, mf.ACT_NONE, mf.ACT_RELU] and m.layers[2].res_tensor == 1
+    pa, pb = str(tmp_path / "base.bhm"), str(tmp_path / "conv.bhm")
+    mf.write_model(pa, base); mf.write_model(pb, m)
+    segs = synth.synth_segments(3, base.sample_count, base.sample_rate, start=11)
+    _, spec = O.OracleModel(pa).forward(segs, dump_tensor=0)             # the front-end's output, shared by both sides
+    xs = torch.from_numpy(spec.reshape(3, C0, H, W).copy())
+
+    def tbn(x, tag):
+        return F.batch_norm(x, P[tag + "_m"], P[tag + "_v"], P[tag + "_g"], P[tag + "_b"], False, 0.0, 1e-3)
+    y = F.conv2d(F.pad(xs, (pads[1], pads[3], pads[0], pads[2])), P["w0"], None, stride=2)
+    a0 = torch.clamp(tbn(y, "bn0"), 0.0, 6.0)
+    y = tbn(F.conv2d(a0, P["w1"], None, padding=1, groups=8), "bn1")
+    a1 = y * torch.sigmoid(y)
+    r2 = F.conv2d(a1, P["w2"], P["b2"]) + a0
+    a3 = F.relu(F.conv2d(r2, P["w3"], P["b3"]))
+    f3 = a3.mean((2, 3))
+    a4 = F.relu(f3 @ P["w4"] + P["b4"])
+    want = (a4 @ P["w5"].T + P["b5"]).numpy()
+    got = O.OracleModel(pb).forward(segs)                                 # logits (the softmax is the output activation)
+    assert np.abs(got - want).max() <= 2e-5 * max(1.0, float(np.abs(want).max())), float(np.abs(got - want).max())
