@@ -4,7 +4,8 @@
 [N, C, H, W] to the logits -- into the layer table `modelfile.py` describes: Conv (group 1 / depthwise
 / 1x1) with BatchNormalization folded, the activation that follows folded into the producing layer
 (Relu, Clip 0..6, Sigmoid*x, the Div-Erf-Add-Mul-Mul spelling of exact GELU, or a fused `Gelu`),
-residual Add folded into the project conv, GlobalAveragePool / ReduceMean, Flatten, Gemm / MatMul + Add,
+residual Add folded into the project conv, squeeze-excite blocks (GlobalAveragePool -> 1x1 Conv -> activation -> 1x1 Conv ->
+Sigmoid -> Mul with the feature map) as pool / 1x1 / 1x1 / OP_SCALE layers, GlobalAveragePool / ReduceMean, Flatten, Gemm / MatMul + Add,
 final Sigmoid / Softmax as the output activation.  Weights move from ONNX's [Cout, Cin/g, kh, kw] to
 the NHWC-friendly layouts of the kernels.
 
@@ -64,6 +65,9 @@ def graph_from_model(m: mf.Model, spell_gelu: str = "erf") -> ox.Graph:
             g.nodes.append(ox.Node("Sigmoid", [x], [tag + "_sig"]))
             g.nodes.append(ox.Node("Mul", [x, tag + "_sig"], [tag + "_swish"]))
             return tag + "_swish"
+        if act == mf.ACT_SIGMOID:
+            g.nodes.append(ox.Node("Sigmoid", [x], [tag + "_gate"]))
+            return tag + "_gate"
         if act == mf.ACT_GELU_ERF:
             if spell_gelu == "gelu":
                 g.nodes.append(ox.Node("Gelu", [x], [tag + "_gelu"], {"approximate": "none"}))
@@ -102,9 +106,16 @@ def graph_from_model(m: mf.Model, spell_gelu: str = "erf") -> ox.Graph:
                 y = activation(y, L.act, tag)
         elif L.op == mf.OP_GAP:
             g.nodes.append(ox.Node("GlobalAveragePool", [x], [tag + "_gap"]))
-            g.nodes.append(ox.Node("Flatten", [tag + "_gap"], [tag + "_flat"], {"axis": 1}))
-            y = tag + "_flat"
-            flat.add(i + 1)
+            feeds_conv = any(M.in_tensor == i + 1 and M.op == mf.OP_PWCONV for M in m.layers)
+            if feeds_conv:       # squeeze-excite: the pooled [N, C, 1, 1] map goes on through 1x1 convolutions
+                y = tag + "_gap"
+            else:
+                g.nodes.append(ox.Node("Flatten", [tag + "_gap"], [tag + "_flat"], {"axis": 1}))
+                y = tag + "_flat"
+                flat.add(i + 1)
+        elif L.op == mf.OP_SCALE:
+            g.nodes.append(ox.Node("Mul", [x, names[L.res_tensor]], [tag + "_se"]))
+            y = tag + "_se"
         elif L.op == mf.OP_DENSE:
             w = m.weight(L.w_off, L.cin * L.cout).reshape(L.cin, L.cout)
             g.nodes.append(ox.Node("Gemm", [x, const(tag + "_w", w), const(tag + "_b", m.weight(L.b_off, L.cout))], [tag + "_fc"],
@@ -371,6 +382,23 @@ def model_from_graph(g: ox.Graph, frontend: mf.Model, spectrogram_input: Optiona
                                    blob.put(W), blob.put(B.reshape(-1))))
             tmap[out] = (len(layers), cout, 1, 1)
             flush_patterns(out)
+        elif op == "Sigmoid" and n.outputs[0] not in graph_out:
+            # the gate of a squeeze-excite block: Sigmoid on a pooled [N, C, 1, 1] tensor, consumed by a Mul with the feature map
+            t = tmap.get(n.inputs[0])
+            if t is None or t[2] * t[3] != 1:
+                raise ConvertError("Sigmoid inside the graph that is neither Sigmoid * x nor a squeeze-excite gate")
+            set_act(n.inputs[0], n.outputs[0], mf.ACT_SIGMOID)
+        elif op == "Mul":
+            a, b = (tmap.get(x) for x in n.inputs)
+            if a is None or b is None:
+                raise ConvertError(f"Mul of {n.inputs}: operands are not both activations on the path")
+            for fm, gate in ((a, b), (b, a)):
+                if fm[2] * fm[3] > 1 and gate[2] * gate[3] == 1 and gate[1] == fm[1]:
+                    layers.append(mf.Layer(mf.OP_SCALE, mf.ACT_NONE, fm[0], gate[0], fm[1], fm[1], 1, 1, 1, 1, 0, 0, fm[2], fm[3], fm[2], fm[3]))
+                    tmap[n.outputs[0]] = (len(layers), fm[1], fm[2], fm[3])
+                    break
+            else:
+                raise ConvertError(f"Mul of {n.inputs}: not a feature map times a [N, C, 1, 1] gate")
         elif op in ("Sigmoid", "Softmax"):
             if n.outputs[0] not in graph_out:
                 raise ConvertError(f"{op} inside the graph (only the output activation is supported, or Sigmoid * x)")

@@ -437,6 +437,10 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
             bh::launch_gap(in, out, (int)n, (int)(L.in_h * L.in_w), (int)L.cout, s);
             ctx_mark(ctx, ST_GAP, (int)i);
             break;
+        case bh::OP_SCALE:   // squeeze-excite: the feature map times its [n][C] gate (res = the gate tensor)
+            bh::launch_scale(in, res, out, (int)n, (int)(L.out_h * L.out_w), (int)L.cout, s);
+            ctx_mark(ctx, ST_DW, (int)i);
+            break;
         default: return fail(BH_ERR_UNSUPPORTED, "layer %u: unsupported op %u", i, L.op);
         }
     }
@@ -954,8 +958,8 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) try {
         } else if (L.op == bh::OP_CONV) {
             if (L.cout % 8 || (size_t)L.kh * L.kw * L.cin * L.cout * 4 > 64 * 1024)
                 return fail(BH_ERR_UNSUPPORTED, "layer %zu: direct conv shape not built", i);
-        } else if (L.op == bh::OP_GAP) {
-            if (L.cout % 4) return fail(BH_ERR_UNSUPPORTED, "layer %zu: pool channels %u not a multiple of 4", i, L.cout);
+        } else if (L.op == bh::OP_GAP || L.op == bh::OP_SCALE) {
+            if (L.cout % 4) return fail(BH_ERR_UNSUPPORTED, "layer %zu: channels %u not a multiple of 4", i, L.cout);
         }
     }
     if (m.layers.empty() || m.layers.back().cout != m.h.n_classes)
@@ -1183,9 +1187,38 @@ int bh_classifier_ensure_warm(bh_classifier *c, size_t batch_size) try {
 
 int bh_batch_context_create(bh_classifier *c, size_t max_batch, bh_batch_context **out) try {
     const char *keep = getenv("BIRDA_HIP_KEEP_TENSORS");
-    return ctx_create(c, max_batch, keep && keep[0] == '1', out);
+    const bool keep_t = keep && keep[0] == '1';
+    if (c && out && !keep_t) {
+        std::lock_guard<std::mutex> g(c->parked_mu);
+        if (c->parked_ctx && c->parked_ctx->max_batch == max_batch && !c->parked_ctx->keep_tensors) {
+            *out = c->parked_ctx;
+            c->parked_ctx = nullptr;
+            return BH_OK;
+        }
+    }
+    return ctx_create(c, max_batch, keep_t, out);
 } catch (...) { return on_exception(); }
-void bh_batch_context_destroy(bh_batch_context *ctx) { ctx_destroy(ctx); }
+
+void bh_batch_context_destroy(bh_batch_context *ctx) {
+    if (!ctx) return;
+    bh_classifier *c = ctx->c;
+    if (!ctx->keep_tensors && !ctx->profiling) {   // parked for the next create of this size (see bh_classifier::parked_ctx)
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(ctx->stream);
+        *ctx->h_nonfinite = 0;
+        (void)hipMemsetAsync(ctx->d_nonfinite, 0, sizeof(unsigned), ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        bh_batch_context *old = nullptr;
+        {
+            std::lock_guard<std::mutex> g(c->parked_mu);
+            old = c->parked_ctx;
+            c->parked_ctx = ctx;
+        }
+        if (old) ctx_destroy(old);
+        return;
+    }
+    ctx_destroy(ctx);
+}
 size_t bh_batch_context_bytes(const bh_batch_context *ctx) {
     return ctx ? ctx->max_batch * (size_t)ctx->c->model.h.sample_count * sizeof(float) : 0;
 }

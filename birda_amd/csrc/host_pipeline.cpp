@@ -603,9 +603,9 @@ struct PcmMapping {
         const int fd = ::open(d.path.c_str(), O_RDONLY);
         if (fd < 0) return false;
         length = (size_t)(d.data_offset + d.data_bytes);
-        // MAP_POPULATE: the page tables are filled in one pass here instead of one minor fault per 4-KB page inside the upload
-        // workers' copies (70 000 faults for a 1 000-segment file)
-        if (d.data_bytes) base = mmap(nullptr, length, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+        // (no MAP_POPULATE: the minor faults are taken inside the upload workers' copies, eight threads at once; populating
+        //  the 70 000 pages of a 1 000-segment file here, on one thread, was slower end to end)
+        if (d.data_bytes) base = mmap(nullptr, length, PROT_READ, MAP_PRIVATE, fd, 0);
         ::close(fd);
         if (d.data_bytes && base == MAP_FAILED) return false;
         if (base != MAP_FAILED) (void)madvise(base, length, MADV_SEQUENTIAL);
@@ -621,6 +621,13 @@ extern "C" int bhh_process_file(bh_classifier *clf, const bhh_processing_config 
     if (!clf || !cfg || !cfg->input_path || !res) return hfail(BH_ERR_INVALID, "process_file: null argument");
     memset(res, 0, sizeof *res);
     const auto t_start = std::chrono::steady_clock::now();
+    const bool timing = getenv("BIRDA_HOST_TIMING") != nullptr;   // diagnostic: phase times of this call to stderr
+    auto lap = [&, last = t_start](const char *what) mutable {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "process_file %-10s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    };
     bh_model_info info;
     if (bh_classifier_info(clf, &info) != BH_OK) return hfail(BH_ERR_INVALID, bh_last_error());
     const uint32_t formats = cfg->formats ? cfg->formats : BHH_FORMAT_CSV;
@@ -692,7 +699,9 @@ extern "C" int bhh_process_file(bh_classifier *clf, const bhh_processing_config 
         res->effective_batch = pl.effective;
     }
 
+    lap("open");
     rc = bh_classifier_ensure_warm(clf, pl.effective);                                       // :577
+    lap("warm");
     if (rc != BH_OK) return hfail(rc, bh_last_error());
     bh_batch_context *ctx = nullptr;                                                         // :582-603
     if (pl.effective > 1 || device || bat_mode) {
@@ -704,12 +713,14 @@ extern "C" int bhh_process_file(bh_classifier *clf, const bhh_processing_config 
     }
     std::unique_ptr<bh_batch_context, void (*)(bh_batch_context *)> ctx_own(ctx, bh_batch_context_destroy);
 
+    lap("context");
     // run_streaming_inference -- :114-190
     std::vector<Detection> detections;
     RunStats st;
     std::string fail_msg;
     const int fail_code = device ? run_device_front_end(clf, pl, info, ctx, map.pcm, map.n_frames, channels, detections, st, fail_msg)
                                  : run_host_front_end(clf, pl, info, ctx, detections, st, fail_msg);
+    lap("inference");
     ctx_own.reset();
     if (fail_code) return hfail(fail_code, fail_msg);
 
@@ -720,6 +731,7 @@ extern "C" int bhh_process_file(bh_classifier *clf, const bhh_processing_config 
         return a.confidence > b.confidence;
     });
 
+    lap("sort");
     const double audio_duration = has_duration ? duration
                                   : (st.segments ? (double)pl.segment_duration + (st.segments - 1.0) * ((double)pl.segment_duration - overlap_secs) : 0.0);  // :692-703
 
@@ -743,6 +755,7 @@ extern "C" int bhh_process_file(bh_classifier *clf, const bhh_processing_config 
         }
     }
     if (!cfg->dual_output && cfg->reporter) bhh::reporter_detections(cfg->reporter, pl.path, detections);   // :739-769
+    lap("write");
 
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     res->detections = detections.size();

@@ -238,6 +238,8 @@ void launch_pw_gemm16(const float *A, const void *Wf, const float *bias, const f
                       int act, int terms, float w_unscale, hipStream_t s);
 // global average pool [n][P][C] -> [n][C]
 void launch_gap(const float *in, float *out, int n_seg, int P, int C, hipStream_t s);
+// squeeze-excite gate: out[n][p][c] = in[n][p][c] * gate[n][c]   (C % 4 == 0)
+void launch_scale(const float *in, const float *gate, float *out, int n_seg, int P, int C, hipStream_t s);
 // head 1x1 conv + GELU + global average pool fused (f16 hi / lo weight planes as for launch_pw_gemm16)
 bool head_gap16_supports(int P, int K, int N, int act);
 void launch_head_gap16(const float *A, const void *Wf, const float *bias, float *out, int n_seg, int P, int K, int N,

@@ -574,6 +574,26 @@ void launch_gap(const float *in, float *out, int n_seg, int P, int C, hipStream_
 }
 
 // ---------------------------------------------------------------------------------------
+// Squeeze-excite gate (ONNX Mul of a feature map with a [N, C, 1, 1] tensor): HBM-bound, 16-byte accesses
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scale_kernel(const float4 *__restrict__ in, const float4 *__restrict__ gate,
+                                                     float4 *__restrict__ out, long total4, int pc4, int c4n) {
+    for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < total4; g += (long)gridDim.x * 256) {
+        const long seg = g / pc4;
+        const int c4 = (int)(g % c4n);
+        const float4 a = in[g], s = gate[seg * c4n + c4];
+        out[g] = make_float4(a.x * s.x, a.y * s.y, a.z * s.z, a.w * s.w);
+    }
+}
+
+void launch_scale(const float *in, const float *gate, float *out, int n_seg, int P, int C, hipStream_t s) {
+    const int c4n = C / 4;
+    const long total4 = (long)n_seg * P * c4n;
+    const unsigned blocks = (unsigned)std::min<long>((total4 + 255) / 256, 256L * 64);
+    hipLaunchKernelGGL(scale_kernel, dim3(blocks), dim3(256), 0, s, (const float4 *)in, (const float4 *)gate, (float4 *)out, total4, P * c4n, c4n);
+}
+
+// ---------------------------------------------------------------------------------------
 // activation + top-k (block per segment).  Ranks on the logit (monotone in the confidence,
 // immune to saturated-sigmoid ties), ties to the lower class index -- same rule as the
 // oracle's bo_topk.  idx = -1 / conf = 0 pad the unused slots.

@@ -8,7 +8,7 @@
 
 namespace bh {
 
-enum Op : uint32_t { OP_CONV = 1, OP_DWCONV = 2, OP_PWCONV = 3, OP_GAP = 4, OP_DENSE = 5 };
+enum Op : uint32_t { OP_CONV = 1, OP_DWCONV = 2, OP_PWCONV = 3, OP_GAP = 4, OP_DENSE = 5, OP_SCALE = 6 };   // OP_SCALE: x * gate[n][c] (squeeze-excite; gate = res_tensor)
 constexpr uint32_t NO_TENSOR = 0xFFFFFFFFu;
 
 #pragma pack(push, 1)
@@ -87,7 +87,8 @@ inline bool load_model(const char *path, Model &m, std::string &err) {
         const uint64_t wn = L.op == OP_CONV ? (uint64_t)L.kh * L.kw * L.cin * L.cout
                           : L.op == OP_DWCONV ? (uint64_t)L.kh * L.kw * L.cout
                           : (L.op == OP_PWCONV || L.op == OP_DENSE) ? (uint64_t)L.cin * L.cout : 0;
-        if (L.op != OP_GAP && (L.w_off + wn > m.h.blob_floats || L.b_off + L.cout > m.h.blob_floats)) {
+        if (L.op == OP_SCALE && (L.res_tensor == NO_TENSOR || m.tensor_floats[L.res_tensor] != L.cout || L.cin != L.cout)) { err = "scale layer without a [C] gate"; return false; }
+        if (L.op != OP_GAP && L.op != OP_SCALE && (L.w_off + wn > m.h.blob_floats || L.b_off + L.cout > m.h.blob_floats)) {
             err = "layer weights outside blob"; return false;
         }
     }

@@ -32,7 +32,7 @@ import numpy as np
 MAGIC = b"BHM1"
 VERSION = 1
 
-OP_CONV, OP_DWCONV, OP_PWCONV, OP_GAP, OP_DENSE = 1, 2, 3, 4, 5
+OP_CONV, OP_DWCONV, OP_PWCONV, OP_GAP, OP_DENSE, OP_SCALE = 1, 2, 3, 4, 5, 6   # OP_SCALE: x[n,h,w,c] * gate[n,c] (squeeze-excite), gate = res_tensor
 ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SWISH, ACT_GELU_ERF, ACT_GELU_TANH, ACT_SIGMOID = range(7)
 OUT_NONE, OUT_SIGMOID, OUT_SOFTMAX = 0, 1, 2
 NO_TENSOR = 0xFFFFFFFF

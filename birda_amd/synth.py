@@ -107,6 +107,10 @@ class _Builder:
                      0, self.put(wt), self.put(self.bias(cout)))
         return self.add(L)
 
+    def scale(self, tin, tgate, h, w, c):
+        L = mf.Layer(mf.OP_SCALE, mf.ACT_NONE, tin, tgate, c, c, 1, 1, 1, 1, 0, 0, h, w, h, w)
+        return self.add(L)
+
     def gap(self, tin, h, w, c):
         L = mf.Layer(mf.OP_GAP, mf.ACT_NONE, tin, mf.NO_TENSOR, c, c, h, w, 1, 1, 0, 0, h, w, 1, 1)
         return self.add(L)
@@ -132,6 +136,7 @@ def build_model(kind: str = "birdnet_v24", seed: int = WEIGHT_SEED,
     'mini' (short segments + toy stack, for second-scale CPU tests),
     'mini_b0' (short segments + the full EfficientNet-B0 channel plan),
     'mini_hg' (toy stack ending in 32 channels + a 128-wide head: fused head conv + pool on a small arena),
+    'mini_se' (toy stack with swish activations and a squeeze-excite gate in every block: the EfficientNet original),
     'perch_v2' (5 s / 32 kHz, Perch-shaped: one 128-mel branch, 14 795 classes)."""
     rng = np.random.default_rng(seed)
     b = _Builder(rng)
@@ -143,7 +148,7 @@ def build_model(kind: str = "birdnet_v24", seed: int = WEIGHT_SEED,
         stages = _B0_STAGES if kind == "birdnet_v24" else _TINY_STAGES
         stem, head, ncls, family = (32, 1024, 6522, 0) if kind == "birdnet_v24" else (8, 64, 50, 0)
         out_act = mf.OUT_SIGMOID
-    elif kind in ("mini", "mini_b0", "mini_hg"):
+    elif kind in ("mini", "mini_b0", "mini_hg", "mini_se"):
         sr, n, dur = 48000, 12000, 0.25
         branches = [mf.Branch(512, 100, 32, (n - 512) // 100 + 1, 0.0, 3000.0, 1.23),
                     mf.Branch(256, 103, 32, (n - 256) // 103 + 1, 500.0, 15000.0, 1.23)]
@@ -167,6 +172,9 @@ def build_model(kind: str = "birdnet_v24", seed: int = WEIGHT_SEED,
         br.mel_w_off = b.put(w)
         # the graph's BatchNorm on the spectrogram, folded to a per-channel affine
         br.out_scale, br.out_shift = 0.8, -0.4
+    se = kind == "mini_se"
+    if se:
+        act = mf.ACT_SWISH      # the EfficientNet original: swish activations, squeeze-excite in every block
     h, w_, c = branches[0].n_mels, branches[0].n_frames, len(branches)
     t, h, w_ = b.conv(0, h, w_, c, stem, 3, 2, act, in_layout=1)
     c = stem
@@ -178,6 +186,12 @@ def build_model(kind: str = "birdnet_v24", seed: int = WEIGHT_SEED,
                 t = b.pwconv(t, h, w_, c, c * e, act)
                 c = c * e
             t, h, w_ = b.dwconv(t, h, w_, c, k, stride, act)
+            if se:   # squeeze-excite between the depthwise and the project conv (EfficientNet): pool -> fc (swish) -> fc (sigmoid) -> gate
+                cr = max(4, cin // 4 // 4 * 4)
+                tg = b.gap(t, h, w_, c)
+                tg = b.pwconv(tg, 1, 1, c, cr, mf.ACT_SWISH)
+                tg = b.pwconv(tg, 1, 1, cr, c, mf.ACT_SIGMOID)
+                t = b.scale(t, tg, h, w_, c)
             res = tin if (stride == 1 and cin == cout) else mf.NO_TENSOR
             # damp residual branches so the synthetic net keeps O(1) activations
             t = b.pwconv(t, h, w_, c, cout, mf.ACT_NONE, res, gain=0.5 if res != mf.NO_TENSOR else 1.0)

@@ -31,7 +31,7 @@
 /* ------------------------------------------------------------------------------------ */
 /* BHM1 container (birda_amd/modelfile.py)                                               */
 /* ------------------------------------------------------------------------------------ */
-enum { OP_CONV = 1, OP_DWCONV = 2, OP_PWCONV = 3, OP_GAP = 4, OP_DENSE = 5 };
+enum { OP_CONV = 1, OP_DWCONV = 2, OP_PWCONV = 3, OP_GAP = 4, OP_DENSE = 5, OP_SCALE = 6 };
 enum { ACT_NONE, ACT_RELU, ACT_RELU6, ACT_SWISH, ACT_GELU_ERF, ACT_GELU_TANH, ACT_SIGMOID };
 enum { OUT_NONE, OUT_SIGMOID, OUT_SOFTMAX };
 #define NO_TENSOR 0xFFFFFFFFu
@@ -330,6 +330,13 @@ static void forward_one(const bo_model *m, const float *seg, float **tensors) {
         case OP_PWCONV: layer_pw((int)(L->out_h * L->out_w), (int)L->cin, (int)L->cout, W, B, in, out); break;
         case OP_DENSE: layer_pw(1, (int)L->cin, (int)L->cout, W, B, in, out); break;
         case OP_GAP: layer_gap(L, in, out); break;
+        case OP_SCALE: {   /* squeeze-excite: every pixel's channels times the gate [C] (tensor res_tensor); ONNX Mul(x, gate) */
+            const float *gate = tensors[L->res_tensor];
+            const int px = (int)(L->out_h * L->out_w), c = (int)L->cout;
+            for (int p = 0; p < px; p++)
+                for (int n = 0; n < c; n++) out[(size_t)p * c + n] = in[(size_t)p * c + n] * gate[n];
+            continue;      /* no bias, activation or residual on this op: res_tensor is the gate */
+        }
         default: break;
         }
         if (L->act != ACT_NONE)

@@ -36,7 +36,7 @@ def model_dir(tmp_path_factory):
     from birda_amd import modelfile as mf, synth
     d = tmp_path_factory.mktemp("models")
     out = {}
-    for kind in ("mini", "birdnet_v24_tiny", "mini_b0", "mini_hg"):
+    for kind in ("mini", "birdnet_v24_tiny", "mini_b0", "mini_hg", "mini_se"):
         m = synth.build_model(kind)
         p = str(d / f"{kind}.bhm")
         mf.write_model(p, m)

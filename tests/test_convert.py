@@ -13,7 +13,7 @@ LAYER_KEYS = ("op", "act", "in_tensor", "res_tensor", "cin", "cout", "kh", "kw",
 
 def _weights(m, L):
     nw = {mf.OP_CONV: L.kh * L.kw * L.cin * L.cout, mf.OP_DWCONV: L.kh * L.kw * L.cout, mf.OP_PWCONV: L.cin * L.cout,
-          mf.OP_DENSE: L.cin * L.cout, mf.OP_GAP: 0}[L.op]
+          mf.OP_DENSE: L.cin * L.cout, mf.OP_GAP: 0, mf.OP_SCALE: 0}[L.op]
     return m.weight(L.w_off, nw), m.weight(L.b_off, L.cout if nw else 0)
 
 
@@ -30,7 +30,7 @@ def _same_model(a, b, exact=True):
         assert np.array_equal(a.weight(x.mel_w_off, x.n_bins * x.n_mels), b.weight(y.mel_w_off, y.n_bins * y.n_mels))
 
 
-@pytest.mark.parametrize("kind", ["mini", "mini_b0", "birdnet_v24_tiny"])
+@pytest.mark.parametrize("kind", ["mini", "mini_b0", "birdnet_v24_tiny", "mini_se"])
 @pytest.mark.parametrize("spelling", ["erf", "gelu"])
 def test_round_trip_through_onnx_bytes(kind, spelling):
     m = synth.build_model(kind)
@@ -38,7 +38,7 @@ def test_round_trip_through_onnx_bytes(kind, spelling):
     g = ox.load(data)
     assert g.inputs[0].name == "spectrogram" and g.inputs[0].shape[1:] == [len(m.branches), m.spec_h, m.spec_w]
     ops = {n.op_type for n in g.nodes}
-    assert "Conv" in ops and ("Erf" in ops) == (spelling == "erf")
+    assert "Conv" in ops and ("Erf" in ops) == (spelling == "erf" and kind != "mini_se")   # mini_se: swish, no GELU at all
     _same_model(m, convert.model_from_graph(g, m))
 
 

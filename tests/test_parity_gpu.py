@@ -581,6 +581,27 @@ def test_f16_activation_overflow_is_reported_not_silent(model_dir, oracle_lib, t
     ctx.close(); clf.close()
 
 
+def test_squeeze_excite_and_swish_stack_matches_oracle(model_dir, oracle_lib):
+    """The EfficientNet original: swish activations and a squeeze-excite gate (pool -> 1x1 -> swish -> 1x1 -> sigmoid -> multiply)
+    in every block.  Such blocks do not run fused (the fused kernel's activation is GELU and the gate sits between the depthwise
+    and the project conv): they take the layer kernels + the gate kernel, correct in every precision mode."""
+    from birda_amd import synth
+    from birda_amd.classifier import BirdClassifier
+    path, labels, m, _ = model_dir["mini_se"]
+    from birda_amd import modelfile as mf
+    assert sum(1 for L in m.layers if L.op == mf.OP_SCALE) == 4
+    segs = synth.synth_segments(5, m.sample_count, m.sample_rate, start=21)
+    ref = oracle_lib.OracleModel(path).forward(segs)
+    scale = max(1.0, float(np.abs(ref).max()))
+    for prec, tol in (("f32", LOGIT_RTOL), ("f16x3", LOGIT_RTOL), ("f16", F16_LOGIT_RTOL)):
+        clf = BirdClassifier(path, labels, precision=prec)
+        assert clf.fused_blocks() == []
+        ctx = clf.create_batch_context(3)
+        got = clf.predict_logits(ctx, segs)
+        assert np.isfinite(got).all() and np.abs(got - ref).max() <= tol * scale, (prec, float(np.abs(got - ref).max()))
+        ctx.close(); clf.close()
+
+
 def test_fused_head_pool_on_a_small_arena(model_dir, oracle_lib):
     """The head conv + GELU + pool launch reads the conv's input while finished workgroups already store pooled rows:
     the arena plan must keep the two apart (on this toy stack first-fit used to put both at offset 0).  Many
