@@ -1,0 +1,136 @@
+// AddressSanitizer / UBSan build of the host-side pipeline pieces that parse untrusted input or format output
+// ("-fsanitize=address,undefined host build").  Compiled and run by tests/test_host_sanitizers.py on
+// the CPU; the device entry points host_pipeline.cpp links against are stubbed out here (nothing below reaches them).
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/birda_hip.h"
+#include "../../include/birda_host.h"
+
+// ---- stubs for the device library (never called by this driver) ----
+extern "C" {
+const char *bh_last_error(void) { return "stub"; }
+int bh_classifier_info(const bh_classifier *, bh_model_info *) { return BH_ERR_NO_DEVICE; }
+const char *bh_classifier_label(const bh_classifier *, uint32_t) { return nullptr; }
+int bh_classifier_ensure_warm(bh_classifier *, size_t) { return BH_ERR_NO_DEVICE; }
+int bh_batch_context_create(bh_classifier *, size_t, bh_batch_context **) { return BH_ERR_NO_DEVICE; }
+void bh_batch_context_destroy(bh_batch_context *) {}
+int bh_predict(bh_classifier *, const float *, size_t, bh_result *) { return BH_ERR_NO_DEVICE; }
+int bh_predict_batch(bh_classifier *, const float *const *, size_t, size_t, bh_result *) { return BH_ERR_NO_DEVICE; }
+int bh_predict_batch_with_context(bh_classifier *, bh_batch_context *, const float *const *, size_t, size_t, bh_result *) { return BH_ERR_NO_DEVICE; }
+int bh_predict_batch_source_rate(bh_classifier *, bh_batch_context *, const float *const *, size_t, size_t, uint32_t, bh_result *) { return BH_ERR_NO_DEVICE; }
+int bh_predict_pcm16(bh_classifier *, bh_batch_context *, const int16_t *, size_t, uint32_t, uint32_t, size_t, bh_result *, size_t, size_t *, uint64_t *) { return BH_ERR_NO_DEVICE; }
+int bh_predict_batch_two_stage(bh_classifier *, bh_batch_context *, bh_custom_classifier *, const float *const *, size_t, size_t, bh_result *, float *) { return BH_ERR_NO_DEVICE; }
+const char *bh_custom_classifier_label(const bh_custom_classifier *, uint32_t) { return nullptr; }
+size_t bh_classifier_default_batch_size(const bh_classifier *) { return 256; }
+}
+
+static int failures = 0;
+#define CHECK(c) do { if (!(c)) { fprintf(stderr, "CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #c); failures++; } } while (0)
+
+static void put32(std::string &s, uint32_t v) { s.append(reinterpret_cast<const char *>(&v), 4); }
+static void put16(std::string &s, uint16_t v) { s.append(reinterpret_cast<const char *>(&v), 2); }
+static void write_file(const std::string &path, const std::string &bytes) {
+    FILE *f = fopen(path.c_str(), "wb");
+    fwrite(bytes.data(), 1, bytes.size(), f);
+    fclose(f);
+}
+
+int main(int argc, char **argv) {
+    const std::string dir = argc > 1 ? argv[1] : "/tmp";
+    // 1. WAV headers: well-formed, truncated at every length, hostile chunk sizes
+    std::string wav = "RIFF";
+    put32(wav, 36 + 2000); wav += "WAVEfmt "; put32(wav, 16); put16(wav, 1); put16(wav, 2); put32(wav, 44100); put32(wav, 176400); put16(wav, 4); put16(wav, 16);
+    wav += "LIST"; put32(wav, 5); wav += "abcde"; wav += '\0';
+    wav += "data"; put32(wav, 2000);
+    for (int i = 0; i < 1000; i++) put16(wav, (uint16_t)(i * 37));
+    for (size_t cut = 0; cut <= wav.size(); cut += (cut < 80 ? 1 : 97)) {
+        const std::string p = dir + "/cut.wav";
+        write_file(p, wav.substr(0, cut));
+        bh_decoder *d = nullptr;
+        if (bhh_decoder_open(p.c_str(), &d) == BH_OK) {
+            std::vector<float> seg(300);
+            size_t start = 0;
+            int n = 0;
+            while (bhh_decoder_next_segment(d, 300, 100, seg.data(), &start) == 1 && n < 100) n++;
+            bhh_decoder_close(d);
+        }
+    }
+    for (uint32_t evil : {0u, 1u, 15u, 17u, 0x7fffffffu, 0xfffffff0u, 0xffffffffu}) {
+        std::string w = "RIFF"; put32(w, 100); w += "WAVEfmt "; put32(w, evil); put16(w, 1); put16(w, 1); put32(w, 48000); put32(w, 96000); put16(w, 2); put16(w, 16);
+        w += "data"; put32(w, evil); w += std::string(64, '\x11');
+        const std::string p = dir + "/evil.wav";
+        write_file(p, w);
+        bh_decoder *d = nullptr;
+        if (bhh_decoder_open(p.c_str(), &d) == BH_OK) {
+            float seg[64]; size_t st;
+            (void)bhh_decoder_next_segment(d, 64, 0, seg, &st);
+            bhh_decoder_close(d);
+        }
+    }
+    // 2. every writer, odd labels and paths, NaN / inf confidences
+    const char *labels[] = {"Passer domesticus_House Sparrow", "NoUnderscore", "_", "a_b_c d_e", "", "\xc3\x84\xc3\xa4kk\xc3\xb6nen laji_\xc3\x96ljy \"quoted\", name\n", "x_\xf0\x9f\x90\xa6 bird"};
+    const char *paths[] = {"/a/b/c.wav", "c.wav", "/", "", "a//b///", "../x/..", "/only"};
+    for (uint32_t fmt = 1; fmt <= 32; fmt <<= 1) {
+        char out[512];
+        size_t n = bhh_output_path_for("/in/some.file.flac", dir.c_str(), fmt, out, sizeof out);
+        CHECK(n > 0 && n < sizeof out);
+        bhh_writer_options o{};
+        o.csv_bom = 1; o.csv_columns = "lat,lon,week,model,overlap,sensitivity,min_conf,species_list,unknown"; o.source_file = "s\"f\\.wav"; o.model = "m";
+        o.min_confidence = 0.1f; o.overlap = 1.5f; o.audio_duration = 1e9f; o.has_lat = 1; o.lat = -89.999999; o.has_lon = 1; o.lon = 1e-9; o.week = 48;
+        bhh_writer *w = nullptr;
+        CHECK(bhh_writer_open(fmt, out, &o, &w) == BH_OK);
+        CHECK(bhh_writer_write_header(w) == BH_OK);
+        int k = 0;
+        for (const char *l : labels)
+            for (const char *pth : paths) {
+                const float conf = k % 11 == 0 ? NAN : k % 13 == 0 ? INFINITY : 0.01f * (float)(k % 100);
+                CHECK(bhh_writer_write_detection(w, l, conf, (float)k * 1.5f, (float)k * 1.5f + 3.0f, pth) == BH_OK);
+                k++;
+            }
+        CHECK(bhh_writer_finalize(w) == BH_OK);
+    }
+    char buf[512];
+    for (double v : {0.0, -0.0, 1e-45, 3.4e38, 1e300, 123456789.125, 0.1, (double)NAN, (double)INFINITY})
+        for (int kind = 0; kind < 4; kind++) CHECK(bhh_format_float(kind, v, buf, sizeof buf) < sizeof buf);
+    char tiny[2] = {'#', '#'};
+    CHECK(bhh_format_float(3, 0.1, tiny, 2) == 3 && tiny[0] == '#');            // too small a buffer: length returned, nothing written past it
+    CHECK(bhh_species_code("\xc3\x84", buf, sizeof buf) > 0);
+    // 3. reporter: every event, hostile strings
+    bhh_reporter *r = nullptr;
+    CHECK(bhh_reporter_open(BHH_REPORT_JSON, (dir + "/events.json").c_str(), &r) == BH_OK);
+    bhh_range_filter_info rf{"3.0.2", 1, 2, 3, 4, "keep", 0.03f};
+    bhh_reporter_pipeline_started(r, 3, "m\"\\\n\t\x01", 0.1f, "gpu", "HIP", nullptr, &rf);
+    bhh_reporter_file_started(r, paths[0], 0, 10, 1, 30.0);
+    for (int i = 0; i <= 100; i += 7) (void)bhh_reporter_file_progress(r, paths[0], (size_t)i, 100, (float)i);
+    (void)bhh_reporter_file_progress(r, paths[0], 1, 0, NAN);
+    bhh_reporter_batch_progress(r, 1, 3, 33.3f);
+    const float c[2] = {0.5f, NAN}, st[2] = {0.f, 3.f}, en[2] = {3.f, 6.f};
+    bhh_reporter_detections(r, paths[1], labels, c, st, en, 2);
+    bhh_reporter_file_completed(r, paths[0], BHH_FILE_PROCESSED, 2, 12, nullptr, nullptr);
+    bhh_reporter_file_completed(r, paths[1], BHH_FILE_FAILED, 0, 0, "code", "msg\n");
+    bhh_reporter_file_completed(r, paths[2], 7, 0, 0, nullptr, nullptr);   // unknown status: ignored
+    bhh_reporter_error(r, "e", 0, "m", nullptr);
+    bhh_reporter_pipeline_completed(r, 1, 1, 0, 2, 10, 99, 123.456);
+    bhh_reporter_close(r);
+    // 4. small host helpers at their edges
+    CHECK(bhh_estimate_segment_count(1, 10.0, 3.0f, 3.0f) == -1);
+    CHECK(bhh_effective_batch_size(8, 0) == 8 && bhh_effective_batch_size(8, 3) == 3);
+    CHECK(bhh_source_samples(144000, 44100, 48000) == 132300);
+    CHECK(bhh_is_audio_file(".wav") == 0 && bhh_is_audio_file("a.WAV") == 1);
+    void *g = bhh_watchdog_start(60000, 8);
+    bhh_watchdog_cancel(g);
+    bhh_watchdog_cancel(nullptr);
+    // 5. process_file on a file that does not decode: an error code, no crash
+    bhh_processing_config cfg{};
+    cfg.input_path = (dir + "/cut.wav").c_str();
+    bhh_process_result res;
+    CHECK(bhh_process_file(reinterpret_cast<bh_classifier *>(&cfg), &cfg, &res) != BH_OK);
+    if (failures) { fprintf(stderr, "%d check(s) failed\n", failures); return 1; }
+    printf("host sanitizer driver: ok\n");
+    return 0;
+}
