@@ -129,7 +129,10 @@ class BirdClassifier:
     def fused_kernel_name(self, cfg: int) -> str:
         buf = C.create_string_buffer(128)
         self._L.bh_mb_config_name(cfg, buf, 128)
-        return "mbconv<" + buf.value.decode() + ">"
+        name = buf.value.decode()
+        if name.startswith("w,"):       # wave-private instantiation (kernels_mbwave.hip)
+            return "mbw<" + name[2:] + ">"
+        return "mbconv<" + name + ">"
 
     def mel_kernel_name(self) -> str:
         """The front-end kernel instantiation as a profiler prints it (e.g. "bh::mel_kernel<6, 3>")."""

@@ -393,7 +393,8 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
             d.X = in;
             d.Y = (i + 2 == nl - 1) ? d_logits : T(i + 3);
             d.R = LP.res_tensor != bh::NO_TENSOR ? T(LP.res_tensor) : nullptr;
-            bh::launch_mbconv(d, (int)n, s);
+            if (d.cfg <= -2) bh::launch_mbwave(d, (int)n, s);
+            else bh::launch_mbconv(d, (int)n, s);
             ctx_mark(ctx, ST_MBCONV, (int)i);
             i += 2;
             continue;
@@ -649,10 +650,12 @@ int plan_fusion(bh_classifier *c) {
         // The split-f16 MFMA and the f32 MFMA agree to ~1e-7 of sum|a b|; measured (profiles/), f16x3 is
         // the faster one on every block, the stem's 18-column im2col GEMM included.
         if (d.stem && c->precision == 3 && getenv("BIRDA_HIP_STEM_F32")) d.prec = 0;   // A/B aid
-        if (!bh::mb_plan(d, force_cfg)) {
-            if (d.prec == 0) continue;
-            d.prec = 0;                       // no f16 instantiation for this shape: f32 one, if any
-            if (!bh::mb_plan(d, force_cfg)) continue;
+        if (force_cfg >= 0 || !bh::mbw_plan(d)) {   // the wave-private kernel takes the early blocks of the f16 modes
+            if (!bh::mb_plan(d, force_cfg)) {
+                if (d.prec == 0) continue;
+                d.prec = 0;                       // no f16 instantiation for this shape: f32 one, if any
+                if (!bh::mb_plan(d, force_cfg)) continue;
+            }
         }
         // per-chunk weight blocks (kernels.hpp MbDesc)
         const int CE = d.CE, NTE = CE / 16, KG = d.KG, NTOP = d.NTOP, nch = d.nchunks, KK = d.KS * d.KS;
@@ -1331,7 +1334,15 @@ int bh_classifier_fused_blocks(const bh_classifier *c, int32_t *cfgs, size_t cap
     return (int)c->mb.size();
 }
 
-int bh_mb_config_name(int32_t cfg, char *out, size_t cap) { return bh::mb_config_name(cfg, out, cap); }
+int bh_mb_config_name(int32_t cfg, char *out, size_t cap) {
+    if (cfg <= -2) {   // a wave-private instantiation (kernels_mbwave.hip): "w," + its template arguments
+        char buf[96];
+        const int n = bh::mbw_config_name(cfg, buf, sizeof buf);
+        if (n <= 0) return 0;
+        return snprintf(out, cap, "w,%s", buf);
+    }
+    return bh::mb_config_name(cfg, out, cap);
+}
 
 int bh_classifier_frontend_kernel(const bh_classifier *c, char *out, size_t cap) {
     if (!c) return 0;

@@ -318,5 +318,9 @@ int mb_config_name(int ci, char *out, size_t cap);
 // picks the instantiation (force_cfg >= 0: that entry or fail) and fills the derived fields
 bool mb_plan(MbDesc &d, int force_cfg);
 void launch_mbconv(const MbDesc &d, int n_seg, hipStream_t s);
+// Wave-private variant for the early blocks (kernels_mbwave.hip): d.cfg <= -2 marks a block planned by mbw_plan
+bool mbw_plan(MbDesc &d);
+void launch_mbwave(const MbDesc &d, int n_seg, hipStream_t s);
+int mbw_config_name(int cfg, char *out, size_t cap);
 
 }  // namespace bh

@@ -471,6 +471,29 @@ def test_precision_modes_on_the_full_model(full_model, oracle_lib):
     assert (out["f16"].argmax(1) == ref.argmax(1)).all() and (out["f16x3"].argmax(1) == ref.argmax(1)).all()
 
 
+def test_wave_private_early_blocks_match_oracle(full_model, oracle_lib, monkeypatch):
+    """The opt-in wave-private instantiations (kernels_mbwave.hip, BIRDA_HIP_MB_WAVE=1: one output tile per wave, no
+    workgroup barrier in the chunk loop) take the early blocks of the full model and hold the same tolerances."""
+    from birda_amd import synth
+    from birda_amd.classifier import BirdClassifier
+    path, labels, m, _ = full_model
+    segs = synth.synth_segments(3, m.sample_count, m.sample_rate, start=321)
+    ref = oracle_lib.OracleModel(path).forward(segs)
+    scale = max(1.0, float(np.abs(ref).max()))
+    monkeypatch.setenv("BIRDA_HIP_MB_WAVE", "1")
+    for prec in ("f16x3", "f16"):
+        clf = BirdClassifier(path, labels, precision=prec)
+        blocks = clf.fused_blocks()
+        assert len(blocks) == 16 and sum(1 for c in blocks if c <= -2) >= 3, blocks
+        ctx = clf.create_batch_context(3)
+        got = clf.predict_logits(ctx, segs)
+        if prec == "f16":
+            assert np.isfinite(got).all() and np.abs(got - ref).max() <= F16_LOGIT_RTOL * scale
+        else:
+            _logit_close(got, ref)
+        ctx.close(); clf.close()
+
+
 def _rescale_trunk(m, scales):
     """A function-preserving re-parameterisation of a synthetic model: every residual-connected group of project outputs
     (the linear 'trunk' tensors between blocks) is multiplied by a power of two -- project weights and bias times s -- and
