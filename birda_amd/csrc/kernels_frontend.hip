@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void mel_kernel(const float *
                                                       float *__restrict__ spec, const FrontendParams *__restrict__ pp,
                                                       const float *__restrict__ gf0, const float *__restrict__ gf1,
                                                       const float *__restrict__ gf2, const float *__restrict__ gf3,
-                                                      const int dbg, const int n_tiles, const int n_items) {
+                                                      const int dbg, const int n_tiles, const int n_items, const int paired) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n_branches = pp->n_branches;
     const int S = pp->sample_count;
@@ -155,8 +155,33 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void mel_kernel(const float *
     static_assert(MM_SPLIT == 8, "16 floats of min / max partials per segment");
     constexpr int MEL_SU = MT <= 6 ? 15 : 16;
     float4 q[MEL_SU], mmq[4];
-    auto issue = [&](int it) {
-        const int tl = it % n_tiles, sb = it / n_tiles, sg = sb / n_branches, br = sb - sg * n_branches;
+    // Work items and the XCD-aware pairing.  Unpaired: item = (seg * n_branches + branch) * n_tiles + tile, workgroup b takes
+    // b, b + gridDim.x, ...  Paired (n_branches > 1, grid a multiple of 8 n_branches): the branches of one (segment, tile)
+    // read almost the same sample span, so they go to workgroups b and b + 8 (+ 16 ...) -- the same XCD under the round-robin
+    // dispatch, hence the same L2 -- at the same step n, and the second read of the span hits L2 instead of HBM (it was
+    // 2.3x the algorithmic read traffic).  The roles rotate by one branch per step so that partners with unequal branches
+    // (K = 1024 against 512) do equal work over n_branches steps and stay within a step of each other.
+    const int pr_xcd = blockIdx.x & 7, pr_slot = blockIdx.x >> 3;
+    const int pr_role = paired ? pr_slot % n_branches : 0, pr_q = (pr_slot / n_branches) * 8 + pr_xcd;
+    const int pr_stride = (int)gridDim.x / n_branches, n_pairs = n_items / n_branches;
+    struct MelItem { int sg, br, tl, ok; };
+    auto decode = [&](int n) __attribute__((always_inline)) -> MelItem {
+        MelItem r;
+        if (paired) {
+            const int P = pr_q + n * pr_stride;
+            r.br = (pr_role + n) % n_branches;
+            r.sg = P / n_tiles; r.tl = P - r.sg * n_tiles;
+            r.ok = P < n_pairs;
+        } else {
+            const int it = (int)blockIdx.x + n * (int)gridDim.x;
+            r.tl = it % n_tiles;
+            const int sb = it / n_tiles;
+            r.sg = sb / n_branches; r.br = sb - r.sg * n_branches;
+            r.ok = it < n_items;
+        }
+        return r;
+    };
+    auto issue = [&](int sg, int br, int tl) __attribute__((always_inline)) {
         const int Hn = pp->br[br].H, Ln = pp->br[br].L;
         const int sp = ((MEL_TN - 1) * Hn + Ln + 3) & ~3, g0 = tl * MEL_TN * Hn;
         const float *xg = x + (size_t)sg * S;
@@ -170,11 +195,12 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void mel_kernel(const float *
         const float4 *mv = reinterpret_cast<const float4 *>(mm + (size_t)sg * MM_SPLIT * 2);
         mmq[0] = mv[0]; mmq[1] = mv[1]; mmq[2] = mv[2]; mmq[3] = mv[3];
     };
-    int item = blockIdx.x;
-    if (item < n_items) issue(item);
+    int step_n = 0;
+    MelItem cur = decode(0);
+    if (cur.ok) issue(cur.sg, cur.br, cur.tl);
 
-    while (item < n_items) {
-    const int tile = item % n_tiles, sbr = item / n_tiles, seg = sbr / n_branches, branch = sbr - seg * n_branches;
+    while (cur.ok) {
+    const int seg = cur.sg, branch = cur.br, tile = cur.tl;
     BranchParams bp = pp->br[branch];
     // the operator pointer comes in as a kernel argument (global address space): read through the
     // struct it is a generic pointer, hipcc emits flat_load, and every LDS wait then also drains the
@@ -354,8 +380,9 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void mel_kernel(const float *
 
     }  // PREC
     // the next item's span: in flight while the reduction and the epilogue below run
-    const int next = item + (int)gridDim.x;
-    issue(min(next, n_items - 1));   // (unconditional on purpose, see issue(); the last pass's fetch is simply not used)
+    const MelItem nxt = decode(step_n + 1);
+    // (unconditional on purpose, see issue(); past the end the current span is fetched again and simply not used)
+    issue(nxt.ok ? nxt.sg : seg, nxt.ok ? nxt.br : branch, nxt.ok ? nxt.tl : tile);
     // cross-wave reduction: wave s parks its partials for the frame tiles it does not own
     __syncthreads();  // every wave is done reading xs
     float4 *red = reinterpret_cast<float4 *>(smem);
@@ -406,7 +433,7 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void mel_kernel(const float *
     }
     }   // owner waves
     __syncthreads();   // the partials have been read: xs / red may be overwritten by the next item's span
-    item = next;
+    step_n++; cur = nxt;
     }   // items
 }
 
@@ -644,7 +671,13 @@ void launch_mel(const float *x, const float *minmax, float *spec, const Frontend
     const size_t smem = span_bytes > red_bytes ? span_bytes : red_bytes;
     const int n_tiles = (max_frames + MEL_TN - 1) / MEL_TN, n_items = n_tiles * p.n_branches * n_seg;
     const int n_cu = device_cu_count();
-    dim3 grid((unsigned)std::min(n_items, (mt <= 6 ? 2 : 1) * n_cu)), block(256);   // persistent: as many workgroups as fit at once
+    int n_wg = std::min(n_items, (mt <= 6 ? 2 : 1) * n_cu);   // persistent: as many workgroups as fit at once
+    // branch partners on one XCD (see the kernel): needs whole groups of 8 n_branches workgroups
+    static const bool pair_off = getenv("BIRDA_HIP_MEL_PAIR") && getenv("BIRDA_HIP_MEL_PAIR")[0] == '0';
+    const int pair_group = 8 * p.n_branches;
+    const int paired = (!pair_off && p.n_branches > 1 && n_wg >= pair_group) ? 1 : 0;
+    if (paired) n_wg -= n_wg % pair_group;
+    dim3 grid((unsigned)n_wg), block(256);
 #define BH_MEL_CASE(MTV)                                                                                   \
     case MTV: {                                                                                            \
         static DeviceOnce attr_set;                                                                        \
@@ -656,10 +689,10 @@ void launch_mel(const float *x, const float *minmax, float *spec, const Frontend
         });                                                                                                \
         if (p.prec == 3)                                                                                   \
             hipLaunchKernelGGL((mel_kernel<MTV, 3>), grid, block, smem, s, x, minmax, spec, d_p, p.br[0].gf,   \
-                               p.br[1].gf, p.br[2].gf, p.br[3].gf, dbg, n_tiles, n_items);                 \
+                               p.br[1].gf, p.br[2].gf, p.br[3].gf, dbg, n_tiles, n_items, paired);                 \
         else                                                                                               \
             hipLaunchKernelGGL((mel_kernel<MTV, 0>), grid, block, smem, s, x, minmax, spec, d_p, p.br[0].gf,   \
-                               p.br[1].gf, p.br[2].gf, p.br[3].gf, dbg, n_tiles, n_items);                 \
+                               p.br[1].gf, p.br[2].gf, p.br[3].gf, dbg, n_tiles, n_items, paired);                 \
     } break;
     switch (mt) {
         BH_MEL_CASE(2)
