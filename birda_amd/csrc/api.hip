@@ -412,7 +412,7 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
             if (!ctx->keep_tensors && c->head_gap[i]) {
                 float *pooled = (i + 1 == nl - 1) ? d_logits : T(i + 2);
                 bh::launch_head_gap16(in, c->d_w16[i], bias, pooled, (int)n, (int)(L.out_h * L.out_w), (int)L.cin, (int)L.cout,
-                                      c->precision == 3 ? 3 : 1, c->w16_unscale[i], s);
+                                      (int)L.act, c->precision == 3 ? 3 : 1, c->w16_unscale[i], s);
                 ctx_mark(ctx, ST_PW, (int)i);
                 i += 1;   // the pool layer is done
                 break;

@@ -184,6 +184,32 @@ __device__ __forceinline__ float act_apply_slow(float v, int act) {
     }
 }
 
+// Compile-time activations for the MFMA kernels' epilogues (a run-time switch inlined at ~40 call sites blew the fused block
+// kernel up to >100 KB of code: instruction-cache misses in the depthwise loop).  The fast forms cover what EfficientNet /
+// MobileNet-style exports use between the convolutions (ONNX Erf-GELU, Mul(Sigmoid) = swish, Clip(0, 6), Relu); anything else
+// takes the exact run-time form.  swish: v / (1 + 2^(-v log2 e)) through v_exp_f32 + v_rcp_f32 (1 ulp each).
+template <int ACT>
+__device__ __forceinline__ float bh_act(float v) {
+    if constexpr (ACT == ACT_NONE) return v;
+    else if constexpr (ACT == ACT_GELU_ERF) return gelu_erf_fast(v);
+    else if constexpr (ACT == ACT_RELU) return bh_relu1(v);
+    else if constexpr (ACT == ACT_RELU6) return __builtin_amdgcn_fmed3f(v, 0.0f, 6.0f);
+    else if constexpr (ACT == ACT_SWISH) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
+    else return act_apply_slow(v, ACT);
+}
+template <int ACT>
+__device__ __forceinline__ bh_f32x2 bh_act2(bh_f32x2 v) {
+    if constexpr (ACT == ACT_GELU_ERF) return gelu_erf_fast2(v);
+    else { bh_f32x2 r; r[0] = bh_act<ACT>(v[0]); r[1] = bh_act<ACT>(v[1]); return r; }
+}
+template <int ACT>
+__device__ __forceinline__ void bh_act4(bh_f32x2 &v0, bh_f32x2 &v1) {
+    if constexpr (ACT == ACT_GELU_ERF) gelu_erf_fast4(v0, v1);
+    else { v0 = bh_act2<ACT>(v0); v1 = bh_act2<ACT>(v1); }
+}
+// the activations the MFMA epilogues are instantiated for (layers with any other one run on the f32 layer kernels)
+inline bool act_is_templated(int act) { return act == ACT_GELU_ERF || act == ACT_SWISH || act == ACT_RELU6; }
+
 // One STFT/mel branch of the front-end, with the Hann window, the
 // real-part DFT and the mel projection folded into one operator Gf[K = L/2][n_mels_pad].
 struct BranchParams {
@@ -240,10 +266,10 @@ void launch_pw_gemm16(const float *A, const void *Wf, const float *bias, const f
 void launch_gap(const float *in, float *out, int n_seg, int P, int C, hipStream_t s);
 // squeeze-excite gate: out[n][p][c] = in[n][p][c] * gate[n][c]   (C % 4 == 0)
 void launch_scale(const float *in, const float *gate, float *out, int n_seg, int P, int C, hipStream_t s);
-// head 1x1 conv + GELU + global average pool fused (f16 hi / lo weight planes as for launch_pw_gemm16)
+// head 1x1 conv + activation (GELU / swish / ReLU6) + global average pool fused (f16 hi / lo weight planes as for launch_pw_gemm16)
 bool head_gap16_supports(int P, int K, int N, int act);
 void launch_head_gap16(const float *A, const void *Wf, const float *bias, float *out, int n_seg, int P, int K, int N,
-                       int terms, float w_unscale, hipStream_t s);
+                       int act, int terms, float w_unscale, hipStream_t s);
 // activation + top-k over logits [n][n_classes] -> idx/conf [n][top_k]
 // Post-filter of the kept top-k (reference apply_range_filter, classifier.rs:587-645): class_score (NaN = species without
 // geomodel entry) selects geomodel_filter.rs:46-82, else species_keep the species-list retain (:617-640); both null = off.

@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void pw_gemm16_kernel(const float *__restrict_
                     // the activation is a template argument: a run-time switch inlined 64 times bloats
                     // the kernel past the instruction cache
                     float v = __builtin_fmaf(acc[i][j][r], w_unscale, bv);   // the planes hold W / w_unscale
-                    if (ACT == ACT_GELU_ERF) v = gelu_erf_fast(v);
+                    v = bh_act<ACT>(v);
                     if (R) v += R[(size_t)row * N + col];
                     C[(size_t)row * N + col] = v;
                 }
@@ -272,15 +272,22 @@ __global__ __launch_bounds__(256) void pw_gemm16_kernel(const float *__restrict_
     }
 }
 
-bool pw_gemm16_supports(int K, int act) { return K % 32 == 0 && (act == ACT_NONE || act == ACT_GELU_ERF); }
+bool pw_gemm16_supports(int K, int act) { return K % 32 == 0 && (act == ACT_NONE || act_is_templated(act)); }
 
 void launch_pw_gemm16(const float *A, const void *Wf, const float *bias, const float *R, float *C, int M, int K, int N,
                       int act, int terms, float w_unscale, hipStream_t s) {
     const int n_tiles = (N + 15) / 16;
     dim3 grid((n_tiles + 7) / 8, (M + 127) / 128), block(256);
 #define BH_G16(T, ACTV) hipLaunchKernelGGL((pw_gemm16_kernel<T, ACTV>), grid, block, 0, s, A, (const f16x8 *)Wf, bias, R, C, M, K, N, n_tiles, w_unscale)
-    if (terms == 3) { if (act == ACT_GELU_ERF) BH_G16(3, ACT_GELU_ERF); else BH_G16(3, ACT_NONE); }
-    else { if (act == ACT_GELU_ERF) BH_G16(1, ACT_GELU_ERF); else BH_G16(1, ACT_NONE); }
+#define BH_G16A(T)                                                   \
+    switch (act) {                                                   \
+    case ACT_GELU_ERF: BH_G16(T, ACT_GELU_ERF); break;               \
+    case ACT_SWISH: BH_G16(T, ACT_SWISH); break;                     \
+    case ACT_RELU6: BH_G16(T, ACT_RELU6); break;                     \
+    default: BH_G16(T, ACT_NONE); break;                             \
+    }
+    if (terms == 3) { BH_G16A(3) } else { BH_G16A(1) }
+#undef BH_G16A
 #undef BH_G16
 }
 
@@ -300,7 +307,7 @@ void launch_pw_gemm16(const float *A, const void *Wf, const float *bias, const f
 // Blocks that share their rows of X are placed on the same XCD (blockIdx % 8) back to back, so X is
 // fetched from HBM once and re-read from that XCD's L2 by the other column blocks.
 // ---------------------------------------------------------------------------------------
-template <int PT, int SW, int TERMS>
+template <int PT, int SW, int TERMS, int ACT>
 __global__ __launch_bounds__(256, 1) void head_gap16_kernel(const float *__restrict__ A, const f16x8 *__restrict__ Wf,
                                                              const float *__restrict__ bias, float *__restrict__ out,
                                                              int n_seg, int P, int K, int N, int n_tiles, int n_cb, float w_unscale) {
@@ -403,7 +410,7 @@ __global__ __launch_bounds__(256, 1) void head_gap16_kernel(const float *__restr
                 const f32x4 a4 = acc[sg * PT + t][j];   // the planes hold W / w_unscale
                 bh_f32x2 v01 = {__builtin_fmaf(a4[0], w_unscale, b), __builtin_fmaf(a4[1], w_unscale, b)},
                          v23 = {__builtin_fmaf(a4[2], w_unscale, b), __builtin_fmaf(a4[3], w_unscale, b)};
-                gelu_erf_fast4(v01, v23);
+                bh_act4<ACT>(v01, v23);
                 const int px = t * 16 + 4 * kq;
                 if (PT * 16 == P || px + 3 < P) sum += (v01[0] + v01[1]) + (v23[0] + v23[1]);
                 else sum += (px < P ? v01[0] : 0.f) + (px + 1 < P ? v01[1] : 0.f) + (px + 2 < P ? v23[0] : 0.f);
@@ -417,19 +424,26 @@ __global__ __launch_bounds__(256, 1) void head_gap16_kernel(const float *__restr
 
 // P pixels per segment; the instantiations cover P <= 48 (two segments per wave) and P <= 80 (one)
 bool head_gap16_supports(int P, int K, int N, int act) {
-    return act == ACT_GELU_ERF && K % 32 == 0 && N % 128 == 0 && P >= 1 && P <= 80;
+    return act_is_templated(act) && K % 32 == 0 && N % 128 == 0 && P >= 1 && P <= 80;
 }
 
 void launch_head_gap16(const float *A, const void *Wf, const float *bias, float *out, int n_seg, int P, int K, int N,
-                       int terms, float w_unscale, hipStream_t s) {
+                       int act, int terms, float w_unscale, hipStream_t s) {
     const int n_tiles = N / 16, n_cb = N / 128;
     const int pt = (P + 15) / 16, sw = pt <= 3 ? 2 : 1;
     const int n_mb = (n_seg + 4 * sw - 1) / (4 * sw);
     dim3 grid((unsigned)(((n_mb + 7) / 8) * n_cb * 8)), block(256);
-#define BH_HG(PTV, SWV, T) hipLaunchKernelGGL((head_gap16_kernel<PTV, SWV, T>), grid, block, 0, s, A, (const f16x8 *)Wf, bias, out, \
-                                              n_seg, P, K, N, n_tiles, n_cb, w_unscale)
-    if (pt <= 3) { if (terms == 3) BH_HG(3, 2, 3); else BH_HG(3, 2, 1); }
-    else { if (terms == 3) BH_HG(5, 1, 3); else BH_HG(5, 1, 1); }
+#define BH_HG(PTV, SWV, T, ACTV) hipLaunchKernelGGL((head_gap16_kernel<PTV, SWV, T, ACTV>), grid, block, 0, s, A, (const f16x8 *)Wf, bias, out, \
+                                                    n_seg, P, K, N, n_tiles, n_cb, w_unscale)
+#define BH_HGA(PTV, SWV, T)                                          \
+    switch (act) {                                                   \
+    case ACT_SWISH: BH_HG(PTV, SWV, T, ACT_SWISH); break;            \
+    case ACT_RELU6: BH_HG(PTV, SWV, T, ACT_RELU6); break;            \
+    default: BH_HG(PTV, SWV, T, ACT_GELU_ERF); break;                \
+    }
+    if (pt <= 3) { if (terms == 3) { BH_HGA(3, 2, 3) } else { BH_HGA(3, 2, 1) } }
+    else { if (terms == 3) { BH_HGA(5, 1, 3) } else { BH_HGA(5, 1, 1) } }
+#undef BH_HGA
 #undef BH_HG
 }
 

@@ -34,27 +34,6 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-// The activation is a compile-time constant: a run-time switch inlined at ~40 call sites blew the
-// kernel up to >100 KB of code (instruction-cache misses in the depthwise loop).
-template <int ACT>
-__device__ __forceinline__ float mb_act(float v) {
-    if constexpr (ACT == ACT_NONE) return v;
-    else if constexpr (ACT == ACT_GELU_ERF) return gelu_erf_fast(v);
-    else if constexpr (ACT == ACT_RELU) return fmaxf(v, 0.f);
-    else return act_apply_slow(v, ACT);
-}
-template <int ACT>
-__device__ __forceinline__ f32x2 mb_act2(f32x2 v) {
-    if constexpr (ACT == ACT_GELU_ERF) return gelu_erf_fast2(v);
-    else { f32x2 r; r[0] = mb_act<ACT>(v[0]); r[1] = mb_act<ACT>(v[1]); return r; }
-}
-template <int ACT>
-__device__ __forceinline__ void mb_act4(f32x2 &v0, f32x2 &v1) {
-    if constexpr (ACT == ACT_GELU_ERF) gelu_erf_fast4(v0, v1);
-    else { v0 = mb_act2<ACT>(v0); v1 = mb_act2<ACT>(v1); }
-}
-constexpr int MB_ACT = ACT_GELU_ERF;  // expand + depthwise activation of every instantiation below
-
 // n / d for 0 <= n < 2^22, d > 0 through the float reciprocal (one multiply, a convert and a
 // fix-up) instead of the ~35-instruction 32-bit integer division sequence
 // (products through the 24-bit multiplier: v_mul_lo_u32 runs at a quarter of the rate of v_mad_u32_u24)
@@ -116,13 +95,14 @@ __device__ __forceinline__ void mb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)
 
 //   PREC        0: f32 MFMA (16x16x4, KG counts 16-deep groups); 3: f16 hi/lo split, three 16x16x32 MFMAs
 //               per product (KG counts 32-deep steps); 1: plain f16 operands (one MFMA, ~1e-3 relative)
+//   ACT         the expand and depthwise activation (GELU, swish, ReLU6 or ReLU: bh_act<>, kernels.hpp)
 //   PERSIST     1: persistent workgroups (grid = workgroups that fit on the chip at once) walking the tiles, with the weights of
 //               EVERY chunk resident in LDS -- loaded once per workgroup, not once per tile and chunk.  For the early blocks
 //               (large images, few channels): a tile's compute is ~5k cycles, and 12 barriers each waiting for a freshly
 //               issued L2 -> LDS transfer plus the launch and set-up of 48-96 workgroups per segment were 70 % of their time
 //               (tools/abl2.sh: chunk loop without any compute 417 of 1061 us, set-up + epilogue 303).
 template <int KS, int ST, int CE, int KG, int RT_W, int NCS, int WM, int WN, int MT_W, int NT_W, int TWL, int XBL,
-          int SS, int OCC, int STEM, int PREC, int PERSIST = 0>
+          int SS, int OCC, int STEM, int PREC, int PERSIST = 0, int ACT = ACT_GELU_ERF>
 __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const int n_seg) {
     static_assert(!STEM || SS == 1, "the stem variant handles one segment per workgroup");
     static_assert(PREC == 0 || CE % 32 == 0 || CE == 16, "f16 project GEMM: 32-deep steps, or one 16-deep step for 16-channel chunks");
@@ -410,7 +390,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                         for (int j = 0; j < NT_U; j++) {
                             f32x2 v01 = {acc[ii][j][0], acc[ii][j][1]}, v23 = {acc[ii][j][2], acc[ii][j][3]};
                             if constexpr (PREC != 0) { v01 *= e_unscale; v23 *= e_unscale; }   // weights and bias carry 2^se
-                            mb_act4<MB_ACT>(v01, v23);
+                            bh_act4<ACT>(v01, v23);
                             *reinterpret_cast<f32x4 *>(erow + j * 16) = (f32x4){v01[0], v01[1], v23[0], v23[1]};
                         }
                     }
@@ -458,7 +438,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
 #pragma unroll
                 for (int x = 0; x < XB; x++) {
                     f32x2 g0 = acc[x][0], g1 = acc[x][1];
-                    mb_act4<MB_ACT>(g0, g1);
+                    bh_act4<ACT>(g0, g1);
                     const float4 v = make_float4(g0[0], g0[1], g1[0], g1[1]);
                     const int prow = p2_prow + x;
                     if constexpr (PREC != 0) {   // the project GEMM's A operand: f16 hi (+ lo) planes
@@ -623,14 +603,14 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
 }
 
 struct MbCfg {
-    int KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC, PERSIST;
+    int KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC, PERSIST, ACT;
     void (*launch)(const MbDesc &, int, hipStream_t);
 };
 
 template <int KS, int ST, int CE, int KG, int RT_W, int NCS, int WM, int WN, int MT_W, int NT_W, int TWL, int XBL,
-          int SS, int OCC, int STEM, int PREC, int PERSIST = 0>
+          int SS, int OCC, int STEM, int PREC, int PERSIST, int ACT>
 void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
-    auto kern = mbconv_kernel<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, SS, OCC, STEM, PREC, PERSIST>;
+    auto kern = mbconv_kernel<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, SS, OCC, STEM, PREC, PERSIST, ACT>;
     static DeviceOnce attr_set;
     attr_set.run([&] { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     dim3 grid(d.tiles_x, d.tiles_y, (n_seg + d.S - 1) / d.S), block(256);
@@ -642,13 +622,14 @@ void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
     hipLaunchKernelGGL(kern, grid, block, d.lds_bytes, s, d, n_seg);
 }
 
+// (MB_A: the activation the table is being expanded for, see kCfgs below)
 #define MB_ENTRY_P(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, PREC) \
-    {KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC, 0,              \
-     mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC, STEM, PREC>}
+    {KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC, 0, MB_A,        \
+     mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC, STEM, PREC, 0, MB_A>}
 // persistent workgroups, every chunk's weights resident in LDS (the early blocks)
 #define MB_ENTRY_PP(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, PREC) \
-    {KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC, 1,               \
-     mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC, STEM, PREC, 1>}
+    {KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC, 1, MB_A,         \
+     mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC, STEM, PREC, 1, MB_A>}
 #define MB_ENTRY_S(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM) \
     MB_ENTRY_P(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, 0)
 #define MB_ENTRY(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC) \
@@ -658,97 +639,23 @@ void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
     MB_ENTRY_P(KS, ST, 32, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, 3),          \
     MB_ENTRY_P(KS, ST, 32, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, 1)
 
-// The instantiations cover the BirdNET-v2.4 / Perch-shaped stacks (EfficientNet-B0 stages);
-// mb_plan() picks, per block, the valid entry with the least MFMA work.
-//        KS ST CE KG RT NCS WM WN MT NT TWL XBL TH S OCC
+// The list (mbconv_cfgs.inc: 85 tile configurations, indices as documented there) is instantiated once per activation:
+// entry ci + k * kNBase is configuration ci with the k-th activation of kActs.
+constexpr int kActs[] = {ACT_GELU_ERF, ACT_SWISH, ACT_RELU6};
 const MbCfg kCfgs[] = {
-    MB_ENTRY(3, 2, 48, 1, 5, 1, 4, 1, 1, 2, 4, 0, 4, 1, 2),    // 0: 16 -> 96 -> 24, 48x256 -> 24x128
-    MB_ENTRY(3, 1, 48, 2, 3, 1, 4, 1, 2, 2, 4, 1, 8, 1, 2),    // 1: 24 -> 144 -> 24, 24x128
-    MB_ENTRY(5, 2, 48, 2, 7, 1, 4, 1, 1, 3, 4, 0, 4, 1, 1),    // 2: 24 -> 144 -> 40, 24x128 -> 12x64
-    MB_ENTRY(5, 1, 48, 3, 4, 1, 4, 1, 3, 3, 4, 2, 12, 1, 1),   // 3: 40 -> 240 -> 40, 12x64, full-height tiles
-    MB_ENTRY(3, 2, 48, 3, 7, 1, 2, 2, 3, 3, 4, 1, 6, 1, 1),    // 4: 40 -> 240 -> 80, 12x64 -> 6x32
-    MB_ENTRY(3, 1, 32, 5, 3, 1, 4, 1, 3, 5, 5, 1, 6, 1, 2),    // 5: 80 -> 480 -> 80, 6x32 whole image
-    MB_ENTRY(5, 1, 32, 5, 3, 1, 4, 1, 3, 7, 5, 1, 6, 1, 1),    // 6: 80 -> 480 -> 112, 6x32
-    MB_ENTRY(5, 1, 32, 7, 3, 1, 4, 1, 3, 7, 5, 1, 6, 1, 1),    // 7: 112 -> 672 -> 112, 6x32
-    MB_ENTRY(5, 2, 32, 7, 3, 1, 1, 4, 3, 3, 4, 1, 3, 1, 1),    // 8: 112 -> 672 -> 192, 6x32 -> 3x16
-    MB_ENTRY(5, 1, 32, 12, 3, 2, 2, 2, 3, 6, 4, 2, 3, 2, 1),   // 9: 192 -> 1152 -> 192, 3x16 x 2 segments
-    MB_ENTRY(3, 1, 32, 12, 3, 2, 2, 2, 3, 10, 4, 2, 3, 2, 1),  // 10: 192 -> 1152 -> 320, 3x16 x 2 segments
-    // 16-channel chunks: a quarter of the LDS, so 2-4 workgroups share a CU and overlap their phases
-    MB_ENTRY(3, 2, 16, 1, 5, 1, 4, 1, 1, 2, 4, 0, 4, 1, 4),    // 11: as 0
-    MB_ENTRY(3, 1, 16, 2, 3, 1, 4, 1, 2, 2, 4, 1, 8, 1, 3),    // 12: as 1
-    MB_ENTRY(5, 2, 16, 2, 7, 1, 4, 1, 1, 3, 4, 0, 4, 1, 2),    // 13: as 2
-    MB_ENTRY(5, 1, 16, 3, 4, 1, 4, 1, 3, 3, 4, 2, 12, 1, 2),   // 14: as 3
-    MB_ENTRY(3, 2, 16, 3, 7, 1, 2, 2, 3, 3, 4, 1, 6, 1, 2),    // 15: as 4
-    MB_ENTRY(3, 1, 16, 5, 3, 1, 4, 1, 3, 5, 5, 2, 6, 1, 2),    // 16: as 5
-    MB_ENTRY(5, 1, 16, 5, 3, 1, 4, 1, 3, 7, 5, 2, 6, 1, 2),    // 17: as 6
-    MB_ENTRY(5, 1, 16, 7, 3, 1, 4, 1, 3, 7, 5, 2, 6, 1, 2),    // 18: as 7
-    MB_ENTRY(5, 2, 16, 7, 3, 1, 1, 4, 3, 3, 4, 0, 3, 1, 2),    // 19: as 8
-    // stem conv (im2col gather from the planar spectrogram) -> depthwise 3x3 -> project: the first block
-    MB_ENTRY_S(3, 1, 16, 2, 3, 1, 4, 1, 2, 1, 4, 1, 8, 1, 3, 2),  // 20: 2-channel spectrogram, 3x3 stem (K = 18)
-    MB_ENTRY_S(3, 1, 16, 1, 3, 1, 4, 1, 2, 1, 4, 1, 8, 1, 3, 1),  // 21: 1-channel spectrogram (K = 9)
-    // f16 MFMA twins (even index: split hi/lo x3, odd: plain f16), 32-channel chunks
-    //         KS ST KG RT NCS WM WN MT NT TWL XBL TH S OCC STEM
-    MB_ENTRY_H(3, 2, 1, 5, 1, 4, 1, 1, 2, 4, 1, 4, 1, 2, 0),    // 22/23: Cin <= 32, 3x3 s2 (16 -> 96 -> 24)
-    MB_ENTRY_H(3, 1, 1, 3, 1, 4, 1, 2, 2, 4, 2, 8, 1, 2, 0),    // 24/25: Cin <= 32, 3x3 s1
-    MB_ENTRY_H(5, 2, 1, 7, 1, 4, 1, 1, 3, 4, 1, 4, 1, 2, 0),    // 26/27: Cin <= 32, 5x5 s2
-    MB_ENTRY_H(5, 1, 2, 4, 1, 4, 1, 3, 3, 4, 3, 12, 1, 1, 0),   // 28/29: Cin <= 64, 5x5 s1, 12x64
-    MB_ENTRY_H(3, 2, 2, 7, 1, 2, 2, 3, 3, 4, 0, 6, 1, 1, 0),    // 30/31: Cin <= 64, 3x3 s2
-    MB_ENTRY_H(3, 1, 3, 3, 1, 4, 1, 3, 5, 5, 3, 6, 1, 2, 0),    // 32/33: 80 -> 480 -> 80, 6x32
-    MB_ENTRY_H(5, 1, 3, 3, 1, 4, 1, 3, 7, 5, 3, 6, 1, 1, 0),    // 34/35: 80 -> 480 -> 112
-    MB_ENTRY_H(5, 1, 4, 3, 1, 4, 1, 3, 7, 5, 3, 6, 1, 1, 0),    // 36/37: 112 -> 672 -> 112
-    MB_ENTRY_H(5, 2, 4, 3, 1, 1, 4, 3, 3, 4, 1, 3, 1, 1, 0),    // 38/39: 112 -> 672 -> 192 stride 2
-    MB_ENTRY_H(5, 1, 6, 3, 2, 2, 2, 3, 6, 4, 2, 3, 2, 1, 0),    // 40/41: 192 -> 1152 -> 192, 3x16 x 2
-    MB_ENTRY_H(3, 1, 6, 3, 2, 2, 2, 3, 10, 4, 2, 3, 2, 1, 0),   // 42/43: 192 -> 1152 -> 320
-    MB_ENTRY_H(3, 1, 1, 3, 1, 4, 1, 2, 1, 4, 2, 8, 1, 2, 2),    // 44/45: stem (2-channel spectrogram) block
-    MB_ENTRY_H(3, 1, 1, 3, 1, 4, 1, 2, 1, 4, 2, 8, 1, 2, 1),    // 46/47: stem (1-channel spectrogram) block
-    // split-f16 with 16-channel chunks (k of the project GEMM zero-padded to 32): the large early images
-    //         KS ST CE KG RT NCS WM WN MT NT TWL XBL TH S OCC STEM PREC
-    MB_ENTRY_P(3, 2, 16, 1, 5, 1, 4, 1, 1, 2, 4, 0, 4, 1, 4, 0, 3),    // 48: as 11
-    MB_ENTRY_P(3, 1, 16, 1, 3, 1, 4, 1, 2, 2, 4, 1, 8, 1, 3, 0, 3),    // 49: as 12
-    MB_ENTRY_P(5, 2, 16, 1, 7, 1, 4, 1, 1, 3, 4, 0, 4, 1, 2, 0, 3),    // 50: as 13
-    MB_ENTRY_P(5, 1, 16, 2, 4, 1, 4, 1, 3, 3, 4, 2, 12, 1, 2, 0, 3),   // 51: as 14
-    MB_ENTRY_P(3, 2, 16, 2, 7, 1, 2, 2, 3, 3, 4, 1, 6, 1, 2, 0, 3),    // 52: as 15
-    MB_ENTRY_P(3, 1, 16, 1, 3, 1, 4, 1, 2, 1, 4, 1, 8, 1, 3, 2, 3),    // 53: as 20 (2-channel stem)
-    MB_ENTRY_P(3, 1, 16, 1, 3, 1, 4, 1, 2, 1, 4, 1, 8, 1, 3, 1, 3),    // 54: as 21 (1-channel stem)
-    MB_ENTRY_P(3, 1, 16, 3, 3, 1, 4, 1, 3, 5, 5, 2, 6, 1, 2, 0, 3),    // 55: as 16 (80 -> 480 -> 80, 6x32)
-    MB_ENTRY_P(5, 1, 16, 3, 3, 1, 4, 1, 3, 7, 5, 2, 6, 1, 2, 0, 3),    // 56: as 17
-    MB_ENTRY_P(5, 1, 16, 4, 3, 1, 4, 1, 3, 7, 5, 2, 6, 1, 2, 0, 3),    // 57: as 18 (112 -> 672 -> 112)
-    MB_ENTRY_P(5, 2, 16, 4, 3, 1, 1, 4, 3, 3, 4, 0, 3, 1, 2, 0, 3),    // 58: as 19
-    // half-image tiles (3x32 of a 6x32 image) for the 5x5 blocks: 1.67x the expand work (cheap on the f16
-    // MFMA) buys two or three workgroups per CU, whose phases then overlap
-    MB_ENTRY_P(5, 1, 16, 4, 3, 1, 2, 2, 3, 4, 5, 2, 3, 1, 2, 0, 3),    // 59: 112 -> 672 -> 112
-    MB_ENTRY_P(5, 1, 16, 3, 3, 1, 2, 2, 3, 4, 5, 2, 3, 1, 2, 0, 3),    // 60: 80 -> 480 -> 112
-    // 32-wide tiles for the large early images: half the workgroups, half the per-workgroup set-up
-    MB_ENTRY_P(3, 2, 16, 1, 10, 1, 4, 1, 2, 2, 5, 1, 4, 1, 2, 0, 3),   // 61: as 48, tile 4x32
-    MB_ENTRY_P(3, 1, 16, 1, 6, 1, 4, 1, 4, 2, 5, 2, 8, 1, 2, 0, 3),    // 62: as 49, tile 8x32
-    MB_ENTRY_S(3, 1, 16, 2, 6, 1, 4, 1, 4, 1, 5, 2, 8, 1, 2, 2),       // 63: as 20 (stem, f32), tile 8x32
-    // four workgroups per CU for the gather-latency-bound stem block
-    MB_ENTRY_S(3, 1, 16, 2, 3, 1, 4, 1, 2, 1, 4, 1, 8, 1, 4, 2),       // 64: as 20, 4 waves per SIMD
-    MB_ENTRY_P(3, 1, 16, 1, 3, 1, 4, 1, 2, 1, 4, 1, 8, 1, 4, 2, 3),    // 65: as 53, 4 waves per SIMD
-    MB_ENTRY_P(3, 1, 16, 1, 3, 1, 4, 1, 2, 1, 4, 1, 8, 1, 4, 1, 3),    // 66: as 54, 4 waves per SIMD
-    // 16-channel chunks for the 3x16 blocks: with the 16-deep project step the workgroup needs < 80 KB of LDS,
-    // so two share a CU
-    MB_ENTRY_P(5, 1, 16, 6, 2, 1, 2, 2, 3, 6, 4, 2, 3, 2, 2, 0, 3),    // 67: as 40 (192 -> 1152 -> 192, 3x16 x 2)
-    MB_ENTRY_P(3, 1, 16, 6, 2, 1, 2, 2, 3, 10, 4, 2, 3, 2, 2, 0, 3),   // 68: as 42 (192 -> 1152 -> 320)
-    MB_ENTRY_P(3, 2, 16, 1, 9, 1, 4, 1, 2, 2, 4, 1, 8, 1, 2, 0, 3),    // 69: as 48, tile 8x16 (17x33 source rows: 10 % halo; the one entry whose last expand group is a single row tile)
-    // whole-image tiles for the Perch-shaped stack (128 mel x 497 frames -> 8x32 and 4x16 images in the late stages)
-    //         KS ST CE KG RT NCS WM WN MT NT TWL XBL TH S OCC STEM PREC
-    MB_ENTRY_P(3, 1, 16, 3, 4, 1, 4, 1, 4, 5, 5, 2, 8, 1, 1, 0, 3),    // 70: 80 -> 480 -> 80, 8x32
-    //         KS ST KG RT NCS WM WN MT NT TWL XBL TH S OCC STEM
-    MB_ENTRY_H(5, 1, 3, 4, 1, 4, 1, 4, 7, 5, 3, 8, 1, 1, 0),           // 71/72: 80 -> 480 -> 112, 8x32
-    MB_ENTRY_H(5, 1, 4, 4, 1, 4, 1, 4, 7, 5, 3, 8, 1, 1, 0),           // 73/74: 112 -> 672 -> 112, 8x32
-    MB_ENTRY_H(5, 1, 6, 2, 2, 2, 2, 2, 6, 4, 2, 4, 1, 1, 0),           // 75/76: 192 -> 1152 -> 192, 4x16 (one segment: no spills)
-    MB_ENTRY_H(3, 1, 6, 2, 2, 2, 2, 2, 10, 4, 2, 4, 1, 1, 0),          // 77/78: 192 -> 1152 -> 320, 4x16
-    // persistent twins of the early-block entries (48, 49, 65, 66, 50, 51): indices 79..84
-    //          KS ST CE KG RT NCS WM WN MT NT TWL XBL TH S OCC STEM PREC
-    MB_ENTRY_PP(3, 2, 16, 1, 5, 1, 4, 1, 1, 2, 4, 0, 4, 1, 4, 0, 3),    // 79: as 48 (16 -> 96 -> 24, 48x256 -> 24x128)
-    MB_ENTRY_PP(3, 1, 16, 1, 3, 1, 4, 1, 2, 2, 4, 1, 8, 1, 3, 0, 3),    // 80: as 49 (24 -> 144 -> 24, 24x128)
-    MB_ENTRY_PP(3, 1, 16, 1, 3, 1, 4, 1, 2, 1, 4, 1, 8, 1, 4, 2, 3),    // 81: as 65 (stem block, 2-channel spectrogram)
-    MB_ENTRY_PP(3, 1, 16, 1, 3, 1, 4, 1, 2, 1, 4, 1, 8, 1, 4, 1, 3),    // 82: as 66 (stem block, 1-channel spectrogram)
-    MB_ENTRY_PP(5, 2, 16, 1, 7, 1, 4, 1, 1, 3, 4, 0, 4, 1, 2, 0, 3),    // 83: as 50 (24 -> 144 -> 40, 5x5 s2)
-    MB_ENTRY_PP(5, 1, 16, 2, 4, 1, 4, 1, 3, 3, 4, 2, 12, 1, 2, 0, 3),   // 84: as 51 (40 -> 240 -> 40, 5x5 s1)
+#define MB_A ACT_GELU_ERF
+#include "mbconv_cfgs.inc"
+#undef MB_A
+#define MB_A ACT_SWISH
+#include "mbconv_cfgs.inc"
+#undef MB_A
+#define MB_A ACT_RELU6
+#include "mbconv_cfgs.inc"
+#undef MB_A
 };
 constexpr int kNCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
+constexpr int kNActs = (int)(sizeof(kActs) / sizeof(kActs[0])), kNBase = kNCfgs / kNActs;
+static_assert(kNBase * kNActs == kNCfgs, "one copy of the list per activation");
 
 // fills the derived fields for entry `ci` with tile height `th`; returns the estimated MFMA work
 // per segment (in 16x16x4 steps), or -1 when the entry cannot run this block at that height
@@ -760,7 +667,7 @@ double mb_try_th(MbDesc &d, int ci, int th) {
     if (d.stem && d.stem_k != 3) return -1;
     if (c.PREC != d.prec) return -1;
     if ((d.Cin + (c.PREC ? 31 : 15)) / (c.PREC ? 32 : 16) != c.KG) return -1;
-    if (d.act_e != MB_ACT || d.act_d != MB_ACT || d.act_p != ACT_NONE) return -1;
+    if (d.act_e != c.ACT || d.act_d != c.ACT || d.act_p != ACT_NONE) return -1;
     const int nto = (d.Cout + 15) / 16;
     if (nto > c.WN * c.NT_W) return -1;
     const int TW = 1 << c.TWL;
@@ -800,6 +707,15 @@ double mb_try_th(MbDesc &d, int ci, int th) {
     return tiles * ((double)t.mpad_max / 16 * t.KG * 4 * (d.Cexp / 16) + (double)pout_pad / 16 * t.NTOP * (d.Cexp / 4));
 }
 
+// Index of configuration `base` (0 .. kNBase - 1: the documented indices) instantiated for this block's activation, -1 when the
+// block's expand / depthwise activation has no instantiation.
+int mb_act_index(const MbDesc &d, int base) {
+    if (base < 0 || base >= kNBase) return -1;
+    for (int k = 0; k < kNActs; k++)
+        if (kActs[k] == d.act_e) return base + k * kNBase;
+    return -1;
+}
+
 // the entry's own tile height if it fits this block's image, else the tallest one that does
 double mb_try(MbDesc &d, int ci) {
     for (int th = std::min(kCfgs[ci].TH, std::max(d.Ho, 1)); th >= 1; th--) {
@@ -818,25 +734,25 @@ int mb_config_count() { return kNCfgs; }
 int mb_config_name(int ci, char *out, size_t cap) {
     if (ci < 0 || ci >= kNCfgs) return 0;
     const MbCfg &c = kCfgs[ci];
-    // all 17 template arguments, as a profiler prints them (the last one marks a persistent instantiation)
-    return snprintf(out, cap, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", c.KS, c.ST, c.CE, c.KG, c.RT_W, c.NCS, c.WM,
-                    c.WN, c.MT_W, c.NT_W, c.TWL, c.XBL, c.S, c.OCC, c.STEM, c.PREC, c.PERSIST);
+    // all 18 template arguments, as a profiler prints them (the last two: persistent instantiation, activation)
+    return snprintf(out, cap, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", c.KS, c.ST, c.CE, c.KG, c.RT_W, c.NCS, c.WM,
+                    c.WN, c.MT_W, c.NT_W, c.TWL, c.XBL, c.S, c.OCC, c.STEM, c.PREC, c.PERSIST, c.ACT);
 }
 
 bool mb_plan(MbDesc &d, int force_cfg) {
     d.cfg = -1;
-    if (force_cfg >= 0) {
-        if (force_cfg >= kNCfgs) return false;
+    if (force_cfg >= 0) {   // (a base index: the block's own activation selects the copy)
+        const int ci = mb_act_index(d, force_cfg);
         MbDesc t = d;
-        if (mb_try(t, force_cfg) < 0) return false;
+        if (ci < 0 || mb_try(t, ci) < 0) return false;
         d = t;
         return true;
     }
     if (const char *pref = getenv("BIRDA_HIP_MB_PREFER")) {  // tuning aid: first valid entry of a comma list
         for (const char *q = pref; *q;) {
-            const int ci = atoi(q);
+            const int ci = mb_act_index(d, atoi(q));
             MbDesc t = d;
-            if (ci >= 0 && ci < kNCfgs && mb_try(t, ci) >= 0) { d = t; return true; }
+            if (ci >= 0 && mb_try(t, ci) >= 0) { d = t; return true; }
             while (*q && *q != ',') q++;
             if (*q == ',') q++;
         }
@@ -856,18 +772,19 @@ bool mb_plan(MbDesc &d, int force_cfg) {
     const char *pe = getenv("BIRDA_HIP_MB_PERSIST");
     const int persist_mode = !pe ? 0 : pe[0] == '1' ? 2 : pe[0] == '2' ? 1 : 0;
     if (d.prec == 0)
-        for (int ci : kPreferred) {  // at the entry's own tile height: the shapes it was measured on
+        for (int base : kPreferred) {  // at the entry's own tile height: the shapes it was measured on
+            const int ci = mb_act_index(d, base);
             MbDesc t = d;
-            if (mb_try_th(t, ci, kCfgs[ci].TH) >= 0) { d = t; return true; }
+            if (ci >= 0 && mb_try_th(t, ci, kCfgs[ci].TH) >= 0) { d = t; return true; }
         }
     if (d.prec == 3) {
         const int *list = persist_mode == 2 ? kPreferred16a : persist_mode == 1 ? kPreferred16p : kPreferred16n;
         const int nlist = persist_mode == 2 ? (int)(sizeof kPreferred16a / sizeof(int))
                         : persist_mode == 1 ? (int)(sizeof kPreferred16p / sizeof(int)) : (int)(sizeof kPreferred16n / sizeof(int));
         for (int q = 0; q < nlist; q++) {
-            const int ci = list[q];
+            const int ci = mb_act_index(d, list[q]);
             MbDesc t = d;
-            if (mb_try_th(t, ci, kCfgs[ci].TH) >= 0) { d = t; return true; }
+            if (ci >= 0 && mb_try_th(t, ci, kCfgs[ci].TH) >= 0) { d = t; return true; }
         }
     }
     double best = -1;

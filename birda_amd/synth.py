@@ -131,16 +131,18 @@ _TINY_STAGES = [(1, 3, 1, 8, 1), (4, 5, 2, 16, 2), (4, 3, 2, 24, 1)]
 
 
 def build_model(kind: str = "birdnet_v24", seed: int = WEIGHT_SEED,
-                n_classes: Optional[int] = None) -> mf.Model:
+                n_classes: Optional[int] = None, act: Optional[int] = None) -> mf.Model:
     """kind: 'birdnet_v24' (full shape), 'birdnet_v24_tiny' (same front-end, toy stack),
     'mini' (short segments + toy stack, for second-scale CPU tests),
     'mini_b0' (short segments + the full EfficientNet-B0 channel plan),
     'mini_hg' (toy stack ending in 32 channels + a 128-wide head: fused head conv + pool on a small arena),
     'mini_se' (toy stack with swish activations and a squeeze-excite gate in every block: the EfficientNet original),
-    'perch_v2' (5 s / 32 kHz, Perch-shaped: one 128-mel branch, 14 795 classes)."""
+    'perch_v2' (5 s / 32 kHz, Perch-shaped: one 128-mel branch, 14 795 classes).
+    act: the activation between the convolutions (default: exact GELU, the north star's; mf.ACT_SWISH / ACT_RELU6 give the
+    EfficientNet / MobileNet spellings of the same stack)."""
     rng = np.random.default_rng(seed)
     b = _Builder(rng)
-    act = mf.ACT_GELU_ERF
+    act_override, act = act, mf.ACT_GELU_ERF
     if kind in ("birdnet_v24", "birdnet_v24_tiny"):
         sr, n, dur = 48000, 144000, 3.0
         branches = [mf.Branch(2048, 278, 96, 511, 0.0, 3000.0, 1.23),
@@ -175,6 +177,8 @@ def build_model(kind: str = "birdnet_v24", seed: int = WEIGHT_SEED,
     se = kind == "mini_se"
     if se:
         act = mf.ACT_SWISH      # the EfficientNet original: swish activations, squeeze-excite in every block
+    if act_override is not None:
+        act = act_override
     h, w_, c = branches[0].n_mels, branches[0].n_frames, len(branches)
     t, h, w_ = b.conv(0, h, w_, c, stem, 3, 2, act, in_layout=1)
     c = stem

@@ -471,6 +471,35 @@ def test_precision_modes_on_the_full_model(full_model, oracle_lib):
     assert (out["f16"].argmax(1) == ref.argmax(1)).all() and (out["f16x3"].argmax(1) == ref.argmax(1)).all()
 
 
+@pytest.mark.parametrize("act_name", ["swish", "relu6"])
+def test_fused_path_with_other_activations(oracle_lib, tmp_path, act_name):
+    """EfficientNet's swish and MobileNet's ReLU6 between the convolutions take the SAME fused kernels as GELU (the activation
+    is a template argument of mbconv_kernel / head_gap16 / pw_gemm16): every inverted-residual block of the B0 channel plan runs
+    fused, in all three precisions, within the same tolerances against the oracle."""
+    from birda_amd import modelfile as mf, synth
+    from birda_amd.classifier import BirdClassifier
+    act = {"swish": mf.ACT_SWISH, "relu6": mf.ACT_RELU6}[act_name]
+    m = synth.build_model("mini_b0", act=act)
+    path = str(tmp_path / f"mini_b0_{act_name}.bhm")
+    mf.write_model(path, m)
+    segs = synth.synth_segments(3, m.sample_count, m.sample_rate, start=11)
+    ref = oracle_lib.OracleModel(path).forward(segs)
+    scale = max(1.0, float(np.abs(ref).max()))
+    n_blocks = sum(1 for L in m.layers if L.op == mf.OP_DWCONV)
+    for prec in ("f32", "f16x3", "f16"):
+        clf = BirdClassifier(path, precision=prec)
+        blocks = clf.fused_blocks()
+        assert len(blocks) == n_blocks, (prec, blocks)
+        assert all(f",{act}>" in clf.fused_kernel_name(b) for b in blocks)      # the activation is the last template argument
+        ctx = clf.create_batch_context(3)
+        got = clf.predict_logits(ctx, segs)
+        if prec == "f16":
+            assert np.isfinite(got).all() and np.abs(got - ref).max() <= F16_LOGIT_RTOL * scale
+        else:
+            _logit_close(got, ref)
+        ctx.close(); clf.close()
+
+
 def test_wave_private_early_blocks_match_oracle(full_model, oracle_lib, monkeypatch):
     """The opt-in wave-private instantiations (kernels_mbwave.hip, BIRDA_HIP_MB_WAVE=1: one output tile per wave, no
     workgroup barrier in the chunk loop) take the early blocks of the full model and hold the same tolerances."""
