@@ -676,7 +676,17 @@ int plan_fusion(bh_classifier *c) {
         const bool p16 = h16 && CE == 16;   // project GEMM as one 16-deep step: [column tile]{hi, lo}[64 lanes][4 halves]
         const size_t we_fl = (size_t)KG * NTE * frag + CE, wp_fl = p16 ? (size_t)NTOP * 256 : psteps * NTOP * frag, wd_fl = (size_t)KK * CE + CE;
         std::vector<float> wef(nch * we_fl, 0.0f), wpf(nch * wp_fl, 0.0f), wdf(nch * wd_fl, 0.0f);
-        auto we_at = [&](int k, int n) { return (k < d.Cin && n < d.Cexp) ? std::ldexp(We[(size_t)k * d.Cexp + n], se) : 0.0f; };
+        // (stem block in the f16 modes: the kernel gathers its im2col columns by memory runs, kernels_mbconv.hip -- position
+        //  8 kq + 3 q + dx of the one 32-deep step is tap (dy, dx) of channel ch with run 2 kq + q = 3 ch + dy)
+        auto we_at = [&](int k, int n) {
+            if (d.stem && h16) {
+                const int kq = k >> 3, jj = k & 7, r = 2 * kq + jj / 3, dx = jj % 3;
+                if (k >= 32 || jj >= 6 || r >= 3 * d.stem_c) return 0.0f;
+                const int ch = r / 3, dy = r - 3 * ch;
+                k = (dy * 3 + dx) * d.stem_c + ch;
+            }
+            return (k < d.Cin && n < d.Cexp) ? std::ldexp(We[(size_t)k * d.Cexp + n], se) : 0.0f;
+        };
         auto wp_at = [&](int k, int n) { return (k < d.Cexp && n < d.Cout) ? std::ldexp(Wp[(size_t)k * d.Cout + n], sp) : 0.0f; };
         // f16: element jj of lane's 8-half fragment = k = 32 g + 8 (lane >> 4) + jj; hi plane then lo plane
         auto put16 = [&](std::vector<float> &dst, size_t base_fl, int plane, int lane, int jj, float v) {

@@ -219,9 +219,32 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
         for (int g = 0; g < KG; g++) {
             float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             const int k0 = (PREC ? 32 * g + 8 * kq : 16 * g + 4 * kq);
-            if constexpr (STEM != 0) {
-                // im2col gather of the 3x3 stem conv (stride s, planar input): column
-                // k = (dy * 3 + dx) * C + ch, exactly the row order of the [kh][kw][cin][cout] weights
+            if constexpr (STEM != 0 && PREC != 0) {
+                // im2col gather of the 3x3 stem conv (stride s, planar input), f16 modes: ONE 32-deep step whose columns are
+                // ordered by memory runs -- lane group kq holds runs 2 kq and 2 kq + 1, a run being the three horizontally
+                // adjacent taps (dx = 0, 1, 2) of one (channel, dy); elements 6, 7 of the group are zero (api.hip plan_fusion
+                // packs the weight rows to match).  Two 12-byte loads per lane and row tile instead of eight scalar ones with
+                // a division chain per element: the gather was the stem block's largest single cost (tools/abl.sh).
+                static_assert(STEM == 0 || PREC == 0 || (STEM <= 2 && KG == 1), "3 STEM runs fit the 8 run slots of one step");
+                const int sy = (xo >> 16) * d.stem_s - d.stem_pt, sx = (xo & 0xffff) * d.stem_s - d.stem_pl;
+                const int bx = min(max(sx, 0), d.stem_w - 3), sh = sx - bx;   // the 3-float window, kept inside the row
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int r = 2 * kq + q, ch = r >= 3 ? 1 : 0, dy = r - 3 * ch, y = sy + dy;
+                    const bool okr = rv && r < 3 * STEM && y >= 0 && y < d.stem_h;
+                    struct __attribute__((packed, aligned(4))) F3 { float a, b, c; };
+                    F3 t = {0.f, 0.f, 0.f};
+                    if (okr) t = *reinterpret_cast<const F3 *>(Xb + ((size_t)ch * d.stem_h + y) * d.stem_w + bx);
+                    // element dx is column sx + dx = bx + sh + dx; sh is -1 / 0 / +1 at the left edge / inside / at the right edge
+                    const float e0 = sh == 0 ? t.a : sh > 0 ? t.b : 0.0f;
+                    const float e1 = sh == 0 ? t.b : sh > 0 ? t.c : t.a;
+                    const float e2 = sh == 0 ? t.c : sh > 0 ? 0.0f : t.b;
+                    v[3 * q] = (okr && sx >= 0) ? e0 : 0.0f;
+                    v[3 * q + 1] = (okr && sx + 1 >= 0 && sx + 1 < d.stem_w) ? e1 : 0.0f;
+                    v[3 * q + 2] = (okr && sx + 2 < d.stem_w) ? e2 : 0.0f;
+                }
+            } else if constexpr (STEM != 0) {
+                // f32 mode: column k = (dy * 3 + dx) * C + ch, exactly the row order of the [kh][kw][cin][cout] weights
                 const int sy = (xo >> 16) * d.stem_s - d.stem_pt, sx = (xo & 0xffff) * d.stem_s - d.stem_pl;
 #pragma unroll
                 for (int c = 0; c < NV; c++) {
