@@ -198,75 +198,128 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
     // channels of ONE source row, li of its row tile, and writes them with one ds_write_b128 at
     // eoff[i] = that row's slot in the LDS grid (padding rows: the trash slot)
     int eoff[RT_W];
+    // Two passes over the wave's row tiles: every load of a batch of row tiles is issued UNCONDITIONALLY from a clamped address
+    // (rows past the tile, columns past Cin and out-of-image taps read a valid address and are replaced by zero afterwards), and
+    // only then are the values split / stored.  With the loads inside `if (valid)` hipcc waited for each row tile's loads before
+    // computing the next one's addresses: RT_W dependent HBM round trips at the start of every workgroup.
+    constexpr int NV = PREC ? 8 : 4;            // consecutive k per lane and step
+    constexpr int NQ = STEM ? 2 : NV / 4;       // 16-byte (stem, f16 modes: 12-byte) loads per (row tile, step)
+    constexpr int XBATCH = (STEM && !PREC) ? 1 : (RT_W * KG * NQ <= 16 ? RT_W : (16 / (KG * NQ) >= 1 ? 16 / (KG * NQ) : 1));
+    struct __attribute__((packed, aligned(4))) F3 { float a, b, c; };
 #pragma unroll
-    for (int i = 0; i < RT_W; i++) {
-        const int rt = rw + RSTEP * i;
-        const bool rv = rt < nrt && !(d.dbg & 64);
-        int xo = 0;   // row offset computed in registers: the loads go out before the table barrier
-        eoff[i] = egrid * CES + 4 * kq;
-        {
+    for (int i0 = 0; i0 < RT_W; i0 += XBATCH) {
+        int xo[XBATCH];
+        bool rvv[XBATCH];
+#pragma unroll
+        for (int ii = 0; ii < XBATCH; ii++) {
+            const int i = i0 + ii;
+            if (i >= RT_W) continue;
+            const int rt = rw + RSTEP * i;
+            rvv[ii] = false;
+            xo[ii] = 0;   // row offset computed in registers: the loads go out before the table barrier
+            eoff[i] = egrid * CES + 4 * kq;
             const int m = rt * 16 + li;
             if (rt < nrt && m < M) {
                 const int sl = SS > 1 ? (m >= Mseg ? 1 : 0) : 0, mm = m - sl * Mseg;
                 const int r = mb_div(mm, vw, rcp_vw), c = mm - __mul24(r, vw);
                 eoff[i] = __mul24(sl * IH * IW + __mul24(ya + r, IW) + xa + c, CES) + 4 * kq;
-                xo = STEM ? (((iy0 + ya + r) << 16) | (ix0 + xa + c))   // stem-output pixel (y, x), gathered below
-                          : __mul24(__mul24(sl * d.H + iy0 + ya + r, d.W) + ix0 + xa + c, Cin);
+                xo[ii] = STEM ? (((iy0 + ya + r) << 16) | (ix0 + xa + c))   // stem-output pixel (y, x), gathered below
+                              : __mul24(__mul24(sl * d.H + iy0 + ya + r, d.W) + ix0 + xa + c, Cin);
+                rvv[ii] = !(d.dbg & 64);
             }
         }
-        constexpr int NV = PREC ? 8 : 4;   // consecutive k per lane and step
+        if constexpr (STEM != 0 && PREC == 0) {
+            // f32 mode: im2col column k = (dy * 3 + dx) * C + ch, exactly the row order of the [kh][kw][cin][cout] weights
+            const int i = i0;
+            const int sy = (xo[0] >> 16) * d.stem_s - d.stem_pt, sx = (xo[0] & 0xffff) * d.stem_s - d.stem_pl;
 #pragma unroll
-        for (int g = 0; g < KG; g++) {
-            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            const int k0 = (PREC ? 32 * g + 8 * kq : 16 * g + 4 * kq);
-            if constexpr (STEM != 0 && PREC != 0) {
-                // im2col gather of the 3x3 stem conv (stride s, planar input), f16 modes: ONE 32-deep step whose columns are
-                // ordered by memory runs -- lane group kq holds runs 2 kq and 2 kq + 1, a run being the three horizontally
-                // adjacent taps (dx = 0, 1, 2) of one (channel, dy); elements 6, 7 of the group are zero (api.hip plan_fusion
-                // packs the weight rows to match).  Two 12-byte loads per lane and row tile instead of eight scalar ones with
-                // a division chain per element: the gather was the stem block's largest single cost (tools/abl.sh).
-                static_assert(STEM == 0 || PREC == 0 || (STEM <= 2 && KG == 1), "3 STEM runs fit the 8 run slots of one step");
-                const int sy = (xo >> 16) * d.stem_s - d.stem_pt, sx = (xo & 0xffff) * d.stem_s - d.stem_pl;
-                const int bx = min(max(sx, 0), d.stem_w - 3), sh = sx - bx;   // the 3-float window, kept inside the row
+            for (int g = 0; g < KG; g++) {
+                float v[4];
 #pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const int r = 2 * kq + q, ch = r >= 3 ? 1 : 0, dy = r - 3 * ch, y = sy + dy;
-                    const bool okr = rv && r < 3 * STEM && y >= 0 && y < d.stem_h;
-                    struct __attribute__((packed, aligned(4))) F3 { float a, b, c; };
-                    F3 t = {0.f, 0.f, 0.f};
-                    if (okr) t = *reinterpret_cast<const F3 *>(Xb + ((size_t)ch * d.stem_h + y) * d.stem_w + bx);
-                    // element dx is column sx + dx = bx + sh + dx; sh is -1 / 0 / +1 at the left edge / inside / at the right edge
-                    const float e0 = sh == 0 ? t.a : sh > 0 ? t.b : 0.0f;
-                    const float e1 = sh == 0 ? t.b : sh > 0 ? t.c : t.a;
-                    const float e2 = sh == 0 ? t.c : sh > 0 ? 0.0f : t.b;
-                    v[3 * q] = (okr && sx >= 0) ? e0 : 0.0f;
-                    v[3 * q + 1] = (okr && sx + 1 >= 0 && sx + 1 < d.stem_w) ? e1 : 0.0f;
-                    v[3 * q + 2] = (okr && sx + 2 < d.stem_w) ? e2 : 0.0f;
-                }
-            } else if constexpr (STEM != 0) {
-                // f32 mode: column k = (dy * 3 + dx) * C + ch, exactly the row order of the [kh][kw][cin][cout] weights
-                const int sy = (xo >> 16) * d.stem_s - d.stem_pt, sx = (xo & 0xffff) * d.stem_s - d.stem_pl;
-#pragma unroll
-                for (int c = 0; c < NV; c++) {
-                    const int k = k0 + c;
+                for (int c = 0; c < 4; c++) {
+                    const int k = 16 * g + 4 * kq + c;
                     const int tap = k / (STEM ? STEM : 1), ch = k - tap * STEM;   // STEM = spectrogram channels
                     const int dy = tap / 3, dx = tap - dy * 3;
                     const int y = sy + dy, x = sx + dx;
-                    const bool ok = rv && k < Cin && y >= 0 && y < d.stem_h && x >= 0 && x < d.stem_w;
+                    const bool ok = rvv[0] && k < Cin && y >= 0 && y < d.stem_h && x >= 0 && x < d.stem_w;
                     v[c] = ok ? Xb[((size_t)ch * d.stem_h + y) * d.stem_w + x] : 0.0f;
                 }
-            } else {
+                afr[i][g] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        } else if constexpr (STEM != 0) {
+            // im2col gather of the 3x3 stem conv (stride s, planar input), f16 modes: ONE 32-deep step whose columns are ordered
+            // by memory runs -- lane group kq holds runs 2 kq and 2 kq + 1, a run being the three horizontally adjacent taps
+            // (dx = 0, 1, 2) of one (channel, dy); elements 6, 7 of the group are zero (api.hip plan_fusion packs the weight rows
+            // to match).  Two 12-byte loads per lane and row tile instead of eight scalar ones with a division chain per
+            // element: the gather was the stem block's largest single cost (tools/abl.sh).
+            static_assert(STEM == 0 || PREC == 0 || (STEM <= 2 && KG == 1), "3 STEM runs fit the 8 run slots of one step");
+            F3 t[XBATCH][2];
+            bool okr[XBATCH][2];
 #pragma unroll
-                for (int q = 0; q < NV / 4; q++) {
-                    const float4 t = (rv && k0 + 4 * q < Cin) ? *reinterpret_cast<const float4 *>(Xb + xo + k0 + 4 * q)
-                                                             : make_float4(0.f, 0.f, 0.f, 0.f);
-                    v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+            for (int ii = 0; ii < XBATCH; ii++) {
+                if (i0 + ii >= RT_W) continue;
+                const int sy = (xo[ii] >> 16) * d.stem_s - d.stem_pt, sx = (xo[ii] & 0xffff) * d.stem_s - d.stem_pl;
+                const int bx = min(max(sx, 0), d.stem_w - 3);   // the 3-float window, kept inside the row
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    const int r = 2 * kq + q, ch = r >= 3 ? 1 : 0, dy = r - 3 * ch, y = sy + dy;
+                    okr[ii][q] = rvv[ii] && r < 3 * STEM && y >= 0 && y < d.stem_h;
+                    const int yc = okr[ii][q] ? y : 0, chc = okr[ii][q] ? ch : 0;
+                    t[ii][q] = *reinterpret_cast<const F3 *>(Xb + ((size_t)chc * d.stem_h + yc) * d.stem_w + bx);
                 }
             }
-            if constexpr (PREC != 0) {
-                bh_split8(v, ah[i][g], al[i][g]);
-            } else {
-                afr[i][g] = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+            for (int ii = 0; ii < XBATCH; ii++) {
+                const int i = i0 + ii;
+                if (i >= RT_W) continue;
+                const int sx = (xo[ii] & 0xffff) * d.stem_s - d.stem_pl;
+                const int sh = sx - min(max(sx, 0), d.stem_w - 3);
+                float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < 2; q++) {
+                    // element dx is column sx + dx = bx + sh + dx; sh is -1 / 0 / +1 at the left edge / inside / at the right edge
+                    const F3 tt = t[ii][q];
+                    const float e0 = sh == 0 ? tt.a : sh > 0 ? tt.b : 0.0f;
+                    const float e1 = sh == 0 ? tt.b : sh > 0 ? tt.c : tt.a;
+                    const float e2 = sh == 0 ? tt.c : sh > 0 ? 0.0f : tt.b;
+                    v[3 * q] = (okr[ii][q] && sx >= 0) ? e0 : 0.0f;
+                    v[3 * q + 1] = (okr[ii][q] && sx + 1 >= 0 && sx + 1 < d.stem_w) ? e1 : 0.0f;
+                    v[3 * q + 2] = (okr[ii][q] && sx + 2 < d.stem_w) ? e2 : 0.0f;
+                }
+                bh_split8(v, ah[i][0], al[i][0]);
+            }
+        } else {
+            float4 raw[XBATCH][KG][NQ];
+#pragma unroll
+            for (int ii = 0; ii < XBATCH; ii++) {
+                if (i0 + ii >= RT_W) continue;
+#pragma unroll
+                for (int g = 0; g < KG; g++)
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) {
+                        const int kk = (PREC ? 32 * g + 8 * kq : 16 * g + 4 * kq) + 4 * q;
+                        const bool ok = rvv[ii] && kk < Cin;
+                        raw[ii][g][q] = *reinterpret_cast<const float4 *>(Xb + (ok ? xo[ii] + kk : 0));
+                    }
+            }
+#pragma unroll
+            for (int ii = 0; ii < XBATCH; ii++) {
+                const int i = i0 + ii;
+                if (i >= RT_W) continue;
+#pragma unroll
+                for (int g = 0; g < KG; g++) {
+                    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < NQ; q++) {
+                        const int kk = (PREC ? 32 * g + 8 * kq : 16 * g + 4 * kq) + 4 * q;
+                        const bool ok = rvv[ii] && kk < Cin;
+                        const float4 t = raw[ii][g][q];
+                        v[4 * q] = ok ? t.x : 0.0f; v[4 * q + 1] = ok ? t.y : 0.0f;
+                        v[4 * q + 2] = ok ? t.z : 0.0f; v[4 * q + 3] = ok ? t.w : 0.0f;
+                    }
+                    if constexpr (PREC != 0) bh_split8(v, ah[i][g], al[i][g]);
+                    else afr[i][g] = make_float4(v[0], v[1], v[2], v[3]);
+                }
             }
         }
     }
@@ -296,13 +349,29 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
     for (int i = 0; i < MT_W; i++) {
         const int4 o4 = *reinterpret_cast<const int4 *>(&omap[(wm * MT_W + i) * 16 + 4 * kq]);
         const int orow[4] = {o4.x, o4.y, o4.z, o4.w};
+        // (unconditional loads from clamped addresses, selected afterwards: inside `cond ? load : 0` every load waited for the
+        //  one before it)
 #pragma unroll
         for (int j = 0; j < NT_W; j++) {
-            const int col = (wn * NT_W + j) * 16 + li;
-            const float bias = col < Cout ? d.bp[col] : 0.0f;
+            const int col = (wn * NT_W + j) * 16 + li, colc = min(col, Cout - 1);
+            if constexpr (MT_W * NT_W <= 8) {   // (the small-tile instantiations of the early blocks; with 30 accumulator tiles
+                                                //  that many loads in flight cost registers the late blocks do not have)
+                const float braw = d.bp[colc];
+                float rres[4] = {0.f, 0.f, 0.f, 0.f};
+                if (Rb) {   // (wave-uniform)
 #pragma unroll
-            for (int r = 0; r < 4; r++)
-                acco[i][j][r] = __builtin_fmaf((Rb && col < Cout && orow[r] >= 0) ? Rb[(size_t)orow[r] * Cout + col] : 0.0f, p_scale, bias);
+                    for (int r = 0; r < 4; r++) rres[r] = Rb[(size_t)max(orow[r], 0) * Cout + colc];
+                }
+                const float bias = col < Cout ? braw : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    acco[i][j][r] = __builtin_fmaf((col < Cout && orow[r] >= 0) ? rres[r] : 0.0f, p_scale, bias);
+            } else {
+                const float bias = col < Cout ? d.bp[col] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    acco[i][j][r] = __builtin_fmaf((Rb && col < Cout && orow[r] >= 0) ? Rb[(size_t)orow[r] * Cout + col] : 0.0f, p_scale, bias);
+            }
         }
     }
 
