@@ -213,6 +213,24 @@ def analyse(clf, m, info, fused, stage_tot, layer_tot, segs_done, steps, slices_
             "rocprof_name": ("bh::mbw_kernel<" + dom["kernel"][len("mbw<"):]) if dom["kernel"].startswith("mbw<") else ("bh::mbconv_kernel<" + dom["kernel"][len("mbconv<"):]),
             "launches": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2),
             "algorithmic_gflop_per_launch": round(total_flops / max(dom["launches"], 1) / 1e9, 3)}
+        # What actually bounds this kernel in the f16 modes: issuing its activation.  Algorithmic count: one
+        # activation per expanded value and one per depthwise output (no tile halo); price: 102 cycles per PAIR of exact GELUs on
+        # one SIMD (tools/microbench/pk_fma_rate.hip on this chip), 1 024 SIMDs at the 2.4 GHz peak clock.
+        if dom_prec != 0:
+            if dom["stem"]:
+                E, D = layers[0], layers[1]
+            else:
+                i_dom = next(i for i in range(len(layers) - 2) if layers[i].op == mf.OP_PWCONV and layers[i + 1].op == mf.OP_DWCONV and
+                             (layers[i].cin, layers[i].cout, layers[i + 2].cout, layers[i + 1].kh, layers[i + 1].sh, layers[i].in_h, layers[i].in_w) == dom_key)
+                E, D = layers[i_dom], layers[i_dom + 1]
+            acts = (E.out_h * E.out_w * E.cout + D.out_h * D.out_w * D.cout) * (segs_done / (steps * slices_per_step))   # per launch
+            floor_us = acts / 2 / 64 * 102.0 / (256 * 4) / 2.4e9 * 1e6
+            avg_us = dom["ms"] * 1e3 / max(dom["launches"], 1)
+            out["roofline"]["vector_issue"] = {
+                "activations_per_launch": int(acts), "cycles_per_pair": 102, "simds": 1024, "clock_ghz": 2.4,
+                "floor_us": round(floor_us, 1), "frac": round(floor_us / avg_us, 4),
+                "note": "exact GELU through 2 v_med3 + 11 v_pk_fma + 2 v_exp per pair (measured issue cost); halo, depthwise taps, "
+                        "f16 splits and index arithmetic come on top"}
         if mb_ms > 0:
             flops = 2.0 * sum(g["macs"] * max(1, g["launches"] // (steps * slices_per_step)) for g in groups.values()) * segs_done
             out["all_fused_blocks"] = {"achieved": round(flops / (mb_ms * 1e-3) / 1e12, 2), "unit": "TFLOP/s (algorithmic)",
