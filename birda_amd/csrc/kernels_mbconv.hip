@@ -73,11 +73,11 @@ struct MbClock {
 //     after B1(ch): We+be of chunk ch+1, Wp of chunk ch      (waited before B2(ch))
 //     after B2(ch): Wd+bd of chunk ch+1                      (waited before B1(ch+1))
 // so the MFMA loops read every operand from registers or LDS and never wait on memory.
-template <int NFLOATS, int NDEAL = 4>
+template <int NFLOATS>
 __device__ __forceinline__ void mb_dma(const float *gsrc, float *lds_dst, int wave, int lane) {
-    constexpr int NP = (NFLOATS + 255) / 256;  // 1-KiB pieces, dealt round-robin to the 4 waves (NDEAL = 1: all to the caller, wave = 0)
+    constexpr int NP = (NFLOATS + 255) / 256;  // 1-KiB pieces, dealt round-robin to the 4 waves
 #pragma unroll
-    for (int p0 = 0; p0 < NP; p0 += NDEAL) {
+    for (int p0 = 0; p0 < NP; p0 += 4) {
         const int p = p0 + wave;
         const int off = p * 256 + lane * 4;
         if (p < NP && off < NFLOATS) {
@@ -493,21 +493,8 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
         if (!ring && !PERSIST) mb_dma_wait();
         __syncthreads();  // B1: Es complete; (ring == 0) WeS / WpS free; Wds (DMA issued after the last B2) landed
         if (!ring && !PERSIST && !(d.dbg & 16)) {
-            // The 1-KiB pieces go through the CU's vector-memory path at ~64 B/clk and block the issuing wave meanwhile
-            // (tools/microbench/lds_fill.hip).  Every late-block instantiation has 192 depthwise tasks: wave 3 sits out P2, so
-            // it issues this whole transfer and the three waves on the critical path issue none of it.
-            if (p2_ntask <= 192 && !(d.dbg & 512)) {
-                if (wave == 3) {
-                    int first = 0;
-                    asm volatile("" : "+s"(first));   // opaque: with a literal 0 hipcc folds the LDS address into a constant
-                                                      // expression and its backend rejects the result ("Illegal instruction")
-                    mb_dma<WE_FLOATS, 1>(d.We + (size_t)chn * WE_FLOATS, WeS, first, lane);
-                    mb_dma<WP_FLOATS, 1>(d.Wp + (size_t)ch * WP_FLOATS, WpS, first, lane);
-                }
-            } else {
-                mb_dma<WE_FLOATS>(d.We + (size_t)chn * WE_FLOATS, WeS, wave, lane);
-                mb_dma<WP_FLOATS>(d.Wp + (size_t)ch * WP_FLOATS, WpS, wave, lane);
-            }
+            mb_dma<WE_FLOATS>(d.We + (size_t)chn * WE_FLOATS, WeS, wave, lane);
+            mb_dma<WP_FLOATS>(d.Wp + (size_t)ch * WP_FLOATS, WpS, wave, lane);
         }
         mb_stamp(d.stamps, t_last, 3);
 
