@@ -179,6 +179,7 @@ HOST_SYMBOLS = [
     ("bhh_writer_write_detection", C.c_int, [_VP, C.c_char_p, C.c_float, C.c_float, C.c_float, C.c_char_p]),
     ("bhh_writer_finalize", C.c_int, [_VP]),
     ("bhh_output_path_for", _SZ, [C.c_char_p, C.c_char_p, C.c_uint32, C.c_char_p, _SZ]),
+    ("bhh_should_process", C.c_int, [C.c_char_p, C.c_char_p, C.c_uint32, C.c_int]),
     ("bhh_species_code", _SZ, [C.c_char_p, C.c_char_p, _SZ]),
     ("bhh_format_float", _SZ, [C.c_int, C.c_double, C.c_char_p, _SZ]),
     ("bhh_reporter_open", C.c_int, [C.c_int, C.c_char_p, C.POINTER(_VP)]),

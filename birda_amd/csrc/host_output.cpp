@@ -13,6 +13,7 @@
 // expansions rounded half-to-even (glibc printf on the widened value does the same), `{}` on a float is the shortest
 // digit string that round-trips, without an exponent (core::fmt::float), and serde_json prints floats through ryu's
 // "pretty" layout.  Host logic only: nothing here touches a logit.
+#include <sys/stat.h>
 #include <algorithm>
 #include <charconv>
 #include <chrono>
@@ -540,6 +541,17 @@ size_t bhh_output_path_for(const char *input_path, const char *output_dir, uint3
     if (!input_path) return 0;
     return copy_out(output_path_for(input_path, output_dir ? output_dir : "", format), out, cap);
 } catch (...) { return (o_on_exception(), (size_t)0); }
+
+int bhh_should_process(const char *input_path, const char *output_dir, uint32_t format_mask, int force) try {
+    if (!input_path || force || (format_mask & BHH_FORMAT_ALL) == 0) return 1;
+    for (uint32_t f = 1; f <= BHH_FORMAT_PARQUET; f <<= 1) {
+        if (!(format_mask & f)) continue;
+        const std::string p = output_path_for(input_path, output_dir ? output_dir : "", f);
+        struct stat st;
+        if (p.empty() || stat(p.c_str(), &st) != 0) return 1;   // (a path that cannot be formed counts as missing, :128-134)
+    }
+    return 0;
+} catch (...) { return (o_on_exception(), 1); }
 
 size_t bhh_species_code(const char *common_name, char *out, size_t cap) try {
     return copy_out(species_code(common_name ? common_name : ""), out, cap);

@@ -300,13 +300,26 @@ def collect_input_files(paths: List[str]) -> List[str]:
     return buf.value.decode().split("\n") if n.value else []
 
 
+def should_process(input_path: str, output_dir: Optional[str], formats=None, force: bool = False) -> bool:
+    """`should_process` of the reference (pipeline/coordinator.rs:96-143) without the lock-file arm: False when every requested
+    format's output already exists and `force` is off (the resume rule of directory mode)."""
+    return bool(_lib.load().bhh_should_process(input_path.encode(), output_dir.encode() if output_dir else None,
+                                                format_mask(formats if formats is not None else ("csv",)), 1 if force else 0))
+
+
 def process_files(classifier, files: List[str], rank: int = 0, world: int = 1, durations: Optional[List[float]] = None,
-                  **kwargs) -> List[ProcessResult]:
+                  force: bool = True, **kwargs) -> List[ProcessResult]:
     """Directory mode on `world` processes (one per GPU): rank g takes the files `sharding.assign_by_duration` gives
     it (the reference scales out as N processes over one directory with lock files, file_lock.rs:36-88)
     and runs them through `process_file` one after another on its own classifier, as `process_files_sequential`
-    does (lib.rs:1003-1100)."""
+    does (lib.rs:1003-1100).  force=False applies the reference's resume rule first (`should_process`, coordinator.rs:96-143):
+    files whose requested outputs all exist are left out before the list is cut."""
     from . import sharding
+    if not force:
+        keep = [i for i, f in enumerate(files) if should_process(f, kwargs.get("output_dir"), kwargs.get("formats"), False)]
+        files = [files[i] for i in keep]
+        if durations is not None:
+            durations = [durations[i] for i in keep]
     if durations is None:
         durations = []
         for f in files:

@@ -78,6 +78,10 @@ BH_API int bhh_writer_finalize(bhh_writer *w);
 /* output_dir_for + output_path_for (coordinator.rs:41-94): stem sanitised, extension by format; output_dir NULL / "" = next
  * to the input.  Returns the length (0 = unknown format); out receives the text when cap allows. */
 BH_API size_t bhh_output_path_for(const char *input_path, const char *output_dir, uint32_t format, char *out, size_t cap);
+/* should_process (pipeline/coordinator.rs:96-143) without the lock-file arm: 0 = SkipExists (every requested format's
+ * output file already exists and force is 0), 1 = Process (force, an output missing, or an empty format mask: "no output
+ * can be found to already exist when none was asked for", :113-127).  The resume rule of directory mode. */
+BH_API int bhh_should_process(const char *input_path, const char *output_dir, uint32_t format_mask, int force);
 /* generate_species_code (raven.rs:72-84) */
 BH_API size_t bhh_species_code(const char *common_name, char *out, size_t cap);
 /* float formatting the writers rely on: Rust `{}` (core::fmt, shortest digits, no exponent) and serde_json (ryu) */

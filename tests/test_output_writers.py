@@ -351,3 +351,26 @@ def test_malformed_wav_headers_fail_cleanly(tmp_path):
     seg, start = d.next_segment(4, 0)
     assert start == 0 and np.allclose(seg, [0.5, -0.5, 0.0, 32767 / 32768])
     d.close()
+
+
+def test_should_process_is_the_reference_resume_rule(tmp_path):
+    """should_process (pipeline/coordinator.rs:96-143) without the lock-file arm: a file is skipped only when EVERY requested
+    format's output exists and force is off; an empty format list always processes (#339 in the reference's comment)."""
+    from birda_amd import _lib, pipeline
+    wav = str(tmp_path / "rec" / "a.wav")
+    os.makedirs(os.path.dirname(wav))
+    open(wav, "wb").close()
+    out = str(tmp_path / "out")
+    os.makedirs(out)
+    assert pipeline.should_process(wav, out, ("csv", "json"))
+    open(pipeline.output_path_for(wav, out, "csv"), "w").close()
+    assert pipeline.should_process(wav, out, ("csv", "json"))            # json still missing
+    assert not pipeline.should_process(wav, out, ("csv",))
+    open(pipeline.output_path_for(wav, out, "json"), "w").close()
+    assert not pipeline.should_process(wav, out, ("csv", "json"))
+    assert pipeline.should_process(wav, out, ("csv", "json"), force=True)
+    assert _lib.load().bhh_should_process(wav.encode(), out.encode(), 0, 0) == 1       # nothing asked for: process
+    # outputs beside the input when no output directory is given (output_path_for)
+    assert pipeline.should_process(wav, None, ("raven",))
+    open(pipeline.output_path_for(wav, None, "raven"), "w").close()
+    assert not pipeline.should_process(wav, None, ("raven",))

@@ -884,6 +884,12 @@ def test_directory_mode_two_ranks_cover_every_file_once(clf_tiny, model_dir, tmp
             seen.append(name)
             assert open(r.output_path, "rb").read() == open(single / name, "rb").read()
     assert sorted(seen) == sorted(os.path.basename(r.output_path) for r in ref)
+    # resume (should_process, coordinator.rs:96-143): with the outputs in place nothing is left to do unless forced, and a
+    # missing output brings exactly its file back
+    assert pipeline.process_files(clf_tiny, files, output_dir=str(single), min_confidence=0.05, batch_size=4, force=False) == []
+    os.remove(ref[1].output_path)
+    again = pipeline.process_files(clf_tiny, files, output_dir=str(single), min_confidence=0.05, batch_size=4, force=False)
+    assert [r.output_path for r in again] == [ref[1].output_path]
 
 
 def test_non_finite_samples_stay_in_their_own_rows(clf_tiny, model_dir):
