@@ -22,6 +22,7 @@
 
 #include "../../include/birda_hip.h"
 #include "kernels.hpp"
+#include "trace.hpp"
 #include "model.hpp"
 
 namespace {
@@ -372,13 +373,20 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
     hipStream_t s = ctx->stream;
     auto T = [&](uint32_t t) { return ctx->d_arena + ctx->t_off[t]; };
     const uint32_t nl = (uint32_t)m.layers.size();
+    bh::TraceRange tr_slice("bh_forward_slice");   // ROCTx ranges (BIRDA_HIP_ROCTX=1): the slice, its front end, every layer group
     ctx_mark(ctx, -1);
-    bh::launch_minmax(d_seg, ctx->d_minmax, ctx->d_inbad, (int)n, (int)m.h.sample_count, s);
-    ctx_mark(ctx, ST_MINMAX);
-    bh::launch_mel(d_seg, ctx->d_minmax, T(0), c->fe, c->d_fe, (int)n, s);
-    ctx_mark(ctx, ST_MEL);
+    {
+        bh::TraceRange tr("front_end: minmax + mel");
+        bh::launch_minmax(d_seg, ctx->d_minmax, ctx->d_inbad, (int)n, (int)m.h.sample_count, s);
+        ctx_mark(ctx, ST_MINMAX);
+        bh::launch_mel(d_seg, ctx->d_minmax, T(0), c->fe, c->d_fe, (int)n, s);
+        ctx_mark(ctx, ST_MEL);
+    }
     for (uint32_t i = 0; i < nl; i++) {
         const auto &L = m.layers[i];
+        static const char *const kOpNames[] = {"layer", "conv", "depthwise", "pointwise", "pool", "dense", "scale"};
+        bh::TraceRange tr((!ctx->keep_tensors || ctx->keep_fused) && c->fused_at[i] >= 0 ? "fused_mbconv_block"
+                          : L.op < sizeof(kOpNames) / sizeof(kOpNames[0]) ? kOpNames[L.op] : kOpNames[0]);
         const float *in = T(L.in_tensor);
         float *out = (i == nl - 1) ? d_logits : T(i + 1);
         const float *res = L.res_tensor != bh::NO_TENSOR ? T(L.res_tensor) : nullptr;
@@ -446,6 +454,7 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
         }
     }
     if (d_idx && d_conf) {
+        bh::TraceRange tr("topk");
         bh::launch_topk(d_logits, (int)n, (int)m.h.n_classes, (int)m.h.output_activation, (int)c->top_k,
                         c->min_conf, c->filter, d_idx, d_conf, ctx->d_inbad, ctx->d_nonfinite, s);
         ctx_mark(ctx, ST_TOPK);

@@ -53,6 +53,9 @@ def test_no_oracle_in_product_library():
                 if f == "multi.hip":     # opens RCCL (and nothing else) at run time for the optional device-side result gather
                     assert set(re.findall(r'"(lib[^"]*\.so[^"]*)"', src)) == {"librccl.so.1", "librccl.so"}
                     continue
+                if f == "trace.hpp":     # opens a ROCTx library when BIRDA_HIP_ROCTX=1 (optional profiler ranges)
+                    assert set(re.findall(r'"(lib[^"]*\.so[^"]*)"', src)) == {"librocprofiler-sdk-roctx.so.1", "libroctx64.so.4", "libroctx64.so"}
+                    continue
                 assert "dlopen" not in src, f
 
 
