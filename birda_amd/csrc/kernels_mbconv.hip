@@ -91,18 +91,40 @@ __device__ __forceinline__ void mb_dma(const float *gsrc, float *lds_dst, int wa
         }
     }
 }
+// The same transfer addressed by an LDS BYTE ADDRESS instead of a pointer.  In some instantiations hipcc does not fold
+// `(unsigned)(size_t)lds_pointer` (a generic pointer: LDS -> flat -> integer) back to the LDS offset and its backend then rejects
+// the aperture test it builds ("Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base"); the column-task
+// instantiations hit that, so they compute the address from float offsets into the one dynamic shared array.
+template <int NFLOATS>
+__device__ __forceinline__ void mb_dma_at(const float *gsrc, unsigned lds_byte_addr, int wave, int lane) {
+    constexpr int NP = (NFLOATS + 255) / 256;
+#pragma unroll
+    for (int p0 = 0; p0 < NP; p0 += 4) {
+        const int p = p0 + wave;
+        const int off = p * 256 + lane * 4;
+        if (p < NP && off < NFLOATS) {
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                         :: "v"(gsrc + off), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr + (unsigned)p * 1024u)) : "memory", "m0");
+        }
+    }
+}
 __device__ __forceinline__ void mb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 //   PREC        0: f32 MFMA (16x16x4, KG counts 16-deep groups); 3: f16 hi/lo split, three 16x16x32 MFMAs
 //               per product (KG counts 32-deep steps); 1: plain f16 operands (one MFMA, ~1e-3 relative)
 //   ACT         the expand and depthwise activation (GELU, swish, ReLU6 or ReLU: bh_act<>, kernels.hpp)
+//   COLTH       > 0: whole-image tiles of COLTH rows (stride 1) whose depthwise phase runs as COLUMN tasks -- one lane = one
+//               output column (all COLTH rows) x 4 channels.  The late blocks' images are 3 or 6 rows high under a 5x5 kernel:
+//               40 / 20 % of the taps of a row-wise task multiply the all-zero padding rows, and its 192 tasks leave a wave idle.
+//               A column task loads only the COLTH real rows of its 5 (3) grid columns once, skips the padding rows at compile
+//               time, and SS * TW * CE / 4 = 256 of them fill the workgroup.
 //   PERSIST     1: persistent workgroups (grid = workgroups that fit on the chip at once) walking the tiles, with the weights of
 //               EVERY chunk resident in LDS -- loaded once per workgroup, not once per tile and chunk.  For the early blocks
 //               (large images, few channels): a tile's compute is ~5k cycles, and 12 barriers each waiting for a freshly
 //               issued L2 -> LDS transfer plus the launch and set-up of 48-96 workgroups per segment were 70 % of their time
 //               (tools/abl2.sh: chunk loop without any compute 417 of 1061 us, set-up + epilogue 303).
 template <int KS, int ST, int CE, int KG, int RT_W, int NCS, int WM, int WN, int MT_W, int NT_W, int TWL, int XBL,
-          int SS, int OCC, int STEM, int PREC, int PERSIST = 0, int ACT = ACT_GELU_ERF>
+          int SS, int OCC, int STEM, int PREC, int PERSIST = 0, int ACT = ACT_GELU_ERF, int COLTH = 0>
 __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const int n_seg) {
     static_assert(!STEM || SS == 1, "the stem variant handles one segment per workgroup");
     static_assert(PREC == 0 || CE % 32 == 0 || CE == 16, "f16 project GEMM: 32-deep steps, or one 16-deep step for 16-channel chunks");
@@ -132,13 +154,19 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
     // chunks are small: the early, large-image blocks): We x 2, Wp x 3, Wd x 2, refilled one whole CHUNK ahead -- a phase of
     // those blocks is a few hundred cycles, shorter than an L2 -> LDS transfer, and the waits in front of both barriers were
     // half of the kernel's wave-cycles (tools/gpu_mb_stamps.py); the ring costs 5-7 KB of LDS.
-    const bool ring = !PERSIST && d.ring != 0;
+    const bool ring = !PERSIST && COLTH == 0 && d.ring != 0;
     const int nbuf_e = PERSIST ? d.nchunks : (ring ? 2 : 1), nbuf_p = PERSIST ? d.nchunks : (ring ? 3 : 1);
     float *WeS = Ds + DS_FLOATS;
     _Float16 *DsH = reinterpret_cast<_Float16 *>(Ds), *DsL = DsH + POUT_PAD * DSH;   // PREC != 0
     float *WpS = WeS + nbuf_e * WE_FLOATS;
     float *Wds = WpS + nbuf_p * WP_FLOATS;
     int *omap = reinterpret_cast<int *>(Wds + nbuf_e * WD_FLOATS);
+    // (column-task instantiations: LDS byte addresses of the weight buffers, see mb_dma_at; the dynamic shared array follows the
+    //  kernel's static LDS, of which there is none here)
+    static_assert(COLTH == 0 || PERSIST == 0, "column tasks: no persistent variant");
+    const unsigned lds0 = (__builtin_amdgcn_groupstaticsize() + 15u) & ~15u;
+    const unsigned we_ba = lds0 + 4u * (unsigned)((egrid + 1) * CES + DS_FLOATS), wp_ba = we_ba + 4u * (unsigned)(nbuf_e * WE_FLOATS),
+                   wd_ba = wp_ba + 4u * (unsigned)(nbuf_p * WP_FLOATS);
 
     MbClock t_last{};
     if (d.stamps) t_last.last = __builtin_readcyclecounter();
@@ -149,8 +177,13 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
             mb_dma<WP_FLOATS>(d.Wp + (size_t)c * WP_FLOATS, WpS + c * WP_FLOATS, wave0, lane0);
         }
     } else {
-        mb_dma<WE_FLOATS>(d.We, WeS, wave0, lane0);
-        mb_dma<WD_FLOATS>(d.Wd, Wds, wave0, lane0);
+        if constexpr (COLTH > 0) {
+            mb_dma_at<WE_FLOATS>(d.We, we_ba, wave0, lane0);
+            mb_dma_at<WD_FLOATS>(d.Wd, wd_ba, wave0, lane0);
+        } else {
+            mb_dma<WE_FLOATS>(d.We, WeS, wave0, lane0);
+            mb_dma<WD_FLOATS>(d.Wd, Wds, wave0, lane0);
+        }
         if (ring) {
             mb_dma<WP_FLOATS>(d.Wp, WpS, wave0, lane0);
             if (d.nchunks > 1) {
@@ -493,12 +526,72 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
         if (!ring && !PERSIST) mb_dma_wait();
         __syncthreads();  // B1: Es complete; (ring == 0) WeS / WpS free; Wds (DMA issued after the last B2) landed
         if (!ring && !PERSIST && !(d.dbg & 16)) {
-            mb_dma<WE_FLOATS>(d.We + (size_t)chn * WE_FLOATS, WeS, wave, lane);
-            mb_dma<WP_FLOATS>(d.Wp + (size_t)ch * WP_FLOATS, WpS, wave, lane);
+            if constexpr (COLTH > 0) {
+                mb_dma_at<WE_FLOATS>(d.We + (size_t)chn * WE_FLOATS, we_ba, wave, lane);
+                mb_dma_at<WP_FLOATS>(d.Wp + (size_t)ch * WP_FLOATS, wp_ba, wave, lane);
+            } else {
+                mb_dma<WE_FLOATS>(d.We + (size_t)chn * WE_FLOATS, WeS, wave, lane);
+                mb_dma<WP_FLOATS>(d.Wp + (size_t)ch * WP_FLOATS, WpS, wave, lane);
+            }
         }
         mb_stamp(d.stamps, t_last, 3);
 
         // ---- P2: depthwise, XB output pixels x 4 channels per lane ---------------------------
+        if constexpr (COLTH > 0) {
+            // column tasks (see COLTH above): task = (segment slot, column x, channel group c4); mb_try_th guarantees TH == H ==
+            // Ho == COLTH, one tile row, pad_t == (KS - 1) / 2 and at most 256 tasks
+            constexpr int PADT = (KS - 1) / 2;
+            static_assert(ST == 1, "column tasks: stride 1");
+            if (tid < nsv * TW * C4N && !(d.dbg & 2)) {
+                const int c4 = tid % C4N, q = tid / C4N, x = q & (TW - 1), sl = q >> TWL;
+                const float *eb = Es + ((sl * IH + PADT) * IW + x) * CES + 4 * c4;   // grid row PADT = image row 0
+                float4 e[COLTH][KS];
+#pragma unroll
+                for (int r = 0; r < COLTH; r++)
+#pragma unroll
+                    for (int dx = 0; dx < KS; dx++) e[r][dx] = *reinterpret_cast<const float4 *>(eb + (r * IW + dx) * CES);
+                const float4 bd4 = *reinterpret_cast<const float4 *>(&bds[4 * c4]);
+                f32x2 acc[COLTH][2];
+#pragma unroll
+                for (int r = 0; r < COLTH; r++) { acc[r][0] = (f32x2){bd4.x, bd4.y}; acc[r][1] = (f32x2){bd4.z, bd4.w}; }
+#pragma unroll
+                for (int dy = 0; dy < KS; dy++) {
+#pragma unroll
+                    for (int dx = 0; dx < KS; dx++) {
+                        const float4 w = *reinterpret_cast<const float4 *>(&WdC[(dy * KS + dx) * CE + 4 * c4]);
+                        const f32x2 w0 = (f32x2){w.x, w.y}, w1 = (f32x2){w.z, w.w};
+#pragma unroll
+                        for (int r = 0; r < COLTH; r++) {
+                            constexpr int dummy = 0; (void)dummy;
+                            const int src = r + dy - PADT;          // image row under this tap; outside [0, COLTH): zero padding
+                            if (src < 0 || src >= COLTH) continue;   // (compile-time after unrolling)
+                            const float4 ev = e[src][dx];
+                            acc[r][0] = __builtin_elementwise_fma((f32x2){ev.x, ev.y}, w0, acc[r][0]);
+                            acc[r][1] = __builtin_elementwise_fma((f32x2){ev.z, ev.w}, w1, acc[r][1]);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // one kernel row of weight loads in flight
+                }
+#pragma unroll
+                for (int r = 0; r < COLTH; r++) {
+                    f32x2 g0 = acc[r][0], g1 = acc[r][1];
+                    bh_act4<ACT>(g0, g1);
+                    const int prow = sl * THTW + (r << TWL) + x;
+                    if constexpr (PREC == 3) {
+                        bh_f16x2 h0, l0, h1, l1;
+                        bh_split2(g0[0], g0[1], h0, l0);
+                        bh_split2(g1[0], g1[1], h1, l1);
+                        *reinterpret_cast<f16x4 *>(&DsH[prow * DSH + 4 * c4]) = (f16x4){h0[0], h0[1], h1[0], h1[1]};
+                        *reinterpret_cast<f16x4 *>(&DsL[prow * DSH + 4 * c4]) = (f16x4){l0[0], l0[1], l1[0], l1[1]};
+                    } else if constexpr (PREC == 1) {
+                        *reinterpret_cast<f16x4 *>(&DsH[prow * DSH + 4 * c4]) =
+                            (f16x4){(_Float16)g0[0], (_Float16)g0[1], (_Float16)g1[0], (_Float16)g1[1]};
+                    } else {
+                        *reinterpret_cast<float4 *>(&Ds[prow * CES + 4 * c4]) = make_float4(g0[0], g0[1], g1[0], g1[1]);
+                    }
+                }
+            }
+        } else
         if (!(d.dbg & 2)) {
             for (int t = tid; t < p2_ntask; t += 256) {
                 if (p2_ntask > 256) p2_task(t);   // wave-uniform
@@ -556,7 +649,10 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
         __syncthreads();  // B2: Ds complete; (ring == 0) WeS (next chunk) and WpS (this chunk) landed; Wds free
         if (PERSIST) {
         } else if (!ring) {
-            if (!(d.dbg & 16)) mb_dma<WD_FLOATS>(d.Wd + (size_t)chn * WD_FLOATS, Wds, wave, lane);
+            if (!(d.dbg & 16)) {
+                if constexpr (COLTH > 0) mb_dma_at<WD_FLOATS>(d.Wd + (size_t)chn * WD_FLOATS, wd_ba, wave, lane);
+                else mb_dma<WD_FLOATS>(d.Wd + (size_t)chn * WD_FLOATS, Wds, wave, lane);
+            }
         } else if (ch + 2 < nchunks && !(d.dbg & 16)) {
             // chunk ch + 2 into the buffers chunk ch has just finished with (We, Wd: read before this barrier) and into the Wp
             // buffer of chunk ch - 1 (its project phase ended before B1 of this chunk)
@@ -695,14 +791,14 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
 }
 
 struct MbCfg {
-    int KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC, PERSIST, ACT;
+    int KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC, PERSIST, ACT, COLTH;
     void (*launch)(const MbDesc &, int, hipStream_t);
 };
 
 template <int KS, int ST, int CE, int KG, int RT_W, int NCS, int WM, int WN, int MT_W, int NT_W, int TWL, int XBL,
-          int SS, int OCC, int STEM, int PREC, int PERSIST, int ACT>
+          int SS, int OCC, int STEM, int PREC, int PERSIST, int ACT, int COLTH = 0>
 void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
-    auto kern = mbconv_kernel<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, SS, OCC, STEM, PREC, PERSIST, ACT>;
+    auto kern = mbconv_kernel<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, SS, OCC, STEM, PREC, PERSIST, ACT, COLTH>;
     static DeviceOnce attr_set;
     attr_set.run([&] { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     dim3 grid(d.tiles_x, d.tiles_y, (n_seg + d.S - 1) / d.S), block(256);
@@ -716,11 +812,18 @@ void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
 
 // (MB_A: the activation the table is being expanded for, see kCfgs below)
 #define MB_ENTRY_P(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, PREC) \
-    {KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC, 0, MB_A,        \
+    {KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC, 0, MB_A, 0,     \
      mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC, STEM, PREC, 0, MB_A>}
+// column-task depthwise phase (COLTH = TH = the image height), split-f16 and plain-f16 twins
+#define MB_ENTRY_PC(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, PREC) \
+    {KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC, 0, MB_A, TH,    \
+     mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC, STEM, PREC, 0, MB_A, TH>}
+#define MB_ENTRY_HC(KS, ST, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM)            \
+    MB_ENTRY_PC(KS, ST, 32, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, 3),         \
+    MB_ENTRY_PC(KS, ST, 32, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, 1)
 // persistent workgroups, every chunk's weights resident in LDS (the early blocks)
 #define MB_ENTRY_PP(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, PREC) \
-    {KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC, 1, MB_A,         \
+    {KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC, 1, MB_A, 0,      \
      mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC, STEM, PREC, 1, MB_A>}
 #define MB_ENTRY_S(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM) \
     MB_ENTRY_P(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, 0)
@@ -731,7 +834,7 @@ void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
     MB_ENTRY_P(KS, ST, 32, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, 3),          \
     MB_ENTRY_P(KS, ST, 32, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, 1)
 
-// The list (mbconv_cfgs.inc: 85 tile configurations, indices as documented there) is instantiated once per activation:
+// The list (mbconv_cfgs.inc: 93 tile configurations, indices as documented there) is instantiated once per activation:
 // entry ci + k * kNBase is configuration ci with the k-th activation of kActs.
 constexpr int kActs[] = {ACT_GELU_ERF, ACT_SWISH, ACT_RELU6};
 const MbCfg kCfgs[] = {
@@ -760,6 +863,10 @@ double mb_try_th(MbDesc &d, int ci, int th) {
     if (c.PREC != d.prec) return -1;
     if ((d.Cin + (c.PREC ? 31 : 15)) / (c.PREC ? 32 : 16) != c.KG) return -1;
     if (d.act_e != c.ACT || d.act_d != c.ACT || d.act_p != ACT_NONE) return -1;
+    if (c.COLTH) {   // column tasks: the tile is the whole image, COLTH rows high, symmetric padding, one task per thread
+        if (th != c.COLTH || d.Ho != c.COLTH || d.H != c.COLTH || d.ST != 1 || d.pad_t != (c.KS - 1) / 2) return -1;
+        if (c.S * (1 << c.TWL) * (c.CE / 4) > 256) return -1;
+    }
     const int nto = (d.Cout + 15) / 16;
     if (nto > c.WN * c.NT_W) return -1;
     const int TW = 1 << c.TWL;
@@ -826,9 +933,9 @@ int mb_config_count() { return kNCfgs; }
 int mb_config_name(int ci, char *out, size_t cap) {
     if (ci < 0 || ci >= kNCfgs) return 0;
     const MbCfg &c = kCfgs[ci];
-    // all 18 template arguments, as a profiler prints them (the last two: persistent instantiation, activation)
-    return snprintf(out, cap, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", c.KS, c.ST, c.CE, c.KG, c.RT_W, c.NCS, c.WM,
-                    c.WN, c.MT_W, c.NT_W, c.TWL, c.XBL, c.S, c.OCC, c.STEM, c.PREC, c.PERSIST, c.ACT);
+    // all 19 template arguments, as a profiler prints them (the last three: persistent instantiation, activation, column tasks)
+    return snprintf(out, cap, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", c.KS, c.ST, c.CE, c.KG, c.RT_W, c.NCS, c.WM,
+                    c.WN, c.MT_W, c.NT_W, c.TWL, c.XBL, c.S, c.OCC, c.STEM, c.PREC, c.PERSIST, c.ACT, c.COLTH);
 }
 
 bool mb_plan(MbDesc &d, int force_cfg) {
@@ -858,13 +965,20 @@ bool mb_plan(MbDesc &d, int force_cfg) {
     // (741 -> 686, 576 -> 536); the stem, 16 -> 96 -> 24 and 24 -> 144 -> 24 blocks LOSE (928 -> 1161, 1032 -> 1504, 737 -> 953):
     // with every chunk's weights resident they fit two workgroups per CU instead of four, and without a prefetch of the next
     // tile's rows nothing hides a tile's set-up.  Off by default; BIRDA_HIP_MB_PERSIST=1 all six, =2 the 5x5 pair.
-    static const int kPreferred16a[] = {79, 80, 81, 82, 83, 84, 48, 49, 50, 51, 52, 55, 58, 65, 66};
-    static const int kPreferred16p[] = {83, 84, 48, 49, 50, 51, 52, 55, 58, 65, 66};
-    static const int kPreferred16n[] = {48, 49, 50, 51, 52, 55, 58, 65, 66};
+    static const int kPreferred16a[] = {79, 80, 81, 82, 83, 84, 48, 49, 50, 51, 52, 55, 58, 65, 66, 85, 87, 89, 91};
+    static const int kPreferred16p[] = {83, 84, 48, 49, 50, 51, 52, 55, 58, 65, 66, 85, 87, 89, 91};
+    static const int kPreferred16n[] = {48, 49, 50, 51, 52, 55, 58, 65, 66, 85, 87, 89, 91};
+    static const int kPreferred1[] = {86, 88, 90, 92};   // plain f16: the column-task twins where they apply, else the work rule
     const char *pe = getenv("BIRDA_HIP_MB_PERSIST");
     const int persist_mode = !pe ? 0 : pe[0] == '1' ? 2 : pe[0] == '2' ? 1 : 0;
     if (d.prec == 0)
         for (int base : kPreferred) {  // at the entry's own tile height: the shapes it was measured on
+            const int ci = mb_act_index(d, base);
+            MbDesc t = d;
+            if (ci >= 0 && mb_try_th(t, ci, kCfgs[ci].TH) >= 0) { d = t; return true; }
+        }
+    if (d.prec == 1)
+        for (int base : kPreferred1) {
             const int ci = mb_act_index(d, base);
             MbDesc t = d;
             if (ci >= 0 && mb_try_th(t, ci, kCfgs[ci].TH) >= 0) { d = t; return true; }

@@ -355,6 +355,34 @@ def test_full_model_runs_every_inverted_residual_block_fused(full_model):
     clf.close()
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "f16"])
+def test_column_task_late_blocks_against_the_row_task_ones(full_model, oracle_lib, monkeypatch, precision):
+    """The whole-image late blocks (6x32 and 3x16 under 5x5 / 3x3 kernels) run their depthwise phase as column tasks
+    (kernels_mbconv.hip COLTH: padding rows skipped at compile time, 256 tasks).  They are the planner's choice on the full
+    model; forcing the row-task entries (34 ... 43) instead must give the same logits to the mode's tolerance, and both must
+    match the oracle."""
+    from birda_amd import synth
+    from birda_amd.classifier import BirdClassifier
+    path, labels, m, _ = full_model
+    segs = synth.synth_segments(5, m.sample_count, m.sample_rate, start=77)     # odd: two-segment tiles see a tail
+    ref = oracle_lib.OracleModel(path).forward(segs)
+    scale = max(1.0, float(np.abs(ref).max()))
+    out = {}
+    for tag, prefer in (("column", None), ("row", "34,35,36,37,40,41,42,43")):
+        if prefer:
+            monkeypatch.setenv("BIRDA_HIP_MB_PREFER", prefer)
+        clf = BirdClassifier(path, labels, precision=precision)
+        names = [clf.fused_kernel_name(b) for b in clf.fused_blocks()]
+        n_col = sum(1 for n in names if int(n.rstrip(">").split(",")[18]) > 0)
+        assert n_col == (7 if tag == "column" else 0), names       # 80->480->112, 2 x 112->672->112, 3 x 192->1152->192, 192->1152->320
+        ctx = clf.create_batch_context(5)
+        out[tag] = clf.predict_logits(ctx, segs)
+        ctx.close(); clf.close()
+    tol = (F16_LOGIT_RTOL if precision == "f16" else LOGIT_RTOL) * scale
+    assert np.abs(out["column"] - ref).max() <= tol and np.abs(out["row"] - ref).max() <= tol
+    assert np.abs(out["column"] - out["row"]).max() <= tol
+
+
 def test_fused_blocks_match_unfused_and_oracle_on_small_images(model_dir, oracle_lib, monkeypatch):
     """mini_b0 = the full B0 channel plan on 16x58 ... 1x4 images: partial tiles everywhere, images
     smaller than a tile, and 5 segments so that the two-segments-per-workgroup tiles see an odd tail."""
@@ -490,7 +518,8 @@ def test_fused_path_with_other_activations(oracle_lib, tmp_path, act_name):
         clf = BirdClassifier(path, precision=prec)
         blocks = clf.fused_blocks()
         assert len(blocks) == n_blocks, (prec, blocks)
-        assert all(f",{act}>" in clf.fused_kernel_name(b) for b in blocks)      # the activation is the last template argument
+        # the activation is the 18th template argument (kernels_mbconv.hip: ..., PREC, PERSIST, ACT, COLTH)
+        assert all(clf.fused_kernel_name(b).rstrip(">").split(",")[17] == str(act) for b in blocks)
         ctx = clf.create_batch_context(3)
         got = clf.predict_logits(ctx, segs)
         if prec == "f16":
