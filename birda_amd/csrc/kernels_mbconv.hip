@@ -445,14 +445,26 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                     if constexpr (PREC != 0) {
                         // fragment planes: [step][column tile]{hi: 64 lanes x 8 halves, lo: same}
                         const f16x8 *wf = reinterpret_cast<const f16x8 *>(WeC);
-#pragma unroll
-                        for (int g = 0; g < KG; g++) {
-                            f16x8 bh[NT_U], bl[NT_U];
+                        // the next step's weight fragments are read from LDS BEFORE this step's MFMAs are issued (two register
+                        // sets, alternating): with the loads right in front of their MFMAs every k step of a late block
+                        // (6 steps x 9 MFMAs) began with an exposed LDS round trip, ~120 of its ~260 cycles
+                        f16x8 bhb[2][NT_U], blb[2][NT_U];
+                        auto wload = [&](int g, f16x8 (&h)[NT_U], f16x8 (&l)[NT_U]) __attribute__((always_inline)) {
 #pragma unroll
                             for (int j = 0; j < NT_U; j++) {
-                                bh[j] = wf[((g * NT_E + cs * NT_U + j) * 2 + 0) * 64 + lane];
-                                if (PREC == 3) bl[j] = wf[((g * NT_E + cs * NT_U + j) * 2 + 1) * 64 + lane];
+                                h[j] = wf[((g * NT_E + cs * NT_U + j) * 2 + 0) * 64 + lane];
+                                if (PREC == 3) l[j] = wf[((g * NT_E + cs * NT_U + j) * 2 + 1) * 64 + lane];
                             }
+                        };
+                        wload(0, bhb[0], blb[0]);
+#pragma unroll
+                        for (int g = 0; g < KG; g++) {
+                            // (KG >= 6 only, the 192-channel blocks: measured -5 % there, nothing at 3-4 steps, and the early
+                            //  blocks' one-step kernels lost 1 % to the changed register allocation)
+                            constexpr bool AHEAD = KG >= 6;
+                            if (AHEAD && g + 1 < KG) wload(g + 1, bhb[(g + 1) & 1], blb[(g + 1) & 1]);
+                            if (!AHEAD && g > 0) wload(g, bhb[g & 1], blb[g & 1]);
+                            f16x8 (&bh)[NT_U] = bhb[g & 1], (&bl)[NT_U] = blb[g & 1];
 #pragma unroll
                             for (int ii = 0; ii < RG; ii++) {
                                 if (i0 + ii >= RT_W) continue;
