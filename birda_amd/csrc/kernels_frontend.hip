@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void mel_kernel(const float *
     float4 *red = reinterpret_cast<float4 *>(smem);
 #pragma unroll
     for (int f = 0; f < MEL_FT; f++) {
-        if (f == wave) continue;
+        if (f == wave || (dbg & 4)) continue;
         const int slot = f - (f > wave ? 1 : 0);
 #pragma unroll
         for (int m = 0; m < MT; m++)
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void mel_kernel(const float *
         f32x4 v = wave == 0 ? acc[0][m] : wave == 1 ? acc[1][m] : wave == 2 ? acc[2][m] : acc[MEL_FT - 1][m];
 #pragma unroll
         for (int s = 0; s < 4; s++) {
-            if (s == wave) continue;
+            if (s == wave || (dbg & 4)) continue;
             const int slot = wave - (wave > s ? 1 : 0);
             const float4 q = red[((s * 3 + slot) * MT + m) * 64 + lane];
             v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void mel_kernel(const float *
                     float o = (dbg & 2) ? v : __builtin_amdgcn_exp2f(__builtin_fmaf(bp.expo, __builtin_amdgcn_logf(v * v), bp.log2_bias));
                     o = o * bp.out_scale + bp.out_shift;
                     const int row = bp.flip ? (bp.n_mels - 1 - mel) : mel;
-                    out[(size_t)row * bp.n_frames + t] = o;
+                    if (!(dbg & 8) || o == 12345.678f) out[(size_t)row * bp.n_frames + t] = o;
                 }
             }
     }
