@@ -74,6 +74,16 @@ inline bool load_model(const char *path, Model &m, std::string &err) {
         if (fread(rec, 1, 128, f) != 128) return bad("truncated layer table");
         memcpy(&L, rec, sizeof L);
     }
+    // the file is untrusted input: sizes are checked against the file before anything is allocated from them, every dimension is
+    // bounded (so that no product below can wrap), and every layer must read exactly the tensor its producer wrote
+    if (fseek(f, 0, SEEK_END) != 0) return bad("cannot seek");
+    const long fsize = ftell(f);
+    if (fsize < 0 || m.h.blob_floats > (1ull << 31) || m.h.blob_offset > (uint64_t)fsize ||
+        m.h.blob_floats * sizeof(float) > (uint64_t)fsize - m.h.blob_offset)
+        return bad("weights outside the file");
+    if (m.h.sample_count == 0 || m.h.sample_count > (1u << 24) || m.h.sample_rate == 0 || m.h.n_classes == 0 || m.h.n_classes > (1u << 24) ||
+        m.h.spec_h == 0 || m.h.spec_w == 0 || m.h.spec_h > (1u << 14) || m.h.spec_w > (1u << 16))
+        return bad("bad model dimensions");
     m.blob.resize(m.h.blob_floats);
     if (fseek(f, (long)m.h.blob_offset, SEEK_SET) != 0) return bad("bad blob offset");
     if (fread(m.blob.data(), sizeof(float), m.h.blob_floats, f) != m.h.blob_floats) return bad("truncated weights");
@@ -82,13 +92,28 @@ inline bool load_model(const char *path, Model &m, std::string &err) {
     m.tensor_floats[0] = (uint64_t)m.h.n_branches * m.h.spec_h * m.h.spec_w;
     for (uint32_t i = 0; i < m.h.n_layers; i++) {
         const auto &L = m.layers[i];
+        if (L.cin == 0 || L.cout == 0 || L.cin > (1u << 16) || L.cout > (1u << 24) || L.kh == 0 || L.kw == 0 || L.kh > 64 || L.kw > 64 ||
+            L.sh == 0 || L.sw == 0 || L.sh > 16 || L.sw > 16 || L.pad_t > 64 || L.pad_l > 64 || L.in_h == 0 || L.in_w == 0 || L.out_h == 0 ||
+            L.out_w == 0 || L.in_h > (1u << 16) || L.in_w > (1u << 16) || L.out_h > (1u << 16) || L.out_w > (1u << 16) ||
+            (uint64_t)L.out_h * L.out_w * L.cout > (1ull << 31) || (uint64_t)L.in_h * L.in_w * L.cin > (1ull << 31)) {
+            err = "layer dimensions out of range"; return false;
+        }
         m.tensor_floats[i + 1] = (uint64_t)L.out_h * L.out_w * L.cout;
         if (L.in_tensor > i || (L.res_tensor != NO_TENSOR && L.res_tensor > i)) { err = "layer reads a later tensor"; return false; }
+        // what the layer reads must be what its input tensor holds (a pool reads in_h x in_w x cout, a dense layer cin values)
+        const uint64_t in_floats = L.op == OP_GAP || L.op == OP_DWCONV || L.op == OP_SCALE ? (uint64_t)L.in_h * L.in_w * L.cout
+                                 : L.op == OP_DENSE ? (uint64_t)L.cin : (uint64_t)L.in_h * L.in_w * L.cin;
+        if (in_floats != m.tensor_floats[L.in_tensor]) { err = "layer input shape does not match its tensor"; return false; }
+        if (L.res_tensor != NO_TENSOR && L.op != OP_SCALE && m.tensor_floats[L.res_tensor] != m.tensor_floats[i + 1]) {
+            err = "residual shape does not match the layer output"; return false;
+        }
+        if (L.op < OP_CONV || L.op > OP_SCALE) { err = "unknown layer op"; return false; }
         const uint64_t wn = L.op == OP_CONV ? (uint64_t)L.kh * L.kw * L.cin * L.cout
                           : L.op == OP_DWCONV ? (uint64_t)L.kh * L.kw * L.cout
                           : (L.op == OP_PWCONV || L.op == OP_DENSE) ? (uint64_t)L.cin * L.cout : 0;
         if (L.op == OP_SCALE && (L.res_tensor == NO_TENSOR || m.tensor_floats[L.res_tensor] != L.cout || L.cin != L.cout)) { err = "scale layer without a [C] gate"; return false; }
-        if (L.op != OP_GAP && L.op != OP_SCALE && (L.w_off + wn > m.h.blob_floats || L.b_off + L.cout > m.h.blob_floats)) {
+        if (L.op != OP_GAP && L.op != OP_SCALE && (L.w_off > m.h.blob_floats || L.b_off > m.h.blob_floats || L.w_off + wn > m.h.blob_floats ||
+                                                   L.b_off + L.cout > m.h.blob_floats)) {
             err = "layer weights outside blob"; return false;
         }
     }
@@ -130,15 +155,20 @@ inline bool load_custom_model(const char *path, CustomModel &m, std::string &err
         if (fread(rec, 1, 32, f) != 32) return bad("truncated layer table");
         memcpy(&L, rec, sizeof L);
     }
-    if (m.h.blob_floats > (1ull << 32)) return bad("weights too large");
+    if (fseek(f, 0, SEEK_END) != 0) return bad("cannot seek");
+    const long fsize = ftell(f);
+    if (fsize < 0 || m.h.blob_floats > (1ull << 31) || m.h.blob_offset > (uint64_t)fsize ||
+        m.h.blob_floats * sizeof(float) > (uint64_t)fsize - m.h.blob_offset)
+        return bad("weights outside the file");
+    if (m.h.input_dim > (1u << 20) || m.h.n_classes > (1u << 24)) return bad("bad dimensions");
     m.blob.resize(m.h.blob_floats);
     if (fseek(f, (long)m.h.blob_offset, SEEK_SET) != 0) return bad("bad blob offset");
     if (fread(m.blob.data(), sizeof(float), m.h.blob_floats, f) != m.h.blob_floats) return bad("truncated weights");
     fclose(f);
     uint32_t dim = m.h.input_dim;
     for (const auto &L : m.layers) {
-        if (L.in_dim != dim || L.out_dim == 0) { err = "custom classifier: layer widths do not chain"; return false; }
-        if (L.w_off + (uint64_t)L.in_dim * L.out_dim > m.h.blob_floats || L.b_off + L.out_dim > m.h.blob_floats) { err = "custom classifier: weights outside blob"; return false; }
+        if (L.in_dim != dim || L.out_dim == 0 || L.out_dim > (1u << 24)) { err = "custom classifier: layer widths do not chain"; return false; }
+        if (L.w_off > m.h.blob_floats || L.b_off > m.h.blob_floats || L.w_off + (uint64_t)L.in_dim * L.out_dim > m.h.blob_floats || L.b_off + L.out_dim > m.h.blob_floats) { err = "custom classifier: weights outside blob"; return false; }
         dim = L.out_dim;
     }
     if (dim != m.h.n_classes) { err = "custom classifier: last layer width != n_classes"; return false; }

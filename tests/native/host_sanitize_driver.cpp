@@ -10,6 +10,7 @@
 
 #include "../../include/birda_hip.h"
 #include "../../include/birda_host.h"
+#include "../../birda_amd/csrc/model.hpp"
 
 // ---- stubs for the device library (never called by this driver) ----
 extern "C" {
@@ -70,6 +71,62 @@ int main(int argc, char **argv) {
             float seg[64]; size_t st;
             (void)bhh_decoder_next_segment(d, 64, 0, seg, &st);
             bhh_decoder_close(d);
+        }
+    }
+    // 1b. random mutations of well-formed WAV headers (PCM16 / PCM24 / PCM32 / float32, 1-3 channels), deterministic xorshift
+    {
+        uint64_t rs = 0x9e3779b97f4a7c15ull;
+        auto rnd = [&]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return rs; };
+        for (int it = 0; it < 3000; it++) {
+            const int fmt_kind = it % 4, ch = 1 + (it / 4) % 3;
+            const uint16_t tag = fmt_kind == 3 ? 3 : 1, bits = fmt_kind == 0 ? 16 : fmt_kind == 1 ? 24 : 32;
+            const uint32_t nbytes = 600 * ch * (bits / 8);
+            std::string w = "RIFF"; put32(w, 36 + nbytes); w += "WAVEfmt "; put32(w, 16); put16(w, tag); put16(w, (uint16_t)ch); put32(w, 22050);
+            put32(w, 22050u * ch * (bits / 8)); put16(w, (uint16_t)(ch * (bits / 8))); put16(w, bits); w += "data"; put32(w, nbytes);
+            for (uint32_t i = 0; i < nbytes; i++) w += (char)rnd();
+            const int nmut = 1 + (int)(rnd() % 4);
+            for (int k = 0; k < nmut; k++) w[rnd() % 44] = (char)rnd();          // header bytes only: the parser is what is fuzzed
+            if (rnd() % 8 == 0) w.resize(rnd() % w.size());
+            const std::string p = dir + "/fuzz.wav";
+            write_file(p, w);
+            bh_decoder *d = nullptr;
+            if (bhh_decoder_open(p.c_str(), &d) == BH_OK) {
+                std::vector<float> seg(257);
+                size_t start = 0;
+                int n = 0;
+                while (bhh_decoder_next_segment(d, 257, (size_t)(rnd() % 257), seg.data(), &start) == 1 && n < 20) n++;
+                bhh_decoder_close(d);
+            }
+        }
+    }
+    // 1c. the model containers (BHM1 / BHC1) are files too: mutated headers and tables must be refused or load consistently
+    if (argc > 3) {
+        uint64_t rs = 0x2545f4914f6cdd1dull;
+        auto rnd = [&]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return rs; };
+        for (int which = 0; which < 2; which++) {
+            std::string good;
+            {
+                FILE *f = fopen(argv[2 + which], "rb");
+                CHECK(f != nullptr);
+                if (!f) continue;
+                char b[65536]; size_t n;
+                while ((n = fread(b, 1, sizeof b, f)) > 0) good.append(b, n);
+                fclose(f);
+            }
+            const size_t table = which == 0 ? 256 + 64 * 4 + 128 * 64 : 64 + 32 * 8;     // header + the first records
+            int loaded = 0;
+            for (int it = 0; it < 1500; it++) {
+                std::string w = good;
+                const int nmut = 1 + (int)(rnd() % 3);
+                for (int k = 0; k < nmut; k++) w[rnd() % std::min(table, w.size())] = (char)rnd();
+                if (rnd() % 10 == 0) w.resize(rnd() % w.size());
+                const std::string p = dir + "/fuzz.model";
+                write_file(p, w);
+                std::string err;
+                if (which == 0) { bh::Model m; if (bh::load_model(p.c_str(), m, err)) { loaded++; (void)m.macs_per_segment(); } }
+                else { bh::CustomModel m; if (bh::load_custom_model(p.c_str(), m, err)) loaded++; }
+            }
+            printf("model fuzz %d: %d of 1500 mutants still load\n", which, loaded);
         }
     }
     // 2. every writer, odd labels and paths, NaN / inf confidences

@@ -17,6 +17,11 @@ def test_host_pipeline_under_asan_and_ubsan(tmp_path):
     work = tmp_path / "work"
     work.mkdir()
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
-    p = subprocess.run([exe, str(work)], capture_output=True, text=True, timeout=300, env=env)
+    # two well-formed containers for the loader fuzz (BHM1 model, BHC1 custom classifier)
+    from birda_amd import modelfile as mf, synth
+    model_path, custom_path = str(work / "mini.bhm"), str(work / "custom.bhc")
+    mf.write_model(model_path, synth.build_model("mini"))
+    mf.write_custom_classifier(custom_path, synth.build_custom_classifier(64, 10, hidden=(32,)))
+    p = subprocess.run([exe, str(work), model_path, custom_path], capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-6000:]
     assert "host sanitizer driver: ok" in p.stdout
