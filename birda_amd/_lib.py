@@ -73,6 +73,10 @@ SYMBOLS = [
     ("bh_predict_batch", C.c_int, [_VP, C.POINTER(_VP), _SZ, _SZ, C.POINTER(BhResult)]),
     ("bh_predict_batch_with_context", C.c_int, [_VP, _VP, C.POINTER(_VP), _SZ, _SZ, C.POINTER(BhResult)]),
     ("bh_predict_batch_contig", C.c_int, [_VP, _VP, _VP, _SZ, C.POINTER(BhResult)]),
+    ("bh_host_alloc", C.c_int, [_SZ, C.POINTER(C.c_void_p)]),
+    ("bh_host_free", None, [_VP]),
+    ("bh_host_register", C.c_int, [_VP, _SZ]),
+    ("bh_host_unregister", C.c_int, [_VP]),
     ("bh_predict_batch_logits", C.c_int, [_VP, _VP, _VP, _SZ, _VP, _VP]),
     ("bh_forward_device", C.c_int, [_VP, _VP, _VP, _SZ, _VP, _VP, _VP]),
     ("bh_batch_context_synchronize", C.c_int, [_VP]),

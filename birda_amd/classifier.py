@@ -34,6 +34,30 @@ class PredictionResult:
     predictions: List[Prediction]
 
 
+class PinnedSegments:
+    """[n][sample_count] float32 in pinned host memory (bh_host_alloc): `array` is a numpy view to fill; handing it to
+    `predict_batch_contig` uploads straight from it, without the gather copy pageable input needs."""
+
+    def __init__(self, n: int, sample_count: int):
+        self._L = _lib.load()
+        self._p = C.c_void_p()
+        check(self._L.bh_host_alloc(n * sample_count * 4, C.byref(self._p)))
+        buf = (C.c_float * (n * sample_count)).from_address(self._p.value)
+        self.array = np.frombuffer(buf, np.float32).reshape(n, sample_count)
+
+    def close(self) -> None:
+        if self._p:
+            self.array = None
+            self._L.bh_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001
+            pass
+
+
 class BatchInferenceContext:
     """create_batch_context(max_batch_size) -- classifier.rs:559-565."""
 

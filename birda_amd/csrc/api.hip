@@ -513,6 +513,15 @@ int predict_slices(bh_classifier *c, bh_batch_context *ctx, const float *const *
     if (segments)
         for (size_t i = 0; i < n; i++)
             if (!segments[i]) return fail(BH_ERR_INVALID, "segment %zu is null", i);
+    // A contiguous list in PINNED (hipHostMalloc / hipHostRegister: bh_host_alloc, bh_host_register) memory goes to the device
+    // straight from the caller's buffer: the gather into the context's own pinned staging -- a host memcpy, the bound of this
+    // entry point for pageable input -- is skipped.
+    bool pinned_src = false;
+    if (contig && n > 0) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, contig) == hipSuccess) pinned_src = attr.type == hipMemoryTypeHost;
+        else (void)hipGetLastError();   // pageable memory: "invalid value", not an error of this call
+    }
     for (size_t b0 = 0; b0 < n; b0 += ctx->max_batch) {
         const size_t nb = std::min(ctx->max_batch, n - b0);
         constexpr size_t CH = 32;
@@ -535,7 +544,7 @@ int predict_slices(bh_classifier *c, bh_batch_context *ctx, const float *const *
                 memcpy(ctx->h_input + i * S, src, S * sizeof(float));
             }
         };
-        const unsigned nthreads = (unsigned)std::min<size_t>(copy_threads(), nchunks);
+        const unsigned nthreads = pinned_src ? 1u : (unsigned)std::min<size_t>(copy_threads(), nchunks);
         std::vector<std::atomic<int>> done(nchunks);
         for (auto &d : done) d.store(0, std::memory_order_relaxed);
         std::atomic<size_t> next{0};
@@ -548,9 +557,10 @@ int predict_slices(bh_classifier *c, bh_batch_context *ctx, const float *const *
         int rc = BH_OK;
         for (size_t j = 0; j < nchunks && rc == BH_OK; j++) {
             if (nthreads > 1) while (!done[j].load(std::memory_order_acquire)) std::this_thread::yield();
-            else gather(j);
+            else if (!pinned_src) gather(j);
             const size_t i0 = j * CH, i1 = std::min(nb, (j + 1) * CH);
-            if (hipMemcpyAsync(ctx->d_input + i0 * S, ctx->h_input + i0 * S, (i1 - i0) * S * sizeof(float), hipMemcpyHostToDevice,
+            const float *h_src = pinned_src ? contig + (b0 + i0) * S : ctx->h_input + i0 * S;
+            if (hipMemcpyAsync(ctx->d_input + i0 * S, h_src, (i1 - i0) * S * sizeof(float), hipMemcpyHostToDevice,
                                ctx->copy_stream) != hipSuccess) { rc = fail(BH_ERR_HIP, "H2D copy failed"); break; }
             if (i1 % sub == 0 || i1 == nb) {   // a sub-slice is complete on the copy stream: compute it
                 const size_t si = (i1 - 1) / sub, s0 = si * sub, ns = i1 - s0;
@@ -1274,6 +1284,29 @@ int bh_predict_batch_with_context(bh_classifier *c, bh_batch_context *ctx, const
     return predict_slices(c, ctx, segments, nullptr, n, out, nullptr, nullptr);
 } catch (...) { return on_exception(); }
 
+int bh_host_alloc(size_t bytes, void **out) try {
+    if (!out || bytes == 0) return fail(BH_ERR_INVALID, "host_alloc: null argument or zero size");
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return fail(BH_ERR_HIP, "hipHostMalloc of %zu bytes failed", bytes); }
+    return BH_OK;
+} catch (...) { return on_exception(); }
+
+void bh_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+}
+
+int bh_host_register(void *p, size_t bytes) try {
+    if (!p || bytes == 0) return fail(BH_ERR_INVALID, "host_register: null argument or zero size");
+    if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return fail(BH_ERR_HIP, "hipHostRegister of %zu bytes failed", bytes); }
+    return BH_OK;
+} catch (...) { return on_exception(); }
+
+int bh_host_unregister(void *p) try {
+    if (!p) return BH_OK;
+    if (hipHostUnregister(p) != hipSuccess) { (void)hipGetLastError(); return fail(BH_ERR_HIP, "hipHostUnregister failed"); }
+    return BH_OK;
+} catch (...) { return on_exception(); }
+
 int bh_predict_batch_contig(bh_classifier *c, bh_batch_context *ctx, const float *base, size_t n, bh_result *out) try {
     int rc = check_ctx(c, ctx);
     if (rc != BH_OK) return rc;
@@ -1528,6 +1561,12 @@ int bh_predict_pcm16(bh_classifier *c, bh_batch_context *ctx, const int16_t *pcm
     }
     const size_t frame_bytes = (size_t)channels * sizeof(int16_t);
     const size_t stage_cap = ctx->max_batch * (size_t)h.sample_count * sizeof(float);   // the pinned input staging buffer
+    bool pcm_pinned = false;
+    {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, pcm) == hipSuccess) pcm_pinned = attr.type == hipMemoryTypeHost;
+        else (void)hipGetLastError();
+    }
     for (size_t b0 = 0; b0 < nseg; b0 += ctx->max_batch) {
         const size_t nb = std::min(ctx->max_batch, nseg - b0);
         const size_t f0 = starts[b0], f1 = std::min<size_t>(n_frames, starts[b0 + nb - 1] + seg);   // frames of this slice
@@ -1540,10 +1579,10 @@ int bh_predict_pcm16(bh_classifier *c, bh_batch_context *ctx, const int16_t *pcm
         // the segment kernel indexes the stream by absolute frame: hand it the slice buffer's virtual origin
         const int16_t *d_origin = ctx->d_pcm - f0 * channels;
         const char *src = reinterpret_cast<const char *>(pcm) + f0 * frame_bytes;
-        const bool staged = bytes <= stage_cap;      // (more than two channels: the span can exceed the staging buffer)
+        const bool staged = !pcm_pinned && bytes <= stage_cap;   // (more than two channels: the span can exceed the staging buffer)
         char *stage = reinterpret_cast<char *>(ctx->h_input);
         const size_t PIECE = (size_t)8 << 20;
-        const size_t npieces = staged ? (bytes + PIECE - 1) / PIECE : 1;
+        const size_t npieces = (staged || pcm_pinned) ? (bytes + PIECE - 1) / PIECE : 1;
         size_t sub = nb;
         if (nb >= 512) sub = std::max<size_t>(128, (nb + 3) / 4);
         const size_t nsub = (nb + sub - 1) / sub;
@@ -1572,6 +1611,11 @@ int bh_predict_pcm16(bh_classifier *c, bh_batch_context *ctx, const int16_t *pcm
                 else gather(j);
                 const size_t o = j * PIECE, len = std::min(PIECE, bytes - o);
                 if (hipMemcpyAsync(reinterpret_cast<char *>(ctx->d_pcm) + o, stage + o, len, hipMemcpyHostToDevice, ctx->copy_stream) != hipSuccess)
+                    { rc = fail(BH_ERR_HIP, "predict_pcm16: upload failed"); break; }
+                sent = o + len;
+            } else if (pcm_pinned) {   // pinned caller memory (bh_host_alloc / bh_host_register): piece by piece straight from it
+                const size_t o = j * PIECE, len = std::min(PIECE, bytes - o);
+                if (hipMemcpyAsync(reinterpret_cast<char *>(ctx->d_pcm) + o, src + o, len, hipMemcpyHostToDevice, ctx->copy_stream) != hipSuccess)
                     { rc = fail(BH_ERR_HIP, "predict_pcm16: upload failed"); break; }
                 sent = o + len;
             } else {

@@ -171,9 +171,18 @@ BH_API int bh_predict_batch_with_context(bh_classifier *c, bh_batch_context *ctx
                                          const float *const *segments, size_t n,
                                          size_t n_samples, bh_result *out);
 
-/* Contiguous host fast path [n][sample_count] (same semantics as predict_batch). */
+/* Contiguous host fast path [n][sample_count] (same semantics as predict_batch).  When `base` is pinned host memory
+ * (bh_host_alloc / bh_host_register below) the segments are uploaded straight from it; pageable memory is first gathered
+ * into the context's own pinned staging by worker threads (a host memcpy: the bound of this entry point). */
 BH_API int bh_predict_batch_contig(bh_classifier *c, bh_batch_context *ctx, const float *base,
                                    size_t n, bh_result *out);
+/* Pinned host memory for segment buffers.  The reference's decode thread fills `Vec<f32>` segments
+ * (audio/decode.rs:150-202) that predict_batch borrows as &[&[f32]] (processor.rs:341): a host that keeps its segments in
+ * one buffer from bh_host_alloc -- or registers the allocation it already has -- gets the upload at PCIe rate. */
+BH_API int bh_host_alloc(size_t bytes, void **out);
+BH_API void bh_host_free(void *p);
+BH_API int bh_host_register(void *p, size_t bytes);
+BH_API int bh_host_unregister(void *p);
 
 /* Raw outputs.  Not exposed to birda today; BASELINE.json's max |dlogit| needs them.
  * logits: host [n][n_classes]; embeddings (nullable): host [n][embedding_dim]

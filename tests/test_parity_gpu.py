@@ -182,6 +182,48 @@ def test_predict_entry_points_agree_and_preserve_order(clf_tiny, model_dir):
     ctx.close(); ctx5.close()
 
 
+def test_pinned_and_registered_host_segments_give_the_same_results(clf_tiny, model_dir):
+    """bh_predict_batch_contig uploads straight from pinned memory (bh_host_alloc, or a caller's buffer under
+    bh_host_register) and gathers pageable memory through its staging first: the results are identical, also across slices
+    (700 segments through a 256-segment context) and after the buffer is unregistered again."""
+    from birda_amd import synth
+    from birda_amd._lib import BhResult, check
+    from birda_amd.classifier import PinnedSegments
+    _, _, m, _ = model_dir["birdnet_v24_tiny"]
+    n = 700
+    uniq = synth.synth_segments(16, m.sample_count, m.sample_rate, start=3)
+    host = np.ascontiguousarray(np.tile(uniq, (n // 16 + 1, 1))[:n])
+    ctx = clf_tiny.create_batch_context(256)
+    L = clf_tiny._L
+
+    def run(ptr):
+        arr = (BhResult * n)()
+        check(L.bh_predict_batch_contig(clf_tiny._h, ctx._h, ptr, n, arr))
+        return [(r.n_pred, list(r.index[: r.n_pred]), [float(c) for c in r.confidence[: r.n_pred]]) for r in arr]
+
+    want = run(host.ctypes.data)
+    assert any(w[0] > 0 for w in want)
+    pin = PinnedSegments(n, m.sample_count)
+    pin.array[:] = host
+    assert run(pin.array.ctypes.data) == want
+    pin.close()
+    other = host.copy()
+    check(L.bh_host_register(other.ctypes.data, other.nbytes))
+    assert run(other.ctypes.data) == want
+    check(L.bh_host_unregister(other.ctypes.data))
+    assert run(other.ctypes.data) == want
+    assert L.bh_host_alloc(0, None) != 0 and L.bh_host_register(None, 16) != 0
+    # the PCM16 stream entry point takes the same short cut
+    pcm = np.clip(np.round(host[:300].reshape(-1).astype(np.float64) * 32767.0), -32768, 32767).astype(np.int16)
+    want16 = clf_tiny.predict_pcm16(ctx, pcm, m.sample_rate, 0)
+    check(L.bh_host_register(pcm.ctypes.data, pcm.nbytes))
+    got16 = clf_tiny.predict_pcm16(ctx, pcm, m.sample_rate, 0)
+    check(L.bh_host_unregister(pcm.ctypes.data))
+    assert got16[1] == want16[1] and [[(p.index, p.confidence) for p in r.predictions] for r in got16[0]] == \
+        [[(p.index, p.confidence) for p in r.predictions] for r in want16[0]]
+    ctx.close()
+
+
 def test_host_batch_pipeline_matches_the_device_path(clf_mini, model_dir):
     """The host entry points gather 32-segment chunks on worker threads, copy each chunk on a second
     stream and compute the slice in sub-slices (n >= 512): rows must come back in order and bit-identical
