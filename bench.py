@@ -338,6 +338,34 @@ def host_legs(clf, m, model_path, precision, tmp):
         r = sorted(rs, key=lambda x: x.segments_per_sec)[len(rs) // 2]
         e2e[fe] = {"value": round(r.segments_per_sec, 1), "unit": "segments/s", "segments": r.segments, "detections": r.detections,
                    "batch": r.effective_batch, "realtime_factor": round(r.audio_duration_secs / r.duration_secs, 1)}
+    # many short recordings (the common field-recorder case: one-minute files = 20 segments): one file at a time as the reference
+    # does (lib.rs:1003-1100), and packed into shared uploads / forwards (bhh_process_files)
+    short_dir = os.path.join(tmp, "short")
+    os.makedirs(short_dir, exist_ok=True)
+    per_file = 20
+    shorts = []
+    for k in range(50):
+        p = os.path.join(short_dir, "rec_%03d.wav" % k)
+        synth.write_wav_pcm16(p, host[(k * per_file) % (n - per_file): (k * per_file) % (n - per_file) + per_file].reshape(-1), m.sample_rate)
+        shorts.append(p)
+    out_a, out_b = os.path.join(tmp, "short_single"), os.path.join(tmp, "short_packed")
+    os.makedirs(out_a, exist_ok=True); os.makedirs(out_b, exist_ok=True)
+    for f in shorts[:3]:
+        pipeline.process_file(c2, f, out_a)
+    t = time.perf_counter()
+    segs_a = sum(pipeline.process_file(c2, f, out_a).segments for f in shorts)
+    t_single = time.perf_counter() - t
+    pipeline.process_files_packed(c2, shorts, out_b)
+    t = time.perf_counter()
+    res_b, status_b = pipeline.process_files_packed(c2, shorts, out_b)
+    t_packed = time.perf_counter() - t
+    segs_b = sum(r.segments for r in res_b)
+    same = all(open(pipeline.output_path_for(f, out_a, "csv"), "rb").read() == open(pipeline.output_path_for(f, out_b, "csv"), "rb").read()
+               for f in shorts)
+    e2e["short_files"] = {"what": "50 PCM16 WAV files of %d segments each -> 50 CSV files" % per_file,
+                          "one_file_at_a_time": {"value": round(segs_a / t_single, 1), "unit": "segments/s"},
+                          "packed": {"value": round(segs_b / t_packed, 1), "unit": "segments/s", "entry_point": "bhh_process_files"},
+                          "identical_outputs": bool(same and not any(status_b))}
     c2.close()
     out["end_to_end"] = {"what": "bhh_process_file on a synthetic %d-segment PCM16 WAV -> CSV (reference metric: segments / wall seconds, "
                                  "processor.rs:771-788), default batch size" % n, **e2e}

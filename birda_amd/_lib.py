@@ -68,6 +68,7 @@ SYMBOLS = [
     ("bh_batch_context_create", C.c_int, [_VP, _SZ, C.POINTER(_VP)]),
     ("bh_batch_context_destroy", None, [_VP]),
     ("bh_batch_context_bytes", _SZ, [_VP]),
+    ("bh_batch_context_host_buffer", C.c_void_p, [_VP, C.POINTER(_SZ)]),
     ("bh_batch_context_device_bytes", _SZ, [_VP]),
     ("bh_predict", C.c_int, [_VP, _VP, _SZ, C.POINTER(BhResult)]),
     ("bh_predict_batch", C.c_int, [_VP, C.POINTER(_VP), _SZ, _SZ, C.POINTER(BhResult)]),
@@ -94,6 +95,7 @@ SYMBOLS = [
     ("bh_segment_starts", _SZ, [_SZ, _SZ, _SZ, _VP, _SZ]),
     ("bh_predict_pcm16", C.c_int, [_VP, _VP, _VP, _SZ, C.c_uint32, C.c_uint32, _SZ, C.POINTER(BhResult), _SZ,
                                    C.POINTER(_SZ), _VP]),
+    ("bh_predict_pcm16_at", C.c_int, [_VP, _VP, _VP, _SZ, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), _SZ, C.POINTER(BhResult)]),
     ("bh_resample", C.c_int, [_VP, _VP, _SZ, C.c_uint32, C.c_uint32, _VP, _SZ, C.POINTER(_SZ)]),
     ("bh_resample_output_len", C.c_int, [_SZ, C.c_uint32, C.c_uint32, C.POINTER(_SZ)]),
     ("bh_resample_device", C.c_int, [_VP, _VP, _VP, _SZ, _SZ, C.c_uint32, C.c_uint32, _VP, _SZ, _SZ, _SZ]),
@@ -178,6 +180,7 @@ HOST_SYMBOLS = [
     ("bhh_csv_header", _SZ, [C.c_int, C.c_char_p, _SZ]),
     ("bhh_csv_row", _SZ, [C.c_char_p, C.c_float, C.c_float, C.c_float, C.c_char_p, C.c_char_p, _SZ]),
     ("bhh_process_file", C.c_int, [_VP, C.POINTER(BhhProcessingConfig), C.POINTER(BhhProcessResult)]),
+    ("bhh_process_files", C.c_int, [_VP, C.POINTER(BhhProcessingConfig), C.POINTER(C.c_char_p), _SZ, _SZ, C.POINTER(BhhProcessResult), C.POINTER(C.c_int)]),
     ("bhh_writer_open", C.c_int, [C.c_uint32, C.c_char_p, C.POINTER(BhhWriterOptions), C.POINTER(_VP)]),
     ("bhh_writer_write_header", C.c_int, [_VP]),
     ("bhh_writer_write_detection", C.c_int, [_VP, C.c_char_p, C.c_float, C.c_float, C.c_float, C.c_char_p]),

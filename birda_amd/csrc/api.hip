@@ -1255,6 +1255,10 @@ size_t bh_batch_context_bytes(const bh_batch_context *ctx) {
     return ctx ? ctx->max_batch * (size_t)ctx->c->model.h.sample_count * sizeof(float) : 0;
 }
 size_t bh_batch_context_device_bytes(const bh_batch_context *ctx) { return ctx ? ctx->device_bytes : 0; }
+void *bh_batch_context_host_buffer(bh_batch_context *ctx, size_t *bytes) {
+    if (bytes) *bytes = ctx ? bh_batch_context_bytes(ctx) : 0;
+    return ctx ? ctx->h_input : nullptr;
+}
 
 int bh_predict(bh_classifier *c, const float *segment, size_t n_samples, bh_result *out) try {
     const float *segs[1] = {segment};
@@ -1521,6 +1525,9 @@ size_t bh_segment_starts(size_t n_frames, size_t segment_samples, size_t overlap
     return n;
 }
 
+static int predict_pcm16_core(bh_classifier *c, bh_batch_context *ctx, const int16_t *pcm, size_t n_frames, uint32_t channels,
+                              uint32_t source_rate, const std::vector<uint64_t> &starts, size_t seg, bh_result *out);
+
 int bh_predict_pcm16(bh_classifier *c, bh_batch_context *ctx, const int16_t *pcm, size_t n_frames, uint32_t channels,
                      uint32_t source_rate, size_t overlap_samples, bh_result *out, size_t out_cap, size_t *n_segments,
                      uint64_t *start_samples) try {
@@ -1540,6 +1547,31 @@ int bh_predict_pcm16(bh_classifier *c, bh_batch_context *ctx, const int16_t *pcm
     std::vector<uint64_t> starts(nseg);
     bh_segment_starts(n_frames, seg, ovl, starts.data(), nseg);
     if (start_samples) memcpy(start_samples, starts.data(), nseg * sizeof(uint64_t));
+    return predict_pcm16_core(c, ctx, pcm, n_frames, channels, source_rate, starts, seg, out);
+} catch (...) { return on_exception(); }
+
+int bh_predict_pcm16_at(bh_classifier *c, bh_batch_context *ctx, const int16_t *pcm, size_t n_frames, uint32_t channels,
+                        uint32_t source_rate, const uint64_t *start_samples, size_t n_segments, bh_result *out) try {
+    int rc = check_ctx(c, ctx);
+    if (rc != BH_OK) return rc;
+    if (!pcm || !out || !start_samples || channels == 0) return fail(BH_ERR_INVALID, "predict_pcm16_at: bad arguments");
+    if (n_segments == 0) return BH_OK;
+    const auto &h = c->model.h;
+    const size_t seg = source_rate != h.sample_rate ? (size_t)std::ceil((double)h.sample_count * source_rate / h.sample_rate) : h.sample_count;
+    std::vector<uint64_t> starts(start_samples, start_samples + n_segments);
+    for (size_t i = 0; i < n_segments; i++)
+        if (starts[i] >= n_frames || (i && starts[i] < starts[i - 1]))
+            return fail(BH_ERR_INVALID, "predict_pcm16_at: segment %zu starts at %llu (stream of %zu frames; starts must not decrease)", i,
+                        (unsigned long long)starts[i], n_frames);
+    return predict_pcm16_core(c, ctx, pcm, n_frames, channels, source_rate, starts, seg, out);
+} catch (...) { return on_exception(); }
+
+static int predict_pcm16_core(bh_classifier *c, bh_batch_context *ctx, const int16_t *pcm, size_t n_frames, uint32_t channels,
+                              uint32_t source_rate, const std::vector<uint64_t> &starts, size_t seg, bh_result *out) {
+    int rc = BH_OK;
+    const auto &h = c->model.h;
+    const bool resampling = source_rate != h.sample_rate;
+    const size_t nseg = starts.size();
     HIPCHK(hipSetDevice(c->device));
     // The stream travels once, as int16 (a quarter of the f32 segments when they overlap by half), slice by
     // slice: worker threads gather 8-MiB pieces of the slice's span into the pinned staging buffer, each
@@ -1665,7 +1697,7 @@ int bh_predict_pcm16(bh_classifier *c, bh_batch_context *ctx, const int16_t *pcm
         if (nf != BH_OK) return nf;
     }
     return BH_OK;
-} catch (...) { return on_exception(); }
+}
 
 // ---- custom classifier on embeddings (reference birdnet_onnx::CustomClassifier; lib.rs:883-901, processor.rs:319-360) ----
 }  // extern "C"

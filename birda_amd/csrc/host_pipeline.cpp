@@ -615,6 +615,57 @@ struct PcmMapping {
     }
 };
 
+// the rest of process_file once the detections exist: sort (:178-187), audio duration (:692-703), write_output per format
+// (:721-736) or the reporter's detections event (:739-769), the result record (:771-788)
+template <class Lap>
+int finish_file(const bhh_processing_config *cfg, const FilePlan &pl, uint32_t formats, std::vector<Detection> &detections, const RunStats &st,
+                int has_duration, double duration, float overlap_secs, std::chrono::steady_clock::time_point t_start, bhh_process_result *res,
+                Lap &&lap) {
+    int rc = BH_OK;
+    // sort: start_time asc then confidence desc (:178-187); stable here (ties keep batch order)
+    std::stable_sort(detections.begin(), detections.end(), [](const Detection &a, const Detection &b) {
+        if (a.start_time < b.start_time) return true;
+        if (a.start_time > b.start_time) return false;
+        return a.confidence > b.confidence;
+    });
+
+    lap("sort");
+    const double audio_duration = has_duration ? duration
+                                  : (st.segments ? (double)pl.segment_duration + (st.segments - 1.0) * ((double)pl.segment_duration - overlap_secs) : 0.0);  // :692-703
+
+    // write_output per format (:721-736) unless a reporter owns stdout-only mode
+    const bool should_write = cfg->dual_output || !cfg->reporter;
+    if (should_write) {
+        bhh::WriterOptions wo;
+        wo.csv_bom = cfg->csv_bom != 0;
+        if (cfg->csv_columns) wo.csv_columns = cfg->csv_columns;
+        if (cfg->model_name) wo.model = cfg->model_name;
+        wo.min_confidence = cfg->min_confidence; wo.overlap = cfg->overlap;
+        wo.audio_duration = (float)audio_duration;                                           // :706-714
+        wo.has_lat = cfg->has_lat != 0; wo.has_lon = cfg->has_lon != 0; wo.lat = cfg->lat; wo.lon = cfg->lon; wo.week = cfg->week;
+        for (uint32_t bit = 1; bit <= BHH_FORMAT_PARQUET; bit <<= 1) {
+            if (!(formats & bit)) continue;
+            std::string out_path, err;
+            rc = bhh::write_output(pl.path, cfg->output_dir ? cfg->output_dir : "", bit, detections, wo, out_path, err);
+            if (rc != BH_OK) return hfail(rc, err);
+            if (!res->formats_written) snprintf(res->output_path, sizeof res->output_path, "%s", out_path.c_str());
+            res->formats_written |= bit;
+        }
+    }
+    if (!cfg->dual_output && cfg->reporter) bhh::reporter_detections(cfg->reporter, pl.path, detections);   // :739-769
+    lap("write");
+
+    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    res->detections = detections.size();
+    res->segments = st.segments;
+    res->batches = st.batches;
+    res->padded_rows = st.padded_rows;
+    res->duration_secs = wall;
+    res->audio_duration_secs = audio_duration;
+    res->segments_per_sec = wall > 0 && st.segments ? (double)st.segments / wall : 0.0;      // :771-778
+    return BH_OK;
+}
+
 }  // namespace
 
 extern "C" int bhh_process_file(bh_classifier *clf, const bhh_processing_config *cfg, bhh_process_result *res) try {
@@ -724,48 +775,206 @@ extern "C" int bhh_process_file(bh_classifier *clf, const bhh_processing_config 
     ctx_own.reset();
     if (fail_code) return hfail(fail_code, fail_msg);
 
-    // sort: start_time asc then confidence desc (:178-187); stable here (ties keep batch order)
-    std::stable_sort(detections.begin(), detections.end(), [](const Detection &a, const Detection &b) {
-        if (a.start_time < b.start_time) return true;
-        if (a.start_time > b.start_time) return false;
-        return a.confidence > b.confidence;
-    });
-
-    lap("sort");
-    const double audio_duration = has_duration ? duration
-                                  : (st.segments ? (double)pl.segment_duration + (st.segments - 1.0) * ((double)pl.segment_duration - overlap_secs) : 0.0);  // :692-703
-
-    // write_output per format (:721-736) unless a reporter owns stdout-only mode
-    const bool should_write = cfg->dual_output || !cfg->reporter;
-    if (should_write) {
-        bhh::WriterOptions wo;
-        wo.csv_bom = cfg->csv_bom != 0;
-        if (cfg->csv_columns) wo.csv_columns = cfg->csv_columns;
-        if (cfg->model_name) wo.model = cfg->model_name;
-        wo.min_confidence = cfg->min_confidence; wo.overlap = cfg->overlap;
-        wo.audio_duration = (float)audio_duration;                                           // :706-714
-        wo.has_lat = cfg->has_lat != 0; wo.has_lon = cfg->has_lon != 0; wo.lat = cfg->lat; wo.lon = cfg->lon; wo.week = cfg->week;
-        for (uint32_t bit = 1; bit <= BHH_FORMAT_PARQUET; bit <<= 1) {
-            if (!(formats & bit)) continue;
-            std::string out_path, err;
-            rc = bhh::write_output(pl.path, cfg->output_dir ? cfg->output_dir : "", bit, detections, wo, out_path, err);
-            if (rc != BH_OK) return hfail(rc, err);
-            if (!res->formats_written) snprintf(res->output_path, sizeof res->output_path, "%s", out_path.c_str());
-            res->formats_written |= bit;
-        }
-    }
-    if (!cfg->dual_output && cfg->reporter) bhh::reporter_detections(cfg->reporter, pl.path, detections);   // :739-769
-    lap("write");
-
-    const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
-    res->detections = detections.size();
-    res->segments = st.segments;
-    res->batches = st.batches;
-    res->padded_rows = st.padded_rows;
-    res->duration_secs = wall;
-    res->audio_duration_secs = audio_duration;
-    res->segments_per_sec = wall > 0 && st.segments ? (double)st.segments / wall : 0.0;      // :771-778
+    rc = finish_file(cfg, pl, formats, detections, st, has_duration, duration, overlap_secs, t_start, res, lap);
+    if (rc != BH_OK) return rc;
     res->front_end = device ? BHH_FRONT_END_DEVICE : BHH_FRONT_END_HOST;
+    return BH_OK;
+} catch (...) { return h_on_exception(); }
+
+
+// ---- many short files: packed uploads (no counterpart in the reference; see include/birda_host.h) ---------------------------
+namespace {
+
+struct PackedFile {
+    size_t index = 0;                 // into paths / results
+    FilePlan pl;
+    PcmMapping map;
+    uint32_t channels = 0;
+    int has_duration = 0;
+    double duration = 0.0;
+    float overlap_secs = 0.f;
+    size_t n_segments = 0;
+    size_t base_frame = 0;            // where its stream starts in the pack
+    std::chrono::steady_clock::time_point t_start;
+};
+
+// the part of bhh_process_file's plan that the device front end needs; false = not packable (leave it to bhh_process_file)
+bool plan_packable(bh_classifier *clf, const bh_model_info &info, const bhh_processing_config *cfg, const char *path, size_t pack_segments,
+                   PackedFile &pf) {
+    bh_decoder *probe = nullptr;
+    if (bhh_decoder_open(path, &probe) != BH_OK) return false;
+    std::unique_ptr<bh_decoder, void (*)(bh_decoder *)> own(probe, bhh_decoder_close);
+    FilePlan &pl = pf.pl;
+    pl.path = path;
+    pl.shown = path;
+    pl.source_rate = bhh_decoder_sample_rate(probe);
+    pf.has_duration = bhh_decoder_duration_hint(probe, &pf.duration);
+    pl.target_rate = info.sample_rate;
+    pl.segment_duration = info.segment_duration;
+    pl.segment_samples = bhh_duration_to_samples(pl.segment_duration, pl.target_rate);
+    pl.overlap_samples = bhh_duration_to_samples(cfg->overlap, pl.target_rate);
+    pf.overlap_secs = cfg->overlap;
+    pl.estimated = bhh_estimate_segment_count(pf.has_duration, pf.duration, pl.segment_duration, pf.overlap_secs);
+    pl.min_confidence = cfg->min_confidence;
+    if (pl.segment_samples != info.sample_count) return false;
+    pl.resampling = pl.source_rate != pl.target_rate;
+    pl.src_segment_samples = bhh_source_samples(pl.segment_samples, pl.source_rate, pl.target_rate);
+    pl.src_overlap_samples = bhh_source_samples(pl.overlap_samples, pl.source_rate, pl.target_rate);
+    if (pl.src_overlap_samples >= pl.src_segment_samples) return false;      // bhh_process_file reports it
+    if (!pf.map.open(*probe)) return false;
+    pf.channels = (uint32_t)probe->channels;
+    pf.n_segments = bh_segment_starts(pf.map.n_frames, pl.src_segment_samples, pl.src_overlap_samples, nullptr, 0);
+    (void)clf;
+    return pf.n_segments > 0 && pf.n_segments < std::max<size_t>(2, pack_segments / 2);
+}
+
+}  // namespace
+
+extern "C" int bhh_process_files(bh_classifier *clf, const bhh_processing_config *cfg, const char *const *paths, size_t n_files,
+                                 size_t pack_segments, bhh_process_result *results, int *status) try {
+    if (!clf || !cfg || (n_files && (!paths || !results))) return hfail(BH_ERR_INVALID, "process_files: null argument");
+    if (pack_segments == 0) pack_segments = 1024;
+    bh_model_info info;
+    if (bh_classifier_info(clf, &info) != BH_OK) return hfail(BH_ERR_INVALID, bh_last_error());
+    const uint32_t formats = cfg->formats ? cfg->formats : BHH_FORMAT_CSV;
+    const bool packing = !cfg->custom_classifier && !cfg->reporter && cfg->front_end != BHH_FRONT_END_HOST && !(formats & ~BHH_FORMAT_ALL);
+    for (size_t i = 0; i < n_files; i++) {
+        memset(&results[i], 0, sizeof results[i]);
+        if (status) status[i] = BH_OK;
+    }
+    auto single = [&](size_t i) {
+        bhh_processing_config c = *cfg;
+        c.input_path = paths[i];
+        c.display_path = nullptr;
+        const int rc = paths[i] ? bhh_process_file(clf, &c, &results[i]) : BH_ERR_INVALID;
+        if (status) status[i] = rc;
+    };
+    bh_batch_context *ctx = nullptr;
+    std::unique_ptr<bh_batch_context, void (*)(bh_batch_context *)> ctx_own(nullptr, bh_batch_context_destroy);
+    void *pinned = nullptr;      // the pack buffer: the context's own pinned staging (bh_batch_context_host_buffer)
+    size_t pinned_bytes = 0;
+
+    std::vector<std::unique_ptr<PackedFile>> pack;
+    size_t pack_segs = 0;
+    const bool timing = getenv("BIRDA_HOST_TIMING") != nullptr;   // diagnostic: where a call's time goes, to stderr
+    double t_plan = 0, t_copy = 0, t_predict = 0, t_finish = 0, t_setup = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    auto flush = [&]() {
+        if (pack.empty()) return;
+        auto tp0 = now();
+        const PackedFile &f0 = *pack.front();
+        const size_t seg = f0.pl.src_segment_samples, ch = f0.channels;
+        // layout: every stream followed by `seg` frames of silence
+        size_t total_frames = 0, total_segs = 0;
+        for (auto &pf : pack) { pf->base_frame = total_frames; total_frames += pf->map.n_frames + seg; total_segs += pf->n_segments; }
+        const size_t bytes = total_frames * ch * sizeof(int16_t);
+        int rc = BH_OK;
+        if (!ctx) {
+            rc = bh_classifier_ensure_warm(clf, std::min<size_t>(pack_segments, 256));
+            if (rc == BH_OK) rc = bh_batch_context_create(clf, pack_segments, &ctx);
+            if (rc == BH_OK) {
+                ctx_own.reset(ctx);
+                pinned = bh_batch_context_host_buffer(ctx, &pinned_bytes);
+            }
+        }
+        // (a pack is at most pack_segments segments of f32 input long in the staging buffer's terms: int16 streams with their
+        //  silences fit unless the files have many channels -- then the pack goes file by file)
+        if (rc == BH_OK && pinned_bytes < bytes) rc = BH_ERR_UNSUPPORTED;
+        std::vector<uint64_t> starts;
+        std::vector<bh_result> rows;
+        auto tp1 = now();
+        t_setup += ms(tp0, tp1);
+        auto tp2 = tp1, tp3 = tp1;
+        if (rc == BH_OK) {
+            int16_t *dst = static_cast<int16_t *>(pinned);
+            // one copy per file, page cache -> pinned memory, on a few threads (the copies fault the mapped pages in)
+            const unsigned nthreads = (unsigned)std::min<size_t>(8, pack.size());
+            std::atomic<size_t> next{0};
+            auto work = [&] {
+                for (size_t k; (k = next.fetch_add(1)) < pack.size();) {
+                    const PackedFile &pf = *pack[k];
+                    int16_t *d = dst + pf.base_frame * ch;
+                    if (pf.map.n_frames) memcpy(d, pf.map.pcm, pf.map.n_frames * ch * sizeof(int16_t));
+                    memset(d + pf.map.n_frames * ch, 0, seg * ch * sizeof(int16_t));
+                }
+            };
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < nthreads; t++) th.emplace_back(work);
+            work();
+            for (auto &t : th) t.join();
+            starts.reserve(total_segs);
+            std::vector<uint64_t> one;
+            for (auto &pf : pack) {
+                one.resize(pf->n_segments);
+                bh_segment_starts(pf->map.n_frames, seg, pf->pl.src_overlap_samples, one.data(), one.size());
+                for (uint64_t v : one) starts.push_back(pf->base_frame + v);
+            }
+            rows.resize(total_segs);
+            tp2 = now();
+            void *guard = bhh_watchdog_start(watchdog_timeout_secs() * 1000, total_segs);
+            rc = bh_predict_pcm16_at(clf, ctx, dst, total_frames, (uint32_t)ch, f0.pl.source_rate, starts.data(), total_segs, rows.data());
+            bhh_watchdog_cancel(guard);
+            tp3 = now();
+            t_copy += ms(tp1, tp2);
+            t_predict += ms(tp2, tp3);
+        }
+        if (rc == BH_ERR_UNSUPPORTED) {   // does not fit the staging buffer: the reference's way, one file at a time
+            for (auto &pfp : pack) single(pfp->index);
+            pack.clear();
+            pack_segs = 0;
+            return;
+        }
+        size_t row = 0;
+        for (auto &pfp : pack) {
+            PackedFile &pf = *pfp;
+            bhh_process_result *res = &results[pf.index];
+            int frc = rc;
+            if (rc == BH_OK) {
+                std::vector<Detection> detections;
+                RunStats st;
+                for (size_t i = 0; i < pf.n_segments; i++, row++) {
+                    float t0, t1;
+                    chunk_times(pf.pl, (size_t)(starts[row] - pf.base_frame), t0, t1);
+                    collect_detections(clf, pf.pl, rows[row], t0, t1, detections);
+                }
+                st.segments = pf.n_segments;
+                st.batches = 1;
+                res->effective_batch = total_segs;
+                auto nolap = [](const char *) {};
+                frc = finish_file(cfg, pf.pl, formats, detections, st, pf.has_duration, pf.duration, pf.overlap_secs, pf.t_start, res, nolap);
+                res->front_end = BHH_FRONT_END_DEVICE;
+            }
+            if (status) status[pf.index] = frc;
+        }
+        t_finish += ms(tp3, now());
+        pack.clear();
+        pack_segs = 0;
+    };
+
+    for (size_t i = 0; i < n_files; i++) {
+        if (!paths[i]) { if (status) status[i] = BH_ERR_INVALID; continue; }
+        std::unique_ptr<PackedFile> pf(new PackedFile);
+        pf->index = i;
+        pf->t_start = std::chrono::steady_clock::now();
+        const bool can = packing && plan_packable(clf, info, cfg, paths[i], pack_segments, *pf);
+        t_plan += ms(pf->t_start, now());
+        if (!can) {
+            flush();             // keep the order of outputs and of any side effects
+            single(i);
+            continue;
+        }
+        if (!pack.empty()) {
+            const PackedFile &f0 = *pack.front();
+            if (f0.pl.source_rate != pf->pl.source_rate || f0.channels != pf->channels || pack_segs + pf->n_segments > pack_segments) flush();
+        }
+        pack_segs += pf->n_segments;
+        pack.push_back(std::move(pf));
+    }
+    flush();
+    if (timing)
+        fprintf(stderr, "process_files: plan %.2f ms, pack set-up %.2f, copy %.2f, predict %.2f, detections + outputs %.2f\n", t_plan, t_setup,
+                t_copy, t_predict, t_finish);
     return BH_OK;
 } catch (...) { return h_on_exception(); }
 

@@ -286,6 +286,28 @@ def process_file(classifier, input_path: str, output_dir: Optional[str] = None, 
                          res.output_path.decode(), "device" if res.front_end == 2 else "host", res.formats_written)
 
 
+def process_files_packed(classifier, files: Sequence[str], output_dir: Optional[str] = None, min_confidence: float = 0.1,
+                         overlap: float = 0.0, csv_bom: bool = True, formats: Sequence[str] = ("csv",),
+                         csv_columns: Optional[Sequence[str]] = None, model_name: str = "", pack_segments: int = 0):
+    """bhh_process_files: many short recordings, packed into shared uploads / forwards (include/birda_host.h); the results and
+    outputs of `process_file` per file.  Returns (results, status) in the order of `files`."""
+    L = _lib.load()
+    cfg = BhhProcessingConfig(None, output_dir.encode() if output_dir else None, None, min_confidence, overlap, 0,
+                              int(csv_bom), format_mask(formats), _lib.FRONT_ENDS["auto"],
+                              ",".join(csv_columns).encode() if csv_columns else None, model_name.encode(),
+                              0, 0, 0.0, 0.0, -1, None, 0, None)
+    n = len(files)
+    raw = [f.encode() for f in files]
+    arr = (C.c_char_p * max(1, n))(*raw)
+    res = (BhhProcessResult * max(1, n))()
+    status = (C.c_int * max(1, n))()
+    _hcheck(L.bhh_process_files(classifier._h, C.byref(cfg), arr, n, pack_segments, res, status))
+    out = [ProcessResult(r.detections, r.segments, r.duration_secs, r.audio_duration_secs, r.segments_per_sec, r.effective_batch,
+                         r.batches, r.padded_rows, r.output_path.decode(), "device" if r.front_end == 2 else "host", r.formats_written)
+           for r in res[:n]]
+    return out, [int(status[i]) for i in range(n)]
+
+
 def collect_input_files(paths: List[str]) -> List[str]:
     """coordinator.rs:146-176: audio files given directly or found under the given directories."""
     L = _lib.load()

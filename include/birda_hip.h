@@ -156,6 +156,10 @@ BH_API int bh_classifier_is_warm(const bh_classifier *c, size_t batch_size);
 BH_API int bh_batch_context_create(bh_classifier *c, size_t max_batch, bh_batch_context **out);
 BH_API void bh_batch_context_destroy(bh_batch_context *ctx);
 BH_API size_t bh_batch_context_bytes(const bh_batch_context *ctx);       /* input buffer bytes */
+/* The context's pinned host staging buffer (bh_batch_context_bytes of it).  Between calls it is the caller's to fill: segments or
+ * a PCM16 stream assembled THERE and handed to bh_predict_batch_contig / bh_predict_pcm16(_at) go up without another host copy,
+ * and a parked context keeps the allocation alive from file to file (a fresh 300-MB hipHostMalloc + hipHostFree costs 35 ms). */
+BH_API void *bh_batch_context_host_buffer(bh_batch_context *ctx, size_t *bytes);
 BH_API size_t bh_batch_context_device_bytes(const bh_batch_context *ctx); /* all device memory */
 
 /* Classifier::predict(&[f32]) (classifier.rs:469-475): exactly sample_count samples. */
@@ -293,6 +297,12 @@ BH_API size_t bh_segment_starts(size_t n_frames, size_t segment_samples, size_t 
 BH_API int bh_predict_pcm16(bh_classifier *c, bh_batch_context *ctx, const int16_t *pcm, size_t n_frames,
                             uint32_t channels, uint32_t source_rate, size_t overlap_samples, bh_result *out,
                             size_t out_cap, size_t *n_segments, uint64_t *start_samples);
+/* The same with the segment starts given (frames, not decreasing, each < n_frames; a segment that runs past n_frames is zero
+ * padded): several short recordings packed into ONE stream -- each followed by a segment's length of silence, so that its
+ * trailing segment pads with zeros as next_segment does (decode.rs:188-196) -- go through one upload and one forward
+ * (bhh_process_files, include/birda_host.h). */
+BH_API int bh_predict_pcm16_at(bh_classifier *c, bh_batch_context *ctx, const int16_t *pcm, size_t n_frames, uint32_t channels,
+                               uint32_t source_rate, const uint64_t *start_samples, size_t n_segments, bh_result *out);
 
 /* ---- resampler (reference src/audio/resample.rs:10-105; rubato Fft<f32>, FixedSync::Both,
  * chunk 1024, one new resampler per segment).  The device kernel applies rubato's block

@@ -173,6 +173,20 @@ typedef struct {
 
 BH_API int bhh_process_file(bh_classifier *clf, const bhh_processing_config *cfg, bhh_process_result *res);
 
+/* process_files_sequential (lib.rs:1003-1100) for MANY SHORT recordings.  The reference runs the files one after another, each
+ * in batches of its own segments; a one-minute recording is 20 segments -- 2 % of what this GPU wants per launch, and a forward
+ * has a ~1.3 ms floor however few segments it holds.  Here consecutive PCM16 WAV files of one sample rate and channel count are
+ * PACKED: their streams are copied into one pinned buffer (each followed by a segment's length of silence, so that trailing
+ * segments pad with zeros exactly as next_segment does), cut into up to `pack_segments` segments and run as ONE upload and ONE
+ * forward (bh_predict_pcm16_at); the rows are scattered back and every file gets the detections, sort and outputs
+ * bhh_process_file would have given it (tests/test_parity_gpu.py::test_packed_short_files_match_the_per_file_pipeline).
+ * cfg is a template: input_path / display_path are ignored, the rest applies to every file.  Files the packer does not take --
+ * not PCM16 WAV, at least `pack_segments / 2` segments long, bat mode, a reporter in the template -- go through
+ * bhh_process_file where they stand.  results[i] belongs to paths[i]; status[i] (nullable) receives each file's BH_OK /
+ * BH_ERR_*; the call itself fails only for bad arguments.  pack_segments 0 = 1024. */
+BH_API int bhh_process_files(bh_classifier *clf, const bhh_processing_config *cfg, const char *const *paths, size_t n_files,
+                             size_t pack_segments, bhh_process_result *results, int *status);
+
 /* ---- directory mode (coordinator.rs:146-190) ------------------------------------------ */
 /* is_audio_file (:179-190): extension in {wav, flac, mp3, m4a, aac}, ASCII case-insensitive. */
 BH_API int bhh_is_audio_file(const char *path);

@@ -25,6 +25,9 @@ int bh_predict_batch(bh_classifier *, const float *const *, size_t, size_t, bh_r
 int bh_predict_batch_with_context(bh_classifier *, bh_batch_context *, const float *const *, size_t, size_t, bh_result *) { return BH_ERR_NO_DEVICE; }
 int bh_predict_batch_source_rate(bh_classifier *, bh_batch_context *, const float *const *, size_t, size_t, uint32_t, bh_result *) { return BH_ERR_NO_DEVICE; }
 int bh_predict_pcm16(bh_classifier *, bh_batch_context *, const int16_t *, size_t, uint32_t, uint32_t, size_t, bh_result *, size_t, size_t *, uint64_t *) { return BH_ERR_NO_DEVICE; }
+int bh_predict_pcm16_at(bh_classifier *, bh_batch_context *, const int16_t *, size_t, uint32_t, uint32_t, const uint64_t *, size_t, bh_result *) { return BH_ERR_NO_DEVICE; }
+size_t bh_segment_starts(size_t, size_t, size_t, uint64_t *, size_t) { return 0; }
+void *bh_batch_context_host_buffer(bh_batch_context *, size_t *) { return nullptr; }
 int bh_predict_batch_two_stage(bh_classifier *, bh_batch_context *, bh_custom_classifier *, const float *const *, size_t, size_t, bh_result *, float *) { return BH_ERR_NO_DEVICE; }
 const char *bh_custom_classifier_label(const bh_custom_classifier *, uint32_t) { return nullptr; }
 size_t bh_classifier_default_batch_size(const bh_classifier *) { return 256; }
@@ -187,6 +190,14 @@ int main(int argc, char **argv) {
     cfg.input_path = (dir + "/cut.wav").c_str();
     bhh_process_result res;
     CHECK(bhh_process_file(reinterpret_cast<bh_classifier *>(&cfg), &cfg, &res) != BH_OK);
+    // 6. process_files: bad arguments are refused, undecodable files get their own status, nothing crashes without a device
+    {
+        const char *many[3] = {cfg.input_path, nullptr, "/nonexistent/x.wav"};
+        bhh_process_result rs[3];
+        int stt[3] = {0, 0, 0};
+        CHECK(bhh_process_files(nullptr, &cfg, many, 3, 0, rs, stt) != BH_OK);
+        CHECK(bhh_process_files(reinterpret_cast<bh_classifier *>(&cfg), &cfg, many, 3, 0, rs, stt) != BH_OK);   // (stub classifier: no model info)
+    }
     if (failures) { fprintf(stderr, "%d check(s) failed\n", failures); return 1; }
     printf("host sanitizer driver: ok\n");
     return 0;

@@ -963,6 +963,62 @@ def test_directory_mode_two_ranks_cover_every_file_once(clf_tiny, model_dir, tmp
     assert [r.output_path for r in again] == [ref[1].output_path]
 
 
+def test_packed_short_files_match_the_per_file_pipeline(clf_tiny, model_dir, tmp_path):
+    """bhh_process_files packs the PCM16 streams of consecutive short recordings into one upload and one forward
+    (bh_predict_pcm16_at) and scatters the rows back: byte for byte the CSV / JSON files bhh_process_file writes per file --
+    with overlap, trailing partial segments, mono and stereo, two sample rates (packs break where rate or channel count change),
+    a file too long to pack, a float32 WAV (host front end) and a file that does not exist in between."""
+    from birda_amd import pipeline, synth
+    _, _, m, _ = model_dir["birdnet_v24_tiny"]
+    rec = tmp_path / "rec"; rec.mkdir()
+    S = m.sample_count
+    spec = [("a.wav", 2 * S + 777, 48000, 1), ("b.wav", S // 3, 48000, 1), ("c.wav", 5 * S, 48000, 1), ("d.wav", 3 * S + 1, 48000, 2),
+            ("e.wav", S + S // 2, 48000, 2), ("f.wav", 2 * S, 44100, 1), ("g.wav", 4 * S - 5, 44100, 1), ("h.wav", 40 * S, 48000, 1),
+            ("i.wav", 1, 48000, 1), ("j.wav", 3 * S, 48000, 1)]
+    files = []
+    for k, (name, n, rate, ch) in enumerate(spec):
+        x = synth.synth_segments(n // S + 1, S, rate, start=20 * k).reshape(-1)[:n]
+        if ch == 2:
+            x = np.stack([x, 0.5 * x[::-1]], 1)
+        synth.write_wav_pcm16(str(rec / name), x, rate, channels=ch)
+        files.append(str(rec / name))
+    f32 = rec / "k_float.wav"                                            # a float32 WAV: the packer leaves it to bhh_process_file
+    import struct
+    xs = synth.synth_segments(2, S, 48000, start=500).reshape(-1).astype("<f4")
+    with open(f32, "wb") as fh:
+        fh.write(b"RIFF" + struct.pack("<I", 36 + xs.nbytes) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 3, 1, 48000, 48000 * 4, 4, 32) +
+                 b"data" + struct.pack("<I", xs.nbytes) + xs.tobytes())
+    files.insert(4, str(f32))
+    files.insert(7, str(rec / "missing.wav"))
+    kw = dict(min_confidence=0.05, overlap=1.0, formats=("csv", "json"))
+    single = tmp_path / "single"; single.mkdir()
+    want = {}
+    for f in files:
+        if os.path.exists(f):
+            want[f] = pipeline.process_file(clf_tiny, f, str(single), **kw)
+    packed = tmp_path / "packed"; packed.mkdir()
+    got, status = pipeline.process_files_packed(clf_tiny, files, str(packed), pack_segments=32, **kw)
+    assert len(got) == len(files)
+    n_packed = 0
+    for f, r, st in zip(files, got, status):
+        if not os.path.exists(f):
+            assert st != 0
+            continue
+        assert st == 0, (f, st)
+        w = want[f]
+        assert (r.segments, r.detections) == (w.segments, w.detections), f
+        for fmt in ("csv", "json"):
+            a = pipeline.output_path_for(f, str(single), fmt)
+            b = pipeline.output_path_for(f, str(packed), fmt)
+            ta, tb = open(a, "rb").read(), open(b, "rb").read()
+            if fmt == "json":                                   # (the document carries its own analysis_date)
+                ta, tb = [b"\n".join(l for l in t.split(b"\n") if b"analysis_date" not in l) for t in (ta, tb)]
+            assert ta == tb, (f, fmt)
+        n_packed += r.effective_batch > r.segments          # its forward held other files' segments too
+    assert n_packed >= 5                                    # {a, b, c} and {i, j} share forwards; the others stand between breaks
+    assert sum(r.detections for r in got) > 0
+
+
 def test_non_finite_samples_stay_in_their_own_rows(clf_tiny, model_dir):
     """A corrupt decode (NaN / Inf samples) must not leak into the other rows of a batch, hang a kernel or produce
     predictions from NaN logits: rows are independent (processor.rs:363-367)."""
