@@ -89,10 +89,11 @@ struct bh_classifier {
     std::set<size_t> warmed;                 // WarmupRegistry, classifier.rs:221-246
     bh_batch_context *internal_ctx = nullptr;
     std::mutex internal_mu;
-    // One destroyed batch context is parked here and handed to the next bh_batch_context_create of the same size: the per-file
-    // pipeline creates and destroys a context per file (reference processor.rs:582-603), and a context is ~1 GB of hipMalloc
-    // plus pinned staging memory -- milliseconds per file at GPU throughput.
-    bh_batch_context *parked_ctx = nullptr;
+    // Up to two destroyed batch contexts are parked here and handed to the next bh_batch_context_create of the same size: the
+    // per-file pipeline creates and destroys a context per file (reference processor.rs:582-603), bhh_process_files keeps two in
+    // flight, and a context is ~1 GB of hipMalloc plus pinned staging memory -- milliseconds per file at GPU throughput.
+    static constexpr int N_PARKED = 2;
+    bh_batch_context *parked_ctx[N_PARKED] = {nullptr, nullptr};
     std::mutex parked_mu;
 };
 
@@ -1061,7 +1062,8 @@ void bh_classifier_destroy(bh_classifier *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->internal_ctx) ctx_destroy(c->internal_ctx);
-    if (c->parked_ctx) ctx_destroy(c->parked_ctx);
+    for (bh_batch_context *p : c->parked_ctx)
+        if (p) ctx_destroy(p);
     for (float *d : c->d_owned) (void)hipFree(d);
     (void)hipFree(c->d_blob);
     (void)hipFree(c->d_stamps);
@@ -1222,11 +1224,12 @@ int bh_batch_context_create(bh_classifier *c, size_t max_batch, bh_batch_context
     const bool keep_t = keep && keep[0] == '1';
     if (c && out && !keep_t) {
         std::lock_guard<std::mutex> g(c->parked_mu);
-        if (c->parked_ctx && c->parked_ctx->max_batch == max_batch && !c->parked_ctx->keep_tensors) {
-            *out = c->parked_ctx;
-            c->parked_ctx = nullptr;
-            return BH_OK;
-        }
+        for (bh_batch_context *&p : c->parked_ctx)
+            if (p && p->max_batch == max_batch && !p->keep_tensors) {
+                *out = p;
+                p = nullptr;
+                return BH_OK;
+            }
     }
     return ctx_create(c, max_batch, keep_t, out);
 } catch (...) { return on_exception(); }
@@ -1243,8 +1246,17 @@ void bh_batch_context_destroy(bh_batch_context *ctx) {
         bh_batch_context *old = nullptr;
         {
             std::lock_guard<std::mutex> g(c->parked_mu);
-            old = c->parked_ctx;
-            c->parked_ctx = ctx;
+            bh_batch_context **slot = nullptr;
+            for (bh_batch_context *&p : c->parked_ctx)
+                if (!p) { slot = &p; break; }
+            if (!slot) {      // both taken: the one of a different size goes, else the older (first) one
+                slot = &c->parked_ctx[0];
+                for (bh_batch_context *&p : c->parked_ctx)
+                    if (p->max_batch != ctx->max_batch) { slot = &p; break; }
+                old = *slot;
+                if (slot == &c->parked_ctx[0] && old->max_batch == ctx->max_batch) { c->parked_ctx[0] = c->parked_ctx[1]; slot = &c->parked_ctx[1]; }
+            }
+            *slot = ctx;
         }
         if (old) ctx_destroy(old);
         return;

@@ -849,109 +849,132 @@ extern "C" int bhh_process_files(bh_classifier *clf, const bhh_processing_config
         const int rc = paths[i] ? bhh_process_file(clf, &c, &results[i]) : BH_ERR_INVALID;
         if (status) status[i] = rc;
     };
-    bh_batch_context *ctx = nullptr;
-    std::unique_ptr<bh_batch_context, void (*)(bh_batch_context *)> ctx_own(nullptr, bh_batch_context_destroy);
-    void *pinned = nullptr;      // the pack buffer: the context's own pinned staging (bh_batch_context_host_buffer)
-    size_t pinned_bytes = 0;
-
-    std::vector<std::unique_ptr<PackedFile>> pack;
-    size_t pack_segs = 0;
-    const bool timing = getenv("BIRDA_HOST_TIMING") != nullptr;   // diagnostic: where a call's time goes, to stderr
-    double t_plan = 0, t_copy = 0, t_predict = 0, t_finish = 0, t_setup = 0;
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    auto flush = [&]() {
-        if (pack.empty()) return;
-        auto tp0 = now();
-        const PackedFile &f0 = *pack.front();
-        const size_t seg = f0.pl.src_segment_samples, ch = f0.channels;
-        // layout: every stream followed by `seg` frames of silence
-        size_t total_frames = 0, total_segs = 0;
-        for (auto &pf : pack) { pf->base_frame = total_frames; total_frames += pf->map.n_frames + seg; total_segs += pf->n_segments; }
-        const size_t bytes = total_frames * ch * sizeof(int16_t);
-        int rc = BH_OK;
-        if (!ctx) {
-            rc = bh_classifier_ensure_warm(clf, std::min<size_t>(pack_segments, 256));
-            if (rc == BH_OK) rc = bh_batch_context_create(clf, pack_segments, &ctx);
-            if (rc == BH_OK) {
-                ctx_own.reset(ctx);
-                pinned = bh_batch_context_host_buffer(ctx, &pinned_bytes);
-            }
-        }
-        // (a pack is at most pack_segments segments of f32 input long in the staging buffer's terms: int16 streams with their
-        //  silences fit unless the files have many channels -- then the pack goes file by file)
-        if (rc == BH_OK && pinned_bytes < bytes) rc = BH_ERR_UNSUPPORTED;
+    // Two packs in flight: while pack k's upload + forward run on a worker thread, this thread scatters and writes pack k - 1
+    // and plans and copies pack k + 1 into the other context's staging buffer.
+    struct Pack {
+        std::vector<std::unique_ptr<PackedFile>> files;
         std::vector<uint64_t> starts;
         std::vector<bh_result> rows;
-        auto tp1 = now();
-        t_setup += ms(tp0, tp1);
-        auto tp2 = tp1, tp3 = tp1;
-        if (rc == BH_OK) {
-            int16_t *dst = static_cast<int16_t *>(pinned);
-            // one copy per file, page cache -> pinned memory, on a few threads (the copies fault the mapped pages in)
-            const unsigned nthreads = (unsigned)std::min<size_t>(8, pack.size());
-            std::atomic<size_t> next{0};
-            auto work = [&] {
-                for (size_t k; (k = next.fetch_add(1)) < pack.size();) {
-                    const PackedFile &pf = *pack[k];
-                    int16_t *d = dst + pf.base_frame * ch;
-                    if (pf.map.n_frames) memcpy(d, pf.map.pcm, pf.map.n_frames * ch * sizeof(int16_t));
-                    memset(d + pf.map.n_frames * ch, 0, seg * ch * sizeof(int16_t));
-                }
-            };
-            std::vector<std::thread> th;
-            for (unsigned t = 1; t < nthreads; t++) th.emplace_back(work);
-            work();
-            for (auto &t : th) t.join();
-            starts.reserve(total_segs);
-            std::vector<uint64_t> one;
-            for (auto &pf : pack) {
-                one.resize(pf->n_segments);
-                bh_segment_starts(pf->map.n_frames, seg, pf->pl.src_overlap_samples, one.data(), one.size());
-                for (uint64_t v : one) starts.push_back(pf->base_frame + v);
-            }
-            rows.resize(total_segs);
-            tp2 = now();
-            void *guard = bhh_watchdog_start(watchdog_timeout_secs() * 1000, total_segs);
-            rc = bh_predict_pcm16_at(clf, ctx, dst, total_frames, (uint32_t)ch, f0.pl.source_rate, starts.data(), total_segs, rows.data());
-            bhh_watchdog_cancel(guard);
-            tp3 = now();
-            t_copy += ms(tp1, tp2);
-            t_predict += ms(tp2, tp3);
+        size_t total_frames = 0, total_segs = 0, seg = 0, ch = 0;
+        uint32_t rate = 0;
+        int rc = BH_OK;
+        int slot = 0;
+        std::thread worker;
+        ~Pack() { if (worker.joinable()) worker.join(); }   // (an exception on the way: never leave a running thread behind)
+    };
+    bh_batch_context *ctx[2] = {nullptr, nullptr};
+    std::unique_ptr<bh_batch_context, void (*)(bh_batch_context *)> ctx_own0(nullptr, bh_batch_context_destroy), ctx_own1(nullptr, bh_batch_context_destroy);
+    const bool timing = getenv("BIRDA_HOST_TIMING") != nullptr;   // diagnostic: where a call's time goes, to stderr
+    double t_plan = 0, t_copy = 0, t_wait = 0, t_finish = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+
+    std::unique_ptr<Pack> building(new Pack), running;   // `running`: its forward is on the worker thread
+    size_t n_packs = 0;
+
+    // scatter the rows of a finished pack back to its files: detections, sort, outputs, result records
+    auto complete = [&](Pack &p) {
+        if (p.worker.joinable()) {
+            auto t0 = now();
+            p.worker.join();
+            t_wait += ms(t0, now());
         }
-        if (rc == BH_ERR_UNSUPPORTED) {   // does not fit the staging buffer: the reference's way, one file at a time
-            for (auto &pfp : pack) single(pfp->index);
-            pack.clear();
-            pack_segs = 0;
+        auto t1 = now();
+        if (p.rc == BH_ERR_UNSUPPORTED) {   // did not fit the staging buffer: the reference's way, one file at a time
+            for (auto &pfp : p.files) single(pfp->index);
             return;
         }
         size_t row = 0;
-        for (auto &pfp : pack) {
+        for (auto &pfp : p.files) {
             PackedFile &pf = *pfp;
             bhh_process_result *res = &results[pf.index];
-            int frc = rc;
-            if (rc == BH_OK) {
+            int frc = p.rc;
+            if (p.rc == BH_OK) {
                 std::vector<Detection> detections;
                 RunStats st;
                 for (size_t i = 0; i < pf.n_segments; i++, row++) {
-                    float t0, t1;
-                    chunk_times(pf.pl, (size_t)(starts[row] - pf.base_frame), t0, t1);
-                    collect_detections(clf, pf.pl, rows[row], t0, t1, detections);
+                    float t0s, t1s;
+                    chunk_times(pf.pl, (size_t)(p.starts[row] - pf.base_frame), t0s, t1s);
+                    collect_detections(clf, pf.pl, p.rows[row], t0s, t1s, detections);
                 }
                 st.segments = pf.n_segments;
                 st.batches = 1;
-                res->effective_batch = total_segs;
+                res->effective_batch = p.total_segs;
                 auto nolap = [](const char *) {};
                 frc = finish_file(cfg, pf.pl, formats, detections, st, pf.has_duration, pf.duration, pf.overlap_secs, pf.t_start, res, nolap);
                 res->front_end = BHH_FRONT_END_DEVICE;
             }
             if (status) status[pf.index] = frc;
         }
-        t_finish += ms(tp3, now());
-        pack.clear();
-        pack_segs = 0;
+        t_finish += ms(t1, now());
+    };
+    auto drain = [&]() {
+        if (running) { complete(*running); running.reset(); }
+    };
+    // assemble `building` in its slot's staging buffer, hand it to the worker, then finish the pack that ran before it
+    auto flush = [&]() {
+        if (building->files.empty()) return;
+        std::unique_ptr<Pack> p = std::move(building);
+        building.reset(new Pack);
+        auto tp0 = now();
+        p->slot = (int)(n_packs++ & 1);
+        const PackedFile &f0 = *p->files.front();
+        p->seg = f0.pl.src_segment_samples; p->ch = f0.channels; p->rate = f0.pl.source_rate;
+        for (auto &pf : p->files) { pf->base_frame = p->total_frames; p->total_frames += pf->map.n_frames + p->seg; p->total_segs += pf->n_segments; }
+        const size_t bytes = p->total_frames * p->ch * sizeof(int16_t);
+        if (!ctx[p->slot]) {
+            int rc = bh_classifier_ensure_warm(clf, std::min<size_t>(pack_segments, 256));
+            if (rc == BH_OK) rc = bh_batch_context_create(clf, pack_segments, &ctx[p->slot]);
+            if (rc == BH_OK) (p->slot ? ctx_own1 : ctx_own0).reset(ctx[p->slot]);
+            p->rc = rc;
+        }
+        size_t cap = 0;
+        int16_t *dst = p->rc == BH_OK ? static_cast<int16_t *>(bh_batch_context_host_buffer(ctx[p->slot], &cap)) : nullptr;
+        // (int16 streams with their silences fit the f32 staging buffer of pack_segments segments unless the files have many
+        //  channels -- then the pack goes file by file)
+        if (p->rc == BH_OK && cap < bytes) p->rc = BH_ERR_UNSUPPORTED;
+        if (p->rc == BH_OK) {
+            // one copy per file, page cache -> pinned memory, on a few threads (the copies fault the mapped pages in)
+            const unsigned nthreads = (unsigned)std::min<size_t>(8, p->files.size());
+            std::atomic<size_t> next{0};
+            Pack *pp = p.get();
+            auto work = [&next, pp, dst] {
+                for (size_t k; (k = next.fetch_add(1)) < pp->files.size();) {
+                    const PackedFile &pf = *pp->files[k];
+                    int16_t *d = dst + pf.base_frame * pp->ch;
+                    if (pf.map.n_frames) memcpy(d, pf.map.pcm, pf.map.n_frames * pp->ch * sizeof(int16_t));
+                    memset(d + pf.map.n_frames * pp->ch, 0, pp->seg * pp->ch * sizeof(int16_t));
+                }
+            };
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < nthreads; t++) th.emplace_back(work);
+            work();
+            for (auto &t : th) t.join();
+            p->starts.reserve(p->total_segs);
+            std::vector<uint64_t> one;
+            for (auto &pf : p->files) {
+                one.resize(pf->n_segments);
+                bh_segment_starts(pf->map.n_frames, p->seg, pf->pl.src_overlap_samples, one.data(), one.size());
+                for (uint64_t v : one) p->starts.push_back(pf->base_frame + v);
+            }
+            p->rows.resize(p->total_segs);
+        }
+        t_copy += ms(tp0, now());
+        if (p->rc == BH_OK) {
+            Pack *pp = p.get();
+            bh_batch_context *c = ctx[p->slot];
+            p->worker = std::thread([pp, c, clf, dst] {
+                void *guard = bhh_watchdog_start(watchdog_timeout_secs() * 1000, pp->total_segs);
+                pp->rc = bh_predict_pcm16_at(clf, c, dst, pp->total_frames, (uint32_t)pp->ch, pp->rate, pp->starts.data(), pp->total_segs, pp->rows.data());
+                bhh_watchdog_cancel(guard);
+            });
+        }
+        std::unique_ptr<Pack> prev = std::move(running);
+        running = std::move(p);
+        if (prev) complete(*prev);     // (its forward ended before this pack's began: one context's stream at a time per slot)
     };
 
+    size_t pack_segs = 0;
     for (size_t i = 0; i < n_files; i++) {
         if (!paths[i]) { if (status) status[i] = BH_ERR_INVALID; continue; }
         std::unique_ptr<PackedFile> pf(new PackedFile);
@@ -961,20 +984,23 @@ extern "C" int bhh_process_files(bh_classifier *clf, const bhh_processing_config
         t_plan += ms(pf->t_start, now());
         if (!can) {
             flush();             // keep the order of outputs and of any side effects
+            pack_segs = 0;
+            drain();
             single(i);
             continue;
         }
-        if (!pack.empty()) {
-            const PackedFile &f0 = *pack.front();
-            if (f0.pl.source_rate != pf->pl.source_rate || f0.channels != pf->channels || pack_segs + pf->n_segments > pack_segments) flush();
+        if (!building->files.empty()) {
+            const PackedFile &f0 = *building->files.front();
+            if (f0.pl.source_rate != pf->pl.source_rate || f0.channels != pf->channels || pack_segs + pf->n_segments > pack_segments) { flush(); pack_segs = 0; }
         }
         pack_segs += pf->n_segments;
-        pack.push_back(std::move(pf));
+        building->files.push_back(std::move(pf));
     }
     flush();
+    drain();
     if (timing)
-        fprintf(stderr, "process_files: plan %.2f ms, pack set-up %.2f, copy %.2f, predict %.2f, detections + outputs %.2f\n", t_plan, t_setup,
-                t_copy, t_predict, t_finish);
+        fprintf(stderr, "process_files: %zu packs; plan %.2f ms, assemble %.2f, waiting for forwards %.2f, detections + outputs %.2f\n", n_packs,
+                t_plan, t_copy, t_wait, t_finish);
     return BH_OK;
 } catch (...) { return h_on_exception(); }
 
