@@ -330,7 +330,7 @@ def should_process(input_path: str, output_dir: Optional[str], formats=None, for
 
 
 def process_files(classifier, files: List[str], rank: int = 0, world: int = 1, durations: Optional[List[float]] = None,
-                  force: bool = True, **kwargs) -> List[ProcessResult]:
+                  force: bool = True, packed: bool = False, **kwargs) -> List[ProcessResult]:
     """Directory mode on `world` processes (one per GPU): rank g takes the files `sharding.assign_by_duration` gives
     it (the reference scales out as N processes over one directory with lock files, file_lock.rs:36-88)
     and runs them through `process_file` one after another on its own classifier, as `process_files_sequential`
@@ -349,4 +349,15 @@ def process_files(classifier, files: List[str], rank: int = 0, world: int = 1, d
             durations.append(d.duration_hint() or 0.0)
             d.close()
     mine = sharding.assign_by_duration(durations, world)[rank]
+    if packed:     # short recordings share uploads and forwards (bhh_process_files); same outputs
+        allowed = {"output_dir", "min_confidence", "overlap", "csv_bom", "formats", "csv_columns", "model_name", "pack_segments"}
+        extra = set(kwargs) - allowed - {"batch_size"}
+        if extra:
+            raise ValueError(f"process_files(packed=True) does not take {sorted(extra)}")
+        kw = {k: v for k, v in kwargs.items() if k in allowed}
+        res, status = process_files_packed(classifier, [files[i] for i in mine], **kw)
+        for f, st in zip([files[i] for i in mine], status):
+            if st != 0:
+                raise BirdaHipError(st, f"process_files: {f}")
+        return res
     return [process_file(classifier, files[i], **kwargs) for i in mine]

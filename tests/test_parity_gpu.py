@@ -955,6 +955,10 @@ def test_directory_mode_two_ranks_cover_every_file_once(clf_tiny, model_dir, tmp
             seen.append(name)
             assert open(r.output_path, "rb").read() == open(single / name, "rb").read()
     assert sorted(seen) == sorted(os.path.basename(r.output_path) for r in ref)
+    # the same share with its short files packed into shared forwards (bhh_process_files): the same CSV files
+    pk = tmp_path / "packed_rank0"; pk.mkdir()
+    res = pipeline.process_files(clf_tiny, files, rank=0, world=2, output_dir=str(pk), min_confidence=0.05, packed=True)
+    assert res and all(open(r.output_path, "rb").read() == open(single / os.path.basename(r.output_path), "rb").read() for r in res)
     # resume (should_process, coordinator.rs:96-143): with the outputs in place nothing is left to do unless forced, and a
     # missing output brings exactly its file back
     assert pipeline.process_files(clf_tiny, files, output_dir=str(single), min_confidence=0.05, batch_size=4, force=False) == []
