@@ -95,6 +95,8 @@ SYMBOLS = [
     ("bh_segment_starts", _SZ, [_SZ, _SZ, _SZ, _VP, _SZ]),
     ("bh_predict_pcm16", C.c_int, [_VP, _VP, _VP, _SZ, C.c_uint32, C.c_uint32, _SZ, C.POINTER(BhResult), _SZ,
                                    C.POINTER(_SZ), _VP]),
+    ("bh_predict_pcm", C.c_int, [_VP, _VP, _VP, C.c_uint32, _SZ, C.c_uint32, C.c_uint32, _SZ, C.POINTER(BhResult), _SZ, C.POINTER(_SZ), _VP]),
+    ("bh_predict_pcm_at", C.c_int, [_VP, _VP, _VP, C.c_uint32, _SZ, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), _SZ, C.POINTER(BhResult)]),
     ("bh_predict_pcm16_at", C.c_int, [_VP, _VP, _VP, _SZ, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), _SZ, C.POINTER(BhResult)]),
     ("bh_resample", C.c_int, [_VP, _VP, _SZ, C.c_uint32, C.c_uint32, _VP, _SZ, C.POINTER(_SZ)]),
     ("bh_resample_output_len", C.c_int, [_SZ, C.c_uint32, C.c_uint32, C.POINTER(_SZ)]),

@@ -1537,15 +1537,22 @@ size_t bh_segment_starts(size_t n_frames, size_t segment_samples, size_t overlap
     return n;
 }
 
-static int predict_pcm16_core(bh_classifier *c, bh_batch_context *ctx, const int16_t *pcm, size_t n_frames, uint32_t channels,
+static int predict_pcm16_core(bh_classifier *c, bh_batch_context *ctx, const void *pcm, uint32_t fmt, size_t n_frames, uint32_t channels,
                               uint32_t source_rate, const std::vector<uint64_t> &starts, size_t seg, bh_result *out);
+static inline size_t pcm_bytes_per_sample(uint32_t fmt) { return fmt == BH_PCM_S16 ? 2 : fmt == BH_PCM_S24 ? 3 : (fmt == BH_PCM_S32 || fmt == BH_PCM_F32) ? 4 : 0; }
 
 int bh_predict_pcm16(bh_classifier *c, bh_batch_context *ctx, const int16_t *pcm, size_t n_frames, uint32_t channels,
                      uint32_t source_rate, size_t overlap_samples, bh_result *out, size_t out_cap, size_t *n_segments,
-                     uint64_t *start_samples) try {
+                     uint64_t *start_samples) {
+    return bh_predict_pcm(c, ctx, pcm, BH_PCM_S16, n_frames, channels, source_rate, overlap_samples, out, out_cap, n_segments, start_samples);
+}
+
+int bh_predict_pcm(bh_classifier *c, bh_batch_context *ctx, const void *pcm, uint32_t sample_format, size_t n_frames, uint32_t channels,
+                   uint32_t source_rate, size_t overlap_samples, bh_result *out, size_t out_cap, size_t *n_segments,
+                   uint64_t *start_samples) try {
     int rc = check_ctx(c, ctx);
     if (rc != BH_OK) return rc;
-    if (!pcm || !out || !n_segments || channels == 0) return fail(BH_ERR_INVALID, "predict_pcm16: bad arguments");
+    if (!pcm || !out || !n_segments || channels == 0 || !pcm_bytes_per_sample(sample_format)) return fail(BH_ERR_INVALID, "predict_pcm: bad arguments");
     const auto &h = c->model.h;
     const bool resampling = source_rate != h.sample_rate;
     // segment and overlap lengths at the source rate (processor.rs:67-82)
@@ -1559,14 +1566,19 @@ int bh_predict_pcm16(bh_classifier *c, bh_batch_context *ctx, const int16_t *pcm
     std::vector<uint64_t> starts(nseg);
     bh_segment_starts(n_frames, seg, ovl, starts.data(), nseg);
     if (start_samples) memcpy(start_samples, starts.data(), nseg * sizeof(uint64_t));
-    return predict_pcm16_core(c, ctx, pcm, n_frames, channels, source_rate, starts, seg, out);
+    return predict_pcm16_core(c, ctx, pcm, sample_format, n_frames, channels, source_rate, starts, seg, out);
 } catch (...) { return on_exception(); }
 
 int bh_predict_pcm16_at(bh_classifier *c, bh_batch_context *ctx, const int16_t *pcm, size_t n_frames, uint32_t channels,
-                        uint32_t source_rate, const uint64_t *start_samples, size_t n_segments, bh_result *out) try {
+                        uint32_t source_rate, const uint64_t *start_samples, size_t n_segments, bh_result *out) {
+    return bh_predict_pcm_at(c, ctx, pcm, BH_PCM_S16, n_frames, channels, source_rate, start_samples, n_segments, out);
+}
+
+int bh_predict_pcm_at(bh_classifier *c, bh_batch_context *ctx, const void *pcm, uint32_t sample_format, size_t n_frames, uint32_t channels,
+                      uint32_t source_rate, const uint64_t *start_samples, size_t n_segments, bh_result *out) try {
     int rc = check_ctx(c, ctx);
     if (rc != BH_OK) return rc;
-    if (!pcm || !out || !start_samples || channels == 0) return fail(BH_ERR_INVALID, "predict_pcm16_at: bad arguments");
+    if (!pcm || !out || !start_samples || channels == 0 || !pcm_bytes_per_sample(sample_format)) return fail(BH_ERR_INVALID, "predict_pcm_at: bad arguments");
     if (n_segments == 0) return BH_OK;
     const auto &h = c->model.h;
     const size_t seg = source_rate != h.sample_rate ? (size_t)std::ceil((double)h.sample_count * source_rate / h.sample_rate) : h.sample_count;
@@ -1575,10 +1587,10 @@ int bh_predict_pcm16_at(bh_classifier *c, bh_batch_context *ctx, const int16_t *
         if (starts[i] >= n_frames || (i && starts[i] < starts[i - 1]))
             return fail(BH_ERR_INVALID, "predict_pcm16_at: segment %zu starts at %llu (stream of %zu frames; starts must not decrease)", i,
                         (unsigned long long)starts[i], n_frames);
-    return predict_pcm16_core(c, ctx, pcm, n_frames, channels, source_rate, starts, seg, out);
+    return predict_pcm16_core(c, ctx, pcm, sample_format, n_frames, channels, source_rate, starts, seg, out);
 } catch (...) { return on_exception(); }
 
-static int predict_pcm16_core(bh_classifier *c, bh_batch_context *ctx, const int16_t *pcm, size_t n_frames, uint32_t channels,
+static int predict_pcm16_core(bh_classifier *c, bh_batch_context *ctx, const void *pcm, uint32_t fmt, size_t n_frames, uint32_t channels,
                               uint32_t source_rate, const std::vector<uint64_t> &starts, size_t seg, bh_result *out) {
     int rc = BH_OK;
     const auto &h = c->model.h;
@@ -1603,7 +1615,7 @@ static int predict_pcm16_core(bh_classifier *c, bh_batch_context *ctx, const int
             return fail(BH_ERR_HIP, "predict_pcm16: scratch allocation failed");
         ctx->raw_len = seg;
     }
-    const size_t frame_bytes = (size_t)channels * sizeof(int16_t);
+    const size_t frame_bytes = (size_t)channels * pcm_bytes_per_sample(fmt);
     const size_t stage_cap = ctx->max_batch * (size_t)h.sample_count * sizeof(float);   // the pinned input staging buffer
     bool pcm_pinned = false;
     {
@@ -1621,7 +1633,7 @@ static int predict_pcm16_core(bh_classifier *c, bh_batch_context *ctx, const int
             ctx->pcm_cap = bytes;
         }
         // the segment kernel indexes the stream by absolute frame: hand it the slice buffer's virtual origin
-        const int16_t *d_origin = ctx->d_pcm - f0 * channels;
+        const char *d_origin = reinterpret_cast<const char *>(ctx->d_pcm) - f0 * frame_bytes;   // (never dereferenced below frame f0)
         const char *src = reinterpret_cast<const char *>(pcm) + f0 * frame_bytes;
         const bool staged = !pcm_pinned && bytes <= stage_cap;   // (more than two channels: the span can exceed the staging buffer)
         char *stage = reinterpret_cast<char *>(ctx->h_input);
@@ -1677,11 +1689,11 @@ static int predict_pcm16_core(bh_classifier *c, bh_batch_context *ctx, const int
                 float *d_in = ctx->d_input + s0 * h.sample_count;
                 if (resampling) {
                     float *d_rw = ctx->d_raw + s0 * seg;
-                    bh::launch_segment_pcm16(d_origin, n_frames, (int)channels, ctx->d_starts + b0 + s0, (int)ns, (int)seg, d_rw, seg, ctx->stream);
+                    bh::launch_segment_pcm(d_origin, (int)fmt, n_frames, (int)channels, ctx->d_starts + b0 + s0, (int)ns, (int)seg, d_rw, seg, ctx->stream);
                     rc = bh_resample_device(c, ctx, d_rw, seg, seg, source_rate, h.sample_rate, d_in, h.sample_count, h.sample_count, ns);
                     if (rc != BH_OK) break;
                 } else {
-                    bh::launch_segment_pcm16(d_origin, n_frames, (int)channels, ctx->d_starts + b0 + s0, (int)ns, (int)seg, d_in, seg, ctx->stream);
+                    bh::launch_segment_pcm(d_origin, (int)fmt, n_frames, (int)channels, ctx->d_starts + b0 + s0, (int)ns, (int)seg, d_in, seg, ctx->stream);
                 }
                 rc = forward_slice(c, ctx, d_in, ns, ctx->d_logits + s0 * h.n_classes, ctx->d_topk_idx + s0 * c->top_k,
                                    ctx->d_topk_conf + s0 * c->top_k);

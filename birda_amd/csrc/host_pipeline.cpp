@@ -553,8 +553,9 @@ int run_host_front_end(bh_classifier *clf, const FilePlan &pl, const bh_model_in
 // DEVICE front end: the PCM16 frames of the file are mapped and handed to bh_predict_pcm16 span by span.
 // A span starts on a multiple of the segment step, so its windows are the stream's windows (decode.rs:150-202); all
 // but the last span end on a full segment, whose trailing overlap remainder belongs to the next span and is dropped here.
-int run_device_front_end(bh_classifier *clf, const FilePlan &pl, const bh_model_info &info, bh_batch_context *ctx, const int16_t *pcm,
-                         size_t n_frames, uint32_t channels, std::vector<Detection> &detections, RunStats &st, std::string &fail_msg) {
+int run_device_front_end(bh_classifier *clf, const FilePlan &pl, const bh_model_info &info, bh_batch_context *ctx, const unsigned char *pcm,
+                         uint32_t fmt, size_t bps, size_t n_frames, uint32_t channels, std::vector<Detection> &detections, RunStats &st,
+                         std::string &fail_msg) {
     (void)info;
     const size_t seg = pl.src_segment_samples, ovl = pl.src_overlap_samples;
     if (ovl >= seg) {   // next_segment's check, decode.rs:156-162
@@ -572,8 +573,8 @@ int run_device_front_end(bh_classifier *clf, const FilePlan &pl, const bh_model_
         const size_t frames = last ? n_frames - f0 : full_span;
         size_t n_seg = 0;
         void *guard = bhh_watchdog_start(watchdog_timeout_secs() * 1000, std::min(pl.effective, span_segments));
-        const int r = bh_predict_pcm16(clf, ctx, pcm + f0 * channels, frames, channels, pl.source_rate, pl.overlap_samples, results.data(),
-                                       results.size(), &n_seg, starts.data());
+        const int r = bh_predict_pcm(clf, ctx, pcm + f0 * channels * bps, fmt, frames, channels, pl.source_rate, pl.overlap_samples, results.data(),
+                                     results.size(), &n_seg, starts.data());
         bhh_watchdog_cancel(guard);
         if (r != BH_OK) { fail_msg = std::string("Inference: ") + bh_last_error(); return r; }
         const size_t keep = last ? n_seg : std::min(n_seg, span_segments);
@@ -595,11 +596,15 @@ int run_device_front_end(bh_classifier *clf, const FilePlan &pl, const bh_model_
 struct PcmMapping {
     void *base = MAP_FAILED;
     size_t length = 0;
-    const int16_t *pcm = nullptr;
+    const unsigned char *pcm = nullptr;   // the data chunk: interleaved samples in the file's own layout
+    uint32_t fmt = 0;                     // BH_PCM_*
+    size_t bps = 0;                       // bytes per sample
     size_t n_frames = 0;
     ~PcmMapping() { if (base != MAP_FAILED) munmap(base, length); }
     bool open(const bh_decoder &d) {
-        if (d.fmt != FMT_S16 || (d.data_offset & 1)) return false;
+        fmt = d.fmt == FMT_S16 ? BH_PCM_S16 : d.fmt == FMT_S24 ? BH_PCM_S24 : d.fmt == FMT_S32 ? BH_PCM_S32 : d.fmt == FMT_F32 ? BH_PCM_F32 : 0;
+        bps = fmt == BH_PCM_S16 ? 2 : fmt == BH_PCM_S24 ? 3 : 4;
+        if (!fmt) return false;            // (8-bit PCM and everything symphonia decodes stay on the host front end)
         const int fd = ::open(d.path.c_str(), O_RDONLY);
         if (fd < 0) return false;
         length = (size_t)(d.data_offset + d.data_bytes);
@@ -609,8 +614,8 @@ struct PcmMapping {
         ::close(fd);
         if (d.data_bytes && base == MAP_FAILED) return false;
         if (base != MAP_FAILED) (void)madvise(base, length, MADV_SEQUENTIAL);
-        pcm = base != MAP_FAILED ? reinterpret_cast<const int16_t *>(static_cast<const char *>(base) + d.data_offset) : nullptr;
-        n_frames = (size_t)(d.data_bytes / ((uint64_t)d.channels * 2));
+        pcm = base != MAP_FAILED ? static_cast<const unsigned char *>(base) + d.data_offset : nullptr;
+        n_frames = (size_t)(d.data_bytes / ((uint64_t)d.channels * bps));
         return true;
     }
 };
@@ -738,7 +743,7 @@ extern "C" int bhh_process_file(bh_classifier *clf, const bhh_processing_config 
     if (cfg->front_end != BHH_FRONT_END_HOST && !bat_mode) {
         device = map.open(*probe);
         if (!device && cfg->front_end == BHH_FRONT_END_DEVICE)
-            return hfail(BH_ERR_UNSUPPORTED, "process_file: the device front end takes PCM16 WAV files only: " + pl.path);
+            return hfail(BH_ERR_UNSUPPORTED, "process_file: the device front end takes PCM16 / PCM24 / PCM32 / float32 WAV files only: " + pl.path);
     }
     const uint32_t channels = (uint32_t)probe->channels;
     probe_own.reset();
@@ -769,7 +774,7 @@ extern "C" int bhh_process_file(bh_classifier *clf, const bhh_processing_config 
     std::vector<Detection> detections;
     RunStats st;
     std::string fail_msg;
-    const int fail_code = device ? run_device_front_end(clf, pl, info, ctx, map.pcm, map.n_frames, channels, detections, st, fail_msg)
+    const int fail_code = device ? run_device_front_end(clf, pl, info, ctx, map.pcm, map.fmt, map.bps, map.n_frames, channels, detections, st, fail_msg)
                                  : run_host_front_end(clf, pl, info, ctx, detections, st, fail_msg);
     lap("inference");
     ctx_own.reset();
@@ -855,8 +860,8 @@ extern "C" int bhh_process_files(bh_classifier *clf, const bhh_processing_config
         std::vector<std::unique_ptr<PackedFile>> files;
         std::vector<uint64_t> starts;
         std::vector<bh_result> rows;
-        size_t total_frames = 0, total_segs = 0, seg = 0, ch = 0;
-        uint32_t rate = 0;
+        size_t total_frames = 0, total_segs = 0, seg = 0, ch = 0, bps = 2;
+        uint32_t rate = 0, fmt = BH_PCM_S16;
         int rc = BH_OK;
         int slot = 0;
         std::thread worker;
@@ -919,9 +924,9 @@ extern "C" int bhh_process_files(bh_classifier *clf, const bhh_processing_config
         auto tp0 = now();
         p->slot = (int)(n_packs++ & 1);
         const PackedFile &f0 = *p->files.front();
-        p->seg = f0.pl.src_segment_samples; p->ch = f0.channels; p->rate = f0.pl.source_rate;
+        p->seg = f0.pl.src_segment_samples; p->ch = f0.channels; p->rate = f0.pl.source_rate; p->fmt = f0.map.fmt; p->bps = f0.map.bps;
         for (auto &pf : p->files) { pf->base_frame = p->total_frames; p->total_frames += pf->map.n_frames + p->seg; p->total_segs += pf->n_segments; }
-        const size_t bytes = p->total_frames * p->ch * sizeof(int16_t);
+        const size_t bytes = p->total_frames * p->ch * p->bps;
         if (!ctx[p->slot]) {
             int rc = bh_classifier_ensure_warm(clf, std::min<size_t>(pack_segments, 256));
             if (rc == BH_OK) rc = bh_batch_context_create(clf, pack_segments, &ctx[p->slot]);
@@ -929,7 +934,7 @@ extern "C" int bhh_process_files(bh_classifier *clf, const bhh_processing_config
             p->rc = rc;
         }
         size_t cap = 0;
-        int16_t *dst = p->rc == BH_OK ? static_cast<int16_t *>(bh_batch_context_host_buffer(ctx[p->slot], &cap)) : nullptr;
+        unsigned char *dst = p->rc == BH_OK ? static_cast<unsigned char *>(bh_batch_context_host_buffer(ctx[p->slot], &cap)) : nullptr;
         // (int16 streams with their silences fit the f32 staging buffer of pack_segments segments unless the files have many
         //  channels -- then the pack goes file by file)
         if (p->rc == BH_OK && cap < bytes) p->rc = BH_ERR_UNSUPPORTED;
@@ -941,9 +946,10 @@ extern "C" int bhh_process_files(bh_classifier *clf, const bhh_processing_config
             auto work = [&next, pp, dst] {
                 for (size_t k; (k = next.fetch_add(1)) < pp->files.size();) {
                     const PackedFile &pf = *pp->files[k];
-                    int16_t *d = dst + pf.base_frame * pp->ch;
-                    if (pf.map.n_frames) memcpy(d, pf.map.pcm, pf.map.n_frames * pp->ch * sizeof(int16_t));
-                    memset(d + pf.map.n_frames * pp->ch, 0, pp->seg * pp->ch * sizeof(int16_t));
+                    const size_t fb = pp->ch * pp->bps;      // bytes per frame; zero bytes are silence in all four formats
+                    unsigned char *d = dst + pf.base_frame * fb;
+                    if (pf.map.n_frames) memcpy(d, pf.map.pcm, pf.map.n_frames * fb);
+                    memset(d + pf.map.n_frames * fb, 0, pp->seg * fb);
                 }
             };
             std::vector<std::thread> th;
@@ -965,7 +971,7 @@ extern "C" int bhh_process_files(bh_classifier *clf, const bhh_processing_config
             bh_batch_context *c = ctx[p->slot];
             p->worker = std::thread([pp, c, clf, dst] {
                 void *guard = bhh_watchdog_start(watchdog_timeout_secs() * 1000, pp->total_segs);
-                pp->rc = bh_predict_pcm16_at(clf, c, dst, pp->total_frames, (uint32_t)pp->ch, pp->rate, pp->starts.data(), pp->total_segs, pp->rows.data());
+                pp->rc = bh_predict_pcm_at(clf, c, dst, pp->fmt, pp->total_frames, (uint32_t)pp->ch, pp->rate, pp->starts.data(), pp->total_segs, pp->rows.data());
                 bhh_watchdog_cancel(guard);
             });
         }
@@ -991,7 +997,8 @@ extern "C" int bhh_process_files(bh_classifier *clf, const bhh_processing_config
         }
         if (!building->files.empty()) {
             const PackedFile &f0 = *building->files.front();
-            if (f0.pl.source_rate != pf->pl.source_rate || f0.channels != pf->channels || pack_segs + pf->n_segments > pack_segments) { flush(); pack_segs = 0; }
+            if (f0.pl.source_rate != pf->pl.source_rate || f0.channels != pf->channels || f0.map.fmt != pf->map.fmt ||
+                pack_segs + pf->n_segments > pack_segments) { flush(); pack_segs = 0; }
         }
         pack_segs += pf->n_segments;
         building->files.push_back(std::move(pf));

@@ -234,8 +234,9 @@ struct FrontendParams {
 };
 
 // interleaved PCM16 on the device -> mono f32 segments starting at d_starts[i] (zero-padded tail)
-void launch_segment_pcm16(const int16_t *d_pcm, size_t n_frames, int channels, const unsigned long long *d_starts,
-                          int n_seg, int seg_len, float *d_out, size_t out_stride, hipStream_t s);
+// sample_format: BH_PCM_S16 = 1, BH_PCM_S24 = 2, BH_PCM_S32 = 3, BH_PCM_F32 = 4 (birda_hip.h); d_pcm_origin = device byte address of frame 0
+void launch_segment_pcm(const void *d_pcm_origin, int sample_format, size_t n_frames, int channels, const unsigned long long *d_starts,
+                        int n_seg, int seg_len, float *d_out, size_t out_stride, hipStream_t s);
 // minmax [n_seg][8][2]: min / max of eight slices of every segment; in_bad (nullable) [n_seg][8]: 1 where the slice holds an inf / NaN
 void launch_minmax(const float *x, float *minmax, unsigned *in_bad, int n_seg, int sample_count, hipStream_t s);
 void launch_mel(const float *x, const float *minmax, float *spec, const FrontendParams &p,

@@ -78,13 +78,27 @@ void launch_minmax(const float *x, float *minmax, unsigned *in_bad, int n_seg, i
 }
 
 // ---------------------------------------------------------------------------------------
-// PCM16 -> mono f32 segments on the device (reference src/audio/decode.rs:353-411 append_samples:
-// s / 32768.0 per channel, channels summed then divided by their count; :150-202 next_segment: the
-// segment is zero-padded past the end of the stream).  grid (blocks over the segment, n_seg).
+// PCM -> mono f32 segments on the device (reference src/audio/decode.rs:353-411 append_samples:
+// s / 32768.0 per channel for 16-bit, s / 2147483648.0 for 32-bit -- and for 24-bit, which symphonia widens into its S32
+// buffer (value << 8) -- float32 as is; channels summed then divided by their count; :150-202 next_segment: the
+// segment is zero-padded past the end of the stream).  grid (blocks over the segment, n_seg).  `pcm` is the byte address of
+// frame 0 (a virtual origin: the caller's buffer holds the slice's frames only); FMT = the host decoder's sample formats.
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void segment_pcm16_kernel(const int16_t *__restrict__ pcm, long n_frames, int channels,
-                                                             const unsigned long long *__restrict__ starts,
-                                                             int seg_len, float *__restrict__ out, long out_stride) {
+template <int FMT>   // 1: int16, 2: int24 (3 bytes, little endian), 3: int32, 4: float32
+__device__ __forceinline__ float pcm_sample(const unsigned char *p) {
+    if constexpr (FMT == 1) return (float)*reinterpret_cast<const int16_t *>(p) / 32768.0f;
+    else if constexpr (FMT == 2) {
+        const int32_t v = (int32_t)((uint32_t)p[0] << 8 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 24);
+        return (float)v / 2147483648.0f;
+    } else if constexpr (FMT == 3) return (float)*reinterpret_cast<const int32_t *>(p) / 2147483648.0f;
+    else return *reinterpret_cast<const float *>(p);
+}
+
+template <int FMT>
+__global__ __launch_bounds__(256) void segment_pcm_kernel(const unsigned char *__restrict__ pcm, long n_frames, int channels,
+                                                           const unsigned long long *__restrict__ starts,
+                                                           int seg_len, float *__restrict__ out, long out_stride) {
+    constexpr int BPS = FMT == 1 ? 2 : FMT == 2 ? 3 : 4;
     const int seg = blockIdx.y;
     const long s0 = (long)starts[seg];
     float *o = out + (long)seg * out_stride;
@@ -93,10 +107,10 @@ __global__ __launch_bounds__(256) void segment_pcm16_kernel(const int16_t *__res
         float v = 0.0f;
         if (f < n_frames) {
             if (channels == 1) {
-                v = (float)pcm[f] / 32768.0f;
+                v = pcm_sample<FMT>(pcm + f * BPS);
             } else {
                 float sum = 0.0f;
-                for (int c = 0; c < channels; c++) sum += (float)pcm[f * channels + c] / 32768.0f;
+                for (int c = 0; c < channels; c++) sum += pcm_sample<FMT>(pcm + (f * channels + c) * BPS);
                 v = sum / (float)channels;
             }
         }
@@ -104,11 +118,18 @@ __global__ __launch_bounds__(256) void segment_pcm16_kernel(const int16_t *__res
     }
 }
 
-void launch_segment_pcm16(const int16_t *d_pcm, size_t n_frames, int channels, const unsigned long long *d_starts,
-                          int n_seg, int seg_len, float *d_out, size_t out_stride, hipStream_t s) {
+void launch_segment_pcm(const void *d_pcm_origin, int sample_format, size_t n_frames, int channels, const unsigned long long *d_starts,
+                        int n_seg, int seg_len, float *d_out, size_t out_stride, hipStream_t s) {
     dim3 grid((unsigned)std::min<size_t>(((size_t)seg_len + 255) / 256, 64), n_seg), block(256);
-    hipLaunchKernelGGL(segment_pcm16_kernel, grid, block, 0, s, d_pcm, (long)n_frames, channels, d_starts, seg_len, d_out,
-                       (long)out_stride);
+    const unsigned char *p = static_cast<const unsigned char *>(d_pcm_origin);
+#define BH_SEG(F) hipLaunchKernelGGL(segment_pcm_kernel<F>, grid, block, 0, s, p, (long)n_frames, channels, d_starts, seg_len, d_out, (long)out_stride)
+    switch (sample_format) {
+    case 2: BH_SEG(2); break;
+    case 3: BH_SEG(3); break;
+    case 4: BH_SEG(4); break;
+    default: BH_SEG(1); break;
+    }
+#undef BH_SEG
 }
 
 // ---------------------------------------------------------------------------------------

@@ -268,7 +268,7 @@ def process_file(classifier, input_path: str, output_dir: Optional[str] = None, 
                  dual_output: bool = False, custom_classifier=None) -> ProcessResult:
     """process_file (processor.rs:418-796).  batch_size 0 = the backend's default (determine_default_batch_size);
     front_end "host" keeps the reference's decode-thread + padded-batch structure, "device" / "auto" run decode
-    scaling, mono mix, segmentation and resampling on the GPU for PCM16 WAV input.  custom_classifier: bat mode
+    scaling, mono mix, segmentation and resampling on the GPU for WAV input (PCM16 / PCM24 / PCM32 / float32).  custom_classifier: bat mode
     (classifier.CustomClassifier): no resampling, 144 000-sample segments overlapping by a quarter, the custom
     classifier's predictions on the backbone's embeddings."""
     L = _lib.load()

@@ -297,6 +297,18 @@ BH_API size_t bh_segment_starts(size_t n_frames, size_t segment_samples, size_t 
 BH_API int bh_predict_pcm16(bh_classifier *c, bh_batch_context *ctx, const int16_t *pcm, size_t n_frames,
                             uint32_t channels, uint32_t source_rate, size_t overlap_samples, bh_result *out,
                             size_t out_cap, size_t *n_segments, uint64_t *start_samples);
+/* The same for the other sample formats a WAV file carries (the host decoder's, audio/decode.rs:353-411): 24-bit PCM is widened
+ * as symphonia does (value << 8, then / 2^31), 32-bit PCM / 2^31, float32 as is.  `pcm` is the interleaved stream in the file's
+ * own byte layout (little endian). */
+#define BH_PCM_S16 1u
+#define BH_PCM_S24 2u
+#define BH_PCM_S32 3u
+#define BH_PCM_F32 4u
+BH_API int bh_predict_pcm(bh_classifier *c, bh_batch_context *ctx, const void *pcm, uint32_t sample_format, size_t n_frames,
+                          uint32_t channels, uint32_t source_rate, size_t overlap_samples, bh_result *out, size_t out_cap,
+                          size_t *n_segments, uint64_t *start_samples);
+BH_API int bh_predict_pcm_at(bh_classifier *c, bh_batch_context *ctx, const void *pcm, uint32_t sample_format, size_t n_frames,
+                             uint32_t channels, uint32_t source_rate, const uint64_t *start_samples, size_t n_segments, bh_result *out);
 /* The same with the segment starts given (frames, not decreasing, each < n_frames; a segment that runs past n_frames is zero
  * padded): several short recordings packed into ONE stream -- each followed by a segment's length of silence, so that its
  * trailing segment pads with zeros as next_segment does (decode.rs:188-196) -- go through one upload and one forward

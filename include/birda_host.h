@@ -129,9 +129,10 @@ BH_API void bhh_reporter_error(bhh_reporter *r, const char *code, int fatal, con
 /* Where decode + segmentation run:
  *   HOST    the reference's structure: a decode thread (decode_and_stream, processor.rs:49-108) feeds AudioChunks through a
  *           bounded channel to the batcher (run_streaming_inference, :114-190), which zero-pads the last batch (:240-258).
- *   DEVICE   the file's PCM16 frames are mapped, uploaded as int16 and scaled / mixed / windowed / resampled on
+ *   DEVICE   the WAV file's frames (PCM16 / PCM24 / PCM32 / float32) are mapped, uploaded in the file's own sample
+ *           layout and scaled / mixed / windowed / resampled on
  *           the GPU (bh_predict_pcm16); the same detections, no padding rows, no per-segment host work.
- *   AUTO    DEVICE when the file is PCM16 WAV, else HOST. */
+ *   AUTO    DEVICE when the file is a WAV of one of those four sample formats, else HOST (8-bit PCM, compressed audio). */
 #define BHH_FRONT_END_AUTO 0u
 #define BHH_FRONT_END_HOST 1u
 #define BHH_FRONT_END_DEVICE 2u
@@ -175,13 +176,13 @@ BH_API int bhh_process_file(bh_classifier *clf, const bhh_processing_config *cfg
 
 /* process_files_sequential (lib.rs:1003-1100) for MANY SHORT recordings.  The reference runs the files one after another, each
  * in batches of its own segments; a one-minute recording is 20 segments -- 2 % of what this GPU wants per launch, and a forward
- * has a ~1.3 ms floor however few segments it holds.  Here consecutive PCM16 WAV files of one sample rate and channel count are
+ * has a ~1.3 ms floor however few segments it holds.  Here consecutive WAV files of one sample format, rate and channel count are
  * PACKED: their streams are copied into one pinned buffer (each followed by a segment's length of silence, so that trailing
  * segments pad with zeros exactly as next_segment does), cut into up to `pack_segments` segments and run as ONE upload and ONE
  * forward (bh_predict_pcm16_at); the rows are scattered back and every file gets the detections, sort and outputs
  * bhh_process_file would have given it (tests/test_parity_gpu.py::test_packed_short_files_match_the_per_file_pipeline).
  * cfg is a template: input_path / display_path are ignored, the rest applies to every file.  Files the packer does not take --
- * not PCM16 WAV, at least `pack_segments / 2` segments long, bat mode, a reporter in the template -- go through
+ * not a WAV the device front end takes, at least `pack_segments / 2` segments long, bat mode, a reporter in the template -- go through
  * bhh_process_file where they stand.  results[i] belongs to paths[i]; status[i] (nullable) receives each file's BH_OK /
  * BH_ERR_*; the call itself fails only for bad arguments.  pack_segments 0 = 1024. */
 BH_API int bhh_process_files(bh_classifier *clf, const bhh_processing_config *cfg, const char *const *paths, size_t n_files,

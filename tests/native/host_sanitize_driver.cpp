@@ -25,7 +25,8 @@ int bh_predict_batch(bh_classifier *, const float *const *, size_t, size_t, bh_r
 int bh_predict_batch_with_context(bh_classifier *, bh_batch_context *, const float *const *, size_t, size_t, bh_result *) { return BH_ERR_NO_DEVICE; }
 int bh_predict_batch_source_rate(bh_classifier *, bh_batch_context *, const float *const *, size_t, size_t, uint32_t, bh_result *) { return BH_ERR_NO_DEVICE; }
 int bh_predict_pcm16(bh_classifier *, bh_batch_context *, const int16_t *, size_t, uint32_t, uint32_t, size_t, bh_result *, size_t, size_t *, uint64_t *) { return BH_ERR_NO_DEVICE; }
-int bh_predict_pcm16_at(bh_classifier *, bh_batch_context *, const int16_t *, size_t, uint32_t, uint32_t, const uint64_t *, size_t, bh_result *) { return BH_ERR_NO_DEVICE; }
+int bh_predict_pcm(bh_classifier *, bh_batch_context *, const void *, uint32_t, size_t, uint32_t, uint32_t, size_t, bh_result *, size_t, size_t *, uint64_t *) { return BH_ERR_NO_DEVICE; }
+int bh_predict_pcm_at(bh_classifier *, bh_batch_context *, const void *, uint32_t, size_t, uint32_t, uint32_t, const uint64_t *, size_t, bh_result *) { return BH_ERR_NO_DEVICE; }
 size_t bh_segment_starts(size_t, size_t, size_t, uint64_t *, size_t) { return 0; }
 void *bh_batch_context_host_buffer(bh_batch_context *, size_t *) { return nullptr; }
 int bh_predict_batch_two_stage(bh_classifier *, bh_batch_context *, bh_custom_classifier *, const float *const *, size_t, size_t, bh_result *, float *) { return BH_ERR_NO_DEVICE; }

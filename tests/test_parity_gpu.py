@@ -967,6 +967,56 @@ def test_directory_mode_two_ranks_cover_every_file_once(clf_tiny, model_dir, tmp
     assert [r.output_path for r in again] == [ref[1].output_path]
 
 
+def _write_wav(path, x, rate, fmt):
+    """x: float [frames] or [frames, channels] in [-1, 1); fmt: 's16' | 's24' | 's32' | 'f32' (canonical 44-byte header)."""
+    import struct
+    x = np.asarray(x, np.float64)
+    ch = 1 if x.ndim == 1 else x.shape[1]
+    if fmt == "f32":
+        data, tag, bits = x.astype("<f4").tobytes(), 3, 32
+    elif fmt == "s32":
+        data, tag, bits = np.clip(np.round(x * 2147483647.0), -2147483648, 2147483647).astype("<i4").tobytes(), 1, 32
+    elif fmt == "s24":
+        v = np.clip(np.round(x * 8388607.0), -8388608, 8388607).astype("<i4").reshape(-1)
+        data, tag, bits = v.view(np.uint8).reshape(-1, 4)[:, :3].tobytes(), 1, 24
+    else:
+        data, tag, bits = np.clip(np.round(x * 32767.0), -32768, 32767).astype("<i2").tobytes(), 1, 16
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, tag, ch, rate, rate * ch * bits // 8, ch * bits // 8, bits)
+    with open(path, "wb") as f:
+        f.write(hdr + b"data" + struct.pack("<I", len(data)) + data)
+
+
+@pytest.mark.parametrize("fmt", ["s24", "s32", "f32"])
+def test_device_front_end_takes_every_wav_sample_format(clf_tiny, model_dir, tmp_path, fmt):
+    """24-bit, 32-bit and float32 WAV streams are uploaded in the file's own layout and scaled on the device exactly as the host
+    decoder scales them (decode.rs:353-411; 24-bit widened << 8 as symphonia does): the device front end writes the same bytes
+    as the host front end, mono and stereo, at the model rate and through the resampler, also when packed with other files."""
+    from birda_amd import pipeline, synth
+    _, _, m, _ = model_dir["birdnet_v24_tiny"]
+    S = m.sample_count
+    files = []
+    for k, (rate, ch, nseg) in enumerate([(48000, 1, 3), (48000, 2, 2), (44100, 1, 2)]):
+        n = nseg * S * rate // 48000 + 1234
+        x = synth.synth_segments(n // S + 2, S, rate, start=31 * k).reshape(-1)[:n]
+        if ch == 2:
+            x = np.stack([x, 0.25 * x[::-1]], 1)
+        f = str(tmp_path / f"{fmt}_{k}.wav")
+        _write_wav(f, x, rate, fmt)
+        files.append(f)
+    outs = {}
+    for fe in ("host", "device"):
+        d = tmp_path / fe; d.mkdir()
+        for f in files:
+            r = pipeline.process_file(clf_tiny, f, str(d), min_confidence=0.05, overlap=0.5, front_end=fe)
+            assert r.front_end == fe and r.segments >= 2
+        outs[fe] = [open(pipeline.output_path_for(f, str(d), "csv"), "rb").read() for f in files]
+    assert outs["host"] == outs["device"] and any(len(b) > 200 for b in outs["device"])
+    pk = tmp_path / "packed"; pk.mkdir()
+    res, status = pipeline.process_files_packed(clf_tiny, files, str(pk), min_confidence=0.05, overlap=0.5)
+    assert status == [0, 0, 0]
+    assert [open(pipeline.output_path_for(f, str(pk), "csv"), "rb").read() for f in files] == outs["host"]
+
+
 def test_packed_short_files_match_the_per_file_pipeline(clf_tiny, model_dir, tmp_path):
     """bhh_process_files packs the PCM16 streams of consecutive short recordings into one upload and one forward
     (bh_predict_pcm16_at) and scatters the rows back: byte for byte the CSV / JSON files bhh_process_file writes per file --
