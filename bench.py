@@ -366,6 +366,22 @@ def host_legs(clf, m, model_path, precision, tmp):
                           "one_file_at_a_time": {"value": round(segs_a / t_single, 1), "unit": "segments/s"},
                           "packed": {"value": round(segs_b / t_packed, 1), "unit": "segments/s", "entry_point": "bhh_process_files"},
                           "identical_outputs": bool(same and not any(status_b))}
+    # the same long file four times over through bhh_process_files: each file is a pack of its own, its forward runs under the
+    # previous file's output writing and the next file's copy into the other context's staging buffer
+    longs = []
+    for k in range(4):
+        p = os.path.join(tmp, "bench_long_%d.wav" % k)
+        if not os.path.exists(p):
+            os.link(wav, p)
+        longs.append(p)
+    out_l = os.path.join(tmp, "long_packed")
+    os.makedirs(out_l, exist_ok=True)
+    pipeline.process_files_packed(c2, longs, out_l)
+    t = time.perf_counter()
+    res_l, status_l = pipeline.process_files_packed(c2, longs, out_l)
+    t_long = time.perf_counter() - t
+    e2e["files_pipelined"] = {"what": "4 files of %d segments each through bhh_process_files (two in flight)" % n,
+                              "value": round(sum(r.segments for r in res_l) / t_long, 1), "unit": "segments/s", "ok": not any(status_l)}
     c2.close()
     out["end_to_end"] = {"what": "bhh_process_file on a synthetic %d-segment PCM16 WAV -> CSV (reference metric: segments / wall seconds, "
                                  "processor.rs:771-788), default batch size" % n, **e2e}

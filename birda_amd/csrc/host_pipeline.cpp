@@ -830,7 +830,11 @@ bool plan_packable(bh_classifier *clf, const bh_model_info &info, const bhh_proc
     pf.channels = (uint32_t)probe->channels;
     pf.n_segments = bh_segment_starts(pf.map.n_frames, pl.src_segment_samples, pl.src_overlap_samples, nullptr, 0);
     (void)clf;
-    return pf.n_segments > 0 && pf.n_segments < std::max<size_t>(2, pack_segments / 2);
+    // anything whose stream (plus its trailing silence) fits a context's staging buffer -- pack_segments f32 segments -- can go
+    // through the two-deep pipeline below, a long file as a pack of its own: its forward then runs under the previous file's
+    // output writing and the next file's copy
+    const size_t bytes = (pf.map.n_frames + pl.src_segment_samples) * pf.channels * pf.map.bps;
+    return pf.n_segments > 0 && bytes <= pack_segments * info.sample_count * sizeof(float);
 }
 
 }  // namespace
@@ -939,17 +943,24 @@ extern "C" int bhh_process_files(bh_classifier *clf, const bhh_processing_config
         //  channels -- then the pack goes file by file)
         if (p->rc == BH_OK && cap < bytes) p->rc = BH_ERR_UNSUPPORTED;
         if (p->rc == BH_OK) {
-            // one copy per file, page cache -> pinned memory, on a few threads (the copies fault the mapped pages in)
-            const unsigned nthreads = (unsigned)std::min<size_t>(8, p->files.size());
+            // one copy, page cache -> pinned memory, in 4-MiB pieces on a few threads (the copies fault the mapped pages in)
+            struct Piece { unsigned char *d; const unsigned char *s; size_t n; };
+            std::vector<Piece> pieces;
+            const size_t fb = p->ch * p->bps;      // bytes per frame; zero bytes are silence in all four formats
+            for (auto &pfp : p->files) {
+                const PackedFile &pf = *pfp;
+                unsigned char *d = dst + pf.base_frame * fb;
+                const size_t nbytes = pf.map.n_frames * fb;
+                for (size_t o = 0; o < nbytes; o += (size_t)4 << 20) pieces.push_back({d + o, pf.map.pcm + o, std::min<size_t>((size_t)4 << 20, nbytes - o)});
+                pieces.push_back({d + nbytes, nullptr, p->seg * fb});
+            }
+            const unsigned nthreads = (unsigned)std::min<size_t>(8, pieces.size());
             std::atomic<size_t> next{0};
-            Pack *pp = p.get();
-            auto work = [&next, pp, dst] {
-                for (size_t k; (k = next.fetch_add(1)) < pp->files.size();) {
-                    const PackedFile &pf = *pp->files[k];
-                    const size_t fb = pp->ch * pp->bps;      // bytes per frame; zero bytes are silence in all four formats
-                    unsigned char *d = dst + pf.base_frame * fb;
-                    if (pf.map.n_frames) memcpy(d, pf.map.pcm, pf.map.n_frames * fb);
-                    memset(d + pf.map.n_frames * fb, 0, pp->seg * fb);
+            auto work = [&next, &pieces] {
+                for (size_t k; (k = next.fetch_add(1)) < pieces.size();) {
+                    const Piece &q = pieces[k];
+                    if (q.s) memcpy(q.d, q.s, q.n);
+                    else memset(q.d, 0, q.n);
                 }
             };
             std::vector<std::thread> th;

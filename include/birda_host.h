@@ -182,7 +182,8 @@ BH_API int bhh_process_file(bh_classifier *clf, const bhh_processing_config *cfg
  * forward (bh_predict_pcm16_at); the rows are scattered back and every file gets the detections, sort and outputs
  * bhh_process_file would have given it (tests/test_parity_gpu.py::test_packed_short_files_match_the_per_file_pipeline).
  * cfg is a template: input_path / display_path are ignored, the rest applies to every file.  Files the packer does not take --
- * not a WAV the device front end takes, at least `pack_segments / 2` segments long, bat mode, a reporter in the template -- go through
+ * not a WAV the device front end takes, a stream longer than a context's staging buffer (about 2 x pack_segments segments of mono
+ * PCM16), bat mode, a reporter in the template -- go through
  * bhh_process_file where they stand.  results[i] belongs to paths[i]; status[i] (nullable) receives each file's BH_OK /
  * BH_ERR_*; the call itself fails only for bad arguments.  pack_segments 0 = 1024. */
 BH_API int bhh_process_files(bh_classifier *clf, const bhh_processing_config *cfg, const char *const *paths, size_t n_files,

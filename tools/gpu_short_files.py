@@ -22,3 +22,10 @@ out = os.path.join(d, "out"); os.makedirs(out)
 for rep in range(3):
     t = time.perf_counter(); res, st = pipeline.process_files_packed(clf, files, out); dt = time.perf_counter() - t
     print(f"packed rep {rep}: {nf * per / dt:9.0f} segments/s ({dt*1e3:.1f} ms)", file=sys.stderr)
+if os.environ.get("ALSO_SINGLE"):
+    for rep in range(2):
+        t = time.perf_counter()
+        for f in files:
+            pipeline.process_file(clf, f, out)
+        dt = time.perf_counter() - t
+        print(f"one file at a time rep {rep}: {nf * per / dt:9.0f} segments/s ({dt*1e3:.1f} ms)", file=sys.stderr)
