@@ -108,6 +108,23 @@ __device__ __forceinline__ void mb_dma_at(const float *gsrc, unsigned lds_byte_a
         }
     }
 }
+// part `part` of `nparts` of the calling wave's share of the same transfer: the column-task kernels issue their chunk's weight
+// pieces a few at a time between the rows of the depthwise phase -- issued as one burst, the 12-13 pieces of a wave block it for
+// ~800 cycles while the vector-memory path takes them in (tools/microbench/lds_fill.hip)
+template <int NFLOATS>
+__device__ __forceinline__ void mb_dma_at_part(const float *gsrc, unsigned lds_byte_addr, int wave, int lane, int part, int nparts) {
+    constexpr int NP = (NFLOATS + 255) / 256;
+#pragma unroll
+    for (int p0 = 0; p0 < NP; p0 += 4) {
+        if ((p0 / 4) % nparts != part) continue;
+        const int p = p0 + wave;
+        const int off = p * 256 + lane * 4;
+        if (p < NP && off < NFLOATS) {
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                         :: "v"(gsrc + off), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr + (unsigned)p * 1024u)) : "memory", "m0");
+        }
+    }
+}
 __device__ __forceinline__ void mb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 //   PREC        0: f32 MFMA (16x16x4, KG counts 16-deep groups); 3: f16 hi/lo split, three 16x16x32 MFMAs
@@ -539,8 +556,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
         __syncthreads();  // B1: Es complete; (ring == 0) WeS / WpS free; Wds (DMA issued after the last B2) landed
         if (!ring && !PERSIST && !(d.dbg & 16)) {
             if constexpr (COLTH > 0) {
-                mb_dma_at<WE_FLOATS>(d.We + (size_t)chn * WE_FLOATS, we_ba, wave, lane);
-                mb_dma_at<WP_FLOATS>(d.Wp + (size_t)ch * WP_FLOATS, wp_ba, wave, lane);
+                // (issued in parts inside the depthwise phase below)
             } else {
                 mb_dma<WE_FLOATS>(d.We + (size_t)chn * WE_FLOATS, WeS, wave, lane);
                 mb_dma<WP_FLOATS>(d.Wp + (size_t)ch * WP_FLOATS, WpS, wave, lane);
@@ -554,7 +570,13 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
             // Ho == COLTH, one tile row, pad_t == (KS - 1) / 2 and at most 256 tasks
             constexpr int PADT = (KS - 1) / 2;
             static_assert(ST == 1, "column tasks: stride 1");
-            if (tid < nsv * TW * C4N && !(d.dbg & 2)) {
+            const bool dma_on = !(d.dbg & 16);
+            if (!(tid < nsv * TW * C4N && !(d.dbg & 2))) {   // (wave-uniform: a wave without tasks issues its pieces at once)
+                if (dma_on) {
+                    mb_dma_at<WE_FLOATS>(d.We + (size_t)chn * WE_FLOATS, we_ba, wave, lane);
+                    mb_dma_at<WP_FLOATS>(d.Wp + (size_t)ch * WP_FLOATS, wp_ba, wave, lane);
+                }
+            } else {
                 const int c4 = tid % C4N, q = tid / C4N, x = q & (TW - 1), sl = q >> TWL;
                 const float *eb = Es + ((sl * IH + PADT) * IW + x) * CES + 4 * c4;   // grid row PADT = image row 0
                 float4 e[COLTH][KS];
@@ -581,6 +603,10 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                             acc[r][0] = __builtin_elementwise_fma((f32x2){ev.x, ev.y}, w0, acc[r][0]);
                             acc[r][1] = __builtin_elementwise_fma((f32x2){ev.z, ev.w}, w1, acc[r][1]);
                         }
+                    }
+                    if (dma_on) {   // this row's share of the next chunk's expand weights and this chunk's project weights
+                        mb_dma_at_part<WE_FLOATS>(d.We + (size_t)chn * WE_FLOATS, we_ba, wave, lane, dy, KS);
+                        mb_dma_at_part<WP_FLOATS>(d.Wp + (size_t)ch * WP_FLOATS, wp_ba, wave, lane, dy, KS);
                     }
                     __builtin_amdgcn_sched_barrier(0);   // one kernel row of weight loads in flight
                 }
