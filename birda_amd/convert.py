@@ -9,12 +9,12 @@ Sigmoid -> Mul with the feature map) as pool / 1x1 / 1x1 / OP_SCALE layers, Glob
 final Sigmoid / Softmax as the output activation.  Weights move from ONNX's [Cout, Cin/g, kh, kw] to
 the NHWC-friendly layouts of the kernels.
 
-What it does NOT do: recover the STFT / mel front-end from the graph.  How the published BirdNET and
-Perch ONNX files spell that part (STFT op, DFT-as-Conv1d, ...) is not knowable offline (no model file,
-no network: SURVEY.md 8c), so the front-end parameters come from the model family's manifest values
- through `frontend`, and the graph is entered at the spectrogram tensor named by
-`spectrogram_input` (default: the graph's first input).  The reference loads the same file through
-`birdnet_onnx::ClassifierBuilder::model_path` (src/inference/classifier.rs:269-283).
+The STFT / mel front-end: either the model family's manifest values through `frontend`, with the
+graph entered at the spectrogram tensor named by `spectrogram_input` (default: the graph's first input) -- or, with
+`frontend=None` and a sample rate, read off the graph itself by probing (`frontend_recover.py`: how the published BirdNET and
+Perch ONNX files spell that part -- STFT op, DFT-as-Conv1d, ... -- is not knowable offline, so no spelling is matched; the nodes
+in front of the first 2-D convolution are evaluated on probe signals and the container's parameters fitted to the responses).
+The reference loads the same file through `birdnet_onnx::ClassifierBuilder::model_path` (src/inference/classifier.rs:269-283).
 
 `graph_from_model` is the inverse for the synthetic models; it exists so that the converter can be
 tested (tests/test_convert.py: model -> ONNX bytes -> model, identical layer tables, weights and oracle
@@ -40,11 +40,108 @@ class ConvertError(ValueError):
 # ---------------------------------------------------------------------------------------
 # model -> ONNX  (test fixture generator)
 # ---------------------------------------------------------------------------------------
-def graph_from_model(m: mf.Model, spell_gelu: str = "erf") -> ox.Graph:
-    """The conv stack of a BHM1 model as an ONNX graph over `spectrogram` [N, C, H, W].
+def frontend_nodes(g: ox.Graph, m: mf.Model, spelling: str) -> None:
+    """Appends the spectrogram front-end of `m` to `g` as nodes from `audio` [N, S] to `spectrogram`
+    [N, C, n_mels, n_frames], in one of several spellings an exporter might choose.  Fixture generator for
+    tests/test_frontend_recover.py: the recovery must not care which one it gets.
+      'conv1d'  DFT as a strided Conv (real rows only) -> MatMul mel -> Mul(t, t) -> Pow(const) -> Mul, Add -> Transpose -> Slice(-1)
+      'stft'    opset-17 STFT node -> Gather real part -> MatMul mel -> Pow(t, 2) -> Pow(1 / (1 + Exp(mag_scale))) ->
+                BatchNormalization-free affine as Sub / Div -> Gather with reversed indices
+      'complex' Conv with cos AND -sin rows -> Slice of the real rows -> 1x1 Conv as the mel projection; the normalisation
+                written as (x - min) * (2 / (range + eps)) - 1
+      'fused'   window, DFT, mel matrix AND the mel flip folded into the Conv weights: [n_mels, 1, L] rows, nothing else linear"""
+    def const(name, arr, dtype=np.float32):
+        g.initializers[name] = np.asarray(arr, dtype)
+        return name
+
+    def node(op, ins, out, **attrs):
+        g.nodes.append(ox.Node(op, list(ins), [out], attrs, name=out))
+        return out
+
+    ax1 = const("fe_ax1", [1], np.int64)
+    mn = node("ReduceMin", ["audio"], "fe_min", axes=[1], keepdims=1)
+    mx = node("ReduceMax", ["audio"], "fe_max", axes=[1], keepdims=1)
+    rng_ = node("Sub", [mx, mn], "fe_range")
+    den = node("Add", [rng_, const("fe_eps", np.float32(m.norm_eps))], "fe_den")
+    if spelling == "complex":
+        sc = node("Div", [const("fe_two", 2.0), den], "fe_sc")
+        xn = node("Sub", [node("Mul", [node("Sub", ["audio", mn], "fe_c"), sc], "fe_cs"), const("fe_one", 1.0)], "fe_xn")
+    else:
+        x01 = node("Div", [node("Sub", ["audio", mn], "fe_c"), den], "fe_x01")
+        xn = node("Mul", [node("Sub", [x01, const("fe_half", 0.5)], "fe_xh"), const("fe_two", 2.0)], "fe_xn")
+    chans = []
+    for b, br in enumerate(m.branches):
+        t = f"fe{b}"
+        L, H, bins = br.frame_length, br.frame_step, br.n_bins
+        n = np.arange(L)
+        hann = 0.5 - 0.5 * np.cos(2.0 * np.pi * n / L)
+        ang = 2.0 * np.pi * ((n[:, None] * np.arange(bins)[None, :]) % L) / L
+        wcos, wsin = hann[:, None] * np.cos(ang), -hann[:, None] * np.sin(ang)          # [L, bins]
+        mel = m.weight(br.mel_w_off, bins * br.n_mels).reshape(bins, br.n_mels).astype(np.float64)
+        expo = 1.0 / (1.0 + math.exp(br.mag_scale))
+        flip = bool(br.flags & 1)
+        if spelling == "stft":
+            sig = node("Unsqueeze", [xn, const("fe_ax2", [2], np.int64)], t + "_sig")
+            st = node("STFT", [sig, const(t + "_step", H, np.int64), const(t + "_win", hann), const(t + "_len", L, np.int64)],
+                      t + "_stft", onesided=1)                                                 # [N, frames, bins, 2]
+            re = node("Gather", [st, const(t + "_zero", 0, np.int64)], t + "_re", axis=3)
+            lin = node("MatMul", [re, const(t + "_mel", mel)], t + "_lin")                      # [N, frames, mels]
+            layout = "tm"
+        else:
+            sig = node("Unsqueeze", [xn, ax1], t + "_sig")                                      # [N, 1, S]
+            if spelling == "conv1d":
+                cv = node("Conv", [sig, const(t + "_dft", wcos.T[:, None, :])], t + "_cv", strides=[H], kernel_shape=[L])
+                tr = node("Transpose", [cv], t + "_tr", perm=[0, 2, 1])
+                lin = node("MatMul", [tr, const(t + "_mel", mel)], t + "_lin")
+                layout = "tm"
+            elif spelling == "complex":
+                w = np.concatenate([wcos.T, wsin.T], axis=0)[:, None, :]                       # [2 bins, 1, L]
+                cv = node("Conv", [sig, const(t + "_dft", w)], t + "_cv", strides=[H], kernel_shape=[L])
+                re = node("Slice", [cv, const(t + "_s0", [0], np.int64), const(t + "_s1", [bins], np.int64), ax1], t + "_re")
+                lin = node("Conv", [re, const(t + "_mel", mel.T[:, :, None])], t + "_lin", kernel_shape=[1])   # [N, mels, frames]
+                layout = "mt"
+            elif spelling == "fused":
+                G = wcos @ mel                                                                  # [L, mels]
+                if flip:
+                    G = G[:, ::-1]
+                lin = node("Conv", [sig, const(t + "_op", np.ascontiguousarray(G.T)[:, None, :])], t + "_lin", strides=[H], kernel_shape=[L])
+                layout, flip = "mt", False
+            else:
+                raise ConvertError(f"front-end spelling {spelling!r}")
+        if spelling == "stft":
+            sq = node("Pow", [lin, const(t + "_p2", 2.0)], t + "_sq")
+            e1 = node("Exp", [const(t + "_mag", np.float32(br.mag_scale))], t + "_e1")
+            ex = node("Div", [const(t + "_n1", 1.0), node("Add", [e1, const(t + "_o1", 1.0)], t + "_e2")], t + "_ex")
+            pw = node("Pow", [sq, ex], t + "_pw")
+            # an affine spelled as a normalisation: (v - mean) / std
+            af = node("Div", [node("Sub", [pw, const(t + "_mean", np.float32(-br.out_shift / br.out_scale))], t + "_ctr"),
+                              const(t + "_std", np.float32(1.0 / br.out_scale))], t + "_af")
+        else:
+            sq = node("Mul", [lin, lin], t + "_sq")
+            pw = node("Pow", [sq, const(t + "_ex", np.float32(expo))], t + "_pw")
+            af = node("Add", [node("Mul", [pw, const(t + "_sc", np.float32(br.out_scale))], t + "_scd"),
+                              const(t + "_sh", np.float32(br.out_shift))], t + "_af")
+        if layout == "tm":
+            af = node("Transpose", [af], t + "_mt", perm=[0, 2, 1])                            # [N, mels, frames]
+        if flip and spelling == "stft":
+            af = node("Gather", [af, const(t + "_rev", np.arange(br.n_mels - 1, -1, -1), np.int64)], t + "_fl", axis=1)
+        elif flip:
+            af = node("Slice", [af, const(t + "_f0", [-1], np.int64), const(t + "_f1", [-(2 ** 62)], np.int64), ax1,
+                                const(t + "_fs", [-1], np.int64)], t + "_fl")
+        chans.append(node("Unsqueeze", [af, ax1], t + "_ch"))
+    node("Concat", chans, "spectrogram", axis=1)
+
+
+def graph_from_model(m: mf.Model, spell_gelu: str = "erf", frontend_spelling: Optional[str] = None) -> ox.Graph:
+    """The conv stack of a BHM1 model as an ONNX graph over `spectrogram` [N, C, H, W] -- or, with `frontend_spelling`
+    (see `frontend_nodes`), the whole model over `audio` [N, S].
     spell_gelu: 'erf' = Div, Erf, Add, Mul, Mul (what exporters emit below opset 20); 'gelu' = one Gelu node."""
     g = ox.Graph(name="birda_conv_stack", producer="birda_amd.convert")
-    g.inputs.append(ox.ValueInfo("spectrogram", ox.FLOAT, ["N", len(m.branches), m.spec_h, m.spec_w]))
+    if frontend_spelling is None:
+        g.inputs.append(ox.ValueInfo("spectrogram", ox.FLOAT, ["N", len(m.branches), m.spec_h, m.spec_w]))
+    else:
+        g.inputs.append(ox.ValueInfo("audio", ox.FLOAT, ["N", m.sample_count]))
+        frontend_nodes(g, m, frontend_spelling)
     names = {0: "spectrogram"}
     flat = set()   # tensors that are [N, C] (after Flatten)
 
@@ -218,13 +315,35 @@ def _collapse_activations(g: ox.Graph):
     return skip, act_of
 
 
-def model_from_graph(g: ox.Graph, frontend: mf.Model, spectrogram_input: Optional[str] = None) -> mf.Model:
+def model_from_graph(g: ox.Graph, frontend: Optional[mf.Model] = None, spectrogram_input: Optional[str] = None,
+                     sample_rate: Optional[int] = None, family: int = 0) -> mf.Model:
     """`frontend` supplies everything the conv stack does not say: family, sample rate / count, segment
     duration, normalisation eps, the STFT / mel branches and their mel weight matrices (its blob is kept as
-    the start of the new blob, so `mel_w_off` stays valid)."""
+    the start of the new blob, so `mel_w_off` stays valid).  Without one, the graph must start at the AUDIO input and the
+    front-end is read off it by probing (`frontend_recover.recover_frontend`; `sample_rate` is then required: the graph does
+    not state it, the reference takes it from the model type's config, src/inference/classifier.rs:360-377)."""
+    if frontend is None:
+        from .frontend_recover import RecoverError, recover_frontend
+        if sample_rate is None:
+            raise ConvertError("no front-end manifest: the sample rate must be given to read the front-end off the graph")
+        try:
+            rec = recover_frontend(g, sample_rate, family)
+        except RecoverError as e:
+            raise ConvertError(f"front-end not recoverable from the graph ({e}); pass a front-end manifest") from None
+        frontend, spectrogram_input = rec.frontend, rec.spectrogram
     spec = spectrogram_input or (g.inputs[0].name if g.inputs else None)
     if spec is None:
         raise ConvertError("graph has no input")
+    # nodes that produce the spectrogram (a graph that starts at the audio input) are the front-end, not layers
+    prod = {o: i for i, n in enumerate(g.nodes) for o in n.outputs}
+    front_nodes, stack = set(), [spec]
+    while stack:
+        t = stack.pop()
+        i = prod.get(t)
+        if i is None or i in front_nodes:
+            continue
+        front_nodes.add(i)
+        stack.extend(g.nodes[i].inputs)
     blob = _Blob(frontend.blob[: max((b.mel_w_off + b.n_bins * b.n_mels for b in frontend.branches), default=0)])
     layers: List[mf.Layer] = []
     # name -> (tensor index, C, H, W) ; H = W = 0 for flattened [N, C]
@@ -254,7 +373,7 @@ def model_from_graph(g: ox.Graph, frontend: mf.Model, spectrogram_input: Optiona
             set_act(x, out_name, act)
 
     for i, n in enumerate(g.nodes):
-        if i in skip:
+        if i in skip or i in front_nodes:
             continue
         op = n.op_type
         if op == "Conv":
@@ -420,8 +539,11 @@ def model_from_graph(g: ox.Graph, frontend: mf.Model, spectrogram_input: Optiona
                      for b in frontend.branches], layers, blob.array())
 
 
-def convert_file(onnx_path: str, frontend_bhm: str, out_path: str, spectrogram_input: Optional[str] = None) -> mf.Model:
-    """ONNX file + a BHM1 file carrying the family's front-end -> BHM1 model."""
-    m = model_from_graph(ox.load(open(onnx_path, "rb").read()), mf.read_model(frontend_bhm), spectrogram_input)
+def convert_file(onnx_path: str, frontend_bhm: Optional[str], out_path: str, spectrogram_input: Optional[str] = None,
+                 sample_rate: Optional[int] = None, family: int = 0) -> mf.Model:
+    """ONNX file (+ a BHM1 file carrying the family's front-end, or none and a sample rate: the front-end is then read
+    off the graph) -> BHM1 model."""
+    m = model_from_graph(ox.load(open(onnx_path, "rb").read()), mf.read_model(frontend_bhm) if frontend_bhm else None,
+                         spectrogram_input, sample_rate, family)
     mf.write_model(out_path, m)
     return m

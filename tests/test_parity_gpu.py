@@ -849,6 +849,33 @@ def test_model_converted_from_onnx_runs_identically(model_dir, tmp_path):
     assert np.array_equal(out[0][1], out[1][1])
 
 
+@pytest.mark.parametrize("spelling", ["stft", "fused"])
+def test_model_converted_from_an_audio_graph_without_a_manifest(model_dir, tmp_path, spelling):
+    """The whole model as an ONNX graph over the AUDIO input (front-end spelled as an STFT node / as one fused Conv), converted
+    with no front-end manifest: frame length / step, the mel operator, exponent, affine, flip and the normalisation epsilon are
+    read off the graph by probing (birda_amd/frontend_recover.py).  The device must give the original model's logits -- within
+    the tolerance of the fitted mel matrix (least squares, float32: ~1e-8 per weight) -- and the oracle's."""
+    from oracle import oracle as O
+    from birda_amd import convert, modelfile as mf, onnx_io as ox, synth
+    from birda_amd.classifier import BirdClassifier
+    path, labels, m, _ = model_dir["mini_b0"]
+    m2 = convert.model_from_graph(ox.load(ox.dump(convert.graph_from_model(m, frontend_spelling=spelling))), None,
+                                  sample_rate=m.sample_rate)
+    p2 = str(tmp_path / "converted.bhm")
+    mf.write_model(p2, m2)
+    segs = synth.synth_segments(5, m.sample_count, m.sample_rate, start=90)
+    out = []
+    for p in (path, p2):
+        clf = BirdClassifier(p, labels, precision="f16x3")
+        ctx = clf.create_batch_context(8)
+        out.append((clf.fused_blocks(), clf.predict_logits(ctx, segs)))
+        ctx.close(); clf.close()
+    assert out[0][0] == out[1][0] and len(out[0][0]) == 16
+    scale = max(1.0, float(np.abs(out[0][1]).max()))
+    assert np.abs(out[0][1] - out[1][1]).max() <= 2e-5 * scale
+    assert np.abs(O.OracleModel(p2).forward(segs) - out[1][1]).max() <= LOGIT_RTOL * scale
+
+
 # ---- range filter / species list on the kept top-k (SURVEY 8f-2) --------------------------------------------
 def test_device_range_filter_reproduces_the_reference_unit_tests(clf_mini, model_dir):
     """geomodel_filter.rs:126-300 as data (tests/golden/reference_unit_cases.json): each case's predictions are

@@ -2,6 +2,7 @@
 # SQ counter pass (own run, kernel-trace only): where the waves' cycles go per kernel
 root=${GRAFT_REPO_ROOT:-$(pwd)}; out=$root/gpurun_out/${1:-sq}; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
+export BIRDA_HIP_PRECISION=${BIRDA_HIP_PRECISION:-f16x3}   # the mode bench.py runs (exported here: no env hop under rocprofv3)
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $out/p1 -- python3 $root/tools/gpu_quick_bench.py birdnet_v24 1000 1000 > /dev/null 2> $out/p1.log
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $out/p2 -- python3 $root/tools/gpu_quick_bench.py birdnet_v24 1000 1000 > /dev/null 2> $out/p2.log
 python3 - <<PY
