@@ -73,11 +73,11 @@ struct MbClock {
 //     after B1(ch): We+be of chunk ch+1, Wp of chunk ch      (waited before B2(ch))
 //     after B2(ch): Wd+bd of chunk ch+1                      (waited before B1(ch+1))
 // so the MFMA loops read every operand from registers or LDS and never wait on memory.
-template <int NFLOATS>
+template <int NFLOATS, int NW = 4>
 __device__ __forceinline__ void mb_dma(const float *gsrc, float *lds_dst, int wave, int lane) {
-    constexpr int NP = (NFLOATS + 255) / 256;  // 1-KiB pieces, dealt round-robin to the 4 waves
+    constexpr int NP = (NFLOATS + 255) / 256;  // 1-KiB pieces, dealt round-robin to the NW waves
 #pragma unroll
-    for (int p0 = 0; p0 < NP; p0 += 4) {
+    for (int p0 = 0; p0 < NP; p0 += NW) {
         const int p = p0 + wave;
         const int off = p * 256 + lane * 4;
         if (p < NP && off < NFLOATS) {
@@ -95,34 +95,36 @@ __device__ __forceinline__ void mb_dma(const float *gsrc, float *lds_dst, int wa
 // `(unsigned)(size_t)lds_pointer` (a generic pointer: LDS -> flat -> integer) back to the LDS offset and its backend then rejects
 // the aperture test it builds ("Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base"); the column-task
 // instantiations hit that, so they compute the address from float offsets into the one dynamic shared array.
+// One piece: the wave's index is made scalar first, so the piece index, the global base (the source is wave-uniform) and the LDS
+// address live in SGPRs and the only per-lane value is the 32-bit byte offset `lane * 16` (the saddr form of the load).  With the
+// 64-bit per-lane addresses of mb_dma the 8-wave kernels (256 registers per wave) spilled exactly these, and a scratch reload's
+// `s_waitcnt vmcnt(0)` in the middle of a burst of pieces waits for every piece issued before it.
 template <int NFLOATS>
+__device__ __forceinline__ void mb_dma_piece(const float *gsrc, unsigned lds_byte_addr, int p /* scalar */, int lane) {
+    constexpr int NP = (NFLOATS + 255) / 256, TAIL = NFLOATS - (NP - 1) * 256;   // floats in the last piece
+    if (p < NP && (TAIL == 256 || p < NP - 1 || lane * 4 < TAIL)) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                     :: "v"((unsigned)lane * 16u), "s"(gsrc + (size_t)p * 256), "s"(lds_byte_addr + (unsigned)p * 1024u) : "memory", "m0");
+    }
+}
+template <int NFLOATS, int NW = 4>
 __device__ __forceinline__ void mb_dma_at(const float *gsrc, unsigned lds_byte_addr, int wave, int lane) {
     constexpr int NP = (NFLOATS + 255) / 256;
+    const int ws = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
-    for (int p0 = 0; p0 < NP; p0 += 4) {
-        const int p = p0 + wave;
-        const int off = p * 256 + lane * 4;
-        if (p < NP && off < NFLOATS) {
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                         :: "v"(gsrc + off), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr + (unsigned)p * 1024u)) : "memory", "m0");
-        }
-    }
+    for (int p0 = 0; p0 < NP; p0 += NW) mb_dma_piece<NFLOATS>(gsrc, lds_byte_addr, p0 + ws, lane);
 }
 // part `part` of `nparts` of the calling wave's share of the same transfer: the column-task kernels issue their chunk's weight
 // pieces a few at a time between the rows of the depthwise phase -- issued as one burst, the 12-13 pieces of a wave block it for
 // ~800 cycles while the vector-memory path takes them in (tools/microbench/lds_fill.hip)
-template <int NFLOATS>
+template <int NFLOATS, int NW = 4>
 __device__ __forceinline__ void mb_dma_at_part(const float *gsrc, unsigned lds_byte_addr, int wave, int lane, int part, int nparts) {
     constexpr int NP = (NFLOATS + 255) / 256;
+    const int ws = __builtin_amdgcn_readfirstlane(wave);
 #pragma unroll
-    for (int p0 = 0; p0 < NP; p0 += 4) {
-        if ((p0 / 4) % nparts != part) continue;
-        const int p = p0 + wave;
-        const int off = p * 256 + lane * 4;
-        if (p < NP && off < NFLOATS) {
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                         :: "v"(gsrc + off), "s"(__builtin_amdgcn_readfirstlane(lds_byte_addr + (unsigned)p * 1024u)) : "memory", "m0");
-        }
+    for (int p0 = 0; p0 < NP; p0 += NW) {
+        if ((p0 / NW) % nparts != part) continue;
+        mb_dma_piece<NFLOATS>(gsrc, lds_byte_addr, p0 + ws, lane);
     }
 }
 __device__ __forceinline__ void mb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -142,14 +144,18 @@ __device__ __forceinline__ void mb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)
 //               (tools/abl2.sh: chunk loop without any compute 417 of 1061 us, set-up + epilogue 303).
 template <int KS, int ST, int CE, int KG, int RT_W, int NCS, int WM, int WN, int MT_W, int NT_W, int TWL, int XBL,
           int SS, int OCC, int STEM, int PREC, int PERSIST = 0, int ACT = ACT_GELU_ERF, int COLTH = 0>
-__global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const int n_seg) {
+__global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc d, const int n_seg) {
     static_assert(!STEM || SS == 1, "the stem variant handles one segment per workgroup");
     static_assert(PREC == 0 || CE % 32 == 0 || CE == 16, "f16 project GEMM: 32-deep steps, or one 16-deep step for 16-channel chunks");
-    static_assert(WM * WN == 4, "4 waves");
+    // NW waves: 4 (one per SIMD; the workgroups of a CU interleave) or 8 (two per SIMD inside ONE workgroup: the late blocks, whose
+    // whole-image tiles leave room for a single workgroup per CU -- with one wave per SIMD nothing fills the issue bubbles of its
+    // dependent vector chains, and its MFMA and vector phases cannot overlap with anybody else's)
+    constexpr int NW = WM * WN, NTH = 64 * NW;
+    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
     constexpr int NT_E = CE / 16, NT_U = NT_E / NCS, CES = CE + 4, C4N = CE / 4, TW = 1 << TWL;
     constexpr int POUT_PAD = WM * MT_W * 16, NTOP = WN * NT_W;
     constexpr int XB = 1 << XBL, XBN = TW / XB, NCOL = (XB - 1) * ST + KS;
-    constexpr int RSTEP = 4 / NCS;  // row-tile stride between a wave's P1 tiles
+    constexpr int RSTEP = NW / NCS;  // row-tile stride between a wave's P1 tiles
     constexpr int RG = (RT_W * NT_U <= 8) ? RT_W : (8 / NT_U >= 1 ? 8 / NT_U : 1);  // row tiles in flight
     constexpr int FRAG = PREC ? 512 : 256;             // floats per (k step, column tile): f16 = hi + lo planes
     constexpr int PSTEPS = PREC ? (CE + 31) / 32 : NT_E;  // k steps of the project GEMM per chunk
@@ -189,24 +195,24 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
     if (d.stamps) t_last.last = __builtin_readcyclecounter();
     if constexpr (PERSIST != 0) {
         for (int c = 0; c < d.nchunks; c++) {   // every chunk's weights, once
-            mb_dma<WE_FLOATS>(d.We + (size_t)c * WE_FLOATS, WeS + c * WE_FLOATS, wave0, lane0);
-            mb_dma<WD_FLOATS>(d.Wd + (size_t)c * WD_FLOATS, Wds + c * WD_FLOATS, wave0, lane0);
-            mb_dma<WP_FLOATS>(d.Wp + (size_t)c * WP_FLOATS, WpS + c * WP_FLOATS, wave0, lane0);
+            mb_dma<WE_FLOATS, NW>(d.We + (size_t)c * WE_FLOATS, WeS + c * WE_FLOATS, wave0, lane0);
+            mb_dma<WD_FLOATS, NW>(d.Wd + (size_t)c * WD_FLOATS, Wds + c * WD_FLOATS, wave0, lane0);
+            mb_dma<WP_FLOATS, NW>(d.Wp + (size_t)c * WP_FLOATS, WpS + c * WP_FLOATS, wave0, lane0);
         }
     } else {
         if constexpr (COLTH > 0) {
-            mb_dma_at<WE_FLOATS>(d.We, we_ba, wave0, lane0);
-            mb_dma_at<WD_FLOATS>(d.Wd, wd_ba, wave0, lane0);
+            mb_dma_at<WE_FLOATS, NW>(d.We, we_ba, wave0, lane0);
+            mb_dma_at<WD_FLOATS, NW>(d.Wd, wd_ba, wave0, lane0);
         } else {
-            mb_dma<WE_FLOATS>(d.We, WeS, wave0, lane0);
-            mb_dma<WD_FLOATS>(d.Wd, Wds, wave0, lane0);
+            mb_dma<WE_FLOATS, NW>(d.We, WeS, wave0, lane0);
+            mb_dma<WD_FLOATS, NW>(d.Wd, Wds, wave0, lane0);
         }
         if (ring) {
-            mb_dma<WP_FLOATS>(d.Wp, WpS, wave0, lane0);
+            mb_dma<WP_FLOATS, NW>(d.Wp, WpS, wave0, lane0);
             if (d.nchunks > 1) {
-                mb_dma<WE_FLOATS>(d.We + WE_FLOATS, WeS + WE_FLOATS, wave0, lane0);
-                mb_dma<WD_FLOATS>(d.Wd + WD_FLOATS, Wds + WD_FLOATS, wave0, lane0);
-                mb_dma<WP_FLOATS>(d.Wp + WP_FLOATS, WpS + WP_FLOATS, wave0, lane0);
+                mb_dma<WE_FLOATS, NW>(d.We + WE_FLOATS, WeS + WE_FLOATS, wave0, lane0);
+                mb_dma<WD_FLOATS, NW>(d.Wd + WD_FLOATS, Wds + WD_FLOATS, wave0, lane0);
+                mb_dma<WP_FLOATS, NW>(d.Wp + WP_FLOATS, WpS + WP_FLOATS, wave0, lane0);
             }
         }
     }
@@ -373,7 +379,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
             }
         }
     }
-    for (int p = tid; p < POUT_PAD; p += 256) {
+    for (int p = tid; p < POUT_PAD; p += NTH) {
         const int sl = (p >= THTW ? 1 : 0) + (p >= 2 * THTW ? 1 : 0), pp = p - sl * THTW;  // SS <= 2
         const int ty = pp >> TWL, tx = pp & (TW - 1);
         int o = -1;
@@ -383,7 +389,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
     if (M != egrid) {  // some of the grid lies outside the image (or a segment is missing): zero padding
         float4 *z = reinterpret_cast<float4 *>(Es);
         const int n4 = egrid * CES / 4;
-        for (int i = tid; i < n4; i += 256) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = tid; i < n4; i += NTH) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     mb_dma_wait();
     __syncthreads();
@@ -558,13 +564,85 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
             if constexpr (COLTH > 0) {
                 // (issued in parts inside the depthwise phase below)
             } else {
-                mb_dma<WE_FLOATS>(d.We + (size_t)chn * WE_FLOATS, WeS, wave, lane);
-                mb_dma<WP_FLOATS>(d.Wp + (size_t)ch * WP_FLOATS, WpS, wave, lane);
+                mb_dma<WE_FLOATS, NW>(d.We + (size_t)chn * WE_FLOATS, WeS, wave, lane);
+                mb_dma<WP_FLOATS, NW>(d.Wp + (size_t)ch * WP_FLOATS, WpS, wave, lane);
             }
         }
         mb_stamp(d.stamps, t_last, 3);
 
         // ---- P2: depthwise, XB output pixels x 4 channels per lane ---------------------------
+        if constexpr (COLTH > 0 && NW == 8) {
+            // column tasks of the 8-wave workgroups: one lane = one output column (all COLTH rows) x TWO channels, so that
+            // SS * TW * CE / 2 = 512 tasks fill the workgroup and a task's rows (COLTH x KS float2) fit beside the resident A
+            // fragments in the 256 registers two waves per SIMD leave; rows are finished two at a time (two interleaved GELU
+            // chains per lane, as bh_act4 does for the 4-channel tasks)
+            constexpr int PADT = (KS - 1) / 2, C2N = CE / 2;
+            static_assert(ST == 1, "column tasks: stride 1");
+            const bool dma_on = !(d.dbg & 16);
+            if (!(tid < nsv * TW * C2N && !(d.dbg & 2))) {   // (wave-uniform)
+                if (dma_on) {
+                    mb_dma_at<WE_FLOATS, NW>(d.We + (size_t)chn * WE_FLOATS, we_ba, wave, lane);
+                    mb_dma_at<WP_FLOATS, NW>(d.Wp + (size_t)ch * WP_FLOATS, wp_ba, wave, lane);
+                }
+            } else {
+                const int c2 = tid % C2N, q = tid / C2N, x = q & (TW - 1), sl = q >> TWL;
+                const float *eb = Es + ((sl * IH + PADT) * IW + x) * CES + 2 * c2;   // grid row PADT = image row 0
+                // one grid COLUMN of the task's window at a time (the next one in flight): all COLTH x KS values at once are 60
+                // registers under a 5x5 kernel on a 6-row image, which the 256 of a wave here do not have beside the A fragments
+                f32x2 e[2][COLTH];
+#pragma unroll
+                for (int r = 0; r < COLTH; r++) e[0][r] = *reinterpret_cast<const f32x2 *>(eb + (r * IW) * CES);
+                const f32x2 bd2 = *reinterpret_cast<const f32x2 *>(&bds[2 * c2]);
+                f32x2 acc[COLTH];
+#pragma unroll
+                for (int r = 0; r < COLTH; r++) acc[r] = bd2;
+#pragma unroll
+                for (int dx = 0; dx < KS; dx++) {
+                    if (dx + 1 < KS) {
+#pragma unroll
+                        for (int r = 0; r < COLTH; r++) e[(dx + 1) & 1][r] = *reinterpret_cast<const f32x2 *>(eb + (r * IW + dx + 1) * CES);
+                    }
+#pragma unroll
+                    for (int dy = 0; dy < KS; dy++) {
+                        const f32x2 w = *reinterpret_cast<const f32x2 *>(&WdC[(dy * KS + dx) * CE + 2 * c2]);
+#pragma unroll
+                        for (int r = 0; r < COLTH; r++) {
+                            constexpr int dummy = 0; (void)dummy;
+                            const int src = r + dy - PADT;          // image row under this tap; outside [0, COLTH): zero padding
+                            if (src < 0 || src >= COLTH) continue;   // (compile-time after unrolling)
+                            acc[r] = __builtin_elementwise_fma(e[dx & 1][src], w, acc[r]);
+                        }
+                    }
+                    if (dma_on) {   // this column's share of the next chunk's expand weights and this chunk's project weights
+                        mb_dma_at_part<WE_FLOATS, NW>(d.We + (size_t)chn * WE_FLOATS, we_ba, wave, lane, dx, KS);
+                        mb_dma_at_part<WP_FLOATS, NW>(d.Wp + (size_t)ch * WP_FLOATS, wp_ba, wave, lane, dx, KS);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);   // one window column of loads in flight
+                }
+#pragma unroll
+                for (int r = 0; r < COLTH; r += 2) {
+                    f32x2 g0 = acc[r], g1 = acc[r + 1 < COLTH ? r + 1 : r];
+                    if (r + 1 < COLTH) bh_act4<ACT>(g0, g1);
+                    else g0 = bh_act2<ACT>(g0);
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        if (r + k >= COLTH) continue;
+                        const f32x2 g = k ? g1 : g0;
+                        const int prow = sl * THTW + ((r + k) << TWL) + x;
+                        if constexpr (PREC == 3) {
+                            bh_f16x2 h, l;
+                            bh_split2(g[0], g[1], h, l);
+                            *reinterpret_cast<bh_f16x2 *>(&DsH[prow * DSH + 2 * c2]) = h;
+                            *reinterpret_cast<bh_f16x2 *>(&DsL[prow * DSH + 2 * c2]) = l;
+                        } else if constexpr (PREC == 1) {
+                            *reinterpret_cast<bh_f16x2 *>(&DsH[prow * DSH + 2 * c2]) = (bh_f16x2){(_Float16)g[0], (_Float16)g[1]};
+                        } else {
+                            *reinterpret_cast<f32x2 *>(&Ds[prow * CES + 2 * c2]) = g;
+                        }
+                    }
+                }
+            }
+        } else
         if constexpr (COLTH > 0) {
             // column tasks (see COLTH above): task = (segment slot, column x, channel group c4); mb_try_th guarantees TH == H ==
             // Ho == COLTH, one tile row, pad_t == (KS - 1) / 2 and at most 256 tasks
@@ -573,8 +651,8 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
             const bool dma_on = !(d.dbg & 16);
             if (!(tid < nsv * TW * C4N && !(d.dbg & 2))) {   // (wave-uniform: a wave without tasks issues its pieces at once)
                 if (dma_on) {
-                    mb_dma_at<WE_FLOATS>(d.We + (size_t)chn * WE_FLOATS, we_ba, wave, lane);
-                    mb_dma_at<WP_FLOATS>(d.Wp + (size_t)ch * WP_FLOATS, wp_ba, wave, lane);
+                    mb_dma_at<WE_FLOATS, NW>(d.We + (size_t)chn * WE_FLOATS, we_ba, wave, lane);
+                    mb_dma_at<WP_FLOATS, NW>(d.Wp + (size_t)ch * WP_FLOATS, wp_ba, wave, lane);
                 }
             } else {
                 const int c4 = tid % C4N, q = tid / C4N, x = q & (TW - 1), sl = q >> TWL;
@@ -605,8 +683,8 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                         }
                     }
                     if (dma_on) {   // this row's share of the next chunk's expand weights and this chunk's project weights
-                        mb_dma_at_part<WE_FLOATS>(d.We + (size_t)chn * WE_FLOATS, we_ba, wave, lane, dy, KS);
-                        mb_dma_at_part<WP_FLOATS>(d.Wp + (size_t)ch * WP_FLOATS, wp_ba, wave, lane, dy, KS);
+                        mb_dma_at_part<WE_FLOATS, NW>(d.We + (size_t)chn * WE_FLOATS, we_ba, wave, lane, dy, KS);
+                        mb_dma_at_part<WP_FLOATS, NW>(d.Wp + (size_t)ch * WP_FLOATS, wp_ba, wave, lane, dy, KS);
                     }
                     __builtin_amdgcn_sched_barrier(0);   // one kernel row of weight loads in flight
                 }
@@ -631,8 +709,8 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
             }
         } else
         if (!(d.dbg & 2)) {
-            for (int t = tid; t < p2_ntask; t += 256) {
-                if (p2_ntask > 256) p2_task(t);   // wave-uniform
+            for (int t = tid; t < p2_ntask; t += NTH) {
+                if (p2_ntask > NTH) p2_task(t);   // wave-uniform
                 const int c4 = p2_c4;
                 const float *eb = Es + p2_eoff;
                 const float4 bd4 = *reinterpret_cast<const float4 *>(&bds[4 * c4]);
@@ -688,15 +766,15 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
         if (PERSIST) {
         } else if (!ring) {
             if (!(d.dbg & 16)) {
-                if constexpr (COLTH > 0) mb_dma_at<WD_FLOATS>(d.Wd + (size_t)chn * WD_FLOATS, wd_ba, wave, lane);
-                else mb_dma<WD_FLOATS>(d.Wd + (size_t)chn * WD_FLOATS, Wds, wave, lane);
+                if constexpr (COLTH > 0) mb_dma_at<WD_FLOATS, NW>(d.Wd + (size_t)chn * WD_FLOATS, wd_ba, wave, lane);
+                else mb_dma<WD_FLOATS, NW>(d.Wd + (size_t)chn * WD_FLOATS, Wds, wave, lane);
             }
         } else if (ch + 2 < nchunks && !(d.dbg & 16)) {
             // chunk ch + 2 into the buffers chunk ch has just finished with (We, Wd: read before this barrier) and into the Wp
             // buffer of chunk ch - 1 (its project phase ended before B1 of this chunk)
-            mb_dma<WE_FLOATS>(d.We + (size_t)(ch + 2) * WE_FLOATS, WeS + (ch & 1) * WE_FLOATS, wave, lane);
-            mb_dma<WD_FLOATS>(d.Wd + (size_t)(ch + 2) * WD_FLOATS, Wds + (ch & 1) * WD_FLOATS, wave, lane);
-            mb_dma<WP_FLOATS>(d.Wp + (size_t)(ch + 2) * WP_FLOATS, WpS + ((ch + 2) % 3) * WP_FLOATS, wave, lane);
+            mb_dma<WE_FLOATS, NW>(d.We + (size_t)(ch + 2) * WE_FLOATS, WeS + (ch & 1) * WE_FLOATS, wave, lane);
+            mb_dma<WD_FLOATS, NW>(d.Wd + (size_t)(ch + 2) * WD_FLOATS, Wds + (ch & 1) * WD_FLOATS, wave, lane);
+            mb_dma<WP_FLOATS, NW>(d.Wp + (size_t)(ch + 2) * WP_FLOATS, WpS + ((ch + 2) % 3) * WP_FLOATS, wave, lane);
         }
         mb_stamp(d.stamps, t_last, 5);
 
@@ -731,7 +809,7 @@ __global__ __launch_bounds__(256, OCC) void mbconv_kernel(const MbDesc d, const 
                 const f16x8 *wf = reinterpret_cast<const f16x8 *>(WpC);
                 // the weight fragments of a step are taken JB column tiles at a time: all NT_W (up to 10 hi +
                 // 10 lo quads) at once cost 80 registers and spilled the 320-channel blocks
-                constexpr int JB = NT_W <= 6 ? NT_W : (NT_W + 1) / 2;
+                constexpr int JB = NT_W <= (NW == 8 ? 4 : 6) ? NT_W : (NT_W + 1) / 2;   // (8 waves: 256 registers each)
 #pragma unroll
                 for (int g = 0; g < PSTEPS; g++) {
                     f16x8 a_h[MT_W], a_l[MT_W];
@@ -839,7 +917,7 @@ void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
     auto kern = mbconv_kernel<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, SS, OCC, STEM, PREC, PERSIST, ACT, COLTH>;
     static DeviceOnce attr_set;
     attr_set.run([&] { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-    dim3 grid(d.tiles_x, d.tiles_y, (n_seg + d.S - 1) / d.S), block(256);
+    dim3 grid(d.tiles_x, d.tiles_y, (n_seg + d.S - 1) / d.S), block(64 * WM * WN);
     if (PERSIST) {   // as many workgroups as are resident at once: registers allow OCC per SIMD, LDS 160 KB per CU
         const long total = (long)d.tiles_x * d.tiles_y * ((n_seg + d.S - 1) / d.S);
         const long per_cu = std::max<long>(1, std::min<long>(OCC, (160 * 1024) / (long)(d.lds_bytes + 256)));
@@ -872,7 +950,7 @@ void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
     MB_ENTRY_P(KS, ST, 32, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, 3),          \
     MB_ENTRY_P(KS, ST, 32, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, 1)
 
-// The list (mbconv_cfgs.inc: 99 tile configurations, indices as documented there) is instantiated once per activation:
+// The list (mbconv_cfgs.inc: 111 tile configurations, indices as documented there) is instantiated once per activation:
 // entry ci + k * kNBase is configuration ci with the k-th activation of kActs.
 constexpr int kActs[] = {ACT_GELU_ERF, ACT_SWISH, ACT_RELU6};
 const MbCfg kCfgs[] = {
@@ -903,7 +981,7 @@ double mb_try_th(MbDesc &d, int ci, int th) {
     if (d.act_e != c.ACT || d.act_d != c.ACT || d.act_p != ACT_NONE) return -1;
     if (c.COLTH) {   // column tasks: the tile is the whole image, COLTH rows high, symmetric padding, one task per thread
         if (th != c.COLTH || d.Ho != c.COLTH || d.H != c.COLTH || d.ST != 1 || d.pad_t != (c.KS - 1) / 2) return -1;
-        if (c.S * (1 << c.TWL) * (c.CE / 4) > 256) return -1;
+        if (c.S * (1 << c.TWL) * (c.CE / (c.WM * c.WN == 8 ? 2 : 4)) > 64 * c.WM * c.WN) return -1;   // one task per thread
     }
     const int nto = (d.Cout + 15) / 16;
     if (nto > c.WN * c.NT_W) return -1;
@@ -917,7 +995,7 @@ double mb_try_th(MbDesc &d, int ci, int th) {
     t.KG = c.KG; t.nchunks = (d.Cexp + c.CE - 1) / c.CE; t.NTOP = c.WN * c.NT_W; t.CE = c.CE;
     const int mseg = std::min(t.IH, d.H) * std::min(t.IW, d.W);
     t.mpad_max = (c.S * mseg + 15) / 16 * 16;
-    if (t.mpad_max / 16 > c.RT_W * (4 / c.NCS)) return -1;  // a wave keeps all its rows of X in registers
+    if (t.mpad_max / 16 > c.RT_W * (c.WM * c.WN / c.NCS)) return -1;  // a wave keeps all its rows of X in registers
     const size_t frag = c.PREC ? 512 : 256, psteps = c.PREC ? (c.CE + 31) / 32 : c.CE / 16;
     const bool p16 = c.PREC && c.CE == 16;   // one 16-deep project step, half-size fragments and D rows
     const size_t we_fl = (size_t)c.KG * (c.CE / 16) * frag + c.CE, wp_fl = p16 ? (size_t)t.NTOP * 256 : psteps * t.NTOP * frag;
@@ -1003,10 +1081,13 @@ bool mb_plan(MbDesc &d, int force_cfg) {
     // (741 -> 686, 576 -> 536); the stem, 16 -> 96 -> 24 and 24 -> 144 -> 24 blocks LOSE (928 -> 1161, 1032 -> 1504, 737 -> 953):
     // with every chunk's weights resident they fit two workgroups per CU instead of four, and without a prefetch of the next
     // tile's rows nothing hides a tile's set-up.  Off by default; BIRDA_HIP_MB_PERSIST=1 all six, =2 the 5x5 pair.
-    static const int kPreferred16a[] = {79, 80, 81, 82, 83, 84, 48, 49, 50, 51, 52, 55, 58, 65, 66, 85, 87, 89, 91, 95, 97};
-    static const int kPreferred16p[] = {83, 84, 48, 49, 50, 51, 52, 55, 58, 65, 66, 85, 87, 89, 91, 95, 97};
-    static const int kPreferred16n[] = {48, 49, 50, 51, 52, 55, 58, 65, 66, 85, 87, 89, 91, 95, 97};
-    static const int kPreferred1[] = {86, 88, 90, 92, 96, 98};   // plain f16: the column-task twins where they apply, else the work rule
+    static const int kPreferred16a[] = {79, 80, 81, 82, 83, 84, 48, 49, 50, 51, 52, 55, 58, 65, 66, 99, 101, 103, 105, 107, 109, 85, 87, 89, 91, 95, 97};
+    static const int kPreferred16p[] = {83, 84, 48, 49, 50, 51, 52, 55, 58, 65, 66, 99, 101, 103, 105, 107, 109, 85, 87, 89, 91, 95, 97};
+    static const int kPreferred16n[] = {48, 49, 50, 51, 52, 55, 58, 65, 66, 99, 101, 103, 105, 107, 109, 85, 87, 89, 91, 95, 97};
+    // 99..110: the 8-wave twins of 85..92 and 95..98 (two waves per SIMD inside the one workgroup a CU holds): 307 -> 257,
+    // 426 -> 391, 258 -> 224, 292 -> 254 us per 1 000 segments (old and new library in one run, tools/ab_lib.sh); Perch-shaped
+    // model 410 -> 256, 407 -> 298
+    static const int kPreferred1[] = {100, 102, 104, 106, 108, 110, 86, 88, 90, 92, 96, 98};   // plain f16: the column-task twins where they apply, else the work rule
     const char *pe = getenv("BIRDA_HIP_MB_PERSIST");
     const int persist_mode = !pe ? 0 : pe[0] == '1' ? 2 : pe[0] == '2' ? 1 : 0;
     if (d.prec == 0)
