@@ -260,7 +260,10 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
     // computing the next one's addresses: RT_W dependent HBM round trips at the start of every workgroup.
     constexpr int NV = PREC ? 8 : 4;            // consecutive k per lane and step
     constexpr int NQ = STEM ? 2 : NV / 4;       // 16-byte (stem, f16 modes: 12-byte) loads per (row tile, step)
-    constexpr int XBATCH = (STEM && !PREC) ? 1 : (RT_W * KG * NQ <= 16 ? RT_W : (16 / (KG * NQ) >= 1 ? 16 / (KG * NQ) : 1));
+    // (8-wave kernels: one workgroup per CU, so nothing hides a second round trip of the set-up, and at that point the 256 registers
+    //  hold nothing but these loads and the fragments they become: all row tiles in one batch)
+    constexpr int XLIM = NW == 8 ? 24 : 16;
+    constexpr int XBATCH = (STEM && !PREC) ? 1 : (RT_W * KG * NQ <= XLIM ? RT_W : (XLIM / (KG * NQ) >= 1 ? XLIM / (KG * NQ) : 1));
     struct __attribute__((packed, aligned(4))) F3 { float a, b, c; };
 #pragma unroll
     for (int i0 = 0; i0 < RT_W; i0 += XBATCH) {
