@@ -256,7 +256,10 @@ int read_labels(const char *path, std::vector<std::string> &out) {
 void ctx_mark(bh_batch_context *ctx, int stage, int layer = -1) {
     if (!ctx->profiling) return;
     hipEvent_t e;
-    if (hipEventCreate(&e) != hipSuccess) return;
+    // timing-only events: without the system-scope fence (an L2 write-back + invalidate between every two kernels, which the
+    // un-profiled pipeline never sees; BIRDA_HIP_EVENT_FENCE=1 restores the default events: A/B aid)
+    static const bool fence = getenv("BIRDA_HIP_EVENT_FENCE") && getenv("BIRDA_HIP_EVENT_FENCE")[0] == '1';
+    if (hipEventCreateWithFlags(&e, fence ? hipEventDefault : hipEventDisableSystemFence) != hipSuccess) return;
     (void)hipEventRecord(e, ctx->stream);
     ctx->ev.push_back(e);
     ctx->ev_stage.push_back(stage);
