@@ -953,7 +953,7 @@ void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
     MB_ENTRY_P(KS, ST, 32, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, 3),          \
     MB_ENTRY_P(KS, ST, 32, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, 1)
 
-// The list (mbconv_cfgs.inc: 113 tile configurations, indices as documented there) is instantiated once per activation:
+// The list (mbconv_cfgs.inc: 115 tile configurations, indices as documented there) is instantiated once per activation:
 // entry ci + k * kNBase is configuration ci with the k-th activation of kActs.
 constexpr int kActs[] = {ACT_GELU_ERF, ACT_SWISH, ACT_RELU6};
 const MbCfg kCfgs[] = {
@@ -1084,13 +1084,13 @@ bool mb_plan(MbDesc &d, int force_cfg) {
     // (741 -> 686, 576 -> 536); the stem, 16 -> 96 -> 24 and 24 -> 144 -> 24 blocks LOSE (928 -> 1161, 1032 -> 1504, 737 -> 953):
     // with every chunk's weights resident they fit two workgroups per CU instead of four, and without a prefetch of the next
     // tile's rows nothing hides a tile's set-up.  Off by default; BIRDA_HIP_MB_PERSIST=1 all six, =2 the 5x5 pair.
-    static const int kPreferred16a[] = {79, 80, 81, 82, 83, 84, 48, 49, 50, 51, 52, 55, 58, 65, 66, 99, 101, 103, 105, 107, 109, 111, 85, 87, 89, 91, 95, 97};
-    static const int kPreferred16p[] = {83, 84, 48, 49, 50, 51, 52, 55, 58, 65, 66, 99, 101, 103, 105, 107, 109, 111, 85, 87, 89, 91, 95, 97};
-    static const int kPreferred16n[] = {48, 49, 50, 51, 52, 55, 58, 65, 66, 99, 101, 103, 105, 107, 109, 111, 85, 87, 89, 91, 95, 97};
+    static const int kPreferred16a[] = {79, 80, 81, 82, 83, 84, 48, 49, 50, 51, 52, 113, 55, 58, 65, 66, 99, 101, 103, 105, 107, 109, 111, 85, 87, 89, 91, 95, 97};
+    static const int kPreferred16p[] = {83, 84, 48, 49, 50, 51, 52, 113, 55, 58, 65, 66, 99, 101, 103, 105, 107, 109, 111, 85, 87, 89, 91, 95, 97};
+    static const int kPreferred16n[] = {48, 49, 50, 51, 52, 113, 55, 58, 65, 66, 99, 101, 103, 105, 107, 109, 111, 85, 87, 89, 91, 95, 97};
     // 99..110: the 8-wave twins of 85..92 and 95..98 (two waves per SIMD inside the one workgroup a CU holds): 307 -> 257,
     // 426 -> 391, 258 -> 224, 292 -> 254 us per 1 000 segments (old and new library in one run, tools/ab_lib.sh); Perch-shaped
     // model 410 -> 256, 407 -> 298
-    static const int kPreferred1[] = {100, 102, 104, 106, 108, 110, 112, 86, 88, 90, 92, 96, 98};   // plain f16: the column-task twins where they apply, else the work rule
+    static const int kPreferred1[] = {100, 102, 104, 106, 108, 110, 112, 114, 86, 88, 90, 92, 96, 98};   // plain f16: the column-task twins where they apply, else the work rule
     const char *pe = getenv("BIRDA_HIP_MB_PERSIST");
     const int persist_mode = !pe ? 0 : pe[0] == '1' ? 2 : pe[0] == '2' ? 1 : 0;
     if (d.prec == 0)

@@ -400,7 +400,7 @@ def test_full_model_runs_every_inverted_residual_block_fused(full_model):
 @pytest.mark.parametrize("precision", ["f16x3", "f16"])
 def test_column_task_late_blocks_against_the_row_task_ones(full_model, oracle_lib, monkeypatch, precision):
     """The whole-image late blocks (6x32 and 3x16 under 5x5 / 3x3 kernels) run their depthwise phase as column tasks
-    (kernels_mbconv.hip COLTH: padding rows skipped at compile time, 256 tasks).  They are the planner's choice on the full
+    (kernels_mbconv.hip COLTH: padding rows skipped at compile time, one task per thread) in 8-wave workgroups.  They are the planner's choice on the full
     model; forcing the row-task entries (34 ... 43) instead must give the same logits to the mode's tolerance, and both must
     match the oracle."""
     from birda_amd import synth
@@ -410,13 +410,16 @@ def test_column_task_late_blocks_against_the_row_task_ones(full_model, oracle_li
     ref = oracle_lib.OracleModel(path).forward(segs)
     scale = max(1.0, float(np.abs(ref).max()))
     out = {}
-    for tag, prefer in (("column", None), ("row", "34,35,36,37,40,41,42,43")):
+    for tag, prefer in (("column", None), ("row", "34,35,36,37,40,41,42,43,55,33")):
         if prefer:
             monkeypatch.setenv("BIRDA_HIP_MB_PREFER", prefer)
         clf = BirdClassifier(path, labels, precision=precision)
         names = [clf.fused_kernel_name(b) for b in clf.fused_blocks()]
         n_col = sum(1 for n in names if int(n.rstrip(">").split(",")[18]) > 0)
-        assert n_col == (7 if tag == "column" else 0), names       # 80->480->112, 2 x 112->672->112, 3 x 192->1152->192, 192->1152->320
+        # 2 x 80->480->80 (3x3), 80->480->112, 2 x 112->672->112, 3 x 192->1152->192, 192->1152->320
+        assert n_col == (9 if tag == "column" else 0), names
+        if tag == "column":     # ... and they are the 8-wave workgroups (wave grid WM x WN = 8)
+            assert all(int(n.split("<")[1].split(",")[6]) * int(n.split(",")[7]) == 8 for n in names if int(n.rstrip(">").split(",")[18]) > 0), names
         ctx = clf.create_batch_context(5)
         out[tag] = clf.predict_logits(ctx, segs)
         ctx.close(); clf.close()
