@@ -291,6 +291,39 @@ def test_device_code_has_no_half_swapped_packed_f32_ops(tmp_path):
     assert n_packed > 1000      # the disassembly really is the library's device code (the GELU alone is packed f32)
 
 
+def test_shipped_hot_kernels_fit_their_register_budget():
+    """The kernels the planner picks for the BirdNET-shaped model, read from the code objects in libbirda_hip.so
+    (tools/kernel_resources.py: metadata notes, no GPU): the early blocks -- vector-issue-bound, every scratch access is issue
+    slots lost -- must not spill at all and must keep the registers of 4 / 3 waves per SIMD; the late blocks must be the 8-wave
+    workgroups (512 threads) at two waves per SIMD with at most a dozen spilled registers; the front-end kernel two workgroups per
+    CU without scratch.  A source change that silently costs one of these shows up here before it shows up in a profile."""
+    import subprocess, sys
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not all(os.path.exists(os.path.join(llvm, t)) for t in ("llvm-objcopy", "clang-offload-bundler", "llvm-readelf")):
+        pytest.skip("ROCm llvm tools not available")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_resources.py"),
+                          os.path.join(ROOT, "birda_amd", "libbirda_hip.so")], check=True, capture_output=True, text=True, timeout=600).stdout
+    res = {}
+    for line in out.splitlines():
+        m = re.match(r"(\S.*?)\s+vgpr\s+(\d+) agpr\s+(\d+) sgpr\s+\d+ scratch\s+(\d+) threads (\d+)", line)
+        if m:
+            res[m.group(1).replace(" ", "")] = tuple(int(v) for v in m.groups()[1:])
+    def k(args):
+        return res["mbconv_kernel<" + args + ">"]
+    # stem, 16->96->24, 24->144->24 (f16x3, GELU): no scratch, 4 / 4 / 3 waves per SIMD
+    for args, max_regs in (("3,1,16,1,3,1,4,1,2,1,4,1,1,4,2,3,0,4,0", 128), ("3,2,16,1,5,1,4,1,1,2,4,0,1,4,0,3,0,4,0", 128),
+                           ("3,1,16,1,3,1,4,1,2,2,4,1,1,3,0,3,0,4,0", 168)):
+        vgpr, agpr, scratch, threads = k(args)
+        assert scratch == 0 and vgpr + agpr <= max_regs and threads == 256, (args, k(args))
+    # the nine late blocks' five instantiations: 8 waves, 256 registers, <= 12 spilled
+    for args in ("3,1,32,3,3,2,4,2,3,3,5,3,1,2,0,3,0,4,6", "5,1,32,3,3,2,4,2,3,4,5,3,1,2,0,3,0,4,6", "5,1,32,4,3,2,4,2,3,4,5,3,1,2,0,3,0,4,6",
+                 "5,1,32,6,2,2,2,4,3,3,4,2,2,2,0,3,0,4,3", "3,1,32,6,2,2,2,4,3,5,4,2,2,2,0,3,0,4,3"):
+        vgpr, agpr, scratch, threads = k(args)
+        assert threads == 512 and vgpr + agpr <= 256 and scratch <= 48, (args, k(args))
+    vgpr, agpr, scratch, threads = res["mel_kernel<6,3>"]
+    assert scratch == 0 and vgpr + agpr <= 256
+
+
 # ---------------- range filter tables (host logic, include/birda_host.h) ----------------
 def test_species_mapping_and_projection_match_reference_cases_and_oracle(L, cases, oracle_lib):
     from birda_amd import pipeline
