@@ -93,8 +93,9 @@ def cpu_baseline(model_path, sample_count, sample_rate, hip_logits=None):
     cores = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     om = O.OracleModel(model_path)
-    base = synth.synth_segments(min(cores, 16), sample_count, sample_rate)
-    ref = om.forward(base[: min(cores, base.shape[0])])  # touch code / pages once; reference logits of segments 0..
+    # the timed lists tile 64 distinct segments: all 64 go through the checker (16 on a small host, where 64 would take minutes)
+    base = synth.synth_segments(64 if cores >= 32 else min(cores, 16), sample_count, sample_rate)
+    ref = om.forward(base)  # touch code / pages once; reference logits of segments 0..
     parity = None
     if hip_logits:
         parity = {}
@@ -417,6 +418,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    n_visible = torch.cuda.device_count()
+    if world > 1 and args.gpus != world:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                 f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...) or unset WORLD_SIZE")
+    if os.environ.get("BIRDA_BENCH_DRYRUN_ONE_DEVICE") != "1" and n_visible < (args.gpus if world == 1 else 1):
+        sys.exit(f"bench.py: --gpus {args.gpus} asked for, but {n_visible} HIP device(s) are visible: refusing to report a line "
+                 f"that says n_gpus={args.gpus} (there is no CPU path and no silent single-GPU fallback)")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -439,8 +449,20 @@ def main():
     m = synth.build_model(kind)
     mf.write_model(model_path, m)
 
-    if args.config == "c3" and world == 1:
-        return bench_c3_multi(args, m, model_path, tmp)
+    if world == 1 and (args.gpus > 1 or args.config == "c3"):
+        # `--gpus N` without torch.distributed.run (and config 3): N shards in this process through bh_multi_*
+        if args.config in ("c4", "c5"):
+            sys.exit(f"bench.py: --config {args.config} --gpus {args.gpus} needs torch.distributed.run (one rank per GPU); "
+                     "the in-process bh_multi_* path serves c2 and c3")
+        if args.config == "c3":
+            devices = [g * args.gpus // 8 for g in range(8)]
+            return bench_inproc_multi(args, m, model_path, tmp, devices, 10000, "strong",
+                                      "configs[2]: 10 000 synthetic 3 s/48 kHz segments as 8 contiguous shards in ONE process through "
+                                      "bh_multi_forward_device (host threads, one context + stream per shard, packed top-k gather); "
+                                      "results include the unpack into bh_result rows")
+        return bench_inproc_multi(args, m, model_path, tmp, list(range(args.gpus)), SEGMENTS_PER_GPU * args.gpus, "weak",
+                                  "configs[1] per GPU: 1000 synthetic 3 s/48 kHz segments per GPU per step, HBM-resident, one shard per GPU, "
+                                  "packed top-k rows gathered to the host")
 
     clf = BirdClassifier(model_path, None, top_k=5, min_confidence=0.1, device=local_rank, precision=args.precision)
     ctx = clf.create_batch_context(args.micro_batch)
@@ -555,8 +577,8 @@ def main():
     if args.config == "c5":
         first = logits[inv[:16]].cpu().numpy()            # list order
     else:
-        first = logits[:16].cpu().numpy()
-    hip_logits = {args.precision: first} if rank == 0 else None   # segments 0..15 of the global list
+        first = logits[:64].cpu().numpy()                 # every distinct segment of the timed batch
+    hip_logits = {args.precision: first} if rank == 0 else None   # segments 0.. of the global list
     value = n_total * args.steps / elapsed
     segs_done = n_local * args.steps
     slices_per_step = max(1, -(-n_local // args.micro_batch))
@@ -610,7 +632,7 @@ def main():
                "gemm": "v_mfma_f32_16x16x4_f32 in every kernel"}
         f32.update(analyse(clf, m, info, clf.fused_blocks(), st2, ly2, n_local * args.steps, args.steps, slices_per_step, "f32"))
         out["f32_mfma_path"] = f32
-        hip_logits["f32"] = logits[:16].cpu().numpy()
+        hip_logits["f32"] = logits[:64].cpu().numpy()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         if args.config == "c5":       # the checker's path for this workload: oracle resampler -> oracle forward on the first segments
             out["cpu_baseline"] = cpu_baseline_c5(model_path, m, hip_logits)
@@ -659,20 +681,23 @@ def cpu_baseline_c5(model_path, m, hip_logits):
             "max_abs_dlogit_vs_oracle": parity}
 
 
-def bench_c3_multi(args, m, model_path, tmp):
-    """BASELINE configs[2] on one process through the C ABI: 10 000 HBM-resident segments as 8 contiguous shards
-    (bh_multi_forward_device).  With fewer than 8 GPUs visible the shards are logical devices on the GPUs that exist
-    (SURVEY.md section 0), which measures the sharding / gather machinery, not 8-GPU scaling."""
+def bench_inproc_multi(args, m, model_path, tmp, devices, n_total, scaling, workload):
+    """Several shards in ONE process through the C ABI (bh_multi_forward_device: one host thread + context + stream per
+    shard, packed top-k gather by RCCL all-gather when every shard has its own device, else hipMemcpyDtoH per shard).
+    Serves `--gpus N` without torch.distributed.run (one shard per device, 1 000 segments each: weak scaling) and
+    `--config c3` (10 000 segments as 8 contiguous shards; with fewer than 8 GPUs the shards are logical devices on the
+    GPUs that exist, SURVEY.md section 0, which measures the sharding / gather machinery, not 8-GPU scaling).
+    A step = one bh_multi_forward_device call: every shard's forward + the gather + the unpack into bh_result rows; the
+    call returns when all shards are done (the barrier), so the wall time of K calls is the max over shards."""
+    import ctypes as C
     import numpy as np
     import torch
     from birda_amd import sharding, synth
+    from birda_amd._lib import BhResult
     from birda_amd.multi import MultiClassifier
-    n_dev = torch.cuda.device_count()
-    G = 8
-    devices = [g * n_dev // G for g in range(G)]
-    n_total = 10000
+    G = len(devices)
     mc = MultiClassifier(model_path, None, devices=devices, top_k=5, min_confidence=0.1, precision=args.precision,
-                         max_batch=min(args.micro_batch, 625))
+                         max_batch=min(args.micro_batch, -(-n_total // G)))
     uniq = synth.synth_segments(64, m.sample_count, m.sample_rate, start=0)
     xs, counts = [], []
     for g in range(G):
@@ -681,35 +706,60 @@ def bench_c3_multi(args, m, model_path, tmp):
         xs.append(torch.from_numpy(host).to(f"cuda:{devices[g]}"))
         counts.append(hi - lo)
     ptrs = [x.data_ptr() for x in xs]
-    import ctypes as C
-    from birda_amd._lib import BhResult
     c_ptrs = (C.c_void_p * G)(*ptrs)
     c_counts = np.asarray(counts, np.uint64)
     c_res = (BhResult * n_total)()
 
-    def step():      # the C call alone: forwards on 8 streams + packed top-k gather + unpack into bh_result rows
+    def step():
         rc = mc._L.bh_multi_forward_device(mc._h, c_ptrs, c_counts.ctypes.data, c_res)
-        assert rc == 0, mc._L.bh_multi_last_error()
+        if rc != 0:
+            raise RuntimeError(mc._L.bh_multi_last_error().decode())
+
+    def sync_all():
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
     res = mc.forward_device(ptrs, counts)
     for _ in range(max(1, args.warmup)):
         step()
-    vals = []
-    for _ in range(5):
-        torch.cuda.synchronize()
+    clf0, ctx0 = mc.shard_classifier(0), mc.shard_context(0)
+    vals, stage_tot, layer_tot = [], None, None
+    for rep in range(5):
+        if rep == 0:
+            ctx0.set_profiling(True)     # HIP events around shard 0's launches, on its own stream
+        sync_all()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
+        sync_all()
         vals.append(n_total * args.steps / (time.perf_counter() - t0))
-    out = {"metric": "3s/48kHz segments/sec (BirdNET v2.4)", "value": round(vals[0], 1), "unit": "segments/s", "n_gpus": n_dev,
+        if rep == 0:
+            stage_tot = {k: [ms, n] for k, (ms, n) in ctx0.stage_ms().items()}
+            layer_tot = [[ms, n] for (ms, n) in ctx0.layer_ms()]
+            ctx0.set_profiling(False)
+    n_gpus = len(set(devices))
+    max_batch = min(args.micro_batch, -(-n_total // G))
+    out = {"metric": "3s/48kHz segments/sec (BirdNET v2.4)", "value": round(vals[0], 1), "unit": "segments/s", "n_gpus": n_gpus,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(n_total / vals[0] * 1e3, 3), "higher_is_better": True,
-           "scaling": "strong", "vs_baseline": None, "dtype": DTYPE[args.precision].split(" ")[0], "data": "synthetic",
-           "config": {"workload": "configs[2]: 10 000 synthetic 3 s/48 kHz segments as 8 contiguous shards in ONE process through bh_multi_forward_device "
-                                  "(host threads, one context + stream per shard, packed top-k gather); results include the unpack into bh_result rows",
-                      "shards": G, "shard_devices": devices, "gather": mc.gather_backend(), "precision": args.precision,
-                      "note": "shards that share a GPU are logical devices: this measures the sharding machinery, not multi-GPU scaling"},
-           "repeats": {"values": [round(v, 1) for v in vals], "median_of_5": round(statistics.median(vals), 1)},
-           "checks": {"results": len(res), "segments_with_predictions": sum(1 for r in res if r.predictions)},
-           "cpu_baseline": None}
+           "scaling": scaling, "vs_baseline": None, "dtype": DTYPE[args.precision].split(" ")[0], "data": "synthetic",
+           "config": {"workload": workload, "launch": "one process, bh_multi_* (no torch.distributed)",
+                      "shards": G, "shard_devices": devices, "segments_per_shard": counts, "micro_batch": max_batch,
+                      "gather_backend": mc.gather_backend(), "precision": args.precision,
+                      "gflop_per_segment": round((2 * mc.info.macs_per_segment + mc.info.mel_flops_per_segment) / 1e9, 3),
+                      "note": ("one shard per GPU" if n_gpus == G else
+                               "shards that share a GPU are logical devices: this measures the sharding machinery, not multi-GPU scaling")},
+           "repeats": {"values": [round(v, 1) for v in vals], "median_of_5": round(statistics.median(vals), 1),
+                       "note": "five regions of exactly --steps steps each; `value` is the first (the one that carries the profiling events)"},
+           "checks": {"results": len(res), "segments_with_predictions": sum(1 for r in res if r.predictions)}}
+    fused = clf0.fused_blocks()
+    out.update(analyse(clf0, m, mc.info, fused, stage_tot, layer_tot, counts[0] * args.steps, args.steps,
+                       max(1, -(-counts[0] // max_batch)), args.precision))
+    for k in ("roofline", "roofline_mel"):
+        if k in out:
+            out[k]["measured_on"] = "shard 0 (device %d), which shares its GPU with %d other shard(s)" % (devices[0], devices.count(devices[0]) - 1)
+    out["cpu_baseline"] = None
+    if n_gpus == 1 and not args.no_cpu_baseline:
+        hip = {args.precision: clf0.predict_logits(ctx0, uniq)}          # the 64 distinct segments of the timed lists
+        out["cpu_baseline"] = cpu_baseline(model_path, m.sample_count, m.sample_rate, hip)
     mc.close()
     print(json.dumps(out), flush=True)
 

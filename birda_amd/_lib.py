@@ -114,6 +114,13 @@ SYMBOLS = [
     ("bh_predict_batch_two_stage", C.c_int, [_VP, _VP, _VP, C.POINTER(_VP), _SZ, _SZ, C.POINTER(BhResult), _VP]),
     ("bh_classifier_set_bsg", C.c_int, [_VP, _VP, _VP, _VP, _SZ]),
     ("bh_classifier_clear_bsg", C.c_int, [_VP]),
+    ("bh_range_filter_create", C.c_int, [C.c_char_p, C.c_char_p, C.c_int32, C.c_float, C.POINTER(_VP)]),
+    ("bh_range_filter_destroy", None, [_VP]),
+    ("bh_range_filter_num_species", C.c_uint32, [_VP]),
+    ("bh_range_filter_label", C.c_char_p, [_VP, C.c_uint32]),
+    ("bh_range_filter_predict", C.c_int, [_VP, C.c_double, C.c_double, C.c_uint32, C.c_uint32, _VP, _SZ, _VP, C.POINTER(_SZ)]),
+    ("bh_range_filter_predict_week", C.c_int, [_VP, C.c_float, C.c_float, C.c_float, _VP, _SZ, _VP, C.POINTER(_SZ)]),
+    ("bh_birdnet_week", C.c_uint32, [C.c_uint32, C.c_uint32]),
     ("bh_multi_create", C.c_int, [C.POINTER(BhMultiConfig), C.POINTER(_VP)]),
     ("bh_multi_destroy", None, [_VP]),
     ("bh_multi_last_error", C.c_char_p, []),
@@ -205,6 +212,9 @@ HOST_SYMBOLS = [
     ("bhh_is_audio_file", C.c_int, [C.c_char_p]),
     ("bhh_collect_input_files", _SZ, [_VP, _SZ, C.c_char_p, _SZ, C.POINTER(_SZ)]),
     ("bhh_scientific_name_len", _SZ, [C.c_char_p]),
+    ("bhh_date_to_week", C.c_uint32, [C.c_uint32, C.c_uint32]),
+    ("bhh_week_to_start_day", C.c_uint32, [C.c_uint32]),
+    ("bhh_day_of_year_to_date", None, [C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("bhh_project_scores", C.c_int, [_VP, _SZ, _VP, _VP, _SZ, _VP, _SZ, C.c_float, _VP, C.POINTER(_SZ), C.POINTER(_SZ)]),
 ]
 

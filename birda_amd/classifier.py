@@ -98,9 +98,18 @@ class BatchInferenceContext:
         check(self._L.bh_batch_context_layer_ms(self._h, ms, cnt, n))
         return [(float(ms[i]), int(cnt[i])) for i in range(n)]
 
+    @classmethod
+    def borrow(cls, classifier: "BirdClassifier", handle, max_batch_size: int = 0) -> "BatchInferenceContext":
+        """A view of a context something else owns (a bh_multi shard's): close() leaves it alone."""
+        self = cls.__new__(cls)
+        self._L, self.classifier, self.max_batch_size = classifier._L, classifier, max_batch_size
+        self._h, self._borrowed = C.c_void_p(handle), True
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
-            self._L.bh_batch_context_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self._L.bh_batch_context_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -339,9 +348,21 @@ class BirdClassifier:
         check(self._L.bh_topk_from_logits(self._h, a.ctypes.data, a.shape[0], arr))
         return self._results(arr, a.shape[0])
 
+    @classmethod
+    def borrow(cls, handle, top_k: int = DEFAULT_TOP_K, min_confidence: float = DEFAULT_MIN_CONFIDENCE, device: int = 0) -> "BirdClassifier":
+        """A view of a classifier something else owns (a bh_multi shard's replica): close() leaves it alone."""
+        self = cls.__new__(cls)
+        self._L = _lib.load()
+        self._h, self._borrowed = C.c_void_p(handle), True
+        info = BhModelInfo()
+        check(self._L.bh_classifier_info(self._h, C.byref(info)))
+        self.info, self.top_k, self.min_confidence, self.device = info, top_k, min_confidence, device
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
-            self._L.bh_classifier_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self._L.bh_classifier_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -389,6 +410,50 @@ class CustomClassifier:
         h, self._h = getattr(self, "_h", None), None
         if h:
             self._L.bh_custom_classifier_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RangeFilter:
+    """birda's RangeFilter (reference src/inference/range_filter.rs:8-51): the geomodel query on the device.
+    `model_path` is the geomodel's .onnx file (read inside the library) or a BHC1 container; `labels_path` the GEOMODEL's
+    labels."""
+
+    def __init__(self, model_path: str, labels_path: str, threshold: float = 0.0, device: int = 0):
+        self._L = _lib.load()
+        h = C.c_void_p()
+        check(self._L.bh_range_filter_create(model_path.encode(), labels_path.encode(), device, threshold, C.byref(h)))
+        self._h = h
+
+    def num_species(self) -> int:
+        return int(self._L.bh_range_filter_num_species(self._h))
+
+    def labels(self) -> List[str]:
+        return [self._L.bh_range_filter_label(self._h, i).decode("utf-8") for i in range(self.num_species())]
+
+    def _run(self, call):
+        n = self.num_species()
+        scores = np.zeros(n, np.float32)
+        idx = np.zeros(n, np.uint32)
+        kept = C.c_size_t()
+        check(call(scores.ctypes.data, n, idx.ctypes.data, C.byref(kept)))
+        return scores, idx[: kept.value].copy()
+
+    def predict(self, latitude: float, longitude: float, month: int, day: int):
+        """-> (scores of every species, indices of those at or above the threshold)"""
+        return self._run(lambda s, n, i, k: self._L.bh_range_filter_predict(self._h, latitude, longitude, month, day, s, n, i, k))
+
+    def predict_week(self, latitude: float, longitude: float, week: float):
+        return self._run(lambda s, n, i, k: self._L.bh_range_filter_predict_week(self._h, latitude, longitude, week, s, n, i, k))
+
+    def close(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._L.bh_range_filter_destroy(h)
 
     def __del__(self):
         try:

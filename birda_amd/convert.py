@@ -547,3 +547,74 @@ def convert_file(onnx_path: str, frontend_bhm: Optional[str], out_path: str, spe
                          spectrogram_input, sample_rate, family)
     mf.write_model(out_path, m)
     return m
+
+
+def dense_stack_from_graph(g: ox.Graph, fold_final_sigmoid: bool = True) -> mf.CustomClassifierModel:
+    """A dense-stack ONNX graph (the BirdNET geomodel's shape: Gemm / MatMul + Add, Relu, a final Sigmoid or Softmax; the
+    reference's fixture tests/fixtures/fixture-geomodel.onnx is Gemm(3 -> 5) + Sigmoid) -> BHC1.  The Python twin of
+    birda_amd/csrc/onnx_dense.hpp (which reads the .onnx file inside the library): same chain walk, same refusals.  A final
+    Sigmoid becomes the last layer's activation, so every class's score leaves the GEMM activated (bh_range_filter_*)."""
+    data_inputs = [vi.name for vi in g.inputs]
+    if len(data_inputs) != 1 or len(g.outputs) != 1:
+        raise ConvertError("a dense stack has one data input and one output")
+    cur, out_name = data_inputs[0], g.outputs[0].name
+    layers: List[mf.CustomLayer] = []
+    out_act = mf.OUT_NONE
+    todo = list(g.nodes)
+    while cur != out_name:
+        node = next((n for n in todo if n.inputs and n.inputs[0] == cur), None)
+        if node is None:
+            raise ConvertError(f"graph is not a chain from its input to its output (at {cur!r})")
+        todo.remove(node)
+        if out_act != mf.OUT_NONE:
+            raise ConvertError(f"operator {node.op_type!r} after the output activation")
+        op = node.op_type
+        if op in ("Gemm", "MatMul"):
+            w = g.initializers.get(node.inputs[1]) if len(node.inputs) > 1 else None
+            if w is None or w.ndim != 2:
+                raise ConvertError(f"{op}: weight must be a 2-D initializer")
+            w = np.asarray(w, np.float32)
+            alpha = np.float32(node.attrs.get("alpha", 1.0)) if op == "Gemm" else np.float32(1.0)
+            beta = np.float32(node.attrs.get("beta", 1.0)) if op == "Gemm" else np.float32(1.0)
+            if op == "Gemm" and node.attrs.get("transA", 0):
+                raise ConvertError("Gemm: transA is not a dense layer")
+            if op == "Gemm" and node.attrs.get("transB", 0):
+                w = w.T
+            w = (alpha * w).astype(np.float32)
+            b = np.zeros(w.shape[1], np.float32)
+            if op == "Gemm" and len(node.inputs) > 2 and node.inputs[2]:
+                bias = np.asarray(g.initializers[node.inputs[2]], np.float32).reshape(-1)
+                b = (beta * np.broadcast_to(bias, (w.shape[1],))).astype(np.float32)
+            if layers and layers[-1].w.shape[1] != w.shape[0]:
+                raise ConvertError(f"{op}: layer widths do not chain")
+            layers.append(mf.CustomLayer(w, b, mf.ACT_NONE))
+        elif op == "Add":
+            bias = g.initializers.get(node.inputs[1]) if len(node.inputs) == 2 else None
+            if not layers or layers[-1].act != mf.ACT_NONE or bias is None or bias.size != layers[-1].w.shape[1]:
+                raise ConvertError("Add: only a bias right after MatMul / Gemm is a dense layer")
+            layers[-1].b = (layers[-1].b + np.asarray(bias, np.float32).reshape(-1)).astype(np.float32)
+        elif op in ("Relu", "Sigmoid"):
+            if not layers or layers[-1].act != mf.ACT_NONE:
+                raise ConvertError(f"{op} without a dense layer in front of it")
+            layers[-1].act = mf.ACT_RELU if op == "Relu" else mf.ACT_SIGMOID
+        elif op == "Softmax":
+            if not layers or layers[-1].act != mf.ACT_NONE:
+                raise ConvertError("Softmax without a dense layer in front of it")
+            out_act = mf.OUT_SOFTMAX
+        elif op in ("Identity", "Flatten", "Dropout"):
+            pass
+        else:
+            raise ConvertError(f"operator {op!r} is not part of a dense stack (Gemm, MatMul + Add, Relu, Sigmoid, Softmax)")
+        cur = node.outputs[0]
+    if not layers:
+        raise ConvertError("no dense layer between input and output")
+    if not fold_final_sigmoid and layers[-1].act == mf.ACT_SIGMOID:
+        layers[-1].act, out_act = mf.ACT_NONE, mf.OUT_SIGMOID
+    return mf.CustomClassifierModel(int(layers[0].w.shape[0]), out_act, layers)
+
+
+def convert_geomodel_file(onnx_path: str, out_path: str) -> mf.CustomClassifierModel:
+    """geomodel .onnx -> BHC1 (bh_range_filter_create takes either file)."""
+    m = dense_stack_from_graph(ox.load(open(onnx_path, "rb").read()))
+    mf.write_custom_classifier(out_path, m)
+    return m

@@ -889,8 +889,13 @@ extern "C" int bhh_process_files(bh_classifier *clf, const bhh_processing_config
             t_wait += ms(t0, now());
         }
         auto t1 = now();
-        if (p.rc == BH_ERR_UNSUPPORTED) {   // did not fit the staging buffer: the reference's way, one file at a time
+        // A pack that failed as a whole -- it did not fit the staging buffer, ONE of its recordings drove an f16 operand out of
+        // range (BH_ERR_NONFINITE), an upload or launch failed -- says nothing about the other files in it: the reference isolates
+        // failures per file (lib.rs:1003-1100 counts the file in files_failed and goes on), so every file of the pack is re-run
+        // the reference's way, one at a time, and only the offending one reports the error.
+        if (p.rc != BH_OK) {
             for (auto &pfp : p.files) single(pfp->index);
+            t_finish += ms(t1, now());
             return;
         }
         size_t row = 0;
@@ -1129,3 +1134,31 @@ extern "C" BH_API size_t bhh_collect_input_files(const char *const *paths, size_
     if (out && cap > joined.size()) std::memcpy(out, joined.c_str(), joined.size() + 1);
     return joined.size() + 1;
 } catch (...) { return (h_on_exception(), (size_t)-1); }
+
+
+// ---- range-filter date arithmetic (reference src/utils/date.rs:21-70; constants.rs:324-330,399) ------------------------------
+namespace {
+const uint32_t kDaysInMonth[12] = {31, 28, 31, 30, 31, 30, 31, 31, 30, 31, 30, 31};
+}
+extern "C" uint32_t bhh_date_to_week(uint32_t month, uint32_t day) {
+    if (month < 1) month = 1;          // (the reference subtracts 1 from an unsigned month: 0 is a panic there)
+    uint32_t doy = day;
+    for (uint32_t m = 0; m + 1 < month && m < 12; m++) doy += kDaysInMonth[m];
+    if (doy < 1) doy = 1;
+    const float q = std::floor((float)(doy - 1) / 7.6f);      // f32 arithmetic, as `(day_of_year - 1) as f32 / DAYS_PER_WEEK`
+    const uint32_t week = (uint32_t)q + 1;
+    return week < 48 ? week : 48;
+}
+extern "C" uint32_t bhh_week_to_start_day(uint32_t week) {
+    if (week < 1) week = 1;
+    return (uint32_t)std::fmaf((float)(week - 1), 7.6f, 1.0f);
+}
+extern "C" void bhh_day_of_year_to_date(uint32_t day_of_year, uint32_t *month, uint32_t *day) {
+    uint32_t remaining = day_of_year, mo = 12, d = 31;
+    for (uint32_t m = 0; m < 12; m++) {
+        if (remaining <= kDaysInMonth[m]) { mo = m + 1; d = remaining; break; }
+        remaining -= kDaysInMonth[m];
+    }
+    if (month) *month = mo;
+    if (day) *day = d;
+}

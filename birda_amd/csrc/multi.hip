@@ -116,6 +116,7 @@ template <class F> int for_each_shard(bh_multi *m, F &&f) {
     std::vector<std::string> msg(G);
     auto body = [&](size_t g) {
         try {
+            m_err.clear();      // G == 1 runs on the caller's thread, whose thread-local text may be an earlier call's
             rc[g] = f(g);
             if (rc[g] != BH_OK) msg[g] = m_err.empty() ? bh_last_error() : m_err;
         } catch (...) { rc[g] = m_on_exception(); msg[g] = m_err; }

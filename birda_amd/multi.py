@@ -42,6 +42,17 @@ class MultiClassifier:
     def shard_devices(self) -> List[int]:
         return [int(self._L.bh_multi_shard_device(self._h, g)) for g in range(self.n_shards)]
 
+    def shard_classifier(self, shard: int):
+        """Shard `shard`'s classifier replica (borrowed: labels, info, kernel names, filters)."""
+        from .classifier import BirdClassifier
+        return BirdClassifier.borrow(self._L.bh_multi_classifier(self._h, shard), self.top_k,
+                                     device=int(self._L.bh_multi_shard_device(self._h, shard)))
+
+    def shard_context(self, shard: int):
+        """Shard `shard`'s batch context (borrowed: profiling events, stream)."""
+        from .classifier import BatchInferenceContext
+        return BatchInferenceContext.borrow(self.shard_classifier(shard), self._L.bh_multi_context(self._h, shard))
+
     def gather_backend(self) -> str:
         return self._L.bh_multi_gather_backend(self._h).decode()
 

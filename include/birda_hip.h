@@ -371,6 +371,37 @@ BH_API int bh_classifier_set_bsg(bh_classifier *c, const float *intercept, const
                                  size_t n_classes);
 BH_API int bh_classifier_clear_bsg(bh_classifier *c);
 
+/* ---- range filter: the geomodel query ------------------------------------------------------
+ * birda's RangeFilter (reference src/inference/range_filter.rs:19-51) wraps birdnet_onnx::RangeFilter: a small model that
+ * maps (latitude, longitude, week) to one occurrence score per species of ITS OWN label set (12 012 for the published
+ * geomodel; the reference's fixture, tests/fixtures/fixture-geomodel.onnx, is Gemm(3 -> 5) + Sigmoid).  Here the dense
+ * stack runs on the device (the f32 MFMA GEMM of the custom classifier, sigmoid in its epilogue).
+ * model_path: the geomodel's .onnx file itself -- read by the library's own protobuf walk (birda_amd/csrc/onnx_dense.hpp:
+ * Gemm / MatMul + Add / Relu / Sigmoid chains; anything else is refused by operator name) -- or a BHC1 container written by
+ * birda_amd/convert.py.  labels_path: the GEOMODEL's labels, one per line (blank lines skipped); a label count that differs
+ * from the model's output width is BH_ERR_LABELS (RangeFilter::from_config's validation, range_filter.rs:13-18; reference
+ * test tests/geomodel_range_filter.rs:104-124).  threshold: species scoring below it are left out of `indices` (birda
+ * queries at 0.0 and thresholds afterwards, geomodel_range_filter.rs:90-102).
+ * The scores feed bhh_project_scores (birda_host.h) -> bh_classifier_set_range_filter. */
+typedef struct bh_range_filter bh_range_filter;
+BH_API int bh_range_filter_create(const char *model_path, const char *labels_path, int32_t device, float threshold,
+                                  bh_range_filter **out);
+BH_API void bh_range_filter_destroy(bh_range_filter *rf);
+BH_API uint32_t bh_range_filter_num_species(const bh_range_filter *rf);
+BH_API const char *bh_range_filter_label(const bh_range_filter *rf, uint32_t index);
+/* RangeFilter::predict(latitude, longitude, month, day) -> Vec<LocationScore> (range_filter.rs:39-51): scores[i] = occurrence
+ * score of geomodel species i for ALL species (cap >= num_species); indices (nullable) receives the species with
+ * score >= threshold in index order, n_kept (nullable) their count.  Latitude / longitude are narrowed to f32 as the
+ * reference narrows them (:46).  [EXT] birdnet-onnx turns (month, day) into BirdNET's week -- 48 per year, four per month:
+ * week = (month - 1) * 4 + min(4, (day - 1) / 7 + 1) = bh_birdnet_week; that is the convention birda's own
+ * week -> start-day -> (month, day) round trip (config/range_filter.rs:120-123, utils/date.rs:57-70) inverts for 47 of 48 weeks,
+ * while its 7.6-day `date_to_week` (bhh_date_to_week) inverts it for 10.  predict_week takes the model's third input as is. */
+BH_API int bh_range_filter_predict(bh_range_filter *rf, double latitude, double longitude, uint32_t month, uint32_t day,
+                                   float *scores, size_t cap, uint32_t *indices, size_t *n_kept);
+BH_API int bh_range_filter_predict_week(bh_range_filter *rf, float latitude, float longitude, float week, float *scores,
+                                        size_t cap, uint32_t *indices, size_t *n_kept);
+BH_API uint32_t bh_birdnet_week(uint32_t month, uint32_t day);
+
 /* ---- several shards in one process (birda_amd/csrc/multi.hip) -----------------------------------
  * Segments are independent through every stage (processor.rs:363-367): shard g of G owns a contiguous block of the
  * global list and nothing is exchanged but the results.  The reference has no counterpart (it scales out as N

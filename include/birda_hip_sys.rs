@@ -35,6 +35,7 @@ pub const BH_ERR_NONFINITE: c_int = -8;
 pub enum BhClassifier {}   // opaque handle `bh_classifier`
 pub enum BhBatchContext {}   // opaque handle `bh_batch_context`
 pub enum BhCustomClassifier {}   // opaque handle `bh_custom_classifier`
+pub enum BhRangeFilter {}   // opaque handle `bh_range_filter`
 pub enum BhMulti {}   // opaque handle `bh_multi`
 
 #[repr(C)]
@@ -161,6 +162,13 @@ extern "C" {
     pub fn bh_predict_batch_two_stage(c: *mut BhClassifier, ctx: *mut BhBatchContext, cc: *mut BhCustomClassifier, segments: *const *const f32, n: usize, n_samples: usize, out: *mut BhResult, logits_out: *mut f32) -> c_int;
     pub fn bh_classifier_set_bsg(c: *mut BhClassifier, intercept: *const f32, slope: *const f32, prior: *const f32, n_classes: usize) -> c_int;
     pub fn bh_classifier_clear_bsg(c: *mut BhClassifier) -> c_int;
+    pub fn bh_range_filter_create(model_path: *const c_char, labels_path: *const c_char, device: i32, threshold: f32, out: *mut *mut BhRangeFilter) -> c_int;
+    pub fn bh_range_filter_destroy(rf: *mut BhRangeFilter);
+    pub fn bh_range_filter_num_species(rf: *const BhRangeFilter) -> u32;
+    pub fn bh_range_filter_label(rf: *const BhRangeFilter, index: u32) -> *const c_char;
+    pub fn bh_range_filter_predict(rf: *mut BhRangeFilter, latitude: f64, longitude: f64, month: u32, day: u32, scores: *mut f32, cap: usize, indices: *mut u32, n_kept: *mut usize) -> c_int;
+    pub fn bh_range_filter_predict_week(rf: *mut BhRangeFilter, latitude: f32, longitude: f32, week: f32, scores: *mut f32, cap: usize, indices: *mut u32, n_kept: *mut usize) -> c_int;
+    pub fn bh_birdnet_week(month: u32, day: u32) -> u32;
     pub fn bh_multi_create(cfg: *const BhMultiConfig, out: *mut *mut BhMulti) -> c_int;
     pub fn bh_multi_destroy(m: *mut BhMulti);
     pub fn bh_multi_last_error() -> *const c_char;

@@ -211,6 +211,14 @@ BH_API int bhh_project_scores(const char *const *geomodel_labels, size_t n_geomo
                               const float *score_values, size_t n_scores, const char *const *classifier_labels,
                               size_t n_classes, float threshold, float *out_scores, size_t *mapped, size_t *in_range);
 
+/* ---- the range filter's date arithmetic (reference src/utils/date.rs; config/range_filter.rs:106-123) ------------------
+ * date_to_week (:21-33): floor((day_of_year - 1) / 7.6) + 1, capped at 48, on a non-leap calendar, in f32 as the reference
+ * computes it; week_to_start_day (:57-70): (week - 1) * 7.6 + 1 truncated (one fused multiply-add in f32, `mul_add`);
+ * day_of_year_to_date (:42-55): (month, day), saturating to December 31. */
+BH_API uint32_t bhh_date_to_week(uint32_t month, uint32_t day);
+BH_API uint32_t bhh_week_to_start_day(uint32_t week);
+BH_API void bhh_day_of_year_to_date(uint32_t day_of_year, uint32_t *month, uint32_t *day);
+
 #ifdef __cplusplus
 }
 #endif

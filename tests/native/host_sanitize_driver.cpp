@@ -11,6 +11,7 @@
 #include "../../include/birda_hip.h"
 #include "../../include/birda_host.h"
 #include "../../birda_amd/csrc/model.hpp"
+#include "../../birda_amd/csrc/onnx_dense.hpp"
 
 // ---- stubs for the device library (never called by this driver) ----
 extern "C" {
@@ -133,6 +134,51 @@ int main(int argc, char **argv) {
             printf("model fuzz %d: %d of 1500 mutants still load\n", which, loaded);
         }
     }
+    // 1d. the geomodel's .onnx file goes through the library's own protobuf walk (onnx_dense.hpp): every prefix of a
+    //     well-formed file and 3 000 random mutants must be refused or load into a consistent dense stack
+    if (argc > 4) {
+        uint64_t rs = 0xda942042e4dd58b5ull;
+        auto rnd = [&]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return rs; };
+        for (int which = 4; which < argc; which++) {
+            std::string good;
+            FILE *f = fopen(argv[which], "rb");
+            CHECK(f != nullptr);
+            if (!f) continue;
+            char b[65536]; size_t n;
+            while ((n = fread(b, 1, sizeof b, f)) > 0) good.append(b, n);
+            fclose(f);
+            const std::string p = dir + "/fuzz.onnx";
+            {
+                bh::CustomModel m; std::string err;
+                CHECK(bh::onnxd::load_dense_onnx(argv[which], m, err));
+                CHECK(m.h.input_dim == 3 && m.layers.size() >= 1 && m.h.n_classes == m.layers.back().out_dim);
+            }
+            int loaded = 0;
+            for (size_t cut = 0; cut < good.size(); cut++) {
+                write_file(p, good.substr(0, cut));
+                bh::CustomModel m; std::string err;
+                if (bh::onnxd::load_dense_onnx(p.c_str(), m, err)) loaded++;
+            }
+            for (int it = 0; it < 3000; it++) {
+                std::string w = good;
+                const int nmut = 1 + (int)(rnd() % 4);
+                for (int k = 0; k < nmut; k++) w[rnd() % w.size()] = (char)rnd();
+                if (rnd() % 10 == 0) w.resize(rnd() % w.size());
+                write_file(p, w);
+                bh::CustomModel m; std::string err;
+                if (bh::onnxd::load_dense_onnx(p.c_str(), m, err)) {
+                    loaded++;
+                    uint64_t dim = m.h.input_dim;
+                    for (const auto &L : m.layers) {
+                        CHECK(L.in_dim == dim && L.w_off + (uint64_t)L.in_dim * L.out_dim <= m.blob.size() && L.b_off + L.out_dim <= m.blob.size());
+                        dim = L.out_dim;
+                    }
+                    CHECK(dim == m.h.n_classes);
+                }
+            }
+            printf("onnx fuzz %s: %d prefixes / mutants still load\n", argv[which], loaded);
+        }
+    }
     // 2. every writer, odd labels and paths, NaN / inf confidences
     const char *labels[] = {"Passer domesticus_House Sparrow", "NoUnderscore", "_", "a_b_c d_e", "", "\xc3\x84\xc3\xa4kk\xc3\xb6nen laji_\xc3\x96ljy \"quoted\", name\n", "x_\xf0\x9f\x90\xa6 bird"};
     const char *paths[] = {"/a/b/c.wav", "c.wav", "/", "", "a//b///", "../x/..", "/only"};
@@ -183,6 +229,8 @@ int main(int argc, char **argv) {
     CHECK(bhh_effective_batch_size(8, 0) == 8 && bhh_effective_batch_size(8, 3) == 3);
     CHECK(bhh_source_samples(144000, 44100, 48000) == 132300);
     CHECK(bhh_is_audio_file(".wav") == 0 && bhh_is_audio_file("a.WAV") == 1);
+    CHECK(bhh_date_to_week(0, 0) == 1 && bhh_date_to_week(13, 40) == 48 && bhh_date_to_week(6, 15) == 22 && bhh_week_to_start_day(0) == 1);
+    { uint32_t mo = 0, dd = 0; bhh_day_of_year_to_date(0, &mo, &dd); CHECK(mo == 1 && dd == 0); bhh_day_of_year_to_date(0xffffffffu, &mo, nullptr); CHECK(mo == 12); }
     void *g = bhh_watchdog_start(60000, 8);
     bhh_watchdog_cancel(g);
     bhh_watchdog_cancel(nullptr);

@@ -22,6 +22,20 @@ def test_host_pipeline_under_asan_and_ubsan(tmp_path):
     model_path, custom_path = str(work / "mini.bhm"), str(work / "custom.bhc")
     mf.write_model(model_path, synth.build_model("mini"))
     mf.write_custom_classifier(custom_path, synth.build_custom_classifier(64, 10, hidden=(32,)))
-    p = subprocess.run([exe, str(work), model_path, custom_path], capture_output=True, text=True, timeout=600, env=env)
+    # ... and two dense-stack ONNX files for the library's own protobuf walk: the reference's geomodel fixture (committed as
+    # data) and a three-layer stack written by this repo's ONNX writer (MatMul + Add, Relu, Gemm with transB / alpha / beta)
+    import numpy as np
+    from birda_amd import onnx_io as ox
+    rng = np.random.default_rng(5)
+    g = ox.Graph(inputs=[ox.ValueInfo("x", ox.FLOAT, ["n", 3])], outputs=[ox.ValueInfo("y", ox.FLOAT, ["n", 7])])
+    g.initializers = {"w0": rng.standard_normal((3, 16)).astype(np.float32), "b0": rng.standard_normal(16).astype(np.float32),
+                      "w1": rng.standard_normal((7, 16)).astype(np.float32), "b1": rng.standard_normal(7).astype(np.float32)}
+    g.nodes = [ox.Node("MatMul", ["x", "w0"], ["h0"]), ox.Node("Add", ["h0", "b0"], ["h1"]), ox.Node("Relu", ["h1"], ["h2"]),
+               ox.Node("Gemm", ["h2", "w1", "b1"], ["h3"], {"transB": 1, "alpha": 0.5, "beta": 2.0}), ox.Node("Sigmoid", ["h3"], ["y"])]
+    stack_path = str(work / "stack.onnx")
+    open(stack_path, "wb").write(ox.dump(g))
+    fixture = os.path.join(ROOT, "tests", "golden", "reference_fixtures", "fixture-geomodel.onnx")
+    p = subprocess.run([exe, str(work), model_path, custom_path, fixture, stack_path], capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-6000:]
     assert "host sanitizer driver: ok" in p.stdout
+    assert p.stdout.count("onnx fuzz") == 2

@@ -1103,6 +1103,76 @@ def test_packed_short_files_match_the_per_file_pipeline(clf_tiny, model_dir, tmp
     assert sum(r.detections for r in got) > 0
 
 
+def test_one_overflowing_recording_does_not_fail_its_pack(model_dir, tmp_path):
+    """a pack-level failure -- here BH_ERR_NONFINITE raised by ONE recording whose activations leave the f16
+    operand range -- used to be copied to every file of the pack.  The reference isolates failures per file (lib.rs:1003-1100
+    counts files_failed and goes on): the pack is re-run file by file, the offending file alone reports the error and the
+    others get exactly the outputs the per-file pipeline writes.
+    The overflow is made content-dependent: the trunk of `mini_b0` is multiplied by a power of two chosen (by trying) so that a
+    full-scale pure tone overflows the split-f16 planes while the noisy synthetic segments stay inside them."""
+    from birda_amd import modelfile as mf, pipeline, synth
+    from birda_amd._lib import BirdaHipError
+    from birda_amd.classifier import BirdClassifier
+    _, labels, m, _ = model_dir["mini_b0"]
+    S, rate = m.sample_count, m.sample_rate
+    good = [synth.synth_segments(3, S, rate, start=40 * k).reshape(-1) for k in range(4)]
+    t = np.arange(3 * S) / rate
+    candidates = {"tone %d Hz" % f: (0.99 * np.sin(2 * np.pi * f * t)).astype(np.float32) for f in (700, 1500, 2500, 5000, 9000)}
+    candidates["click"] = np.where(np.arange(3 * S) % 997 == 0, 0.99, -0.99).astype(np.float32)
+    found = None
+    tried = []
+    for e in range(8, 15):
+        m2, _ = _rescale_trunk(m, [2.0 ** e])
+        path = str(tmp_path / f"trunk_2e{e}.bhm")
+        mf.write_model(path, m2)
+        clf = BirdClassifier(path, labels, min_confidence=0.05, precision="f16x3")
+        ctx = clf.create_batch_context(16)
+
+        def overflows(x):
+            try:
+                clf.predict_batch_with_context(ctx, list(x.reshape(3, S)))
+                return False
+            except BirdaHipError as err:
+                assert err.code == -8
+                return True
+        g = [overflows(x) for x in good]
+        b = {name: overflows(x) for name, x in candidates.items()}
+        tried.append((e, g, b))
+        ctx.close()
+        if not any(g) and any(b.values()):
+            found = (clf, next(name for name, v in b.items() if v))
+            break
+        clf.close()
+    assert found, f"no trunk scale separates the probes from the synthetic segments: {tried}"
+    clf, bad_name = found
+    rec = tmp_path / "rec"; rec.mkdir()
+    files = []
+    for k, x in enumerate(good[:2]):
+        synth.write_wav_pcm16(str(rec / f"a{k}.wav"), x, rate); files.append(str(rec / f"a{k}.wav"))
+    synth.write_wav_pcm16(str(rec / "bad.wav"), candidates[bad_name], rate); files.append(str(rec / "bad.wav"))
+    for k, x in enumerate(good[2:]):
+        synth.write_wav_pcm16(str(rec / f"b{k}.wav"), x, rate); files.append(str(rec / f"b{k}.wav"))
+    single = tmp_path / "single"; single.mkdir()
+    packed = tmp_path / "packed"; packed.mkdir()
+    want = {}
+    for f in files:
+        try:
+            want[f] = pipeline.process_file(clf, f, str(single), min_confidence=0.05)
+        except BirdaHipError as err:
+            want[f] = err.code
+    assert want[files[2]] == -8 and all(not isinstance(want[f], int) for f in files if f != files[2])
+    got, status = pipeline.process_files_packed(clf, files, str(packed), min_confidence=0.05, pack_segments=64)
+    assert status == [0, 0, -8, 0, 0], (bad_name, status)
+    for f, r in zip(files, got):
+        if f == files[2]:
+            continue
+        assert (r.segments, r.detections) == (want[f].segments, want[f].detections)
+        a, b = pipeline.output_path_for(f, str(single), "csv"), pipeline.output_path_for(f, str(packed), "csv")
+        assert open(a, "rb").read() == open(b, "rb").read(), f
+    assert not os.path.exists(pipeline.output_path_for(files[2], str(packed), "csv"))
+    clf.close()
+
+
 def test_non_finite_samples_stay_in_their_own_rows(clf_tiny, model_dir):
     """A corrupt decode (NaN / Inf samples) must not leak into the other rows of a batch, hang a kernel or produce
     predictions from NaN logits: rows are independent (processor.rs:363-367)."""
