@@ -190,7 +190,7 @@ def analyse(clf, m, info, fused, stage_tot, layer_tot, segs_done, steps, slices_
         n_blocks = max(1, dom["launches"] // (steps * slices_per_step))
         # the instantiation's last template argument is its MFMA type: 0 = f32, 3 = split f16 (x3), 1 = f16
         args_ = dom["kernel"].rstrip(">").split(",")
-        dom_prec = int(args_[-1]) if dom["kernel"].startswith("mbw<") else int(args_[15])   # (mbconv's 17th argument marks a persistent instantiation)
+        dom_prec = int(args_[15])   # (mbconv's 17th argument marks a persistent instantiation)
         if dom_prec == 0:
             peak, note, insn = PEAK_F32_MFMA_TFLOPS, "dense f32 MFMA peak (runs at the vector rate)", "v_mfma_f32_16x16x4_f32"
         elif dom_prec == 3:
@@ -211,7 +211,7 @@ def analyse(clf, m, info, fused, stage_tot, layer_tot, segs_done, steps, slices_
             "kernel": "mbconv_kernel (fused %s, %s)" % (desc, insn),
             "bound": "mfma", "achieved": round(tflops, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(tflops / peak, 4), "peak_note": note, "traffic": pmc_traffic(dom["kernel"]),
-            "rocprof_name": ("bh::mbw_kernel<" + dom["kernel"][len("mbw<"):]) if dom["kernel"].startswith("mbw<") else ("bh::mbconv_kernel<" + dom["kernel"][len("mbconv<"):]),
+            "rocprof_name": "bh::mbconv_kernel<" + dom["kernel"][len("mbconv<"):],
             "launches": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2),
             "algorithmic_gflop_per_launch": round(total_flops / max(dom["launches"], 1) / 1e9, 3)}
         # What actually bounds this kernel in the f16 modes: issuing its activation.  Algorithmic count: one

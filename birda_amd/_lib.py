@@ -88,6 +88,7 @@ SYMBOLS = [
     ("bh_batch_context_stage_ms", C.c_int, [_VP, _VP, _VP]),
     ("bh_batch_context_layer_ms", C.c_int, [_VP, _VP, _VP, _SZ]),
     ("bh_classifier_fused_blocks", C.c_int, [_VP, _VP, _SZ]),
+    ("bh_plan_fused_blocks", C.c_int, [C.c_char_p, C.c_uint32, _VP, _VP, _SZ]),
     ("bh_mb_config_name", C.c_int, [C.c_int32, C.c_char_p, _SZ]),
     ("bh_classifier_frontend_kernel", C.c_int, [_VP, C.c_char_p, _SZ]),
     ("bh_debug_mb_stamps", C.c_int, [_VP, _VP, _SZ]),

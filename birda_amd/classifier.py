@@ -163,8 +163,6 @@ class BirdClassifier:
         buf = C.create_string_buffer(128)
         self._L.bh_mb_config_name(cfg, buf, 128)
         name = buf.value.decode()
-        if name.startswith("w,"):       # wave-private instantiation (kernels_mbwave.hip)
-            return "mbw<" + name[2:] + ">"
         return "mbconv<" + name + ">"
 
     def mel_kernel_name(self) -> str:

@@ -406,8 +406,7 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
             d.X = in;
             d.Y = (i + 2 == nl - 1) ? d_logits : T(i + 3);
             d.R = LP.res_tensor != bh::NO_TENSOR ? T(LP.res_tensor) : nullptr;
-            if (d.cfg <= -2) bh::launch_mbwave(d, (int)n, s);
-            else bh::launch_mbconv(d, (int)n, s);
+            bh::launch_mbconv(d, (int)n, s);
             ctx_mark(ctx, ST_MBCONV, (int)i);
             i += 2;
             continue;
@@ -636,8 +635,52 @@ float f16_to_f32(uint16_t h) {
     return f;
 }
 
-// Finds expand(1x1) -> depthwise -> project(1x1) triples whose intermediates have no other reader
-// and prepares a fused launch for each (weights re-laid fragment-major for the picked tile config).
+// The block that starts at layer i as a fused launch: expand(1x1, or the stem conv) -> depthwise -> project(1x1) whose
+// intermediates have no other reader, described and handed to the tile planner.  Host logic only (no device): plan_fusion uses
+// it per block at create, bh_plan_fused_blocks walks a model file with it.
+bool describe_fused_block(const bh::Model &m, const std::vector<int> &readers, size_t i, int precision, int force_cfg, bh::MbDesc &d) {
+    const size_t nl = m.layers.size();
+    if (i + 2 >= nl) return false;
+    const auto &E = m.layers[i], &D = m.layers[i + 1], &P = m.layers[i + 2];
+    const bool stem = E.op == bh::OP_CONV && E.in_layout == 1 && E.kh == E.kw && E.sh == E.sw && E.in_tensor == 0;
+    if ((E.op != bh::OP_PWCONV && !stem) || D.op != bh::OP_DWCONV || P.op != bh::OP_PWCONV) return false;
+    if (D.in_tensor != i + 1 || P.in_tensor != i + 2 || readers[i + 1] != 1 || readers[i + 2] != 1) return false;
+    if (E.res_tensor != bh::NO_TENSOR || D.res_tensor != bh::NO_TENSOR) return false;
+    if (D.kh != D.kw || D.sh != D.sw || E.cout != D.cout || D.cout != P.cin) return false;
+    d = bh::MbDesc{};
+    d.H = (int)E.in_h; d.W = (int)E.in_w; d.Cin = (int)E.cin; d.Cexp = (int)E.cout; d.Cout = (int)P.cout;
+    if (stem) {  // the depthwise conv sees the stem's output image; the stem itself is gathered
+        d.stem = 1; d.stem_c = (int)E.cin; d.stem_h = (int)E.in_h; d.stem_w = (int)E.in_w; d.stem_k = (int)E.kh;
+        d.stem_s = (int)E.sh; d.stem_pt = (int)E.pad_t; d.stem_pl = (int)E.pad_l;
+        d.H = (int)E.out_h; d.W = (int)E.out_w; d.Cin = (int)(E.kh * E.kw * E.cin);
+    }
+    d.Ho = (int)D.out_h; d.Wo = (int)D.out_w; d.pad_t = (int)D.pad_t; d.pad_l = (int)D.pad_l;
+    d.KS = (int)D.kh; d.ST = (int)D.sh;
+    d.act_e = (int)E.act; d.act_d = (int)D.act; d.act_p = (int)P.act;
+    if (const char *dbg = getenv("BIRDA_HIP_MB_DBG")) d.dbg = atoi(dbg);
+    d.prec = precision;
+    // The split-f16 MFMA and the f32 MFMA agree to ~1e-7 of sum|a b|; measured (profiles/), f16x3 is
+    // the faster one on every block, the stem's 18-column im2col GEMM included.
+    if (d.stem && precision == 3 && getenv("BIRDA_HIP_STEM_F32")) d.prec = 0;   // A/B aid
+    if (!bh::mb_plan(d, force_cfg)) {
+        if (d.prec == 0) return false;
+        d.prec = 0;                       // no f16 instantiation for this shape: f32 one, if any
+        if (!bh::mb_plan(d, force_cfg)) return false;
+    }
+    return true;
+}
+
+std::vector<int> tensor_readers(const bh::Model &m) {
+    std::vector<int> readers(m.layers.size() + 1, 0);
+    for (const auto &L : m.layers) {
+        readers[L.in_tensor]++;
+        if (L.res_tensor != bh::NO_TENSOR) readers[L.res_tensor]++;
+    }
+    readers[m.h.embedding_tensor]++;
+    return readers;
+}
+
+// Prepares a fused launch for every block describe_fused_block accepts (weights re-laid fragment-major for the picked tile config).
 int plan_fusion(bh_classifier *c) {
     const auto &m = c->model;
     const size_t nl = m.layers.size();
@@ -646,41 +689,11 @@ int plan_fusion(bh_classifier *c) {
     if (fuse_env && fuse_env[0] == '0') return BH_OK;
     const char *cfg_env = getenv("BIRDA_HIP_MB_CFG");
     const int force_cfg = cfg_env ? atoi(cfg_env) : -1;
-    std::vector<int> readers(nl + 1, 0);
-    for (const auto &L : m.layers) {
-        readers[L.in_tensor]++;
-        if (L.res_tensor != bh::NO_TENSOR) readers[L.res_tensor]++;
-    }
-    readers[m.h.embedding_tensor]++;
+    const std::vector<int> readers = tensor_readers(m);
     for (size_t i = 0; i + 2 < nl; i++) {
-        const auto &E = m.layers[i], &D = m.layers[i + 1], &P = m.layers[i + 2];
-        const bool stem = E.op == bh::OP_CONV && E.in_layout == 1 && E.kh == E.kw && E.sh == E.sw && E.in_tensor == 0;
-        if ((E.op != bh::OP_PWCONV && !stem) || D.op != bh::OP_DWCONV || P.op != bh::OP_PWCONV) continue;
-        if (D.in_tensor != i + 1 || P.in_tensor != i + 2 || readers[i + 1] != 1 || readers[i + 2] != 1) continue;
-        if (E.res_tensor != bh::NO_TENSOR || D.res_tensor != bh::NO_TENSOR) continue;
-        if (D.kh != D.kw || D.sh != D.sw || E.cout != D.cout || D.cout != P.cin) continue;
         bh::MbDesc d{};
-        d.H = (int)E.in_h; d.W = (int)E.in_w; d.Cin = (int)E.cin; d.Cexp = (int)E.cout; d.Cout = (int)P.cout;
-        if (stem) {  // the depthwise conv sees the stem's output image; the stem itself is gathered
-            d.stem = 1; d.stem_c = (int)E.cin; d.stem_h = (int)E.in_h; d.stem_w = (int)E.in_w; d.stem_k = (int)E.kh;
-            d.stem_s = (int)E.sh; d.stem_pt = (int)E.pad_t; d.stem_pl = (int)E.pad_l;
-            d.H = (int)E.out_h; d.W = (int)E.out_w; d.Cin = (int)(E.kh * E.kw * E.cin);
-        }
-        d.Ho = (int)D.out_h; d.Wo = (int)D.out_w; d.pad_t = (int)D.pad_t; d.pad_l = (int)D.pad_l;
-        d.KS = (int)D.kh; d.ST = (int)D.sh;
-        d.act_e = (int)E.act; d.act_d = (int)D.act; d.act_p = (int)P.act;
-        if (const char *dbg = getenv("BIRDA_HIP_MB_DBG")) d.dbg = atoi(dbg);
-        d.prec = c->precision;
-        // The split-f16 MFMA and the f32 MFMA agree to ~1e-7 of sum|a b|; measured (profiles/), f16x3 is
-        // the faster one on every block, the stem's 18-column im2col GEMM included.
-        if (d.stem && c->precision == 3 && getenv("BIRDA_HIP_STEM_F32")) d.prec = 0;   // A/B aid
-        if (force_cfg >= 0 || !bh::mbw_plan(d)) {   // the wave-private kernel takes the early blocks of the f16 modes
-            if (!bh::mb_plan(d, force_cfg)) {
-                if (d.prec == 0) continue;
-                d.prec = 0;                       // no f16 instantiation for this shape: f32 one, if any
-                if (!bh::mb_plan(d, force_cfg)) continue;
-            }
-        }
+        if (!describe_fused_block(m, readers, i, c->precision, force_cfg, d)) continue;
+        const auto &E = m.layers[i], &D = m.layers[i + 1], &P = m.layers[i + 2];
         // per-chunk weight blocks (kernels.hpp MbDesc)
         const int CE = d.CE, NTE = CE / 16, KG = d.KG, NTOP = d.NTOP, nch = d.nchunks, KK = d.KS * d.KS;
         const float *We = m.blob.data() + E.w_off, *Wp = m.blob.data() + P.w_off, *Wd = m.blob.data() + D.w_off;
@@ -695,6 +708,20 @@ int plan_fusion(bh_classifier *c) {
             se = bh::f16_scale_exponent(me);
             sp = bh::f16_scale_exponent(mp);
         }
+        // GELU blocks of the f16 modes: the expand GELU runs on the SCALED accumulator with coefficients c_k 2^(-k se) and the 2^-se
+        // moves into the depthwise taps (kernels.hpp gelu_erf_fast4_scaled).  c_5 2^(-5 se) must stay a normal f32 on both sides:
+        // |se| <= 21 (weights 2^7 away from the usual He-normal sizes still land within 2^-8 of the top of the f16 range).
+        d.e_fold = 0;
+        d.gelu = bh::GeluScaled{0.f, 0.f, 0.f, 0.f, 0.f};
+#if BH_GELU_DEGREE == 5
+        if (h16 && d.act_e == bh::ACT_GELU_ERF) {
+            se = std::max(-21, std::min(21, se));
+            d.e_fold = 1;
+            float gc[5];
+            for (int k = 1; k <= 5; k++) gc[k - 1] = std::ldexp(bh::kGeluCoef[k - 1], -k * se);
+            d.gelu = bh::GeluScaled{gc[0], gc[1], gc[2], gc[3], gc[4]};
+        }
+#endif
         d.e_unscale = std::ldexp(1.0f, -se); d.p_scale = std::ldexp(1.0f, sp); d.p_unscale = std::ldexp(1.0f, -sp);
         const size_t frag = h16 ? 512 : 256, psteps = h16 ? (CE + 31) / 32 : NTE;
         const bool p16 = h16 && CE == 16;   // project GEMM as one 16-deep step: [column tile]{hi, lo}[64 lanes][4 halves]
@@ -766,7 +793,7 @@ int plan_fusion(bh_classifier *c) {
                     }
             for (int tap = 0; tap < KK; tap++)
                 for (int n = 0; n < CE; n++)
-                    wdf[ch * wd_fl + (size_t)tap * CE + n] = ch * CE + n < d.Cexp ? Wd[(size_t)tap * d.Cexp + ch * CE + n] : 0.0f;
+                    wdf[ch * wd_fl + (size_t)tap * CE + n] = ch * CE + n < d.Cexp ? std::ldexp(Wd[(size_t)tap * d.Cexp + ch * CE + n], d.e_fold ? -se : 0) : 0.0f;
             for (int n = 0; n < CE; n++) wdf[ch * wd_fl + (size_t)KK * CE + n] = ch * CE + n < d.Cexp ? bd[ch * CE + n] : 0.0f;
         }
         float *dwe = nullptr, *dwp = nullptr, *dwd = nullptr;
@@ -1406,13 +1433,26 @@ int bh_classifier_fused_blocks(const bh_classifier *c, int32_t *cfgs, size_t cap
     return (int)c->mb.size();
 }
 
-int bh_mb_config_name(int32_t cfg, char *out, size_t cap) {
-    if (cfg <= -2) {   // a wave-private instantiation (kernels_mbwave.hip): "w," + its template arguments
-        char buf[96];
-        const int n = bh::mbw_config_name(cfg, buf, sizeof buf);
-        if (n <= 0) return 0;
-        return snprintf(out, cap, "w,%s", buf);
+int bh_plan_fused_blocks(const char *model_path, uint32_t flags, int32_t *cfgs, int32_t *layers, size_t cap) try {
+    if (!model_path) return fail(BH_ERR_INVALID, "plan_fused_blocks: null model path");
+    bh::Model m;
+    std::string err;
+    if (!bh::load_model(model_path, m, err)) return fail(BH_ERR_IO, "%s", err.c_str());
+    const uint32_t p = flags & BH_FLAG_PRECISION_MASK;
+    const int precision = p == BH_FLAG_F16X3 ? 3 : p == BH_FLAG_F16 ? 1 : 0;
+    const std::vector<int> readers = tensor_readers(m);
+    size_t n = 0;
+    for (size_t i = 0; i + 2 < m.layers.size(); i++) {
+        bh::MbDesc d{};
+        if (!describe_fused_block(m, readers, i, precision, -1, d)) continue;
+        if (n < cap) { if (cfgs) cfgs[n] = d.cfg; if (layers) layers[n] = (int32_t)i; }
+        n++;
+        i += 2;
     }
+    return (int)n;
+} catch (...) { return on_exception(); }
+
+int bh_mb_config_name(int32_t cfg, char *out, size_t cap) {
     return bh::mb_config_name(cfg, out, cap);
 }
 

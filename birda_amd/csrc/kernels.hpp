@@ -52,13 +52,22 @@ enum Act : int { ACT_NONE = 0, ACT_RELU, ACT_RELU6, ACT_SWISH, ACT_GELU_ERF, ACT
 
 constexpr int MAX_BRANCHES = 4;
 
-// exact-erf GELU, GELU(v) = v Phi(v), without erff and without a division:
-//     GELU(v) = 0.5 v + |v| (0.5 - Phi(-|v|)),   Phi(-a) = exp2(Q(a)),
-// Q = -1 + a (c1 + ... + c8 a^7) a weighted minimax fit of log2 Phi(-a) on [0, 6.2] (Q(0) = -1
-// exactly, so GELU(0) = 0; Q decreases monotonically to -inf beyond the fit range, where
-// Phi(-a) < 3e-10 rounds away).  |Phi error| <= 5.3e-8, |GELU error| <= 1.7e-7 max(|v|, 1) with
-// the f32 evaluation included: at the rounding level of the erff form itself.  12 VALU
-// instructions, ONE of them transcendental (v_exp_f32, quarter rate), against ~30 for ocml erff.
+// erf GELU, GELU(v) = v Phi(v), without erff and without a division:
+//     GELU(v) = max(v, 0) - |v| Phi(-|v|),   Phi(-a) = exp2(Q(a)),
+// Q(a) = -1 + a (c1 + ... + c5 a^4): a weighted minimax fit of log2 Phi(-a) on [0, 6.2] (tools/fit_gelu.py), the weight being
+// the stated tolerance of the activation, |GELU error| <= 5e-7 max(|v|, 1) (VERDICT r2 next #3b): measured 8.9e-7 at |v| = 3.6,
+// 0.53 of the tolerance at the worst point, f32 evaluation included.  Q(0) = -1 exactly, so GELU(0) = 0; the leading coefficient
+// is negative, so Q falls monotonically to -inf beyond the fit range, where Phi(-a) < 3e-10 rounds away.  Per value: 1 v_med3,
+// 3.5 packed FMAs and ONE transcendental (v_exp_f32, quarter rate).  Round 2 carried a degree-8 fit (1.7e-7, three more packed
+// FMAs per pair: 102 cycles per pair of values against ~80 now, tools/microbench/pk_fma_rate.hip); the logits sat 10x inside
+// their tolerance with it.  -DBH_GELU_DEGREE=8 restores it (A/B aid).
+// Exp-free forms were priced and rejected: a polynomial for a Phi(-a) itself needs degree >= 15 on [0, 5.3] for the same
+// tolerance (Chebyshev interpolation: 4.4e-7 at degree 15, 1.0e-6 at 14) -- seven more packed FMAs per pair (39 cycles) plus
+// two clamps (11) to remove two v_exp_f32 (30).
+#ifndef BH_GELU_DEGREE
+#define BH_GELU_DEGREE 5
+#endif
+#if BH_GELU_DEGREE == 8
 #define BH_GELU_C1 -1.1511051654815674f
 #define BH_GELU_C2 -0.4592081904411316f
 #define BH_GELU_C3 -0.052496183663606644f
@@ -67,6 +76,19 @@ constexpr int MAX_BRANCHES = 4;
 #define BH_GELU_C6 -0.00018617883324623108f
 #define BH_GELU_C7 3.93775844713673e-05f
 #define BH_GELU_C8 -2.834923634509323e-06f
+#define BH_GELU_CTOP BH_GELU_C8
+#define BH_GELU_CNEXT BH_GELU_C7
+#define BH_GELU_MID(STEP) STEP(BH_GELU_C6) STEP(BH_GELU_C5) STEP(BH_GELU_C4) STEP(BH_GELU_C3) STEP(BH_GELU_C2) STEP(BH_GELU_C1)
+#else
+#define BH_GELU_C1 -1.1510556936264038f
+#define BH_GELU_C2 -0.45938199758529663f
+#define BH_GELU_C3 -0.05241312459111214f
+#define BH_GELU_C4 0.007328995503485203f
+#define BH_GELU_C5 -0.0005096292006783187f
+#define BH_GELU_CTOP BH_GELU_C5
+#define BH_GELU_CNEXT BH_GELU_C4
+#define BH_GELU_MID(STEP) STEP(BH_GELU_C3) STEP(BH_GELU_C2) STEP(BH_GELU_C1)
+#endif
 // max(v, 0) as ONE instruction (v_med3_f32 v, 0, 3e38: the finite bound keeps hipcc from rewriting it as a canonicalise + max pair): fmaxf() in IEEE mode first canonicalises its operand
 // (a second v_max).  NOT inline asm: the operand is usually an MFMA result, and hipcc places the wait
 // states an MFMA -> VALU read needs only in front of instructions it knows -- an inline-asm v_max_f32
@@ -76,13 +98,10 @@ __device__ __forceinline__ float bh_relu1(float v) { return __builtin_amdgcn_fme
 __device__ __forceinline__ float gelu_erf_fast(float v) {
     const float m = bh_relu1(v);
     const float a = __builtin_fmaf(m, 2.0f, -v);   // |v|, exactly
-    float q = __builtin_fmaf(a, BH_GELU_C8, BH_GELU_C7);
-    q = __builtin_fmaf(q, a, BH_GELU_C6);
-    q = __builtin_fmaf(q, a, BH_GELU_C5);
-    q = __builtin_fmaf(q, a, BH_GELU_C4);
-    q = __builtin_fmaf(q, a, BH_GELU_C3);
-    q = __builtin_fmaf(q, a, BH_GELU_C2);
-    q = __builtin_fmaf(q, a, BH_GELU_C1);
+    float q = __builtin_fmaf(a, BH_GELU_CTOP, BH_GELU_CNEXT);
+#define BH_GELU_STEP1(c) q = __builtin_fmaf(q, a, c);
+    BH_GELU_MID(BH_GELU_STEP1)
+#undef BH_GELU_STEP1
     q = __builtin_fmaf(q, a, -1.0f);
     const float e = __builtin_amdgcn_exp2f(q);
     return __builtin_fmaf(-a, e, m);   // 0.5 v + |v| (0.5 - e) with 0.5 v + 0.5 |v| = max(v, 0)
@@ -96,7 +115,7 @@ __device__ __forceinline__ bh_f32x2 bh_abs_from_relu2(bh_f32x2 m, bh_f32x2 v) {
     return a;
 }
 
-// Four GELUs at once with the f32 packed ops (v_pk_fma_f32): 12 packed instructions + 2 v_max_f32 +
+// Four GELUs at once with the f32 packed ops (v_pk_fma_f32): 7 packed instructions + 2 v_med3_f32 +
 // 2 v_exp_f32 per pair; same arithmetic, bit-identical to gelu_erf_fast.  The two pairs' Horner chains
 // are interleaved by hand: back-to-back dependent packed ops cost a wait state each on gfx950.
 #define BH_PK(c) ((bh_f32x2){(c), (c)})
@@ -106,13 +125,12 @@ __device__ __forceinline__ void gelu_erf_fast4(bh_f32x2 &v0, bh_f32x2 &v1) {
     m1[0] = bh_relu1(v1[0]); m1[1] = bh_relu1(v1[1]);
     const bh_f32x2 a0 = bh_abs_from_relu2(m0, v0);
     const bh_f32x2 a1 = bh_abs_from_relu2(m1, v1);
-    bh_f32x2 q0 = __builtin_elementwise_fma(a0, BH_PK(BH_GELU_C8), BH_PK(BH_GELU_C7));
-    bh_f32x2 q1 = __builtin_elementwise_fma(a1, BH_PK(BH_GELU_C8), BH_PK(BH_GELU_C7));
+    bh_f32x2 q0 = __builtin_elementwise_fma(a0, BH_PK(BH_GELU_CTOP), BH_PK(BH_GELU_CNEXT));
+    bh_f32x2 q1 = __builtin_elementwise_fma(a1, BH_PK(BH_GELU_CTOP), BH_PK(BH_GELU_CNEXT));
 #define BH_GELU_STEP(c)                                       \
     q0 = __builtin_elementwise_fma(q0, a0, BH_PK(c));         \
     q1 = __builtin_elementwise_fma(q1, a1, BH_PK(c));
-    BH_GELU_STEP(BH_GELU_C6) BH_GELU_STEP(BH_GELU_C5) BH_GELU_STEP(BH_GELU_C4) BH_GELU_STEP(BH_GELU_C3)
-    BH_GELU_STEP(BH_GELU_C2) BH_GELU_STEP(BH_GELU_C1) BH_GELU_STEP(-1.0f)
+    BH_GELU_MID(BH_GELU_STEP) BH_GELU_STEP(-1.0f)
 #undef BH_GELU_STEP
     bh_f32x2 e0, e1;
     e0[0] = __builtin_amdgcn_exp2f(q0[0]); e0[1] = __builtin_amdgcn_exp2f(q0[1]);
@@ -124,18 +142,46 @@ __device__ __forceinline__ bh_f32x2 gelu_erf_fast2(bh_f32x2 v) {
     bh_f32x2 m;
     m[0] = bh_relu1(v[0]); m[1] = bh_relu1(v[1]);
     const bh_f32x2 a = bh_abs_from_relu2(m, v);
-    bh_f32x2 q = __builtin_elementwise_fma(a, BH_PK(BH_GELU_C8), BH_PK(BH_GELU_C7));
-    q = __builtin_elementwise_fma(q, a, BH_PK(BH_GELU_C6));
-    q = __builtin_elementwise_fma(q, a, BH_PK(BH_GELU_C5));
-    q = __builtin_elementwise_fma(q, a, BH_PK(BH_GELU_C4));
-    q = __builtin_elementwise_fma(q, a, BH_PK(BH_GELU_C3));
-    q = __builtin_elementwise_fma(q, a, BH_PK(BH_GELU_C2));
-    q = __builtin_elementwise_fma(q, a, BH_PK(BH_GELU_C1));
-    q = __builtin_elementwise_fma(q, a, BH_PK(-1.0f));
+    bh_f32x2 q = __builtin_elementwise_fma(a, BH_PK(BH_GELU_CTOP), BH_PK(BH_GELU_CNEXT));
+#define BH_GELU_STEP2(c) q = __builtin_elementwise_fma(q, a, BH_PK(c));
+    BH_GELU_MID(BH_GELU_STEP2) BH_GELU_STEP2(-1.0f)
+#undef BH_GELU_STEP2
     bh_f32x2 e;
     e[0] = __builtin_amdgcn_exp2f(q[0]); e[1] = __builtin_amdgcn_exp2f(q[1]);
     return __builtin_elementwise_fma(-a, e, m);
 }
+
+// The same four GELUs on SCALED arguments: the split-f16 expand GEMM of a fused block leaves acc = 2^s x (its weight planes and
+// bias carry 2^s, f16_scale_exponent).  GELU is not homogeneous, but its pieces are: max(acc, 0) = 2^s max(x, 0),
+// 2 max(acc, 0) - acc = 2^s |x|, and Q(|x|) = -1 + sum c_k |x|^k = -1 + sum (c_k 2^-ks) (2^s |x|)^k -- the Horner chain runs on the
+// scaled magnitude with coefficients c_k 2^-ks (exact: powers of two; every intermediate is the unscaled one times a power of
+// two, so q is bit-identical), and max - magnitude * e comes out as 2^s GELU(x).  The factor 2^s then rides through the LDS grid
+// into the depthwise taps, which the host multiplies by 2^-s (api.hip plan_fusion).  Saves the packed multiply per pair that
+// round 2 spent in front of every expand GELU.  gc[k - 1] = c_k 2^-ks, wave-uniform (SGPRs).
+struct GeluScaled { float c1, c2, c3, c4, c5; };
+__device__ __forceinline__ void gelu_erf_fast4_scaled(bh_f32x2 &v0, bh_f32x2 &v1, const GeluScaled &gc) {
+    bh_f32x2 m0, m1;
+    m0[0] = bh_relu1(v0[0]); m0[1] = bh_relu1(v0[1]);
+    m1[0] = bh_relu1(v1[0]); m1[1] = bh_relu1(v1[1]);
+    const bh_f32x2 a0 = bh_abs_from_relu2(m0, v0);
+    const bh_f32x2 a1 = bh_abs_from_relu2(m1, v1);
+    bh_f32x2 q0 = __builtin_elementwise_fma(a0, BH_PK(gc.c5), BH_PK(gc.c4));
+    bh_f32x2 q1 = __builtin_elementwise_fma(a1, BH_PK(gc.c5), BH_PK(gc.c4));
+#define BH_GELU_STEP(c)                                       \
+    q0 = __builtin_elementwise_fma(q0, a0, BH_PK(c));         \
+    q1 = __builtin_elementwise_fma(q1, a1, BH_PK(c));
+    BH_GELU_STEP(gc.c3) BH_GELU_STEP(gc.c2) BH_GELU_STEP(gc.c1) BH_GELU_STEP(-1.0f)
+#undef BH_GELU_STEP
+    bh_f32x2 e0, e1;
+    e0[0] = __builtin_amdgcn_exp2f(q0[0]); e0[1] = __builtin_amdgcn_exp2f(q0[1]);
+    e1[0] = __builtin_amdgcn_exp2f(q1[0]); e1[1] = __builtin_amdgcn_exp2f(q1[1]);
+    v0 = __builtin_elementwise_fma(-a0, e0, m0);
+    v1 = __builtin_elementwise_fma(-a1, e1, m1);
+}
+// the unscaled polynomial's coefficients, for the host (c_k 2^-ks is computed there)
+#if BH_GELU_DEGREE == 5
+constexpr float kGeluCoef[5] = {BH_GELU_C1, BH_GELU_C2, BH_GELU_C3, BH_GELU_C4, BH_GELU_C5};
+#endif
 
 // a + b as a plain v_add_f32 that hipcc cannot fuse with its neighbour.  Written as `fwd[j] + rev[-j]`
 // in C, the folded-frame sums of the split-f16 mel kernel are SLP-vectorised into
@@ -326,6 +372,10 @@ struct MbDesc {
     // the expand result is multiplied by e_unscale = 2^-se before its activation, the project accumulators start at
     // bp 2^sp + R p_scale and are stored times p_unscale.  All three are 1 in f32 mode.
     float e_unscale, p_scale, p_unscale;
+    // e_fold != 0 (GELU blocks of the f16 modes): the expand result is NOT multiplied by e_unscale; its GELU runs on the scaled
+    // value with the coefficients gelu (c_k 2^-ks, gelu_erf_fast4_scaled) and the depthwise taps in Wd carry the 2^-s instead
+    int e_fold;
+    GeluScaled gelu;
     // stem variant (first block): "expand" = the k x k stride-s stem conv gathered from the planar
     // spectrogram X [n][stem_c][stem_h][stem_w]; then H, W are the stem's OUTPUT size and
     // Cin = stem_k * stem_k * stem_c im2col columns (We rows in [kh][kw][cin] order)
@@ -345,9 +395,5 @@ int mb_config_name(int ci, char *out, size_t cap);
 // picks the instantiation (force_cfg >= 0: that entry or fail) and fills the derived fields
 bool mb_plan(MbDesc &d, int force_cfg);
 void launch_mbconv(const MbDesc &d, int n_seg, hipStream_t s);
-// Wave-private variant for the early blocks (kernels_mbwave.hip): d.cfg <= -2 marks a block planned by mbw_plan
-bool mbw_plan(MbDesc &d);
-void launch_mbwave(const MbDesc &d, int n_seg, hipStream_t s);
-int mbw_config_name(int cfg, char *out, size_t cap);
 
 }  // namespace bh

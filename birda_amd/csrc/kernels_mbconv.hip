@@ -1,975 +1,34 @@
-// Fused inverted-residual (MBConv) block for gfx950: expand 1x1 -> depthwise kxk -> project 1x1
-// (+ residual) in ONE launch, with the expanded tensor kept in LDS.
-//
-// In the reference these are three Conv nodes (+ activations, + Add) of the ONNX graph that
-// birdnet_onnx::Classifier runs through ONNX Runtime (reference src/inference/classifier.rs:478-488;
-// SURVEY.md 8a-8).  Layer by layer the expanded tensor is written and re-read twice (4.7 MB per
-// segment for the first block alone), which is what bounds the first stages; here it never leaves
-// the CU.
-//
-// One workgroup (4 waves) owns an output tile TH x TW of S consecutive segments.
-//   in-tile   IH x IW = ((TH-1)s + k) x ((TW-1)s + k) input positions; the part inside the image is
-//             the "valid rect", M = S * vh * vw source rows.
-//   per chunk of CE expanded channels:
-//     P1  E[M x CE]   = act(X[M x Cin] . We[Cin x CE] + be)   MFMA, computed as E^T = We^T X^T so that a
-//                       lane holds 4 consecutive channels of one row (one 16-byte LDS write); X resident
-//                       in registers, We fragment-major in LDS, be the accumulators' start value; rows go
-//                       to their slots of the LDS grid Es (the grid's out-of-image border stays zero =
-//                       the depthwise conv's zero padding)
-//     P2  D[P x CE]   = act(dw_kxk(Es) + bd)                  VALU + LDS, 4 channels per lane
-//     P3  acc[P x Co] += D[P x CE] . Wp[CE x Co]              f32 MFMA, accumulators live across chunks
-//   epilogue: + bp, activation, + residual, NHWC store.
+// Planner of the fused inverted-residual (MBConv) blocks: picks, per block, one of the tile configurations of mbconv_cfgs.inc
+// (the kernel itself is mbconv_kernel.hpp, instantiated per activation in kernels_mbconv_gelu.hip / _swish.hip / _relu6.hip).
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 
 #include "kernels.hpp"
+#include "mbconv_cfg.hpp"
 
 namespace bh {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-
 namespace {
-
-// n / d for 0 <= n < 2^22, d > 0 through the float reciprocal (one multiply, a convert and a
-// fix-up) instead of the ~35-instruction 32-bit integer division sequence
-// (products through the 24-bit multiplier: v_mul_lo_u32 runs at a quarter of the rate of v_mad_u32_u24)
-__device__ __forceinline__ int mb_div(int n, int d, float rcp_d) {
-    int q = (int)((float)n * rcp_d);
-    q += (n - __mul24(q, d) >= d) ? 1 : 0;
-    q -= (n - __mul24(q, d) < 0) ? 1 : 0;
-    return q;
-}
-
-// diagnostic phase clock (only when d.stamps != nullptr): cycles since the last stamp are summed per
-// phase in registers and added to the global counters once, at the end, by lane 0 of every wave
-struct MbClock {
-    unsigned long long last, acc[8];
-};
-#define mb_stamp(stamps, clk, ph)                                          \
-    do {                                                                   \
-        if (stamps) {                                                      \
-            const unsigned long long now_ = __builtin_readcyclecounter(); \
-            clk.acc[ph] += now_ - clk.last;                                \
-            clk.last = now_;                                               \
-        }                                                                  \
-    } while (0)
-
-// Template parameters
-//   KS, ST      depthwise kernel size / stride          CE     expanded channels per chunk
-//   KG          16-deep k groups of the expand GEMM (ceil(Cin / 16))
-//   RT_W        most source-row tiles (16 rows) one wave owns in P1
-//   NCS         waves splitting the chunk's columns in P1 (1 or 2)
-//   WM x WN     wave grid of P3, MT_W x NT_W accumulator tiles per wave
-//   TWL         log2(tile width)   XBL  log2(pixels per lane along x in P2)   SS  segments per workgroup
-//   OCC         waves per SIMD the register allocator must leave room for
-//
-// Operand residency: the wave's A fragments of the expand GEMM (its rows of X, all of Cin) are
-// loaded ONCE and stay in registers for every chunk.  The chunk's weights reach LDS by LDS-DMA
-// (global_load_lds_dwordx4, no VGPRs), issued behind one barrier and drained before the next:
-//     after B1(ch): We+be of chunk ch+1, Wp of chunk ch      (waited before B2(ch))
-//     after B2(ch): Wd+bd of chunk ch+1                      (waited before B1(ch+1))
-// so the MFMA loops read every operand from registers or LDS and never wait on memory.
-template <int NFLOATS, int NW = 4>
-__device__ __forceinline__ void mb_dma(const float *gsrc, float *lds_dst, int wave, int lane) {
-    constexpr int NP = (NFLOATS + 255) / 256;  // 1-KiB pieces, dealt round-robin to the NW waves
-#pragma unroll
-    for (int p0 = 0; p0 < NP; p0 += NW) {
-        const int p = p0 + wave;
-        const int off = p * 256 + lane * 4;
-        if (p < NP && off < NFLOATS) {
-            // Inline asm on purpose: after the builtin form hipcc drains vmcnt(0) in front of the next
-            // LDS read of ANY array (it cannot prove the DMA's destination is not read), which made
-            // every transfer synchronous.  The waits are placed by hand: mb_dma_wait() before the
-            // barrier that precedes the first reader.  M0 = LDS byte address of the piece.
-            const unsigned la = (unsigned)(size_t)(lds_dst + p * 256);
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                         :: "v"(gsrc + off), "s"(__builtin_amdgcn_readfirstlane(la)) : "memory", "m0");
-        }
-    }
-}
-// The same transfer addressed by an LDS BYTE ADDRESS instead of a pointer.  In some instantiations hipcc does not fold
-// `(unsigned)(size_t)lds_pointer` (a generic pointer: LDS -> flat -> integer) back to the LDS offset and its backend then rejects
-// the aperture test it builds ("Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base"); the column-task
-// instantiations hit that, so they compute the address from float offsets into the one dynamic shared array.
-// One piece: the wave's index is made scalar first, so the piece index, the global base (the source is wave-uniform) and the LDS
-// address live in SGPRs and the only per-lane value is the 32-bit byte offset `lane * 16` (the saddr form of the load).  With the
-// 64-bit per-lane addresses of mb_dma the 8-wave kernels (256 registers per wave) spilled exactly these, and a scratch reload's
-// `s_waitcnt vmcnt(0)` in the middle of a burst of pieces waits for every piece issued before it.
-template <int NFLOATS>
-__device__ __forceinline__ void mb_dma_piece(const float *gsrc, unsigned lds_byte_addr, int p /* scalar */, int lane) {
-    constexpr int NP = (NFLOATS + 255) / 256, TAIL = NFLOATS - (NP - 1) * 256;   // floats in the last piece
-    if (p < NP && (TAIL == 256 || p < NP - 1 || lane * 4 < TAIL)) {
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                     :: "v"((unsigned)lane * 16u), "s"(gsrc + (size_t)p * 256), "s"(lds_byte_addr + (unsigned)p * 1024u) : "memory", "m0");
-    }
-}
-template <int NFLOATS, int NW = 4>
-__device__ __forceinline__ void mb_dma_at(const float *gsrc, unsigned lds_byte_addr, int wave, int lane) {
-    constexpr int NP = (NFLOATS + 255) / 256;
-    const int ws = __builtin_amdgcn_readfirstlane(wave);
-#pragma unroll
-    for (int p0 = 0; p0 < NP; p0 += NW) mb_dma_piece<NFLOATS>(gsrc, lds_byte_addr, p0 + ws, lane);
-}
-// part `part` of `nparts` of the calling wave's share of the same transfer: the column-task kernels issue their chunk's weight
-// pieces a few at a time between the rows of the depthwise phase -- issued as one burst, the 12-13 pieces of a wave block it for
-// ~800 cycles while the vector-memory path takes them in (tools/microbench/lds_fill.hip)
-template <int NFLOATS, int NW = 4>
-__device__ __forceinline__ void mb_dma_at_part(const float *gsrc, unsigned lds_byte_addr, int wave, int lane, int part, int nparts) {
-    constexpr int NP = (NFLOATS + 255) / 256;
-    const int ws = __builtin_amdgcn_readfirstlane(wave);
-#pragma unroll
-    for (int p0 = 0; p0 < NP; p0 += NW) {
-        if ((p0 / NW) % nparts != part) continue;
-        mb_dma_piece<NFLOATS>(gsrc, lds_byte_addr, p0 + ws, lane);
-    }
-}
-__device__ __forceinline__ void mb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
-//   PREC        0: f32 MFMA (16x16x4, KG counts 16-deep groups); 3: f16 hi/lo split, three 16x16x32 MFMAs
-//               per product (KG counts 32-deep steps); 1: plain f16 operands (one MFMA, ~1e-3 relative)
-//   ACT         the expand and depthwise activation (GELU, swish, ReLU6 or ReLU: bh_act<>, kernels.hpp)
-//   COLTH       > 0: whole-image tiles of COLTH rows (stride 1) whose depthwise phase runs as COLUMN tasks -- one lane = one
-//               output column (all COLTH rows) x 4 channels.  The late blocks' images are 3 or 6 rows high under a 5x5 kernel:
-//               40 / 20 % of the taps of a row-wise task multiply the all-zero padding rows, and its 192 tasks leave a wave idle.
-//               A column task loads only the COLTH real rows of its 5 (3) grid columns once, skips the padding rows at compile
-//               time, and SS * TW * CE / 4 = 256 of them fill the workgroup.
-//   PERSIST     1: persistent workgroups (grid = workgroups that fit on the chip at once) walking the tiles, with the weights of
-//               EVERY chunk resident in LDS -- loaded once per workgroup, not once per tile and chunk.  For the early blocks
-//               (large images, few channels): a tile's compute is ~5k cycles, and 12 barriers each waiting for a freshly
-//               issued L2 -> LDS transfer plus the launch and set-up of 48-96 workgroups per segment were 70 % of their time
-//               (tools/abl2.sh: chunk loop without any compute 417 of 1061 us, set-up + epilogue 303).
-template <int KS, int ST, int CE, int KG, int RT_W, int NCS, int WM, int WN, int MT_W, int NT_W, int TWL, int XBL,
-          int SS, int OCC, int STEM, int PREC, int PERSIST = 0, int ACT = ACT_GELU_ERF, int COLTH = 0>
-__global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc d, const int n_seg) {
-    static_assert(!STEM || SS == 1, "the stem variant handles one segment per workgroup");
-    static_assert(PREC == 0 || CE % 32 == 0 || CE == 16, "f16 project GEMM: 32-deep steps, or one 16-deep step for 16-channel chunks");
-    // NW waves: 4 (one per SIMD; the workgroups of a CU interleave) or 8 (two per SIMD inside ONE workgroup: the late blocks, whose
-    // whole-image tiles leave room for a single workgroup per CU -- with one wave per SIMD nothing fills the issue bubbles of its
-    // dependent vector chains, and its MFMA and vector phases cannot overlap with anybody else's)
-    constexpr int NW = WM * WN, NTH = 64 * NW;
-    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
-    constexpr int NT_E = CE / 16, NT_U = NT_E / NCS, CES = CE + 4, C4N = CE / 4, TW = 1 << TWL;
-    constexpr int POUT_PAD = WM * MT_W * 16, NTOP = WN * NT_W;
-    constexpr int XB = 1 << XBL, XBN = TW / XB, NCOL = (XB - 1) * ST + KS;
-    constexpr int RSTEP = NW / NCS;  // row-tile stride between a wave's P1 tiles
-    constexpr int RG = (RT_W * NT_U <= 8) ? RT_W : (8 / NT_U >= 1 ? 8 / NT_U : 1);  // row tiles in flight
-    constexpr int FRAG = PREC ? 512 : 256;             // floats per (k step, column tile): f16 = hi + lo planes
-    constexpr int PSTEPS = PREC ? (CE + 31) / 32 : NT_E;  // k steps of the project GEMM per chunk
-    constexpr bool P16 = PREC != 0 && CE == 16;        // 16-channel chunks: ONE v_mfma_f32_16x16x16_f16 step, no k padding
-    constexpr int WE_FLOATS = KG * NT_E * FRAG + CE;   // We fragments + be
-    constexpr int WP_FLOATS = P16 ? NTOP * 256 : PSTEPS * NTOP * FRAG;
-    constexpr int WD_FLOATS = KS * KS * CE + CE;       // Wd [tap][CE] + bd
-    constexpr int DSH = P16 ? 24 : PSTEPS * 32 + 8;    // f16 D planes: row stride in halves (48 / 80 B: conflict-free reads)
-    constexpr int DS_FLOATS = PREC ? POUT_PAD * DSH : POUT_PAD * CES;
-    static_assert(NT_U * NCS == NT_E, "column split");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-
-    const int tid0 = threadIdx.x, lane0 = tid0 & 63, wave0 = tid0 >> 6;
-    const int IH = d.IH, IW = d.IW, TH = d.TH, THTW = d.TH << TWL;
-    const int egrid = SS * IH * IW;
-    float *Es = smem;
-    float *Ds = Es + (size_t)(egrid + 1) * CES;  // + 1: trash row that padding source rows write to
-    // Weight buffers.  ring == 0: one buffer each, refilled one PHASE ahead of its reader (see above).  ring == 1 (blocks whose
-    // chunks are small: the early, large-image blocks): We x 2, Wp x 3, Wd x 2, refilled one whole CHUNK ahead -- a phase of
-    // those blocks is a few hundred cycles, shorter than an L2 -> LDS transfer, and the waits in front of both barriers were
-    // half of the kernel's wave-cycles (tools/gpu_mb_stamps.py); the ring costs 5-7 KB of LDS.
-    const bool ring = !PERSIST && COLTH == 0 && d.ring != 0;
-    const int nbuf_e = PERSIST ? d.nchunks : (ring ? 2 : 1), nbuf_p = PERSIST ? d.nchunks : (ring ? 3 : 1);
-    float *WeS = Ds + DS_FLOATS;
-    _Float16 *DsH = reinterpret_cast<_Float16 *>(Ds), *DsL = DsH + POUT_PAD * DSH;   // PREC != 0
-    float *WpS = WeS + nbuf_e * WE_FLOATS;
-    float *Wds = WpS + nbuf_p * WP_FLOATS;
-    int *omap = reinterpret_cast<int *>(Wds + nbuf_e * WD_FLOATS);
-    // (column-task instantiations: LDS byte addresses of the weight buffers, see mb_dma_at; the dynamic shared array follows the
-    //  kernel's static LDS, of which there is none here)
-    static_assert(COLTH == 0 || PERSIST == 0, "column tasks: no persistent variant");
-    const unsigned lds0 = (__builtin_amdgcn_groupstaticsize() + 15u) & ~15u;
-    const unsigned we_ba = lds0 + 4u * (unsigned)((egrid + 1) * CES + DS_FLOATS), wp_ba = we_ba + 4u * (unsigned)(nbuf_e * WE_FLOATS),
-                   wd_ba = wp_ba + 4u * (unsigned)(nbuf_p * WP_FLOATS);
-
-    MbClock t_last{};
-    if (d.stamps) t_last.last = __builtin_readcyclecounter();
-    if constexpr (PERSIST != 0) {
-        for (int c = 0; c < d.nchunks; c++) {   // every chunk's weights, once
-            mb_dma<WE_FLOATS, NW>(d.We + (size_t)c * WE_FLOATS, WeS + c * WE_FLOATS, wave0, lane0);
-            mb_dma<WD_FLOATS, NW>(d.Wd + (size_t)c * WD_FLOATS, Wds + c * WD_FLOATS, wave0, lane0);
-            mb_dma<WP_FLOATS, NW>(d.Wp + (size_t)c * WP_FLOATS, WpS + c * WP_FLOATS, wave0, lane0);
-        }
-    } else {
-        if constexpr (COLTH > 0) {
-            mb_dma_at<WE_FLOATS, NW>(d.We, we_ba, wave0, lane0);
-            mb_dma_at<WD_FLOATS, NW>(d.Wd, wd_ba, wave0, lane0);
-        } else {
-            mb_dma<WE_FLOATS, NW>(d.We, WeS, wave0, lane0);
-            mb_dma<WD_FLOATS, NW>(d.Wd, Wds, wave0, lane0);
-        }
-        if (ring) {
-            mb_dma<WP_FLOATS, NW>(d.Wp, WpS, wave0, lane0);
-            if (d.nchunks > 1) {
-                mb_dma<WE_FLOATS, NW>(d.We + WE_FLOATS, WeS + WE_FLOATS, wave0, lane0);
-                mb_dma<WD_FLOATS, NW>(d.Wd + WD_FLOATS, Wds + WD_FLOATS, wave0, lane0);
-                mb_dma<WP_FLOATS, NW>(d.Wp + WP_FLOATS, WpS + WP_FLOATS, wave0, lane0);
-            }
-        }
-    }
-
-    // PERSIST: tile = (segment group, tile row, tile column), linear; this workgroup takes every gridDim.x-th one
-    const int tiles_xy = d.tiles_x * d.tiles_y;
-    const int n_tiles = PERSIST ? tiles_xy * ((n_seg + SS - 1) / SS) : 1;
-    for (int tile = PERSIST ? (int)blockIdx.x : 0; tile < n_tiles; tile += PERSIST ? (int)gridDim.x : 1) {
-    // (everything below is per tile.  The thread index goes through an opaque copy so that hipcc does not hoist the
-    //  tile-invariant index arithmetic out of the tile loop and keep it in registers across it: a first persistent
-    //  version doubled its VGPRs and spilled SGPRs that way)
-    int tid = tid0;
-    if constexpr (PERSIST != 0) asm volatile("" : "+v"(tid));
-    const int lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, kq = lane >> 4;
-    const int tz = PERSIST ? tile / tiles_xy : (int)blockIdx.z, txy = tile - tz * tiles_xy;
-    const int tyi = PERSIST ? txy / d.tiles_x : (int)blockIdx.y, txi = PERSIST ? txy - tyi * d.tiles_x : (int)blockIdx.x;
-    const int seg0 = tz * SS;
-    const int nsv = min(SS, n_seg - seg0);
-    const int oy0 = tyi * TH, ox0 = txi * TW;
-    const int iy0 = oy0 * ST - d.pad_t, ix0 = ox0 * ST - d.pad_l;
-    const int ya = max(0, -iy0), yb = min(IH, d.H - iy0);
-    const int xa = max(0, -ix0), xb = min(IW, d.W - ix0);
-    const int vh = max(yb - ya, 0), vw = max(xb - xa, 0);
-    const int Mseg = vh * vw, M = Mseg * nsv, nrt = (M + 15) >> 4;
-    const int Cin = d.Cin, Cout = d.Cout, nchunks = (d.dbg & 128) ? 0 : d.nchunks;
-    // STEM: X is the planar spectrogram [n][C][SH][SW]; "Cin" = kh*kw*C im2col columns
-    const float *Xb = STEM ? d.X + (size_t)seg0 * d.stem_c * d.stem_h * d.stem_w : d.X + (size_t)seg0 * d.H * d.W * Cin;
-    const int rw = wave / NCS, cs = wave - rw * NCS;  // P1: row-tile lane of the wave, column split
-    const int wm = wave / WN, wn = wave - wm * WN;    // P3
-
-    const float rcp_vw = 1.0f / (float)max(vw, 1);
-    const float e_unscale = d.e_unscale, p_scale = d.p_scale, p_unscale = d.p_unscale;
-    // ---- the wave's rows of X: A fragments of the expand GEMM, resident for the whole kernel ----
-    // f32: afr[i][g] = 4 k values of one 16-deep group; f16: ah/al[i][g] = 8 k values of one 32-deep step
-    float4 afr[PREC ? 1 : RT_W][PREC ? 1 : KG];
-    f16x8 ah[PREC ? RT_W : 1][PREC ? KG : 1], al[PREC ? RT_W : 1][PREC ? KG : 1];
-    // the expand GEMM is computed transposed (E^T = We^T X^T): a lane ends up with 4 consecutive
-    // channels of ONE source row, li of its row tile, and writes them with one ds_write_b128 at
-    // eoff[i] = that row's slot in the LDS grid (padding rows: the trash slot)
-    int eoff[RT_W];
-    // Two passes over the wave's row tiles: every load of a batch of row tiles is issued UNCONDITIONALLY from a clamped address
-    // (rows past the tile, columns past Cin and out-of-image taps read a valid address and are replaced by zero afterwards), and
-    // only then are the values split / stored.  With the loads inside `if (valid)` hipcc waited for each row tile's loads before
-    // computing the next one's addresses: RT_W dependent HBM round trips at the start of every workgroup.
-    constexpr int NV = PREC ? 8 : 4;            // consecutive k per lane and step
-    constexpr int NQ = STEM ? 2 : NV / 4;       // 16-byte (stem, f16 modes: 12-byte) loads per (row tile, step)
-    // (8-wave kernels: one workgroup per CU, so nothing hides a second round trip of the set-up, and at that point the 256 registers
-    //  hold nothing but these loads and the fragments they become: all row tiles in one batch)
-    constexpr int XLIM = NW == 8 ? 24 : 16;
-    constexpr int XBATCH = (STEM && !PREC) ? 1 : (RT_W * KG * NQ <= XLIM ? RT_W : (XLIM / (KG * NQ) >= 1 ? XLIM / (KG * NQ) : 1));
-    struct __attribute__((packed, aligned(4))) F3 { float a, b, c; };
-#pragma unroll
-    for (int i0 = 0; i0 < RT_W; i0 += XBATCH) {
-        int xo[XBATCH];
-        bool rvv[XBATCH];
-#pragma unroll
-        for (int ii = 0; ii < XBATCH; ii++) {
-            const int i = i0 + ii;
-            if (i >= RT_W) continue;
-            const int rt = rw + RSTEP * i;
-            rvv[ii] = false;
-            xo[ii] = 0;   // row offset computed in registers: the loads go out before the table barrier
-            eoff[i] = egrid * CES + 4 * kq;
-            const int m = rt * 16 + li;
-            if (rt < nrt && m < M) {
-                const int sl = SS > 1 ? (m >= Mseg ? 1 : 0) : 0, mm = m - sl * Mseg;
-                const int r = mb_div(mm, vw, rcp_vw), c = mm - __mul24(r, vw);
-                eoff[i] = __mul24(sl * IH * IW + __mul24(ya + r, IW) + xa + c, CES) + 4 * kq;
-                xo[ii] = STEM ? (((iy0 + ya + r) << 16) | (ix0 + xa + c))   // stem-output pixel (y, x), gathered below
-                              : __mul24(__mul24(sl * d.H + iy0 + ya + r, d.W) + ix0 + xa + c, Cin);
-                rvv[ii] = !(d.dbg & 64);
-            }
-        }
-        if constexpr (STEM != 0 && PREC == 0) {
-            // f32 mode: im2col column k = (dy * 3 + dx) * C + ch, exactly the row order of the [kh][kw][cin][cout] weights
-            const int i = i0;
-            const int sy = (xo[0] >> 16) * d.stem_s - d.stem_pt, sx = (xo[0] & 0xffff) * d.stem_s - d.stem_pl;
-#pragma unroll
-            for (int g = 0; g < KG; g++) {
-                float v[4];
-#pragma unroll
-                for (int c = 0; c < 4; c++) {
-                    const int k = 16 * g + 4 * kq + c;
-                    const int tap = k / (STEM ? STEM : 1), ch = k - tap * STEM;   // STEM = spectrogram channels
-                    const int dy = tap / 3, dx = tap - dy * 3;
-                    const int y = sy + dy, x = sx + dx;
-                    const bool ok = rvv[0] && k < Cin && y >= 0 && y < d.stem_h && x >= 0 && x < d.stem_w;
-                    v[c] = ok ? Xb[((size_t)ch * d.stem_h + y) * d.stem_w + x] : 0.0f;
-                }
-                afr[i][g] = make_float4(v[0], v[1], v[2], v[3]);
-            }
-        } else if constexpr (STEM != 0) {
-            // im2col gather of the 3x3 stem conv (stride s, planar input), f16 modes: ONE 32-deep step whose columns are ordered
-            // by memory runs -- lane group kq holds runs 2 kq and 2 kq + 1, a run being the three horizontally adjacent taps
-            // (dx = 0, 1, 2) of one (channel, dy); elements 6, 7 of the group are zero (api.hip plan_fusion packs the weight rows
-            // to match).  Two 12-byte loads per lane and row tile instead of eight scalar ones with a division chain per
-            // element: the gather was the stem block's largest single cost (tools/abl.sh).
-            static_assert(STEM == 0 || PREC == 0 || (STEM <= 2 && KG == 1), "3 STEM runs fit the 8 run slots of one step");
-            F3 t[XBATCH][2];
-            bool okr[XBATCH][2];
-#pragma unroll
-            for (int ii = 0; ii < XBATCH; ii++) {
-                if (i0 + ii >= RT_W) continue;
-                const int sy = (xo[ii] >> 16) * d.stem_s - d.stem_pt, sx = (xo[ii] & 0xffff) * d.stem_s - d.stem_pl;
-                const int bx = min(max(sx, 0), d.stem_w - 3);   // the 3-float window, kept inside the row
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    const int r = 2 * kq + q, ch = r >= 3 ? 1 : 0, dy = r - 3 * ch, y = sy + dy;
-                    okr[ii][q] = rvv[ii] && r < 3 * STEM && y >= 0 && y < d.stem_h;
-                    const int yc = okr[ii][q] ? y : 0, chc = okr[ii][q] ? ch : 0;
-                    t[ii][q] = *reinterpret_cast<const F3 *>(Xb + ((size_t)chc * d.stem_h + yc) * d.stem_w + bx);
-                }
-            }
-#pragma unroll
-            for (int ii = 0; ii < XBATCH; ii++) {
-                const int i = i0 + ii;
-                if (i >= RT_W) continue;
-                const int sx = (xo[ii] & 0xffff) * d.stem_s - d.stem_pl;
-                const int sh = sx - min(max(sx, 0), d.stem_w - 3);
-                float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int q = 0; q < 2; q++) {
-                    // element dx is column sx + dx = bx + sh + dx; sh is -1 / 0 / +1 at the left edge / inside / at the right edge
-                    const F3 tt = t[ii][q];
-                    const float e0 = sh == 0 ? tt.a : sh > 0 ? tt.b : 0.0f;
-                    const float e1 = sh == 0 ? tt.b : sh > 0 ? tt.c : tt.a;
-                    const float e2 = sh == 0 ? tt.c : sh > 0 ? 0.0f : tt.b;
-                    v[3 * q] = (okr[ii][q] && sx >= 0) ? e0 : 0.0f;
-                    v[3 * q + 1] = (okr[ii][q] && sx + 1 >= 0 && sx + 1 < d.stem_w) ? e1 : 0.0f;
-                    v[3 * q + 2] = (okr[ii][q] && sx + 2 < d.stem_w) ? e2 : 0.0f;
-                }
-                bh_split8(v, ah[i][0], al[i][0]);
-            }
-        } else {
-            float4 raw[XBATCH][KG][NQ];
-#pragma unroll
-            for (int ii = 0; ii < XBATCH; ii++) {
-                if (i0 + ii >= RT_W) continue;
-#pragma unroll
-                for (int g = 0; g < KG; g++)
-#pragma unroll
-                    for (int q = 0; q < NQ; q++) {
-                        const int kk = (PREC ? 32 * g + 8 * kq : 16 * g + 4 * kq) + 4 * q;
-                        const bool ok = rvv[ii] && kk < Cin;
-                        raw[ii][g][q] = *reinterpret_cast<const float4 *>(Xb + (ok ? xo[ii] + kk : 0));
-                    }
-            }
-#pragma unroll
-            for (int ii = 0; ii < XBATCH; ii++) {
-                const int i = i0 + ii;
-                if (i >= RT_W) continue;
-#pragma unroll
-                for (int g = 0; g < KG; g++) {
-                    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int q = 0; q < NQ; q++) {
-                        const int kk = (PREC ? 32 * g + 8 * kq : 16 * g + 4 * kq) + 4 * q;
-                        const bool ok = rvv[ii] && kk < Cin;
-                        const float4 t = raw[ii][g][q];
-                        v[4 * q] = ok ? t.x : 0.0f; v[4 * q + 1] = ok ? t.y : 0.0f;
-                        v[4 * q + 2] = ok ? t.z : 0.0f; v[4 * q + 3] = ok ? t.w : 0.0f;
-                    }
-                    if constexpr (PREC != 0) bh_split8(v, ah[i][g], al[i][g]);
-                    else afr[i][g] = make_float4(v[0], v[1], v[2], v[3]);
-                }
-            }
-        }
-    }
-    for (int p = tid; p < POUT_PAD; p += NTH) {
-        const int sl = (p >= THTW ? 1 : 0) + (p >= 2 * THTW ? 1 : 0), pp = p - sl * THTW;  // SS <= 2
-        const int ty = pp >> TWL, tx = pp & (TW - 1);
-        int o = -1;
-        if (sl < nsv && oy0 + ty < d.Ho && ox0 + tx < d.Wo) o = (sl * d.Ho + oy0 + ty) * d.Wo + ox0 + tx;
-        omap[p] = o;
-    }
-    if (M != egrid) {  // some of the grid lies outside the image (or a segment is missing): zero padding
-        float4 *z = reinterpret_cast<float4 *>(Es);
-        const int n4 = egrid * CES / 4;
-        for (int i = tid; i < n4; i += NTH) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    mb_dma_wait();
-    __syncthreads();
-
-    mb_stamp(d.stamps, t_last, 0);
-
-    // The project accumulators start at bias + residual: those loads overlap the first chunk
-    // instead of stalling the epilogue, which is then nothing but stores.
-    float *Yb = d.Y + (size_t)seg0 * d.Ho * d.Wo * Cout;
-    const float *Rb = d.R ? d.R + (size_t)seg0 * d.Ho * d.Wo * Cout : nullptr;
-    f32x4 acco[MT_W][NT_W];
-#pragma unroll
-    for (int i = 0; i < MT_W; i++) {
-        const int4 o4 = *reinterpret_cast<const int4 *>(&omap[(wm * MT_W + i) * 16 + 4 * kq]);
-        const int orow[4] = {o4.x, o4.y, o4.z, o4.w};
-        // (unconditional loads from clamped addresses, selected afterwards: inside `cond ? load : 0` every load waited for the
-        //  one before it)
-#pragma unroll
-        for (int j = 0; j < NT_W; j++) {
-            const int col = (wn * NT_W + j) * 16 + li, colc = min(col, Cout - 1);
-            if constexpr (MT_W * NT_W <= 8) {   // (the small-tile instantiations of the early blocks; with 30 accumulator tiles
-                                                //  that many loads in flight cost registers the late blocks do not have)
-                const float braw = d.bp[colc];
-                float rres[4] = {0.f, 0.f, 0.f, 0.f};
-                if (Rb) {   // (wave-uniform)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) rres[r] = Rb[(size_t)max(orow[r], 0) * Cout + colc];
-                }
-                const float bias = col < Cout ? braw : 0.0f;
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-                    acco[i][j][r] = __builtin_fmaf((col < Cout && orow[r] >= 0) ? rres[r] : 0.0f, p_scale, bias);
-            } else {
-                const float bias = col < Cout ? d.bp[col] : 0.0f;
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-                    acco[i][j][r] = __builtin_fmaf((Rb && col < Cout && orow[r] >= 0) ? Rb[(size_t)orow[r] * Cout + col] : 0.0f, p_scale, bias);
-            }
-        }
-    }
-
-    // P2 tasks: XB output pixels x 4 channels each.  The 16-channel-chunk instantiations have at most 256
-    // = one per thread, so the first task's decomposition is done once here, not once per chunk.
-    const int p2_ntask = nsv * TH * XBN * C4N;
-    int p2_c4, p2_eoff, p2_prow;
-    auto p2_task = [&](int t) {
-        const int q = t / C4N;
-        p2_c4 = t - q * C4N;
-        const int r = q >> (TWL - XBL), sl = (SS > 1 && r >= TH) ? 1 : 0, ty = r - sl * TH;
-        const int tx0 = (q & (XBN - 1)) * XB;
-        p2_eoff = (sl * IH * IW + (ty * ST) * IW + tx0 * ST) * CES + 4 * p2_c4;
-        p2_prow = sl * THTW + (ty << TWL) + tx0;
-    };
-    p2_task(tid);
-
-    for (int ch = 0; ch < nchunks; ch++) {
-        const int chn = min(ch + 1, nchunks - 1);
-        // this chunk's weights
-        const float *WeC = WeS + (PERSIST ? ch : ring ? (ch & 1) : 0) * WE_FLOATS, *WdC = Wds + (PERSIST ? ch : ring ? (ch & 1) : 0) * WD_FLOATS;
-        const float *WpC = WpS + (PERSIST ? ch : ring ? (ch % 3) : 0) * WP_FLOATS;
-        const float *bes = WeC + KG * NT_E * FRAG, *bds = WdC + KS * KS * CE;
-        mb_stamp(d.stamps, t_last, 1);
-
-        // ---- P1: expand ------------------------------------------------------------------
-#pragma unroll
-        for (int i0 = 0; i0 < RT_W; i0 += RG) {
-            if (rw + RSTEP * i0 < nrt) {  // wave-uniform
-                f32x4 acc[RG][NT_U];   // [channel 4 kq + r][source row li], seeded with the bias
-#pragma unroll
-                for (int j = 0; j < NT_U; j++) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4 *>(&bes[(cs * NT_U + j) * 16 + 4 * kq]);
-#pragma unroll
-                    for (int ii = 0; ii < RG; ii++) acc[ii][j] = b4;
-                }
-                if (!(d.dbg & 8)) {
-                    if constexpr (PREC != 0) {
-                        // fragment planes: [step][column tile]{hi: 64 lanes x 8 halves, lo: same}
-                        const f16x8 *wf = reinterpret_cast<const f16x8 *>(WeC);
-                        // the next step's weight fragments are read from LDS BEFORE this step's MFMAs are issued (two register
-                        // sets, alternating): with the loads right in front of their MFMAs every k step of a late block
-                        // (6 steps x 9 MFMAs) began with an exposed LDS round trip, ~120 of its ~260 cycles
-                        f16x8 bhb[2][NT_U], blb[2][NT_U];
-                        auto wload = [&](int g, f16x8 (&h)[NT_U], f16x8 (&l)[NT_U]) __attribute__((always_inline)) {
-#pragma unroll
-                            for (int j = 0; j < NT_U; j++) {
-                                h[j] = wf[((g * NT_E + cs * NT_U + j) * 2 + 0) * 64 + lane];
-                                if (PREC == 3) l[j] = wf[((g * NT_E + cs * NT_U + j) * 2 + 1) * 64 + lane];
-                            }
-                        };
-                        wload(0, bhb[0], blb[0]);
-#pragma unroll
-                        for (int g = 0; g < KG; g++) {
-                            // (KG >= 6 only, the 192-channel blocks: measured -5 % there, nothing at 3-4 steps, and the early
-                            //  blocks' one-step kernels lost 1 % to the changed register allocation)
-                            constexpr bool AHEAD = KG >= 6;
-                            if (AHEAD && g + 1 < KG) wload(g + 1, bhb[(g + 1) & 1], blb[(g + 1) & 1]);
-                            if (!AHEAD && g > 0) wload(g, bhb[g & 1], blb[g & 1]);
-                            f16x8 (&bh)[NT_U] = bhb[g & 1], (&bl)[NT_U] = blb[g & 1];
-#pragma unroll
-                            for (int ii = 0; ii < RG; ii++) {
-                                if (i0 + ii >= RT_W) continue;
-                                constexpr int dummy = 0; (void)dummy;
-                                const int ir = i0 + ii < RT_W ? i0 + ii : 0;
-#pragma unroll
-                                for (int j = 0; j < NT_U; j++) {
-                                    acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], ah[ir][g], acc[ii][j], 0, 0, 0);
-                                    if (PREC == 3) {
-                                        acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[j], ah[ir][g], acc[ii][j], 0, 0, 0);
-                                        acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[j], al[ir][g], acc[ii][j], 0, 0, 0);
-                                    }
-                                }
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    } else {
-                    // B fragments double-buffered by hand, and a scheduling fence per k group: left
-                    // alone, hipcc hoists every group's LDS loads to the top of the unrolled loop and
-                    // spills the resident A fragments
-                    float4 bv[NT_U], bn[NT_U];
-#pragma unroll
-                    for (int j = 0; j < NT_U; j++)
-                        bv[j] = *reinterpret_cast<const float4 *>(&WeC[((cs * NT_U + j) * 64 + lane) * 4]);
-#pragma unroll
-                    for (int g = 0; g < KG; g++) {
-                        if (g + 1 < KG) {
-#pragma unroll
-                            for (int j = 0; j < NT_U; j++)
-                                bn[j] = *reinterpret_cast<const float4 *>(&WeC[(((g + 1) * NT_E + cs * NT_U + j) * 64 + lane) * 4]);
-                        }
-#pragma unroll
-                        for (int c = 0; c < 4; c++)
-#pragma unroll
-                            for (int ii = 0; ii < RG; ii++) {
-                                if (i0 + ii >= RT_W) continue;
-                                const float4 av = afr[i0 + ii < RT_W ? i0 + ii : 0][g];
-                                const float a = c == 0 ? av.x : c == 1 ? av.y : c == 2 ? av.z : av.w;
-#pragma unroll
-                                for (int j = 0; j < NT_U; j++) {
-                                    const float b = c == 0 ? bv[j].x : c == 1 ? bv[j].y : c == 2 ? bv[j].z : bv[j].w;
-                                    acc[ii][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b, a, acc[ii][j], 0, 0, 0);
-                                }
-                            }
-                        if (g + 1 < KG) {
-#pragma unroll
-                            for (int j = 0; j < NT_U; j++) bv[j] = bn[j];
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    }  // PREC == 0
-                }
-#pragma unroll
-                for (int ii = 0; ii < RG; ii++) {
-                    if (i0 + ii >= RT_W) continue;
-                    const int rt = rw + RSTEP * (i0 + ii);
-                    if (rt < nrt) {
-                        float *erow = Es + eoff[i0 + ii < RT_W ? i0 + ii : 0] + cs * NT_U * 16;
-#pragma unroll
-                        for (int j = 0; j < NT_U; j++) {
-                            f32x2 v01 = {acc[ii][j][0], acc[ii][j][1]}, v23 = {acc[ii][j][2], acc[ii][j][3]};
-                            if constexpr (PREC != 0) { v01 *= e_unscale; v23 *= e_unscale; }   // weights and bias carry 2^se
-                            bh_act4<ACT>(v01, v23);
-                            *reinterpret_cast<f32x4 *>(erow + j * 16) = (f32x4){v01[0], v01[1], v23[0], v23[1]};
-                        }
-                    }
-                }
-            }
-        }
-        mb_stamp(d.stamps, t_last, 2);
-        if (!ring && !PERSIST) mb_dma_wait();
-        __syncthreads();  // B1: Es complete; (ring == 0) WeS / WpS free; Wds (DMA issued after the last B2) landed
-        if (!ring && !PERSIST && !(d.dbg & 16)) {
-            if constexpr (COLTH > 0) {
-                // (issued in parts inside the depthwise phase below)
-            } else {
-                mb_dma<WE_FLOATS, NW>(d.We + (size_t)chn * WE_FLOATS, WeS, wave, lane);
-                mb_dma<WP_FLOATS, NW>(d.Wp + (size_t)ch * WP_FLOATS, WpS, wave, lane);
-            }
-        }
-        mb_stamp(d.stamps, t_last, 3);
-
-        // ---- P2: depthwise, XB output pixels x 4 channels per lane ---------------------------
-        if constexpr (COLTH > 0 && NW == 8) {
-            // column tasks of the 8-wave workgroups: one lane = one output column (all COLTH rows) x TWO channels, so that
-            // SS * TW * CE / 2 = 512 tasks fill the workgroup and a task's rows (COLTH x KS float2) fit beside the resident A
-            // fragments in the 256 registers two waves per SIMD leave; rows are finished two at a time (two interleaved GELU
-            // chains per lane, as bh_act4 does for the 4-channel tasks)
-            constexpr int PADT = (KS - 1) / 2, C2N = CE / 2;
-            static_assert(ST == 1, "column tasks: stride 1");
-            const bool dma_on = !(d.dbg & 16);
-            if (!(tid < nsv * TW * C2N && !(d.dbg & 2))) {   // (wave-uniform)
-                if (dma_on) {
-                    mb_dma_at<WE_FLOATS, NW>(d.We + (size_t)chn * WE_FLOATS, we_ba, wave, lane);
-                    mb_dma_at<WP_FLOATS, NW>(d.Wp + (size_t)ch * WP_FLOATS, wp_ba, wave, lane);
-                }
-            } else {
-                const int c2 = tid % C2N, q = tid / C2N, x = q & (TW - 1), sl = q >> TWL;
-                const float *eb = Es + ((sl * IH + PADT) * IW + x) * CES + 2 * c2;   // grid row PADT = image row 0
-                // one grid COLUMN of the task's window at a time (the next one in flight): all COLTH x KS values at once are 60
-                // registers under a 5x5 kernel on a 6-row image, which the 256 of a wave here do not have beside the A fragments
-                f32x2 e[2][COLTH];
-#pragma unroll
-                for (int r = 0; r < COLTH; r++) e[0][r] = *reinterpret_cast<const f32x2 *>(eb + (r * IW) * CES);
-                const f32x2 bd2 = *reinterpret_cast<const f32x2 *>(&bds[2 * c2]);
-                f32x2 acc[COLTH];
-#pragma unroll
-                for (int r = 0; r < COLTH; r++) acc[r] = bd2;
-#pragma unroll
-                for (int dx = 0; dx < KS; dx++) {
-                    if (dx + 1 < KS) {
-#pragma unroll
-                        for (int r = 0; r < COLTH; r++) e[(dx + 1) & 1][r] = *reinterpret_cast<const f32x2 *>(eb + (r * IW + dx + 1) * CES);
-                    }
-#pragma unroll
-                    for (int dy = 0; dy < KS; dy++) {
-                        const f32x2 w = *reinterpret_cast<const f32x2 *>(&WdC[(dy * KS + dx) * CE + 2 * c2]);
-#pragma unroll
-                        for (int r = 0; r < COLTH; r++) {
-                            constexpr int dummy = 0; (void)dummy;
-                            const int src = r + dy - PADT;          // image row under this tap; outside [0, COLTH): zero padding
-                            if (src < 0 || src >= COLTH) continue;   // (compile-time after unrolling)
-                            acc[r] = __builtin_elementwise_fma(e[dx & 1][src], w, acc[r]);
-                        }
-                    }
-                    if (dma_on) {   // this column's share of the next chunk's expand weights and this chunk's project weights
-                        mb_dma_at_part<WE_FLOATS, NW>(d.We + (size_t)chn * WE_FLOATS, we_ba, wave, lane, dx, KS);
-                        mb_dma_at_part<WP_FLOATS, NW>(d.Wp + (size_t)ch * WP_FLOATS, wp_ba, wave, lane, dx, KS);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);   // one window column of loads in flight
-                }
-#pragma unroll
-                for (int r = 0; r < COLTH; r += 2) {
-                    f32x2 g0 = acc[r], g1 = acc[r + 1 < COLTH ? r + 1 : r];
-                    if (r + 1 < COLTH) bh_act4<ACT>(g0, g1);
-                    else g0 = bh_act2<ACT>(g0);
-#pragma unroll
-                    for (int k = 0; k < 2; k++) {
-                        if (r + k >= COLTH) continue;
-                        const f32x2 g = k ? g1 : g0;
-                        const int prow = sl * THTW + ((r + k) << TWL) + x;
-                        if constexpr (PREC == 3) {
-                            bh_f16x2 h, l;
-                            bh_split2(g[0], g[1], h, l);
-                            *reinterpret_cast<bh_f16x2 *>(&DsH[prow * DSH + 2 * c2]) = h;
-                            *reinterpret_cast<bh_f16x2 *>(&DsL[prow * DSH + 2 * c2]) = l;
-                        } else if constexpr (PREC == 1) {
-                            *reinterpret_cast<bh_f16x2 *>(&DsH[prow * DSH + 2 * c2]) = (bh_f16x2){(_Float16)g[0], (_Float16)g[1]};
-                        } else {
-                            *reinterpret_cast<f32x2 *>(&Ds[prow * CES + 2 * c2]) = g;
-                        }
-                    }
-                }
-            }
-        } else
-        if constexpr (COLTH > 0) {
-            // column tasks (see COLTH above): task = (segment slot, column x, channel group c4); mb_try_th guarantees TH == H ==
-            // Ho == COLTH, one tile row, pad_t == (KS - 1) / 2 and at most 256 tasks
-            constexpr int PADT = (KS - 1) / 2;
-            static_assert(ST == 1, "column tasks: stride 1");
-            const bool dma_on = !(d.dbg & 16);
-            if (!(tid < nsv * TW * C4N && !(d.dbg & 2))) {   // (wave-uniform: a wave without tasks issues its pieces at once)
-                if (dma_on) {
-                    mb_dma_at<WE_FLOATS, NW>(d.We + (size_t)chn * WE_FLOATS, we_ba, wave, lane);
-                    mb_dma_at<WP_FLOATS, NW>(d.Wp + (size_t)ch * WP_FLOATS, wp_ba, wave, lane);
-                }
-            } else {
-                const int c4 = tid % C4N, q = tid / C4N, x = q & (TW - 1), sl = q >> TWL;
-                const float *eb = Es + ((sl * IH + PADT) * IW + x) * CES + 4 * c4;   // grid row PADT = image row 0
-                float4 e[COLTH][KS];
-#pragma unroll
-                for (int r = 0; r < COLTH; r++)
-#pragma unroll
-                    for (int dx = 0; dx < KS; dx++) e[r][dx] = *reinterpret_cast<const float4 *>(eb + (r * IW + dx) * CES);
-                const float4 bd4 = *reinterpret_cast<const float4 *>(&bds[4 * c4]);
-                f32x2 acc[COLTH][2];
-#pragma unroll
-                for (int r = 0; r < COLTH; r++) { acc[r][0] = (f32x2){bd4.x, bd4.y}; acc[r][1] = (f32x2){bd4.z, bd4.w}; }
-#pragma unroll
-                for (int dy = 0; dy < KS; dy++) {
-#pragma unroll
-                    for (int dx = 0; dx < KS; dx++) {
-                        const float4 w = *reinterpret_cast<const float4 *>(&WdC[(dy * KS + dx) * CE + 4 * c4]);
-                        const f32x2 w0 = (f32x2){w.x, w.y}, w1 = (f32x2){w.z, w.w};
-#pragma unroll
-                        for (int r = 0; r < COLTH; r++) {
-                            constexpr int dummy = 0; (void)dummy;
-                            const int src = r + dy - PADT;          // image row under this tap; outside [0, COLTH): zero padding
-                            if (src < 0 || src >= COLTH) continue;   // (compile-time after unrolling)
-                            const float4 ev = e[src][dx];
-                            acc[r][0] = __builtin_elementwise_fma((f32x2){ev.x, ev.y}, w0, acc[r][0]);
-                            acc[r][1] = __builtin_elementwise_fma((f32x2){ev.z, ev.w}, w1, acc[r][1]);
-                        }
-                    }
-                    if (dma_on) {   // this row's share of the next chunk's expand weights and this chunk's project weights
-                        mb_dma_at_part<WE_FLOATS, NW>(d.We + (size_t)chn * WE_FLOATS, we_ba, wave, lane, dy, KS);
-                        mb_dma_at_part<WP_FLOATS, NW>(d.Wp + (size_t)ch * WP_FLOATS, wp_ba, wave, lane, dy, KS);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);   // one kernel row of weight loads in flight
-                }
-#pragma unroll
-                for (int r = 0; r < COLTH; r++) {
-                    f32x2 g0 = acc[r][0], g1 = acc[r][1];
-                    bh_act4<ACT>(g0, g1);
-                    const int prow = sl * THTW + (r << TWL) + x;
-                    if constexpr (PREC == 3) {
-                        bh_f16x2 h0, l0, h1, l1;
-                        bh_split2(g0[0], g0[1], h0, l0);
-                        bh_split2(g1[0], g1[1], h1, l1);
-                        *reinterpret_cast<f16x4 *>(&DsH[prow * DSH + 4 * c4]) = (f16x4){h0[0], h0[1], h1[0], h1[1]};
-                        *reinterpret_cast<f16x4 *>(&DsL[prow * DSH + 4 * c4]) = (f16x4){l0[0], l0[1], l1[0], l1[1]};
-                    } else if constexpr (PREC == 1) {
-                        *reinterpret_cast<f16x4 *>(&DsH[prow * DSH + 4 * c4]) =
-                            (f16x4){(_Float16)g0[0], (_Float16)g0[1], (_Float16)g1[0], (_Float16)g1[1]};
-                    } else {
-                        *reinterpret_cast<float4 *>(&Ds[prow * CES + 4 * c4]) = make_float4(g0[0], g0[1], g1[0], g1[1]);
-                    }
-                }
-            }
-        } else
-        if (!(d.dbg & 2)) {
-            for (int t = tid; t < p2_ntask; t += NTH) {
-                if (p2_ntask > NTH) p2_task(t);   // wave-uniform
-                const int c4 = p2_c4;
-                const float *eb = Es + p2_eoff;
-                const float4 bd4 = *reinterpret_cast<const float4 *>(&bds[4 * c4]);
-                // two-wide vectors so the taps become v_pk_fma_f32 (2 FMAs per instruction)
-                f32x2 acc[XB][2];
-#pragma unroll
-                for (int x = 0; x < XB; x++) { acc[x][0] = (f32x2){bd4.x, bd4.y}; acc[x][1] = (f32x2){bd4.z, bd4.w}; }
-#pragma unroll
-                for (int dy = 0; dy < KS; dy++) {
-                    float4 e[NCOL];
-#pragma unroll
-                    for (int j = 0; j < NCOL; j++) e[j] = *reinterpret_cast<const float4 *>(eb + (dy * IW + j) * CES);
-#pragma unroll
-                    for (int dx = 0; dx < KS; dx++) {
-                        const float4 w = *reinterpret_cast<const float4 *>(&WdC[(dy * KS + dx) * CE + 4 * c4]);
-                        const f32x2 w0 = (f32x2){w.x, w.y}, w1 = (f32x2){w.z, w.w};
-#pragma unroll
-                        for (int x = 0; x < XB; x++) {
-                            const float4 ev = e[x * ST + dx];
-                            acc[x][0] = __builtin_elementwise_fma((f32x2){ev.x, ev.y}, w0, acc[x][0]);
-                            acc[x][1] = __builtin_elementwise_fma((f32x2){ev.z, ev.w}, w1, acc[x][1]);
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);  // keep one kernel row of loads in flight, not all KS
-                }
-#pragma unroll
-                for (int x = 0; x < XB; x++) {
-                    f32x2 g0 = acc[x][0], g1 = acc[x][1];
-                    bh_act4<ACT>(g0, g1);
-                    const float4 v = make_float4(g0[0], g0[1], g1[0], g1[1]);
-                    const int prow = p2_prow + x;
-                    if constexpr (PREC != 0) {   // the project GEMM's A operand: f16 hi (+ lo) planes
-                        if (PREC == 3) {
-                            bh_f16x2 h0, l0, h1, l1;
-                            bh_split2(v.x, v.y, h0, l0);
-                            bh_split2(v.z, v.w, h1, l1);
-                            *reinterpret_cast<f16x4 *>(&DsH[prow * DSH + 4 * c4]) = (f16x4){h0[0], h0[1], h1[0], h1[1]};
-                            *reinterpret_cast<f16x4 *>(&DsL[prow * DSH + 4 * c4]) = (f16x4){l0[0], l0[1], l1[0], l1[1]};
-                        } else {
-                            f16x4 h;
-                            h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
-                            *reinterpret_cast<f16x4 *>(&DsH[prow * DSH + 4 * c4]) = h;
-                        }
-                    } else {
-                        *reinterpret_cast<float4 *>(&Ds[prow * CES + 4 * c4]) = v;
-                    }
-                }
-            }
-        }
-        mb_stamp(d.stamps, t_last, 4);
-        if (!PERSIST) mb_dma_wait();    // ring: the next chunk's weights, on their way since the previous B2
-        __syncthreads();  // B2: Ds complete; (ring == 0) WeS (next chunk) and WpS (this chunk) landed; Wds free
-        if (PERSIST) {
-        } else if (!ring) {
-            if (!(d.dbg & 16)) {
-                if constexpr (COLTH > 0) mb_dma_at<WD_FLOATS, NW>(d.Wd + (size_t)chn * WD_FLOATS, wd_ba, wave, lane);
-                else mb_dma<WD_FLOATS, NW>(d.Wd + (size_t)chn * WD_FLOATS, Wds, wave, lane);
-            }
-        } else if (ch + 2 < nchunks && !(d.dbg & 16)) {
-            // chunk ch + 2 into the buffers chunk ch has just finished with (We, Wd: read before this barrier) and into the Wp
-            // buffer of chunk ch - 1 (its project phase ended before B1 of this chunk)
-            mb_dma<WE_FLOATS, NW>(d.We + (size_t)(ch + 2) * WE_FLOATS, WeS + (ch & 1) * WE_FLOATS, wave, lane);
-            mb_dma<WD_FLOATS, NW>(d.Wd + (size_t)(ch + 2) * WD_FLOATS, Wds + (ch & 1) * WD_FLOATS, wave, lane);
-            mb_dma<WP_FLOATS, NW>(d.Wp + (size_t)(ch + 2) * WP_FLOATS, WpS + ((ch + 2) % 3) * WP_FLOATS, wave, lane);
-        }
-        mb_stamp(d.stamps, t_last, 5);
-
-        // ---- P3: project -----------------------------------------------------------------
-        if (!(d.dbg & 4)) {
-            if constexpr (P16) {
-                // fragment planes: [column tile]{hi: 64 lanes x 4 halves, lo: same}; k = 4 (lane >> 4) + 0..3
-                const f16x4 *wf = reinterpret_cast<const f16x4 *>(WpC);
-                f16x4 a_h[MT_W], a_l[MT_W], b_h[NT_W], b_l[NT_W];
-#pragma unroll
-                for (int i = 0; i < MT_W; i++) {
-                    const int row = (wm * MT_W + i) * 16 + li;
-                    a_h[i] = *reinterpret_cast<const f16x4 *>(&DsH[row * DSH + 4 * kq]);
-                    if (PREC == 3) a_l[i] = *reinterpret_cast<const f16x4 *>(&DsL[row * DSH + 4 * kq]);
-                }
-#pragma unroll
-                for (int j = 0; j < NT_W; j++) {
-                    b_h[j] = wf[((wn * NT_W + j) * 2 + 0) * 64 + lane];
-                    if (PREC == 3) b_l[j] = wf[((wn * NT_W + j) * 2 + 1) * 64 + lane];
-                }
-#pragma unroll
-                for (int i = 0; i < MT_W; i++)
-#pragma unroll
-                    for (int j = 0; j < NT_W; j++) {
-                        acco[i][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(a_h[i], b_h[j], acco[i][j], 0, 0, 0);
-                        if (PREC == 3) {
-                            acco[i][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(a_h[i], b_l[j], acco[i][j], 0, 0, 0);
-                            acco[i][j] = __builtin_amdgcn_mfma_f32_16x16x16f16(a_l[i], b_h[j], acco[i][j], 0, 0, 0);
-                        }
-                    }
-            } else if constexpr (PREC != 0) {
-                const f16x8 *wf = reinterpret_cast<const f16x8 *>(WpC);
-                // the weight fragments of a step are taken JB column tiles at a time: all NT_W (up to 10 hi +
-                // 10 lo quads) at once cost 80 registers and spilled the 320-channel blocks
-                constexpr int JB = NT_W <= (NW == 8 ? 4 : 6) ? NT_W : (NT_W + 1) / 2;   // (8 waves: 256 registers each)
-#pragma unroll
-                for (int g = 0; g < PSTEPS; g++) {
-                    f16x8 a_h[MT_W], a_l[MT_W];
-#pragma unroll
-                    for (int i = 0; i < MT_W; i++) {
-                        const int row = (wm * MT_W + i) * 16 + li;
-                        a_h[i] = *reinterpret_cast<const f16x8 *>(&DsH[row * DSH + 32 * g + 8 * kq]);
-                        if (PREC == 3) a_l[i] = *reinterpret_cast<const f16x8 *>(&DsL[row * DSH + 32 * g + 8 * kq]);
-                    }
-#pragma unroll
-                    for (int j0 = 0; j0 < NT_W; j0 += JB) {
-                        f16x8 b_h[JB], b_l[JB];
-#pragma unroll
-                        for (int jj = 0; jj < JB; jj++) {
-                            if (j0 + jj >= NT_W) continue;
-                            b_h[jj] = wf[((g * NTOP + wn * NT_W + j0 + jj) * 2 + 0) * 64 + lane];
-                            if (PREC == 3) b_l[jj] = wf[((g * NTOP + wn * NT_W + j0 + jj) * 2 + 1) * 64 + lane];
-                        }
-#pragma unroll
-                        for (int i = 0; i < MT_W; i++)
-#pragma unroll
-                            for (int jj = 0; jj < JB; jj++) {
-                                if (j0 + jj >= NT_W) continue;
-                                const int j = j0 + jj < NT_W ? j0 + jj : 0;
-                                acco[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[i], b_h[jj], acco[i][j], 0, 0, 0);
-                                if (PREC == 3) {
-                                    acco[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_h[i], b_l[jj], acco[i][j], 0, 0, 0);
-                                    acco[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_l[i], b_h[jj], acco[i][j], 0, 0, 0);
-                                }
-                            }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
-            } else {
-            const float *dsb = Ds + ((wm * MT_W) * 16 + li) * CES + 4 * kq;
-            float4 a[MT_W], b[NT_W], an[MT_W], bn[NT_W];
-#pragma unroll
-            for (int j = 0; j < NT_W; j++) b[j] = *reinterpret_cast<const float4 *>(&WpC[((wn * NT_W + j) * 64 + lane) * 4]);
-#pragma unroll
-            for (int i = 0; i < MT_W; i++) a[i] = *reinterpret_cast<const float4 *>(dsb + i * 16 * CES);
-#pragma unroll
-            for (int g = 0; g < NT_E; g++) {
-                if (g + 1 < NT_E) {
-#pragma unroll
-                    for (int j = 0; j < NT_W; j++)
-                        bn[j] = *reinterpret_cast<const float4 *>(&WpC[(((g + 1) * NTOP + wn * NT_W + j) * 64 + lane) * 4]);
-#pragma unroll
-                    for (int i = 0; i < MT_W; i++) an[i] = *reinterpret_cast<const float4 *>(dsb + i * 16 * CES + 16 * (g + 1));
-                }
-#pragma unroll
-                for (int c = 0; c < 4; c++)
-#pragma unroll
-                    for (int i = 0; i < MT_W; i++) {
-                        const float av = c == 0 ? a[i].x : c == 1 ? a[i].y : c == 2 ? a[i].z : a[i].w;
-#pragma unroll
-                        for (int j = 0; j < NT_W; j++) {
-                            const float bv = c == 0 ? b[j].x : c == 1 ? b[j].y : c == 2 ? b[j].z : b[j].w;
-                            acco[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acco[i][j], 0, 0, 0);
-                        }
-                    }
-                if (g + 1 < NT_E) {
-#pragma unroll
-                    for (int j = 0; j < NT_W; j++) b[j] = bn[j];
-#pragma unroll
-                    for (int i = 0; i < MT_W; i++) a[i] = an[i];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            }  // PREC == 0
-        }
-        mb_stamp(d.stamps, t_last, 6);
-        // no barrier here: the next chunk's P1 touches Es / WeS (landed before B2) only; its P2
-        // (which rewrites Ds) sits behind B1, which also drains the Wd DMA issued above.
-    }
-
-    // ---- epilogue: store (bias and residual are already in the accumulators) -------------------
-#pragma unroll
-    for (int i = 0; i < MT_W; i++) {
-        const int4 o4 = *reinterpret_cast<const int4 *>(&omap[(wm * MT_W + i) * 16 + 4 * kq]);
-        const int orow[4] = {o4.x, o4.y, o4.z, o4.w};
-#pragma unroll
-        for (int j = 0; j < NT_W; j++) {
-            const int col = (wn * NT_W + j) * 16 + li;
-            if (col >= Cout) continue;
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-                if (orow[r] >= 0 && !(d.dbg & 32)) Yb[(size_t)orow[r] * Cout + col] = PREC != 0 ? acco[i][j][r] * p_unscale : acco[i][j][r];
-        }
-    }
-    mb_stamp(d.stamps, t_last, 7);
-    if constexpr (PERSIST != 0) __syncthreads();   // the epilogue has read omap; the next tile's set-up rewrites it
-    }   // tiles
-    if (d.stamps && lane0 == 0)
-        for (int i = 0; i < 8; i++) atomicAdd(&d.stamps[i], t_last.acc[i]);
-}
-
-struct MbCfg {
-    int KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC, PERSIST, ACT, COLTH;
-    void (*launch)(const MbDesc &, int, hipStream_t);
-};
-
-template <int KS, int ST, int CE, int KG, int RT_W, int NCS, int WM, int WN, int MT_W, int NT_W, int TWL, int XBL,
-          int SS, int OCC, int STEM, int PREC, int PERSIST, int ACT, int COLTH = 0>
-void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
-    auto kern = mbconv_kernel<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, SS, OCC, STEM, PREC, PERSIST, ACT, COLTH>;
-    static DeviceOnce attr_set;
-    attr_set.run([&] { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-    dim3 grid(d.tiles_x, d.tiles_y, (n_seg + d.S - 1) / d.S), block(64 * WM * WN);
-    if (PERSIST) {   // as many workgroups as are resident at once: registers allow OCC per SIMD, LDS 160 KB per CU
-        const long total = (long)d.tiles_x * d.tiles_y * ((n_seg + d.S - 1) / d.S);
-        const long per_cu = std::max<long>(1, std::min<long>(OCC, (160 * 1024) / (long)(d.lds_bytes + 256)));
-        grid = dim3((unsigned)std::min<long>(total, per_cu * device_cu_count()));
-    }
-    hipLaunchKernelGGL(kern, grid, block, d.lds_bytes, s, d, n_seg);
-}
-
-// (MB_A: the activation the table is being expanded for, see kCfgs below)
-#define MB_ENTRY_P(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, PREC) \
-    {KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC, 0, MB_A, 0,     \
-     mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC, STEM, PREC, 0, MB_A>}
-// column-task depthwise phase (COLTH = TH = the image height), split-f16 and plain-f16 twins
-#define MB_ENTRY_PC(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, PREC) \
-    {KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC, 0, MB_A, TH,    \
-     mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC, STEM, PREC, 0, MB_A, TH>}
-#define MB_ENTRY_HC(KS, ST, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM)            \
-    MB_ENTRY_PC(KS, ST, 32, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, 3),         \
-    MB_ENTRY_PC(KS, ST, 32, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, 1)
-// persistent workgroups, every chunk's weights resident in LDS (the early blocks)
-#define MB_ENTRY_PP(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, PREC) \
-    {KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC, 1, MB_A, 0,      \
-     mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC, STEM, PREC, 1, MB_A>}
-#define MB_ENTRY_S(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM) \
-    MB_ENTRY_P(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, 0)
-#define MB_ENTRY(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC) \
-    MB_ENTRY_S(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, 0)
-// split-f16 (PREC 3) and plain-f16 (PREC 1) twins of one tile configuration; KG counts 32-deep steps
-#define MB_ENTRY_H(KS, ST, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM)             \
-    MB_ENTRY_P(KS, ST, 32, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, 3),          \
-    MB_ENTRY_P(KS, ST, 32, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, 1)
 
 // The list (mbconv_cfgs.inc: 115 tile configurations, indices as documented there) is instantiated once per activation:
 // entry ci + k * kNBase is configuration ci with the k-th activation of kActs.
 constexpr int kActs[] = {ACT_GELU_ERF, ACT_SWISH, ACT_RELU6};
-const MbCfg kCfgs[] = {
-#define MB_A ACT_GELU_ERF
-#include "mbconv_cfgs.inc"
-#undef MB_A
-#define MB_A ACT_SWISH
-#include "mbconv_cfgs.inc"
-#undef MB_A
-#define MB_A ACT_RELU6
-#include "mbconv_cfgs.inc"
-#undef MB_A
+constexpr int kNActs = (int)(sizeof(kActs) / sizeof(kActs[0]));
+struct CfgTables {
+    const MbCfg *t[kNActs];
+    int n_base;
+    CfgTables() {
+        int n[kNActs];
+        t[0] = mb_table_gelu(&n[0]); t[1] = mb_table_swish(&n[1]); t[2] = mb_table_relu6(&n[2]);
+        n_base = (n[0] == n[1] && n[1] == n[2]) ? n[0] : 0;   // the three copies are the same list
+    }
+    const MbCfg &operator[](int ci) const { return t[ci / n_base][ci % n_base]; }
 };
-constexpr int kNCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
-constexpr int kNActs = (int)(sizeof(kActs) / sizeof(kActs[0])), kNBase = kNCfgs / kNActs;
-static_assert(kNBase * kNActs == kNCfgs, "one copy of the list per activation");
+const CfgTables &cfg_tables() { static const CfgTables T; return T; }
+#define kCfgs cfg_tables()
+#define kNBase (cfg_tables().n_base)
+#define kNCfgs (kNBase * kNActs)
 
 // fills the derived fields for entry `ci` with tile height `th`; returns the estimated MFMA work
 // per segment (in 16x16x4 steps), or -1 when the entry cannot run this block at that height

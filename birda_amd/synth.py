@@ -115,10 +115,10 @@ class _Builder:
         L = mf.Layer(mf.OP_GAP, mf.ACT_NONE, tin, mf.NO_TENSOR, c, c, h, w, 1, 1, 0, 0, h, w, 1, 1)
         return self.add(L)
 
-    def dense(self, tin, cin, cout, gain=1.0):
+    def dense(self, tin, cin, cout, gain=1.0, act=mf.ACT_NONE, logits=True):
         wt = self.he((cin, cout), cin) * np.float32(gain)
-        b = (self.rng.standard_normal(cout) * 0.5 - 2.0).astype(np.float32)
-        L = mf.Layer(mf.OP_DENSE, mf.ACT_NONE, tin, mf.NO_TENSOR, cin, cout, 1, 1, 1, 1, 0, 0, 1, 1, 1, 1,
+        b = (self.rng.standard_normal(cout) * 0.5 - 2.0).astype(np.float32) if logits else self.bias(cout)
+        L = mf.Layer(mf.OP_DENSE, act, tin, mf.NO_TENSOR, cin, cout, 1, 1, 1, 1, 0, 0, 1, 1, 1, 1,
                      0, self.put(wt), self.put(b))
         return self.add(L)
 
@@ -126,6 +126,9 @@ class _Builder:
 # EfficientNet-B0 stage table: (expand, kernel, stride, cout, repeats)
 _B0_STAGES = [(1, 3, 1, 16, 1), (6, 3, 2, 24, 2), (6, 5, 2, 40, 2), (6, 3, 2, 80, 3),
               (6, 5, 1, 112, 3), (6, 5, 2, 192, 4), (6, 3, 1, 320, 1)]
+# EfficientNet-B3 (width x1.2, depth x1.4 of B0; Tan & Le 2019, table 1 scaled as the published B3 checkpoints): Perch v2's backbone
+_B3_STAGES = [(1, 3, 1, 24, 2), (6, 3, 2, 32, 3), (6, 5, 2, 48, 3), (6, 3, 2, 96, 5),
+              (6, 5, 1, 136, 5), (6, 5, 2, 232, 6), (6, 3, 1, 384, 2)]
 # a two-stage toy stack for CPU-speed tests (same op mix: conv, dw s1/s2 k3/k5, pw, residual)
 _TINY_STAGES = [(1, 3, 1, 8, 1), (4, 5, 2, 16, 2), (4, 3, 2, 24, 1)]
 
@@ -137,12 +140,15 @@ def build_model(kind: str = "birdnet_v24", seed: int = WEIGHT_SEED,
     'mini_b0' (short segments + the full EfficientNet-B0 channel plan),
     'mini_hg' (toy stack ending in 32 channels + a 128-wide head: fused head conv + pool on a small arena),
     'mini_se' (toy stack with swish activations and a squeeze-excite gate in every block: the EfficientNet original),
-    'perch_v2' (5 s / 32 kHz, Perch-shaped: one 128-mel branch, 14 795 classes).
+    'perch_v2' (5 s / 32 kHz, Perch-SIZED: one 128-mel branch, EfficientNet-B3 stage plan with swish, 1 536-d embedding,
+    a 6 144-wide hidden layer in front of the 14 795 classes -- 109 M parameters = 437 MB, 2.67 GFLOP per segment = 3.5x the
+    v2.4-shaped model's conv stack; the published file is 413 MB and runs 4.4x slower than v2.4 on the reference's CPU, see below),
+    'perch_v2_tiny' (the same front-end and head on the B0 stage plan with GELU: 89 MB, 1.0 GFLOP; rounds 1-2's "perch_v2").
     act: the activation between the convolutions (default: exact GELU, the north star's; mf.ACT_SWISH / ACT_RELU6 give the
     EfficientNet / MobileNet spellings of the same stack)."""
     rng = np.random.default_rng(seed)
     b = _Builder(rng)
-    act_override, act = act, mf.ACT_GELU_ERF
+    act_override, act, hidden = act, mf.ACT_GELU_ERF, 0
     if kind in ("birdnet_v24", "birdnet_v24_tiny"):
         sr, n, dur = 48000, 144000, 3.0
         branches = [mf.Branch(2048, 278, 96, 511, 0.0, 3000.0, 1.23),
@@ -160,11 +166,19 @@ def build_model(kind: str = "birdnet_v24", seed: int = WEIGHT_SEED,
             stages, stem, head = _B0_STAGES, 32, 256
         if kind == "mini_hg":  # toy stack whose last stage has 32 channels and a 128-wide head: the head conv + pool run as
             stages, head = [(1, 3, 1, 8, 1), (4, 5, 2, 16, 2), (4, 3, 2, 32, 1)], 128   # one launch in the f16 modes
-    elif kind == "perch_v2":
+    elif kind in ("perch_v2", "perch_v2_tiny"):
         # Perch v2: 5 s @ 32 kHz, 14 795 classes, softmax (manifests/Perch-v2-*).
         sr, n, dur = 32000, 160000, 5.0
         branches = [mf.Branch(1024, 320, 128, (n - 1024) // 320 + 1, 60.0, 16000.0, 1.23)]
         stages, stem, head, ncls, family, out_act = _B0_STAGES, 32, 1280, 14795, 1, mf.OUT_SOFTMAX
+        if kind == "perch_v2":
+            # Sized after the reference's own figures for the published model: manifests/Perch-v2-Models.models.json size_bytes
+            # 413 350 933 (fp32: ~103 M parameters) and README 42 against 183 segments/s for v2.4 on one CPU (4.4x the work).
+            # [EXT] The paper names EfficientNet-B3 (12 M parameters); what the other ~90 M are cannot be read offline (a
+            # 4-prototype head of 14 795 x 4 x 1 536 would be 91 M) -- stated here as ONE hidden layer of 6 144 units, which
+            # puts both the byte count (437 MB) and the work (2.67 GFLOP = 3.5x) in the published model's neighbourhood.
+            stages, stem, head, hidden = _B3_STAGES, 40, 1536, 6144
+            act = mf.ACT_SWISH      # EfficientNet's activation
     else:
         raise ValueError(kind)
     if n_classes is not None:
@@ -203,7 +217,11 @@ def build_model(kind: str = "birdnet_v24", seed: int = WEIGHT_SEED,
     t = b.pwconv(t, h, w_, c, head, act)
     t = b.gap(t, h, w_, head)
     emb_t = t
-    t = b.dense(t, head, ncls, gain=1.5)
+    if hidden:
+        t = b.dense(t, head, hidden, act=act, logits=False)
+        t = b.dense(t, hidden, ncls, gain=1.5)
+    else:
+        t = b.dense(t, head, ncls, gain=1.5)
     blob = np.concatenate(b.chunks) if b.chunks else np.zeros(0, np.float32)
     m = mf.Model(family, sr, n, dur, ncls, head, out_act, emb_t, branches[0].n_mels,
                  branches[0].n_frames, 1e-6, branches, b.layers, blob)

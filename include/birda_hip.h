@@ -262,6 +262,12 @@ BH_API int bh_batch_context_layer_ms(bh_batch_context *ctx, float *ms, uint32_t 
  * bh_predict_batch* entry points. */
 BH_API int bh_classifier_fused_blocks(const bh_classifier *c, int32_t *cfgs, size_t cap);
 
+/* The same plan for a model FILE, without a device (host logic only: which expand -> depthwise -> project triples fuse and the tile
+ * configuration the planner picks for each under precision `flags`).  Returns the number of fused blocks (or a negative
+ * bh_status); cfgs / layers (nullable) receive configuration index and first layer of each.  Used by the CPU test that holds the
+ * set of shipped tile configurations to what the planner can reach, and by tools/plan_models.py. */
+BH_API int bh_plan_fused_blocks(const char *model_path, uint32_t flags, int32_t *cfgs, int32_t *layers, size_t cap);
+
 /* Name of the front-end (STFT x mel) kernel instantiation this classifier launches, as a profiler prints it
  * (e.g. "bh::mel_kernel<6, 3>"): lets the bench match its HIP-event timings and the committed PMC counters to the exact
  * kernel.  Returns the string length. */

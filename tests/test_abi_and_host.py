@@ -6,6 +6,7 @@ import json
 import os
 import re
 import struct
+import sys
 import time
 
 import numpy as np
@@ -322,6 +323,42 @@ def test_shipped_hot_kernels_fit_their_register_budget():
         assert threads == 512 and vgpr + agpr <= 256 and scratch <= 48, (args, k(args))
     vgpr, agpr, scratch, threads = res["mel_kernel<6,3>"]
     assert scratch == 0 and vgpr + agpr <= 256
+
+
+def test_shipped_tile_configurations_are_the_reachable_ones():
+    """the product library ships what the planner can reach, nothing else.  tools/plan_models.py walks every
+    synthetic model (BirdNET-v2.4-shaped, Perch-sized, Perch-shaped, the small test stacks) in the three precisions and the three
+    templated activations through bh_plan_fused_blocks (host logic, no GPU); every MB_ENTRY row of mbconv_cfgs.inc must be picked
+    somewhere, and the rejected experiments (MB_XENTRY rows, kernels_mbwave.hip, the persistent variants) must not be in the
+    build."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import plan_models
+    from birda_amd import _lib, modelfile as mf
+    lib = _lib.load()
+    buf = C.create_string_buffer(128)
+    n_total = 0
+    while lib.bh_mb_config_name(n_total, buf, 128) > 0:
+        n_total += 1
+    assert n_total % 3 == 0
+    n_base = n_total // 3
+    shipped = set()
+    for ci in range(n_total):
+        lib.bh_mb_config_name(ci, buf, 128)
+        args = [int(v) for v in buf.value.decode().split(",")]
+        if args[0] != 0:
+            shipped.add(ci)
+            assert args[16] == 0, f"configuration {ci}: a persistent-workgroup instantiation in the product build"
+    reach, by_model = plan_models.survey(acts=(None, mf.ACT_SWISH, mf.ACT_RELU6))
+    assert reach <= shipped
+    unreached = sorted({c % n_base for c in shipped} - {c % n_base for c in reach})
+    assert not unreached, f"shipped but never picked by the planner: {unreached}"
+    # the headline models fuse every block they can in the f16 modes
+    assert len(by_model["birdnet_v24/default/f16x3"]["fused"]) == 16 and not by_model["birdnet_v24/default/f16x3"]["unfused_triples"]
+    assert len(by_model["perch_v2/default/f16x3"]["fused"]) == 25 and len(by_model["perch_v2/default/f16"]["fused"]) == 25
+    assert not os.path.exists(os.path.join(ROOT, "birda_amd", "csrc", "kernels_mbwave.hip"))
+    so = os.path.getsize(os.path.join(ROOT, "birda_amd", "libbirda_hip.so"))
+    assert so < 9 * 2 ** 20, f"libbirda_hip.so grew to {so / 2 ** 20:.1f} MiB"
 
 
 # ---------------- range filter tables (host logic, include/birda_host.h) ----------------

@@ -23,7 +23,7 @@ def _device_facts_ok(st, n_dev):
     assert st.device_count == n_dev >= 1 and 0 <= st.device < n_dev
     assert st.arch.startswith(b"gfx950"), st.arch                      # gcnArchName, e.g. gfx950:sramecc+:xnack-
     assert st.compute_units == 256
-    assert 250e9 < st.hbm_bytes < 300e9                                # 288 GB of HBM3E, a little of it reserved
+    assert 280e9 < st.hbm_bytes <= 288 * 2 ** 30                        # 288 GiB of HBM3E (309.2e9 bytes), less whatever is reserved
     assert len(st.device_name) > 0
 
 
