@@ -141,6 +141,7 @@ extern "C" {
     pub fn bh_batch_context_stage_ms(ctx: *mut BhBatchContext, ms: *mut f32, launches: *mut u32) -> c_int;
     pub fn bh_batch_context_layer_ms(ctx: *mut BhBatchContext, ms: *mut f32, launches: *mut u32, n_layers: usize) -> c_int;
     pub fn bh_classifier_fused_blocks(c: *const BhClassifier, cfgs: *mut i32, cap: usize) -> c_int;
+    pub fn bh_plan_fused_blocks(model_path: *const c_char, flags: u32, cfgs: *mut i32, layers: *mut i32, cap: usize) -> c_int;
     pub fn bh_classifier_frontend_kernel(c: *const BhClassifier, out: *mut c_char, cap: usize) -> c_int;
     pub fn bh_mb_config_name(cfg: i32, out: *mut c_char, cap: usize) -> c_int;
     pub fn bh_debug_mb_stamps(c: *mut BhClassifier, out: *mut u64, cap: usize) -> c_int;
