@@ -503,6 +503,24 @@ unsigned copy_threads() {
     return n;
 }
 
+// Sub-slices of a host-fed slice: each is computed as soon as its own samples are on the copy stream.  A forward has a floor of
+// about a millisecond however few segments it holds (21 launches whose workgroups walk their chunk loops serially) and the late
+// blocks need >= 128 segments to fill the GPU, so FEW sub-slices of GROWING size beat four equal ones: a small first one starts
+// the compute stream early, and the last -- more than half of the slice -- runs at the full-batch rate while nothing is left to
+// upload.  With upload 5.2 us and forward 0.85 ms + 6.3 us per PCM16 segment the model gives 9.6 ms per 1 000 for (1/8, 1/3, rest)
+// against 11.0 for four quarters (measured: DESIGN.md section 6).  Boundaries are multiples of `align` segments.
+std::vector<size_t> sub_slice_cuts(size_t nb, size_t align, bool single) {
+    std::vector<size_t> cuts;
+    if (!single && nb >= 512) {
+        auto up = [&](size_t v) { return std::min(nb, (v + align - 1) / align * align); };
+        const size_t c1 = up(std::max<size_t>(128, nb / 8)), c2 = up(std::max<size_t>(c1 + 128, nb * 9 / 20));
+        if (c1 < nb) cuts.push_back(c1);
+        if (c2 < nb && c2 > c1) cuts.push_back(c2);
+    }
+    cuts.push_back(nb);
+    return cuts;
+}
+
 // host slices -> results through ctx.
 // A slice of up to max_batch segments is pipelined three ways: worker threads gather 32-segment chunks into
 // pinned memory; each chunk's H2D copy is enqueued on the copy stream as soon as it is complete; and the
@@ -530,12 +548,10 @@ int predict_slices(bh_classifier *c, bh_batch_context *ctx, const float *const *
         const size_t nb = std::min(ctx->max_batch, n - b0);
         constexpr size_t CH = 32;
         const size_t nchunks = (nb + CH - 1) / CH;
-        // sub-slices: a quarter of the slice, in whole chunks, never below 128 segments (the late blocks
-        // need that many to fill the GPU); debug contexts keep one (bh_debug_read_tensor reads the last)
-        size_t sub = nb;
+        // sub-slices (sub_slice_cuts above), in whole chunks; debug contexts keep one (bh_debug_read_tensor reads the last)
         // (whole_slice: the caller reads an arena tensor of the slice afterwards -- the embeddings of the two-stage path)
-        if (nb >= 512 && !ctx->keep_tensors && !emb_out && !whole_slice) sub = std::max<size_t>(128, ((nb + 3) / 4 + CH - 1) / CH * CH);
-        const size_t nsub = (nb + sub - 1) / sub;
+        const std::vector<size_t> cuts = sub_slice_cuts(nb, CH, ctx->keep_tensors || emb_out || whole_slice);
+        const size_t nsub = cuts.size();
         while (ctx->copy_ev.size() < nsub) {
             hipEvent_t e;
             HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -559,6 +575,7 @@ int predict_slices(bh_classifier *c, bh_batch_context *ctx, const float *const *
                     for (size_t j; (j = next.fetch_add(1)) < nchunks;) { gather(j); done[j].store(1, std::memory_order_release); }
                 });
         int rc = BH_OK;
+        size_t si_next = 0;
         for (size_t j = 0; j < nchunks && rc == BH_OK; j++) {
             if (nthreads > 1) while (!done[j].load(std::memory_order_acquire)) std::this_thread::yield();
             else if (!pinned_src) gather(j);
@@ -566,8 +583,8 @@ int predict_slices(bh_classifier *c, bh_batch_context *ctx, const float *const *
             const float *h_src = pinned_src ? contig + (b0 + i0) * S : ctx->h_input + i0 * S;
             if (hipMemcpyAsync(ctx->d_input + i0 * S, h_src, (i1 - i0) * S * sizeof(float), hipMemcpyHostToDevice,
                                ctx->copy_stream) != hipSuccess) { rc = fail(BH_ERR_HIP, "H2D copy failed"); break; }
-            if (i1 % sub == 0 || i1 == nb) {   // a sub-slice is complete on the copy stream: compute it
-                const size_t si = (i1 - 1) / sub, s0 = si * sub, ns = i1 - s0;
+            if (i1 == cuts[si_next]) {   // a sub-slice is complete on the copy stream: compute it
+                const size_t si = si_next++, s0 = si ? cuts[si - 1] : 0, ns = i1 - s0;
                 if (hipEventRecord(ctx->copy_ev[si], ctx->copy_stream) != hipSuccess ||
                     hipStreamWaitEvent(ctx->stream, ctx->copy_ev[si], 0) != hipSuccess) { rc = fail(BH_ERR_HIP, "stream event failed"); break; }
                 rc = forward_slice(c, ctx, ctx->d_input + s0 * S, ns, ctx->d_logits + s0 * NC, ctx->d_topk_idx + s0 * TK,
@@ -1683,9 +1700,8 @@ static int predict_pcm16_core(bh_classifier *c, bh_batch_context *ctx, const voi
         char *stage = reinterpret_cast<char *>(ctx->h_input);
         const size_t PIECE = (size_t)8 << 20;
         const size_t npieces = (staged || pcm_pinned) ? (bytes + PIECE - 1) / PIECE : 1;
-        size_t sub = nb;
-        if (nb >= 512) sub = std::max<size_t>(128, (nb + 3) / 4);
-        const size_t nsub = (nb + sub - 1) / sub;
+        const std::vector<size_t> cuts = sub_slice_cuts(nb, 1, false);
+        const size_t nsub = cuts.size();
         while (ctx->copy_ev.size() < nsub) {
             hipEvent_t e;
             HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -1725,7 +1741,7 @@ static int predict_pcm16_core(bh_classifier *c, bh_batch_context *ctx, const voi
             }
             const size_t frames_sent = f0 + sent / frame_bytes;
             while (si < nsub && rc == BH_OK) {
-                const size_t s0 = si * sub, ns = std::min(sub, nb - s0);
+                const size_t s0 = si ? cuts[si - 1] : 0, ns = cuts[si] - s0;
                 const size_t need = std::min<size_t>(n_frames, starts[b0 + s0 + ns - 1] + seg);
                 if (need > frames_sent && sent < bytes) break;   // its last frames are not on their way yet
                 if (hipEventRecord(ctx->copy_ev[si], ctx->copy_stream) != hipSuccess ||

@@ -166,8 +166,38 @@ static void fft_rec(const cpx *in, cpx *out, int n, int stride, const cpx *tw, i
     }
 }
 
+/* The same transform for n = 2^s without the recursion: bit-reversed load, then the s butterfly levels bottom-up.  Every output
+ * is computed by exactly the operations fft_rec performs for p = 2 -- out[k] = a + b * W_n^{k step}, out[k + m] = a + b *
+ * W_n^{(k + m) step}, both twiddles READ FROM THE TABLE (not negated), products and sums in the same order -- so the results are
+ * bit-identical to the recursive form (the factor W^0 = (1, 0) of the first operand reproduces it exactly); it only drops the
+ * call overhead and the per-element modulo, which were most of the front-end's time (0.24 s of 0.41 s per segment). */
+static void fft_pow2(const cpx *in, cpx *out, int n, const cpx *tw) {
+    int s = 0;
+    while ((1 << s) < n) s++;
+    for (int i = 0; i < n; i++) {
+        int r = 0;
+        for (int b = 0; b < s; b++) r |= ((i >> b) & 1) << (s - 1 - b);
+        out[r] = in[i];
+    }
+    for (int len = 2; len <= n; len <<= 1) {            /* sub-transform length at this level */
+        const int m = len >> 1, step = n / len;         /* fft_rec: n = len, tw_step = step */
+        for (int base = 0; base < n; base += len)
+            for (int k = 0; k < m; k++) {
+                const cpx a = out[base + k], b = out[base + k + m];
+                const cpx w0 = tw[(size_t)k * step], w1 = tw[(size_t)(k + m) * step];
+                cpx lo, hi;
+                lo.re = a.re + (b.re * w0.re - b.im * w0.im);
+                lo.im = a.im + (b.re * w0.im + b.im * w0.re);
+                hi.re = a.re + (b.re * w1.re - b.im * w1.im);
+                hi.im = a.im + (b.re * w1.im + b.im * w1.re);
+                out[base + k] = lo; out[base + k + m] = hi;
+            }
+    }
+}
+
 /* sign = -1 forward, +1 inverse (unscaled) */
 static void fft_any(const cpx *in, cpx *out, int n, int sign) {
+    if (n >= 2 && (n & (n - 1)) == 0) { fft_pow2(in, out, n, twiddles(n, sign)); return; }
     cpx *tmp = malloc(sizeof(cpx) * (size_t)(n > 2 ? n : 2));
     fft_rec(in, out, n, 1, twiddles(n, sign), 1, tmp);
     free(tmp);
@@ -209,15 +239,22 @@ BO_API void bo_frontend(const bo_model *m, const float *seg, float *spec) {
         float *win = malloc(sizeof(float) * L);
         for (int i = 0; i < L; i++) win[i] = (float)(0.5 - 0.5 * cos(2.0 * M_PI * i / L));
         cpx *fin = malloc(sizeof(cpx) * L), *fout = malloc(sizeof(cpx) * L);
-        float *re = malloc(sizeof(float) * nb);
+        float *re = malloc(sizeof(float) * nb), *macc = malloc(sizeof(float) * nm);
         float *out = spec + (size_t)b * nm * nf;
         for (int t = 0; t < nf; t++) {
             for (int i = 0; i < L; i++) { fin[i].re = (double)(x[(size_t)t * H + i] * win[i]); fin[i].im = 0; }
             fft_any(fin, fout, L, -1);
             for (int k = 0; k < nb; k++) re[k] = (float)fout[k].re;
+            /* spec = Re(stft) . mel_W: every mel bin's sum runs over k ascending, as a dense MatMul does; the loops are ordered k
+             * outer / j inner so that the rows of W are read contiguously (the sums themselves are unchanged) */
+            for (int j = 0; j < nm; j++) macc[j] = 0.0f;
+            for (int k = 0; k < nb; k++) {
+                const float rk = re[k];
+                const float *wr = W + (size_t)k * nm;
+                for (int j = 0; j < nm; j++) macc[j] += rk * wr[j];
+            }
             for (int j = 0; j < nm; j++) {
-                float acc = 0.0f;
-                for (int k = 0; k < nb; k++) acc += re[k] * W[(size_t)k * nm + j];
+                float acc = macc[j];
                 float p = acc * acc;
                 float v = powf(p, expo);
                 v = v * br->out_scale + br->out_shift;
@@ -225,7 +262,7 @@ BO_API void bo_frontend(const bo_model *m, const float *seg, float *spec) {
                 out[(size_t)row * nf + t] = v;
             }
         }
-        free(win); free(fin); free(fout); free(re);
+        free(win); free(fin); free(fout); free(re); free(macc);
     }
     free(x);
 }
@@ -292,16 +329,46 @@ static void layer_dwconv(const bhm_layer *L, const float *W, const float *B, con
         }
 }
 
-__attribute__((target_clones("avx2", "default")))
+/* 1x1 convolution / dense layer, out[r][n] = B[n] + sum_k in[r][k] W[k][n] with the sum over k ASCENDING and a separate
+ * multiply and add per term (-ffp-contract=off) -- the order the first, row-at-a-time version of this function used and the
+ * parity tests were pinned on.  This version computes 4 rows x 32 columns at a time in registers: W is read once per four rows
+ * instead of once per row and the output row is no longer re-loaded for every k.  Per output element the operations and their
+ * order are unchanged, so the results are bit-identical; it is what lets the `cpu_baseline` leg of bench.py run within a small
+ * factor of an optimised CPU runtime instead of 27x below it. */
+#define PW_RB 4
+#define PW_NB 32
+__attribute__((target_clones("avx512f", "avx2", "default")))
 static void layer_pw(int rows, int ci, int co, const float *W, const float *B, const float *in, float *out) {
-    for (int r = 0; r < rows; r++) {
-        float *o = out + (size_t)r * co;
-        const float *a = in + (size_t)r * ci;
-        for (int n = 0; n < co; n++) o[n] = B[n];
-        for (int k = 0; k < ci; k++) {
-            const float av = a[k];
-            const float *w = W + (size_t)k * co;
-            for (int n = 0; n < co; n++) o[n] += av * w[n];
+    for (int n0 = 0; n0 < co; n0 += PW_NB) {
+        const int nn = co - n0 < PW_NB ? co - n0 : PW_NB;
+        int r0 = 0;
+        if (nn == PW_NB) {
+            for (; r0 + PW_RB <= rows; r0 += PW_RB) {
+                float acc[PW_RB][PW_NB];
+                for (int r = 0; r < PW_RB; r++)
+                    for (int j = 0; j < PW_NB; j++) acc[r][j] = B[n0 + j];
+                const float *a0 = in + (size_t)r0 * ci;
+                for (int k = 0; k < ci; k++) {
+                    const float *w = W + (size_t)k * co + n0;
+                    for (int r = 0; r < PW_RB; r++) {
+                        const float av = a0[(size_t)r * ci + k];
+                        for (int j = 0; j < PW_NB; j++) acc[r][j] += av * w[j];
+                    }
+                }
+                for (int r = 0; r < PW_RB; r++)
+                    for (int j = 0; j < PW_NB; j++) out[(size_t)(r0 + r) * co + n0 + j] = acc[r][j];
+            }
+        }
+        for (; r0 < rows; r0++) {      /* remaining rows, and every row of a ragged last column block */
+            float acc[PW_NB];
+            for (int j = 0; j < nn; j++) acc[j] = B[n0 + j];
+            const float *a = in + (size_t)r0 * ci;
+            for (int k = 0; k < ci; k++) {
+                const float av = a[k];
+                const float *w = W + (size_t)k * co + n0;
+                for (int j = 0; j < nn; j++) acc[j] += av * w[j];
+            }
+            for (int j = 0; j < nn; j++) out[(size_t)r0 * co + n0 + j] = acc[j];
         }
     }
 }
@@ -359,16 +426,21 @@ BO_API int bo_forward(const bo_model *m, const float *segs, int n, float *logits
                       int dump_tensor, float *dump) {
     const uint32_t nt = m->h.n_layers + 1;
     int rc = 0;
-#pragma omp parallel for schedule(dynamic, 1)
-    for (int s = 0; s < n; s++) {
+    /* every thread keeps ONE set of tensor buffers for all the segments it takes: allocating the ~50 tensors (21 MB) afresh per
+     * segment meant an mmap / page-fault / munmap round per tensor and segment, which 256 host threads serialised on */
+#pragma omp parallel
+    {
         float **t = malloc(sizeof(float *) * nt);
         for (uint32_t i = 0; i < nt; i++) t[i] = malloc(sizeof(float) * (m->tensor_floats[i] ? m->tensor_floats[i] : 1));
-        forward_one(m, segs + (size_t)s * m->h.sample_count, t);
-        memcpy(logits + (size_t)s * m->h.n_classes, t[nt - 1], sizeof(float) * m->h.n_classes);
-        if (embeddings)
-            memcpy(embeddings + (size_t)s * m->h.embedding_dim, t[m->h.embedding_tensor], sizeof(float) * m->h.embedding_dim);
-        if (dump && dump_tensor >= 0 && (uint32_t)dump_tensor < nt)
-            memcpy(dump + (size_t)s * m->tensor_floats[dump_tensor], t[dump_tensor], sizeof(float) * m->tensor_floats[dump_tensor]);
+#pragma omp for schedule(dynamic, 1)
+        for (int s = 0; s < n; s++) {
+            forward_one(m, segs + (size_t)s * m->h.sample_count, t);
+            memcpy(logits + (size_t)s * m->h.n_classes, t[nt - 1], sizeof(float) * m->h.n_classes);
+            if (embeddings)
+                memcpy(embeddings + (size_t)s * m->h.embedding_dim, t[m->h.embedding_tensor], sizeof(float) * m->h.embedding_dim);
+            if (dump && dump_tensor >= 0 && (uint32_t)dump_tensor < nt)
+                memcpy(dump + (size_t)s * m->tensor_floats[dump_tensor], t[dump_tensor], sizeof(float) * m->tensor_floats[dump_tensor]);
+        }
         for (uint32_t i = 0; i < nt; i++) free(t[i]);
         free(t);
     }

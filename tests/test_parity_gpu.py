@@ -1149,7 +1149,7 @@ def test_one_overflowing_recording_does_not_fail_its_pack(model_dir, tmp_path):
     from birda_amd.classifier import BirdClassifier
     _, labels, m, _ = model_dir["mini_b0"]
     S, rate = m.sample_count, m.sample_rate
-    good = [synth.synth_segments(3, S, rate, start=40 * k).reshape(-1) for k in range(4)]
+    pool = [synth.synth_segments(3, S, rate, start=40 * k).reshape(-1) for k in range(10)]   # candidates for the healthy files
     t = np.arange(3 * S) / rate
     candidates = {"tone %d Hz" % f: (0.99 * np.sin(2 * np.pi * f * t)).astype(np.float32) for f in (700, 1500, 2500, 5000, 9000)}
     candidates["click"] = np.where(np.arange(3 * S) % 997 == 0, 0.99, -0.99).astype(np.float32)
@@ -1169,11 +1169,12 @@ def test_one_overflowing_recording_does_not_fail_its_pack(model_dir, tmp_path):
             except BirdaHipError as err:
                 assert err.code == -8
                 return True
-        g = [overflows(x) for x in good]
+        g = [overflows(x) for x in pool]
         b = {name: overflows(x) for name, x in candidates.items()}
         tried.append((e, g, b))
         ctx.close()
-        if not any(g) and any(b.values()):
+        if g.count(False) >= 4 and any(b.values()):     # four recordings that stay inside the f16 range, one that leaves it
+            good = [x for x, over in zip(pool, g) if not over][:4]
             found = (clf, next(name for name, v in b.items() if v))
             break
         clf.close()
