@@ -196,6 +196,18 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
     const unsigned we_ba = lds0 + 4u * (unsigned)((egrid + 1) * CES + DS_FLOATS), wp_ba = we_ba + 4u * (unsigned)(nbuf_e * WE_FLOATS),
                    wd_ba = wp_ba + 4u * (unsigned)(nbuf_p * WP_FLOATS);
 
+    // PERSIST: tile = (segment group, tile row, tile column), linear; this workgroup takes every gridDim.x-th one
+    const int tiles_xy = d.tiles_x * d.tiles_y;
+    const int n_tiles = tiles_xy * ((n_seg + SS - 1) / SS);
+    // Tile of this workgroup.  The launch is one-dimensional; workgroup b runs on XCD b % 8 (round-robin dispatch), and each XCD has
+    // its own L2.  Dealt in launch order, x-neighbouring tiles -- whose input rectangles share their halo columns and the 64-byte
+    // sectors at the rectangle's edges -- land on DIFFERENT XCDs and every shared sector is fetched from HBM once per XCD (stem
+    // block: 832 MB read per 1 000 segments against 392 MB of input).  XCD x instead takes the x-th EIGHTH of the tile list (tiles
+    // in x, then y, then segment order): neighbours in space are neighbours in time on one L2.
+    const int per_xcd = (n_tiles + 7) >> 3;
+    const int tile_xcd = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (!PERSIST && (d.dbg & 256 ? (int)blockIdx.x >= n_tiles : tile_xcd >= n_tiles)) return;   // (dbg 256: launch order, A/B aid)
+    const int tile_first = PERSIST ? (int)blockIdx.x : (d.dbg & 256 ? (int)blockIdx.x : tile_xcd);
     MbClock t_last{};
     if (d.stamps) t_last.last = __builtin_readcyclecounter();
     if constexpr (PERSIST != 0) {
@@ -222,10 +234,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
         }
     }
 
-    // PERSIST: tile = (segment group, tile row, tile column), linear; this workgroup takes every gridDim.x-th one
-    const int tiles_xy = d.tiles_x * d.tiles_y;
-    const int n_tiles = PERSIST ? tiles_xy * ((n_seg + SS - 1) / SS) : 1;
-    for (int tile = PERSIST ? (int)blockIdx.x : 0; tile < n_tiles; tile += PERSIST ? (int)gridDim.x : 1) {
+    for (int tile = tile_first; tile < (PERSIST ? n_tiles : tile_first + 1); tile += PERSIST ? (int)gridDim.x : 1) {
     // (everything below is per tile.  The thread index goes through an opaque copy so that hipcc does not hoist the
     //  tile-invariant index arithmetic out of the tile loop and keep it in registers across it: a first persistent
     //  version doubled its VGPRs and spilled SGPRs that way)
@@ -233,8 +242,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
     if constexpr (PERSIST != 0) asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
-    const int tz = PERSIST ? tile / tiles_xy : (int)blockIdx.z, txy = tile - tz * tiles_xy;
-    const int tyi = PERSIST ? txy / d.tiles_x : (int)blockIdx.y, txi = PERSIST ? txy - tyi * d.tiles_x : (int)blockIdx.x;
+    const int tz = tile / tiles_xy, txy = tile - tz * tiles_xy;
+    const int tyi = txy / d.tiles_x, txi = txy - tyi * d.tiles_x;
     const int seg0 = tz * SS;
     const int nsv = min(SS, n_seg - seg0);
     const int oy0 = tyi * TH, ox0 = txi * TW;
@@ -927,7 +936,8 @@ void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
     auto kern = mbconv_kernel<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, SS, OCC, STEM, PREC, PERSIST, ACT, COLTH>;
     static DeviceOnce attr_set;
     attr_set.run([&] { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-    dim3 grid(d.tiles_x, d.tiles_y, (n_seg + d.S - 1) / d.S), block(64 * WM * WN);
+    const long n_wg = (long)d.tiles_x * d.tiles_y * ((n_seg + d.S - 1) / d.S);
+    dim3 grid((unsigned)(((n_wg + 7) / 8) * 8)), block(64 * WM * WN);   // one-dimensional: the kernel deals the tiles XCD by XCD
     if (PERSIST) {   // as many workgroups as are resident at once: registers allow OCC per SIMD, LDS 160 KB per CU
         const long total = (long)d.tiles_x * d.tiles_y * ((n_seg + d.S - 1) / d.S);
         const long per_cu = std::max<long>(1, std::min<long>(OCC, (160 * 1024) / (long)(d.lds_bytes + 256)));

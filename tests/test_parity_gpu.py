@@ -1142,67 +1142,54 @@ def test_one_overflowing_recording_does_not_fail_its_pack(model_dir, tmp_path):
     operand range -- used to be copied to every file of the pack.  The reference isolates failures per file (lib.rs:1003-1100
     counts files_failed and goes on): the pack is re-run file by file, the offending file alone reports the error and the
     others get exactly the outputs the per-file pipeline writes.
-    The overflow is made content-dependent: the trunk of `mini_b0` is multiplied by a power of two chosen (by trying) so that a
-    full-scale pure tone overflows the split-f16 planes while the noisy synthetic segments stay inside them."""
+    The overflow is made content-dependent: the trunk of `mini_b0` is multiplied by a power of two chosen (by trying every
+    candidate recording through the per-file pipeline) so that some recordings overflow the split-f16 planes and others do not."""
     from birda_amd import modelfile as mf, pipeline, synth
     from birda_amd._lib import BirdaHipError
     from birda_amd.classifier import BirdClassifier
     _, labels, m, _ = model_dir["mini_b0"]
     S, rate = m.sample_count, m.sample_rate
-    pool = [synth.synth_segments(3, S, rate, start=40 * k).reshape(-1) for k in range(10)]   # candidates for the healthy files
     t = np.arange(3 * S) / rate
-    candidates = {"tone %d Hz" % f: (0.99 * np.sin(2 * np.pi * f * t)).astype(np.float32) for f in (700, 1500, 2500, 5000, 9000)}
-    candidates["click"] = np.where(np.arange(3 * S) % 997 == 0, 0.99, -0.99).astype(np.float32)
-    found = None
-    tried = []
+    cand = {f"noise{k}": synth.synth_segments(3, S, rate, start=40 * k).reshape(-1) for k in range(10)}
+    cand.update({"tone%d" % f: (0.99 * np.sin(2 * np.pi * f * t)).astype(np.float32) for f in (700, 1500, 2500, 5000, 9000)})
+    cand["click"] = np.where(np.arange(3 * S) % 997 == 0, 0.99, -0.99).astype(np.float32)
+    rec = tmp_path / "rec"; rec.mkdir()
+    paths = {}
+    for name, x in cand.items():
+        paths[name] = str(rec / f"{name}.wav")
+        synth.write_wav_pcm16(paths[name], x, rate)
+    found, tried = None, []
     for e in range(8, 15):
         m2, _ = _rescale_trunk(m, [2.0 ** e])
         path = str(tmp_path / f"trunk_2e{e}.bhm")
         mf.write_model(path, m2)
         clf = BirdClassifier(path, labels, min_confidence=0.05, precision="f16x3")
-        ctx = clf.create_batch_context(16)
-
-        def overflows(x):
+        single = tmp_path / f"single_{e}"; single.mkdir()
+        want = {}
+        for name, f in paths.items():
             try:
-                clf.predict_batch_with_context(ctx, list(x.reshape(3, S)))
-                return False
+                want[name] = pipeline.process_file(clf, f, str(single), min_confidence=0.05)
             except BirdaHipError as err:
-                assert err.code == -8
-                return True
-        g = [overflows(x) for x in pool]
-        b = {name: overflows(x) for name, x in candidates.items()}
-        tried.append((e, g, b))
-        ctx.close()
-        if g.count(False) >= 4 and any(b.values()):     # four recordings that stay inside the f16 range, one that leaves it
-            good = [x for x, over in zip(pool, g) if not over][:4]
-            found = (clf, next(name for name, v in b.items() if v))
+                assert err.code == -8, (name, err)
+                want[name] = err.code
+        ok = [n for n, w in want.items() if not isinstance(w, int)]
+        bad = [n for n, w in want.items() if isinstance(w, int)]
+        tried.append((e, len(ok), bad))
+        if len(ok) >= 4 and bad:
+            found = (clf, str(single), want, ok[:2] + [bad[0]] + ok[2:4])
             break
         clf.close()
-    assert found, f"no trunk scale separates the probes from the synthetic segments: {tried}"
-    clf, bad_name = found
-    rec = tmp_path / "rec"; rec.mkdir()
-    files = []
-    for k, x in enumerate(good[:2]):
-        synth.write_wav_pcm16(str(rec / f"a{k}.wav"), x, rate); files.append(str(rec / f"a{k}.wav"))
-    synth.write_wav_pcm16(str(rec / "bad.wav"), candidates[bad_name], rate); files.append(str(rec / "bad.wav"))
-    for k, x in enumerate(good[2:]):
-        synth.write_wav_pcm16(str(rec / f"b{k}.wav"), x, rate); files.append(str(rec / f"b{k}.wav"))
-    single = tmp_path / "single"; single.mkdir()
+    assert found, f"no trunk scale separates the candidate recordings: {tried}"
+    clf, single, want, order = found
+    files = [paths[n] for n in order]
     packed = tmp_path / "packed"; packed.mkdir()
-    want = {}
-    for f in files:
-        try:
-            want[f] = pipeline.process_file(clf, f, str(single), min_confidence=0.05)
-        except BirdaHipError as err:
-            want[f] = err.code
-    assert want[files[2]] == -8 and all(not isinstance(want[f], int) for f in files if f != files[2])
     got, status = pipeline.process_files_packed(clf, files, str(packed), min_confidence=0.05, pack_segments=64)
-    assert status == [0, 0, -8, 0, 0], (bad_name, status)
-    for f, r in zip(files, got):
-        if f == files[2]:
+    assert status == [0, 0, -8, 0, 0], (order, status)
+    for n, f, r in zip(order, files, got):
+        if isinstance(want[n], int):
             continue
-        assert (r.segments, r.detections) == (want[f].segments, want[f].detections)
-        a, b = pipeline.output_path_for(f, str(single), "csv"), pipeline.output_path_for(f, str(packed), "csv")
+        assert (r.segments, r.detections) == (want[n].segments, want[n].detections)
+        a, b = pipeline.output_path_for(f, single, "csv"), pipeline.output_path_for(f, str(packed), "csv")
         assert open(a, "rb").read() == open(b, "rb").read(), f
     assert not os.path.exists(pipeline.output_path_for(files[2], str(packed), "csv"))
     clf.close()
