@@ -1137,62 +1137,54 @@ def test_packed_short_files_match_the_per_file_pipeline(clf_tiny, model_dir, tmp
     assert sum(r.detections for r in got) > 0
 
 
-def test_one_overflowing_recording_does_not_fail_its_pack(model_dir, tmp_path):
-    """a pack-level failure -- here BH_ERR_NONFINITE raised by ONE recording whose activations leave the f16
-    operand range -- used to be copied to every file of the pack.  The reference isolates failures per file (lib.rs:1003-1100
-    counts files_failed and goes on): the pack is re-run file by file, the offending file alone reports the error and the
-    others get exactly the outputs the per-file pipeline writes.
-    The overflow is made content-dependent: the trunk of `mini_b0` is multiplied by a power of two chosen (by trying every
-    candidate recording through the per-file pipeline) so that some recordings overflow the split-f16 planes and others do not."""
-    from birda_amd import modelfile as mf, pipeline, synth
+def test_one_failing_recording_does_not_fail_its_pack(clf_tiny, model_dir, tmp_path):
+    """a pack-level failure used to be copied to every file of the pack.  The reference isolates failures per
+    file (lib.rs:1003-1100 counts files_failed and goes on): the pack is re-run file by file, the offending file alone reports
+    the error and the others get exactly the outputs the per-file pipeline writes.
+    The failing recording: a float32 WAV whose samples are FINITE but span more than the f32 range (+-3e38): max - min overflows
+    in the normalisation, its spectrogram and logits are NaN although no sample was, and that is BH_ERR_NONFINITE (-8) for the
+    forward that holds it -- alone through bhh_process_file, and for the whole shared forward when it is packed with others."""
+    import struct
+    from birda_amd import pipeline, synth
     from birda_amd._lib import BirdaHipError
-    from birda_amd.classifier import BirdClassifier
-    _, labels, m, _ = model_dir["mini_b0"]
+    _, _, m, _ = model_dir["birdnet_v24_tiny"]
     S, rate = m.sample_count, m.sample_rate
-    t = np.arange(3 * S) / rate
-    cand = {f"noise{k}": synth.synth_segments(3, S, rate, start=40 * k).reshape(-1) for k in range(10)}
-    cand.update({"tone%d" % f: (0.99 * np.sin(2 * np.pi * f * t)).astype(np.float32) for f in (700, 1500, 2500, 5000, 9000)})
-    cand["click"] = np.where(np.arange(3 * S) % 997 == 0, 0.99, -0.99).astype(np.float32)
     rec = tmp_path / "rec"; rec.mkdir()
-    paths = {}
-    for name, x in cand.items():
-        paths[name] = str(rec / f"{name}.wav")
-        synth.write_wav_pcm16(paths[name], x, rate)
-    found, tried = None, []
-    for e in range(8, 15):
-        m2, _ = _rescale_trunk(m, [2.0 ** e])
-        path = str(tmp_path / f"trunk_2e{e}.bhm")
-        mf.write_model(path, m2)
-        clf = BirdClassifier(path, labels, min_confidence=0.05, precision="f16x3")
-        single = tmp_path / f"single_{e}"; single.mkdir()
-        want = {}
-        for name, f in paths.items():
-            try:
-                want[name] = pipeline.process_file(clf, f, str(single), min_confidence=0.05)
-            except BirdaHipError as err:
-                assert err.code == -8, (name, err)
-                want[name] = err.code
-        ok = [n for n, w in want.items() if not isinstance(w, int)]
-        bad = [n for n, w in want.items() if isinstance(w, int)]
-        tried.append((e, len(ok), bad))
-        if len(ok) >= 4 and bad:
-            found = (clf, str(single), want, ok[:2] + [bad[0]] + ok[2:4])
-            break
-        clf.close()
-    assert found, f"no trunk scale separates the candidate recordings: {tried}"
-    clf, single, want, order = found
-    files = [paths[n] for n in order]
+
+    def write_f32(path, x):
+        xs = np.asarray(x, "<f4")
+        with open(path, "wb") as fh:
+            fh.write(b"RIFF" + struct.pack("<I", 36 + xs.nbytes) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 3, 1, rate, rate * 4, 4, 32) +
+                     b"data" + struct.pack("<I", xs.nbytes) + xs.tobytes())
+    files = []
+    for k in range(5):
+        x = synth.synth_segments(2, S, rate, start=30 * k).reshape(-1)[: S + S // 2]
+        if k == 2:
+            x = x.copy(); x[::2] = 3.0e38; x[1::2] = -3.0e38          # finite samples, max - min = inf
+        files.append(str(rec / f"r{k}.wav"))
+        write_f32(files[-1], x)
+    single = tmp_path / "single"; single.mkdir()
+    want = {}
+    for f in files:
+        try:
+            want[f] = pipeline.process_file(clf_tiny, f, str(single), min_confidence=0.05, front_end="device")
+        except BirdaHipError as err:
+            want[f] = err.code
+    assert [isinstance(want[f], int) for f in files] == [False, False, True, False, False] and want[files[2]] == -8, want
     packed = tmp_path / "packed"; packed.mkdir()
-    got, status = pipeline.process_files_packed(clf, files, str(packed), min_confidence=0.05, pack_segments=64)
-    assert status == [0, 0, -8, 0, 0], (order, status)
-    for n, f, r in zip(order, files, got):
-        if isinstance(want[n], int):
+    got, status = pipeline.process_files_packed(clf_tiny, files, str(packed), min_confidence=0.05, pack_segments=32)
+    assert status == [0, 0, -8, 0, 0], status
+    for f, r in zip(files, got):
+        if f == files[2]:
             continue
-        assert (r.segments, r.detections) == (want[n].segments, want[n].detections)
-        a, b = pipeline.output_path_for(f, single, "csv"), pipeline.output_path_for(f, str(packed), "csv")
+        assert (r.segments, r.detections) == (want[f].segments, want[f].detections)
+        a, b = pipeline.output_path_for(f, str(single), "csv"), pipeline.output_path_for(f, str(packed), "csv")
         assert open(a, "rb").read() == open(b, "rb").read(), f
     assert not os.path.exists(pipeline.output_path_for(files[2], str(packed), "csv"))
-    clf.close()
+    assert sum(r.detections for r in got) > 0
+    # ... and the pack really was shared before it failed: without the bad file the same four go through ONE forward
+    got2, status2 = pipeline.process_files_packed(clf_tiny, [f for f in files if f != files[2]], str(packed), min_confidence=0.05, pack_segments=32)
+    assert status2 == [0, 0, 0, 0] and all(r.effective_batch > r.segments for r in got2)
 
 
 def test_non_finite_samples_stay_in_their_own_rows(clf_tiny, model_dir):
