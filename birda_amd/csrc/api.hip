@@ -1477,8 +1477,7 @@ int bh_classifier_frontend_kernel(const bh_classifier *c, char *out, size_t cap)
     if (!c) return 0;
     char buf[64];
     const int nmp = c->fe.br[0].nm_pad;
-    if (bh::melr_supports(c->fe)) snprintf(buf, sizeof buf, "bh::melr_kernel");
-    else if (c->fe.prec == 32) snprintf(buf, sizeof buf, "bh::mel32_kernel<%d>", nmp / 32);
+    if (c->fe.prec == 32) snprintf(buf, sizeof buf, "bh::mel32_kernel<%d>", nmp / 32);
     else snprintf(buf, sizeof buf, "bh::mel_kernel<%d, %d>", nmp / 16, c->fe.prec);
     const int n = (int)strlen(buf);
     if (out && cap > (size_t)n) memcpy(out, buf, (size_t)n + 1);

@@ -287,9 +287,7 @@ void launch_segment_pcm(const void *d_pcm_origin, int sample_format, size_t n_fr
 void launch_minmax(const float *x, float *minmax, unsigned *in_bad, int n_seg, int sample_count, hipStream_t s);
 void launch_mel(const float *x, const float *minmax, float *spec, const FrontendParams &p,
                 const FrontendParams *d_p, int n_seg, hipStream_t s);
-// the operator-stationary front-end kernel (kernels_melr.hip): BirdNET-v2.4-shaped front-ends in the split-f16 mode
-bool melr_supports(const FrontendParams &p);
-bool launch_melr(const float *x, const float *minmax, float *spec, const FrontendParams &p, const FrontendParams *d_p, int n_seg, hipStream_t s);
+
 
 struct ConvParams {
     int in_h, in_w, out_h, out_w, cin, cout, kh, kw, sh, sw, pad_t, pad_l, in_layout, act;

@@ -662,7 +662,6 @@ void launch_mel(const float *x, const float *minmax, float *spec, const Frontend
         max_frames = p.br[b].n_frames > max_frames ? p.br[b].n_frames : max_frames;
     }
     static const int dbg = getenv("BIRDA_HIP_MEL_DBG") ? atoi(getenv("BIRDA_HIP_MEL_DBG")) : 0;  // tuning ablations
-    if (p.prec == 3 && launch_melr(x, minmax, spec, p, d_p, n_seg, s)) return;   // operator-stationary kernel (kernels_melr.hip)
     if (p.prec == 32) {
         int span32 = 0;
         for (int b = 0; b < p.n_branches; b++) span32 = std::max(span32, (MEL32_TN - 1) * p.br[b].H + p.br[b].L);

@@ -1,3 +1,14 @@
+// EXPERIMENT, not part of the product build (round 3).  Measured on MI355X, 1 000 segments, f16x3: 1.04 us per segment against
+// mel_kernel's 0.68 -- parity-green (all front-end tests pass with it), but slower.  Why: with the operator out of the way the
+// bound moves to building the MFMA B fragments: 16 lanes of a fragment are 16 FRAMES, i.e. LDS reads at a stride of the hop.
+// An item needs 2 K 32 frames 4 B = 262 KB of such reads per 4 608 MFMA cycles = 57 B/clk/CU; ds_read_b32 delivers 64 B/clk/CU
+// conflict-free (hop 278) and 16 B/clk at the 4-way conflicts of hop 280 (280 = 24 mod 32: sixteen consecutive frames fall on four
+// banks whatever permutation of k the fragment uses), the folded pair x[tH + k + 1] + x[tH + L - 1 - k] has one odd start whatever
+// the grouping (no aligned ds_read_b64 / b128 for both), and with ONE wave per SIMD (512 registers for the operator) nothing
+// overlaps those reads with the MFMAs unless the loop is software-pipelined by hand.  The branch-1 workgroups (hop 280) are the
+// critical path: 8 192 LDS cycles against 2 304 MFMA cycles per item.  What would have to change: a skewed staging layout
+// (effective hop 282) written through registers instead of LDS-DMA, plus a hand-interleaved main loop.  DESIGN.md section 3.
+//
 // melr_kernel: the folded STFT x mel GEMM of the BirdNET front-end with the OPERATOR STATIONARY IN REGISTERS.
 //
 // (Same mathematics as kernels_frontend.hip: per segment and branch spec_t = Gf^T y_t, y_t[j] = x[tH + j + 1] + x[tH + L - 1 - j],
@@ -102,7 +113,7 @@ __device__ __forceinline__ void mr_item(const float *__restrict__ x, const float
                 for (int jj = 0; jj < 8; jj++) {
                     // (one v_add_f32, on purpose: the packed form with swapped halves is not safe beside in-flight f16 MFMAs,
                     //  kernels.hpp bh_add_unpacked)
-                    const float sum = bh_add_unpacked(xf[f * 16 * H + j0 + 4 * jj + 1], xf[f * 16 * H + L - 1 - j0 - 4 * jj]);
+                    const float sum = (dbg & 4) ? sc * (float)jj : bh_add_unpacked(xf[f * 16 * H + j0 + 4 * jj + 1], xf[f * 16 * H + L - 1 - j0 - 4 * jj]);
                     y[jj] = __builtin_fmaf(sum, sc, nb);
                 }
                 bh_split8(y, bhv[f], blv[f]);
@@ -112,6 +123,7 @@ __device__ __forceinline__ void mr_item(const float *__restrict__ x, const float
             for (int m = 0; m < MR_MT; m++)
 #pragma unroll
                 for (int f = 0; f < MR_NT; f++) {
+                    if (dbg & 8) { acc[f][m][0] += (float)bhv[f][0] + (float)blv[f][1]; continue; }
                     acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(oph[s][m], bhv[f], acc[f][m], 0, 0, 0);
                     acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(oph[s][m], blv[f], acc[f][m], 0, 0, 0);
                     acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(opl[s][m], bhv[f], acc[f][m], 0, 0, 0);
