@@ -20,7 +20,7 @@ per-file pipeline (`bhh_process_file`: WAV in, CSV out), which pay the host copy
 `cpu_baseline` is the oracle timed on this box's host cores over a bounded sample.
 
 Other workloads: --config c3 (10 000 segments as 8 shards through the C ABI's bh_multi_*; on a 1-GPU box the shards
-are logical devices on ordinal 0), c4 (Perch-shaped model, 5 s / 32 kHz), c5 (22.05 / 44.1 / 48 kHz round-robin ->
+are logical devices on ordinal 0), c4 (Perch-sized model, 5 s / 32 kHz), c5 (22.05 / 44.1 / 48 kHz round-robin ->
 device resampler -> v2.4-shaped model with f16 MFMA operands).
 """
 import argparse
@@ -399,7 +399,7 @@ def main():
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the f32, H2D-inclusive and end-to-end legs (profiling runs)")
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="BASELINE.json configs: c2 = configs[1] (the bench line), c3 = 10 000 segments as 8 shards through bh_multi_*, "
-                         "c4 = Perch-shaped model, c5 = mixed-rate input -> resampler -> f16 MFMA")
+                         "c4 = Perch-sized model, c5 = mixed-rate input -> resampler -> f16 MFMA")
     ap.add_argument("--precision", default=os.environ.get("BIRDA_HIP_BENCH_PRECISION", ""),
                     choices=["", "f32", "f16x3", "f16"],
                     help="GEMM operands: f16x3 = f32 values split into f16 hi + lo, three f16 MFMAs per product, "
@@ -586,11 +586,12 @@ def main():
         "c2": "configs[1]: 1000 synthetic 3 s/48 kHz segments per GPU per step, HBM-resident, seeded synthetic BirdNET-v2.4-shaped "
               "model (EfficientNet-B0-like, 6522 classes)",
         "c3": "configs[2]: 10 000 synthetic 3 s/48 kHz segments sharded over the ranks (contiguous blocks), HBM-resident, top-k gather to rank 0",
-        "c4": "configs[3]: 1000 synthetic 5 s/32 kHz segments per GPU per step, HBM-resident, seeded synthetic Perch-v2-shaped model "
-              "(one 128-mel branch, EfficientNet-B0-like, 14 795 classes, softmax)",
+        "c4": "configs[3]: 1000 synthetic 5 s/32 kHz segments per GPU per step, HBM-resident, seeded synthetic Perch-v2-SIZED model "
+              "(one 128-mel branch, EfficientNet-B3 stage plan with swish, 1536-d embedding, 6144-wide hidden layer, 14 795 classes, "
+              "softmax: 437 MB, 2.7 GFLOP per segment)",
         "c5": "configs[4]: 1000 segments per GPU per step synthesised at 22.05/44.1/48 kHz round-robin, HBM-resident at the SOURCE rate -> "
               "device polyphase resampler -> BirdNET-v2.4-shaped model with f16 MFMA operands"}
-    metric = {"c4": "5s/32kHz segments/sec (Perch-v2-shaped)"}.get(args.config, "3s/48kHz segments/sec (BirdNET v2.4)")
+    metric = {"c4": "5s/32kHz segments/sec (Perch-v2-sized)"}.get(args.config, "3s/48kHz segments/sec (BirdNET v2.4)")
     out = {
         "metric": metric, "value": round(value, 1), "unit": "segments/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -610,6 +611,20 @@ def main():
     }
     out.update(analyse(clf, m, info, fused, stage_tot, layer_tot, segs_done, args.steps, slices_per_step, args.precision))
     extra = rank == 0 and world == 1 and not args.no_extra_legs
+    if extra and args.config in ("c2", "c4"):
+        # what birda's own batch sizes reach (-b 1..512, constants.rs:44,55; bh_default_batch_size = 256): the same 1 000 resident
+        # segments through micro-batches of 256 and 512
+        for mb in (256, 512):
+            cx = clf.create_batch_context(mb)
+            for _ in range(2):
+                clf.forward_device(cx, x.data_ptr(), n_local, logits.data_ptr(), tk_idx.data_ptr(), tk_conf.data_ptr())
+            cx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                clf.forward_device(cx, x.data_ptr(), n_local, logits.data_ptr(), tk_idx.data_ptr(), tk_conf.data_ptr())
+            cx.synchronize()
+            out["value_at_batch_%d" % mb] = round(n_local * args.steps / (time.perf_counter() - t0), 1)
+            cx.close()
     if extra and args.config == "c2":
         out.update(h2d_inclusive=None)
         legs = host_legs(clf, m, model_path, args.precision, tmp)
