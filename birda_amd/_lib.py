@@ -156,13 +156,18 @@ class BhhRangeFilterInfo(C.Structure):
                 ("threshold", C.c_float)]
 
 
+class BhhBsgMetadata(C.Structure):
+    _fields_ = [("calibration_applied", C.c_int), ("sdm_applied", C.c_int), ("has_location", C.c_int), ("latitude", C.c_float),
+                ("longitude", C.c_float), ("has_day", C.c_int), ("day_of_year", C.c_uint32)]
+
+
 class BhhProcessingConfig(C.Structure):
     _fields_ = [("input_path", C.c_char_p), ("output_dir", C.c_char_p), ("display_path", C.c_char_p),
                 ("min_confidence", C.c_float), ("overlap", C.c_float), ("batch_size", C.c_size_t),
                 ("csv_bom", C.c_int), ("formats", C.c_uint32), ("front_end", C.c_uint32), ("csv_columns", C.c_char_p),
                 ("model_name", C.c_char_p), ("has_lat", C.c_int), ("has_lon", C.c_int), ("lat", C.c_double),
                 ("lon", C.c_double), ("week", C.c_int), ("reporter", C.c_void_p), ("dual_output", C.c_int),
-                ("custom_classifier", C.c_void_p)]
+                ("custom_classifier", C.c_void_p), ("bsg", C.POINTER(BhhBsgMetadata))]
 
 
 class BhhProcessResult(C.Structure):
@@ -208,6 +213,7 @@ HOST_SYMBOLS = [
     ("bhh_reporter_batch_progress", None, [_VP, _SZ, _SZ, C.c_float]),
     ("bhh_reporter_file_completed", None, [_VP, C.c_char_p, C.c_int, _SZ, C.c_uint64, C.c_char_p, C.c_char_p]),
     ("bhh_reporter_detections", None, [_VP, C.c_char_p, _VP, _VP, _VP, _VP, _SZ]),
+    ("bhh_reporter_detections_bsg", None, [_VP, C.c_char_p, _VP, _VP, _VP, _VP, _SZ, C.POINTER(BhhBsgMetadata)]),
     ("bhh_reporter_pipeline_completed", None, [_VP, _SZ, _SZ, _SZ, _SZ, _SZ, C.c_uint64, C.c_double]),
     ("bhh_reporter_error", None, [_VP, C.c_char_p, C.c_int, C.c_char_p, C.c_char_p]),
     ("bhh_is_audio_file", C.c_int, [C.c_char_p]),

@@ -42,6 +42,6 @@ int write_output(const std::string &input_path, const std::string &out_dir, uint
                  const WriterOptions &opt, std::string &out_path, std::string &err);
 int write_parquet_file(const std::string &path, const std::vector<Detection> &detections, const std::vector<std::string> &extra_columns,
                        std::string &err);
-void reporter_detections(bhh_reporter *r, const std::string &file, const std::vector<Detection> &dets);
+void reporter_detections(bhh_reporter *r, const std::string &file, const std::vector<Detection> &dets, const bhh_bsg_metadata *bsg);
 
 }  // namespace bhh

@@ -679,8 +679,17 @@ void bhh_reporter_file_completed(bhh_reporter *r, const char *file, int status, 
     r->r.emit("file_completed", p + "}");
 } catch (...) { (void)o_on_exception(); }
 
-void bhh_reporter_detections(bhh_reporter *r, const char *file, const char *const *labels, const float *confidence,
-                             const float *start_time, const float *end_time, size_t n) try {
+static std::string bsg_json(const bhh_bsg_metadata *b) {   // ,"bsg":{...} or nothing (skip_serializing_if = "Option::is_none")
+    if (!b) return "";
+    std::string p = std::string(",\"bsg\":{\"calibration_applied\":") + (b->calibration_applied ? "true" : "false") + ",\"sdm_applied\":" +
+                    (b->sdm_applied ? "true" : "false");
+    if (b->has_location) p += ",\"latitude\":" + json_f32(b->latitude) + ",\"longitude\":" + json_f32(b->longitude);
+    if (b->has_day) p += ",\"day_of_year\":" + std::to_string(b->day_of_year);
+    return p + "}";
+}
+
+void bhh_reporter_detections_bsg(bhh_reporter *r, const char *file, const char *const *labels, const float *confidence,
+                                 const float *start_time, const float *end_time, size_t n, const bhh_bsg_metadata *bsg) try {
     REPORTER_GUARD(r);
     std::string p = "{\"file\":" + json_string(file ? file : "") + ",\"detections\":[";
     for (size_t i = 0; i < n; i++) {   // DetectionInfo (json_envelope.rs:379-395; reporter.rs:404-418)
@@ -690,8 +699,13 @@ void bhh_reporter_detections(bhh_reporter *r, const char *file, const char *cons
              ",\"scientific_name\":" + json_string(d.scientific_name) + ",\"confidence\":" + json_f32(d.confidence) + ",\"start_time\":" +
              json_f32(d.start_time) + ",\"end_time\":" + json_f32(d.end_time) + "}";
     }
-    r->r.emit("detections", p + "]}");
+    r->r.emit("detections", p + "]" + bsg_json(bsg) + "}");
 } catch (...) { (void)o_on_exception(); }
+
+void bhh_reporter_detections(bhh_reporter *r, const char *file, const char *const *labels, const float *confidence,
+                             const float *start_time, const float *end_time, size_t n) {
+    bhh_reporter_detections_bsg(r, file, labels, confidence, start_time, end_time, n, nullptr);
+}
 
 void bhh_reporter_pipeline_completed(bhh_reporter *r, size_t files_processed, size_t files_failed, size_t files_skipped,
                                      size_t total_detections, size_t total_segments, uint64_t duration_ms, double realtime_factor) try {
@@ -716,7 +730,7 @@ void bhh_reporter_error(bhh_reporter *r, const char *code, int fatal, const char
 }  // extern "C"
 
 namespace bhh {
-void reporter_detections(bhh_reporter *r, const std::string &file, const std::vector<Detection> &dets) {
+void reporter_detections(bhh_reporter *r, const std::string &file, const std::vector<Detection> &dets, const bhh_bsg_metadata *bsg) {
     if (!r) return;
     std::lock_guard<std::mutex> lock_(r->r.mu);
     std::string p = "{\"file\":" + json_string(file) + ",\"detections\":[";
@@ -727,6 +741,6 @@ void reporter_detections(bhh_reporter *r, const std::string &file, const std::ve
              ",\"scientific_name\":" + json_string(d.scientific_name) + ",\"confidence\":" + json_f32(d.confidence) + ",\"start_time\":" +
              json_f32(d.start_time) + ",\"end_time\":" + json_f32(d.end_time) + "}";
     }
-    r->r.emit("detections", p + "]}");
+    r->r.emit("detections", p + "]" + bsg_json(bsg) + "}");
 }
 }  // namespace bhh

@@ -657,7 +657,7 @@ int finish_file(const bhh_processing_config *cfg, const FilePlan &pl, uint32_t f
             res->formats_written |= bit;
         }
     }
-    if (!cfg->dual_output && cfg->reporter) bhh::reporter_detections(cfg->reporter, pl.path, detections);   // :739-769
+    if (!cfg->dual_output && cfg->reporter) bhh::reporter_detections(cfg->reporter, pl.path, detections, cfg->bsg);   // :739-769
     lap("write");
 
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();

@@ -114,6 +114,14 @@ def project_scores(geomodel_labels: List[str], reported: List[Tuple[str, float]]
     return out[:n].copy(), MappingSummary(mapped.value, n, n - mapped.value, in_range.value)
 
 
+def bsg_metadata(latitude: Optional[float] = None, longitude: Optional[float] = None, day_of_year: Optional[int] = None):
+    """BsgMetadata as process_file builds it (processor.rs:741-768): calibration always applied; with a location the SDM is
+    applied only when the day of year is known too."""
+    loc = latitude is not None and longitude is not None
+    return _lib.BhhBsgMetadata(1, int(loc and day_of_year is not None), int(loc), float(latitude or 0.0), float(longitude or 0.0),
+                               int(loc and day_of_year is not None), int(day_of_year or 0))
+
+
 def format_mask(formats: Sequence[str]) -> int:
     """OutputFormat::from_str (config/types.rs:354-370) onto the BHH_FORMAT_* bits."""
     mask = 0
@@ -214,15 +222,17 @@ class ProgressReporter:
     def file_skipped(self, file, locked=False):
         self._L.bhh_reporter_file_completed(self._h, file.encode(), 3 if locked else 2, 0, 0, None, None)
 
-    def detections(self, file, dets):
-        """dets: (label, confidence, start_time, end_time) tuples."""
+    def detections(self, file, dets, bsg=None):
+        """dets: (label, confidence, start_time, end_time) tuples; bsg: bsg_metadata(...) for BSG models (BsgMetadata,
+        json_envelope.rs:362-378) or None."""
         n = len(dets)
         raw = [d[0].encode("utf-8") for d in dets]
         labels = (C.c_char_p * max(1, n))(*raw)
         conf = np.asarray([d[1] for d in dets] or [0.0], np.float32)
         st = np.asarray([d[2] for d in dets] or [0.0], np.float32)
         en = np.asarray([d[3] for d in dets] or [0.0], np.float32)
-        self._L.bhh_reporter_detections(self._h, file.encode(), labels, conf.ctypes.data, st.ctypes.data, en.ctypes.data, n)
+        self._L.bhh_reporter_detections_bsg(self._h, file.encode(), labels, conf.ctypes.data, st.ctypes.data, en.ctypes.data, n,
+                                            C.byref(bsg) if bsg is not None else None)
 
     def pipeline_completed(self, files_processed, files_failed, files_skipped, total_detections, total_segments,
                            duration_ms, realtime_factor):
@@ -265,7 +275,7 @@ def process_file(classifier, input_path: str, output_dir: Optional[str] = None, 
                  display_path: Optional[str] = None, formats: Sequence[str] = ("csv",), front_end: str = "auto",
                  csv_columns: Optional[Sequence[str]] = None, model_name: str = "", lat: Optional[float] = None,
                  lon: Optional[float] = None, week: Optional[int] = None, reporter: Optional[ProgressReporter] = None,
-                 dual_output: bool = False, custom_classifier=None) -> ProcessResult:
+                 dual_output: bool = False, custom_classifier=None, bsg=None) -> ProcessResult:
     """process_file (processor.rs:418-796).  batch_size 0 = the backend's default (determine_default_batch_size);
     front_end "host" keeps the reference's decode-thread + padded-batch structure, "device" / "auto" run decode
     scaling, mono mix, segmentation and resampling on the GPU for WAV input (PCM16 / PCM24 / PCM32 / float32).  custom_classifier: bat mode
@@ -278,7 +288,8 @@ def process_file(classifier, input_path: str, output_dir: Optional[str] = None, 
                               ",".join(csv_columns).encode() if csv_columns else None, model_name.encode(),
                               int(lat is not None), int(lon is not None), lat or 0.0, lon or 0.0,
                               -1 if week is None else week, reporter._h if reporter is not None else None,
-                              int(dual_output), custom_classifier._h if custom_classifier is not None else None)
+                              int(dual_output), custom_classifier._h if custom_classifier is not None else None,
+                              C.pointer(bsg) if bsg is not None else None)
     res = BhhProcessResult()
     _hcheck(L.bhh_process_file(classifier._h, C.byref(cfg), C.byref(res)))
     return ProcessResult(res.detections, res.segments, res.duration_secs, res.audio_duration_secs,
@@ -295,7 +306,7 @@ def process_files_packed(classifier, files: Sequence[str], output_dir: Optional[
     cfg = BhhProcessingConfig(None, output_dir.encode() if output_dir else None, None, min_confidence, overlap, 0,
                               int(csv_bom), format_mask(formats), _lib.FRONT_ENDS["auto"],
                               ",".join(csv_columns).encode() if csv_columns else None, model_name.encode(),
-                              0, 0, 0.0, 0.0, -1, None, 0, None)
+                              0, 0, 0.0, 0.0, -1, None, 0, None, None)
     n = len(files)
     raw = [f.encode() for f in files]
     arr = (C.c_char_p * max(1, n))(*raw)

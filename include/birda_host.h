@@ -121,6 +121,18 @@ BH_API void bhh_reporter_file_completed(bhh_reporter *r, const char *file, int s
                                         const char *error_code, const char *error_message);
 BH_API void bhh_reporter_detections(bhh_reporter *r, const char *file, const char *const *labels, const float *confidence,
                                     const float *start_time, const float *end_time, size_t n);
+/* BsgMetadata (output/json_envelope.rs:362-378), attached to the detections event whenever the classifier has a BSG processor
+ * (processor.rs:741-768): calibration is always applied; the SDM only when latitude / longitude AND a day of year are known.
+ * latitude / longitude / day_of_year are Option<>s: has_location / has_day = 0 leaves them out of the payload. */
+typedef struct {
+    int calibration_applied, sdm_applied;
+    int has_location;
+    float latitude, longitude;
+    int has_day;
+    uint32_t day_of_year;
+} bhh_bsg_metadata;
+BH_API void bhh_reporter_detections_bsg(bhh_reporter *r, const char *file, const char *const *labels, const float *confidence,
+                                        const float *start_time, const float *end_time, size_t n, const bhh_bsg_metadata *bsg /* NULL = None */);
 BH_API void bhh_reporter_pipeline_completed(bhh_reporter *r, size_t files_processed, size_t files_failed, size_t files_skipped,
                                             size_t total_detections, size_t total_segments, uint64_t duration_ms, double realtime_factor);
 BH_API void bhh_reporter_error(bhh_reporter *r, const char *code, int fatal, const char *message, const char *suggestion /* NULL = None */);
@@ -160,6 +172,9 @@ typedef struct {
      * overlapping by a quarter (:502-508, constants.rs:525-542), and the custom classifier's predictions on the backbone's
      * embeddings replace the backbone's (:319-360, :369-372).  Runs on the HOST front end. */
     bh_custom_classifier *custom_classifier;
+    /* BSG models (bh_classifier_set_bsg installed on the classifier): the metadata the stdout reporter attaches to its detections
+     * event (processor.rs:741-768); NULL = the classifier has no BSG processor */
+    const bhh_bsg_metadata *bsg;
 } bhh_processing_config;
 
 /* ProcessResult (processor.rs:877-886) + batching counters */

@@ -128,7 +128,8 @@ def test_ctypes_mirror_matches_the_header(header):
     mirrors = {"bh_config": _lib.BhConfig, "bh_model_info": _lib.BhModelInfo, "bh_result": _lib.BhResult,
                "bh_provider_status": _lib.BhProviderStatus, "bh_multi_config": _lib.BhMultiConfig,
                "bhh_writer_options": _lib.BhhWriterOptions, "bhh_range_filter_info": _lib.BhhRangeFilterInfo,
-               "bhh_processing_config": _lib.BhhProcessingConfig, "bhh_process_result": _lib.BhhProcessResult}
+               "bhh_processing_config": _lib.BhhProcessingConfig, "bhh_process_result": _lib.BhhProcessResult,
+               "bhh_bsg_metadata": _lib.BhhBsgMetadata}
     allst = {**structs, **hs}
     assert set(mirrors) == set(allst)
     for name, cls in mirrors.items():

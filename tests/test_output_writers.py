@@ -259,6 +259,20 @@ def test_reporter_reference_cases_and_event_shapes(cases, tmp_path):
     arr = json.loads(open(out2).read())
     assert [e["event"] for e in arr] == ["pipeline_started", "pipeline_completed"] and arr[1]["payload"]["status"] == "success"
     assert arr[0]["payload"]["range_filter"]["unmatched_policy"] == "keep" and arr[0]["payload"]["execution_provider"]["actual"] == "HIP"
+    # BSG models: the detections event carries BsgMetadata (json_envelope.rs:352-378; processor.rs:741-768), Option fields skipped
+    out3 = str(tmp_path / "bsg.ndjson")
+    r = pipeline.ProgressReporter("ndjson", out3)
+    det = [("Parus major_Great Tit", 0.5, 0.0, 3.0)]
+    r.detections("a.wav", det)                                                        # no BSG processor: no "bsg" key
+    r.detections("a.wav", det, pipeline.bsg_metadata())                               # calibration only
+    r.detections("a.wav", det, pipeline.bsg_metadata(60.25, 24.5))                    # location, no day: SDM not applied
+    r.detections("a.wav", det, pipeline.bsg_metadata(60.25, 24.5, 166))               # SDM applied
+    r.close()
+    pl = [json.loads(l)["payload"] for l in open(out3, encoding="utf-8").read().splitlines()]
+    assert "bsg" not in pl[0] and list(pl[1]) == ["file", "detections", "bsg"]
+    assert pl[1]["bsg"] == {"calibration_applied": True, "sdm_applied": False}
+    assert pl[2]["bsg"] == {"calibration_applied": True, "sdm_applied": False, "latitude": 60.25, "longitude": 24.5}
+    assert pl[3]["bsg"] == {"calibration_applied": True, "sdm_applied": True, "latitude": 60.25, "longitude": 24.5, "day_of_year": 166}
 
 
 def test_progress_throttler_reference_cases(cases, tmp_path):
