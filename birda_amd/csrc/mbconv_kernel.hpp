@@ -54,6 +54,7 @@ __device__ __forceinline__ int mb_div(int n, int d, float rcp_d) {
 struct MbClock {
     unsigned long long last, acc[8];
 };
+#ifdef BIRDA_HIP_EXPERIMENTS
 #define mb_stamp(stamps, clk, ph)                                          \
     do {                                                                   \
         if (stamps) {                                                      \
@@ -62,6 +63,11 @@ struct MbClock {
             clk.last = now_;                                               \
         }                                                                  \
     } while (0)
+#else
+// (product build: the phase clock is compiled out -- its eight 64-bit accumulators were live across the whole kernel and every
+//  phase boundary carried an s_memtime and a branch; make EXPERIMENTS=1 brings it back for tools/gpu_mb_stamps.py)
+#define mb_stamp(stamps, clk, ph) do { } while (0)
+#endif
 
 // Template parameters
 //   KS, ST      depthwise kernel size / stride          CE     expanded channels per chunk
@@ -208,8 +214,10 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
     const int tile_xcd = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
     if (!PERSIST && (d.dbg & 256 ? (int)blockIdx.x >= n_tiles : tile_xcd >= n_tiles)) return;   // (dbg 256: launch order, A/B aid)
     const int tile_first = PERSIST ? (int)blockIdx.x : (d.dbg & 256 ? (int)blockIdx.x : tile_xcd);
+#ifdef BIRDA_HIP_EXPERIMENTS
     MbClock t_last{};
     if (d.stamps) t_last.last = __builtin_readcyclecounter();
+#endif
     if constexpr (PERSIST != 0) {
         for (int c = 0; c < d.nchunks; c++) {   // every chunk's weights, once
             mb_dma<WE_FLOATS, NW>(d.We + (size_t)c * WE_FLOATS, WeS + c * WE_FLOATS, wave0, lane0);
@@ -926,8 +934,10 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
     mb_stamp(d.stamps, t_last, 7);
     if constexpr (PERSIST != 0) __syncthreads();   // the epilogue has read omap; the next tile's set-up rewrites it
     }   // tiles
+#ifdef BIRDA_HIP_EXPERIMENTS
     if (d.stamps && lane0 == 0)
         for (int i = 0; i < 8; i++) atomicAdd(&d.stamps[i], t_last.acc[i]);
+#endif
 }
 
 template <int KS, int ST, int CE, int KG, int RT_W, int NCS, int WM, int WN, int MT_W, int NT_W, int TWL, int XBL,
