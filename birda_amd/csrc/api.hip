@@ -505,17 +505,29 @@ unsigned copy_threads() {
 
 // Sub-slices of a host-fed slice: each is computed as soon as its own samples are on the copy stream.  A forward has a floor of
 // about a millisecond however few segments it holds (21 launches whose workgroups walk their chunk loops serially) and the late
-// blocks need >= 128 segments to fill the GPU, so FEW sub-slices of GROWING size beat four equal ones: a small first one starts
-// the compute stream early, and the last -- more than half of the slice -- runs at the full-batch rate while nothing is left to
-// upload.  With upload 5.2 us and forward 0.85 ms + 6.3 us per PCM16 segment the model gives 9.6 ms per 1 000 for (1/8, 1/3, rest)
-// against 11.0 for four quarters (measured: DESIGN.md section 6).  Boundaries are multiples of `align` segments.
-std::vector<size_t> sub_slice_cuts(size_t nb, size_t align, bool single) {
+// blocks need >= 128 segments to fill the GPU.  Which split is best depends on which side is the longer one (a small pipeline
+// model, upload 55 GB/s, forward 0.85 ms + t per segment; measured in DESIGN.md section 6):
+//   * the upload is SHORTER than the compute (PCM16 mono into the v2.4-shaped model: 5.2 against 6.3 us per segment; anything
+//     into the Perch-sized one): few sub-slices of GROWING size -- a small first one starts the compute stream early, the last,
+//     more than half of the slice, runs at the full-batch rate while nothing is left to upload: (1/8, 1/3, rest) = 9.5 ms per
+//     1 000 segments against 11.0 for four quarters;
+//   * the upload is LONGER (f32 segments: 10.5 us): the forward of the last sub-slice is all that is left after the last byte
+//     has arrived, so it must be small: equal quarters (12.9 ms against 14.8 for the growing split).
+// Boundaries are multiples of `align` segments.
+std::vector<size_t> sub_slice_cuts(const bh_classifier *c, size_t nb, size_t align, bool single, size_t bytes_per_segment) {
     std::vector<size_t> cuts;
     if (!single && nb >= 512) {
         auto up = [&](size_t v) { return std::min(nb, (v + align - 1) / align * align); };
-        const size_t c1 = up(std::max<size_t>(128, nb / 8)), c2 = up(std::max<size_t>(c1 + 128, nb * 9 / 20));
-        if (c1 < nb) cuts.push_back(c1);
-        if (c2 < nb && c2 > c1) cuts.push_back(c2);
+        const double upload_us = (double)bytes_per_segment / 55e3;
+        const double compute_us = (2.0 * (double)c->model.macs_per_segment() + (double)c->mel_flops) / 130e6;   // ~130 TFLOP/s over the whole forward
+        if (upload_us < compute_us) {
+            const size_t c1 = up(std::max<size_t>(128, nb / 8)), c2 = up(std::max<size_t>(c1 + 128, nb * 9 / 20));
+            if (c1 < nb) cuts.push_back(c1);
+            if (c2 < nb && c2 > c1) cuts.push_back(c2);
+        } else {
+            const size_t sub = up(std::max<size_t>(128, (nb + 3) / 4));
+            for (size_t v = sub; v < nb; v += sub) cuts.push_back(v);
+        }
     }
     cuts.push_back(nb);
     return cuts;
@@ -550,7 +562,7 @@ int predict_slices(bh_classifier *c, bh_batch_context *ctx, const float *const *
         const size_t nchunks = (nb + CH - 1) / CH;
         // sub-slices (sub_slice_cuts above), in whole chunks; debug contexts keep one (bh_debug_read_tensor reads the last)
         // (whole_slice: the caller reads an arena tensor of the slice afterwards -- the embeddings of the two-stage path)
-        const std::vector<size_t> cuts = sub_slice_cuts(nb, CH, ctx->keep_tensors || emb_out || whole_slice);
+        const std::vector<size_t> cuts = sub_slice_cuts(c, nb, CH, ctx->keep_tensors || emb_out || whole_slice, S * sizeof(float));
         const size_t nsub = cuts.size();
         while (ctx->copy_ev.size() < nsub) {
             hipEvent_t e;
@@ -1700,7 +1712,7 @@ static int predict_pcm16_core(bh_classifier *c, bh_batch_context *ctx, const voi
         char *stage = reinterpret_cast<char *>(ctx->h_input);
         const size_t PIECE = (size_t)8 << 20;
         const size_t npieces = (staged || pcm_pinned) ? (bytes + PIECE - 1) / PIECE : 1;
-        const std::vector<size_t> cuts = sub_slice_cuts(nb, 1, false);
+        const std::vector<size_t> cuts = sub_slice_cuts(c, nb, 1, false, (size_t)((double)bytes / (double)nb));
         const size_t nsub = cuts.size();
         while (ctx->copy_ev.size() < nsub) {
             hipEvent_t e;
