@@ -171,6 +171,16 @@ def analyse(clf, m, info, fused, stage_tot, layer_tot, segs_done, steps, slices_
         i = 3
     while fused and i + 2 < len(layers) and bi + n_stem_blocks < len(fused):
         E, D, P = layers[i], layers[i + 1], layers[i + 2]
+        if E.op == mf.OP_DWCONV and D.op == mf.OP_PWCONV and D.in_tensor == i + 1 and layer_tot[i][1] > 0 and layer_tot[i + 1][1] == 0:
+            # a fused block WITHOUT an expand convolution (depthwise -> project): layers i, i + 1
+            key = ("noexp", E.cout, D.cout, E.kh, E.sh, E.in_h, E.in_w)
+            g = groups.setdefault(key, {"ms": 0.0, "launches": 0, "macs": macs(E) + macs(D),
+                                        "kernel": clf.fused_kernel_name(fused[bi + n_stem_blocks]), "stem": False})
+            g["ms"] += layer_tot[i][0]
+            g["launches"] += layer_tot[i][1]
+            bi += 1
+            i += 2
+            continue
         if (E.op == mf.OP_PWCONV and D.op == mf.OP_DWCONV and P.op == mf.OP_PWCONV and D.in_tensor == i + 1
                 and P.in_tensor == i + 2 and layer_tot[i][1] > 0 and layer_tot[i + 1][1] == 0):
             key = (E.cin, E.cout, P.cout, D.kh, D.sh, E.in_h, E.in_w)
@@ -201,7 +211,9 @@ def analyse(clf, m, info, fused, stage_tot, layer_tot, segs_done, steps, slices_
             peak, note, insn = PEAK_F16_MFMA_TFLOPS, "dense f16 MFMA peak", "v_mfma_f32_16x16x32_f16"
         total_flops = 2.0 * dom["macs"] * segs_done * n_blocks
         tflops = total_flops / (dom["ms"] * 1e-3) / 1e12
-        if dom["stem"]:
+        if dom_key[0] == "noexp":
+            desc = "depthwise %dx%d s%d -> project 1x1, %d -> %d at %dx%d" % (dom_key[3], dom_key[3], dom_key[4], dom_key[1], dom_key[2], dom_key[5], dom_key[6])
+        elif dom["stem"]:
             desc = "stem conv %dx%d s%d (im2col GEMM) -> depthwise -> project 1x1, %d -> %d -> %d at %dx%d" % (
                 3, 3, 2, dom_key[1], dom_key[2], dom_key[3], dom_key[6], dom_key[7])
         else:
@@ -218,7 +230,11 @@ def analyse(clf, m, info, fused, stage_tot, layer_tot, segs_done, steps, slices_
         # activation per expanded value and one per depthwise output (no tile halo); price: 102 cycles per PAIR of exact GELUs on
         # one SIMD (tools/microbench/pk_fma_rate.hip on this chip), 1 024 SIMDs at the 2.4 GHz peak clock.
         if dom_prec != 0:
-            if dom["stem"]:
+            if dom_key[0] == "noexp":
+                i_dom = next(i for i in range(len(layers) - 1) if layers[i].op == mf.OP_DWCONV and layers[i + 1].op == mf.OP_PWCONV and
+                             ("noexp", layers[i].cout, layers[i + 1].cout, layers[i].kh, layers[i].sh, layers[i].in_h, layers[i].in_w) == dom_key)
+                E = D = layers[i_dom]
+            elif dom["stem"]:
                 E, D = layers[0], layers[1]
             else:
                 i_dom = next(i for i in range(len(layers) - 2) if layers[i].op == mf.OP_PWCONV and layers[i + 1].op == mf.OP_DWCONV and

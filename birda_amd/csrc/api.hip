@@ -282,10 +282,11 @@ void plan_arena(const bh::Model &m, const std::vector<int> &fused_at, const std:
     if (!keep)
         for (size_t i = 0; i < fused_at.size(); i++)
             if (fused_at[i] >= 0) {
-                // one launch reads the block input while it writes tensor i+3; the expanded
-                // tensors i+1, i+2 stay in LDS and take no arena space
-                last[m.layers[i].in_tensor] = std::max(last[m.layers[i].in_tensor], i + 3);
-                sz[i + 1] = sz[i + 2] = 0;
+                // one launch reads the block input while it writes the block's last tensor (i + 3; i + 2 for a block without an
+                // expand convolution: depthwise -> project); the tensors in between stay in LDS and take no arena space
+                const size_t len = (i + 2 < m.layers.size() && m.layers[i].op != bh::OP_DWCONV) ? 3 : 2;
+                last[m.layers[i].in_tensor] = std::max(last[m.layers[i].in_tensor], i + len);
+                for (size_t k = 1; k < len; k++) sz[i + k] = 0;
             }
     if (!keep)
         for (size_t i = 0; i + 1 < head_gap.size(); i++)
@@ -402,13 +403,14 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
         if ((!ctx->keep_tensors || ctx->keep_fused) && c->fused_at[i] >= 0) {
             // expand (i) -> depthwise (i+1) -> project (i+2) in one launch
             bh::MbDesc d = c->mb[c->fused_at[i]];
-            const auto &LP = m.layers[i + 2];
+            const size_t ip = d.noexp ? i + 1 : i + 2;   // the project layer
+            const auto &LP = m.layers[ip];
             d.X = in;
-            d.Y = (i + 2 == nl - 1) ? d_logits : T(i + 3);
+            d.Y = (ip == nl - 1) ? d_logits : T(ip + 1);
             d.R = LP.res_tensor != bh::NO_TENSOR ? T(LP.res_tensor) : nullptr;
             bh::launch_mbconv(d, (int)n, s);
             ctx_mark(ctx, ST_MBCONV, (int)i);
-            i += 2;
+            i = ip;
             continue;
         }
         switch (L.op) {
@@ -669,6 +671,27 @@ float f16_to_f32(uint16_t h) {
 // it per block at create, bh_plan_fused_blocks walks a model file with it.
 bool describe_fused_block(const bh::Model &m, const std::vector<int> &readers, size_t i, int precision, int force_cfg, bh::MbDesc &d) {
     const size_t nl = m.layers.size();
+    if (i + 1 < nl && m.layers[i].op == bh::OP_DWCONV && m.layers[i + 1].op == bh::OP_PWCONV) {
+        // depthwise -> project (+ residual) WITHOUT an expand convolution (the expand-ratio-1 blocks of EfficientNet after the
+        // first): fused with the block input standing in for the expanded tensor (MbDesc::noexp)
+        const auto &D = m.layers[i], &P = m.layers[i + 1];
+        if (P.in_tensor != i + 1 || readers[i + 1] != 1 || D.res_tensor != bh::NO_TENSOR) return false;
+        if (D.kh != D.kw || D.sh != D.sw || D.cout != P.cin || D.in_layout != 0) return false;
+        d = bh::MbDesc{};
+        d.noexp = 1;
+        d.H = (int)D.in_h; d.W = (int)D.in_w; d.Cin = (int)D.cout; d.Cexp = (int)D.cout; d.Cout = (int)P.cout;
+        d.Ho = (int)D.out_h; d.Wo = (int)D.out_w; d.pad_t = (int)D.pad_t; d.pad_l = (int)D.pad_l;
+        d.KS = (int)D.kh; d.ST = (int)D.sh;
+        d.act_e = (int)D.act; d.act_d = (int)D.act; d.act_p = (int)P.act;   // (no expand activation: the kernel template is keyed on one)
+        if (const char *dbg = getenv("BIRDA_HIP_MB_DBG")) d.dbg = atoi(dbg);
+        d.prec = precision;
+        if (!bh::mb_plan(d, force_cfg)) {
+            if (d.prec == 0) return false;
+            d.prec = 0;
+            if (!bh::mb_plan(d, force_cfg)) return false;
+        }
+        return true;
+    }
     if (i + 2 >= nl) return false;
     const auto &E = m.layers[i], &D = m.layers[i + 1], &P = m.layers[i + 2];
     const bool stem = E.op == bh::OP_CONV && E.in_layout == 1 && E.kh == E.kw && E.sh == E.sw && E.in_tensor == 0;
@@ -722,7 +745,8 @@ int plan_fusion(bh_classifier *c) {
     for (size_t i = 0; i + 2 < nl; i++) {
         bh::MbDesc d{};
         if (!describe_fused_block(m, readers, i, c->precision, force_cfg, d)) continue;
-        const auto &E = m.layers[i], &D = m.layers[i + 1], &P = m.layers[i + 2];
+        // (a no-expand block is layers i = depthwise, i + 1 = project; E then only lends the code below a valid layer to name)
+        const auto &E = m.layers[i], &D = m.layers[d.noexp ? i : i + 1], &P = m.layers[d.noexp ? i + 1 : i + 2];
         // per-chunk weight blocks (kernels.hpp MbDesc)
         const int CE = d.CE, NTE = CE / 16, KG = d.KG, NTOP = d.NTOP, nch = d.nchunks, KK = d.KS * d.KS;
         const float *We = m.blob.data() + E.w_off, *Wp = m.blob.data() + P.w_off, *Wd = m.blob.data() + D.w_off;
@@ -732,7 +756,7 @@ int plan_fusion(bh_classifier *c) {
         int se = 0, sp = 0;
         if (h16) {
             float me = 0.0f, mp = 0.0f;
-            for (size_t q = 0; q < (size_t)d.Cin * d.Cexp; q++) me = std::max(me, std::fabs(We[q]));
+            for (size_t q = 0; !d.noexp && q < (size_t)d.Cin * d.Cexp; q++) me = std::max(me, std::fabs(We[q]));
             for (size_t q = 0; q < (size_t)d.Cexp * d.Cout; q++) mp = std::max(mp, std::fabs(Wp[q]));
             se = bh::f16_scale_exponent(me);
             sp = bh::f16_scale_exponent(mp);
@@ -743,7 +767,8 @@ int plan_fusion(bh_classifier *c) {
         d.e_fold = 0;
         d.gelu = bh::GeluScaled{0.f, 0.f, 0.f, 0.f, 0.f};
 #if BH_GELU_DEGREE == 5
-        if (h16 && d.act_e == bh::ACT_GELU_ERF) {
+        if (d.noexp) se = 0;
+        if (h16 && d.act_e == bh::ACT_GELU_ERF && !d.noexp) {
             se = std::max(-21, std::min(21, se));
             d.e_fold = 1;
             float gc[5];
@@ -765,7 +790,7 @@ int plan_fusion(bh_classifier *c) {
                 const int ch = r / 3, dy = r - 3 * ch;
                 k = (dy * 3 + dx) * d.stem_c + ch;
             }
-            return (k < d.Cin && n < d.Cexp) ? std::ldexp(We[(size_t)k * d.Cexp + n], se) : 0.0f;
+            return (!d.noexp && k < d.Cin && n < d.Cexp) ? std::ldexp(We[(size_t)k * d.Cexp + n], se) : 0.0f;
         };
         auto wp_at = [&](int k, int n) { return (k < d.Cexp && n < d.Cout) ? std::ldexp(Wp[(size_t)k * d.Cout + n], sp) : 0.0f; };
         // f16: element jj of lane's 8-half fragment = k = 32 g + 8 (lane >> 4) + jj; hi plane then lo plane
@@ -791,7 +816,7 @@ int plan_fusion(bh_classifier *c) {
                                 wef[ch * we_fl + (((size_t)g * NTE + j) * 64 + lane) * 4 + cc] = we_at(16 * g + 4 * (lane >> 4) + cc, n);
                         }
                     }
-            for (int n = 0; n < CE; n++) wef[ch * we_fl + (size_t)KG * NTE * frag + n] = ch * CE + n < d.Cexp ? std::ldexp(be[ch * CE + n], se) : 0.0f;
+            for (int n = 0; n < CE; n++) wef[ch * we_fl + (size_t)KG * NTE * frag + n] = (!d.noexp && ch * CE + n < d.Cexp) ? std::ldexp(be[ch * CE + n], se) : 0.0f;
             if (p16) {
                 for (int j = 0; j < NTOP; j++)
                     for (int lane = 0; lane < 64; lane++)
@@ -848,7 +873,7 @@ int plan_fusion(bh_classifier *c) {
         }
         c->fused_at[i] = (int)c->mb.size();
         c->mb.push_back(d);
-        i += 2;
+        i += d.noexp ? 1 : 2;
     }
     return BH_OK;
 }
@@ -1065,7 +1090,10 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) try {
     if (c->precision != 0) {
         std::vector<char> in_block(m.layers.size(), 0);
         for (size_t i = 0; i < m.layers.size(); i++)
-            if (c->fused_at[i] >= 0) in_block[i] = in_block[i + 1] = in_block[i + 2] = 1;
+            if (c->fused_at[i] >= 0) {
+                in_block[i] = in_block[i + 1] = 1;
+                if (!c->mb[c->fused_at[i]].noexp) in_block[i + 2] = 1;
+            }
         for (size_t i = 0; i < m.layers.size(); i++) {
             const auto &L = m.layers[i];
             if (in_block[i] || (L.op != bh::OP_PWCONV && L.op != bh::OP_DENSE) || !bh::pw_gemm16_supports((int)L.cin, (int)L.act)) continue;
@@ -1476,7 +1504,7 @@ int bh_plan_fused_blocks(const char *model_path, uint32_t flags, int32_t *cfgs, 
         if (!describe_fused_block(m, readers, i, precision, -1, d)) continue;
         if (n < cap) { if (cfgs) cfgs[n] = d.cfg; if (layers) layers[n] = (int32_t)i; }
         n++;
-        i += 2;
+        i += d.noexp ? 1 : 2;
     }
     return (int)n;
 } catch (...) { return on_exception(); }

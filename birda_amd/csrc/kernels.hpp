@@ -377,6 +377,9 @@ struct MbDesc {
     // value with the coefficients gelu (c_k 2^-ks, gelu_erf_fast4_scaled) and the depthwise taps in Wd carry the 2^-s instead
     int e_fold;
     GeluScaled gelu;
+    // 1: a block without an expand convolution (depthwise -> project (+ residual), EfficientNet's expand-ratio-1 blocks): Cexp ==
+    // Cin, X's channels are copied into the grid chunk by chunk, We holds nothing but zero biases (tile entries with KG = 0)
+    int noexp;
     // stem variant (first block): "expand" = the k x k stride-s stem conv gathered from the planar
     // spectrogram X [n][stem_c][stem_h][stem_w]; then H, W are the stem's OUTPUT size and
     // Cin = stem_k * stem_k * stem_c im2col columns (We rows in [kh][kw][cin] order)

@@ -39,7 +39,8 @@ double mb_try_th(MbDesc &d, int ci, int th) {
     if (c.STEM != (d.stem ? d.stem_c : 0)) return -1;
     if (d.stem && d.stem_k != 3) return -1;
     if (c.PREC != d.prec) return -1;
-    if ((d.Cin + (c.PREC ? 31 : 15)) / (c.PREC ? 32 : 16) != c.KG) return -1;
+    if (c.KG == 0) { if (!d.noexp || d.stem) return -1; }   // the no-expand entries serve the no-expand blocks, and only them
+    else if (d.noexp || (d.Cin + (c.PREC ? 31 : 15)) / (c.PREC ? 32 : 16) != c.KG) return -1;
     if (d.act_e != c.ACT || d.act_d != c.ACT || d.act_p != ACT_NONE) return -1;
     if (c.COLTH) {   // column tasks: the tile is the whole image, COLTH rows high, symmetric padding, one task per thread
         if (th != c.COLTH || d.Ho != c.COLTH || d.H != c.COLTH || d.ST != 1 || d.pad_t != (c.KS - 1) / 2) return -1;

@@ -271,8 +271,13 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
     const GeluScaled gelu_sc = d.gelu;
     // ---- the wave's rows of X: A fragments of the expand GEMM, resident for the whole kernel ----
     // f32: afr[i][g] = 4 k values of one 16-deep group; f16: ah/al[i][g] = 8 k values of one 32-deep step
-    float4 afr[PREC ? 1 : RT_W][PREC ? 1 : KG];
-    f16x8 ah[PREC ? RT_W : 1][PREC ? KG : 1], al[PREC ? RT_W : 1][PREC ? KG : 1];
+    // KG == 0: a block WITHOUT an expand convolution (EfficientNet's expand-ratio-1 blocks after the first: depthwise -> project
+    // + residual).  Its "expanded" tensor is the block input itself: P1 copies the chunk's channels of X into the LDS grid (no
+    // GEMM, no activation), everything else is the same kernel.
+    constexpr int KGA = KG > 0 ? KG : 1;
+    float4 afr[PREC ? 1 : RT_W][PREC ? 1 : KGA];
+    f16x8 ah[PREC ? RT_W : 1][PREC ? KGA : 1], al[PREC ? RT_W : 1][PREC ? KGA : 1];
+    int xrow[KG == 0 ? RT_W : 1];   // KG == 0: float offset of the lane's source row in X (-1: padding row)
     // the expand GEMM is computed transposed (E^T = We^T X^T): a lane ends up with 4 consecutive
     // channels of ONE source row, li of its row tile, and writes them with one ds_write_b128 at
     // eoff[i] = that row's slot in the LDS grid (padding rows: the trash slot)
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
     // (8-wave kernels: one workgroup per CU, so nothing hides a second round trip of the set-up, and at that point the 256 registers
     //  hold nothing but these loads and the fragments they become: all row tiles in one batch)
     constexpr int XLIM = NW == 8 ? 24 : 16;
-    constexpr int XBATCH = (STEM && !PREC) ? 1 : (RT_W * KG * NQ <= XLIM ? RT_W : (XLIM / (KG * NQ) >= 1 ? XLIM / (KG * NQ) : 1));
+    constexpr int XBATCH = (STEM && !PREC) ? 1 : (RT_W * KGA * NQ <= XLIM ? RT_W : (XLIM / (KGA * NQ) >= 1 ? XLIM / (KGA * NQ) : 1));
     struct __attribute__((packed, aligned(4))) F3 { float a, b, c; };
 #pragma unroll
     for (int i0 = 0; i0 < RT_W; i0 += XBATCH) {
@@ -310,6 +315,11 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                 rvv[ii] = !(d.dbg & 64);
             }
         }
+        if constexpr (KG == 0) {
+#pragma unroll
+            for (int ii = 0; ii < XBATCH; ii++)
+                if (i0 + ii < RT_W) xrow[i0 + ii < RT_W ? i0 + ii : 0] = rvv[ii] ? xo[ii] : -1;
+        } else
         if constexpr (STEM != 0 && PREC == 0) {
             // f32 mode: im2col column k = (dy * 3 + dx) * C + ch, exactly the row order of the [kh][kw][cin][cout] weights
             const int i = i0;
@@ -480,6 +490,28 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
         mb_stamp(d.stamps, t_last, 1);
 
         // ---- P1: expand ------------------------------------------------------------------
+        if constexpr (KG == 0) {
+            // no expand convolution: the chunk's CE channels of the block input go into the grid as they are.  Lane (li, kq) of row
+            // tile i moves channels 16 j + 4 kq .. + 3 of its row: one 16-byte load and one ds_write_b128, the slots the GEMM's
+            // epilogue would have written.
+            static_assert(KG != 0 || NCS == 1, "no-expand blocks: no column split");
+            float4 xv[RT_W][NT_E];
+#pragma unroll
+            for (int i = 0; i < RT_W; i++)
+#pragma unroll
+                for (int j = 0; j < NT_E; j++) {
+                    const int c0 = ch * CE + 16 * j + 4 * kq;
+                    const bool ok = xrow[i] >= 0 && c0 < Cin;     // (Cin % 4 == 0: a quad is wholly inside or outside)
+                    xv[i][j] = *reinterpret_cast<const float4 *>(Xb + (ok ? xrow[i] + c0 : 0));
+                    if (!ok) xv[i][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+            for (int i = 0; i < RT_W; i++)
+                if (rw + RSTEP * i < nrt) {
+#pragma unroll
+                    for (int j = 0; j < NT_E; j++) *reinterpret_cast<float4 *>(Es + eoff[i] + j * 16) = xv[i][j];
+                }
+        } else
 #pragma unroll
         for (int i0 = 0; i0 < RT_W; i0 += RG) {
             if (rw + RSTEP * i0 < nrt) {  // wave-uniform

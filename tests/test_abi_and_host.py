@@ -316,11 +316,11 @@ def test_shipped_hot_kernels_fit_their_register_budget():
                            ("3,1,16,1,3,1,4,1,2,2,4,1,1,3,0,3,0,4,0", 168)):
         vgpr, agpr, scratch, threads = k(args)
         assert scratch == 0 and vgpr + agpr <= max_regs and threads == 256, (args, k(args))
-    # the nine late blocks' five instantiations: 8 waves, 256 registers, <= 12 spilled
+    # the nine late blocks' five instantiations: 8 waves, 256 registers, <= 16 spilled
     for args in ("3,1,32,3,3,2,4,2,3,3,5,3,1,2,0,3,0,4,6", "5,1,32,3,3,2,4,2,3,4,5,3,1,2,0,3,0,4,6", "5,1,32,4,3,2,4,2,3,4,5,3,1,2,0,3,0,4,6",
                  "5,1,32,6,2,2,2,4,3,3,4,2,2,2,0,3,0,4,3", "3,1,32,6,2,2,2,4,3,5,4,2,2,2,0,3,0,4,3"):
         vgpr, agpr, scratch, threads = k(args)
-        assert threads == 512 and vgpr + agpr <= 256 and scratch <= 48, (args, k(args))
+        assert threads == 512 and vgpr + agpr <= 256 and scratch <= 64, (args, k(args))   # (<= 16 spilled registers, one reload per chunk)
     vgpr, agpr, scratch, threads = res["mel_kernel<6,3>"]
     assert scratch == 0 and vgpr + agpr <= 256
 
@@ -355,7 +355,8 @@ def test_shipped_tile_configurations_are_the_reachable_ones():
     assert not unreached, f"shipped but never picked by the planner: {unreached}"
     # the headline models fuse every block they can in the f16 modes
     assert len(by_model["birdnet_v24/default/f16x3"]["fused"]) == 16 and not by_model["birdnet_v24/default/f16x3"]["unfused_triples"]
-    assert len(by_model["perch_v2/default/f16x3"]["fused"]) == 25 and len(by_model["perch_v2/default/f16"]["fused"]) == 25
+    assert len(by_model["perch_v2/default/f16x3"]["fused"]) == 26 and len(by_model["perch_v2/default/f16"]["fused"]) == 26
+    assert not by_model["perch_v2/default/f16x3"]["unfused_triples"]
     assert not os.path.exists(os.path.join(ROOT, "birda_amd", "csrc", "kernels_mbwave.hip"))
     so = os.path.getsize(os.path.join(ROOT, "birda_amd", "libbirda_hip.so"))
     assert so < 9 * 2 ** 20, f"libbirda_hip.so grew to {so / 2 ** 20:.1f} MiB"

@@ -42,6 +42,10 @@ def fusable_triples(m):
         if (L[i].op == mf.OP_PWCONV or stem) and L[i + 1].op == mf.OP_DWCONV and L[i + 2].op == mf.OP_PWCONV \
                 and L[i + 1].in_tensor == i + 1 and L[i + 2].in_tensor == i + 2:
             out.append(i)
+    fused3 = set(out) | {i + 1 for i in out} | {i + 2 for i in out}
+    for i in range(len(L) - 1):   # depthwise -> project without an expand convolution
+        if i not in fused3 and L[i].op == mf.OP_DWCONV and L[i + 1].op == mf.OP_PWCONV and L[i + 1].in_tensor == i + 1:
+            out.append(i)
     return out
 
 
@@ -60,7 +64,9 @@ def survey(models=MODELS, acts=(None,)):
                 for prec, flag in PRECISIONS.items():
                     got = plan(p, flag)
                     key = f"{kind}/{'default' if act is None else act}/{prec}"
-                    by_model[key] = {"fused": got, "unfused_triples": sorted(set(triples) - {l for l, _ in got})}
+                    starts = {l for l, _ in got}
+                    # (a candidate whose depthwise layer heads a fused two-layer block is not a triple: its first layer has two readers)
+                    by_model[key] = {"fused": got, "unfused_triples": sorted(t for t in set(triples) - starts if t + 1 not in starts)}
                     reach |= {c for _, c in got}
                 os.remove(p)
     return reach, by_model
