@@ -70,6 +70,7 @@ SYMBOLS = [
     ("bh_batch_context_bytes", _SZ, [_VP]),
     ("bh_batch_context_host_buffer", C.c_void_p, [_VP, C.POINTER(_SZ)]),
     ("bh_batch_context_device_bytes", _SZ, [_VP]),
+    ("bh_classifier_trim", _SZ, [_VP]),
     ("bh_predict", C.c_int, [_VP, _VP, _SZ, C.POINTER(BhResult)]),
     ("bh_predict_batch", C.c_int, [_VP, C.POINTER(_VP), _SZ, _SZ, C.POINTER(BhResult)]),
     ("bh_predict_batch_with_context", C.c_int, [_VP, _VP, C.POINTER(_VP), _SZ, _SZ, C.POINTER(BhResult)]),

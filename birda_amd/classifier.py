@@ -181,6 +181,10 @@ class BirdClassifier:
         """determine_default_batch_size (lib.rs:256-288) for this backend."""
         return int(self._L.bh_classifier_default_batch_size(self._h))
 
+    def trim(self) -> int:
+        """Release the parked batch contexts and the internal one; returns the device bytes freed."""
+        return int(self._L.bh_classifier_trim(self._h))
+
     # ---- warm-up (classifier.rs:414-466) ----
     def ensure_warm(self, batch_size: int):
         check(self._L.bh_classifier_ensure_warm(self._h, batch_size))

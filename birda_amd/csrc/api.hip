@@ -1312,15 +1312,41 @@ int bh_batch_context_create(bh_classifier *c, size_t max_batch, bh_batch_context
     const bool keep_t = keep && keep[0] == '1';
     if (c && out && !keep_t) {
         std::lock_guard<std::mutex> g(c->parked_mu);
+        // a parked context of this size, or failing that one up to twice as large (files of slightly different lengths cap their
+        // effective batch differently, processor.rs:531-545: an exact match alone would rebuild 4 GB of arena for each of them)
+        bh_batch_context **pick = nullptr;
         for (bh_batch_context *&p : c->parked_ctx)
-            if (p && p->max_batch == max_batch && !p->keep_tensors) {
-                *out = p;
-                p = nullptr;
-                return BH_OK;
-            }
+            if (p && !p->keep_tensors && p->max_batch == max_batch) { pick = &p; break; }
+        if (!pick)
+            for (bh_batch_context *&p : c->parked_ctx)
+                if (p && !p->keep_tensors && p->max_batch > max_batch && p->max_batch <= 2 * max_batch && (!pick || p->max_batch < (*pick)->max_batch)) pick = &p;
+        if (pick) {
+            *out = *pick;
+            *pick = nullptr;
+            return BH_OK;
+        }
     }
     return ctx_create(c, max_batch, keep_t, out);
 } catch (...) { return on_exception(); }
+
+size_t bh_classifier_trim(bh_classifier *c) {
+    if (!c) return 0;
+    size_t freed = 0;
+    bh_batch_context *gone[bh_classifier::N_PARKED + 1] = {};
+    int n = 0;
+    {
+        std::lock_guard<std::mutex> g(c->parked_mu);
+        for (bh_batch_context *&p : c->parked_ctx)
+            if (p) { gone[n++] = p; p = nullptr; }
+    }
+    {
+        std::lock_guard<std::mutex> g(c->internal_mu);
+        if (c->internal_ctx) { gone[n++] = c->internal_ctx; c->internal_ctx = nullptr; }
+    }
+    (void)hipSetDevice(c->device);
+    for (int i = 0; i < n; i++) { freed += gone[i]->device_bytes; ctx_destroy(gone[i]); }
+    return freed;
+}
 
 void bh_batch_context_destroy(bh_batch_context *ctx) {
     if (!ctx) return;

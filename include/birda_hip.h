@@ -161,6 +161,11 @@ BH_API size_t bh_batch_context_bytes(const bh_batch_context *ctx);       /* inpu
  * and a parked context keeps the allocation alive from file to file (a fresh 300-MB hipHostMalloc + hipHostFree costs 35 ms). */
 BH_API void *bh_batch_context_host_buffer(bh_batch_context *ctx, size_t *bytes);
 BH_API size_t bh_batch_context_device_bytes(const bh_batch_context *ctx); /* all device memory */
+/* A destroyed context is PARKED in its classifier (up to two) and handed to the next create of that size (or up to twice that
+ * size): the per-file pipeline creates one per file (processor.rs:582-603), and 4 GB of hipMalloc + 576 MB of pinned staging cost
+ * more than a short file's inference.  bh_classifier_trim releases the parked contexts and the classifier's internal one
+ * (bh_predict / bh_predict_batch); returns the device bytes freed.  Call between runs, from the predicting thread. */
+BH_API size_t bh_classifier_trim(bh_classifier *c);
 
 /* Classifier::predict(&[f32]) (classifier.rs:469-475): exactly sample_count samples. */
 BH_API int bh_predict(bh_classifier *c, const float *segment, size_t n_samples, bh_result *out);

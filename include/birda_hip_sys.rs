@@ -119,6 +119,7 @@ extern "C" {
     pub fn bh_batch_context_bytes(ctx: *const BhBatchContext) -> usize;
     pub fn bh_batch_context_host_buffer(ctx: *mut BhBatchContext, bytes: *mut usize) -> *mut c_void;
     pub fn bh_batch_context_device_bytes(ctx: *const BhBatchContext) -> usize;
+    pub fn bh_classifier_trim(c: *mut BhClassifier) -> usize;
     pub fn bh_predict(c: *mut BhClassifier, segment: *const f32, n_samples: usize, out: *mut BhResult) -> c_int;
     pub fn bh_predict_batch(c: *mut BhClassifier, segments: *const *const f32, n: usize, n_samples: usize, out: *mut BhResult) -> c_int;
     pub fn bh_predict_batch_with_context(c: *mut BhClassifier, ctx: *mut BhBatchContext, segments: *const *const f32, n: usize, n_samples: usize, out: *mut BhResult) -> c_int;

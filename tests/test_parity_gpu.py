@@ -1187,6 +1187,33 @@ def test_one_failing_recording_does_not_fail_its_pack(clf_tiny, model_dir, tmp_p
     assert status2 == [0, 0, 0, 0] and all(r.effective_batch > r.segments for r in got2)
 
 
+def test_parked_contexts_are_reused_and_trimmed(model_dir):
+    """a destroyed context is parked in its classifier; a create of that size -- or of up to half that size, files of
+    slightly different lengths cap their effective batch differently -- gets it back, and bh_classifier_trim releases what is
+    parked (and the internal context of bh_predict / bh_predict_batch)."""
+    from birda_amd import synth
+    from birda_amd.classifier import BirdClassifier
+    path, labels, m, _ = model_dir["mini"]
+    clf = BirdClassifier(path, labels)
+    a = clf.create_batch_context(64)
+    h_a, bytes_a = a._h.value, a.device_bytes()
+    a.close()                                           # parked
+    b = clf.create_batch_context(40)                    # 40 <= 64 <= 80: the parked one
+    assert b._h.value == h_a and b.device_bytes() == bytes_a
+    b.close()
+    c = clf.create_batch_context(16)                    # 64 > 2 * 16: a new, small one
+    assert c.device_bytes() < bytes_a
+    c.close()
+    clf.predict(synth.synth_segments(1, m.sample_count, m.sample_rate)[0])     # builds the internal context
+    freed = clf.trim()
+    assert freed >= bytes_a
+    assert clf.trim() == 0
+    d = clf.create_batch_context(64)                    # nothing parked any more: a fresh context, same results as ever
+    segs = synth.synth_segments(3, m.sample_count, m.sample_rate, start=9)
+    assert len(clf.predict_batch_with_context(d, list(segs))) == 3
+    d.close(); clf.close()
+
+
 def test_non_finite_samples_stay_in_their_own_rows(clf_tiny, model_dir):
     """A corrupt decode (NaN / Inf samples) must not leak into the other rows of a batch, hang a kernel or produce
     predictions from NaN logits: rows are independent (processor.rs:363-367)."""
