@@ -143,7 +143,9 @@ def build_model(kind: str = "birdnet_v24", seed: int = WEIGHT_SEED,
     'perch_v2' (5 s / 32 kHz, Perch-SIZED: one 128-mel branch, EfficientNet-B3 stage plan with swish, 1 536-d embedding,
     a 6 144-wide hidden layer in front of the 14 795 classes -- 109 M parameters = 437 MB, 2.67 GFLOP per segment = 3.5x the
     v2.4-shaped model's conv stack; the published file is 413 MB and runs 4.4x slower than v2.4 on the reference's CPU, see below),
-    'perch_v2_tiny' (the same front-end and head on the B0 stage plan with GELU: 89 MB, 1.0 GFLOP; rounds 1-2's "perch_v2").
+    'perch_v2_tiny' (the same front-end and head on the B0 stage plan with GELU: 89 MB, 1.0 GFLOP; rounds 1-2's "perch_v2"),
+    'birdnet_v30' (the v3.0 contract of the reference's manifest: 5 s / 32 kHz, 11 560 classes with the sigmoid inside the model,
+    1 280-d embedding; trunk and front-end [EXT]: B0 on the 128-mel front-end).
     act: the activation between the convolutions (default: exact GELU, the north star's; mf.ACT_SWISH / ACT_RELU6 give the
     EfficientNet / MobileNet spellings of the same stack)."""
     rng = np.random.default_rng(seed)
@@ -166,6 +168,14 @@ def build_model(kind: str = "birdnet_v24", seed: int = WEIGHT_SEED,
             stages, stem, head = _B0_STAGES, 32, 256
         if kind == "mini_hg":  # toy stack whose last stage has 32 channels and a 128-wide head: the head conv + pool run as
             stages, head = [(1, 3, 1, 8, 1), (4, 5, 2, 16, 2), (4, 3, 2, 32, 1)], 128   # one launch in the f16 modes
+    elif kind == "birdnet_v30":
+        # BirdNET v3.0 as the reference's manifest describes it (manifests/BirdNET-v3.0-Models.models.json): 5 s @ 32 kHz, 160 000
+        # samples, 11 560 classes whose sigmoid sits INSIDE the graph (`predictions`, activation "sigmoid": output activation NONE
+        # here, the last layer carries the sigmoid), a 1 280-d `embeddings` output.  [EXT] The trunk and front-end are not published
+        # in the manifest: the EfficientNet-B0 plan on the Perch-style 128-mel front-end stands in.
+        sr, n, dur = 32000, 160000, 5.0
+        branches = [mf.Branch(1024, 320, 128, (n - 1024) // 320 + 1, 60.0, 16000.0, 1.23)]
+        stages, stem, head, ncls, family, out_act = _B0_STAGES, 32, 1280, 11560, 2, mf.OUT_NONE
     elif kind in ("perch_v2", "perch_v2_tiny"):
         # Perch v2: 5 s @ 32 kHz, 14 795 classes, softmax (manifests/Perch-v2-*).
         sr, n, dur = 32000, 160000, 5.0
@@ -221,7 +231,7 @@ def build_model(kind: str = "birdnet_v24", seed: int = WEIGHT_SEED,
         t = b.dense(t, head, hidden, act=act, logits=False)
         t = b.dense(t, hidden, ncls, gain=1.5)
     else:
-        t = b.dense(t, head, ncls, gain=1.5)
+        t = b.dense(t, head, ncls, gain=1.5, act=mf.ACT_SIGMOID if kind == "birdnet_v30" else mf.ACT_NONE)
     blob = np.concatenate(b.chunks) if b.chunks else np.zeros(0, np.float32)
     m = mf.Model(family, sr, n, dur, ncls, head, out_act, emb_t, branches[0].n_mels,
                  branches[0].n_frames, 1e-6, branches, b.layers, blob)
