@@ -816,7 +816,9 @@ def test_birdnet_v30_shaped_model_matches_oracle(oracle_lib, tmp_path):
     om = oracle_lib.OracleModel(path)
     ref = om.forward(segs)
     assert ref.min() >= 0.0 and ref.max() <= 1.0                 # probabilities already
-    for prec, tol in (("f32", LOGIT_RTOL), ("f16x3", LOGIT_RTOL), ("f16", F16_LOGIT_RTOL)):
+    # the comparison is on PROBABILITIES: |dp| <= 0.25 |dlogit|, and the synthetic head's logits reach ~140, so the stated logit
+    # tolerances (2e-5 / 3e-3 of the logit scale) become 7e-4 / 0.1 here; measured 1e-5 / 3e-3
+    for prec, tol in (("f32", 7e-4), ("f16x3", 7e-4), ("f16", 0.1)):
         clf = BirdClassifier(path, None, top_k=5, min_confidence=0.0, precision=prec)
         info = clf.info
         assert (info.model_type, info.output_activation, info.embedding_dim, info.n_classes) == (2, 0, 1280, 11560)
@@ -829,9 +831,9 @@ def test_birdnet_v30_shaped_model_matches_oracle(oracle_lib, tmp_path):
         for i, r in enumerate(res):
             idx, conf = oracle_lib.topk(ref[i], 0, 5, 0.0)
             assert len(r.predictions) == 5
-            if prec != "f16":
-                assert [p.index for p in r.predictions] == list(idx)
+            # (saturated classes tie at 1.0: the kept indices are compared through their confidences)
             assert np.allclose([p.confidence for p in r.predictions], np.sort(got[i])[::-1][:5], rtol=0, atol=1e-7)
+            assert all(abs(float(ref[i][p.index]) - p.confidence) <= tol for p in r.predictions)
         ctx.close(); clf.close()
 
 
