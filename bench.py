@@ -82,6 +82,33 @@ def reference_ort_leg(model_path, hip_logits_first, sample_count):
         return {"available": False, "note": f"ORT reference leg failed: {e!r}"}
 
 
+def usable_cores():
+    """Host cores this process may actually use: the scheduler affinity mask, capped by the cgroup CPU quota when the container has
+    one (os.cpu_count() reports the machine's 256 hardware threads whatever the quota; 256 OpenMP threads time-sliced onto a
+    32-core quota is not a 256-thread baseline)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())     # cgroup v1
+            period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    if quota:
+        n = max(1, min(n, int(quota + 0.5)))
+    return n, {"hardware_threads": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+               "cgroup_quota_cores": quota}
+
+
 def cpu_baseline(model_path, sample_count, sample_rate, hip_logits=None):
     """The oracle (a port, not the reference: the reference's ORT path cannot run here) timed
     on this box's host cores over a bounded sample of the same synthetic workload.  As the checker it
@@ -90,7 +117,7 @@ def cpu_baseline(model_path, sample_count, sample_rate, hip_logits=None):
     from birda_amd import synth
     from oracle import oracle as O
 
-    cores = os.cpu_count() or 1
+    cores, core_facts = usable_cores()
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     om = O.OracleModel(model_path)
     # the timed lists tile 64 distinct segments: all 64 go through the checker (16 on a small host, where 64 would take minutes)
@@ -110,7 +137,8 @@ def cpu_baseline(model_path, sample_count, sample_rate, hip_logits=None):
     t = time.perf_counter()
     om.forward(segs)
     dt = time.perf_counter() - t
-    return {"value": round(n / dt, 2), "unit": "segments/s", "cores": cores, "kind": "port",
+    return {"value": round(n / dt, 2), "unit": "segments/s", "cores": cores, "kind": "port", "core_facts": core_facts,
+            "per_core": round(n / dt / cores, 3),
             "reference": reference_ort_leg(model_path, hip_logits, sample_count),
             "readme_context": "reference README: 183 segments/s for BirdNET v2.4 on a 24-thread i7-13700K (ORT CPU EP, batch 8)",
             "sample": f"{n} synthetic segments, oracle/birda_oracle.c, OpenMP across segments "
@@ -227,8 +255,9 @@ def analyse(clf, m, info, fused, stage_tot, layer_tot, segs_done, steps, slices_
             "launches": dom["launches"], "avg_launch_us": round(dom["ms"] * 1e3 / max(dom["launches"], 1), 2),
             "algorithmic_gflop_per_launch": round(total_flops / max(dom["launches"], 1) / 1e9, 3)}
         # What actually bounds this kernel in the f16 modes: issuing its activation.  Algorithmic count: one
-        # activation per expanded value and one per depthwise output (no tile halo); price: 102 cycles per PAIR of exact GELUs on
-        # one SIMD (tools/microbench/pk_fma_rate.hip on this chip), 1 024 SIMDs at the 2.4 GHz peak clock.
+        # activation per expanded value and one per depthwise output (no tile halo); price: the THROUGHPUT of a SIMD shared by 3-4
+        # waves, measured on this chip (tools/microbench/valu_throughput.hip, profiles/r3_c_valu_throughput.txt): 27.4 ns per
+        # wave-instruction PAIR of GELUs (2 v_med3 + 7 v_pk_fma + 2 v_exp; 128 values), 23.4 ns for swish; 1 024 SIMDs.
         if dom_prec != 0:
             if dom_key[0] == "noexp":
                 i_dom = next(i for i in range(len(layers) - 1) if layers[i].op == mf.OP_DWCONV and layers[i + 1].op == mf.OP_PWCONV and
@@ -240,14 +269,16 @@ def analyse(clf, m, info, fused, stage_tot, layer_tot, segs_done, steps, slices_
                 i_dom = next(i for i in range(len(layers) - 2) if layers[i].op == mf.OP_PWCONV and layers[i + 1].op == mf.OP_DWCONV and
                              (layers[i].cin, layers[i].cout, layers[i + 2].cout, layers[i + 1].kh, layers[i + 1].sh, layers[i].in_h, layers[i].in_w) == dom_key)
                 E, D = layers[i_dom], layers[i_dom + 1]
-            acts = (E.out_h * E.out_w * E.cout + D.out_h * D.out_w * D.cout) * (segs_done / (steps * slices_per_step))   # per launch
-            floor_us = acts / 2 / 64 * 102.0 / (256 * 4) / 2.4e9 * 1e6
+            acts = ((0 if dom_key[0] == "noexp" else E.out_h * E.out_w * E.cout) + D.out_h * D.out_w * D.cout) * (segs_done / (steps * slices_per_step))   # per launch
+            ns_pair = 23.4 if D.act == mf.ACT_SWISH else 27.4
+            floor_us = acts / 128 * ns_pair / (256 * 4) * 1e-3
             avg_us = dom["ms"] * 1e3 / max(dom["launches"], 1)
             out["roofline"]["vector_issue"] = {
-                "activations_per_launch": int(acts), "cycles_per_pair": 102, "simds": 1024, "clock_ghz": 2.4,
+                "activations_per_launch": int(acts), "ns_per_wave_instruction_pair": ns_pair, "simds": 1024,
                 "floor_us": round(floor_us, 1), "frac": round(floor_us / avg_us, 4),
-                "note": "exact GELU through 2 v_med3 + 11 v_pk_fma + 2 v_exp per pair (measured issue cost); halo, depthwise taps, "
-                        "f16 splits and index arithmetic come on top"}
+                "note": "activation issue alone at the measured multi-wave VALU throughput (profiles/r3_c_valu_throughput.txt); tile halo, "
+                        "depthwise taps, f16 splits and index arithmetic come on top -- the kernel's vector pipe is 77-90 % busy "
+                        "(profiles/r3_e_sq_counters.txt)"}
         if mb_ms > 0:
             flops = 2.0 * sum(g["macs"] * max(1, g["launches"] // (steps * slices_per_step)) for g in groups.values()) * segs_done
             out["all_fused_blocks"] = {"achieved": round(flops / (mb_ms * 1e-3) / 1e12, 2), "unit": "TFLOP/s (algorithmic)",
@@ -686,7 +717,7 @@ def cpu_baseline_c5(model_path, m, hip_logits):
     import numpy as np
     from birda_amd import pipeline, synth
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
+    cores, _ = usable_cores()
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     om = O.OracleModel(model_path)
     rates = [22050, 44100, 48000]
