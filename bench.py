@@ -122,7 +122,9 @@ def cpu_baseline(model_path, sample_count, sample_rate, hip_logits=None):
     om = O.OracleModel(model_path)
     # the timed lists tile 64 distinct segments: all 64 go through the checker (16 on a small host, where 64 would take minutes)
     base = synth.synth_segments(64 if cores >= 32 else min(cores, 16), sample_count, sample_rate)
-    ref = om.forward(base)  # touch code / pages once; reference logits of segments 0..
+    t = time.perf_counter()
+    ref = om.forward(base)  # touch code / pages once; reference logits of segments 0..; its time sizes the timed sample
+    warm_rate = base.shape[0] / max(time.perf_counter() - t, 1e-3)
     parity = None
     if hip_logits:
         parity = {}
@@ -132,7 +134,7 @@ def cpu_baseline(model_path, sample_count, sample_rate, hip_logits=None):
             d = float(np.abs(got[:k] - ref[:k]).max())
             parity[name] = {"max_abs_dlogit": round(d, 6), "max_abs_logit": round(scale, 3), "relative": float(f"{d / scale:.3e}"),
                             "segments": k, "top1_agree": bool((got[:k].argmax(1) == ref[:k].argmax(1)).all())}
-    n = int(min(1024, max(64, 4 * cores)))         # ~10-30 s of CPU work on 8 ... 256 cores
+    n = int(min(2048, max(64, 12.0 * warm_rate)))  # ~12 s of CPU work at the rate the warm-up pass showed (<= 1.2 GB of segments)
     segs = np.tile(base, (n // base.shape[0] + 1, 1))[:n]
     t = time.perf_counter()
     om.forward(segs)
