@@ -121,7 +121,7 @@ def cpu_baseline(model_path, sample_count, sample_rate, hip_logits=None):
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     om = O.OracleModel(model_path)
     # the timed lists tile 64 distinct segments: all 64 go through the checker (16 on a small host, where 64 would take minutes)
-    base = synth.synth_segments(64 if cores >= 32 else min(cores, 16), sample_count, sample_rate)
+    base = synth.synth_segments(64 if cores >= 8 else 16, sample_count, sample_rate)
     t = time.perf_counter()
     ref = om.forward(base)  # touch code / pages once; reference logits of segments 0..; its time sizes the timed sample
     warm_rate = base.shape[0] / max(time.perf_counter() - t, 1e-3)
@@ -416,10 +416,11 @@ def host_legs(clf, m, model_path, precision, tmp):
                           "one_file_at_a_time": {"value": round(segs_a / t_single, 1), "unit": "segments/s"},
                           "packed": {"value": round(segs_b / t_packed, 1), "unit": "segments/s", "entry_point": "bhh_process_files"},
                           "identical_outputs": bool(same and not any(status_b))}
-    # the same long file four times over through bhh_process_files: each file is a pack of its own, its forward runs under the
-    # previous file's output writing and the next file's copy into the other context's staging buffer
+    # the same long file eight times over through bhh_process_files: each file is a pack of its own; three packs are in flight, so a
+    # file's upload and forward run under its neighbours' forwards, the previous file's output writing and the next one's copy into
+    # a free context's staging buffer (median of three runs: one run is 70 ms of wall time)
     longs = []
-    for k in range(4):
+    for k in range(8):
         p = os.path.join(tmp, "bench_long_%d.wav" % k)
         if not os.path.exists(p):
             os.link(wav, p)
@@ -427,11 +428,14 @@ def host_legs(clf, m, model_path, precision, tmp):
     out_l = os.path.join(tmp, "long_packed")
     os.makedirs(out_l, exist_ok=True)
     pipeline.process_files_packed(c2, longs, out_l)
-    t = time.perf_counter()
-    res_l, status_l = pipeline.process_files_packed(c2, longs, out_l)
-    t_long = time.perf_counter() - t
-    e2e["files_pipelined"] = {"what": "4 files of %d segments each through bhh_process_files (two in flight)" % n,
-                              "value": round(sum(r.segments for r in res_l) / t_long, 1), "unit": "segments/s", "ok": not any(status_l)}
+    rates, ok_l = [], True
+    for _ in range(3):
+        t = time.perf_counter()
+        res_l, status_l = pipeline.process_files_packed(c2, longs, out_l)
+        rates.append(sum(r.segments for r in res_l) / (time.perf_counter() - t))
+        ok_l = ok_l and not any(status_l)
+    e2e["files_pipelined"] = {"what": "8 files of %d segments each through bhh_process_files (three in flight), median of 3 runs" % n,
+                              "value": round(sorted(rates)[1], 1), "unit": "segments/s", "runs": [round(r, 1) for r in rates], "ok": ok_l}
     c2.close()
     out["end_to_end"] = {"what": "bhh_process_file on a synthetic %d-segment PCM16 WAV -> CSV (reference metric: segments / wall seconds, "
                                  "processor.rs:771-788), default batch size" % n, **e2e}

@@ -51,6 +51,9 @@ class BhResult(C.Structure):
 
 # every symbol include/birda_hip.h declares: (name, restype, argtypes)
 _VP, _SZ = C.c_void_p, C.c_size_t
+# bh_rows_fn: (user, first_segment, n_segments, rows, start_samples) -- rows of a host-fed stream as they complete
+BhRowsFn = C.CFUNCTYPE(None, C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(BhResult), C.POINTER(C.c_uint64))
+
 SYMBOLS = [
     ("bh_device_count", C.c_int, []),
     ("bh_backend_name", C.c_char_p, []),
@@ -69,6 +72,7 @@ SYMBOLS = [
     ("bh_batch_context_destroy", None, [_VP]),
     ("bh_batch_context_bytes", _SZ, [_VP]),
     ("bh_batch_context_host_buffer", C.c_void_p, [_VP, C.POINTER(_SZ)]),
+    ("bh_batch_context_set_sub_slices", C.c_int, [_VP, C.c_uint32]),
     ("bh_batch_context_device_bytes", _SZ, [_VP]),
     ("bh_classifier_trim", _SZ, [_VP]),
     ("bh_predict", C.c_int, [_VP, _VP, _SZ, C.POINTER(BhResult)]),
@@ -98,6 +102,8 @@ SYMBOLS = [
     ("bh_predict_pcm16", C.c_int, [_VP, _VP, _VP, _SZ, C.c_uint32, C.c_uint32, _SZ, C.POINTER(BhResult), _SZ,
                                    C.POINTER(_SZ), _VP]),
     ("bh_predict_pcm", C.c_int, [_VP, _VP, _VP, C.c_uint32, _SZ, C.c_uint32, C.c_uint32, _SZ, C.POINTER(BhResult), _SZ, C.POINTER(_SZ), _VP]),
+    ("bh_predict_pcm_rows", C.c_int, [_VP, _VP, _VP, C.c_uint32, _SZ, C.c_uint32, C.c_uint32, _SZ, C.POINTER(BhResult), _SZ, C.POINTER(_SZ), _VP,
+                                       BhRowsFn, _VP]),
     ("bh_predict_pcm_at", C.c_int, [_VP, _VP, _VP, C.c_uint32, _SZ, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), _SZ, C.POINTER(BhResult)]),
     ("bh_predict_pcm16_at", C.c_int, [_VP, _VP, _VP, _SZ, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), _SZ, C.POINTER(BhResult)]),
     ("bh_resample", C.c_int, [_VP, _VP, _SZ, C.c_uint32, C.c_uint32, _VP, _SZ, C.POINTER(_SZ)]),

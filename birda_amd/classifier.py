@@ -264,8 +264,10 @@ class BirdClassifier:
         self._L.bh_segment_starts(n_frames, segment_samples, overlap_samples, buf, n)
         return [int(buf[i]) for i in range(n)]
 
-    def predict_pcm16(self, ctx: BatchInferenceContext, pcm: np.ndarray, source_rate: int, overlap_samples: int = 0):
-        """pcm: int16 [frames] or [frames, channels].  Returns (results, start_samples)."""
+    def predict_pcm16(self, ctx: BatchInferenceContext, pcm: np.ndarray, source_rate: int, overlap_samples: int = 0, on_rows=None):
+        """pcm: int16 [frames] or [frames, channels].  Returns (results, start_samples).
+        on_rows(first_segment, results, start_samples): bh_predict_pcm_rows -- called for each finished run of consecutive
+        segments, in order, while the device computes the later ones."""
         a = np.ascontiguousarray(pcm, np.int16)
         channels = 1 if a.ndim == 1 else a.shape[1]
         n_frames = a.shape[0]
@@ -275,8 +277,15 @@ class BirdClassifier:
             res = (BhResult * cap)()
             starts = (C.c_uint64 * cap)()
             n = C.c_size_t()
-            rc = self._L.bh_predict_pcm16(self._h, ctx._h, a.ctypes.data, n_frames, channels, source_rate, overlap_samples,
-                                          res, cap, C.byref(n), starts)
+            if on_rows is None:
+                rc = self._L.bh_predict_pcm16(self._h, ctx._h, a.ctypes.data, n_frames, channels, source_rate, overlap_samples,
+                                              res, cap, C.byref(n), starts)
+            else:
+                def _cb(_user, first, count, rows, st):
+                    on_rows(int(first), self._results(rows, int(count)), [int(st[i]) for i in range(int(count))])
+                cb = _lib.BhRowsFn(_cb)
+                rc = self._L.bh_predict_pcm_rows(self._h, ctx._h, a.ctypes.data, 1, n_frames, channels, source_rate, overlap_samples,
+                                                 res, cap, C.byref(n), starts, cb, None)
             if rc != 0 and int(n.value) > cap:
                 cap = int(n.value)
                 continue

@@ -18,6 +18,7 @@
 #include <set>
 #include <string>
 #include <thread>
+#include <map>
 #include <vector>
 
 #include "../../include/birda_hip.h"
@@ -90,11 +91,11 @@ struct bh_classifier {
     std::set<size_t> warmed;                 // WarmupRegistry, classifier.rs:221-246
     bh_batch_context *internal_ctx = nullptr;
     std::mutex internal_mu;
-    // Up to two destroyed batch contexts are parked here and handed to the next bh_batch_context_create of the same size: the
-    // per-file pipeline creates and destroys a context per file (reference processor.rs:582-603), bhh_process_files keeps two in
+    // Up to three destroyed batch contexts are parked here and handed to the next bh_batch_context_create of the same size: the
+    // per-file pipeline creates and destroys a context per file (reference processor.rs:582-603), bhh_process_files keeps three in
     // flight, and a context is ~1 GB of hipMalloc plus pinned staging memory -- milliseconds per file at GPU throughput.
-    static constexpr int N_PARKED = 2;
-    bh_batch_context *parked_ctx[N_PARKED] = {nullptr, nullptr};
+    static constexpr int N_PARKED = 3;
+    bh_batch_context *parked_ctx[N_PARKED] = {nullptr, nullptr, nullptr};
     std::mutex parked_mu;
 };
 
@@ -106,6 +107,18 @@ struct bh_batch_context {
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;       // H2D of host batches, ahead of the compute stream
     std::vector<hipEvent_t> copy_ev;         // one per sub-slice in flight
+    std::vector<hipEvent_t> done_ev;         // bh_predict_pcm*: a sub-slice's rows are in the pinned result buffers
+    // Two compute lanes for the sub-slices of a host-fed slice (lanes_begin below): sub-slice k runs on stream (k & 1 ? stream2 :
+    // stream) in its own part of the arena, so the launch chain of one sub-slice (21 dependent launches: ~0.85 ms however few
+    // segments it holds) runs under the other's kernels instead of after them.
+    static constexpr int MAX_LANES = 4;
+    hipStream_t lane_stream[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};   // [0] = stream
+    hipEvent_t fork_ev = nullptr, join_ev[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
+    int n_lanes = 3;
+    struct ArenaPlan { std::vector<size_t> t_off; size_t total = 0; };
+    std::map<size_t, ArenaPlan> plans;       // arena plan of an n-segment forward (n < max_batch), built on first use
+    size_t arena_cap = 0;                    // floats allocated (arena_floats + slack for the lanes' alignment losses)
+    uint32_t forced_sub_slices = 0;          // bh_batch_context_set_sub_slices: 0 automatic, 1 whole slices, n equal sub-slices
     float *d_input = nullptr;    // [max_batch][sample_count]
     float *d_minmax = nullptr;   // [max_batch][8][2]
     unsigned *d_inbad = nullptr; // [max_batch][8]: the slice of the segment holds an inf / NaN sample
@@ -338,7 +351,15 @@ int ctx_create(bh_classifier *c, size_t max_batch, bool keep, bh_batch_context *
     HIPCHK(hipMalloc((void **)&ctx->d_minmax, max_batch * 16 * sizeof(float)));
     HIPCHK(hipMalloc((void **)&ctx->d_inbad, max_batch * 8 * sizeof(unsigned)));
     plan_arena(m, c->fused_at, c->head_gap, max_batch, keep, ctx->t_off, ctx->arena_floats);
-    HIPCHK(hipMalloc((void **)&ctx->d_arena, ctx->arena_floats * sizeof(float)));
+    ctx->arena_cap = ctx->arena_floats + 8 * 64 * (m.layers.size() + 1);
+    HIPCHK(hipMalloc((void **)&ctx->d_arena, ctx->arena_cap * sizeof(float)));
+    if (const char *e = getenv("BIRDA_HIP_NLANES")) ctx->n_lanes = std::max(1, std::min((int)bh_batch_context::MAX_LANES, atoi(e)));
+    ctx->lane_stream[0] = ctx->stream;
+    for (int l = 1; l < ctx->n_lanes; l++) {
+        HIPCHK(hipStreamCreateWithFlags(&ctx->lane_stream[l], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&ctx->join_ev[l], hipEventDisableTiming));
+    }
+    HIPCHK(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
     HIPCHK(hipMalloc((void **)&ctx->d_logits, max_batch * (size_t)m.h.n_classes * sizeof(float)));
     HIPCHK(hipMalloc((void **)&ctx->d_topk_idx, max_batch * c->top_k * sizeof(int32_t)));
     HIPCHK(hipMalloc((void **)&ctx->d_topk_conf, max_batch * c->top_k * sizeof(float)));
@@ -361,7 +382,13 @@ void ctx_destroy(bh_batch_context *ctx) {
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto e : ctx->ev) (void)hipEventDestroy(e);
     for (auto e : ctx->copy_ev) (void)hipEventDestroy(e);
+    for (auto e : ctx->done_ev) (void)hipEventDestroy(e);
     if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+    for (int l = 1; l < bh_batch_context::MAX_LANES; l++) {
+        if (ctx->lane_stream[l]) { (void)hipStreamSynchronize(ctx->lane_stream[l]); (void)hipStreamDestroy(ctx->lane_stream[l]); }
+        if (ctx->join_ev[l]) (void)hipEventDestroy(ctx->join_ev[l]);
+    }
+    if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
     (void)hipFree(ctx->d_input); (void)hipFree(ctx->d_minmax); (void)hipFree(ctx->d_inbad); (void)hipFree(ctx->d_arena);
     (void)hipFree(ctx->d_logits); (void)hipFree(ctx->d_topk_idx); (void)hipFree(ctx->d_topk_conf);
     (void)hipHostFree(ctx->h_input); (void)hipHostFree(ctx->h_topk_idx); (void)hipHostFree(ctx->h_topk_conf);
@@ -373,19 +400,27 @@ void ctx_destroy(bh_batch_context *ctx) {
 }
 
 // one slice (n <= max_batch) of the forward pass, enqueued on ctx->stream
+// (lane: where a sub-slice of a host-fed slice runs -- its stream, its own part of the arena with the plan of an n-segment forward,
+//  and its first segment's index within the slice, which places its rows of the per-segment scratch; nullptr: the context's stream
+//  and whole arena)
+struct SliceLane { hipStream_t s; float *arena; const size_t *t_off; size_t seg0; };
 int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, size_t n, float *d_logits,
-                  int32_t *d_idx, float *d_conf) {
+                  int32_t *d_idx, float *d_conf, const SliceLane *lane = nullptr) {
     const auto &m = c->model;
-    hipStream_t s = ctx->stream;
-    auto T = [&](uint32_t t) { return ctx->d_arena + ctx->t_off[t]; };
+    hipStream_t s = lane ? lane->s : ctx->stream;
+    float *const arena = lane ? lane->arena : ctx->d_arena;
+    const size_t *const t_off = lane ? lane->t_off : ctx->t_off.data();
+    float *const d_minmax = ctx->d_minmax + (lane ? lane->seg0 * 16 : 0);
+    unsigned *const d_inbad = ctx->d_inbad + (lane ? lane->seg0 * 8 : 0);
+    auto T = [&](uint32_t t) { return arena + t_off[t]; };
     const uint32_t nl = (uint32_t)m.layers.size();
     bh::TraceRange tr_slice("bh_forward_slice");   // ROCTx ranges (BIRDA_HIP_ROCTX=1): the slice, its front end, every layer group
     ctx_mark(ctx, -1);
     {
         bh::TraceRange tr("front_end: minmax + mel");
-        bh::launch_minmax(d_seg, ctx->d_minmax, ctx->d_inbad, (int)n, (int)m.h.sample_count, s);
+        bh::launch_minmax(d_seg, d_minmax, d_inbad, (int)n, (int)m.h.sample_count, s);
         ctx_mark(ctx, ST_MINMAX);
-        bh::launch_mel(d_seg, ctx->d_minmax, T(0), c->fe, c->d_fe, (int)n, s);
+        bh::launch_mel(d_seg, d_minmax, T(0), c->fe, c->d_fe, (int)n, s);
         ctx_mark(ctx, ST_MEL);
     }
     for (uint32_t i = 0; i < nl; i++) {
@@ -462,7 +497,7 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
     if (d_idx && d_conf) {
         bh::TraceRange tr("topk");
         bh::launch_topk(d_logits, (int)n, (int)m.h.n_classes, (int)m.h.output_activation, (int)c->top_k,
-                        c->min_conf, c->filter, d_idx, d_conf, ctx->d_inbad, ctx->d_nonfinite, s);
+                        c->min_conf, c->filter, d_idx, d_conf, d_inbad, ctx->d_nonfinite, s);
         ctx_mark(ctx, ST_TOPK);
     }
     HIPCHK(hipGetLastError());
@@ -507,19 +542,40 @@ unsigned copy_threads() {
 
 // Sub-slices of a host-fed slice: each is computed as soon as its own samples are on the copy stream.  A forward has a floor of
 // about a millisecond however few segments it holds (21 launches whose workgroups walk their chunk loops serially) and the late
-// blocks need >= 128 segments to fill the GPU.  Which split is best depends on which side is the longer one (a small pipeline
-// model, upload 55 GB/s, forward 0.85 ms + t per segment; measured in DESIGN.md section 6):
-//   * the upload is SHORTER than the compute (PCM16 mono into the v2.4-shaped model: 5.2 against 6.3 us per segment; anything
-//     into the Perch-sized one): few sub-slices of GROWING size -- a small first one starts the compute stream early, the last,
-//     more than half of the slice, runs at the full-batch rate while nothing is left to upload: (1/8, 1/3, rest) = 9.5 ms per
-//     1 000 segments against 11.0 for four quarters;
-//   * the upload is LONGER (f32 segments: 10.5 us): the forward of the last sub-slice is all that is left after the last byte
-//     has arrived, so it must be small: equal quarters (12.9 ms against 14.8 for the growing split).
+// blocks need >= 128 segments to fill the GPU.
+//   * `lanes` (the normal case, lanes_begin below: sub-slices alternate between the context's compute streams, so one's launch
+//     chain runs under another's kernels): EQUAL sub-slices of an eighth of the slice, at least 128 segments -- the first one
+//     starts the device after 1/8 of the upload, and the floors overlap (measured, 1 000 PCM16 segments from pinned memory:
+//     8 sub-slices on 3 lanes 8.8 ms, 6 on 2 lanes 9.1, 4 on 2 lanes 9.5, round 3's growing split in sequence 10.4;
+//     12 sub-slices of 84 segments 10.4 again).
+//   * in sequence on one stream (profiling / debug contexts, the resampling path, BIRDA_HIP_LANES=0) the split depends on which side
+//     is the longer one (a small pipeline model, upload 55 GB/s, forward 0.85 ms + t per segment):
+//       - the upload is SHORTER than the compute (PCM16 mono into the v2.4-shaped model: 5.2 against 6.3 us per segment; anything
+//         into the Perch-sized one): few sub-slices of GROWING size -- a small first one starts the compute stream early, the last,
+//         more than half of the slice, runs at the full-batch rate while nothing is left to upload: (1/8, 1/3, rest) = 9.5 ms per
+//         1 000 segments against 11.0 for four quarters;
+//       - the upload is LONGER (f32 segments: 10.5 us): the forward of the last sub-slice is all that is left after the last byte
+//         has arrived, so it must be small: equal quarters (12.9 ms against 14.8 for the growing split).
 // Boundaries are multiples of `align` segments.
-std::vector<size_t> sub_slice_cuts(const bh_classifier *c, size_t nb, size_t align, bool single, size_t bytes_per_segment) {
+bool lanes_possible(const bh_batch_context *ctx) {
+    static const bool off = getenv("BIRDA_HIP_LANES") && getenv("BIRDA_HIP_LANES")[0] == '0';
+    return !off && !ctx->profiling && !ctx->keep_tensors && ctx->n_lanes >= 2;
+}
+std::vector<size_t> sub_slice_cuts(const bh_classifier *c, size_t nb, size_t align, bool single, size_t bytes_per_segment, bool lanes = false,
+                                   uint32_t ctx_forced = 0) {
     std::vector<size_t> cuts;
+    static const int env_forced = getenv("BIRDA_HIP_SUBSLICES") ? atoi(getenv("BIRDA_HIP_SUBSLICES")) : 0;   // (A/B aid: n equal sub-slices)
+    const int forced = ctx_forced ? (int)ctx_forced : env_forced;
+    auto up = [&](size_t v) { return std::min(nb, (v + align - 1) / align * align); };
+    if (forced == 1) {
+    } else if (!single && forced > 1 && nb >= 256) {
+        const size_t sub = up((nb + forced - 1) / forced);
+        for (size_t v = sub; v < nb; v += sub) cuts.push_back(v);
+    } else if (!single && lanes && nb >= 256) {
+        const size_t sub = up(std::max<size_t>(128, (nb + 7) / 8));
+        for (size_t v = sub; v + 64 <= nb; v += sub) cuts.push_back(v);   // (a tail under 64 segments joins the last sub-slice)
+    } else
     if (!single && nb >= 512) {
-        auto up = [&](size_t v) { return std::min(nb, (v + align - 1) / align * align); };
         const double upload_us = (double)bytes_per_segment / 55e3;
         const double compute_us = (2.0 * (double)c->model.macs_per_segment() + (double)c->mel_flops) / 130e6;   // ~130 TFLOP/s over the whole forward
         if (upload_us < compute_us) {
@@ -533,6 +589,48 @@ std::vector<size_t> sub_slice_cuts(const bh_classifier *c, size_t nb, size_t ali
     }
     cuts.push_back(nb);
     return cuts;
+}
+
+// The sub-slices of one host-fed slice as concurrent lanes: the plan of each sub-slice's own size, side by side in the arena,
+// alternating between the context's two compute streams.  A forward is a chain of 21 dependent launches (~0.85 ms however few
+// segments it holds, and the late blocks need >= 128 segments to fill the chip); one after the other on one stream the chains of
+// three sub-slices were 2.5 ms of a 10.4 ms slice.  False -- run them in sequence on the context's stream, as before -- for
+// single-slice calls, profiling / debug contexts, BIRDA_HIP_LANES=0, or if the plans do not fit the arena.
+bool lanes_begin(bh_classifier *c, bh_batch_context *ctx, const std::vector<size_t> &cuts, std::vector<SliceLane> &lanes) {
+    lanes.clear();
+    if (cuts.size() < 2 || !lanes_possible(ctx)) return false;
+    if (ctx->plans.size() > 64) ctx->plans.clear();
+    size_t base = 0;
+    for (size_t si = 0; si < cuts.size(); si++) {
+        const size_t s0 = si ? cuts[si - 1] : 0, ns = cuts[si] - s0;
+        auto it = ctx->plans.find(ns);
+        if (it == ctx->plans.end()) {
+            bh_batch_context::ArenaPlan p;
+            plan_arena(c->model, c->fused_at, c->head_gap, ns, false, p.t_off, p.total);
+            it = ctx->plans.emplace(ns, std::move(p)).first;
+        }
+        if (base + it->second.total > ctx->arena_cap) { lanes.clear(); return false; }
+        lanes.push_back({ctx->lane_stream[si % (size_t)ctx->n_lanes], ctx->d_arena + base, it->second.t_off.data(), s0});
+        base += align_up(it->second.total, 64);
+    }
+    // the other lanes' streams start behind everything enqueued on the context's stream so far
+    bool ok = hipEventRecord(ctx->fork_ev, ctx->stream) == hipSuccess;
+    for (int l = 1; ok && l < ctx->n_lanes; l++) ok = hipStreamWaitEvent(ctx->lane_stream[l], ctx->fork_ev, 0) == hipSuccess;
+    if (!ok) { (void)hipGetLastError(); lanes.clear(); }
+    return ok;
+}
+// ... and the context's stream continues behind them (result downloads, the next slice)
+hipError_t lanes_end(bh_batch_context *ctx, const std::vector<SliceLane> &lanes) {
+    if (lanes.empty()) return hipSuccess;
+    for (int l = 1; l < ctx->n_lanes; l++) {
+        hipError_t e = hipEventRecord(ctx->join_ev[l], ctx->lane_stream[l]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->join_ev[l], 0);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+void lanes_sync(bh_batch_context *ctx) {
+    for (int l = 1; l < ctx->n_lanes; l++) (void)hipStreamSynchronize(ctx->lane_stream[l]);
 }
 
 // host slices -> results through ctx.
@@ -564,7 +662,10 @@ int predict_slices(bh_classifier *c, bh_batch_context *ctx, const float *const *
         const size_t nchunks = (nb + CH - 1) / CH;
         // sub-slices (sub_slice_cuts above), in whole chunks; debug contexts keep one (bh_debug_read_tensor reads the last)
         // (whole_slice: the caller reads an arena tensor of the slice afterwards -- the embeddings of the two-stage path)
-        const std::vector<size_t> cuts = sub_slice_cuts(c, nb, CH, ctx->keep_tensors || emb_out || whole_slice, S * sizeof(float));
+        const bool one = ctx->keep_tensors || emb_out || whole_slice;
+        std::vector<size_t> cuts = sub_slice_cuts(c, nb, CH, one, S * sizeof(float), lanes_possible(ctx), ctx->forced_sub_slices);
+        std::vector<SliceLane> lanes;
+        if (!lanes_begin(c, ctx, cuts, lanes) && cuts.size() > 1) cuts = sub_slice_cuts(c, nb, CH, one, S * sizeof(float), false, ctx->forced_sub_slices);
         const size_t nsub = cuts.size();
         while (ctx->copy_ev.size() < nsub) {
             hipEvent_t e;
@@ -599,14 +700,19 @@ int predict_slices(bh_classifier *c, bh_batch_context *ctx, const float *const *
                                ctx->copy_stream) != hipSuccess) { rc = fail(BH_ERR_HIP, "H2D copy failed"); break; }
             if (i1 == cuts[si_next]) {   // a sub-slice is complete on the copy stream: compute it
                 const size_t si = si_next++, s0 = si ? cuts[si - 1] : 0, ns = i1 - s0;
+                const SliceLane *lane = lanes.empty() ? nullptr : &lanes[si];
                 if (hipEventRecord(ctx->copy_ev[si], ctx->copy_stream) != hipSuccess ||
-                    hipStreamWaitEvent(ctx->stream, ctx->copy_ev[si], 0) != hipSuccess) { rc = fail(BH_ERR_HIP, "stream event failed"); break; }
+                    hipStreamWaitEvent(lane ? lane->s : ctx->stream, ctx->copy_ev[si], 0) != hipSuccess) { rc = fail(BH_ERR_HIP, "stream event failed"); break; }
                 rc = forward_slice(c, ctx, ctx->d_input + s0 * S, ns, ctx->d_logits + s0 * NC, ctx->d_topk_idx + s0 * TK,
-                                   ctx->d_topk_conf + s0 * TK);
+                                   ctx->d_topk_conf + s0 * TK, lane);
             }
         }
         for (auto &w : workers) w.join();
-        if (rc != BH_OK) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamSynchronize(ctx->stream); return rc; }
+        if (rc == BH_OK && lanes_end(ctx, lanes) != hipSuccess) rc = fail(BH_ERR_HIP, "stream event failed");
+        if (rc != BH_OK) {
+            (void)hipStreamSynchronize(ctx->copy_stream); lanes_sync(ctx); (void)hipStreamSynchronize(ctx->stream);
+            return rc;
+        }
         if (out) {
             HIPCHK(hipMemcpyAsync(ctx->h_topk_idx, ctx->d_topk_idx, nb * TK * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipMemcpyAsync(ctx->h_topk_conf, ctx->d_topk_conf, nb * TK * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -1352,6 +1458,7 @@ void bh_batch_context_destroy(bh_batch_context *ctx) {
     if (!ctx) return;
     bh_classifier *c = ctx->c;
     if (!ctx->keep_tensors && !ctx->profiling) {   // parked for the next create of this size (see bh_classifier::parked_ctx)
+        ctx->forced_sub_slices = 0;
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(ctx->stream);
         *ctx->h_nonfinite = 0;
@@ -1363,12 +1470,13 @@ void bh_batch_context_destroy(bh_batch_context *ctx) {
             bh_batch_context **slot = nullptr;
             for (bh_batch_context *&p : c->parked_ctx)
                 if (!p) { slot = &p; break; }
-            if (!slot) {      // both taken: the one of a different size goes, else the older (first) one
-                slot = &c->parked_ctx[0];
-                for (bh_batch_context *&p : c->parked_ctx)
-                    if (p->max_batch != ctx->max_batch) { slot = &p; break; }
-                old = *slot;
-                if (slot == &c->parked_ctx[0] && old->max_batch == ctx->max_batch) { c->parked_ctx[0] = c->parked_ctx[1]; slot = &c->parked_ctx[1]; }
+            if (!slot) {      // all taken: one of a different size goes, else the oldest (first) one; the newcomer is the youngest (last)
+                int gone = 0;
+                for (int i = 0; i < bh_classifier::N_PARKED; i++)
+                    if (c->parked_ctx[i]->max_batch != ctx->max_batch) { gone = i; break; }
+                old = c->parked_ctx[gone];
+                for (int i = gone; i + 1 < bh_classifier::N_PARKED; i++) c->parked_ctx[i] = c->parked_ctx[i + 1];
+                slot = &c->parked_ctx[bh_classifier::N_PARKED - 1];
             }
             *slot = ctx;
         }
@@ -1381,6 +1489,11 @@ size_t bh_batch_context_bytes(const bh_batch_context *ctx) {
     return ctx ? ctx->max_batch * (size_t)ctx->c->model.h.sample_count * sizeof(float) : 0;
 }
 size_t bh_batch_context_device_bytes(const bh_batch_context *ctx) { return ctx ? ctx->device_bytes : 0; }
+int bh_batch_context_set_sub_slices(bh_batch_context *ctx, uint32_t n) {
+    if (!ctx) return fail(BH_ERR_INVALID, "null batch context");
+    ctx->forced_sub_slices = n;
+    return BH_OK;
+}
 void *bh_batch_context_host_buffer(bh_batch_context *ctx, size_t *bytes) {
     if (bytes) *bytes = ctx ? bh_batch_context_bytes(ctx) : 0;
     return ctx ? ctx->h_input : nullptr;
@@ -1665,7 +1778,8 @@ size_t bh_segment_starts(size_t n_frames, size_t segment_samples, size_t overlap
 }
 
 static int predict_pcm16_core(bh_classifier *c, bh_batch_context *ctx, const void *pcm, uint32_t fmt, size_t n_frames, uint32_t channels,
-                              uint32_t source_rate, const std::vector<uint64_t> &starts, size_t seg, bh_result *out);
+                              uint32_t source_rate, const std::vector<uint64_t> &starts, size_t seg, bh_result *out,
+                              bh_rows_fn on_rows = nullptr, void *user = nullptr);
 static inline size_t pcm_bytes_per_sample(uint32_t fmt) { return fmt == BH_PCM_S16 ? 2 : fmt == BH_PCM_S24 ? 3 : (fmt == BH_PCM_S32 || fmt == BH_PCM_F32) ? 4 : 0; }
 
 int bh_predict_pcm16(bh_classifier *c, bh_batch_context *ctx, const int16_t *pcm, size_t n_frames, uint32_t channels,
@@ -1676,7 +1790,14 @@ int bh_predict_pcm16(bh_classifier *c, bh_batch_context *ctx, const int16_t *pcm
 
 int bh_predict_pcm(bh_classifier *c, bh_batch_context *ctx, const void *pcm, uint32_t sample_format, size_t n_frames, uint32_t channels,
                    uint32_t source_rate, size_t overlap_samples, bh_result *out, size_t out_cap, size_t *n_segments,
-                   uint64_t *start_samples) try {
+                   uint64_t *start_samples) {
+    return bh_predict_pcm_rows(c, ctx, pcm, sample_format, n_frames, channels, source_rate, overlap_samples, out, out_cap, n_segments,
+                               start_samples, nullptr, nullptr);
+}
+
+int bh_predict_pcm_rows(bh_classifier *c, bh_batch_context *ctx, const void *pcm, uint32_t sample_format, size_t n_frames, uint32_t channels,
+                        uint32_t source_rate, size_t overlap_samples, bh_result *out, size_t out_cap, size_t *n_segments,
+                        uint64_t *start_samples, bh_rows_fn on_rows, void *user) try {
     int rc = check_ctx(c, ctx);
     if (rc != BH_OK) return rc;
     if (!pcm || !out || !n_segments || channels == 0 || !pcm_bytes_per_sample(sample_format)) return fail(BH_ERR_INVALID, "predict_pcm: bad arguments");
@@ -1693,7 +1814,7 @@ int bh_predict_pcm(bh_classifier *c, bh_batch_context *ctx, const void *pcm, uin
     std::vector<uint64_t> starts(nseg);
     bh_segment_starts(n_frames, seg, ovl, starts.data(), nseg);
     if (start_samples) memcpy(start_samples, starts.data(), nseg * sizeof(uint64_t));
-    return predict_pcm16_core(c, ctx, pcm, sample_format, n_frames, channels, source_rate, starts, seg, out);
+    return predict_pcm16_core(c, ctx, pcm, sample_format, n_frames, channels, source_rate, starts, seg, out, on_rows, user);
 } catch (...) { return on_exception(); }
 
 int bh_predict_pcm16_at(bh_classifier *c, bh_batch_context *ctx, const int16_t *pcm, size_t n_frames, uint32_t channels,
@@ -1718,7 +1839,8 @@ int bh_predict_pcm_at(bh_classifier *c, bh_batch_context *ctx, const void *pcm, 
 } catch (...) { return on_exception(); }
 
 static int predict_pcm16_core(bh_classifier *c, bh_batch_context *ctx, const void *pcm, uint32_t fmt, size_t n_frames, uint32_t channels,
-                              uint32_t source_rate, const std::vector<uint64_t> &starts, size_t seg, bh_result *out) {
+                              uint32_t source_rate, const std::vector<uint64_t> &starts, size_t seg, bh_result *out,
+                              bh_rows_fn on_rows, void *user) {
     int rc = BH_OK;
     const auto &h = c->model.h;
     const bool resampling = source_rate != h.sample_rate;
@@ -1766,12 +1888,21 @@ static int predict_pcm16_core(bh_classifier *c, bh_batch_context *ctx, const voi
         char *stage = reinterpret_cast<char *>(ctx->h_input);
         const size_t PIECE = (size_t)8 << 20;
         const size_t npieces = (staged || pcm_pinned) ? (bytes + PIECE - 1) / PIECE : 1;
-        const std::vector<size_t> cuts = sub_slice_cuts(c, nb, 1, false, (size_t)((double)bytes / (double)nb));
+        const size_t bps = (size_t)((double)bytes / (double)nb);
+        const bool can_lane = !resampling && lanes_possible(ctx);   // (the resampler's scratch is one per context)
+        std::vector<size_t> cuts = sub_slice_cuts(c, nb, 1, false, bps, can_lane, ctx->forced_sub_slices);
+        std::vector<SliceLane> lanes;
+        if (can_lane && !lanes_begin(c, ctx, cuts, lanes) && cuts.size() > 1) cuts = sub_slice_cuts(c, nb, 1, false, bps, false, ctx->forced_sub_slices);
         const size_t nsub = cuts.size();
         while (ctx->copy_ev.size() < nsub) {
             hipEvent_t e;
             HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             ctx->copy_ev.push_back(e);
+        }
+        while (ctx->done_ev.size() < nsub) {
+            hipEvent_t e;
+            HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ctx->done_ev.push_back(e);
         }
         const unsigned nthreads = staged ? (unsigned)std::min<size_t>(copy_threads(), npieces) : 1;
         std::vector<std::atomic<int>> done(npieces);
@@ -1810,8 +1941,10 @@ static int predict_pcm16_core(bh_classifier *c, bh_batch_context *ctx, const voi
                 const size_t s0 = si ? cuts[si - 1] : 0, ns = cuts[si] - s0;
                 const size_t need = std::min<size_t>(n_frames, starts[b0 + s0 + ns - 1] + seg);
                 if (need > frames_sent && sent < bytes) break;   // its last frames are not on their way yet
+                const SliceLane *lane = lanes.empty() ? nullptr : &lanes[si];
+                hipStream_t ls = lane ? lane->s : ctx->stream;
                 if (hipEventRecord(ctx->copy_ev[si], ctx->copy_stream) != hipSuccess ||
-                    hipStreamWaitEvent(ctx->stream, ctx->copy_ev[si], 0) != hipSuccess) { rc = fail(BH_ERR_HIP, "stream event failed"); break; }
+                    hipStreamWaitEvent(ls, ctx->copy_ev[si], 0) != hipSuccess) { rc = fail(BH_ERR_HIP, "stream event failed"); break; }
                 float *d_in = ctx->d_input + s0 * h.sample_count;
                 if (resampling) {
                     float *d_rw = ctx->d_raw + s0 * seg;
@@ -1819,30 +1952,47 @@ static int predict_pcm16_core(bh_classifier *c, bh_batch_context *ctx, const voi
                     rc = bh_resample_device(c, ctx, d_rw, seg, seg, source_rate, h.sample_rate, d_in, h.sample_count, h.sample_count, ns);
                     if (rc != BH_OK) break;
                 } else {
-                    bh::launch_segment_pcm(d_origin, (int)fmt, n_frames, (int)channels, ctx->d_starts + b0 + s0, (int)ns, (int)seg, d_in, seg, ctx->stream);
+                    bh::launch_segment_pcm(d_origin, (int)fmt, n_frames, (int)channels, ctx->d_starts + b0 + s0, (int)ns, (int)seg, d_in, seg, ls);
                 }
                 rc = forward_slice(c, ctx, d_in, ns, ctx->d_logits + s0 * h.n_classes, ctx->d_topk_idx + s0 * c->top_k,
-                                   ctx->d_topk_conf + s0 * c->top_k);
+                                   ctx->d_topk_conf + s0 * c->top_k, lane);
+                // the sub-slice's rows follow its forward down the same stream: they are on the host -- and handed to the caller,
+                // below -- while the later sub-slices are still being computed
+                if (rc == BH_OK &&
+                    (hipMemcpyAsync(ctx->h_topk_idx + s0 * c->top_k, ctx->d_topk_idx + s0 * c->top_k, ns * c->top_k * sizeof(int32_t), hipMemcpyDeviceToHost, ls) != hipSuccess ||
+                     hipMemcpyAsync(ctx->h_topk_conf + s0 * c->top_k, ctx->d_topk_conf + s0 * c->top_k, ns * c->top_k * sizeof(float), hipMemcpyDeviceToHost, ls) != hipSuccess ||
+                     hipEventRecord(ctx->done_ev[si], ls) != hipSuccess))
+                    rc = fail(BH_ERR_HIP, "predict_pcm16: result download failed");
                 si++;
             }
         }
         for (auto &w : workers) w.join();
-        if (rc != BH_OK) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamSynchronize(ctx->stream); return rc; }
-        if (hipMemcpyAsync(ctx->h_topk_idx, ctx->d_topk_idx, nb * c->top_k * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            hipMemcpyAsync(ctx->h_topk_conf, ctx->d_topk_conf, nb * c->top_k * sizeof(float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-            fetch_nonfinite(ctx) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
-            return fail(BH_ERR_HIP, "predict_pcm16: result download failed");
-        for (size_t i = 0; i < nb; i++) {
-            bh_result &r = out[b0 + i];
-            r.n_pred = 0;
-            for (uint32_t k = 0; k < c->top_k; k++) {
-                const int32_t id = ctx->h_topk_idx[i * c->top_k + k];
-                if (id < 0) break;
-                r.index[r.n_pred] = id;
-                r.confidence[r.n_pred] = ctx->h_topk_conf[i * c->top_k + k];
-                r.n_pred++;
-            }
+        if (rc == BH_OK && lanes_end(ctx, lanes) != hipSuccess) rc = fail(BH_ERR_HIP, "stream event failed");
+        if (rc != BH_OK) {
+            (void)hipStreamSynchronize(ctx->copy_stream); lanes_sync(ctx); (void)hipStreamSynchronize(ctx->stream);
+            return rc;
         }
+        if (fetch_nonfinite(ctx) != hipSuccess) return fail(BH_ERR_HIP, "predict_pcm16: result download failed");
+        for (size_t sj = 0; sj < nsub; sj++) {
+            const size_t s0 = sj ? cuts[sj - 1] : 0, ns = cuts[sj] - s0;
+            if (hipEventSynchronize(ctx->done_ev[sj]) != hipSuccess) {
+                lanes_sync(ctx); (void)hipStreamSynchronize(ctx->stream);
+                return fail(BH_ERR_HIP, "predict_pcm16: result download failed");
+            }
+            for (size_t i = s0; i < s0 + ns; i++) {
+                bh_result &r = out[b0 + i];
+                r.n_pred = 0;
+                for (uint32_t k = 0; k < c->top_k; k++) {
+                    const int32_t id = ctx->h_topk_idx[i * c->top_k + k];
+                    if (id < 0) break;
+                    r.index[r.n_pred] = id;
+                    r.confidence[r.n_pred] = ctx->h_topk_conf[i * c->top_k + k];
+                    r.n_pred++;
+                }
+            }
+            if (on_rows) on_rows(user, b0 + s0, ns, out + b0 + s0, starts.data() + b0 + s0);
+        }
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(BH_ERR_HIP, "predict_pcm16: result download failed");
         const int nf = nonfinite_status(c, ctx);
         if (nf != BH_OK) return nf;
     }

@@ -28,6 +28,7 @@ void set_host_error(const std::string &msg);   // host_pipeline.cpp: the text bh
 
 Detection detection_from_label(const std::string &label, float conf, float start, float end, const std::string &file_path);
 std::string escape_csv(const std::string &v);
+void append_fixed(std::string &o, double v, int places);   // "{:.N}" of v, appended (host_output.cpp)
 std::string rust_display_f32(float v);
 std::string rust_display_f64(double v);
 std::string json_f32(float v);

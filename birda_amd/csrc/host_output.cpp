@@ -144,16 +144,49 @@ std::string escape_csv(const std::string &v) {
 
 // Detection::from_label -- types.rs:58-79
 Detection detection_from_label(const std::string &label, float conf, float start, float end, const std::string &file_path) {
-    Detection d{start, end, conf, label, label, file_path};
     const size_t us = label.find('_');
-    if (us != std::string::npos) { d.scientific_name = label.substr(0, us); d.common_name = label.substr(us + 1); }
-    return d;
+    if (us == std::string::npos) return Detection{start, end, conf, label, label, file_path};
+    return Detection{start, end, conf, label.substr(0, us), label.substr(us + 1), file_path};
 }
 
+// format!("{:.N}") of a value: printf's %.Nf (both round the exact binary value half to even).  Fast path: scale, round to an
+// integer and print its digits -- valid away from a rounding tie, where the double product and the exact one round alike (the
+// product's error is below 1e-7 for scaled values under 1e9); at or near a tie, and for anything unusual, printf decides on the
+// exact value.  A 1 000-segment file formats 15 000 numbers; through snprintf that was 2 ms of a 15 ms file.
+void append_fixed(std::string &o, double v, int places) {
+    static const double P10[] = {1.0, 10.0, 100.0, 1e3, 1e4, 1e5, 1e6};
+    if (places >= 0 && places <= 6 && std::isfinite(v)) {
+        const double scaled = std::fabs(v) * P10[places];
+        if (scaled < 1e9) {
+            const double r = std::nearbyint(scaled);
+            if (std::fabs(std::fabs(scaled - r) - 0.5) > 1e-6) {
+                uint64_t q = (uint64_t)r;
+                char b[32];
+                int n = 0;
+                for (int i = 0; i < places; i++) { b[n++] = (char)('0' + q % 10); q /= 10; }
+                if (places) b[n++] = '.';
+                do { b[n++] = (char)('0' + q % 10); q /= 10; } while (q);
+                if (std::signbit(v)) b[n++] = '-';
+                while (n) o.push_back(b[--n]);
+                return;
+            }
+        }
+    }
+    char b[400];   // (DBL_MAX has 309 integer digits)
+    const int n = snprintf(b, sizeof b, "%.*f", places, v);
+    o.append(b, (size_t)std::min<int>(std::max(n, 0), (int)sizeof b - 1));
+}
 static std::string fixed(double v, int places) {
-    char b[96];
-    snprintf(b, sizeof b, "%.*f", places, v);
-    return b;
+    std::string s;
+    append_fixed(s, v, places);
+    return s;
+}
+// escape_csv appended in place (the common case, nothing to quote, copies the field once)
+static void append_csv(std::string &o, const std::string &v) {
+    if (v.find_first_of(",\"\n") == std::string::npos) { o += v; return; }
+    o += '"';
+    for (char c : v) { if (c == '"') o += '"'; o += c; }
+    o += '"';
 }
 
 static std::string replace_all(std::string s, const std::string &from, const std::string &to) {
@@ -288,6 +321,8 @@ struct Writer {
     uint32_t selection_id = 0;              // Raven
     std::vector<Detection> kept;            // JSON / Parquet collect, then write at finalize
     bool failed = false;
+    size_t extra_columns = 0;               // CSV: additional (empty) cells per row
+    std::string row;                        // CSV: the row being built (reused)
     ~Writer() { if (f) fclose(f); }
     bool put(const std::string &s) {
         if (!f || fwrite(s.data(), 1, s.size(), f) != s.size()) { failed = true; return false; }
@@ -310,6 +345,7 @@ int writer_open(uint32_t format, const std::string &path, const WriterOptions &o
     if (!format_extension(format)) { err = "InvalidOutputFormat: unknown format bit"; return BH_ERR_INVALID; }
     auto w = std::make_unique<Writer>();
     w->format = format; w->path = path; w->opt = opt;
+    w->extra_columns = split_columns(opt.csv_columns).size();
     if (format != BHH_FORMAT_JSON && format != BHH_FORMAT_PARQUET) {   // those two create their file at finalize
         w->f = fopen(path.c_str(), "wb");
         if (!w->f) { err = "cannot create " + path; return BH_ERR_IO; }
@@ -339,10 +375,17 @@ int writer_detection(Writer &w, const Detection &d) {
     switch (w.format) {
     case BHH_FORMAT_CSV: {   // csv.rs:54-118; DetectionMetadata is all-None on this path (types.rs:69-78), so the extra
         // columns are empty cells
-        std::string row = fixed(d.start_time, 1) + "," + fixed(d.end_time, 1) + "," + escape_csv(d.scientific_name) + "," +
-                          escape_csv(d.common_name) + "," + fixed(d.confidence, 4) + "," + escape_csv(d.file_path);
-        for (size_t i = 0, n = split_columns(w.opt.csv_columns).size(); i < n; i++) row += ',';
-        return w.put(row + "\n") ? BH_OK : BH_ERR_IO;
+        std::string &row = w.row;
+        row.clear();
+        append_fixed(row, d.start_time, 1); row += ',';
+        append_fixed(row, d.end_time, 1); row += ',';
+        append_csv(row, d.scientific_name); row += ',';
+        append_csv(row, d.common_name); row += ',';
+        append_fixed(row, d.confidence, 4); row += ',';
+        append_csv(row, d.file_path);
+        row.append(w.extra_columns, ',');
+        row += '\n';
+        return w.put(row) ? BH_OK : BH_ERR_IO;
     }
     case BHH_FORMAT_RAVEN: {   // raven.rs:38-63; VIEW "Spectrogram 1", CHANNEL 1, 150 / 15000 Hz (constants.rs:300-309)
         w.selection_id++;

@@ -572,18 +572,29 @@ int run_device_front_end(bh_classifier *clf, const FilePlan &pl, const bh_model_
         const bool last = n_frames - f0 <= full_span;
         const size_t frames = last ? n_frames - f0 : full_span;
         size_t n_seg = 0;
+        // process_batch's per-batch work (threshold, Detection::from_label, progress; processor.rs:363-407) runs in the rows
+        // callback: on this thread, for each finished run of segments, while the device computes the later ones
+        struct Sink {
+            bh_classifier *clf; const FilePlan *pl; std::vector<Detection> *detections; size_t f0, limit; size_t *segments_done;
+            static void rows(void *user, size_t first, size_t n, const bh_result *r, const uint64_t *st) {
+                Sink &s = *static_cast<Sink *>(user);
+                for (size_t i = 0; i < n && first + i < s.limit; i++) {
+                    float t0, t1;
+                    chunk_times(*s.pl, s.f0 + (size_t)st[i], t0, t1);
+                    collect_detections(s.clf, *s.pl, r[i], t0, t1, *s.detections);
+                    report_progress(*s.pl, *s.segments_done);
+                }
+            }
+        } sink{clf, &pl, &detections, f0, last ? (size_t)-1 : span_segments, &segments_done};
         void *guard = bhh_watchdog_start(watchdog_timeout_secs() * 1000, std::min(pl.effective, span_segments));
-        const int r = bh_predict_pcm(clf, ctx, pcm + f0 * channels * bps, fmt, frames, channels, pl.source_rate, pl.overlap_samples, results.data(),
-                                     results.size(), &n_seg, starts.data());
+        int r;
+        try {
+            r = bh_predict_pcm_rows(clf, ctx, pcm + f0 * channels * bps, fmt, frames, channels, pl.source_rate, pl.overlap_samples, results.data(),
+                                    results.size(), &n_seg, starts.data(), &Sink::rows, &sink);
+        } catch (...) { bhh_watchdog_cancel(guard); throw; }
         bhh_watchdog_cancel(guard);
         if (r != BH_OK) { fail_msg = std::string("Inference: ") + bh_last_error(); return r; }
         const size_t keep = last ? n_seg : std::min(n_seg, span_segments);
-        for (size_t i = 0; i < keep; i++) {
-            float t0, t1;
-            chunk_times(pl, f0 + (size_t)starts[i], t0, t1);
-            collect_detections(clf, pl, results[i], t0, t1, detections);
-            report_progress(pl, segments_done);
-        }
         st.segments += keep;
         st.batches += (keep + pl.effective - 1) / pl.effective;
         if (last) break;
@@ -858,8 +869,8 @@ extern "C" int bhh_process_files(bh_classifier *clf, const bhh_processing_config
         const int rc = paths[i] ? bhh_process_file(clf, &c, &results[i]) : BH_ERR_INVALID;
         if (status) status[i] = rc;
     };
-    // Two packs in flight: while pack k's upload + forward run on a worker thread, this thread scatters and writes pack k - 1
-    // and plans and copies pack k + 1 into the other context's staging buffer.
+    // Several packs in flight: while the uploads + forwards of packs k and k - 1 run on their worker threads, this thread scatters
+    // and writes pack k - 2 and plans and copies pack k + 1 into a free context's staging buffer.
     struct Pack {
         std::vector<std::unique_ptr<PackedFile>> files;
         std::vector<uint64_t> starts;
@@ -871,14 +882,23 @@ extern "C" int bhh_process_files(bh_classifier *clf, const bhh_processing_config
         std::thread worker;
         ~Pack() { if (worker.joinable()) worker.join(); }   // (an exception on the way: never leave a running thread behind)
     };
-    bh_batch_context *ctx[2] = {nullptr, nullptr};
-    std::unique_ptr<bh_batch_context, void (*)(bh_batch_context *)> ctx_own0(nullptr, bh_batch_context_destroy), ctx_own1(nullptr, bh_batch_context_destroy);
+    // DEPTH packs in flight, each in its own batch context: with two, a pack's forward ran alone while this thread assembled the
+    // next one and wrote the previous one's outputs (4.6 ms of every 9: the device then works one launch chain at a time); with
+    // three there are always two forwards for the device to interleave (6 files of 1 000 segments: 96 k -> see DESIGN section 6)
+    constexpr int MAX_DEPTH = 4;
+    static const int DEPTH = [] {
+        const char *e = getenv("BIRDA_HOST_PIPELINE_DEPTH");
+        return e ? std::max(2, std::min(4, atoi(e))) : 3;
+    }();
+    bh_batch_context *ctx[MAX_DEPTH] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<std::unique_ptr<bh_batch_context, void (*)(bh_batch_context *)>> ctx_own;
     const bool timing = getenv("BIRDA_HOST_TIMING") != nullptr;   // diagnostic: where a call's time goes, to stderr
     double t_plan = 0, t_copy = 0, t_wait = 0, t_finish = 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
 
-    std::unique_ptr<Pack> building(new Pack), running;   // `running`: its forward is on the worker thread
+    std::unique_ptr<Pack> building(new Pack);
+    std::deque<std::unique_ptr<Pack>> running;           // forwards on their worker threads, oldest first
     size_t n_packs = 0;
 
     // scatter the rows of a finished pack back to its files: detections, sort, outputs, result records
@@ -922,16 +942,18 @@ extern "C" int bhh_process_files(bh_classifier *clf, const bhh_processing_config
         }
         t_finish += ms(t1, now());
     };
-    auto drain = [&]() {
-        if (running) { complete(*running); running.reset(); }
+    auto retire = [&](size_t keep) {   // finish the oldest packs until at most `keep` are in flight (outputs stay in file order)
+        while (running.size() > keep) { complete(*running.front()); running.pop_front(); }
     };
+    auto drain = [&]() { retire(0); };
     // assemble `building` in its slot's staging buffer, hand it to the worker, then finish the pack that ran before it
     auto flush = [&]() {
         if (building->files.empty()) return;
         std::unique_ptr<Pack> p = std::move(building);
         building.reset(new Pack);
         auto tp0 = now();
-        p->slot = (int)(n_packs++ & 1);
+        retire((size_t)DEPTH - 1);            // the slot this pack takes is free again
+        p->slot = (int)(n_packs++ % (size_t)DEPTH);
         const PackedFile &f0 = *p->files.front();
         p->seg = f0.pl.src_segment_samples; p->ch = f0.channels; p->rate = f0.pl.source_rate; p->fmt = f0.map.fmt; p->bps = f0.map.bps;
         for (auto &pf : p->files) { pf->base_frame = p->total_frames; p->total_frames += pf->map.n_frames + p->seg; p->total_segs += pf->n_segments; }
@@ -939,7 +961,11 @@ extern "C" int bhh_process_files(bh_classifier *clf, const bhh_processing_config
         if (!ctx[p->slot]) {
             int rc = bh_classifier_ensure_warm(clf, std::min<size_t>(pack_segments, 256));
             if (rc == BH_OK) rc = bh_batch_context_create(clf, pack_segments, &ctx[p->slot]);
-            if (rc == BH_OK) (p->slot ? ctx_own1 : ctx_own0).reset(ctx[p->slot]);
+            if (rc == BH_OK) ctx_own.emplace_back(ctx[p->slot], bh_batch_context_destroy);
+            // several packs in flight: another pack's forward covers this one's upload, so a pack runs as few, large sub-slices
+            // (measured, 8 files of 1 000 segments, three in flight: automatic split 97 k segments/s, two halves 112 k)
+            static const int sub = getenv("BIRDA_HOST_PACK_SUBSLICES") ? atoi(getenv("BIRDA_HOST_PACK_SUBSLICES")) : 2;
+            if (rc == BH_OK) (void)bh_batch_context_set_sub_slices(ctx[p->slot], (uint32_t)std::max(0, sub));
             p->rc = rc;
         }
         size_t cap = 0;
@@ -991,9 +1017,8 @@ extern "C" int bhh_process_files(bh_classifier *clf, const bhh_processing_config
                 bhh_watchdog_cancel(guard);
             });
         }
-        std::unique_ptr<Pack> prev = std::move(running);
-        running = std::move(p);
-        if (prev) complete(*prev);     // (its forward ended before this pack's began: one context's stream at a time per slot)
+        running.push_back(std::move(p));
+        retire((size_t)DEPTH - 1);
     };
 
     size_t pack_segs = 0;

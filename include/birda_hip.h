@@ -160,6 +160,12 @@ BH_API size_t bh_batch_context_bytes(const bh_batch_context *ctx);       /* inpu
  * a PCM16 stream assembled THERE and handed to bh_predict_batch_contig / bh_predict_pcm16(_at) go up without another host copy,
  * and a parked context keeps the allocation alive from file to file (a fresh 300-MB hipHostMalloc + hipHostFree costs 35 ms). */
 BH_API void *bh_batch_context_host_buffer(bh_batch_context *ctx, size_t *bytes);
+/* How the host-fed entry points split a slice of this context (bh_predict_batch*, bh_predict_pcm*): 0 = automatically (the
+ * default: sub-slices small enough that the device starts after an eighth of the upload, on the context's own streams), 1 = whole
+ * slices, n = n equal sub-slices.  A caller that keeps several contexts busy at once -- bhh_process_files, three packs in flight --
+ * overlaps one context's upload with another's forward itself, and a forward over the whole slice is the efficient one then.
+ * Results do not depend on it.  Reset to 0 when the context is destroyed (parked). */
+BH_API int bh_batch_context_set_sub_slices(bh_batch_context *ctx, uint32_t n);
 BH_API size_t bh_batch_context_device_bytes(const bh_batch_context *ctx); /* all device memory */
 /* A destroyed context is PARKED in its classifier (up to two) and handed to the next create of that size (or up to twice that
  * size): the per-file pipeline creates one per file (processor.rs:582-603), and 4 GB of hipMalloc + 576 MB of pinned staging cost
@@ -320,6 +326,17 @@ BH_API int bh_predict_pcm(bh_classifier *c, bh_batch_context *ctx, const void *p
                           size_t *n_segments, uint64_t *start_samples);
 BH_API int bh_predict_pcm_at(bh_classifier *c, bh_batch_context *ctx, const void *pcm, uint32_t sample_format, size_t n_frames,
                              uint32_t channels, uint32_t source_rate, const uint64_t *start_samples, size_t n_segments, bh_result *out);
+/* bh_predict_pcm with the rows handed over AS THEY COMPLETE: the stream is computed in sub-slices (a few hundred segments each,
+ * uploaded and classified one behind the other), and `on_rows` is called on the calling thread for each finished run of
+ * consecutive segments -- in order, rows = &out[first_segment], start_samples = their starts at the source rate -- while the
+ * device is still busy with the later ones.  This is where process_batch's per-batch work goes (thresholding, building and
+ * formatting detections, processor.rs:363-407): a 1 000-segment file's 5 000 detections are collected under the forward instead
+ * of after it.  Every row has been delivered exactly once when the call returns BH_OK; on an error some may not have been.
+ * The callback must not call back into this context and must not unwind into the library. */
+typedef void (*bh_rows_fn)(void *user, size_t first_segment, size_t n_segments, const bh_result *rows, const uint64_t *start_samples);
+BH_API int bh_predict_pcm_rows(bh_classifier *c, bh_batch_context *ctx, const void *pcm, uint32_t sample_format, size_t n_frames,
+                               uint32_t channels, uint32_t source_rate, size_t overlap_samples, bh_result *out, size_t out_cap,
+                               size_t *n_segments, uint64_t *start_samples, bh_rows_fn on_rows, void *user);
 /* The same with the segment starts given (frames, not decreasing, each < n_frames; a segment that runs past n_frames is zero
  * padded): several short recordings packed into ONE stream -- each followed by a segment's length of silence, so that its
  * trailing segment pads with zeros as next_segment does (decode.rs:188-196) -- go through one upload and one forward

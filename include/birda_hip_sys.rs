@@ -99,6 +99,8 @@ pub struct BhMultiConfig {
     pub gather: u32,
 }
 
+pub type bh_rows_fn = Option<unsafe extern "C" fn(user: *mut c_void, first_segment: usize, n_segments: usize, rows: *const BhResult, start_samples: *const u64)>;
+
 #[link(name = "birda_hip")]
 extern "C" {
     pub fn bh_device_count() -> c_int;
@@ -118,6 +120,7 @@ extern "C" {
     pub fn bh_batch_context_destroy(ctx: *mut BhBatchContext);
     pub fn bh_batch_context_bytes(ctx: *const BhBatchContext) -> usize;
     pub fn bh_batch_context_host_buffer(ctx: *mut BhBatchContext, bytes: *mut usize) -> *mut c_void;
+    pub fn bh_batch_context_set_sub_slices(ctx: *mut BhBatchContext, n: u32) -> c_int;
     pub fn bh_batch_context_device_bytes(ctx: *const BhBatchContext) -> usize;
     pub fn bh_classifier_trim(c: *mut BhClassifier) -> usize;
     pub fn bh_predict(c: *mut BhClassifier, segment: *const f32, n_samples: usize, out: *mut BhResult) -> c_int;
@@ -151,6 +154,7 @@ extern "C" {
     pub fn bh_predict_pcm16(c: *mut BhClassifier, ctx: *mut BhBatchContext, pcm: *const i16, n_frames: usize, channels: u32, source_rate: u32, overlap_samples: usize, out: *mut BhResult, out_cap: usize, n_segments: *mut usize, start_samples: *mut u64) -> c_int;
     pub fn bh_predict_pcm(c: *mut BhClassifier, ctx: *mut BhBatchContext, pcm: *const c_void, sample_format: u32, n_frames: usize, channels: u32, source_rate: u32, overlap_samples: usize, out: *mut BhResult, out_cap: usize, n_segments: *mut usize, start_samples: *mut u64) -> c_int;
     pub fn bh_predict_pcm_at(c: *mut BhClassifier, ctx: *mut BhBatchContext, pcm: *const c_void, sample_format: u32, n_frames: usize, channels: u32, source_rate: u32, start_samples: *const u64, n_segments: usize, out: *mut BhResult) -> c_int;
+    pub fn bh_predict_pcm_rows(c: *mut BhClassifier, ctx: *mut BhBatchContext, pcm: *const c_void, sample_format: u32, n_frames: usize, channels: u32, source_rate: u32, overlap_samples: usize, out: *mut BhResult, out_cap: usize, n_segments: *mut usize, start_samples: *mut u64, on_rows: bh_rows_fn, user: *mut c_void) -> c_int;
     pub fn bh_predict_pcm16_at(c: *mut BhClassifier, ctx: *mut BhBatchContext, pcm: *const i16, n_frames: usize, channels: u32, source_rate: u32, start_samples: *const u64, n_segments: usize, out: *mut BhResult) -> c_int;
     pub fn bh_resample(c: *mut BhClassifier, in_: *const f32, n_in: usize, from_rate: u32, to_rate: u32, out: *mut f32, out_cap: usize, n_out: *mut usize) -> c_int;
     pub fn bh_resample_output_len(n_in: usize, from_rate: u32, to_rate: u32, n_out: *mut usize) -> c_int;

@@ -12,6 +12,7 @@
 #include "../../include/birda_host.h"
 #include "../../birda_amd/csrc/model.hpp"
 #include "../../birda_amd/csrc/onnx_dense.hpp"
+#include "../../birda_amd/csrc/host_internal.hpp"
 
 // ---- stubs for the device library (never called by this driver) ----
 extern "C" {
@@ -29,6 +30,9 @@ int bh_predict_pcm16(bh_classifier *, bh_batch_context *, const int16_t *, size_
 int bh_predict_pcm(bh_classifier *, bh_batch_context *, const void *, uint32_t, size_t, uint32_t, uint32_t, size_t, bh_result *, size_t, size_t *, uint64_t *) { return BH_ERR_NO_DEVICE; }
 int bh_predict_pcm_at(bh_classifier *, bh_batch_context *, const void *, uint32_t, size_t, uint32_t, uint32_t, const uint64_t *, size_t, bh_result *) { return BH_ERR_NO_DEVICE; }
 size_t bh_segment_starts(size_t, size_t, size_t, uint64_t *, size_t) { return 0; }
+int bh_predict_pcm_rows(bh_classifier *, bh_batch_context *, const void *, uint32_t, size_t, uint32_t, uint32_t, size_t, bh_result *, size_t, size_t *, uint64_t *,
+                        bh_rows_fn, void *) { return BH_ERR_NO_DEVICE; }
+int bh_batch_context_set_sub_slices(bh_batch_context *, uint32_t) { return BH_OK; }
 void *bh_batch_context_host_buffer(bh_batch_context *, size_t *) { return nullptr; }
 int bh_predict_batch_two_stage(bh_classifier *, bh_batch_context *, bh_custom_classifier *, const float *const *, size_t, size_t, bh_result *, float *) { return BH_ERR_NO_DEVICE; }
 const char *bh_custom_classifier_label(const bh_custom_classifier *, uint32_t) { return nullptr; }
@@ -48,6 +52,35 @@ static void write_file(const std::string &path, const std::string &bytes) {
 
 int main(int argc, char **argv) {
     const std::string dir = argc > 1 ? argv[1] : "/tmp";
+    // 0. the writers' number formatting (append_fixed: an integer fast path beside printf) against printf itself: random floats,
+    //    exact ties of the rounding (x.x5, x.xxxx5 where representable), values around them, signs, zeros, the unusual
+    {
+        uint64_t rs = 0xd1b54a32d192ed03ull;
+        auto rnd = [&]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return rs; };
+        auto same = [&](double v, int places) {
+            std::string a;
+            bhh::append_fixed(a, v, places);
+            char b[400];
+            snprintf(b, sizeof b, "%.*f", places, v);
+            if (a != b) { fprintf(stderr, "append_fixed(%a, %d) = %s, printf says %s\n", v, places, a.c_str(), b); failures++; }
+        };
+        for (int it = 0; it < 200000; it++) {
+            const uint32_t bits = (uint32_t)rnd();
+            float f; memcpy(&f, &bits, 4);
+            const int places = it % 3 == 0 ? 1 : it % 3 == 1 ? 4 : (int)(rnd() % 8);
+            same((double)f, places);
+            same((double)(float)((double)(rnd() % 2000000) / 1000.0), places);          // times like the pipeline's
+            same((double)(float)((double)(rnd() % 100001) / 100000.0), 4);             // confidences
+            const double tie = ((double)(rnd() % 100000) + 0.5) / (it % 2 ? 10.0 : 10000.0);
+            same(tie, it % 2 ? 1 : 4);
+            same(std::nextafter(tie, 0.0), it % 2 ? 1 : 4);
+            same(std::nextafter(tie, 1e9), it % 2 ? 1 : 4);
+            same(-tie, it % 2 ? 1 : 4);
+        }
+        for (double v : {0.0, -0.0, 0.05, -0.04, 0.25, 0.35, 2.5, 1e9, 1e15, 1e300, -1e-300, 999999999.95, 0.99995, 0.00005})
+            for (int places = 0; places <= 7; places++) same(v, places);
+        same(std::nan(""), 1); same(INFINITY, 4); same(-INFINITY, 1);
+    }
     // 1. WAV headers: well-formed, truncated at every length, hostile chunk sizes
     std::string wav = "RIFF";
     put32(wav, 36 + 2000); wav += "WAVEfmt "; put32(wav, 16); put16(wav, 1); put16(wav, 2); put32(wav, 44100); put32(wav, 176400); put16(wav, 4); put16(wav, 16);

@@ -256,6 +256,22 @@ def test_pcm16_pipeline_with_sub_slices_matches_the_f32_entry_point(model_dir):
     for i, (a, b) in enumerate(zip(res, want)):
         assert [p.index for p in a.predictions] == [p.index for p in b.predictions], i
         assert np.allclose([p.confidence for p in a.predictions], [p.confidence for p in b.predictions], atol=2e-6), i
+    # bh_predict_pcm_rows: the same rows, handed over run by run as the sub-slices finish -- every segment exactly once, in
+    # order, with its start sample, and in more than one run per slice (the sub-slices of a 600-segment slice)
+    runs = []
+    res2, starts2 = clf.predict_pcm16(ctx, pcm, m.sample_rate, ovl, on_rows=lambda first, rows, st: runs.append((first, rows, st)))
+    assert starts2 == starts and len(runs) > 2
+    nxt = 0
+    for first, rows, st in runs:
+        assert first == nxt and len(rows) == len(st) > 0
+        assert st == starts[first: first + len(rows)]
+        for a, b in zip(rows, res[first: first + len(rows)]):
+            assert [p.index for p in a.predictions] == [p.index for p in b.predictions]
+            assert [p.confidence for p in a.predictions] == [p.confidence for p in b.predictions]
+        nxt += len(rows)
+    assert nxt == nseg
+    for a, b in zip(res2, res):
+        assert [(p.index, p.confidence) for p in a.predictions] == [(p.index, p.confidence) for p in b.predictions]
     ctx.close(); clf.close()
 
 

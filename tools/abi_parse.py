@@ -42,6 +42,8 @@ def c_class(decl_type: str, array: str | None, defines: dict) -> str:
     else:
         t = re.sub(r"\b(const|volatile|struct|enum)\b", " ", t)
         t = " ".join(t.split())
+        if t in defines.get("__fnptr__", ()):     # `typedef void (*name)(...)`: a function pointer
+            return "ptr" if array is None else f"ptr[{array}]"
         if t not in C_SCALARS:
             raise ValueError(f"unknown C type {decl_type!r}")
         cls = C_SCALARS[t]
@@ -49,6 +51,12 @@ def c_class(decl_type: str, array: str | None, defines: dict) -> str:
         n = defines[array] if array in defines else int(array)
         cls = f"{cls}[{n}]"
     return cls
+
+
+def fn_typedefs(text: str) -> dict:
+    """`typedef void (*name)(args);` -> {name: (return type, "args")} (comment-stripped text)"""
+    return {m.group(2): (" ".join(m.group(1).split()), " ".join(m.group(3).split()))
+            for m in re.finditer(r"typedef\s+([\w\s\*]+?)\(\s*\*\s*(\w+)\s*\)\s*\(([^;]*?)\)\s*;", text, flags=re.S)}
 
 
 def _split_c_declarators(body: str):
@@ -74,6 +82,7 @@ def parse_c_header(path: str, extra_defines: dict | None = None):
     defines = dict(extra_defines or {})
     defines.update(_c_defines(raw))
     text = strip_c_comments(raw)
+    defines["__fnptr__"] = set(defines.get("__fnptr__", ())) | set(fn_typedefs(text))
     structs = {}
     for m in re.finditer(r"typedef\s+struct\s*\{(.*?)\}\s*(\w+)\s*;", text, flags=re.S):
         structs[m.group(2)] = [(name, c_class(t, arr, defines)) for t, name, arr in _split_c_declarators(m.group(1))]
@@ -94,9 +103,12 @@ def parse_c_header(path: str, extra_defines: dict | None = None):
     return structs, functions, defines
 
 
+RUST_FN_ALIASES: set = set()      # `pub type name = Option<unsafe extern "C" fn(...)>;` seen by parse_rust
+
+
 def rust_class(t: str) -> str:
     t = " ".join(t.split())
-    if t.startswith("*"):
+    if t.startswith("*") or t in RUST_FN_ALIASES:
         return "ptr"
     m = re.match(r"^\[\s*(.+?)\s*;\s*(\d+)\s*\]$", t)
     if m:
@@ -129,6 +141,8 @@ def parse_rust(text: str):
     """Every `#[repr(C)] ... struct Name { field: type, ... }` and every `fn name(arg: type, ...) [-> type];` inside an
     `extern "C" { }` block -> (structs {Name: [(field, class)]}, functions {name: (ret, [args])})."""
     text = re.sub(r"//[^\n]*", " ", text)
+    for m in re.finditer(r"\btype\s+(\w+)\s*=\s*Option\s*<\s*(?:unsafe\s+)?extern", text):
+        RUST_FN_ALIASES.add(m.group(1))
     structs = {}
     for m in re.finditer(r"#\[repr\(C\)\](?:\s*#\[[^\]]*\])*\s*(?:pub\s+)?struct\s+(\w+)\s*\{(.*?)\}", text, flags=re.S):
         fields = []

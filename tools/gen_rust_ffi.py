@@ -27,6 +27,8 @@ RUST_OF = {"i8": "c_char", "u8": "u8", "i16": "i16", "u16": "u16", "i32": "i32",
 
 def rust_type(c_type: str, array, defines, opaque) -> str:
     t = " ".join(c_type.split())
+    if " ".join(re.sub(r"\bconst\b", " ", t).split()) in defines.get("__fnptr__", ()):
+        return " ".join(re.sub(r"\bconst\b", " ", t).split())      # a `pub type` alias emitted below
     stars = t.count("*")
     if stars:
         # walk the declarator right to left: `const float *const *` = pointer to const pointer to const float
@@ -60,6 +62,8 @@ def generate() -> str:
     defines = A._c_defines(raw)
     text = A.strip_c_comments(raw)
     opaque = re.findall(r"typedef\s+struct\s+(\w+)\s+\1\s*;", text)
+    fnptr = A.fn_typedefs(text)
+    defines["__fnptr__"] = set(fnptr)
     lines = [
         "// birda_hip_sys.rs -- GENERATED from include/birda_hip.h by tools/gen_rust_ffi.py; do not edit.",
         "// The raw `extern \"C\"` surface of libbirda_hip.so for src/inference/hip_backend.rs (INTEGRATION.md section 2).",
@@ -86,6 +90,14 @@ def generate() -> str:
             lines.append(f"    pub {name}: {rust_type(t, arr, defines, opaque)},")
         lines.append("}")
         lines.append("")
+    for name, (ret, args) in fnptr.items():
+        rargs = []
+        for a in args.split(","):
+            mm = re.match(r"^(.*?)(\**)\s*(\w+)$", a.strip())
+            rargs.append(f"{mm.group(3)}: {rust_type(mm.group(1) + mm.group(2), None, defines, opaque)}")
+        rret = "" if ret == "void" else f" -> {rust_type(ret, None, defines, opaque)}"
+        lines.append(f'pub type {name} = Option<unsafe extern "C" fn({", ".join(rargs)}){rret}>;')
+    lines.append("")
     lines.append('#[link(name = "birda_hip")]')
     lines.append('extern "C" {')
     for m in re.finditer(r"\bBH_API\s+([^;(]*?)(\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
