@@ -101,7 +101,9 @@ struct bh_classifier {
 
 struct bh_batch_context {
     bh_classifier *c = nullptr;
-    size_t max_batch = 0;
+    size_t max_batch = 0;        // what the buffers hold
+    size_t asked_batch = 0;      // what bh_batch_context_create was asked for (a parked context of up to twice that may serve it): the
+                                 // capacity the entry points enforce
     bool keep_tensors = false;
     bool keep_fused = false;   // BIRDA_HIP_KEEP_FUSED=1: a debug context still runs the fused blocks (their outputs are readable)
     hipStream_t stream = nullptr;
@@ -341,6 +343,7 @@ int ctx_create(bh_classifier *c, size_t max_batch, bool keep, bh_batch_context *
     auto ctx = std::make_unique<bh_batch_context>();
     ctx->c = c;
     ctx->max_batch = max_batch;
+    ctx->asked_batch = max_batch;
     ctx->keep_tensors = keep;
     if (const char *kf = getenv("BIRDA_HIP_KEEP_FUSED")) ctx->keep_fused = kf[0] == '1';
     const auto &m = c->model;
@@ -1429,6 +1432,7 @@ int bh_batch_context_create(bh_classifier *c, size_t max_batch, bh_batch_context
         if (pick) {
             *out = *pick;
             *pick = nullptr;
+            (*out)->asked_batch = max_batch;
             return BH_OK;
         }
     }
@@ -1521,7 +1525,7 @@ int bh_predict_batch_with_context(bh_classifier *c, bh_batch_context *ctx, const
     int rc = check_ctx(c, ctx);
     if (rc != BH_OK) return rc;
     if (!segments || !out) return fail(BH_ERR_INVALID, "predict_batch_with_context: null argument");
-    if (n > ctx->max_batch) return fail(BH_ERR_INVALID, "batch of %zu exceeds context capacity %zu", n, ctx->max_batch);
+    if (n > ctx->asked_batch) return fail(BH_ERR_INVALID, "batch of %zu exceeds context capacity %zu", n, ctx->asked_batch);
     if (n_samples != c->model.h.sample_count)
         return fail(BH_ERR_INVALID, "segment has %zu samples, model expects %u", n_samples, c->model.h.sample_count);
     return predict_slices(c, ctx, segments, nullptr, n, out, nullptr, nullptr);
@@ -1718,7 +1722,7 @@ int bh_predict_batch_source_rate(bh_classifier *c, bh_batch_context *ctx, const 
     } else {
         int rc0 = check_ctx(c, ctx);
         if (rc0 != BH_OK) return rc0;
-        if (n > ctx->max_batch) return fail(BH_ERR_INVALID, "batch of %zu exceeds context capacity %zu", n, ctx->max_batch);
+        if (n > ctx->asked_batch) return fail(BH_ERR_INVALID, "batch of %zu exceeds context capacity %zu", n, ctx->asked_batch);
     }
     HIPCHK(hipSetDevice(c->device));
     if (ctx->raw_len < n_src_samples) {
