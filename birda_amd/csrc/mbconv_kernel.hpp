@@ -432,59 +432,40 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
 
     mb_stamp(d.stamps, t_last, 0);
 
-    // The project accumulators start at bias + p_scale * residual, so the epilogue is nothing but stores.  The residual is fetched
-    // as ONE batch of unconditional 4-byte loads from clamped 32-bit offsets -- a row offset per accumulator row, a column offset
-    // per column tile; invalid rows / columns read a valid address and are replaced afterwards.  (Round 2 computed a 64-bit
-    // `row * Cout + col` and branched around every load: ~11 instructions and an exec-mask branch per element, 48 elements per lane
-    // in the late blocks, with vmcnt(0) waits between them wherever hipcc reused an address register.)
+    // The project accumulators start at bias + residual: those loads overlap the first chunk
+    // instead of stalling the epilogue, which is then nothing but stores.
     float *Yb = d.Y + (size_t)seg0 * d.Ho * d.Wo * Cout;
     const float *Rb = d.R ? d.R + (size_t)seg0 * d.Ho * d.Wo * Cout : nullptr;
-    const bool has_res = Rb != nullptr;   // (wave-uniform)
     f32x4 acco[MT_W][NT_W];
-    int coff[NT_W];
-    float biasv[NT_W];
 #pragma unroll
-    for (int j = 0; j < NT_W; j++) {
-        coff[j] = min((wn * NT_W + j) * 16 + li, Cout - 1);
-        biasv[j] = d.bp[coff[j]];
-    }
-    if (has_res) {
+    for (int i = 0; i < MT_W; i++) {
+        const int4 o4 = *reinterpret_cast<const int4 *>(&omap[(wm * MT_W + i) * 16 + 4 * kq]);
+        const int orow[4] = {o4.x, o4.y, o4.z, o4.w};
+        // (unconditional loads from clamped addresses, selected afterwards: inside `cond ? load : 0` every load waited for the
+        //  one before it)
 #pragma unroll
-        for (int i = 0; i < MT_W; i++) {
-            const int4 o4 = *reinterpret_cast<const int4 *>(&omap[(wm * MT_W + i) * 16 + 4 * kq]);
-            const int orow[4] = {o4.x, o4.y, o4.z, o4.w};
+        for (int j = 0; j < NT_W; j++) {
+            const int col = (wn * NT_W + j) * 16 + li, colc = min(col, Cout - 1);
+            if constexpr (MT_W * NT_W <= 8) {   // (the small-tile instantiations of the early blocks; with 30 accumulator tiles
+                                                //  that many loads in flight cost registers the late blocks do not have)
+                const float braw = d.bp[colc];
+                float rres[4] = {0.f, 0.f, 0.f, 0.f};
+                if (Rb) {   // (wave-uniform)
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int ro = __mul24(max(orow[r], 0), Cout);   // (rows x channels of a tile's segments: far below 2^31)
-#pragma unroll
-                for (int j = 0; j < NT_W; j++) acco[i][j][r] = Rb[(unsigned)(ro + coff[j])];
-            }
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < MT_W; i++)
-#pragma unroll
-            for (int j = 0; j < NT_W; j++) acco[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    // acc = bias + p_scale * residual.  The 8-wave kernels (one workgroup per CU: nobody else hides a round trip to HBM) do this
-    // in front of the first chunk's project phase, so the residual loads fly under its expand and depthwise phases.
-    auto acc_seed = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < MT_W; i++) {
-            const int4 o4 = *reinterpret_cast<const int4 *>(&omap[(wm * MT_W + i) * 16 + 4 * kq]);
-            const int orow[4] = {o4.x, o4.y, o4.z, o4.w};
-#pragma unroll
-            for (int j = 0; j < NT_W; j++) {
-                const bool colok = (wn * NT_W + j) * 16 + li < Cout;
-                const float bias = colok ? biasv[j] : 0.0f;
+                    for (int r = 0; r < 4; r++) rres[r] = Rb[(size_t)max(orow[r], 0) * Cout + colc];
+                }
+                const float bias = col < Cout ? braw : 0.0f;
 #pragma unroll
                 for (int r = 0; r < 4; r++)
-                    acco[i][j][r] = __builtin_fmaf((has_res && colok && orow[r] >= 0) ? acco[i][j][r] : 0.0f, p_scale, bias);
+                    acco[i][j][r] = __builtin_fmaf((col < Cout && orow[r] >= 0) ? rres[r] : 0.0f, p_scale, bias);
+            } else {
+                const float bias = col < Cout ? d.bp[col] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    acco[i][j][r] = __builtin_fmaf((Rb && col < Cout && orow[r] >= 0) ? Rb[(size_t)orow[r] * Cout + col] : 0.0f, p_scale, bias);
             }
         }
-    };
-    constexpr bool SEED_LATE = NW == 8;
-    if (!SEED_LATE || nchunks == 0) acc_seed();
+    }
 
     // P2 tasks: XB output pixels x 4 channels each.  The 16-channel-chunk instantiations have at most 256
     // = one per thread, so the first task's decomposition is done once here, not once per chunk.
@@ -862,7 +843,6 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
         mb_stamp(d.stamps, t_last, 5);
 
         // ---- P3: project -----------------------------------------------------------------
-        if (SEED_LATE && ch == 0) acc_seed();
         if (!(d.dbg & 4)) {
             if constexpr (P16) {
                 // fragment planes: [column tile]{hi: 64 lanes x 4 halves, lo: same}; k = 4 (lane >> 4) + 0..3
@@ -970,21 +950,17 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
     }
 
     // ---- epilogue: store (bias and residual are already in the accumulators) -------------------
-    // (32-bit offsets, one multiply per accumulator row: see the residual loads above)
 #pragma unroll
     for (int i = 0; i < MT_W; i++) {
         const int4 o4 = *reinterpret_cast<const int4 *>(&omap[(wm * MT_W + i) * 16 + 4 * kq]);
         const int orow[4] = {o4.x, o4.y, o4.z, o4.w};
-        int ro[4];
-#pragma unroll
-        for (int r = 0; r < 4; r++) ro[r] = __mul24(max(orow[r], 0), Cout);
 #pragma unroll
         for (int j = 0; j < NT_W; j++) {
             const int col = (wn * NT_W + j) * 16 + li;
             if (col >= Cout) continue;
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                if (orow[r] >= 0 && !(d.dbg & 32)) Yb[(unsigned)(ro[r] + col)] = PREC != 0 ? acco[i][j][r] * p_unscale : acco[i][j][r];
+                if (orow[r] >= 0 && !(d.dbg & 32)) Yb[(size_t)orow[r] * Cout + col] = PREC != 0 ? acco[i][j][r] * p_unscale : acco[i][j][r];
         }
     }
     mb_stamp(d.stamps, t_last, 7);
