@@ -117,6 +117,7 @@ struct bh_batch_context {
     hipStream_t lane_stream[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};   // [0] = stream
     hipEvent_t fork_ev = nullptr, join_ev[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
     int n_lanes = 3;
+    int lanes_in_use = 1;        // of the slice being enqueued
     struct ArenaPlan { std::vector<size_t> t_off; size_t total = 0; };
     std::map<size_t, ArenaPlan> plans;       // arena plan of an n-segment forward (n < max_batch), built on first use
     size_t arena_cap = 0;                    // floats allocated (arena_floats + slack for the lanes' alignment losses)
@@ -357,11 +358,7 @@ int ctx_create(bh_classifier *c, size_t max_batch, bool keep, bh_batch_context *
     ctx->arena_cap = ctx->arena_floats + 8 * 64 * (m.layers.size() + 1);
     HIPCHK(hipMalloc((void **)&ctx->d_arena, ctx->arena_cap * sizeof(float)));
     if (const char *e = getenv("BIRDA_HIP_NLANES")) ctx->n_lanes = std::max(1, std::min((int)bh_batch_context::MAX_LANES, atoi(e)));
-    ctx->lane_stream[0] = ctx->stream;
-    for (int l = 1; l < ctx->n_lanes; l++) {
-        HIPCHK(hipStreamCreateWithFlags(&ctx->lane_stream[l], hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&ctx->join_ev[l], hipEventDisableTiming));
-    }
+    ctx->lane_stream[0] = ctx->stream;   // (the other lanes' streams are created when a slice first needs them: lanes_begin)
     HIPCHK(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
     HIPCHK(hipMalloc((void **)&ctx->d_logits, max_batch * (size_t)m.h.n_classes * sizeof(float)));
     HIPCHK(hipMalloc((void **)&ctx->d_topk_idx, max_batch * c->top_k * sizeof(int32_t)));
@@ -603,6 +600,15 @@ bool lanes_begin(bh_classifier *c, bh_batch_context *ctx, const std::vector<size
     lanes.clear();
     if (cuts.size() < 2 || !lanes_possible(ctx)) return false;
     if (ctx->plans.size() > 64) ctx->plans.clear();
+    // streams for as many lanes as this slice has sub-slices, created on first use: the runtime maps a process's streams onto a few
+    // hardware queues (four by default) in creation order, and every stream that exists -- used or not -- shifts that mapping
+    const int want = (int)std::min<size_t>((size_t)ctx->n_lanes, cuts.size());
+    for (int l = 1; l < want; l++)
+        if (!ctx->lane_stream[l]) {
+            if (hipStreamCreateWithFlags(&ctx->lane_stream[l], hipStreamNonBlocking) != hipSuccess ||
+                hipEventCreateWithFlags(&ctx->join_ev[l], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+        }
+    ctx->lanes_in_use = want;
     size_t base = 0;
     for (size_t si = 0; si < cuts.size(); si++) {
         const size_t s0 = si ? cuts[si - 1] : 0, ns = cuts[si] - s0;
@@ -613,19 +619,19 @@ bool lanes_begin(bh_classifier *c, bh_batch_context *ctx, const std::vector<size
             it = ctx->plans.emplace(ns, std::move(p)).first;
         }
         if (base + it->second.total > ctx->arena_cap) { lanes.clear(); return false; }
-        lanes.push_back({ctx->lane_stream[si % (size_t)ctx->n_lanes], ctx->d_arena + base, it->second.t_off.data(), s0});
+        lanes.push_back({ctx->lane_stream[si % (size_t)want], ctx->d_arena + base, it->second.t_off.data(), s0});
         base += align_up(it->second.total, 64);
     }
     // the other lanes' streams start behind everything enqueued on the context's stream so far
     bool ok = hipEventRecord(ctx->fork_ev, ctx->stream) == hipSuccess;
-    for (int l = 1; ok && l < ctx->n_lanes; l++) ok = hipStreamWaitEvent(ctx->lane_stream[l], ctx->fork_ev, 0) == hipSuccess;
+    for (int l = 1; ok && l < want; l++) ok = hipStreamWaitEvent(ctx->lane_stream[l], ctx->fork_ev, 0) == hipSuccess;
     if (!ok) { (void)hipGetLastError(); lanes.clear(); }
     return ok;
 }
 // ... and the context's stream continues behind them (result downloads, the next slice)
 hipError_t lanes_end(bh_batch_context *ctx, const std::vector<SliceLane> &lanes) {
     if (lanes.empty()) return hipSuccess;
-    for (int l = 1; l < ctx->n_lanes; l++) {
+    for (int l = 1; l < ctx->lanes_in_use; l++) {
         hipError_t e = hipEventRecord(ctx->join_ev[l], ctx->lane_stream[l]);
         if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->join_ev[l], 0);
         if (e != hipSuccess) return e;
@@ -633,7 +639,8 @@ hipError_t lanes_end(bh_batch_context *ctx, const std::vector<SliceLane> &lanes)
     return hipSuccess;
 }
 void lanes_sync(bh_batch_context *ctx) {
-    for (int l = 1; l < ctx->n_lanes; l++) (void)hipStreamSynchronize(ctx->lane_stream[l]);
+    for (int l = 1; l < bh_batch_context::MAX_LANES; l++)
+        if (ctx->lane_stream[l]) (void)hipStreamSynchronize(ctx->lane_stream[l]);
 }
 
 // host slices -> results through ctx.
