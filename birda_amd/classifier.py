@@ -106,6 +106,10 @@ class BatchInferenceContext:
         self._h, self._borrowed = C.c_void_p(handle), True
         return self
 
+    def set_sub_slices(self, n: int):
+        """bh_batch_context_set_sub_slices: 0 automatic, 1 whole slices, n equal sub-slices (results do not depend on it)."""
+        check(self._L.bh_batch_context_set_sub_slices(self._h, n))
+
     def close(self):
         if getattr(self, "_h", None):
             if not getattr(self, "_borrowed", False):

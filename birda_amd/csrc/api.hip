@@ -80,6 +80,8 @@ struct bh_classifier {
     bh::FrontendParams *d_fe = nullptr;      // device copy read by the mel kernel
     std::vector<int> fused_at;               // per layer: index into mb (expand layer of a fused block) or -1
     std::vector<bh::MbDesc> mb;              // fused MBConv blocks (kernels_mbconv.hip)
+    int twin_max_segments = 256;             // launches up to this size take the twins (one workgroup per CU at most either way)
+    std::vector<bh::MbDesc> mb_small;        // per block: its small-launch twin (cfg < 0: none), same weights (mb_plan_twin)
     int precision = 0;                       // GEMM operands of the fused blocks: 0 f32, 3 f16 hi/lo split, 1 f16
     unsigned long long *d_stamps = nullptr;  // BIRDA_HIP_MB_STAMPS=1: [mb.size()][8] phase counters
     uint64_t mel_flops = 0;
@@ -437,7 +439,10 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
                          (int)L.in_layout, (int)L.act};
         if ((!ctx->keep_tensors || ctx->keep_fused) && c->fused_at[i] >= 0) {
             // expand (i) -> depthwise (i+1) -> project (i+2) in one launch
-            bh::MbDesc d = c->mb[c->fused_at[i]];
+            // (a launch of at most 256 segments: the one-segment-per-workgroup twin where the block has one -- the two-segment
+            //  tiles would leave half of the CUs, or more, without a workgroup)
+            const bh::MbDesc &twin = c->mb_small[c->fused_at[i]];
+            bh::MbDesc d = (twin.cfg >= 0 && n <= (size_t)c->twin_max_segments) ? twin : c->mb[c->fused_at[i]];
             const size_t ip = d.noexp ? i + 1 : i + 2;   // the project layer
             const auto &LP = m.layers[ip];
             d.X = in;
@@ -989,6 +994,13 @@ int plan_fusion(bh_classifier *c) {
         }
         c->fused_at[i] = (int)c->mb.size();
         c->mb.push_back(d);
+        {
+            bh::MbDesc tw{};
+            tw.cfg = -1;
+            static const bool no_twin = getenv("BIRDA_HIP_MB_TWIN") && getenv("BIRDA_HIP_MB_TWIN")[0] == '0';   // (A/B aid)
+            if (force_cfg < 0 && !no_twin && bh::mb_plan_twin(d, tw)) c->mb_small.push_back(tw);
+            else { tw.cfg = -1; c->mb_small.push_back(tw); }
+        }
         i += d.noexp ? 1 : 2;
     }
     return BH_OK;
@@ -1256,7 +1268,7 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) try {
     if (const char *st = getenv("BIRDA_HIP_MB_STAMPS"); st && st[0] == '1' && !c->mb.empty()) {
         HIPCHK(hipMalloc((void **)&c->d_stamps, c->mb.size() * 8 * sizeof(unsigned long long)));
         HIPCHK(hipMemset(c->d_stamps, 0, c->mb.size() * 8 * sizeof(unsigned long long)));
-        for (size_t i = 0; i < c->mb.size(); i++) c->mb[i].stamps = c->d_stamps + i * 8;
+        for (size_t i = 0; i < c->mb.size(); i++) { c->mb[i].stamps = c->d_stamps + i * 8; c->mb_small[i].stamps = c->mb[i].stamps; }
     }
     *out = c.release();
     return BH_OK;
@@ -1654,6 +1666,11 @@ int bh_plan_fused_blocks(const char *model_path, uint32_t flags, int32_t *cfgs, 
         if (!describe_fused_block(m, readers, i, precision, -1, d)) continue;
         if (n < cap) { if (cfgs) cfgs[n] = d.cfg; if (layers) layers[n] = (int32_t)i; }
         n++;
+        bh::MbDesc tw{};
+        if (bh::mb_plan_twin(d, tw)) {   // the block's small-launch twin is part of what the library must ship: listed behind it
+            if (n < cap) { if (cfgs) cfgs[n] = tw.cfg; if (layers) layers[n] = (int32_t)i; }
+            n++;
+        }
         i += d.noexp ? 1 : 2;
     }
     return (int)n;

@@ -189,6 +189,23 @@ bool mb_plan(MbDesc &d, int force_cfg) {
     return true;
 }
 
+// The small-batch twin of a planned block, if its configuration has one: the same chunk size, k steps, precision, activation and
+// project-tile count (so the weights plan_fusion laid out for `d` are the twin's too) with ONE segment per workgroup instead of two.
+bool mb_plan_twin(const MbDesc &d, MbDesc &twin) {
+    if (d.cfg < 0 || d.cfg >= kNCfgs) return false;
+    const MbCfg &c = kCfgs[d.cfg];
+    if (c.S != 2 || !c.COLTH || c.WM * c.WN != 8) return false;
+    const int k0 = (d.cfg / kNBase) * kNBase;   // the same activation's copy of the list
+    for (int b = 0; b < kNBase; b++) {
+        const MbCfg &q = kCfgs[k0 + b];
+        if (q.S != 1 || q.COLTH != c.COLTH || q.KS != c.KS || q.ST != c.ST || q.CE != c.CE || q.KG != c.KG || q.PREC != c.PREC ||
+            q.TWL != c.TWL || q.WM * q.WN != 8 || q.WN * q.NT_W != c.WN * c.NT_W || q.STEM != c.STEM || q.PERSIST) continue;
+        MbDesc t = d;
+        if (mb_try_th(t, k0 + b, q.TH) >= 0 && t.NTOP == d.NTOP && t.nchunks == d.nchunks && t.KG == d.KG && t.CE == d.CE) { twin = t; return true; }
+    }
+    return false;
+}
+
 void launch_mbconv(const MbDesc &d, int n_seg, hipStream_t s) { kCfgs[d.cfg].launch(d, n_seg, s); }
 
 }  // namespace bh

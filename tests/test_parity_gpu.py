@@ -376,6 +376,13 @@ def test_full_size_batch_properties(full_model, precision):
         clf.forward_device(ctx2, x.data_ptr(), 1000, logits2.data_ptr())
         ctx2.synchronize()
         assert torch.equal(logits, logits2)
+    # launches of more than 256 segments run the late blocks on two-segment tiles, smaller ones on their one-segment twins
+    # (mbconv_cfgs.inc 133-136, mb_plan_twin): the same bits either way
+    ctx3 = clf.create_batch_context(600)
+    clf.forward_device(ctx3, x.data_ptr(), 1000, logits2.data_ptr())
+    ctx3.synchronize()
+    assert torch.equal(logits, logits2)
+    ctx3.close()
     ii = idx.cpu().numpy(); cc = conf.cpu().numpy()
     assert ((ii >= -1) & (ii < m.n_classes)).all()
     valid = ii >= 0

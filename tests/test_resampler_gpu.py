@@ -272,6 +272,14 @@ def test_pcm16_pipeline_with_sub_slices_matches_the_f32_entry_point(model_dir):
     assert nxt == nseg
     for a, b in zip(res2, res):
         assert [(p.index, p.confidence) for p in a.predictions] == [(p.index, p.confidence) for p in b.predictions]
+    # bh_batch_context_set_sub_slices: however a slice is split -- whole, halves, five parts, back to automatic -- the rows are the
+    # same bits (every kernel of the forward is independent of the batch it runs in)
+    for n_sub in (1, 2, 5, 0):
+        ctx.set_sub_slices(n_sub)
+        res3, starts3 = clf.predict_pcm16(ctx, pcm, m.sample_rate, ovl)
+        assert starts3 == starts
+        for a, b in zip(res3, res):
+            assert [(p.index, p.confidence) for p in a.predictions] == [(p.index, p.confidence) for p in b.predictions], n_sub
     ctx.close(); clf.close()
 
 

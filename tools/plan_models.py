@@ -62,12 +62,18 @@ def survey(models=MODELS, acts=(None,)):
                 mf.write_model(p, m)
                 triples = fusable_triples(m)
                 for prec, flag in PRECISIONS.items():
-                    got = plan(p, flag)
+                    both = plan(p, flag)
+                    # (bh_plan_fused_blocks lists a block's small-launch twin -- one segment per workgroup, launches of <= 256
+                    #  segments -- right behind the block: same layer index)
+                    got, twins, seen = [], [], set()
+                    for l, c in both:
+                        (twins if l in seen else got).append((l, c))
+                        seen.add(l)
                     key = f"{kind}/{'default' if act is None else act}/{prec}"
                     starts = {l for l, _ in got}
                     # (a candidate whose depthwise layer heads a fused two-layer block is not a triple: its first layer has two readers)
-                    by_model[key] = {"fused": got, "unfused_triples": sorted(t for t in set(triples) - starts if t + 1 not in starts)}
-                    reach |= {c for _, c in got}
+                    by_model[key] = {"fused": got, "twins": twins, "unfused_triples": sorted(t for t in set(triples) - starts if t + 1 not in starts)}
+                    reach |= {c for _, c in both}
                 os.remove(p)
     return reach, by_model
 
@@ -80,7 +86,8 @@ def main():
         print(json.dumps({"reachable": sorted(reach), "by_model": by_model}))
         return
     for k, v in by_model.items():
-        print(f"{k:40s} fused {len(v['fused']):2d} {[c for _, c in v['fused']]}" + (f"  NOT fused at layers {v['unfused_triples']}" if v["unfused_triples"] else ""))
+        print(f"{k:40s} fused {len(v['fused']):2d} {[c for _, c in v['fused']]}" + (f"  twins {[c for _, c in v['twins']]}" if v["twins"] else "") +
+              (f"  NOT fused at layers {v['unfused_triples']}" if v["unfused_triples"] else ""))
     print("reachable configuration indices (activation copies folded):", sorted(reach))
 
 
