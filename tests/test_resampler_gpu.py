@@ -205,6 +205,18 @@ def test_pcm16_stream_is_segmented_scaled_and_mixed_on_the_device(oracle_lib, mo
         pcm = np.clip(np.round(x * 32767.0), -32768, 32767).astype(np.int16)
         ovl = int(np.float32(overlap_s) * np.float32(m.sample_rate))
         res, starts = clf.predict_pcm16(ctx, pcm if channels > 1 else pcm[:, 0], rate, ovl)
+        # bh_predict_pcm_rows over several slices of a 3-segment context, with and without the device resampler: every segment
+        # handed over once, in order, with the rows the plain call returns
+        runs = []
+        res_cb, starts_cb = clf.predict_pcm16(ctx, pcm if channels > 1 else pcm[:, 0], rate, ovl,
+                                              on_rows=lambda first, rows, st: runs.append((first, rows, st)))
+        assert starts_cb == starts and sum(len(r[1]) for r in runs) == len(res) and len(runs) >= (len(res) + 2) // 3
+        nxt = 0
+        for first, rows, st in runs:
+            assert first == nxt and st == starts[first: first + len(rows)]
+            for a, b in zip(rows, res[first: first + len(rows)]):
+                assert [(p.index, p.confidence) for p in a.predictions] == [(p.index, p.confidence) for p in b.predictions]
+            nxt += len(rows)
         # oracle: PCM scaling + mono mix, segmenter at the source rate, resample + resize, forward, top-k
         mono = np.zeros(n, np.float32)
         oracle_lib.lib().bo_pcm16_to_mono(pcm.ctypes.data, n, channels, mono)
