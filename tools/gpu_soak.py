@@ -1,5 +1,6 @@
 """Soak: the same batch through the same context N times must give bit-identical logits every time, and identical segments at
-different batch positions identical rows (races between waves / DMA pieces show up here first).  python tools/gpu_soak.py [kind] [reps]"""
+different batch positions identical rows (races between waves / DMA pieces show up here first).  python tools/gpu_soak.py [kind] [reps] [micro-batch]
+(micro-batch <= 256 runs the late blocks on their one-segment-per-workgroup twins, mbconv_cfgs.inc 133-136)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -17,7 +18,7 @@ for prec in ("f16x3", "f16"):
     order = np.arange(n) % 8
     x = torch.from_numpy(uniq[order]).cuda()
     logits = torch.empty((n, m.n_classes), device="cuda")
-    ctx = clf.create_batch_context(1000)
+    ctx = clf.create_batch_context(int(sys.argv[3]) if len(sys.argv) > 3 else 1000)
     clf.forward_device(ctx, x.data_ptr(), n, logits.data_ptr()); ctx.synchronize()
     ref = logits.clone()
     twins = sum(int((ref[order == k] != ref[k]).any(dim=1).sum()) for k in range(8))
