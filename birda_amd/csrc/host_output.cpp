@@ -323,10 +323,18 @@ struct Writer {
     bool failed = false;
     size_t extra_columns = 0;               // CSV: additional (empty) cells per row
     std::string row;                        // CSV: the row being built (reused)
-    ~Writer() { if (f) fclose(f); }
+    ~Writer() { if (f) { (void)flush_pending(); fclose(f); } }
+    std::string pending;                    // rows not yet handed to stdio (one fwrite per 256 KB, not one per row)
+    bool flush_pending() {
+        if (pending.empty()) return !failed;
+        if (!f || fwrite(pending.data(), 1, pending.size(), f) != pending.size()) failed = true;
+        pending.clear();
+        return !failed;
+    }
     bool put(const std::string &s) {
-        if (!f || fwrite(s.data(), 1, s.size(), f) != s.size()) { failed = true; return false; }
-        return true;
+        if (!f) { failed = true; return false; }
+        pending += s;
+        return pending.size() < (256u << 10) ? !failed : flush_pending();
     }
 };
 
@@ -465,6 +473,7 @@ int writer_finalize(Writer &w, std::string &err) {
         if (rc != BH_OK) return rc;
     }
     if (w.f) {
+        (void)w.flush_pending();
         if (fflush(w.f) != 0 || w.failed) rc = BH_ERR_IO;   // every sibling writer flushes explicitly (json.rs:196-209)
         if (fclose(w.f) != 0) rc = BH_ERR_IO;
         w.f = nullptr;
