@@ -436,6 +436,17 @@ def host_legs(clf, m, model_path, precision, tmp):
         ok_l = ok_l and not any(status_l)
     e2e["files_pipelined"] = {"what": "8 files of %d segments each through bhh_process_files (three in flight), median of 3 runs" % n,
                               "value": round(sorted(rates)[1], 1), "unit": "segments/s", "runs": [round(r, 1) for r in rates], "ok": ok_l}
+    # The same eight files in a process of its own -- one classifier and nothing else, which is what a birda process is.  The HIP
+    # runtime deals a process's streams onto a few hardware queues by what exists, and this process has
+    # created and destroyed dozens by now; a child process (started, never exec'ed into) shows the pipeline without that history.
+    try:
+        import subprocess
+        child = subprocess.run([sys.executable, os.path.abspath(__file__), "--child-files", model_path, labels, precision, out_l] + longs,
+                               capture_output=True, text=True, timeout=300)
+        got = json.loads(child.stdout.strip().splitlines()[-1]) if child.returncode == 0 and child.stdout.strip() else None
+    except Exception as ex:  # noqa: BLE001 -- a leg that cannot run is reported, not fatal
+        got = {"error": str(ex)[:200]}
+    e2e["files_pipelined_own_process"] = got
     c2.close()
     out["end_to_end"] = {"what": "bhh_process_file on a synthetic %d-segment PCM16 WAV -> CSV (reference metric: segments / wall seconds, "
                                  "processor.rs:771-788), default batch size" % n, **e2e}
@@ -832,5 +843,26 @@ def bench_inproc_multi(args, m, model_path, tmp, devices, n_total, scaling, work
     print(json.dumps(out), flush=True)
 
 
+def child_files(argv):
+    """`bench.py --child-files model labels precision out_dir wav...`: the files_pipelined leg in a process of its own (no torch)."""
+    model_path, labels, precision, out_dir, wavs = argv[0], argv[1], argv[2], argv[3], argv[4:]
+    from birda_amd import pipeline
+    from birda_amd.classifier import BirdClassifier
+    c = BirdClassifier(model_path, labels, top_k=5, min_confidence=0.1, precision=precision)
+    pipeline.process_files_packed(c, wavs, out_dir)
+    rates, ok = [], True
+    for _ in range(3):
+        t = time.perf_counter()
+        res, status = pipeline.process_files_packed(c, wavs, out_dir)
+        rates.append(sum(r.segments for r in res) / (time.perf_counter() - t))
+        ok = ok and not any(status)
+    c.close()
+    print(json.dumps({"what": "%d files through bhh_process_files in a process of its own, median of 3 runs" % len(wavs),
+                      "value": round(sorted(rates)[1], 1), "unit": "segments/s", "runs": [round(r, 1) for r in rates], "ok": ok}))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--child-files":
+        child_files(sys.argv[2:])
+    else:
+        main()
