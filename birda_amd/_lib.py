@@ -60,6 +60,7 @@ SYMBOLS = [
     ("bh_last_error", C.c_char_p, []),
     ("bh_select_provider", C.c_int, [C.c_char_p, C.c_int32, C.POINTER(BhProviderStatus)]),
     ("bh_classifier_provider_status", C.c_int, [_VP, C.POINTER(BhProviderStatus)]),
+    ("bh_classifier_fallback_segments", C.c_uint64, [_VP]),
     ("bh_default_batch_size", _SZ, [C.c_uint32, C.c_char_p]),
     ("bh_classifier_default_batch_size", _SZ, [_VP]),
     ("bh_classifier_create", C.c_int, [C.POINTER(BhConfig), C.POINTER(_VP)]),

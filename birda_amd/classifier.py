@@ -123,12 +123,16 @@ class BatchInferenceContext:
             pass
 
 
+# BH_FLAG_* (include/birda_hip.h): "auto" = split-f16 compute with rows that leave the f16 range re-run on the f32 kernels
+PRECISION_FLAGS = {"auto": 0, "f16x3": 1, "f16": 2, "f32": 3}
+
+
 class BirdClassifier:
     def __init__(self, model_path: str, labels_path: Optional[str] = None, top_k: int = DEFAULT_TOP_K,
                  min_confidence: float = DEFAULT_MIN_CONFIDENCE, device: int = 0, precision: str = "f32"):
         self._L = _lib.load()
         self._keep = (model_path.encode(), labels_path.encode() if labels_path else None)
-        flags = {"f32": 0, "f16x3": 1, "f16": 2}[precision]   # BH_FLAG_* (include/birda_hip.h)
+        flags = PRECISION_FLAGS[precision]   # BH_FLAG_* (include/birda_hip.h)
         cfg = BhConfig(self._keep[0], self._keep[1], top_k, min_confidence, device, flags)
         h = C.c_void_p()
         check(self._L.bh_classifier_create(C.byref(cfg), C.byref(h)))
@@ -180,6 +184,10 @@ class BirdClassifier:
         st = _lib.BhProviderStatus()
         check(self._L.bh_classifier_provider_status(self._h, C.byref(st)))
         return st
+
+    def fallback_segments(self) -> int:
+        """Segments BH_FLAG_AUTO has re-run on the f32 kernels so far."""
+        return int(self._L.bh_classifier_fallback_segments(self._h))
 
     def default_batch_size(self) -> int:
         """determine_default_batch_size (lib.rs:256-288) for this backend."""
@@ -285,11 +293,20 @@ class BirdClassifier:
                 rc = self._L.bh_predict_pcm16(self._h, ctx._h, a.ctypes.data, n_frames, channels, source_rate, overlap_samples,
                                               res, cap, C.byref(n), starts)
             else:
+                raised = []   # an exception inside the ctypes trampoline would only be printed: kept, and re-raised after the call
+
                 def _cb(_user, first, count, rows, st):
-                    on_rows(int(first), self._results(rows, int(count)), [int(st[i]) for i in range(int(count))])
+                    if raised:
+                        return
+                    try:
+                        on_rows(int(first), self._results(rows, int(count)), [int(st[i]) for i in range(int(count))])
+                    except BaseException as e:   # noqa: BLE001 -- handed back to the caller below
+                        raised.append(e)
                 cb = _lib.BhRowsFn(_cb)
                 rc = self._L.bh_predict_pcm_rows(self._h, ctx._h, a.ctypes.data, 1, n_frames, channels, source_rate, overlap_samples,
                                                  res, cap, C.byref(n), starts, cb, None)
+                if raised and not (rc != 0 and int(n.value) > cap):
+                    raise raised[0]
             if rc != 0 and int(n.value) > cap:
                 cap = int(n.value)
                 continue

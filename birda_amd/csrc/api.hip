@@ -83,6 +83,15 @@ struct bh_classifier {
     int twin_max_segments = 256;             // launches up to this size take the twins (one workgroup per CU at most either way)
     std::vector<bh::MbDesc> mb_small;        // per block: its small-launch twin (cfg < 0: none), same weights (mb_plan_twin)
     int precision = 0;                       // GEMM operands of the fused blocks: 0 f32, 3 f16 hi/lo split, 1 f16
+    // BH_FLAG_AUTO (the default): split-f16 compute, and a row whose logits come out inf / NaN from finite samples (an activation
+    // left the f16 range) is computed again on the library's own f32 kernels -- by `fb`, a second classifier of the same model
+    // file built with BH_FLAG_F32 the first time that happens.  The reference's dispatch never fails a batch on operand range
+    // (processor.rs:269-277) and its provider selection degrades with a recorded reason (classifier.rs:742-754).
+    bool auto_fallback = false;
+    std::string model_path;
+    bh_classifier *fb = nullptr;
+    std::mutex fb_mu;
+    std::atomic<unsigned long long> fallback_segments{0};
     unsigned long long *d_stamps = nullptr;  // BIRDA_HIP_MB_STAMPS=1: [mb.size()][8] phase counters
     uint64_t mel_flops = 0;
     bh::TopkFilter filter;                   // range filter / species list applied to the kept top-k (device tables below)
@@ -145,6 +154,10 @@ struct bh_batch_context {
     float *h_topk_conf = nullptr;
     unsigned *d_nonfinite = nullptr;   // segments whose logits came out inf / NaN from finite samples (top-k kernel), since the last check
     unsigned *h_nonfinite = nullptr;   // pinned
+    // bh_forward_device calls (with top-k buffers) since the last bh_batch_context_synchronize: what BH_FLAG_AUTO re-runs from
+    struct Pending { const float *d_seg; size_t n; float *d_logits; int32_t *d_idx; float *d_conf; };
+    std::vector<Pending> pending;
+    bool pending_overflow = false;
     size_t device_bytes = 0;
     size_t last_n = 0;
     const float *last_logits = nullptr;
@@ -523,8 +536,97 @@ int nonfinite_status(bh_classifier *c, bh_batch_context *ctx) {
     *ctx->h_nonfinite = 0;
     (void)hipMemsetAsync(ctx->d_nonfinite, 0, sizeof(unsigned), ctx->stream);
     return fail(BH_ERR_NONFINITE, "%u segment(s) with finite samples produced inf / NaN logits%s", bad,
-                c->precision != 0 ? ": an activation left the f16 operand range (|x| >= 65504); build the classifier with BH_FLAG_F32 for this model"
+                c->precision != 0 ? ": an activation left the f16 operand range (|x| >= 65504); build the classifier with BH_FLAG_AUTO (the default: such rows are re-run in f32) or BH_FLAG_F32"
                                   : " (f32 overflow inside the network)");
+}
+
+void clear_nonfinite(bh_batch_context *ctx) {
+    *ctx->h_nonfinite = 0;
+    (void)hipMemsetAsync(ctx->d_nonfinite, 0, sizeof(unsigned), ctx->stream);
+}
+
+// ---- BH_FLAG_AUTO: the rows the split-f16 forward could not represent, again on the f32 kernels -----------------------------
+constexpr uint32_t FLAG_INTERNAL_NO_ENV = 0x80000000u;   // (the fallback classifier: BIRDA_HIP_PRECISION must not turn it into f16 again)
+int internal_ctx(bh_classifier *c, size_t n, bh_batch_context **out);
+
+int fallback_classifier(bh_classifier *c, bh_classifier **out) {
+    std::lock_guard<std::mutex> g(c->fb_mu);
+    if (!c->fb) {
+        bh_config cfg{};
+        cfg.model_path = c->model_path.c_str();
+        cfg.labels_path = nullptr;
+        cfg.top_k = c->top_k; cfg.min_confidence = c->min_conf; cfg.device = c->device;
+        cfg.flags = BH_FLAG_F32 | FLAG_INTERNAL_NO_ENV;
+        const int rc = bh_classifier_create(&cfg, &c->fb);
+        if (rc != BH_OK) { c->fb = nullptr; return rc; }
+    }
+    *out = c->fb;
+    return BH_OK;
+}
+
+// Rows `bad` of one forward (inputs d_seg [.][sample_count], outputs as given; d_idx / d_conf / d_emb nullable) computed again by
+// the f32 classifier and written over the split-f16 ones.  The caller has synchronised whatever produced those rows.  Top-k
+// goes through the PRIMARY classifier's filters (range filter / species list / BSG: device tables of the same device).
+int redo_rows_f32(bh_classifier *c, const float *d_seg, const std::vector<size_t> &bad, float *d_logits, int32_t *d_idx, float *d_conf,
+                  float *d_emb) {
+    if (bad.empty()) return BH_OK;
+    bh_classifier *fb = nullptr;
+    int rc = fallback_classifier(c, &fb);
+    if (rc != BH_OK) return rc;
+    std::lock_guard<std::mutex> g(fb->internal_mu);
+    const auto &h = c->model.h;
+    const size_t S = h.sample_count, NC = h.n_classes, TK = c->top_k, ED = h.embedding_dim;
+    fb->filter = c->filter;
+    fb->min_conf = c->min_conf;
+    constexpr size_t CH = 64;
+    bh_batch_context *fx = nullptr;
+    rc = internal_ctx(fb, std::min(bad.size(), CH), &fx);
+    if (rc != BH_OK) return rc;
+    for (size_t q0 = 0; q0 < bad.size(); q0 += CH) {
+        const size_t nq = std::min(CH, bad.size() - q0);
+        for (size_t j = 0; j < nq; j++)
+            HIPCHK(hipMemcpyAsync(fx->d_input + j * S, d_seg + bad[q0 + j] * S, S * sizeof(float), hipMemcpyDeviceToDevice, fx->stream));
+        rc = forward_slice(fb, fx, fx->d_input, nq, fx->d_logits, fx->d_topk_idx, fx->d_topk_conf);
+        if (rc != BH_OK) return rc;
+        const float *f_emb = (d_emb && ED) ? fx->d_arena + fx->t_off[h.embedding_tensor] : nullptr;
+        for (size_t j = 0; j < nq; j++) {
+            const size_t i = bad[q0 + j];
+            if (d_logits) HIPCHK(hipMemcpyAsync(d_logits + i * NC, fx->d_logits + j * NC, NC * sizeof(float), hipMemcpyDeviceToDevice, fx->stream));
+            if (d_idx) HIPCHK(hipMemcpyAsync(d_idx + i * TK, fx->d_topk_idx + j * TK, TK * sizeof(int32_t), hipMemcpyDeviceToDevice, fx->stream));
+            if (d_conf) HIPCHK(hipMemcpyAsync(d_conf + i * TK, fx->d_topk_conf + j * TK, TK * sizeof(float), hipMemcpyDeviceToDevice, fx->stream));
+            if (f_emb) HIPCHK(hipMemcpyAsync(d_emb + i * ED, f_emb + j * ED, ED * sizeof(float), hipMemcpyDeviceToDevice, fx->stream));
+        }
+        HIPCHK(fetch_nonfinite(fx));
+        HIPCHK(hipStreamSynchronize(fx->stream));
+        if (*fx->h_nonfinite) {
+            const unsigned n_bad = *fx->h_nonfinite;
+            clear_nonfinite(fx);
+            return fail(BH_ERR_NONFINITE, "%u segment(s) with finite samples produced inf / NaN logits on the f32 kernels too (f32 overflow inside the network)", n_bad);
+        }
+    }
+    c->fallback_segments += bad.size();
+    return BH_OK;
+}
+
+// Rows [r0, r0 + nr) of a host-fed slice whose results are in the context's buffers (inputs in ctx->d_input, host copies of the
+// top-k rows in h_topk_*), after the synchronise that ended the slice: under BH_FLAG_AUTO the rows the top-k stage marked
+// (BH_TOPK_NONFINITE in their first slot) are re-run and their host copies refreshed; *redone says whether any were.
+int settle_rows(bh_classifier *c, bh_batch_context *ctx, size_t r0, size_t nr, float *d_emb, bool *redone) {
+    *redone = false;
+    if (!c->auto_fallback) return BH_OK;
+    const size_t TK = c->top_k;
+    std::vector<size_t> bad;
+    for (size_t i = r0; i < r0 + nr; i++)
+        if (ctx->h_topk_idx[i * TK] == BH_TOPK_NONFINITE) bad.push_back(i);
+    if (bad.empty()) return BH_OK;
+    const int rc = redo_rows_f32(c, ctx->d_input, bad, ctx->d_logits, ctx->d_topk_idx, ctx->d_topk_conf, d_emb);
+    if (rc != BH_OK) return rc;
+    for (size_t i : bad) {
+        HIPCHK(hipMemcpy(ctx->h_topk_idx + i * TK, ctx->d_topk_idx + i * TK, TK * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(ctx->h_topk_conf + i * TK, ctx->d_topk_conf + i * TK, TK * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    *redone = true;
+    return BH_OK;
 }
 
 int check_ctx(bh_classifier *c, bh_batch_context *ctx) {
@@ -746,8 +848,21 @@ int predict_slices(bh_classifier *c, bh_batch_context *ctx, const float *const *
         if (emb_out)
             HIPCHK(hipMemcpyAsync(emb_out + b0 * m.h.embedding_dim, ctx->d_arena + ctx->t_off[m.h.embedding_tensor],
                                   nb * (size_t)m.h.embedding_dim * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        if (!out && c->auto_fallback)   // (logits-only calls: the marks of the top-k rows are how the bad rows are found)
+            HIPCHK(hipMemcpyAsync(ctx->h_topk_idx, ctx->d_topk_idx, nb * TK * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(fetch_nonfinite(ctx));
         HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (*ctx->h_nonfinite && c->auto_fallback) {   // BH_FLAG_AUTO: those rows again, on the f32 kernels
+            bool redone = false;
+            float *d_emb = (emb_out || whole_slice) ? ctx->d_arena + ctx->t_off[m.h.embedding_tensor] : nullptr;
+            const int rr = settle_rows(c, ctx, 0, nb, d_emb, &redone);
+            if (rr != BH_OK) return rr;
+            clear_nonfinite(ctx);
+            if (redone && logits_out) HIPCHK(hipMemcpy(logits_out + b0 * NC, ctx->d_logits, nb * NC * sizeof(float), hipMemcpyDeviceToHost));
+            if (redone && emb_out)
+                HIPCHK(hipMemcpy(emb_out + b0 * m.h.embedding_dim, ctx->d_arena + ctx->t_off[m.h.embedding_tensor],
+                                 nb * (size_t)m.h.embedding_dim * sizeof(float), hipMemcpyDeviceToHost));
+        }
         if (out)
             for (size_t i = 0; i < nb; i++) {
                 bh_result &r = out[b0 + i];
@@ -760,7 +875,7 @@ int predict_slices(bh_classifier *c, bh_batch_context *ctx, const float *const *
                     r.n_pred++;
                 }
             }
-        const int nf = nonfinite_status(c, ctx);   // the rows are filled (NaN logits are never chosen); the call still fails
+        const int nf = nonfinite_status(c, ctx);   // the rows are filled (marked rows come out empty); the call still fails
         if (nf != BH_OK) return nf;
     }
     return BH_OK;
@@ -906,7 +1021,15 @@ int plan_fusion(bh_classifier *c) {
             d.gelu = bh::GeluScaled{gc[0], gc[1], gc[2], gc[3], gc[4]};
         }
 #endif
-        d.e_unscale = std::ldexp(1.0f, -se); d.p_scale = std::ldexp(1.0f, sp); d.p_unscale = std::ldexp(1.0f, -sp);
+        // ... and both GELUs of such a block leave TWICE their value (gelu2x_fast4, kernels.hpp): the expand one's factor joins the
+        // 2^-se in the depthwise taps (x2e), the depthwise one's raises the exponent the project accumulators live at (x2d).
+        int x2e = 0, x2d = 0;
+#if BH_GELU_DEGREE == 5
+        if (h16 && d.act_d == bh::ACT_GELU_ERF) x2d = 1;
+        x2e = d.e_fold;
+#endif
+        const int spa = sp + x2d;   // the project accumulators hold 2^spa times the output
+        d.e_unscale = std::ldexp(1.0f, -se); d.p_scale = std::ldexp(1.0f, spa); d.p_unscale = std::ldexp(1.0f, -spa);
         const size_t frag = h16 ? 512 : 256, psteps = h16 ? (CE + 31) / 32 : NTE;
         const bool p16 = h16 && CE == 16;   // project GEMM as one 16-deep step: [column tile]{hi, lo}[64 lanes][4 halves]
         const size_t we_fl = (size_t)KG * NTE * frag + CE, wp_fl = p16 ? (size_t)NTOP * 256 : psteps * NTOP * frag, wd_fl = (size_t)KK * CE + CE;
@@ -977,7 +1100,7 @@ int plan_fusion(bh_classifier *c) {
                     }
             for (int tap = 0; tap < KK; tap++)
                 for (int n = 0; n < CE; n++)
-                    wdf[ch * wd_fl + (size_t)tap * CE + n] = ch * CE + n < d.Cexp ? std::ldexp(Wd[(size_t)tap * d.Cexp + ch * CE + n], d.e_fold ? -se : 0) : 0.0f;
+                    wdf[ch * wd_fl + (size_t)tap * CE + n] = ch * CE + n < d.Cexp ? std::ldexp(Wd[(size_t)tap * d.Cexp + ch * CE + n], d.e_fold ? -se - x2e : 0) : 0.0f;
             for (int n = 0; n < CE; n++) wdf[ch * wd_fl + (size_t)KK * CE + n] = ch * CE + n < d.Cexp ? bd[ch * CE + n] : 0.0f;
         }
         float *dwe = nullptr, *dwp = nullptr, *dwd = nullptr;
@@ -992,9 +1115,9 @@ int plan_fusion(bh_classifier *c) {
         c->d_owned.push_back(dwd);
         d.We = dwe; d.Wp = dwp; d.Wd = dwd;
         d.bp = c->d_blob + P.b_off;
-        if (sp != 0) {   // bp * 2^sp: the project accumulators start there
+        if (spa != 0) {   // bp * 2^spa: the project accumulators start there
             std::vector<float> bps(d.Cout);
-            for (int n = 0; n < d.Cout; n++) bps[n] = std::ldexp(m.blob[P.b_off + n], sp);
+            for (int n = 0; n < d.Cout; n++) bps[n] = std::ldexp(m.blob[P.b_off + n], spa);
             float *dbp = nullptr;
             rc = upload(bps.data(), bps.size() * sizeof(float), &dbp);
             if (rc != BH_OK) return rc;
@@ -1083,8 +1206,14 @@ int bh_classifier_provider_status(const bh_classifier *c, bh_provider_status *ou
     out->device = c->device;
     out->device_count = (uint32_t)std::max(bh_device_count(), 0);
     fill_device_facts(c->device, out);
+    // BH_FLAG_AUTO degraded some rows to the f32 kernels: recorded as the reference records a provider fall-back (classifier.rs:742-754)
+    if (const unsigned long long nfb = c->fallback_segments.load())
+        snprintf(out->fallback_reason, sizeof out->fallback_reason,
+                 "%llu segment(s) re-run on the f32 kernels: an activation left the f16 operand range of the split-f16 path", nfb);
     return BH_OK;
 } catch (...) { return on_exception(); }
+
+uint64_t bh_classifier_fallback_segments(const bh_classifier *c) { return c ? (uint64_t)c->fallback_segments.load() : 0; }
 
 size_t bh_default_batch_size(uint32_t model_type, const char *provider_actual) {
     const char *p = provider_actual ? provider_actual : "HIP";
@@ -1125,12 +1254,18 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) try {
     // front-end operators
     // GEMM operand precision (decided here: the front-end operator layout depends on it)
     // the spectrogram front-end keeps f32-grade products in every mode: f32 MFMA, or split f16 in the f16 modes
-    c->precision = (cfg->flags & BH_FLAG_PRECISION_MASK) == BH_FLAG_F16X3 ? 3 : (cfg->flags & BH_FLAG_PRECISION_MASK) == BH_FLAG_F16 ? 1 : 0;
-    if (const char *pe = getenv("BIRDA_HIP_PRECISION")) {
-        if (!strcmp(pe, "f32")) c->precision = 0;
-        else if (!strcmp(pe, "f16x3")) c->precision = 3;
-        else if (!strcmp(pe, "f16")) c->precision = 1;
-        else return fail(BH_ERR_INVALID, "BIRDA_HIP_PRECISION must be f32, f16x3 or f16");
+    {
+        const uint32_t pf = cfg->flags & BH_FLAG_PRECISION_MASK;
+        c->precision = pf == BH_FLAG_F32 ? 0 : pf == BH_FLAG_F16 ? 1 : 3;
+        c->auto_fallback = pf == BH_FLAG_AUTO;
+        c->model_path = cfg->model_path;
+    }
+    if (const char *pe = (cfg->flags & FLAG_INTERNAL_NO_ENV) ? nullptr : getenv("BIRDA_HIP_PRECISION")) {
+        if (!strcmp(pe, "f32")) { c->precision = 0; c->auto_fallback = false; }
+        else if (!strcmp(pe, "f16x3")) { c->precision = 3; c->auto_fallback = false; }
+        else if (!strcmp(pe, "auto")) { c->precision = 3; c->auto_fallback = true; }
+        else if (!strcmp(pe, "f16")) { c->precision = 1; c->auto_fallback = false; }
+        else return fail(BH_ERR_INVALID, "BIRDA_HIP_PRECISION must be auto, f32, f16x3 or f16");
     }
     // f16x3 and f16: the front-end GEMM on the split-f16 MFMA (f32-grade products, faster than the f32 MFMA;
     // BIRDA_HIP_MEL_F32=1 keeps it on the f32 MFMA: A/B aid)
@@ -1286,6 +1421,7 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) try {
 void bh_classifier_destroy(bh_classifier *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->fb) { bh_classifier_destroy(c->fb); c->fb = nullptr; }
     if (c->internal_ctx) ctx_destroy(c->internal_ctx);
     for (bh_batch_context *p : c->parked_ctx)
         if (p) ctx_destroy(p);
@@ -1406,7 +1542,7 @@ int bh_classifier_info(const bh_classifier *c, bh_model_info *info) {
     info->n_layers = h.n_layers; info->macs_per_segment = c->model.macs_per_segment();
     info->mel_flops_per_segment = c->mel_flops;
     info->model_type = h.family;
-    info->precision = c->precision == 3 ? BH_FLAG_F16X3 : c->precision == 1 ? BH_FLAG_F16 : BH_FLAG_F32;
+    info->precision = c->auto_fallback ? BH_FLAG_AUTO : c->precision == 3 ? BH_FLAG_F16X3 : c->precision == 1 ? BH_FLAG_F16 : BH_FLAG_F32;
     return BH_OK;
 }
 
@@ -1610,17 +1746,46 @@ int bh_forward_device(bh_classifier *c, bh_batch_context *ctx, const float *d_se
                            d_topk_index ? d_topk_index + b0 * c->top_k : nullptr,
                            d_topk_conf ? d_topk_conf + b0 * c->top_k : nullptr);
         if (rc != BH_OK) return rc;
+        if (c->auto_fallback && d_topk_index && d_topk_conf) {   // what bh_batch_context_synchronize re-runs marked rows from
+            const bh_batch_context::Pending p{d_segments + b0 * h.sample_count, nb, d_logits + b0 * h.n_classes,
+                                              d_topk_index + b0 * c->top_k, d_topk_conf + b0 * c->top_k};
+            bool known = false;
+            for (const auto &q : ctx->pending) known |= q.d_seg == p.d_seg && q.n == p.n && q.d_logits == p.d_logits && q.d_idx == p.d_idx && q.d_conf == p.d_conf;
+            if (!known) {
+                if (ctx->pending.size() < 256) ctx->pending.push_back(p);
+                else ctx->pending_overflow = true;
+            }
+        }
     }
     return BH_OK;
 } catch (...) { return on_exception(); }
 
-int bh_batch_context_synchronize(bh_batch_context *ctx) {
+int bh_batch_context_synchronize(bh_batch_context *ctx) try {
     if (!ctx) return fail(BH_ERR_INVALID, "synchronize: null context");
-    HIPCHK(hipSetDevice(ctx->c->device));
+    bh_classifier *c = ctx->c;
+    HIPCHK(hipSetDevice(c->device));
     HIPCHK(fetch_nonfinite(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    return nonfinite_status(ctx->c, ctx);   // BH_ERR_NONFINITE once per occurrence: the counter is cleared
-}
+    if (*ctx->h_nonfinite && c->auto_fallback && !ctx->pending_overflow) {
+        // BH_FLAG_AUTO: the marked rows of every forward enqueued since the last synchronise, again on the f32 kernels.  (Forwards
+        // that shared their buffers have been overwritten by the last one of them, whose rows these are.)
+        std::vector<int32_t> h_idx;
+        std::vector<size_t> bad;
+        for (const auto &p : ctx->pending) {
+            h_idx.resize(p.n * c->top_k);
+            HIPCHK(hipMemcpy(h_idx.data(), p.d_idx, h_idx.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+            bad.clear();
+            for (size_t i = 0; i < p.n; i++)
+                if (h_idx[i * c->top_k] == BH_TOPK_NONFINITE) bad.push_back(i);
+            const int rc = redo_rows_f32(c, p.d_seg, bad, p.d_logits, p.d_idx, p.d_conf, nullptr);
+            if (rc != BH_OK) { ctx->pending.clear(); clear_nonfinite(ctx); return rc; }
+        }
+        clear_nonfinite(ctx);
+    }
+    ctx->pending.clear();
+    ctx->pending_overflow = false;
+    return nonfinite_status(c, ctx);   // BH_ERR_NONFINITE once per occurrence: the counter is cleared
+} catch (...) { return on_exception(); }
 void *bh_batch_context_stream(bh_batch_context *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 uint64_t bh_tensor_floats(const bh_classifier *c, uint32_t tensor) {
@@ -1667,7 +1832,7 @@ int bh_plan_fused_blocks(const char *model_path, uint32_t flags, int32_t *cfgs, 
     std::string err;
     if (!bh::load_model(model_path, m, err)) return fail(BH_ERR_IO, "%s", err.c_str());
     const uint32_t p = flags & BH_FLAG_PRECISION_MASK;
-    const int precision = p == BH_FLAG_F16X3 ? 3 : p == BH_FLAG_F16 ? 1 : 0;
+    const int precision = p == BH_FLAG_F32 ? 0 : p == BH_FLAG_F16 ? 1 : 3;
     const std::vector<int> readers = tensor_readers(m);
     size_t n = 0;
     for (size_t i = 0; i + 2 < m.layers.size(); i++) {
@@ -1782,6 +1947,12 @@ int bh_predict_batch_source_rate(bh_classifier *c, bh_batch_context *ctx, const 
         HIPCHK(hipMemcpyAsync(ctx->h_topk_conf, ctx->d_topk_conf, nb * c->top_k * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(fetch_nonfinite(ctx));
         HIPCHK(hipStreamSynchronize(ctx->stream));
+        if (*ctx->h_nonfinite && c->auto_fallback) {
+            bool redone = false;
+            const int rr = settle_rows(c, ctx, 0, nb, nullptr, &redone);
+            if (rr != BH_OK) return rr;
+            clear_nonfinite(ctx);
+        }
         for (size_t i = 0; i < nb; i++) {
             bh_result &r = out[b0 + i];
             r.n_pred = 0;
@@ -2010,12 +2181,23 @@ static int predict_pcm16_core(bh_classifier *c, bh_batch_context *ctx, const voi
             return rc;
         }
         if (fetch_nonfinite(ctx) != hipSuccess) return fail(BH_ERR_HIP, "predict_pcm16: result download failed");
+        bool poisoned = false;   // a sub-slice with marked rows and no BH_FLAG_AUTO: its rows and the later ones are not handed out
         for (size_t sj = 0; sj < nsub; sj++) {
             const size_t s0 = sj ? cuts[sj - 1] : 0, ns = cuts[sj] - s0;
             if (hipEventSynchronize(ctx->done_ev[sj]) != hipSuccess) {
                 lanes_sync(ctx); (void)hipStreamSynchronize(ctx->stream);
                 return fail(BH_ERR_HIP, "predict_pcm16: result download failed");
             }
+            // Rows the top-k stage marked (logits inf / NaN from finite samples: an activation left the f16 range) are looked for
+            // BEFORE the sub-slice's rows go to the caller: BH_FLAG_AUTO re-runs them on the f32 kernels here; otherwise nothing
+            // from this sub-slice on is delivered and the call ends in BH_ERR_NONFINITE (what was delivered before is valid).
+            bool marked = false;
+            for (size_t i = s0; i < s0 + ns && !marked; i++) marked = ctx->h_topk_idx[i * c->top_k] == BH_TOPK_NONFINITE;
+            if (marked && c->auto_fallback) {
+                bool redone = false;
+                const int rr = settle_rows(c, ctx, s0, ns, nullptr, &redone);
+                if (rr != BH_OK) { lanes_sync(ctx); (void)hipStreamSynchronize(ctx->stream); clear_nonfinite(ctx); return rr; }
+            } else if (marked) poisoned = true;
             for (size_t i = s0; i < s0 + ns; i++) {
                 bh_result &r = out[b0 + i];
                 r.n_pred = 0;
@@ -2027,9 +2209,10 @@ static int predict_pcm16_core(bh_classifier *c, bh_batch_context *ctx, const voi
                     r.n_pred++;
                 }
             }
-            if (on_rows) on_rows(user, b0 + s0, ns, out + b0 + s0, starts.data() + b0 + s0);
+            if (on_rows && !poisoned) on_rows(user, b0 + s0, ns, out + b0 + s0, starts.data() + b0 + s0);
         }
         if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(BH_ERR_HIP, "predict_pcm16: result download failed");
+        if (c->auto_fallback && *ctx->h_nonfinite) clear_nonfinite(ctx);   // (every marked row was re-run above)
         const int nf = nonfinite_status(c, ctx);
         if (nf != BH_OK) return nf;
     }
@@ -2303,7 +2486,9 @@ uint32_t bh_birdnet_week(uint32_t month, uint32_t day) {
     if (month < 1) month = 1;
     if (month > 12) month = 12;
     if (day < 1) day = 1;
-    return (month - 1) * 4 + std::min<uint32_t>(4, (day - 1) / 7 + 1);
+    // no clamp on the week inside the month: days 29-31 belong to the next month's first week (capped at 48 for the last days of
+    // December) -- the one form birda's week -> start day -> (month, day) round trip inverts for all 48 weeks (birda_hip.h)
+    return std::min<uint32_t>(48, (month - 1) * 4 + (day - 1) / 7 + 1);
 }
 
 int bh_range_filter_predict_week(bh_range_filter *rf, float latitude, float longitude, float week, float *scores, size_t cap,

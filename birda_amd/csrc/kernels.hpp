@@ -178,9 +178,40 @@ __device__ __forceinline__ void gelu_erf_fast4_scaled(bh_f32x2 &v0, bh_f32x2 &v1
     v0 = __builtin_elementwise_fma(-a0, e0, m0);
     v1 = __builtin_elementwise_fma(-a1, e1, m1);
 }
-// the unscaled polynomial's coefficients, for the host (c_k 2^-ks is computed there)
 #if BH_GELU_DEGREE == 5
+// TWICE the GELU, for the fused blocks of the f16 modes (round 4): 2 GELU(v) = (v + |v|) - |v| 2 Phi(-|v|), with
+// 2 Phi(-a) = exp2(Q(a) + 1) and Q(a) + 1 = a (c1 + a (c2 + ... + a c5)) -- the constant term is gone, so the Horner chain ends in a
+// multiply, and v + |v| replaces max(v, 0).  Every operand that is |v| is a VOP3 source modifier (free) as long as the
+// operations stay scalar v_fma_f32 / v_mul_f32 / v_add_f32, which is what this form is written for: packed f32 FMAs buy no
+// throughput on gfx950 (tools/microbench/valu_throughput.hip: v_pk_fma_f32 = 1.8 v_fma_f32) and have no abs modifier, and
+// v_med3_f32 costs 1.5 v_fma_f32.  Per value: 4 FMA + MUL + EXP + ADD + FMA = 8 instructions of which one is quarter rate, against
+// 1 v_med3 + 3.5 packed FMAs + 1 v_exp (5.5 instructions, 12 FMA issue slots against 10.5 here).  The factor two is a power of two
+// and is folded on the host into the next linear stage (depthwise taps after the expand GELU, project planes' exponent after the
+// depthwise GELU: api.hip plan_fusion).  Same polynomial, same rounding points but the last: measured against float64 erfc, the
+// worst point is 0.63 of the activation's stated tolerance, as for gelu_erf_fast (tools/fit_gelu.py --check).
+// gc = c_k 2^(-k s) when the argument arrives multiplied by 2^s (gelu_erf_fast4_scaled's convention), c_k otherwise.
+__device__ __forceinline__ float gelu2x_one(float v, const GeluScaled &gc) {
+    const float a = __builtin_fabsf(v);
+    float t = __builtin_fmaf(a, gc.c5, gc.c4);
+    t = __builtin_fmaf(t, a, gc.c3);
+    t = __builtin_fmaf(t, a, gc.c2);
+    t = __builtin_fmaf(t, a, gc.c1);
+    const float e2 = __builtin_amdgcn_exp2f(t * a);
+    return __builtin_fmaf(-a, e2, v + a);
+}
+__device__ __forceinline__ void gelu2x_fast4(bh_f32x2 &v0, bh_f32x2 &v1, const GeluScaled &gc) {
+    // (four independent chains: the compiler interleaves them; scalar on purpose, see above)
+    const float r0 = gelu2x_one(v0[0], gc), r1 = gelu2x_one(v0[1], gc), r2 = gelu2x_one(v1[0], gc), r3 = gelu2x_one(v1[1], gc);
+    v0[0] = r0; v0[1] = r1; v1[0] = r2; v1[1] = r3;
+}
+__device__ __forceinline__ bh_f32x2 gelu2x_fast2(bh_f32x2 v, const GeluScaled &gc) {
+    bh_f32x2 r;
+    r[0] = gelu2x_one(v[0], gc); r[1] = gelu2x_one(v[1], gc);
+    return r;
+}
+// the unscaled polynomial's coefficients, for the host (c_k 2^-ks is computed there) and for the unscaled 2 GELU
 constexpr float kGeluCoef[5] = {BH_GELU_C1, BH_GELU_C2, BH_GELU_C3, BH_GELU_C4, BH_GELU_C5};
+constexpr GeluScaled kGeluUnscaled = {BH_GELU_C1, BH_GELU_C2, BH_GELU_C3, BH_GELU_C4, BH_GELU_C5};
 #endif
 
 // a + b as a plain v_add_f32 that hipcc cannot fuse with its neighbour.  Written as `fwd[j] + rev[-j]`

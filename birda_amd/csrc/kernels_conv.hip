@@ -635,13 +635,14 @@ __global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ log
     bool bad = false;   // an inf / NaN logit
     for (int i = tid; i < n_classes; i += 256) { const float v = lg[i]; row[i] = v; m = fmaxf(m, v); bad |= !(fabsf(v) <= 3.4028235e38f); }
     const int any_bad = __syncthreads_or(bad ? 1 : 0);
+    bool mark = false;   // (thread 0) this row is counted: it leaves with index -2 in its first slot (BH_TOPK_NONFINITE, birda_hip.h)
     if (nonfinite && any_bad && tid == 0) {
         // non-finite logits from FINITE samples: an operand overflowed on the way (f16 range); a segment that came in with
         // NaN / inf samples is the caller's business and is not counted
         bool in_ok = true;
         if (in_bad)
             for (int q = 0; q < 8; q++) in_ok &= in_bad[(size_t)seg * 8 + q] == 0u;
-        if (in_ok) atomicAdd(nonfinite, 1u);
+        if (in_ok) { atomicAdd(nonfinite, 1u); mark = true; }
     }
     // softmax statistics
     float mx = -INFINITY, sum = 0.f;
@@ -746,8 +747,8 @@ __global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ log
             for (int i = w; i < n; i++) { koi[i] = -1; koc[i] = 0.f; }
         }
         for (int k = 0; k < top_k; k++) {
-            idx[(size_t)seg * top_k + k] = koi[k];
-            conf[(size_t)seg * top_k + k] = koc[k];
+            idx[(size_t)seg * top_k + k] = mark ? (k == 0 ? -2 : -1) : koi[k];
+            conf[(size_t)seg * top_k + k] = mark ? 0.f : koc[k];
         }
     }
 }

@@ -64,10 +64,14 @@ double mb_try_th(MbDesc &d, int ci, int th) {
     const size_t we_fl = (size_t)c.KG * (c.CE / 16) * frag + c.CE, wp_fl = p16 ? (size_t)t.NTOP * 256 : psteps * t.NTOP * frag;
     const size_t wd_fl = (size_t)c.KS * c.KS * c.CE + c.CE;
     const size_t ds_fl = c.PREC ? (size_t)pout_pad * (p16 ? 24 : psteps * 32 + 8) : (size_t)pout_pad * ces;
-    const size_t lds_base = (((size_t)c.S * t.IH * t.IW + 1) * ces + ds_fl) * 4 + (size_t)pout_pad * 4;
-    t.lds_bytes = lds_base + (we_fl + wp_fl + wd_fl) * 4 * (c.PERSIST ? (size_t)t.nchunks : 1);   // persistent: every chunk resident
+    if (c.PERSIST == 2) {   // strip-walking workgroups: more than one tile row to walk, one segment, a halo the step inherits
+        if (t.tiles_y < 2 || c.S != 1 || c.KS <= c.ST || th * c.ST < c.KS - c.ST || d.pad_t > th * c.ST) return -1;
+    }
+    const size_t halo_bytes = c.PERSIST == 2 ? (size_t)t.nchunks * (c.KS - c.ST) * t.IW * ces * 4 : 0;   // [chunk][KS - ST rows][IW][ces]
+    const size_t lds_base = (((size_t)c.S * t.IH * t.IW + 1) * ces + ds_fl) * 4 + (size_t)pout_pad * 4 + halo_bytes;
+    t.lds_bytes = lds_base + (we_fl + wp_fl + wd_fl) * 4 * (c.PERSIST == 1 ? (size_t)t.nchunks : 1);   // persistent: every chunk resident
     if (t.lds_bytes > 160 * 1024) return -1;
-    if (c.PERSIST && t.lds_bytes > 80 * 1024) return -1;   // one workgroup per CU cannot hide its own set-up
+    if (c.PERSIST == 1 && t.lds_bytes > 80 * 1024) return -1;   // one workgroup per CU cannot hide its own set-up
     // weight ring (We x 2, Wp x 3, Wd x 2, a whole chunk of prefetch distance): for 16-channel chunks, when the workgroups the
     // entry's register budget allows per CU still fit in LDS with it.  BIRDA_HIP_MB_RING=0/1 forces it off / on where it fits.
     t.ring = 0;
@@ -82,6 +86,8 @@ double mb_try_th(MbDesc &d, int ci, int th) {
     }
     d = t;
     const double tiles = (double)t.tiles_y * t.tiles_x / c.S;
+    if (c.PERSIST == 2)   // (the halo rows are not expanded again: TH * ST new rows per step)
+        return tiles * ((double)(c.S * std::min(th * c.ST, d.H) * std::min(t.IW, d.W) + 15) / 16 * t.KG * 4 * (d.Cexp / 16) + (double)pout_pad / 16 * t.NTOP * (d.Cexp / 4));
     return tiles * ((double)t.mpad_max / 16 * t.KG * 4 * (d.Cexp / 16) + (double)pout_pad / 16 * t.NTOP * (d.Cexp / 4));
 }
 

@@ -140,6 +140,26 @@ __device__ __forceinline__ void mb_dma_at_part(const float *gsrc, unsigned lds_b
 }
 __device__ __forceinline__ void mb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// The depthwise activation of the fused blocks.  GELU in the f16 modes leaves TWICE the GELU (gelu2x_fast4, kernels.hpp): the
+// project planes' exponent carries the factor (api.hip plan_fusion), as the depthwise taps do for the expand GELU.
+template <int ACT, int PREC> constexpr bool mb_gelu2x() { return PREC != 0 && ACT == ACT_GELU_ERF && BH_GELU_DEGREE == 5; }
+template <int ACT, int PREC>
+__device__ __forceinline__ void mb_act4(bh_f32x2 &v0, bh_f32x2 &v1) {
+#if BH_GELU_DEGREE == 5
+    if constexpr (mb_gelu2x<ACT, PREC>()) gelu2x_fast4(v0, v1, kGeluUnscaled);
+    else
+#endif
+        bh_act4<ACT>(v0, v1);
+}
+template <int ACT, int PREC>
+__device__ __forceinline__ bh_f32x2 mb_act2(bh_f32x2 v) {
+#if BH_GELU_DEGREE == 5
+    if constexpr (mb_gelu2x<ACT, PREC>()) return gelu2x_fast2(v, kGeluUnscaled);
+    else
+#endif
+        return bh_act2<ACT>(v);
+}
+
 //   PREC        0: f32 MFMA (16x16x4, KG counts 16-deep groups); 3: f16 hi/lo split, three 16x16x32 MFMAs
 //               per product (KG counts 32-deep steps); 1: plain f16 operands (one MFMA, ~1e-3 relative)
 //   ACT         the expand and depthwise activation (GELU, swish, ReLU6 or ReLU: bh_act<>, kernels.hpp)
@@ -148,7 +168,13 @@ __device__ __forceinline__ void mb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)
 //               40 / 20 % of the taps of a row-wise task multiply the all-zero padding rows, and its 192 tasks leave a wave idle.
 //               A column task loads only the COLTH real rows of its 5 (3) grid columns once, skips the padding rows at compile
 //               time, and SS * TW * CE / 4 = 256 of them fill the workgroup.
-//   PERSIST     1: persistent workgroups (grid = workgroups that fit on the chip at once) walking the tiles, with the weights of
+//   PERSIST     2: STRIP-WALKING workgroups (round 4).  A workgroup owns one tile COLUMN of one segment and walks down the image, tile
+//               row by tile row.  The last KS - ST rows of a tile's expanded grid are the first rows of the next tile's: they are
+//               kept -- per chunk, in an LDS halo store -- instead of being expanded (and GELU-ed) again, so the expand phase covers
+//               only the TH * ST NEW rows of a step (3x3 stride 1 at TH = 8: 10 -> 8 rows, the k - 1 halo rows of the old tiles were
+//               a fifth of all expand work), the tile decomposition and the grid's zero fill happen once per strip, and the next
+//               tile's chunk-0 weights arrive under the last chunk of this one.  Weights stream per chunk as in the plain kernel.
+//               1: persistent workgroups (grid = workgroups that fit on the chip at once) walking the tiles, with the weights of
 //               EVERY chunk resident in LDS -- loaded once per workgroup, not once per tile and chunk.  For the early blocks
 //               (large images, few channels): a tile's compute is ~5k cycles, and 12 barriers each waiting for a freshly
 //               issued L2 -> LDS transfer plus the launch and set-up of 48-96 workgroups per segment were 70 % of their time
@@ -162,6 +188,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
     // whole-image tiles leave room for a single workgroup per CU -- with one wave per SIMD nothing fills the issue bubbles of its
     // dependent vector chains, and its MFMA and vector phases cannot overlap with anybody else's)
     constexpr int NW = WM * WN, NTH = 64 * NW;
+    constexpr bool RESIDENT = PERSIST == 1, STRIP = PERSIST == 2;
+    constexpr int KH = KS - ST;          // STRIP: grid rows a tile inherits from the tile above
+    static_assert(!STRIP || (SS == 1 && COLTH == 0 && KH > 0), "strip-walking: one segment per workgroup, row tasks");
     static_assert(NW == 4 || NW == 8, "4 or 8 waves");
     constexpr int NT_E = CE / 16, NT_U = NT_E / NCS, CES = CE + 4, C4N = CE / 4, TW = 1 << TWL;
     constexpr int POUT_PAD = WM * MT_W * 16, NTOP = WN * NT_W;
@@ -189,12 +218,15 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
     // those blocks is a few hundred cycles, shorter than an L2 -> LDS transfer, and the waits in front of both barriers were
     // half of the kernel's wave-cycles (tools/gpu_mb_stamps.py); the ring costs 5-7 KB of LDS.
     const bool ring = !PERSIST && COLTH == 0 && d.ring != 0;
-    const int nbuf_e = PERSIST ? d.nchunks : (ring ? 2 : 1), nbuf_p = PERSIST ? d.nchunks : (ring ? 3 : 1);
+    const int nbuf_e = RESIDENT ? d.nchunks : (ring ? 2 : 1), nbuf_p = RESIDENT ? d.nchunks : (ring ? 3 : 1);
     float *WeS = Ds + DS_FLOATS;
     _Float16 *DsH = reinterpret_cast<_Float16 *>(Ds), *DsL = DsH + POUT_PAD * DSH;   // PREC != 0
     float *WpS = WeS + nbuf_e * WE_FLOATS;
     float *Wds = WpS + nbuf_p * WP_FLOATS;
     int *omap = reinterpret_cast<int *>(Wds + nbuf_e * WD_FLOATS);
+    // STRIP: the halo store, [chunk][KH grid rows][IW][CES] -- the bottom rows of every chunk's grid, as the next tile needs them
+    const int halo_fl = KH > 0 ? KH * IW * CES : 0;
+    float *Hs = reinterpret_cast<float *>(omap + POUT_PAD);
     // (column-task instantiations: LDS byte addresses of the weight buffers, see mb_dma_at; the dynamic shared array follows the
     //  kernel's static LDS, of which there is none here)
     static_assert(COLTH == 0 || PERSIST == 0, "column tasks: no persistent variant");
@@ -203,7 +235,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                    wd_ba = wp_ba + 4u * (unsigned)(nbuf_p * WP_FLOATS);
 
     // PERSIST: tile = (segment group, tile row, tile column), linear; this workgroup takes every gridDim.x-th one
-    const int tiles_xy = d.tiles_x * d.tiles_y;
+    // (STRIP: the work list is (segment, tile column); the tile rows are walked inside)
+    const int tiles_xy = STRIP ? d.tiles_x : d.tiles_x * d.tiles_y;
     const int n_tiles = tiles_xy * ((n_seg + SS - 1) / SS);
     // Tile of this workgroup.  The launch is one-dimensional; workgroup b runs on XCD b % 8 (round-robin dispatch), and each XCD has
     // its own L2.  Dealt in launch order, x-neighbouring tiles -- whose input rectangles share their halo columns and the 64-byte
@@ -212,13 +245,13 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
     // in x, then y, then segment order): neighbours in space are neighbours in time on one L2.
     const int per_xcd = (n_tiles + 7) >> 3;
     const int tile_xcd = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
-    if (!PERSIST && (d.dbg & 256 ? (int)blockIdx.x >= n_tiles : tile_xcd >= n_tiles)) return;   // (dbg 256: launch order, A/B aid)
-    const int tile_first = PERSIST ? (int)blockIdx.x : (d.dbg & 256 ? (int)blockIdx.x : tile_xcd);
+    if (!RESIDENT && (d.dbg & 256 ? (int)blockIdx.x >= n_tiles : tile_xcd >= n_tiles)) return;   // (dbg 256: launch order, A/B aid)
+    const int tile_first = RESIDENT ? (int)blockIdx.x : (d.dbg & 256 ? (int)blockIdx.x : tile_xcd);
 #ifdef BIRDA_HIP_EXPERIMENTS
     MbClock t_last{};
     if (d.stamps) t_last.last = __builtin_readcyclecounter();
 #endif
-    if constexpr (PERSIST != 0) {
+    if constexpr (RESIDENT) {
         for (int c = 0; c < d.nchunks; c++) {   // every chunk's weights, once
             mb_dma<WE_FLOATS, NW>(d.We + (size_t)c * WE_FLOATS, WeS + c * WE_FLOATS, wave0, lane0);
             mb_dma<WD_FLOATS, NW>(d.Wd + (size_t)c * WD_FLOATS, Wds + c * WD_FLOATS, wave0, lane0);
@@ -242,7 +275,10 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
         }
     }
 
-    for (int tile = tile_first; tile < (PERSIST ? n_tiles : tile_first + 1); tile += PERSIST ? (int)gridDim.x : 1) {
+    // (STRIP: `tile` stays the strip's index and `trow` walks its tile rows)
+    const int n_trows = STRIP ? d.tiles_y : 1;
+    for (int tile = tile_first; tile < (RESIDENT ? n_tiles : tile_first + 1); tile += RESIDENT ? (int)gridDim.x : 1)
+    for (int trow = 0; trow < n_trows; trow++) {
     // (everything below is per tile.  The thread index goes through an opaque copy so that hipcc does not hoist the
     //  tile-invariant index arithmetic out of the tile loop and keep it in registers across it: a first persistent
     //  version doubled its VGPRs and spilled SGPRs that way)
@@ -251,14 +287,16 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const int tz = tile / tiles_xy, txy = tile - tz * tiles_xy;
-    const int tyi = txy / d.tiles_x, txi = txy - tyi * d.tiles_x;
+    const int tyi = STRIP ? trow : txy / d.tiles_x, txi = STRIP ? txy : txy - tyi * d.tiles_x;
     const int seg0 = tz * SS;
     const int nsv = min(SS, n_seg - seg0);
     const int oy0 = tyi * TH, ox0 = txi * TW;
     const int iy0 = oy0 * ST - d.pad_t, ix0 = ox0 * ST - d.pad_l;
     const int ya = max(0, -iy0), yb = min(IH, d.H - iy0);
     const int xa = max(0, -ix0), xb = min(IW, d.W - ix0);
-    const int vh = max(yb - ya, 0), vw = max(xb - xa, 0);
+    // STRIP, below the first tile row: grid rows [0, KH) come from the halo store; the expand phase starts at row ra = KH
+    const int ra = (STRIP && trow > 0) ? max(ya, KH) : ya;
+    const int vh = max(yb - ra, 0), vw = max(xb - xa, 0);
     const int Mseg = vh * vw, M = Mseg * nsv, nrt = (M + 15) >> 4;
     const int Cin = d.Cin, Cout = d.Cout, nchunks = (d.dbg & 128) ? 0 : d.nchunks;
     // STEM: X is the planar spectrogram [n][C][SH][SW]; "Cin" = kh*kw*C im2col columns
@@ -309,9 +347,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
             if (rt < nrt && m < M) {
                 const int sl = SS > 1 ? (m >= Mseg ? 1 : 0) : 0, mm = m - sl * Mseg;
                 const int r = mb_div(mm, vw, rcp_vw), c = mm - __mul24(r, vw);
-                eoff[i] = __mul24(sl * IH * IW + __mul24(ya + r, IW) + xa + c, CES) + 4 * kq;
-                xo[ii] = STEM ? (((iy0 + ya + r) << 16) | (ix0 + xa + c))   // stem-output pixel (y, x), gathered below
-                              : __mul24(__mul24(sl * d.H + iy0 + ya + r, d.W) + ix0 + xa + c, Cin);
+                eoff[i] = __mul24(sl * IH * IW + __mul24(ra + r, IW) + xa + c, CES) + 4 * kq;
+                xo[ii] = STEM ? (((iy0 + ra + r) << 16) | (ix0 + xa + c))   // stem-output pixel (y, x), gathered below
+                              : __mul24(__mul24(sl * d.H + iy0 + ra + r, d.W) + ix0 + xa + c, Cin);
                 rvv[ii] = !(d.dbg & 64);
             }
         }
@@ -422,6 +460,14 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
         if (sl < nsv && oy0 + ty < d.Ho && ox0 + tx < d.Wo) o = (sl * d.Ho + oy0 + ty) * d.Wo + ox0 + tx;
         omap[p] = o;
     }
+    if constexpr (STRIP) {
+        // the whole grid once, at the top of the strip (image columns outside the strip's rectangle and the rows above the image
+        // then stay zero: nothing writes them); further down only the rows below the image -- they hold the previous tile's values
+        float4 *z = reinterpret_cast<float4 *>(Es);
+        const int z0 = trow == 0 ? 0 : yb * IW * CES / 4, n4 = egrid * CES / 4;   // (IW * CES is a multiple of 4)
+        if (trow == 0 || yb < IH)
+            for (int i = z0 + tid; i < n4; i += NTH) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else
     if (M != egrid) {  // some of the grid lies outside the image (or a segment is missing): zero padding
         float4 *z = reinterpret_cast<float4 *>(Es);
         const int n4 = egrid * CES / 4;
@@ -482,10 +528,19 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
     p2_task(tid);
 
     for (int ch = 0; ch < nchunks; ch++) {
-        const int chn = min(ch + 1, nchunks - 1);
+        // (STRIP: behind the last chunk comes chunk 0 of the next tile row -- its weights arrive under this tile's last phases)
+        const int chn = STRIP ? (ch + 1 < nchunks ? ch + 1 : 0) : min(ch + 1, nchunks - 1);
         // this chunk's weights
-        const float *WeC = WeS + (PERSIST ? ch : ring ? (ch & 1) : 0) * WE_FLOATS, *WdC = Wds + (PERSIST ? ch : ring ? (ch & 1) : 0) * WD_FLOATS;
-        const float *WpC = WpS + (PERSIST ? ch : ring ? (ch % 3) : 0) * WP_FLOATS;
+        const float *WeC = WeS + (RESIDENT ? ch : ring ? (ch & 1) : 0) * WE_FLOATS, *WdC = Wds + (RESIDENT ? ch : ring ? (ch & 1) : 0) * WD_FLOATS;
+        const float *WpC = WpS + (RESIDENT ? ch : ring ? (ch % 3) : 0) * WP_FLOATS;
+        if constexpr (STRIP) {
+            // the chunk's rows of the tile above: halo store -> grid rows [0, KH)  (one float4 per thread)
+            if (trow > 0) {
+                const float4 *hsrc = reinterpret_cast<const float4 *>(Hs + (size_t)ch * halo_fl);
+                float4 *hdst = reinterpret_cast<float4 *>(Es);
+                for (int i = tid; i < halo_fl / 4; i += NTH) hdst[i] = hsrc[i];
+            }
+        }
         const float *bes = WeC + KG * NT_E * FRAG, *bds = WdC + KS * KS * CE;
         mb_stamp(d.stamps, t_last, 1);
 
@@ -608,9 +663,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                         for (int j = 0; j < NT_U; j++) {
                             f32x2 v01 = {acc[ii][j][0], acc[ii][j][1]}, v23 = {acc[ii][j][2], acc[ii][j][3]};
                             if constexpr (PREC != 0 && ACT == ACT_GELU_ERF && BH_GELU_DEGREE == 5) {
-                                // weights and bias carry 2^se: the GELU runs on the scaled value and leaves 2^se GELU(x) in the grid;
-                                // the depthwise taps carry the 2^-se (kernels.hpp gelu_erf_fast4_scaled, api.hip plan_fusion)
-                                gelu_erf_fast4_scaled(v01, v23, gelu_sc);
+                                // weights and bias carry 2^se: the GELU runs on the scaled value and leaves 2^(se + 1) GELU(x) in the grid;
+                                // the depthwise taps carry the 2^-(se + 1) (kernels.hpp gelu2x_fast4, api.hip plan_fusion)
+                                gelu2x_fast4(v01, v23, gelu_sc);
                             } else {
                                 if constexpr (PREC != 0) { v01 *= e_unscale; v23 *= e_unscale; }   // weights and bias carry 2^se
                                 bh_act4<ACT>(v01, v23);
@@ -622,9 +677,18 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
             }
         }
         mb_stamp(d.stamps, t_last, 2);
-        if (!ring && !PERSIST) mb_dma_wait();
+        if (!ring && !RESIDENT) mb_dma_wait();
         __syncthreads();  // B1: Es complete; (ring == 0) WeS / WpS free; Wds (DMA issued after the last B2) landed
-        if (!ring && !PERSIST && !(d.dbg & 16)) {
+        if constexpr (STRIP) {
+            // ... and this chunk's bottom rows for the tile below: grid rows [TH * ST, TH * ST + KH) -> halo store.  (Read-only in
+            // this phase; the store's next reader is this chunk's P1 phase of the next tile row, many barriers from here.)
+            if (trow + 1 < n_trows) {
+                const float4 *gsrc = reinterpret_cast<const float4 *>(Es + (size_t)TH * ST * IW * CES);
+                float4 *hdst = reinterpret_cast<float4 *>(Hs + (size_t)ch * halo_fl);
+                for (int i = tid; i < halo_fl / 4; i += NTH) hdst[i] = gsrc[i];
+            }
+        }
+        if (!ring && !RESIDENT && !(d.dbg & 16)) {
             if constexpr (COLTH > 0) {
                 // (issued in parts inside the depthwise phase below)
             } else {
@@ -686,8 +750,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
 #pragma unroll
                 for (int r = 0; r < COLTH; r += 2) {
                     f32x2 g0 = acc[r], g1 = acc[r + 1 < COLTH ? r + 1 : r];
-                    if (r + 1 < COLTH) bh_act4<ACT>(g0, g1);
-                    else g0 = bh_act2<ACT>(g0);
+                    if (r + 1 < COLTH) mb_act4<ACT, PREC>(g0, g1);
+                    else g0 = mb_act2<ACT, PREC>(g0);
 #pragma unroll
                     for (int k = 0; k < 2; k++) {
                         if (r + k >= COLTH) continue;
@@ -755,7 +819,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
 #pragma unroll
                 for (int r = 0; r < COLTH; r++) {
                     f32x2 g0 = acc[r][0], g1 = acc[r][1];
-                    bh_act4<ACT>(g0, g1);
+                    mb_act4<ACT, PREC>(g0, g1);
                     const int prow = sl * THTW + (r << TWL) + x;
                     if constexpr (PREC == 3) {
                         bh_f16x2 h0, l0, h1, l1;
@@ -803,7 +867,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
 #pragma unroll
                 for (int x = 0; x < XB; x++) {
                     f32x2 g0 = acc[x][0], g1 = acc[x][1];
-                    bh_act4<ACT>(g0, g1);
+                    mb_act4<ACT, PREC>(g0, g1);
                     const float4 v = make_float4(g0[0], g0[1], g1[0], g1[1]);
                     const int prow = p2_prow + x;
                     if constexpr (PREC != 0) {   // the project GEMM's A operand: f16 hi (+ lo) planes
@@ -825,9 +889,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
             }
         }
         mb_stamp(d.stamps, t_last, 4);
-        if (!PERSIST) mb_dma_wait();    // ring: the next chunk's weights, on their way since the previous B2
+        if (!RESIDENT) mb_dma_wait();    // ring: the next chunk's weights, on their way since the previous B2
         __syncthreads();  // B2: Ds complete; (ring == 0) WeS (next chunk) and WpS (this chunk) landed; Wds free
-        if (PERSIST) {
+        if (RESIDENT) {
         } else if (!ring) {
             if (!(d.dbg & 16)) {
                 if constexpr (COLTH > 0) mb_dma_at<WD_FLOATS, NW>(d.Wd + (size_t)chn * WD_FLOATS, wd_ba, wave, lane);
@@ -978,9 +1042,10 @@ void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
     auto kern = mbconv_kernel<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, SS, OCC, STEM, PREC, PERSIST, ACT, COLTH>;
     static DeviceOnce attr_set;
     attr_set.run([&] { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-    const long n_wg = (long)d.tiles_x * d.tiles_y * ((n_seg + d.S - 1) / d.S);
+    // (PERSIST == 2, strip-walking: one workgroup per tile COLUMN and segment)
+    const long n_wg = (long)d.tiles_x * (PERSIST == 2 ? 1 : d.tiles_y) * ((n_seg + d.S - 1) / d.S);
     dim3 grid((unsigned)(((n_wg + 7) / 8) * 8)), block(64 * WM * WN);   // one-dimensional: the kernel deals the tiles XCD by XCD
-    if (PERSIST) {   // as many workgroups as are resident at once: registers allow OCC per SIMD, LDS 160 KB per CU
+    if (PERSIST == 1) {   // as many workgroups as are resident at once: registers allow OCC per SIMD, LDS 160 KB per CU
         const long total = (long)d.tiles_x * d.tiles_y * ((n_seg + d.S - 1) / d.S);
         const long per_cu = std::max<long>(1, std::min<long>(OCC, (160 * 1024) / (long)(d.lds_bytes + 256)));
         grid = dim3((unsigned)std::min<long>(total, per_cu * device_cu_count()));
@@ -1003,6 +1068,10 @@ void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
 #define MB_ENTRY_PP(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, PREC) \
     {KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC, 1, MB_A, 0,      \
      mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC, STEM, PREC, 1, MB_A>}
+// strip-walking workgroups (PERSIST = 2): the early blocks on large batches
+#define MB_ENTRY_PW(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, PREC) \
+    {KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC, 2, MB_A, 0,      \
+     mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC, STEM, PREC, 2, MB_A>}
 #define MB_ENTRY_S(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM) \
     MB_ENTRY_P(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, 0)
 #define MB_ENTRY(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC) \
@@ -1020,6 +1089,7 @@ void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
 #define MB_XENTRY_S(...) MB_ENTRY_S(__VA_ARGS__)
 #define MB_XENTRY_P(...) MB_ENTRY_P(__VA_ARGS__)
 #define MB_XENTRY_PP(...) MB_ENTRY_PP(__VA_ARGS__)
+#define MB_XENTRY_PW(...) MB_ENTRY_PW(__VA_ARGS__)
 #define MB_XENTRY_H(...) MB_ENTRY_H(__VA_ARGS__)
 #define MB_XENTRY_HC(...) MB_ENTRY_HC(__VA_ARGS__)
 #define MB_XENTRY_PC(...) MB_ENTRY_PC(__VA_ARGS__)
@@ -1028,6 +1098,7 @@ void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
 #define MB_XENTRY_S(...) MB_NONE
 #define MB_XENTRY_P(...) MB_NONE
 #define MB_XENTRY_PP(...) MB_NONE
+#define MB_XENTRY_PW(...) MB_NONE
 #define MB_XENTRY_H(...) MB_NONE2
 #define MB_XENTRY_HC(...) MB_NONE2
 #define MB_XENTRY_PC(...) MB_NONE

@@ -11,7 +11,7 @@ from ._lib import BhMultiConfig, BhResult, BirdaHipError
 from .classifier import Prediction, PredictionResult
 
 GATHER = {"auto": 0, "host": 1, "rccl": 2}
-PRECISION_FLAGS = {"f32": 0, "f16x3": 1, "f16": 2}
+PRECISION_FLAGS = {"auto": 0, "f16x3": 1, "f16": 2, "f32": 3}   # BH_FLAG_* (include/birda_hip.h)
 
 
 def _mcheck(rc: int):

@@ -50,19 +50,32 @@ typedef struct {
     uint32_t top_k;          /* DEFAULT_TOP_K = 5, constants.rs:178 */
     float min_confidence;    /* DEFAULT_MIN_CONFIDENCE = 0.1, constants.rs:25 */
     int32_t device;          /* HIP device ordinal (one process per GPU) */
-    uint32_t flags;          /* BH_FLAG_* below; 0 = f32 */
+    uint32_t flags;          /* BH_FLAG_* below; 0 = BH_FLAG_AUTO */
 } bh_config;
 
 /* GEMM operand precision of the fused conv blocks (accumulation is always f32):
- *   BH_FLAG_F32    v_mfma_f32_16x16x4_f32: exact f32 fmaf chains (default)
+ *   BH_FLAG_AUTO   (0, the default) BH_FLAG_F16X3 compute that never fails a batch on operand range: a row whose logits come
+ *                  out inf / NaN although its samples were finite (an activation reached the f16 maximum 65 504) is computed
+ *                  again on the library's own f32 kernels -- that row only, the other rows of the call are untouched -- and
+ *                  the event is recorded in bh_classifier_provider_status().fallback_reason and
+ *                  bh_classifier_fallback_segments().  The f32 weights are built the first time it happens (a second copy of
+ *                  the model on the device).  Mirrors the reference, whose dispatch never fails a batch on operand range
+ *                  (processor.rs:269-277) and whose provider selection degrades with a recorded reason (classifier.rs:742-754).
  *   BH_FLAG_F16X3  every f32 operand split into f16 hi + lo, three f16 MFMAs per product:
- *                  ~1e-7 of sum|a b| like the f32 chain, 4.4x its MFMA rate; operands < 65504
- *   BH_FLAG_F16    operands rounded to f16 once (BASELINE config 5): ~1e-3 relative
- * The environment variable BIRDA_HIP_PRECISION = f32 | f16x3 | f16 overrides the flag. */
+ *                  ~1e-7 of sum|a b| like the f32 chain, 4.4x its MFMA rate; operands < 65504, else BH_ERR_NONFINITE
+ *   BH_FLAG_F16    operands rounded to f16 once (BASELINE config 5): ~1e-3 relative; same range rule
+ *   BH_FLAG_F32    v_mfma_f32_16x16x4_f32: exact f32 fmaf chains (0.6x the throughput of the split-f16 path)
+ * The environment variable BIRDA_HIP_PRECISION = auto | f32 | f16x3 | f16 overrides the flag. */
 #define BH_FLAG_PRECISION_MASK 0x3u
-#define BH_FLAG_F32 0x0u
+#define BH_FLAG_AUTO 0x0u
 #define BH_FLAG_F16X3 0x1u
 #define BH_FLAG_F16 0x2u
+#define BH_FLAG_F32 0x3u
+/* First index of a top-k row whose logits were inf / NaN although the segment's samples were finite (the other slots are -1):
+ * what the non-finite counter counted.  Host entry points never hand such a row out under BH_FLAG_AUTO (it has been re-run);
+ * in the other modes the call that produced it returns BH_ERR_NONFINITE.  Device-resident callers (bh_forward_device) see it
+ * in d_topk_index until bh_batch_context_synchronize has re-run the row (BH_FLAG_AUTO) or reported it. */
+#define BH_TOPK_NONFINITE -2
 
 /* birdnet_onnx::ModelConfig{sample_rate, segment_duration, sample_count} + labels().len()
  * (classifier.rs:295-297,306,360-377) */
@@ -78,7 +91,7 @@ typedef struct {
     uint64_t macs_per_segment;  /* conv stack multiply-accumulates (for MFMA utilisation) */
     uint64_t mel_flops_per_segment;
     uint32_t model_type;        /* BH_MODEL_* */
-    uint32_t precision;         /* BH_FLAG_F32 / F16X3 / F16 the classifier was built with */
+    uint32_t precision;         /* BH_FLAG_AUTO / F16X3 / F16 / F32 the classifier was built with */
 } bh_model_info;
 
 /* birdnet_onnx::PredictionResult{predictions: Vec<Prediction{species, confidence, index}>}
@@ -121,6 +134,8 @@ typedef struct {
 BH_API int bh_select_provider(const char *requested, int32_t device_ordinal, bh_provider_status *out);
 /* The status a built classifier runs under (BirdClassifier::execution_provider_status). */
 BH_API int bh_classifier_provider_status(const bh_classifier *c, bh_provider_status *out);
+/* segments BH_FLAG_AUTO has re-run on the f32 kernels so far (0: the split-f16 path served everything) */
+BH_API uint64_t bh_classifier_fallback_segments(const bh_classifier *c);
 
 /* ModelType (config/types.rs:375-388) as carried in the model container's header */
 #define BH_MODEL_BIRDNET_V24 0u
@@ -235,9 +250,13 @@ BH_API int bh_topk_from_logits(bh_classifier *c, const float *logits, size_t n, 
 BH_API int bh_forward_device(bh_classifier *c, bh_batch_context *ctx, const float *d_segments,
                              size_t n, float *d_logits, int32_t *d_topk_index,
                              float *d_topk_conf);
-/* Returns BH_ERR_NONFINITE (once; the counter is cleared) when a forward enqueued since the last check produced inf / NaN
- * logits for a segment whose samples were all finite: in the f16 operand modes an activation reached 65 504.  The host
- * entry points (bh_predict*) report the same after filling their results.  Counted by the top-k stage, i.e. only for
+/* Waits for the context's stream.  When a forward enqueued since the last check produced inf / NaN logits for a segment whose
+ * samples were all finite (in the f16 operand modes: an activation reached 65 504):
+ *   BH_FLAG_AUTO        those rows (BH_TOPK_NONFINITE in d_topk_index) of every bh_forward_device call since the last
+ *                       synchronise are computed again on the f32 kernels, in place (logits and top-k rows), from the calls'
+ *                       d_segments -- which must therefore stay valid until the synchronise -- and BH_OK is returned;
+ *   the other modes     BH_ERR_NONFINITE (once; the counter is cleared).
+ * The host entry points (bh_predict*) do the same before they return their results.  Counted by the top-k stage, i.e. only for
  * forwards that were given top-k buffers. */
 BH_API int bh_batch_context_synchronize(bh_batch_context *ctx);
 BH_API void *bh_batch_context_stream(bh_batch_context *ctx); /* hipStream_t */
@@ -421,9 +440,13 @@ BH_API const char *bh_range_filter_label(const bh_range_filter *rf, uint32_t ind
  * score of geomodel species i for ALL species (cap >= num_species); indices (nullable) receives the species with
  * score >= threshold in index order, n_kept (nullable) their count.  Latitude / longitude are narrowed to f32 as the
  * reference narrows them (:46).  [EXT] birdnet-onnx turns (month, day) into BirdNET's week -- 48 per year, four per month:
- * week = (month - 1) * 4 + min(4, (day - 1) / 7 + 1) = bh_birdnet_week; that is the convention birda's own
- * week -> start-day -> (month, day) round trip (config/range_filter.rs:120-123, utils/date.rs:57-70) inverts for 47 of 48 weeks,
- * while its 7.6-day `date_to_week` (bhh_date_to_week) inverts it for 10.  predict_week takes the model's third input as is. */
+ * week = min(48, (month - 1) * 4 + (day - 1) / 7 + 1) = bh_birdnet_week, WITHOUT a clamp of the week inside the month (days
+ * 29-31 count towards the next month's first week).  The crate's source is not in the reference tree; the form is pinned by
+ * birda's own call site instead: `--week w` reaches the query as week_to_start_day(w) -> (month, day)
+ * (config/range_filter.rs:120-123, utils/date.rs:57-70), and this is the one four-weeks-per-month form that maps every one of
+ * the 48 start days back to its week (a clamp to four weeks per month, rounds 2-3, sent `--week 5` = January 31 to week 4;
+ * birda's own 7.6-day `date_to_week`, bhh_date_to_week, inverts 10 of 48).  Open risk, stated: a crate that clamps would give
+ * days 29-31 the previous week.  predict_week takes the model's third input as is. */
 BH_API int bh_range_filter_predict(bh_range_filter *rf, double latitude, double longitude, uint32_t month, uint32_t day,
                                    float *scores, size_t cap, uint32_t *indices, size_t *n_kept);
 BH_API int bh_range_filter_predict_week(bh_range_filter *rf, float latitude, float longitude, float week, float *scores,

@@ -5,9 +5,11 @@ use std::ffi::{c_char, c_int, c_void};
 
 pub const BH_MAX_TOP_K: usize = 32;
 pub const BH_FLAG_PRECISION_MASK: u32 = 0x3;
-pub const BH_FLAG_F32: u32 = 0x0;
+pub const BH_FLAG_AUTO: u32 = 0x0;
 pub const BH_FLAG_F16X3: u32 = 0x1;
 pub const BH_FLAG_F16: u32 = 0x2;
+pub const BH_FLAG_F32: u32 = 0x3;
+pub const BH_TOPK_NONFINITE: i32 = -2;
 pub const BH_MODEL_BIRDNET_V24: u32 = 0;
 pub const BH_MODEL_PERCH_V2: u32 = 1;
 pub const BH_MODEL_BIRDNET_V30: u32 = 2;
@@ -108,6 +110,7 @@ extern "C" {
     pub fn bh_last_error() -> *const c_char;
     pub fn bh_select_provider(requested: *const c_char, device_ordinal: i32, out: *mut BhProviderStatus) -> c_int;
     pub fn bh_classifier_provider_status(c: *const BhClassifier, out: *mut BhProviderStatus) -> c_int;
+    pub fn bh_classifier_fallback_segments(c: *const BhClassifier) -> u64;
     pub fn bh_default_batch_size(model_type: u32, provider_actual: *const c_char) -> usize;
     pub fn bh_classifier_default_batch_size(c: *const BhClassifier) -> usize;
     pub fn bh_classifier_create(cfg: *const BhConfig, out: *mut *mut BhClassifier) -> c_int;

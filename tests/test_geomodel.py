@@ -110,8 +110,11 @@ def test_date_arithmetic_matches_the_reference_unit_tests():
         L.bhh_day_of_year_to_date(L.bhh_week_to_start_day(wk), C.byref(mo), C.byref(d))
         back4 += L.bh_birdnet_week(mo.value, d.value) == wk
         back76 += L.bhh_date_to_week(mo.value, d.value) == wk
-    assert back4 == 47 and back76 == 10
+    assert back4 == 48 and back76 == 10      # every `--week w` reaches the model as week w (the clamped form lost week 5)
     assert L.bh_birdnet_week(TEST_MONTH, TEST_DAY) == 23 and L.bh_birdnet_week(1, 1) == 1 and L.bh_birdnet_week(12, 31) == 48
+    # days 29-31: the next month's first week, no clamp inside the month; the year's last days stay in week 48
+    assert [L.bh_birdnet_week(1, d) for d in (28, 29, 30, 31)] == [4, 5, 5, 5] and L.bh_birdnet_week(2, 1) == 5
+    assert L.bh_birdnet_week(11, 30) == 45 and L.bh_birdnet_week(12, 28) == 48 and L.bh_birdnet_week(12, 29) == 48
 
 
 # ---- GPU: the fixture through the device GEMM, and the reference's end-to-end assertions ------------------------

@@ -89,6 +89,27 @@ def test_v24_frontend_geometry_matches_float64_vectors(oracle_lib, model_dir, ve
     assert np.abs(logits[0] - vectors["tiny_logits_seg3"]).max() < 1e-3
 
 
+# The models bench.py and the GPU parity tests run: float64 torch / numpy logits of a few segments of the FULL
+# synthetic stacks (tools/gen_golden.py full -> full_model_vectors.npz), so the oracle is not the sole authority for them.
+FULL_GOLDEN_TOL = 2e-5    # of max(1, max |logit|): the f32 oracle against the float64 evaluation (measured 1e-6 ... 4e-6)
+
+
+@pytest.mark.parametrize("kind", ["birdnet_v24", "perch_v2", "birdnet_v30", "mini_se"])
+def test_oracle_matches_float64_vectors_of_the_full_models(oracle_lib, tmp_path, kind):
+    from birda_amd import modelfile as mf, synth
+    g = np.load(os.path.join(GOLDEN, "full_model_vectors.npz"))
+    ref = g[f"{kind}_logits"]
+    m = synth.build_model(kind)
+    path = str(tmp_path / f"{kind}.bhm")
+    mf.write_model(path, m)
+    segs = synth.synth_segments(ref.shape[0], m.sample_count, m.sample_rate, start=int(g[f"{kind}_start"][0]))
+    got = oracle_lib.OracleModel(path).forward(segs)
+    scale = max(1.0, float(np.abs(ref).max()))
+    err = float(np.abs(got - ref).max())
+    print(f"{kind}: oracle vs float64 max|dlogit| = {err:.3e} on max|logit| {scale:.2f}")
+    assert got.shape == ref.shape and err <= FULL_GOLDEN_TOL * scale, (kind, err)
+
+
 def test_topk_semantics(oracle_lib):
     logits = np.array([0.0, 3.0, -1.0, 3.0, 2.0, -20.0], np.float32)
     idx, conf = oracle_lib.topk(logits, 1, 5, 0.1)           # sigmoid, top 5, min conf 0.1

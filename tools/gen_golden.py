@@ -91,8 +91,10 @@ def torch_forward(m: mf.Model, seg: np.ndarray, keep=()):
             w = blob[L.w_off: L.w_off + L.cin * L.cout].reshape(L.cin, L.cout)
             b = blob[L.b_off: L.b_off + L.cout]
             y = (x.reshape(1, L.cin) @ w + b).reshape(1, L.cout, 1, 1)
+        elif L.op == mf.OP_SCALE:   # squeeze-excite: the feature map times its [C] gate (the gate rides in res_tensor)
+            y = x * tensors[L.res_tensor].reshape(1, -1, 1, 1)
         y = torch_act(y, L.act)
-        if L.res_tensor != mf.NO_TENSOR:
+        if L.res_tensor != mf.NO_TENSOR and L.op != mf.OP_SCALE:
             y = y + tensors[L.res_tensor]
         tensors[i + 1] = y
     logits = tensors[len(m.layers)].reshape(-1).numpy()
@@ -249,8 +251,31 @@ REFERENCE_UNIT_CASES = {
 }
 
 
+# The models bench.py and the GPU parity tests actually run: float64 torch / numpy logits of a few segments of
+# the FULL synthetic stacks, so that the oracle is not the sole authority for them.  kind -> (segments, first segment's seed index)
+FULL_MODELS = {"birdnet_v24": (4, 300), "perch_v2": (3, 310), "birdnet_v30": (3, 320), "mini_se": (3, 330)}
+
+
+def gen_full_models():
+    store = {}
+    for kind, (n, start) in FULL_MODELS.items():
+        m = synth.build_model(kind)
+        segs = synth.synth_segments(n, m.sample_count, m.sample_rate, start=start)
+        rows = []
+        for s in segs:
+            lg, _ = torch_forward(m, s)
+            rows.append(lg)
+        store[f"{kind}_logits"] = np.array(rows, np.float32)
+        store[f"{kind}_start"] = np.array([start])
+        print(kind, store[f"{kind}_logits"].shape, float(np.abs(store[f"{kind}_logits"]).max()), flush=True)
+    np.savez_compressed(os.path.join(OUT, "full_model_vectors.npz"), **store)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "full":   # (minutes of float64 CPU work: on request)
+        gen_full_models()
+        return
     with open(os.path.join(OUT, "reference_unit_cases.json"), "w") as f:
         json.dump(REFERENCE_UNIT_CASES, f, indent=1)
 

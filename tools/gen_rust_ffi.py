@@ -72,7 +72,8 @@ def generate() -> str:
         "",
     ]
     for m in re.finditer(r"^[ \t]*#define[ \t]+(BH_\w+)[ \t]+(0x[0-9a-fA-F]+|-?\d+)(u?)[ \t]*$", text, flags=re.M):
-        lines.append(f"pub const {m.group(1)}: {'u32' if m.group(3) else 'usize'} = {m.group(2)};")
+        ty = "u32" if m.group(3) else ("i32" if m.group(2).startswith("-") else "usize")   # (a negative value: an index sentinel)
+        lines.append(f"pub const {m.group(1)}: {ty} = {m.group(2)};")
     for m in re.finditer(r"typedef\s+enum\s*\{(.*?)\}\s*(\w+)\s*;", text, flags=re.S):
         for e in m.group(1).split(","):
             e = e.strip()

@@ -12,6 +12,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // MODE 0: 32 v_fma_f32; 1: 16 v_pk_fma_f32 (VGPR operands); 2: 16 v_pk_fma_f32, addend an SGPR pair; 3: 16 v_exp_f32; 4: 32 v_med3_f32;
 //      5: 8 GELU pairs of round 2 (degree 8: 2 med3 + 10 pk + 2 exp each; + the pre-scale multiply = 11 pk);
 //      6: 8 GELU pairs of round 3 (degree 5, scaled coefficients from SGPRs: 2 med3 + 7 pk + 2 exp each); 7: 16 v_pk_mul_f32;
+//      10: 8 GELU pairs of round 4 (2 x (4 fma + mul + exp + add + fma), scalar, |v| as source modifier);
 //      8: 8 swish pairs (mul, exp, add, rcp, mul per value: scalar ops); 9: 16 v_rcp_f32
 template <int MODE>
 __global__ __launch_bounds__(1024) void k(float *out, int iters, float s0, float s1) {
@@ -66,6 +67,29 @@ __global__ __launch_bounds__(1024) void k(float *out, int iters, float s0, float
                 f32x2 e;
                 e[0] = __builtin_amdgcn_exp2f(q[0]); e[1] = __builtin_amdgcn_exp2f(q[1]);
                 p[j] = __builtin_elementwise_fma(-aa, e, m);
+            } else if (MODE == 10) {
+                // round 4: 2 GELU(v) = (v + |v|) - |v| exp2(|v| (c1 + ... )), scalar FMAs with |v| as a source modifier
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const float x = v[2 * j + h], a = __builtin_fabsf(x);
+                    float t = __builtin_fmaf(a, s0, s1);
+                    t = __builtin_fmaf(t, a, s0); t = __builtin_fmaf(t, a, s1); t = __builtin_fmaf(t, a, s0);
+                    const float e2 = __builtin_amdgcn_exp2f(t * a);
+                    v[2 * j + h] = __builtin_fmaf(-a, e2, x + a);
+                }
+            } else if (MODE == 11) {
+                // the same 2 GELU with PACKED FMAs: |v| by v_and_b32 (no abs modifier on packed ops), v + |v| and the final fma packed
+                const f32x2 x = p[j];
+                f32x2 aa;
+                aa[0] = __builtin_fabsf(x[0]); aa[1] = __builtin_fabsf(x[1]);
+                asm volatile("" : "+v"(aa));   // (materialised: what the packed form costs)
+                f32x2 q = __builtin_elementwise_fma(aa, sc, sd);
+#pragma unroll
+                for (int r = 0; r < 3; r++) q = __builtin_elementwise_fma(q, aa, r & 1 ? sc : sd);
+                q = q * aa;
+                f32x2 e;
+                e[0] = __builtin_amdgcn_exp2f(q[0]); e[1] = __builtin_amdgcn_exp2f(q[1]);
+                p[j] = __builtin_elementwise_fma(-aa, e, x + aa);
             } else if (MODE == 8) {
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
@@ -118,6 +142,8 @@ int main() {
     run<9>("v_rcp_f32", 16, d, it);
     run<5>("GELU pair, round 2 (2 med3 + 11 pk + 2 exp), per PAIR", 8, d, it);
     run<6>("GELU pair, round 3 (2 med3 + 7 pk [SGPR coefficients] + 2 exp), per PAIR", 8, d, it);
+    run<10>("GELU pair, round 4 (2 x (4 fma + mul + exp + add + fma), |v| modifiers), per PAIR", 8, d, it);
+    run<11>("GELU pair, round 4 packed (2 and + 4 pk fma + pk mul + 2 exp + pk add + pk fma), per PAIR", 8, d, it);
     run<8>("swish pair (2 x (mul, exp, add, rcp, mul)), per PAIR", 8, d, it);
     return 0;
 }

@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 MODELS = ["birdnet_v24", "perch_v2", "perch_v2_tiny", "birdnet_v30", "mini", "mini_b0", "mini_hg", "mini_se", "birdnet_v24_tiny"]
-PRECISIONS = {"f32": 0, "f16x3": 1, "f16": 2}
+PRECISIONS = {"f32": 3, "f16x3": 1, "f16": 2}   # BH_FLAG_* (auto plans as f16x3)
 
 
 def plan(path: str, flags: int):
