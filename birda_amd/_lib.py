@@ -61,6 +61,7 @@ SYMBOLS = [
     ("bh_select_provider", C.c_int, [C.c_char_p, C.c_int32, C.POINTER(BhProviderStatus)]),
     ("bh_classifier_provider_status", C.c_int, [_VP, C.POINTER(BhProviderStatus)]),
     ("bh_classifier_fallback_segments", C.c_uint64, [_VP]),
+    ("bh_onnx_to_bhm", C.c_int, [C.c_char_p, C.c_char_p]),
     ("bh_default_batch_size", _SZ, [C.c_uint32, C.c_char_p]),
     ("bh_classifier_default_batch_size", _SZ, [_VP]),
     ("bh_classifier_create", C.c_int, [C.POINTER(BhConfig), C.POINTER(_VP)]),
@@ -90,6 +91,7 @@ SYMBOLS = [
     ("bh_batch_context_stream", _VP, [_VP]),
     ("bh_debug_read_tensor", C.c_int, [_VP, _VP, C.c_uint32, _VP, _SZ]),
     ("bh_tensor_floats", C.c_uint64, [_VP, C.c_uint32]),
+    ("bh_batch_context_lane_fallbacks", C.c_uint64, [_VP]),
     ("bh_batch_context_set_profiling", C.c_int, [_VP, C.c_int]),
     ("bh_batch_context_stage_ms", C.c_int, [_VP, _VP, _VP]),
     ("bh_batch_context_layer_ms", C.c_int, [_VP, _VP, _VP, _SZ]),

@@ -4,30 +4,10 @@
 // (src/inference/classifier.rs:191-646): owns the model, the device weights, the batch
 // contexts and the per-layer kernel schedule.  No CPU compute path exists here: every
 // numeric result comes from the kernels in kernels_frontend.hip / kernels_conv.hip.
-#include <hip/hip_runtime.h>
+#include "api_internal.hpp"
 
-#include <algorithm>
-#include <atomic>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <memory>
-#include <mutex>
-#include <new>
-#include <set>
-#include <string>
-#include <thread>
-#include <map>
-#include <vector>
+namespace bhi {
 
-#include "../../include/birda_hip.h"
-#include "kernels.hpp"
-#include "trace.hpp"
-#include "model.hpp"
-#include "onnx_dense.hpp"
-
-namespace {
 
 thread_local std::string g_err;
 
@@ -50,209 +30,11 @@ int on_exception() noexcept {
     catch (...) { return fail(BH_ERR_INTERNAL, "internal error (unknown exception)"); }
 }
 
-#define HIPCHK(expr)                                                                             \
-    do {                                                                                         \
-        hipError_t e_ = (expr);                                                                  \
-        if (e_ != hipSuccess)                                                                    \
-            return fail(BH_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-    } while (0)
+}  // namespace bhi
 
-enum Stage { ST_MINMAX = 0, ST_MEL, ST_STEM, ST_DW, ST_PW, ST_GAP, ST_DENSE, ST_TOPK, ST_MBCONV };
+using namespace bhi;
 
-size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-
-}  // namespace
-
-struct bh_classifier {
-    bh::Model model;
-    int device = 0;
-    uint32_t top_k = 5;
-    float min_conf = 0.1f;
-    std::vector<std::string> labels;
-    float *d_blob = nullptr;                 // raw model blob (dw / conv weights, biases)
-    std::vector<float *> d_w;                // per layer: weights as the kernels want them
-    std::vector<int> ldw;                    // per layer: padded row length of d_w (pw / dense)
-    std::vector<void *> d_w16;               // per layer: f16 hi / lo fragment planes (pw / dense outside fused blocks), or null
-    std::vector<float> w16_unscale;          // per layer: 2^-s of those planes (they hold W * 2^s, kernels.hpp f16_scale_exponent)
-    std::vector<char> head_gap;              // per layer: 1 = this 1x1 conv + GELU and the global average pool after it run as one launch
-    std::vector<float *> d_owned;            // re-laid buffers to free
-    bh::FrontendParams fe{};
-    bh::FrontendParams *d_fe = nullptr;      // device copy read by the mel kernel
-    std::vector<int> fused_at;               // per layer: index into mb (expand layer of a fused block) or -1
-    std::vector<bh::MbDesc> mb;              // fused MBConv blocks (kernels_mbconv.hip)
-    int twin_max_segments = 256;             // launches up to this size take the twins (one workgroup per CU at most either way)
-    std::vector<bh::MbDesc> mb_small;        // per block: its small-launch twin (cfg < 0: none), same weights (mb_plan_twin)
-    int precision = 0;                       // GEMM operands of the fused blocks: 0 f32, 3 f16 hi/lo split, 1 f16
-    // BH_FLAG_AUTO (the default): split-f16 compute, and a row whose logits come out inf / NaN from finite samples (an activation
-    // left the f16 range) is computed again on the library's own f32 kernels -- by `fb`, a second classifier of the same model
-    // file built with BH_FLAG_F32 the first time that happens.  The reference's dispatch never fails a batch on operand range
-    // (processor.rs:269-277) and its provider selection degrades with a recorded reason (classifier.rs:742-754).
-    bool auto_fallback = false;
-    std::string model_path;
-    bh_classifier *fb = nullptr;
-    std::mutex fb_mu;
-    std::atomic<unsigned long long> fallback_segments{0};
-    unsigned long long *d_stamps = nullptr;  // BIRDA_HIP_MB_STAMPS=1: [mb.size()][8] phase counters
-    uint64_t mel_flops = 0;
-    bh::TopkFilter filter;                   // range filter / species list applied to the kept top-k (device tables below)
-    float *d_class_score = nullptr;
-    unsigned char *d_species_keep = nullptr;
-    float *d_bsg = nullptr;                  // intercept | slope | prior, n_classes each
-    std::mutex warm_mu;
-    std::set<size_t> warmed;                 // WarmupRegistry, classifier.rs:221-246
-    bh_batch_context *internal_ctx = nullptr;
-    std::mutex internal_mu;
-    // Up to three destroyed batch contexts are parked here and handed to the next bh_batch_context_create of the same size: the
-    // per-file pipeline creates and destroys a context per file (reference processor.rs:582-603), bhh_process_files keeps three in
-    // flight, and a context is ~1 GB of hipMalloc plus pinned staging memory -- milliseconds per file at GPU throughput.
-    static constexpr int N_PARKED = 3;
-    bh_batch_context *parked_ctx[N_PARKED] = {nullptr, nullptr, nullptr};
-    std::mutex parked_mu;
-};
-
-struct bh_batch_context {
-    bh_classifier *c = nullptr;
-    size_t max_batch = 0;        // what the buffers hold
-    size_t asked_batch = 0;      // what bh_batch_context_create was asked for (a parked context of up to twice that may serve it): the
-                                 // capacity the entry points enforce
-    bool keep_tensors = false;
-    bool keep_fused = false;   // BIRDA_HIP_KEEP_FUSED=1: a debug context still runs the fused blocks (their outputs are readable)
-    hipStream_t stream = nullptr;
-    hipStream_t copy_stream = nullptr;       // H2D of host batches, ahead of the compute stream
-    std::vector<hipEvent_t> copy_ev;         // one per sub-slice in flight
-    std::vector<hipEvent_t> done_ev;         // bh_predict_pcm*: a sub-slice's rows are in the pinned result buffers
-    // Two compute lanes for the sub-slices of a host-fed slice (lanes_begin below): sub-slice k runs on stream (k & 1 ? stream2 :
-    // stream) in its own part of the arena, so the launch chain of one sub-slice (21 dependent launches: ~0.85 ms however few
-    // segments it holds) runs under the other's kernels instead of after them.
-    static constexpr int MAX_LANES = 4;
-    hipStream_t lane_stream[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};   // [0] = stream
-    hipEvent_t fork_ev = nullptr, join_ev[MAX_LANES] = {nullptr, nullptr, nullptr, nullptr};
-    int n_lanes = 3;
-    int lanes_in_use = 1;        // of the slice being enqueued
-    struct ArenaPlan { std::vector<size_t> t_off; size_t total = 0; };
-    std::map<size_t, ArenaPlan> plans;       // arena plan of an n-segment forward (n < max_batch), built on first use
-    size_t arena_cap = 0;                    // floats allocated (arena_floats + slack for the lanes' alignment losses)
-    uint32_t forced_sub_slices = 0;          // bh_batch_context_set_sub_slices: 0 automatic, 1 whole slices, n equal sub-slices
-    float *d_input = nullptr;    // [max_batch][sample_count]
-    float *d_minmax = nullptr;   // [max_batch][8][2]
-    unsigned *d_inbad = nullptr; // [max_batch][8]: the slice of the segment holds an inf / NaN sample
-    float *d_arena = nullptr;
-    size_t arena_floats = 0;
-    std::vector<size_t> t_off;   // per tensor offset (floats) into the arena
-    float *d_logits = nullptr;   // [max_batch][n_classes]
-    int32_t *d_topk_idx = nullptr;
-    float *d_topk_conf = nullptr;
-    float *h_input = nullptr;    // pinned staging
-    int16_t *d_pcm = nullptr;    // bh_predict_pcm16: the slice's span of the decoded stream (grow-only)
-    size_t pcm_cap = 0;          // bytes
-    unsigned long long *d_starts = nullptr;
-    size_t starts_cap = 0;       // entries
-    float *d_raw = nullptr;      // source-rate segments awaiting the resampler [max_batch][raw_len]
-    float *h_raw = nullptr;
-    size_t raw_len = 0;
-    int32_t *h_topk_idx = nullptr;
-    float *h_topk_conf = nullptr;
-    unsigned *d_nonfinite = nullptr;   // segments whose logits came out inf / NaN from finite samples (top-k kernel), since the last check
-    unsigned *h_nonfinite = nullptr;   // pinned
-    // bh_forward_device calls (with top-k buffers) since the last bh_batch_context_synchronize: what BH_FLAG_AUTO re-runs from
-    struct Pending { const float *d_seg; size_t n; float *d_logits; int32_t *d_idx; float *d_conf; };
-    std::vector<Pending> pending;
-    bool pending_overflow = false;
-    size_t device_bytes = 0;
-    size_t last_n = 0;
-    const float *last_logits = nullptr;
-    // profiling
-    bool profiling = false;
-    std::vector<hipEvent_t> ev;
-    std::vector<int> ev_stage;
-    std::vector<int> ev_layer;   // layer index of the launch an event closes (-1: front-end / top-k)
-    float stage_ms[BH_N_STAGES] = {0};
-    uint32_t stage_launches[BH_N_STAGES] = {0};
-};
-
-namespace {
-
-uint16_t f32_to_f16(float f);
-float f16_to_f32(uint16_t h);
-
-// Gf for one branch (see kernels_frontend.hip): double precision on the host, once.
-// prec 0: f32 fragment-major; prec 3: f16 hi / lo planes for the split MFMA (same byte count).
-std::vector<float> build_gf(const bh::BranchRec &b, const float *W, int nm_pad, int prec, int *scale_exp) {
-    const int L = (int)b.frame_length, K = L / 2, nb = (int)b.n_bins, nm = (int)b.n_mels;
-    std::vector<double> ct(L);
-    for (int i = 0; i < L; i++) ct[i] = std::cos(2.0 * M_PI * (double)i / (double)L);
-    std::vector<int> rows;
-    for (int k = 0; k < nb; k++) {
-        bool nz = false;
-        for (int m = 0; m < nm && !nz; m++) nz = W[(size_t)k * nm + m] != 0.0f;
-        if (nz) rows.push_back(k);
-    }
-    std::vector<float> gf((size_t)K * nm_pad, 0.0f);
-    std::vector<double> acc(nm);
-    for (int j = 0; j < K; j++) {
-        const int n = j + 1;
-        const double wn = 0.5 - 0.5 * ct[n % L];
-        std::fill(acc.begin(), acc.end(), 0.0);
-        for (int k : rows) {
-            const double cv = ct[(size_t)((long long)k * n % L)];
-            const float *wr = W + (size_t)k * nm;
-            for (int m = 0; m < nm; m++) acc[m] += cv * (double)wr[m];
-        }
-        const double scale = (j == K - 1) ? 0.5 * wn : wn;  // the centre sample is added to itself
-        for (int m = 0; m < nm; m++) gf[(size_t)j * nm_pad + m] = (float)(scale * acc[m]);
-    }
-    // f16 planes hold Gf * 2^s (kernels.hpp f16_scale_exponent); the kernel's power law undoes it (BranchParams::log2_bias)
-    *scale_exp = 0;
-    if (prec != 0) {
-        float mx = 0.0f;
-        for (float v : gf) mx = std::max(mx, std::fabs(v));
-        *scale_exp = bh::f16_scale_exponent(mx);
-        for (float &v : gf) v = std::ldexp(v, *scale_exp);
-    }
-    // MFMA-fragment-major relayout (kernels.hpp BranchParams::gf)
-    const int mt_n = nm_pad / 16;
-    std::vector<float> frag((size_t)K * nm_pad);
-    if (prec == 32) {  // mel32_kernel: [step of 16 k][mel tile of 32][plane hi, lo][64 lanes][8 halves]; within a chunk of 64 k the
-        // staged Y rows pair k with k + 32 in one dword, so element jj of step s holds k = 64 (s / 4) + 8 (s % 4) + 4 (lane >> 5) + jj / 2 + 32 (jj % 2)
-        uint16_t *h = reinterpret_cast<uint16_t *>(frag.data());
-        const int mt32 = nm_pad / 32;
-        for (int st = 0; st < K / 16; st++)
-            for (int mt = 0; mt < mt32; mt++)
-                for (int lane = 0; lane < 64; lane++)
-                    for (int jj = 0; jj < 8; jj++) {
-                        const float v = gf[(size_t)(64 * (st >> 2) + 8 * (st & 3) + 4 * (lane >> 5) + (jj >> 1) + 32 * (jj & 1)) * nm_pad + 32 * mt + (lane & 31)];
-                        const uint16_t hi = f32_to_f16(v);
-                        const size_t base = (((size_t)st * mt32 + mt) * 2) * 64 * 8;
-                        h[base + (size_t)lane * 8 + jj] = hi;
-                        h[base + 64 * 8 + (size_t)lane * 8 + jj] = f32_to_f16(v - f16_to_f32(hi));
-                    }
-        return frag;
-    }
-    if (prec != 0) {  // [step of 32 k][mel tile][plane hi, lo][64 lanes][8 halves]: k = 32 s + 4 jj + (lane >> 4)
-        // (the k of a step are dealt to the four lane groups round-robin, not in runs of 8: the kernel's frame-strided LDS
-        //  reads of the matching samples then fall on distinct banks -- kernels_frontend.hip, mel_kernel)
-        uint16_t *h = reinterpret_cast<uint16_t *>(frag.data());
-        for (int st = 0; st < K / 32; st++)
-            for (int mt = 0; mt < mt_n; mt++)
-                for (int lane = 0; lane < 64; lane++)
-                    for (int jj = 0; jj < 8; jj++) {
-                        const float v = gf[(size_t)(32 * st + 4 * jj + (lane >> 4)) * nm_pad + 16 * mt + (lane & 15)];
-                        const uint16_t hi = f32_to_f16(v);
-                        const size_t base = (((size_t)st * mt_n + mt) * 2) * 64 * 8;
-                        h[base + (size_t)lane * 8 + jj] = hi;
-                        h[base + 64 * 8 + (size_t)lane * 8 + jj] = f32_to_f16(v - f16_to_f32(hi));
-                    }
-        return frag;
-    }
-    for (int g = 0; g < K / 16; g++)
-        for (int mt = 0; mt < mt_n; mt++)
-            for (int lane = 0; lane < 64; lane++)
-                for (int c = 0; c < 4; c++) {
-                    const int k = 16 * g + 4 * (lane >> 4) + c, mel = 16 * mt + (lane & 15);
-                    frag[(((size_t)g * mt_n + mt) * 64 + lane) * 4 + c] = gf[(size_t)k * nm_pad + mel];
-                }
-    return frag;
-}
+namespace bhi {
 
 int upload(const void *src, size_t bytes, float **dst) {
     HIPCHK(hipMalloc((void **)dst, bytes ? bytes : 4));
@@ -284,75 +66,18 @@ int read_labels(const char *path, std::vector<std::string> &out) {
         out[0] = out[0].substr(3);
     return BH_OK;
 }
-
 void ctx_mark(bh_batch_context *ctx, int stage, int layer = -1) {
     if (!ctx->profiling) return;
     hipEvent_t e;
     // timing-only events: without the system-scope fence (an L2 write-back + invalidate between every two kernels, which the
     // un-profiled pipeline never sees; BIRDA_HIP_EVENT_FENCE=1 restores the default events: A/B aid)
-    static const bool fence = getenv("BIRDA_HIP_EVENT_FENCE") && getenv("BIRDA_HIP_EVENT_FENCE")[0] == '1';
+    static const bool fence = BH_XENV("BIRDA_HIP_EVENT_FENCE") && BH_XENV("BIRDA_HIP_EVENT_FENCE")[0] == '1';
     if (hipEventCreateWithFlags(&e, fence ? hipEventDefault : hipEventDisableSystemFence) != hipSuccess) return;
     (void)hipEventRecord(e, ctx->stream);
     ctx->ev.push_back(e);
     ctx->ev_stage.push_back(stage);
     ctx->ev_layer.push_back(layer);
 }
-
-// liveness-based arena plan: tensor t is born at step t (tensor 0 = front-end) and dies after
-// the last layer that reads it; the embedding tensor and the logits live to the end.
-void plan_arena(const bh::Model &m, const std::vector<int> &fused_at, const std::vector<char> &head_gap, size_t max_batch,
-                bool keep, std::vector<size_t> &off, size_t &total) {
-    const size_t nt = m.layers.size() + 1;
-    std::vector<size_t> last(nt, 0), sz(nt);
-    for (size_t t = 0; t < nt; t++) { last[t] = t; sz[t] = align_up(m.tensor_floats[t] * max_batch, 64); }
-    for (size_t i = 0; i < m.layers.size(); i++) {
-        const auto &L = m.layers[i];
-        last[L.in_tensor] = std::max(last[L.in_tensor], i + 1);
-        if (L.res_tensor != bh::NO_TENSOR) last[L.res_tensor] = std::max(last[L.res_tensor], i + 1);
-    }
-    if (!keep)
-        for (size_t i = 0; i < fused_at.size(); i++)
-            if (fused_at[i] >= 0) {
-                // one launch reads the block input while it writes the block's last tensor (i + 3; i + 2 for a block without an
-                // expand convolution: depthwise -> project); the tensors in between stay in LDS and take no arena space
-                const size_t len = (i + 2 < m.layers.size() && m.layers[i].op != bh::OP_DWCONV) ? 3 : 2;
-                last[m.layers[i].in_tensor] = std::max(last[m.layers[i].in_tensor], i + len);
-                for (size_t k = 1; k < len; k++) sz[i + k] = 0;
-            }
-    if (!keep)
-        for (size_t i = 0; i + 1 < head_gap.size(); i++)
-            if (head_gap[i]) {
-                // head conv + pool in one launch: workgroups still read the conv's input while finished ones store
-                // pooled rows (tensor i+2), so the input lives through step i+2; the conv's output never exists
-                last[m.layers[i].in_tensor] = std::max(last[m.layers[i].in_tensor], i + 2);
-                sz[i + 1] = 0;
-            }
-    last[m.h.embedding_tensor] = nt;
-    last[nt - 1] = nt;
-    off.assign(nt, 0);
-    total = 0;
-    if (keep) {
-        for (size_t t = 0; t < nt; t++) { off[t] = total; total += sz[t]; }
-        return;
-    }
-    struct Live { size_t off, size, last; };
-    std::vector<Live> live;
-    for (size_t t = 0; t < nt; t++) {
-        // tensors whose last reader ran before step t are dead (step t writes tensor t while
-        // reading tensors with last >= t)
-        live.erase(std::remove_if(live.begin(), live.end(), [&](const Live &l) { return l.last < t; }), live.end());
-        std::sort(live.begin(), live.end(), [](const Live &a, const Live &b) { return a.off < b.off; });
-        size_t pos = 0;
-        for (const auto &l : live) {
-            if (pos + sz[t] <= l.off) break;
-            pos = std::max(pos, l.off + l.size);
-        }
-        off[t] = pos;
-        live.push_back({pos, sz[t], last[t]});
-        total = std::max(total, pos + sz[t]);
-    }
-}
-
 int ctx_create(bh_classifier *c, size_t max_batch, bool keep, bh_batch_context **out) {
     if (!c || !out || max_batch == 0) return fail(BH_ERR_INVALID, "batch context: bad arguments");
     HIPCHK(hipSetDevice(c->device));
@@ -370,9 +95,12 @@ int ctx_create(bh_classifier *c, size_t max_batch, bool keep, bh_batch_context *
     HIPCHK(hipMalloc((void **)&ctx->d_minmax, max_batch * 16 * sizeof(float)));
     HIPCHK(hipMalloc((void **)&ctx->d_inbad, max_batch * 8 * sizeof(unsigned)));
     plan_arena(m, c->fused_at, c->head_gap, max_batch, keep, ctx->t_off, ctx->arena_floats);
-    ctx->arena_cap = ctx->arena_floats + 8 * 64 * (m.layers.size() + 1);
+    // (slack for the lanes: the plans of a slice's sub-slices, side by side, exceed the whole slice's plan by up to 64 floats of
+    //  alignment per tensor and sub-plan; the automatic split makes up to 9 sub-slices, bh_batch_context_set_sub_slices more --
+    //  16 sub-plans fit, beyond that lanes_begin falls back to one stream and counts it: bh_batch_context_lane_fallbacks)
+    ctx->arena_cap = ctx->arena_floats + 16 * 64 * (m.layers.size() + 1);
     HIPCHK(hipMalloc((void **)&ctx->d_arena, ctx->arena_cap * sizeof(float)));
-    if (const char *e = getenv("BIRDA_HIP_NLANES")) ctx->n_lanes = std::max(1, std::min((int)bh_batch_context::MAX_LANES, atoi(e)));
+    if (const char *e = BH_XENV("BIRDA_HIP_NLANES")) ctx->n_lanes = std::max(1, std::min((int)bh_batch_context::MAX_LANES, atoi(e)));
     ctx->lane_stream[0] = ctx->stream;   // (the other lanes' streams are created when a slice first needs them: lanes_begin)
     HIPCHK(hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming));
     HIPCHK(hipMalloc((void **)&ctx->d_logits, max_batch * (size_t)m.h.n_classes * sizeof(float)));
@@ -629,6 +357,18 @@ int settle_rows(bh_classifier *c, bh_batch_context *ctx, size_t r0, size_t nr, f
     return BH_OK;
 }
 
+// The model file as the caller has it: the BHM1 container, or -- what birda's ClassifierBuilder::model_path() is (reference
+// classifier.rs:269-283) -- the .onnx file itself, read by the library's own graph walk (onnx_conv.hpp).  Told apart by the magic.
+bool load_any_model(const char *path, bh::Model &m, std::string &err) {
+    char magic[4] = {0, 0, 0, 0};
+    if (FILE *f = fopen(path, "rb")) { const size_t got = fread(magic, 1, 4, f); fclose(f); if (got != 4) memset(magic, 0, 4); }
+    else { err = std::string("cannot open model file ") + path; return false; }
+    if (!memcmp(magic, "BHM1", 4)) return bh::load_model(path, m, err);
+    if (bh::onnxc::load_onnx_model(path, m, err)) return true;
+    if (err.find("not an ONNX ModelProto") != std::string::npos) err = std::string(path) + ": neither a BHM1 container nor an ONNX model (no ModelProto graph)";
+    return false;
+}
+
 int check_ctx(bh_classifier *c, bh_batch_context *ctx) {
     if (!c || !ctx) return fail(BH_ERR_INVALID, "null classifier or batch context");
     if (ctx->c != c) return fail(BH_ERR_INVALID, "batch context belongs to another classifier");
@@ -665,13 +405,13 @@ unsigned copy_threads() {
 //         has arrived, so it must be small: equal quarters (12.9 ms against 14.8 for the growing split).
 // Boundaries are multiples of `align` segments.
 bool lanes_possible(const bh_batch_context *ctx) {
-    static const bool off = getenv("BIRDA_HIP_LANES") && getenv("BIRDA_HIP_LANES")[0] == '0';
+    static const bool off = BH_XENV("BIRDA_HIP_LANES") && BH_XENV("BIRDA_HIP_LANES")[0] == '0';
     return !off && !ctx->profiling && !ctx->keep_tensors && ctx->n_lanes >= 2;
 }
 std::vector<size_t> sub_slice_cuts(const bh_classifier *c, size_t nb, size_t align, bool single, size_t bytes_per_segment, bool lanes = false,
                                    uint32_t ctx_forced = 0) {
     std::vector<size_t> cuts;
-    static const int env_forced = getenv("BIRDA_HIP_SUBSLICES") ? atoi(getenv("BIRDA_HIP_SUBSLICES")) : 0;   // (A/B aid: n equal sub-slices)
+    static const int env_forced = BH_XENV("BIRDA_HIP_SUBSLICES") ? atoi(BH_XENV("BIRDA_HIP_SUBSLICES")) : 0;   // (A/B aid: n equal sub-slices)
     const int forced = ctx_forced ? (int)ctx_forced : env_forced;
     auto up = [&](size_t v) { return std::min(nb, (v + align - 1) / align * align); };
     if (forced == 1) {
@@ -683,7 +423,7 @@ std::vector<size_t> sub_slice_cuts(const bh_classifier *c, size_t nb, size_t ali
         // a first sub-slice of 64 segments where the upload is the shorter side (PCM16: 5.2 against 6.3 us per segment): the device
         // starts after 0.33 ms instead of 0.65 and the short forward's floor runs under the next sub-slices (pinned PCM16
         // 111-114 k -> 115-117 k segments/s; 32 or 96 segments: no gain; pinned f32 segments, upload-bound, lose 2 % to it)
-        static const int first_env = getenv("BIRDA_HIP_FIRST_SUBSLICE") ? atoi(getenv("BIRDA_HIP_FIRST_SUBSLICE")) : -1;   // (A/B aid)
+        static const int first_env = BH_XENV("BIRDA_HIP_FIRST_SUBSLICE") ? atoi(BH_XENV("BIRDA_HIP_FIRST_SUBSLICE")) : -1;   // (A/B aid)
         const double upload_us = (double)bytes_per_segment / 55e3;
         const double compute_us = (2.0 * (double)c->model.macs_per_segment() + (double)c->mel_flops) / 130e6;
         const size_t first = first_env >= 0 ? (size_t)first_env : (upload_us < compute_us ? 64 : 0);
@@ -734,7 +474,7 @@ bool lanes_begin(bh_classifier *c, bh_batch_context *ctx, const std::vector<size
             plan_arena(c->model, c->fused_at, c->head_gap, ns, false, p.t_off, p.total);
             it = ctx->plans.emplace(ns, std::move(p)).first;
         }
-        if (base + it->second.total > ctx->arena_cap) { lanes.clear(); return false; }
+        if (base + it->second.total > ctx->arena_cap) { lanes.clear(); ctx->lane_fallbacks++; return false; }
         lanes.push_back({ctx->lane_stream[si % (size_t)want], ctx->d_arena + base, it->second.t_off.data(), s0});
         base += align_up(it->second.total, 64);
     }
@@ -766,7 +506,7 @@ void lanes_sync(bh_batch_context *ctx) {
 // (reference: the decode thread filling the channel while the main thread runs batches,
 // src/pipeline/processor.rs:647-671).
 int predict_slices(bh_classifier *c, bh_batch_context *ctx, const float *const *segments, const float *contig,
-                   size_t n, bh_result *out, float *logits_out, float *emb_out, bool whole_slice = false) {
+                   size_t n, bh_result *out, float *logits_out, float *emb_out, bool whole_slice) {
     const auto &m = c->model;
     const size_t S = m.h.sample_count, NC = m.h.n_classes, TK = c->top_k;
     HIPCHK(hipSetDevice(c->device));
@@ -880,264 +620,6 @@ int predict_slices(bh_classifier *c, bh_batch_context *ctx, const float *const *
     }
     return BH_OK;
 }
-
-// IEEE binary16 round-to-nearest-even of a float, and back (host side of the hi/lo operand split)
-uint16_t f32_to_f16(float f) {
-    uint32_t x; memcpy(&x, &f, 4);
-    const uint32_t sign = (x >> 16) & 0x8000u;
-    x &= 0x7fffffffu;
-    if (x >= 0x47800000u) return (uint16_t)(sign | (x > 0x7f800000u ? 0x7e00u : 0x7c00u));   // overflow / nan
-    if (x < 0x38800000u) {                                                                     // subnormal half
-        if (x < 0x33000000u) return (uint16_t)sign;
-        const int shift = 113 - (int)(x >> 23);
-        uint32_t m = (x & 0x7fffffu) | 0x800000u;
-        const uint32_t half = m >> (shift + 13), rem = m & ((1u << (shift + 13)) - 1), mid = 1u << (shift + 12);
-        return (uint16_t)(sign | (half + ((rem > mid || (rem == mid && (half & 1))) ? 1 : 0)));
-    }
-    const uint32_t e = ((x >> 23) - 112) << 10, m = (x >> 13) & 0x3ffu, rem = x & 0x1fffu;
-    uint32_t h = e | m;
-    if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) h++;
-    return (uint16_t)(sign | h);
-}
-float f16_to_f32(uint16_t h) {
-    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1f, m = h & 0x3ffu;
-    uint32_t x;
-    if (e == 0) {
-        if (m == 0) x = sign;
-        else { int k = 0; uint32_t mm = m; while (!(mm & 0x400u)) { mm <<= 1; k++; } x = sign | ((uint32_t)(113 - k) << 23) | ((mm & 0x3ffu) << 13); }
-    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
-    else x = sign | ((e + 112) << 23) | (m << 13);
-    float f; memcpy(&f, &x, 4);
-    return f;
-}
-
-// The block that starts at layer i as a fused launch: expand(1x1, or the stem conv) -> depthwise -> project(1x1) whose
-// intermediates have no other reader, described and handed to the tile planner.  Host logic only (no device): plan_fusion uses
-// it per block at create, bh_plan_fused_blocks walks a model file with it.
-bool describe_fused_block(const bh::Model &m, const std::vector<int> &readers, size_t i, int precision, int force_cfg, bh::MbDesc &d) {
-    const size_t nl = m.layers.size();
-    if (i + 1 < nl && m.layers[i].op == bh::OP_DWCONV && m.layers[i + 1].op == bh::OP_PWCONV) {
-        // depthwise -> project (+ residual) WITHOUT an expand convolution (the expand-ratio-1 blocks of EfficientNet after the
-        // first): fused with the block input standing in for the expanded tensor (MbDesc::noexp)
-        const auto &D = m.layers[i], &P = m.layers[i + 1];
-        if (P.in_tensor != i + 1 || readers[i + 1] != 1 || D.res_tensor != bh::NO_TENSOR) return false;
-        if (D.kh != D.kw || D.sh != D.sw || D.cout != P.cin || D.in_layout != 0) return false;
-        d = bh::MbDesc{};
-        d.noexp = 1;
-        d.H = (int)D.in_h; d.W = (int)D.in_w; d.Cin = (int)D.cout; d.Cexp = (int)D.cout; d.Cout = (int)P.cout;
-        d.Ho = (int)D.out_h; d.Wo = (int)D.out_w; d.pad_t = (int)D.pad_t; d.pad_l = (int)D.pad_l;
-        d.KS = (int)D.kh; d.ST = (int)D.sh;
-        d.act_e = (int)D.act; d.act_d = (int)D.act; d.act_p = (int)P.act;   // (no expand activation: the kernel template is keyed on one)
-        if (const char *dbg = getenv("BIRDA_HIP_MB_DBG")) d.dbg = atoi(dbg);
-        d.prec = precision;
-        if (!bh::mb_plan(d, force_cfg)) {
-            if (d.prec == 0) return false;
-            d.prec = 0;
-            if (!bh::mb_plan(d, force_cfg)) return false;
-        }
-        return true;
-    }
-    if (i + 2 >= nl) return false;
-    const auto &E = m.layers[i], &D = m.layers[i + 1], &P = m.layers[i + 2];
-    const bool stem = E.op == bh::OP_CONV && E.in_layout == 1 && E.kh == E.kw && E.sh == E.sw && E.in_tensor == 0;
-    if ((E.op != bh::OP_PWCONV && !stem) || D.op != bh::OP_DWCONV || P.op != bh::OP_PWCONV) return false;
-    if (D.in_tensor != i + 1 || P.in_tensor != i + 2 || readers[i + 1] != 1 || readers[i + 2] != 1) return false;
-    if (E.res_tensor != bh::NO_TENSOR || D.res_tensor != bh::NO_TENSOR) return false;
-    if (D.kh != D.kw || D.sh != D.sw || E.cout != D.cout || D.cout != P.cin) return false;
-    d = bh::MbDesc{};
-    d.H = (int)E.in_h; d.W = (int)E.in_w; d.Cin = (int)E.cin; d.Cexp = (int)E.cout; d.Cout = (int)P.cout;
-    if (stem) {  // the depthwise conv sees the stem's output image; the stem itself is gathered
-        d.stem = 1; d.stem_c = (int)E.cin; d.stem_h = (int)E.in_h; d.stem_w = (int)E.in_w; d.stem_k = (int)E.kh;
-        d.stem_s = (int)E.sh; d.stem_pt = (int)E.pad_t; d.stem_pl = (int)E.pad_l;
-        d.H = (int)E.out_h; d.W = (int)E.out_w; d.Cin = (int)(E.kh * E.kw * E.cin);
-    }
-    d.Ho = (int)D.out_h; d.Wo = (int)D.out_w; d.pad_t = (int)D.pad_t; d.pad_l = (int)D.pad_l;
-    d.KS = (int)D.kh; d.ST = (int)D.sh;
-    d.act_e = (int)E.act; d.act_d = (int)D.act; d.act_p = (int)P.act;
-    if (const char *dbg = getenv("BIRDA_HIP_MB_DBG")) d.dbg = atoi(dbg);
-    d.prec = precision;
-    // The split-f16 MFMA and the f32 MFMA agree to ~1e-7 of sum|a b|; measured (profiles/), f16x3 is
-    // the faster one on every block, the stem's 18-column im2col GEMM included.
-    if (d.stem && precision == 3 && getenv("BIRDA_HIP_STEM_F32")) d.prec = 0;   // A/B aid
-    if (!bh::mb_plan(d, force_cfg)) {
-        if (d.prec == 0) return false;
-        d.prec = 0;                       // no f16 instantiation for this shape: f32 one, if any
-        if (!bh::mb_plan(d, force_cfg)) return false;
-    }
-    return true;
-}
-
-std::vector<int> tensor_readers(const bh::Model &m) {
-    std::vector<int> readers(m.layers.size() + 1, 0);
-    for (const auto &L : m.layers) {
-        readers[L.in_tensor]++;
-        if (L.res_tensor != bh::NO_TENSOR) readers[L.res_tensor]++;
-    }
-    readers[m.h.embedding_tensor]++;
-    return readers;
-}
-
-// Prepares a fused launch for every block describe_fused_block accepts (weights re-laid fragment-major for the picked tile config).
-int plan_fusion(bh_classifier *c) {
-    const auto &m = c->model;
-    const size_t nl = m.layers.size();
-    c->fused_at.assign(nl, -1);
-    const char *fuse_env = getenv("BIRDA_HIP_FUSE");
-    if (fuse_env && fuse_env[0] == '0') return BH_OK;
-    const char *cfg_env = getenv("BIRDA_HIP_MB_CFG");
-    const int force_cfg = cfg_env ? atoi(cfg_env) : -1;
-    const std::vector<int> readers = tensor_readers(m);
-    for (size_t i = 0; i + 2 < nl; i++) {
-        bh::MbDesc d{};
-        if (!describe_fused_block(m, readers, i, c->precision, force_cfg, d)) continue;
-        // (a no-expand block is layers i = depthwise, i + 1 = project; E then only lends the code below a valid layer to name)
-        const auto &E = m.layers[i], &D = m.layers[d.noexp ? i : i + 1], &P = m.layers[d.noexp ? i + 1 : i + 2];
-        // per-chunk weight blocks (kernels.hpp MbDesc)
-        const int CE = d.CE, NTE = CE / 16, KG = d.KG, NTOP = d.NTOP, nch = d.nchunks, KK = d.KS * d.KS;
-        const float *We = m.blob.data() + E.w_off, *Wp = m.blob.data() + P.w_off, *Wd = m.blob.data() + D.w_off;
-        const float *be = m.blob.data() + E.b_off, *bd = m.blob.data() + D.b_off;
-        const bool h16 = d.prec != 0;
-        // f16 operand planes hold We * 2^se and Wp * 2^sp (kernels.hpp f16_scale_exponent); be / bp are multiplied alike
-        int se = 0, sp = 0;
-        if (h16) {
-            float me = 0.0f, mp = 0.0f;
-            for (size_t q = 0; !d.noexp && q < (size_t)d.Cin * d.Cexp; q++) me = std::max(me, std::fabs(We[q]));
-            for (size_t q = 0; q < (size_t)d.Cexp * d.Cout; q++) mp = std::max(mp, std::fabs(Wp[q]));
-            se = bh::f16_scale_exponent(me);
-            sp = bh::f16_scale_exponent(mp);
-        }
-        // GELU blocks of the f16 modes: the expand GELU runs on the SCALED accumulator with coefficients c_k 2^(-k se) and the 2^-se
-        // moves into the depthwise taps (kernels.hpp gelu_erf_fast4_scaled).  c_5 2^(-5 se) must stay a normal f32 on both sides:
-        // |se| <= 21 (weights 2^7 away from the usual He-normal sizes still land within 2^-8 of the top of the f16 range).
-        d.e_fold = 0;
-        d.gelu = bh::GeluScaled{0.f, 0.f, 0.f, 0.f, 0.f};
-#if BH_GELU_DEGREE == 5
-        if (d.noexp) se = 0;
-        if (h16 && d.act_e == bh::ACT_GELU_ERF && !d.noexp) {
-            se = std::max(-21, std::min(21, se));
-            d.e_fold = 1;
-            float gc[5];
-            for (int k = 1; k <= 5; k++) gc[k - 1] = std::ldexp(bh::kGeluCoef[k - 1], -k * se);
-            d.gelu = bh::GeluScaled{gc[0], gc[1], gc[2], gc[3], gc[4]};
-        }
-#endif
-        // ... and both GELUs of such a block leave TWICE their value (gelu2x_fast4, kernels.hpp): the expand one's factor joins the
-        // 2^-se in the depthwise taps (x2e), the depthwise one's raises the exponent the project accumulators live at (x2d).
-        int x2e = 0, x2d = 0;
-#if BH_GELU_DEGREE == 5
-        if (h16 && d.act_d == bh::ACT_GELU_ERF) x2d = 1;
-        x2e = d.e_fold;
-#endif
-        const int spa = sp + x2d;   // the project accumulators hold 2^spa times the output
-        d.e_unscale = std::ldexp(1.0f, -se); d.p_scale = std::ldexp(1.0f, spa); d.p_unscale = std::ldexp(1.0f, -spa);
-        const size_t frag = h16 ? 512 : 256, psteps = h16 ? (CE + 31) / 32 : NTE;
-        const bool p16 = h16 && CE == 16;   // project GEMM as one 16-deep step: [column tile]{hi, lo}[64 lanes][4 halves]
-        const size_t we_fl = (size_t)KG * NTE * frag + CE, wp_fl = p16 ? (size_t)NTOP * 256 : psteps * NTOP * frag, wd_fl = (size_t)KK * CE + CE;
-        std::vector<float> wef(nch * we_fl, 0.0f), wpf(nch * wp_fl, 0.0f), wdf(nch * wd_fl, 0.0f);
-        // (stem block in the f16 modes: the kernel gathers its im2col columns by memory runs, kernels_mbconv.hip -- position
-        //  8 kq + 3 q + dx of the one 32-deep step is tap (dy, dx) of channel ch with run 2 kq + q = 3 ch + dy)
-        auto we_at = [&](int k, int n) {
-            if (d.stem && h16) {
-                const int kq = k >> 3, jj = k & 7, r = 2 * kq + jj / 3, dx = jj % 3;
-                if (k >= 32 || jj >= 6 || r >= 3 * d.stem_c) return 0.0f;
-                const int ch = r / 3, dy = r - 3 * ch;
-                k = (dy * 3 + dx) * d.stem_c + ch;
-            }
-            return (!d.noexp && k < d.Cin && n < d.Cexp) ? std::ldexp(We[(size_t)k * d.Cexp + n], se) : 0.0f;
-        };
-        auto wp_at = [&](int k, int n) { return (k < d.Cexp && n < d.Cout) ? std::ldexp(Wp[(size_t)k * d.Cout + n], sp) : 0.0f; };
-        // f16: element jj of lane's 8-half fragment = k = 32 g + 8 (lane >> 4) + jj; hi plane then lo plane
-        auto put16 = [&](std::vector<float> &dst, size_t base_fl, int plane, int lane, int jj, float v) {
-            uint16_t *h = reinterpret_cast<uint16_t *>(dst.data() + base_fl) + ((size_t)plane * 64 + lane) * 8 + jj;
-            const uint16_t hi = f32_to_f16(v);
-            *h = plane == 0 ? hi : f32_to_f16(v - f16_to_f32(hi));
-        };
-        for (int ch = 0; ch < nch; ch++) {
-            for (int g = 0; g < KG; g++)
-                for (int j = 0; j < NTE; j++)
-                    for (int lane = 0; lane < 64; lane++) {
-                        const int n = ch * CE + 16 * j + (lane & 15);
-                        if (h16) {
-                            for (int jj = 0; jj < 8; jj++) {
-                                const float v = we_at(32 * g + 8 * (lane >> 4) + jj, n);
-                                const size_t base = ch * we_fl + ((size_t)g * NTE + j) * 512;
-                                put16(wef, base, 0, lane, jj, v);
-                                put16(wef, base, 1, lane, jj, v);
-                            }
-                        } else {
-                            for (int cc = 0; cc < 4; cc++)
-                                wef[ch * we_fl + (((size_t)g * NTE + j) * 64 + lane) * 4 + cc] = we_at(16 * g + 4 * (lane >> 4) + cc, n);
-                        }
-                    }
-            for (int n = 0; n < CE; n++) wef[ch * we_fl + (size_t)KG * NTE * frag + n] = (!d.noexp && ch * CE + n < d.Cexp) ? std::ldexp(be[ch * CE + n], se) : 0.0f;
-            if (p16) {
-                for (int j = 0; j < NTOP; j++)
-                    for (int lane = 0; lane < 64; lane++)
-                        for (int jj = 0; jj < 4; jj++) {
-                            const float v = wp_at(ch * CE + 4 * (lane >> 4) + jj, 16 * j + (lane & 15));
-                            uint16_t *h = reinterpret_cast<uint16_t *>(wpf.data() + ch * wp_fl + (size_t)j * 256);
-                            const uint16_t hi = f32_to_f16(v);
-                            h[(size_t)lane * 4 + jj] = hi;
-                            h[(size_t)(64 + lane) * 4 + jj] = f32_to_f16(v - f16_to_f32(hi));
-                        }
-            }
-            for (int g = 0; g < (int)psteps && !p16; g++)
-                for (int j = 0; j < NTOP; j++)
-                    for (int lane = 0; lane < 64; lane++) {
-                        const int n = 16 * j + (lane & 15);
-                        if (h16) {
-                            for (int jj = 0; jj < 8; jj++) {
-                                const int kk = 32 * g + 8 * (lane >> 4) + jj;          // k inside the chunk (zero padding past CE)
-                                const float v = kk < CE ? wp_at(ch * CE + kk, n) : 0.0f;
-                                const size_t base = ch * wp_fl + ((size_t)g * NTOP + j) * 512;
-                                put16(wpf, base, 0, lane, jj, v);
-                                put16(wpf, base, 1, lane, jj, v);
-                            }
-                        } else {
-                            for (int cc = 0; cc < 4; cc++)
-                                wpf[ch * wp_fl + (((size_t)g * NTOP + j) * 64 + lane) * 4 + cc] = wp_at(ch * CE + 16 * g + 4 * (lane >> 4) + cc, n);
-                        }
-                    }
-            for (int tap = 0; tap < KK; tap++)
-                for (int n = 0; n < CE; n++)
-                    wdf[ch * wd_fl + (size_t)tap * CE + n] = ch * CE + n < d.Cexp ? std::ldexp(Wd[(size_t)tap * d.Cexp + ch * CE + n], d.e_fold ? -se - x2e : 0) : 0.0f;
-            for (int n = 0; n < CE; n++) wdf[ch * wd_fl + (size_t)KK * CE + n] = ch * CE + n < d.Cexp ? bd[ch * CE + n] : 0.0f;
-        }
-        float *dwe = nullptr, *dwp = nullptr, *dwd = nullptr;
-        int rc = upload(wef.data(), wef.size() * sizeof(float), &dwe);
-        if (rc != BH_OK) return rc;
-        c->d_owned.push_back(dwe);
-        rc = upload(wpf.data(), wpf.size() * sizeof(float), &dwp);
-        if (rc != BH_OK) return rc;
-        c->d_owned.push_back(dwp);
-        rc = upload(wdf.data(), wdf.size() * sizeof(float), &dwd);
-        if (rc != BH_OK) return rc;
-        c->d_owned.push_back(dwd);
-        d.We = dwe; d.Wp = dwp; d.Wd = dwd;
-        d.bp = c->d_blob + P.b_off;
-        if (spa != 0) {   // bp * 2^spa: the project accumulators start there
-            std::vector<float> bps(d.Cout);
-            for (int n = 0; n < d.Cout; n++) bps[n] = std::ldexp(m.blob[P.b_off + n], spa);
-            float *dbp = nullptr;
-            rc = upload(bps.data(), bps.size() * sizeof(float), &dbp);
-            if (rc != BH_OK) return rc;
-            c->d_owned.push_back(dbp);
-            d.bp = dbp;
-        }
-        c->fused_at[i] = (int)c->mb.size();
-        c->mb.push_back(d);
-        {
-            bh::MbDesc tw{};
-            tw.cfg = -1;
-            static const bool no_twin = getenv("BIRDA_HIP_MB_TWIN") && getenv("BIRDA_HIP_MB_TWIN")[0] == '0';   // (A/B aid)
-            if (force_cfg < 0 && !no_twin && bh::mb_plan_twin(d, tw)) c->mb_small.push_back(tw);
-            else { tw.cfg = -1; c->mb_small.push_back(tw); }
-        }
-        i += d.noexp ? 1 : 2;
-    }
-    return BH_OK;
-}
-
 int internal_ctx(bh_classifier *c, size_t n, bh_batch_context **out) {
     if (c->internal_ctx && c->internal_ctx->max_batch >= n) { *out = c->internal_ctx; return BH_OK; }
     if (c->internal_ctx) { ctx_destroy(c->internal_ctx); c->internal_ctx = nullptr; }
@@ -1146,7 +628,8 @@ int internal_ctx(bh_classifier *c, size_t n, bh_batch_context **out) {
     return rc;
 }
 
-}  // namespace
+}  // namespace bhi
+
 
 extern "C" {
 
@@ -1235,7 +718,7 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) try {
     if (cfg->top_k == 0 || cfg->top_k > BH_MAX_TOP_K) return fail(BH_ERR_INVALID, "top_k must be 1..%d", BH_MAX_TOP_K);
     auto c = std::make_unique<bh_classifier>();
     std::string err;
-    if (!bh::load_model(cfg->model_path, c->model, err)) return fail(BH_ERR_IO, "%s", err.c_str());
+    if (!load_any_model(cfg->model_path, c->model, err)) return fail(BH_ERR_IO, "%s", err.c_str());
     const auto &m = c->model;
     if (cfg->labels_path) {
         int rc = read_labels(cfg->labels_path, c->labels);
@@ -1409,7 +892,7 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) try {
             if (!other_reader) c->head_gap[i] = 1;
         }
     }
-    if (const char *st = getenv("BIRDA_HIP_MB_STAMPS"); st && st[0] == '1' && !c->mb.empty()) {
+    if (const char *st = BH_XENV("BIRDA_HIP_MB_STAMPS"); st && st[0] == '1' && !c->mb.empty()) {
         HIPCHK(hipMalloc((void **)&c->d_stamps, c->mb.size() * 8 * sizeof(unsigned long long)));
         HIPCHK(hipMemset(c->d_stamps, 0, c->mb.size() * 8 * sizeof(unsigned long long)));
         for (size_t i = 0; i < c->mb.size(); i++) { c->mb[i].stamps = c->d_stamps + i * 8; c->mb_small[i].stamps = c->mb[i].stamps; }
@@ -1657,6 +1140,7 @@ size_t bh_batch_context_bytes(const bh_batch_context *ctx) {
     return ctx ? ctx->max_batch * (size_t)ctx->c->model.h.sample_count * sizeof(float) : 0;
 }
 size_t bh_batch_context_device_bytes(const bh_batch_context *ctx) { return ctx ? ctx->device_bytes : 0; }
+uint64_t bh_batch_context_lane_fallbacks(const bh_batch_context *ctx) { return ctx ? ctx->lane_fallbacks : 0; }
 int bh_batch_context_set_sub_slices(bh_batch_context *ctx, uint32_t n) {
     if (!ctx) return fail(BH_ERR_INVALID, "null batch context");
     ctx->forced_sub_slices = n;
@@ -1826,11 +1310,20 @@ int bh_classifier_fused_blocks(const bh_classifier *c, int32_t *cfgs, size_t cap
     return (int)c->mb.size();
 }
 
+int bh_onnx_to_bhm(const char *onnx_path, const char *bhm_path) try {
+    if (!onnx_path || !bhm_path) return fail(BH_ERR_INVALID, "onnx_to_bhm: null path");
+    bh::Model m;
+    std::string err;
+    if (!bh::onnxc::load_onnx_model(onnx_path, m, err)) return fail(BH_ERR_IO, "%s", err.c_str());
+    if (!bh::onnxc::write_bhm(bhm_path, m, err)) return fail(BH_ERR_IO, "%s", err.c_str());
+    return BH_OK;
+} catch (...) { return on_exception(); }
+
 int bh_plan_fused_blocks(const char *model_path, uint32_t flags, int32_t *cfgs, int32_t *layers, size_t cap) try {
     if (!model_path) return fail(BH_ERR_INVALID, "plan_fused_blocks: null model path");
     bh::Model m;
     std::string err;
-    if (!bh::load_model(model_path, m, err)) return fail(BH_ERR_IO, "%s", err.c_str());
+    if (!load_any_model(model_path, m, err)) return fail(BH_ERR_IO, "%s", err.c_str());
     const uint32_t p = flags & BH_FLAG_PRECISION_MASK;
     const int precision = p == BH_FLAG_F32 ? 0 : p == BH_FLAG_F16 ? 1 : 3;
     const std::vector<int> readers = tensor_readers(m);
@@ -2218,305 +1711,9 @@ static int predict_pcm16_core(bh_classifier *c, bh_batch_context *ctx, const voi
     }
     return BH_OK;
 }
-
-// ---- custom classifier on embeddings (reference birdnet_onnx::CustomClassifier; lib.rs:883-901, processor.rs:319-360) ----
 }  // extern "C"
 
-struct bh_custom_classifier {
-    bh::CustomModel model;
-    int device = 0;
-    uint32_t top_k = 0;
-    std::vector<std::string> labels;
-    float *d_blob = nullptr;
-    std::vector<float *> d_w;     // per layer: W with rows padded to a multiple of 4 (or a pointer into d_blob)
-    std::vector<int> ldw;
-    std::vector<float *> d_owned;
-    // scratch, grown on demand: activations of the two widest layers, logits, top-k rows, host copies
-    float *d_act[2] = {nullptr, nullptr};
-    float *d_in = nullptr;
-    int32_t *d_idx = nullptr;
-    float *d_conf = nullptr;
-    size_t cap_rows = 0;
-    uint32_t max_width = 0;
-    uint32_t k0 = 0;              // input width padded to a multiple of 4 (the GEMM's k step): rows of d_in have this stride
-    hipStream_t stream = nullptr;
-    std::mutex mu;
-};
-
-namespace {
-
-int cc_reserve(bh_custom_classifier *cc, size_t rows) {
-    if (rows <= cc->cap_rows) return BH_OK;
-    for (float *&p : cc->d_act) { (void)hipFree(p); p = nullptr; }
-    (void)hipFree(cc->d_in); (void)hipFree(cc->d_idx); (void)hipFree(cc->d_conf);
-    cc->d_in = nullptr; cc->d_idx = nullptr; cc->d_conf = nullptr; cc->cap_rows = 0;
-    for (float *&p : cc->d_act) HIPCHK(hipMalloc((void **)&p, rows * (size_t)cc->max_width * sizeof(float)));
-    HIPCHK(hipMalloc((void **)&cc->d_in, rows * (size_t)cc->k0 * sizeof(float)));
-    HIPCHK(hipMalloc((void **)&cc->d_idx, rows * (size_t)cc->top_k * sizeof(int32_t)));
-    HIPCHK(hipMalloc((void **)&cc->d_conf, rows * (size_t)cc->top_k * sizeof(float)));
-    cc->cap_rows = rows;
-    return BH_OK;
-}
-
-// dense stack + activation / top-k on device rows [n][input_dim] (row stride in_stride); results to the host
-int cc_run(bh_custom_classifier *cc, const float *d_emb, size_t in_stride, size_t n, hipStream_t s, bh_result *out, float *logits_out) {
-    const auto &m = cc->model;
-    int rc = cc_reserve(cc, n);
-    if (rc != BH_OK) return rc;
-    const float *cur = d_emb;
-    if (in_stride != cc->k0) return fail(BH_ERR_INVALID, "custom classifier: input rows must be contiguous and %u wide", cc->k0);
-    for (size_t i = 0; i < m.layers.size(); i++) {
-        const auto &L = m.layers[i];
-        float *dst = cc->d_act[i & 1];
-        bh::launch_pw_gemm(cur, cc->d_w[i], cc->d_blob + L.b_off, nullptr, dst, (int)n, (int)(i == 0 ? cc->k0 : L.in_dim), (int)L.out_dim, cc->ldw[i], (int)L.act, s);
-        cur = dst;
-    }
-    if (!out) {   // every class's activated output, no ranking (the range filter: its last layer carries the sigmoid)
-        HIPCHK(hipGetLastError());
-        if (logits_out) HIPCHK(hipMemcpyAsync(logits_out, cur, n * (size_t)m.h.n_classes * sizeof(float), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        return BH_OK;
-    }
-    const uint32_t TK = cc->top_k;
-    bh::launch_topk(cur, (int)n, (int)m.h.n_classes, (int)m.h.output_activation, (int)TK, 0.0f, bh::TopkFilter{}, cc->d_idx, cc->d_conf, nullptr, nullptr, s);
-    HIPCHK(hipGetLastError());
-    std::vector<int32_t> hi(n * TK);
-    std::vector<float> hc(n * TK);
-    HIPCHK(hipMemcpyAsync(hi.data(), cc->d_idx, n * TK * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(hc.data(), cc->d_conf, n * TK * sizeof(float), hipMemcpyDeviceToHost, s));
-    if (logits_out) HIPCHK(hipMemcpyAsync(logits_out, cur, n * (size_t)m.h.n_classes * sizeof(float), hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    for (size_t i = 0; i < n; i++) {
-        bh_result &r = out[i];
-        r.n_pred = 0;
-        for (uint32_t k = 0; k < TK; k++) {
-            if (hi[i * TK + k] < 0) break;
-            r.index[r.n_pred] = hi[i * TK + k];
-            r.confidence[r.n_pred] = hc[i * TK + k];
-            r.n_pred++;
-        }
-    }
-    return BH_OK;
-}
-
-}  // namespace
-
 extern "C" {
-
-void bh_custom_classifier_destroy(bh_custom_classifier *cc) {
-    if (!cc) return;
-    (void)hipSetDevice(cc->device);
-    if (cc->stream) { (void)hipStreamSynchronize(cc->stream); (void)hipStreamDestroy(cc->stream); }
-    for (float *p : cc->d_owned) (void)hipFree(p);
-    for (float *p : cc->d_act) (void)hipFree(p);
-    (void)hipFree(cc->d_in); (void)hipFree(cc->d_idx); (void)hipFree(cc->d_conf); (void)hipFree(cc->d_blob);
-    delete cc;
-}
-
-// labels, device, stream, weights on the device: everything after the model itself has been read into cc->model
-static int cc_build(bh_custom_classifier *cc, const char *labels_path, int32_t device, uint32_t top_k, bool drop_blank_labels) {
-    const auto &m = cc->model;
-    if (labels_path) {
-        int rc = read_labels(labels_path, cc->labels);
-        if (rc != BH_OK) return rc;
-        if (drop_blank_labels) {   // (a geomodel label file: lines trimmed, blank ones skipped, as the reference's loader reads it)
-            std::vector<std::string> kept;
-            for (auto &l : cc->labels) {
-                size_t a = 0, b = l.size();
-                while (a < b && isspace((unsigned char)l[a])) a++;
-                while (b > a && isspace((unsigned char)l[b - 1])) b--;
-                if (b > a) kept.push_back(l.substr(a, b - a));
-            }
-            cc->labels.swap(kept);
-        }
-        if (cc->labels.size() != m.h.n_classes)
-            return fail(BH_ERR_LABELS, "label count %zu does not match the model's output width %u", cc->labels.size(), m.h.n_classes);
-    }
-    const int ndev = bh_device_count();
-    if (ndev <= 0) return fail(BH_ERR_NO_DEVICE, "no HIP device available (libbirda_hip has no CPU path)");
-    if (device < 0 || device >= ndev) return fail(BH_ERR_NO_DEVICE, "device %d out of range (0..%d)", device, ndev - 1);
-    cc->device = device;
-    cc->top_k = top_k ? std::min<uint32_t>(top_k, BH_MAX_TOP_K) : std::min<uint32_t>(m.h.n_classes, BH_MAX_TOP_K);
-    HIPCHK(hipSetDevice(device));
-    HIPCHK(hipStreamCreateWithFlags(&cc->stream, hipStreamNonBlocking));
-    int rc = upload(m.blob.data(), m.blob.size() * sizeof(float), &cc->d_blob);
-    if (rc != BH_OK) return rc;
-    cc->k0 = (uint32_t)align_up(m.h.input_dim, 4);
-    cc->max_width = cc->k0;
-    for (size_t li = 0; li < m.layers.size(); li++) {
-        const auto &L = m.layers[li];
-        // the GEMM steps k by 4: the FIRST layer's input rows are zero-padded to k0 (a geomodel has 3 inputs); a hidden width
-        // that is not a multiple of 4 would need padded activation rows and is refused
-        if (li > 0 && L.in_dim % 4) return fail(BH_ERR_UNSUPPORTED, "dense stack: hidden width %u not a multiple of 4", L.in_dim);
-        const uint32_t k_rows = li == 0 ? cc->k0 : L.in_dim;
-        cc->max_width = std::max(cc->max_width, L.out_dim);
-        const int ld = (int)align_up(L.out_dim, 4);
-        float *w = cc->d_blob + L.w_off;
-        if (ld != (int)L.out_dim || (L.w_off % 4) || k_rows != L.in_dim) {   // rows padded / 16-byte aligned for the GEMM's loads
-            std::vector<float> wp((size_t)k_rows * ld, 0.0f);
-            for (uint32_t k = 0; k < L.in_dim; k++) memcpy(&wp[(size_t)k * ld], m.blob.data() + L.w_off + (size_t)k * L.out_dim, L.out_dim * sizeof(float));
-            float *d = nullptr;
-            rc = upload(wp.data(), wp.size() * sizeof(float), &d);
-            if (rc != BH_OK) return rc;
-            cc->d_owned.push_back(d);
-            w = d;
-        }
-        cc->d_w.push_back(w);
-        cc->ldw.push_back(ld);
-    }
-    return BH_OK;
-}
-
-// host rows [n][input_dim] -> d_in rows [n][k0] (zero padded)
-static int cc_upload_rows(bh_custom_classifier *cc, const float *rows, size_t n) {
-    int rc = cc_reserve(cc, n);
-    if (rc != BH_OK) return rc;
-    const size_t in = cc->model.h.input_dim;
-    if (cc->k0 == in) {
-        HIPCHK(hipMemcpyAsync(cc->d_in, rows, n * in * sizeof(float), hipMemcpyHostToDevice, cc->stream));
-    } else {
-        HIPCHK(hipMemsetAsync(cc->d_in, 0, n * (size_t)cc->k0 * sizeof(float), cc->stream));
-        HIPCHK(hipMemcpy2DAsync(cc->d_in, (size_t)cc->k0 * sizeof(float), rows, in * sizeof(float), in * sizeof(float), n, hipMemcpyHostToDevice, cc->stream));
-    }
-    return BH_OK;
-}
-
-int bh_custom_classifier_create(const char *model_path, const char *labels_path, int32_t device, uint32_t top_k,
-                                bh_custom_classifier **out) try {
-    if (!model_path || !out) return fail(BH_ERR_INVALID, "custom_classifier_create: null argument");
-    *out = nullptr;
-    std::unique_ptr<bh_custom_classifier, void (*)(bh_custom_classifier *)> cc(new bh_custom_classifier(), bh_custom_classifier_destroy);
-    std::string err;
-    if (!bh::load_custom_model(model_path, cc->model, err)) return fail(BH_ERR_IO, "%s", err.c_str());
-    int rc = cc_build(cc.get(), labels_path, device, top_k, false);
-    if (rc != BH_OK) return rc;
-    *out = cc.release();
-    return BH_OK;
-} catch (...) { return on_exception(); }
-
-uint32_t bh_custom_classifier_num_classes(const bh_custom_classifier *cc) { return cc ? cc->model.h.n_classes : 0; }
-uint32_t bh_custom_classifier_input_dim(const bh_custom_classifier *cc) { return cc ? cc->model.h.input_dim : 0; }
-const char *bh_custom_classifier_label(const bh_custom_classifier *cc, uint32_t index) {
-    if (!cc || index >= cc->labels.size()) return nullptr;
-    return cc->labels[index].c_str();
-}
-
-int bh_custom_classifier_predict_batch(bh_custom_classifier *cc, const float *embeddings, size_t n, bh_result *out) try {
-    if (!cc || (n && (!embeddings || !out))) return fail(BH_ERR_INVALID, "custom_classifier_predict_batch: null argument");
-    if (n == 0) return BH_OK;
-    std::lock_guard<std::mutex> g(cc->mu);
-    HIPCHK(hipSetDevice(cc->device));
-    int rc = cc_upload_rows(cc, embeddings, n);
-    if (rc != BH_OK) return rc;
-    return cc_run(cc, cc->d_in, cc->k0, n, cc->stream, out, nullptr);
-} catch (...) { return on_exception(); }
-
-int bh_predict_batch_two_stage(bh_classifier *c, bh_batch_context *ctx, bh_custom_classifier *cc, const float *const *segments,
-                               size_t n, size_t n_samples, bh_result *out, float *logits_out) try {
-    int rc = check_ctx(c, ctx);
-    if (rc != BH_OK) return rc;
-    if (!cc || !segments || !out) return fail(BH_ERR_INVALID, "predict_batch_two_stage: null argument");
-    const auto &h = c->model.h;
-    if (n_samples != h.sample_count) return fail(BH_ERR_INVALID, "segment has %zu samples, model expects %u", n_samples, h.sample_count);
-    if (cc->device != c->device) return fail(BH_ERR_INVALID, "two-stage: backbone and custom classifier live on different devices");
-    if (h.embedding_dim != cc->model.h.input_dim || cc->k0 != cc->model.h.input_dim)
-        return fail(BH_ERR_INVALID, "bat mode requires %u-d embeddings from the backbone, the model exposes %u", cc->model.h.input_dim, h.embedding_dim);
-    std::lock_guard<std::mutex> g(cc->mu);
-    HIPCHK(hipSetDevice(c->device));
-    std::vector<bh_result> backbone(std::min(n, ctx->max_batch));
-    for (size_t b0 = 0; b0 < n; b0 += ctx->max_batch) {
-        const size_t nb = std::min(ctx->max_batch, n - b0);
-        // the backbone on this slice (results discarded: the custom classifier's replace them, processor.rs:369-372); the
-        // embedding tensor of the slice then sits in the context's arena
-        rc = predict_slices(c, ctx, segments + b0, nullptr, nb, backbone.data(), nullptr, nullptr, true);
-        if (rc != BH_OK) return rc;
-        const float *d_emb = ctx->d_arena + ctx->t_off[h.embedding_tensor];
-        rc = cc_run(cc, d_emb, h.embedding_dim, nb, ctx->stream, out + b0, logits_out ? logits_out + b0 * cc->model.h.n_classes : nullptr);
-        if (rc != BH_OK) return rc;
-    }
-    return BH_OK;
-} catch (...) { return on_exception(); }
-
-// ---- range filter: the geomodel query (reference src/inference/range_filter.rs:19-51 over birdnet_onnx::RangeFilter) ----
-}  // extern "C"
-
-struct bh_range_filter {
-    bh_custom_classifier *cc = nullptr;
-    float threshold = 0.0f;
-};
-
-extern "C" {
-
-void bh_range_filter_destroy(bh_range_filter *rf) {
-    if (!rf) return;
-    bh_custom_classifier_destroy(rf->cc);
-    delete rf;
-}
-
-int bh_range_filter_create(const char *model_path, const char *labels_path, int32_t device, float threshold, bh_range_filter **out) try {
-    if (!model_path || !labels_path || !out) return fail(BH_ERR_INVALID, "range_filter_create: null argument (a geomodel is built from ITS OWN labels)");
-    *out = nullptr;
-    if (!(threshold >= 0.0f && threshold <= 1.0f)) return fail(BH_ERR_INVALID, "range filter threshold %g outside 0..1", (double)threshold);
-    std::unique_ptr<bh_range_filter, void (*)(bh_range_filter *)> rf(new bh_range_filter(), bh_range_filter_destroy);
-    rf->cc = new bh_custom_classifier();
-    rf->threshold = threshold;
-    char magic[4] = {0, 0, 0, 0};
-    if (FILE *f = fopen(model_path, "rb")) { (void)!fread(magic, 1, 4, f); fclose(f); }
-    else return fail(BH_ERR_IO, "cannot open geomodel file %s", model_path);
-    std::string err;
-    const bool ok = memcmp(magic, "BHC1", 4) == 0 ? bh::load_custom_model(model_path, rf->cc->model, err)
-                                                  : bh::onnxd::load_dense_onnx(model_path, rf->cc->model, err);
-    if (!ok) return fail(BH_ERR_IO, "%s", err.c_str());
-    const auto &h = rf->cc->model.h;
-    if (h.input_dim != 3) return fail(BH_ERR_UNSUPPORTED, "a geomodel takes (latitude, longitude, week): this model has %u inputs", h.input_dim);
-    // the scores must leave the last layer activated: a sigmoid folded into it (onnx_dense.hpp) or written there by the converter
-    if (h.output_activation != 0 || rf->cc->model.layers.back().act != bh::ACT_SIGMOID)
-        return fail(BH_ERR_UNSUPPORTED, "a geomodel ends in a sigmoid over its species (output activation %u, last layer activation %u)",
-                    h.output_activation, rf->cc->model.layers.back().act);
-    int rc = cc_build(rf->cc, labels_path, device, 1, true);
-    if (rc != BH_OK) return rc;
-    *out = rf.release();
-    return BH_OK;
-} catch (...) { return on_exception(); }
-
-uint32_t bh_range_filter_num_species(const bh_range_filter *rf) { return rf ? rf->cc->model.h.n_classes : 0; }
-const char *bh_range_filter_label(const bh_range_filter *rf, uint32_t index) { return rf ? bh_custom_classifier_label(rf->cc, index) : nullptr; }
-
-uint32_t bh_birdnet_week(uint32_t month, uint32_t day) {
-    if (month < 1) month = 1;
-    if (month > 12) month = 12;
-    if (day < 1) day = 1;
-    // no clamp on the week inside the month: days 29-31 belong to the next month's first week (capped at 48 for the last days of
-    // December) -- the one form birda's week -> start day -> (month, day) round trip inverts for all 48 weeks (birda_hip.h)
-    return std::min<uint32_t>(48, (month - 1) * 4 + (day - 1) / 7 + 1);
-}
-
-int bh_range_filter_predict_week(bh_range_filter *rf, float latitude, float longitude, float week, float *scores, size_t cap,
-                                 uint32_t *indices, size_t *n_kept) try {
-    if (!rf || !scores) return fail(BH_ERR_INVALID, "range_filter_predict: null argument");
-    const size_t n = rf->cc->model.h.n_classes;
-    if (cap < n) return fail(BH_ERR_INVALID, "range_filter_predict: room for %zu scores, the geomodel has %zu species", cap, n);
-    bh_custom_classifier *cc = rf->cc;
-    std::lock_guard<std::mutex> g(cc->mu);
-    HIPCHK(hipSetDevice(cc->device));
-    const float row[3] = {latitude, longitude, week};
-    int rc = cc_upload_rows(cc, row, 1);
-    if (rc != BH_OK) return rc;
-    rc = cc_run(cc, cc->d_in, cc->k0, 1, cc->stream, nullptr, scores);
-    if (rc != BH_OK) return rc;
-    size_t kept = 0;
-    for (size_t i = 0; i < n; i++)
-        if (scores[i] >= rf->threshold) { if (indices) indices[kept] = (uint32_t)i; kept++; }
-    if (n_kept) *n_kept = kept;
-    return BH_OK;
-} catch (...) { return on_exception(); }
-
-int bh_range_filter_predict(bh_range_filter *rf, double latitude, double longitude, uint32_t month, uint32_t day, float *scores,
-                            size_t cap, uint32_t *indices, size_t *n_kept) {
-    if (month < 1 || month > 12 || day < 1 || day > 31) return fail(BH_ERR_INVALID, "range_filter_predict: month %u / day %u is not a date", month, day);
-    // range_filter.rs:46: `latitude as f32, longitude as f32`
-    return bh_range_filter_predict_week(rf, (float)latitude, (float)longitude, (float)bh_birdnet_week(month, day), scores, cap, indices, n_kept);
-}
 
 int bh_resample_output_len(size_t n_in, uint32_t from_rate, uint32_t to_rate, size_t *n_out) try {
     if (!n_out || from_rate == 0 || to_rate == 0) return fail(BH_ERR_INVALID, "resample_output_len: bad arguments");
@@ -2546,7 +1743,7 @@ int bh_resample_device(bh_classifier *c, bh_batch_context *ctx, const float *d_i
     const bh::ResamplePlan *pl = bh::resample_plan(from_rate, to_rate, &err);
     if (!pl) return fail(BH_ERR_UNSUPPORTED, "%s (%u -> %u Hz)", err ? err : "resampler", from_rate, to_rate);
     bh::launch_resample(*pl, d_in, in_stride, (int)src_len, d_out, out_stride, (int)out_len, (int)n_seg,
-                        c->precision != 0 && !(getenv("BIRDA_HIP_RESAMPLE_F32") && getenv("BIRDA_HIP_RESAMPLE_F32")[0] == '1'), ctx->stream);
+                        c->precision != 0 && !(BH_XENV("BIRDA_HIP_RESAMPLE_F32") && BH_XENV("BIRDA_HIP_RESAMPLE_F32")[0] == '1'), ctx->stream);
     HIPCHK(hipGetLastError());
     return BH_OK;
 } catch (...) { return on_exception(); }

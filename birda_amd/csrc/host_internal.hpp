@@ -1,5 +1,13 @@
 // Shared between the host-side translation units (host_pipeline.cpp, host_output.cpp, host_parquet.cpp).  Not installed.
 #pragma once
+// (see kernels.hpp: A/B switches exist only in the EXPERIMENTS build)
+#ifndef BH_XENV
+#ifdef BIRDA_HIP_EXPERIMENTS
+#define BH_XENV(name) getenv(name)
+#else
+#define BH_XENV(name) (static_cast<const char *>(nullptr))
+#endif
+#endif
 #include <memory>
 #include <string>
 #include <vector>

@@ -967,7 +967,7 @@ extern "C" int bhh_process_files(bh_classifier *clf, const bhh_processing_config
             if (rc == BH_OK) ctx_own.emplace_back(ctx[p->slot], bh_batch_context_destroy);
             // several packs in flight: another pack's forward covers this one's upload, so a pack runs as few, large sub-slices
             // (measured, 8 files of 1 000 segments, three in flight: automatic split 97 k segments/s, two halves 112 k)
-            static const int sub = getenv("BIRDA_HOST_PACK_SUBSLICES") ? atoi(getenv("BIRDA_HOST_PACK_SUBSLICES")) : 2;
+            static const int sub = [] { const char *e = BH_XENV("BIRDA_HOST_PACK_SUBSLICES"); return e ? atoi(e) : 2; }();
             if (rc == BH_OK) (void)bh_batch_context_set_sub_slices(ctx[p->slot], (uint32_t)std::max(0, sub));
             p->rc = rc;
         }

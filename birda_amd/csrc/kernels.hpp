@@ -7,6 +7,17 @@
 #include <cmath>
 #include <mutex>
 
+// Environment switches.  The PRODUCT library reads a short, documented list (tests/test_abi_and_host.py holds the shipped .so to
+// it): BIRDA_HIP_PRECISION, BIRDA_HIP_COPY_THREADS, BIRDA_HOST_PIPELINE_DEPTH, BIRDA_INFERENCE_TIMEOUT, BIRDA_HIP_ROCTX,
+// BIRDA_HOST_TIMING, and the switches the parity tests drive it with (BIRDA_HIP_KEEP_TENSORS, _KEEP_FUSED, _MB_CFG, _MB_PREFER,
+// _FUSE, _MEL32, _MEL_F32, _HEAD_GAP).  Everything else -- ablation bits, A/B aids of experiments DESIGN.md reports -- goes through
+// BH_XENV and exists only in the EXPERIMENTS build (`make EXPERIMENTS=1`): in the product the name is not even in the binary.
+#ifdef BIRDA_HIP_EXPERIMENTS
+#define BH_XENV(name) getenv(name)
+#else
+#define BH_XENV(name) (static_cast<const char *>(nullptr))
+#endif
+
 namespace bh {
 
 // One-time launcher set-up (kernel attributes, CU count) is per DEVICE, not per process: one process may hold
@@ -178,36 +189,55 @@ __device__ __forceinline__ void gelu_erf_fast4_scaled(bh_f32x2 &v0, bh_f32x2 &v1
     v0 = __builtin_elementwise_fma(-a0, e0, m0);
     v1 = __builtin_elementwise_fma(-a1, e1, m1);
 }
+// -DBH_GELU_2X=0 restores round 3's GELU (max(v, 0) form, no factor two to fold) in the fused blocks: the A/B twin of the library
+#ifndef BH_GELU_2X
+#define BH_GELU_2X 1
+#endif
 #if BH_GELU_DEGREE == 5
 // TWICE the GELU, for the fused blocks of the f16 modes (round 4): 2 GELU(v) = (v + |v|) - |v| 2 Phi(-|v|), with
 // 2 Phi(-a) = exp2(Q(a) + 1) and Q(a) + 1 = a (c1 + a (c2 + ... + a c5)) -- the constant term is gone, so the Horner chain ends in a
-// multiply, and v + |v| replaces max(v, 0).  Every operand that is |v| is a VOP3 source modifier (free) as long as the
-// operations stay scalar v_fma_f32 / v_mul_f32 / v_add_f32, which is what this form is written for: packed f32 FMAs buy no
-// throughput on gfx950 (tools/microbench/valu_throughput.hip: v_pk_fma_f32 = 1.8 v_fma_f32) and have no abs modifier, and
-// v_med3_f32 costs 1.5 v_fma_f32.  Per value: 4 FMA + MUL + EXP + ADD + FMA = 8 instructions of which one is quarter rate, against
-// 1 v_med3 + 3.5 packed FMAs + 1 v_exp (5.5 instructions, 12 FMA issue slots against 10.5 here).  The factor two is a power of two
-// and is folded on the host into the next linear stage (depthwise taps after the expand GELU, project planes' exponent after the
-// depthwise GELU: api.hip plan_fusion).  Same polynomial, same rounding points but the last: measured against float64 erfc, the
-// worst point is 0.63 of the activation's stated tolerance, as for gelu_erf_fast (tools/fit_gelu.py --check).
+// multiply -- and v + |v| = 2 max(v, 0) replaces the v_med3_f32 (1.8 v_fma_f32 at the occupancy these kernels run at) and the
+// packed FMA that made |v| from it: |v| is a v_and_b32 per value.  Per PAIR of values: 2 v_and + 4 packed FMAs + 1 packed multiply +
+// 2 v_exp + 1 packed add + 1 packed FMA = 11 instructions, as many as gelu_erf_fast4's (2 v_med3 + 7 packed FMAs + 2 v_exp), with
+// the two dearest non-transcendental ones replaced by the two cheapest: 22.5 ns per pair and SIMD against 25.6
+// (tools/microbench/valu_throughput.hip at 4 waves per SIMD, profiles/r4_d_valu_throughput.txt).  A scalar spelling with |v| as
+// a free VOP3 source modifier (8 instructions per value instead of 5.5) was built first and measured SLOWER in isolation, 31.2 ns:
+// at this occupancy the instruction count, not the issue cycles, is what the SIMD charges for.
+// The factor two is a power of two and is folded on the host into the next linear stage (depthwise taps after the expand GELU,
+// the exponent the project accumulators live at after the depthwise GELU: api.hip plan_fusion).  Same polynomial, same rounding
+// points but the last: against float64 erfc the worst point is 0.63 of the activation's stated tolerance, as for gelu_erf_fast.
 // gc = c_k 2^(-k s) when the argument arrives multiplied by 2^s (gelu_erf_fast4_scaled's convention), c_k otherwise.
-__device__ __forceinline__ float gelu2x_one(float v, const GeluScaled &gc) {
-    const float a = __builtin_fabsf(v);
-    float t = __builtin_fmaf(a, gc.c5, gc.c4);
-    t = __builtin_fmaf(t, a, gc.c3);
-    t = __builtin_fmaf(t, a, gc.c2);
-    t = __builtin_fmaf(t, a, gc.c1);
-    const float e2 = __builtin_amdgcn_exp2f(t * a);
-    return __builtin_fmaf(-a, e2, v + a);
+__device__ __forceinline__ bh_f32x2 bh_abs2(bh_f32x2 v) {
+    bh_f32x2 a;
+    a[0] = __builtin_fabsf(v[0]); a[1] = __builtin_fabsf(v[1]);
+    return a;
 }
 __device__ __forceinline__ void gelu2x_fast4(bh_f32x2 &v0, bh_f32x2 &v1, const GeluScaled &gc) {
-    // (four independent chains: the compiler interleaves them; scalar on purpose, see above)
-    const float r0 = gelu2x_one(v0[0], gc), r1 = gelu2x_one(v0[1], gc), r2 = gelu2x_one(v1[0], gc), r3 = gelu2x_one(v1[1], gc);
-    v0[0] = r0; v0[1] = r1; v1[0] = r2; v1[1] = r3;
+    const bh_f32x2 a0 = bh_abs2(v0), a1 = bh_abs2(v1);
+    bh_f32x2 q0 = __builtin_elementwise_fma(a0, BH_PK(gc.c5), BH_PK(gc.c4));
+    bh_f32x2 q1 = __builtin_elementwise_fma(a1, BH_PK(gc.c5), BH_PK(gc.c4));
+#define BH_GELU_STEP(c)                                       \
+    q0 = __builtin_elementwise_fma(q0, a0, BH_PK(c));         \
+    q1 = __builtin_elementwise_fma(q1, a1, BH_PK(c));
+    BH_GELU_STEP(gc.c3) BH_GELU_STEP(gc.c2) BH_GELU_STEP(gc.c1)
+#undef BH_GELU_STEP
+    q0 = q0 * a0; q1 = q1 * a1;
+    bh_f32x2 e0, e1;
+    e0[0] = __builtin_amdgcn_exp2f(q0[0]); e0[1] = __builtin_amdgcn_exp2f(q0[1]);
+    e1[0] = __builtin_amdgcn_exp2f(q1[0]); e1[1] = __builtin_amdgcn_exp2f(q1[1]);
+    v0 = __builtin_elementwise_fma(-a0, e0, v0 + a0);
+    v1 = __builtin_elementwise_fma(-a1, e1, v1 + a1);
 }
 __device__ __forceinline__ bh_f32x2 gelu2x_fast2(bh_f32x2 v, const GeluScaled &gc) {
-    bh_f32x2 r;
-    r[0] = gelu2x_one(v[0], gc); r[1] = gelu2x_one(v[1], gc);
-    return r;
+    const bh_f32x2 a = bh_abs2(v);
+    bh_f32x2 q = __builtin_elementwise_fma(a, BH_PK(gc.c5), BH_PK(gc.c4));
+    q = __builtin_elementwise_fma(q, a, BH_PK(gc.c3));
+    q = __builtin_elementwise_fma(q, a, BH_PK(gc.c2));
+    q = __builtin_elementwise_fma(q, a, BH_PK(gc.c1));
+    q = q * a;
+    bh_f32x2 e;
+    e[0] = __builtin_amdgcn_exp2f(q[0]); e[1] = __builtin_amdgcn_exp2f(q[1]);
+    return __builtin_elementwise_fma(-a, e, v + a);
 }
 // the unscaled polynomial's coefficients, for the host (c_k 2^-ks is computed there) and for the unscaled 2 GELU
 constexpr float kGeluCoef[5] = {BH_GELU_C1, BH_GELU_C2, BH_GELU_C3, BH_GELU_C4, BH_GELU_C5};

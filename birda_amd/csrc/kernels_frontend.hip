@@ -676,7 +676,7 @@ void launch_mel(const float *x, const float *minmax, float *spec, const Frontend
         max_span = span > max_span ? span : max_span;
         max_frames = p.br[b].n_frames > max_frames ? p.br[b].n_frames : max_frames;
     }
-    static const int dbg = getenv("BIRDA_HIP_MEL_DBG") ? atoi(getenv("BIRDA_HIP_MEL_DBG")) : 0;  // tuning ablations
+    static const int dbg = BH_XENV("BIRDA_HIP_MEL_DBG") ? atoi(BH_XENV("BIRDA_HIP_MEL_DBG")) : 0;  // tuning ablations
     if (p.prec == 32) {
         int span32 = 0;
         for (int b = 0; b < p.n_branches; b++) span32 = std::max(span32, (MEL32_TN - 1) * p.br[b].H + p.br[b].L);
@@ -709,7 +709,7 @@ void launch_mel(const float *x, const float *minmax, float *spec, const Frontend
     const int n_cu = device_cu_count();
     int n_wg = std::min(n_items, (mt <= 6 ? 2 : 1) * n_cu);   // persistent: as many workgroups as fit at once
     // branch partners on one XCD (see the kernel): needs whole groups of 8 n_branches workgroups
-    static const bool pair_off = getenv("BIRDA_HIP_MEL_PAIR") && getenv("BIRDA_HIP_MEL_PAIR")[0] == '0';
+    static const bool pair_off = BH_XENV("BIRDA_HIP_MEL_PAIR") && BH_XENV("BIRDA_HIP_MEL_PAIR")[0] == '0';
     const int pair_group = 8 * p.n_branches;
     const int paired = (!pair_off && p.n_branches > 1 && n_wg >= pair_group) ? 1 : 0;
     if (paired) n_wg -= n_wg % pair_group;

@@ -77,7 +77,7 @@ double mb_try_th(MbDesc &d, int ci, int th) {
     t.ring = 0;
     {
         const size_t lds_ring = lds_base + (2 * we_fl + 3 * wp_fl + 2 * wd_fl) * 4;
-        const char *re = getenv("BIRDA_HIP_MB_RING");
+        const char *re = BH_XENV("BIRDA_HIP_MB_RING");
         // Measured (profiles/r2 notes): the ring removes the wait in front of B1 (22 % -> 3 % of a wave's
         // cycles) but the time moves to B2 and the launch does not get shorter, and wherever it costs a workgroup per CU it is
         // slower (7.31 -> 8.02 us per segment over all blocks when forced).  Off unless BIRDA_HIP_MB_RING=1.
@@ -157,7 +157,7 @@ bool mb_plan(MbDesc &d, int force_cfg) {
     // 426 -> 391, 258 -> 224, 292 -> 254 us per 1 000 segments (old and new library in one run, tools/ab_lib.sh); Perch-shaped
     // model 410 -> 256, 407 -> 298
     static const int kPreferred1[] = {100, 102, 104, 106, 108, 110, 112, 114, 86, 88, 90, 92, 96, 98};   // plain f16: the column-task twins where they apply, else the work rule
-    const char *pe = getenv("BIRDA_HIP_MB_PERSIST");
+    const char *pe = BH_XENV("BIRDA_HIP_MB_PERSIST");
     const int persist_mode = !pe ? 0 : pe[0] == '1' ? 2 : pe[0] == '2' ? 1 : 0;
     if (d.prec == 0)
         for (int base : kPreferred) {  // at the entry's own tile height: the shapes it was measured on

@@ -142,7 +142,7 @@ __device__ __forceinline__ void mb_dma_wait() { asm volatile("s_waitcnt vmcnt(0)
 
 // The depthwise activation of the fused blocks.  GELU in the f16 modes leaves TWICE the GELU (gelu2x_fast4, kernels.hpp): the
 // project planes' exponent carries the factor (api.hip plan_fusion), as the depthwise taps do for the expand GELU.
-template <int ACT, int PREC> constexpr bool mb_gelu2x() { return PREC != 0 && ACT == ACT_GELU_ERF && BH_GELU_DEGREE == 5; }
+template <int ACT, int PREC> constexpr bool mb_gelu2x() { return BH_GELU_2X != 0 && PREC != 0 && ACT == ACT_GELU_ERF && BH_GELU_DEGREE == 5; }
 template <int ACT, int PREC>
 __device__ __forceinline__ void mb_act4(bh_f32x2 &v0, bh_f32x2 &v1) {
 #if BH_GELU_DEGREE == 5
@@ -665,7 +665,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                             if constexpr (PREC != 0 && ACT == ACT_GELU_ERF && BH_GELU_DEGREE == 5) {
                                 // weights and bias carry 2^se: the GELU runs on the scaled value and leaves 2^(se + 1) GELU(x) in the grid;
                                 // the depthwise taps carry the 2^-(se + 1) (kernels.hpp gelu2x_fast4, api.hip plan_fusion)
-                                gelu2x_fast4(v01, v23, gelu_sc);
+                                if constexpr (BH_GELU_2X != 0) gelu2x_fast4(v01, v23, gelu_sc);
+                                else gelu_erf_fast4_scaled(v01, v23, gelu_sc);
                             } else {
                                 if constexpr (PREC != 0) { v01 *= e_unscale; v23 *= e_unscale; }   // weights and bias carry 2^se
                                 bh_act4<ACT>(v01, v23);

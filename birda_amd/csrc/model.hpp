@@ -53,6 +53,47 @@ struct Model {
     }
 };
 
+// The checks every model goes through, whichever file it came from (a BHM1 container, or an ONNX graph read by onnx_conv.hpp):
+// every dimension is bounded (so that no size product below can wrap), every layer must read exactly the tensor its producer
+// wrote, and every weight must lie inside the blob.  Fills tensor_floats.
+inline bool validate_model(Model &m, std::string &err) {
+    if (m.h.n_branches == 0 || m.h.n_branches > 16 || m.h.n_layers == 0 || m.h.n_layers > 4096 || m.branches.size() != m.h.n_branches ||
+        m.layers.size() != m.h.n_layers || m.blob.size() != m.h.blob_floats) { err = "bad counts"; return false; }
+    if (m.h.sample_count == 0 || m.h.sample_count > (1u << 24) || m.h.sample_rate == 0 || m.h.n_classes == 0 || m.h.n_classes > (1u << 24) ||
+        m.h.spec_h == 0 || m.h.spec_w == 0 || m.h.spec_h > (1u << 14) || m.h.spec_w > (1u << 16)) { err = "bad model dimensions"; return false; }
+    m.tensor_floats.assign(m.h.n_layers + 1, 0);
+    m.tensor_floats[0] = (uint64_t)m.h.n_branches * m.h.spec_h * m.h.spec_w;
+    for (uint32_t i = 0; i < m.h.n_layers; i++) {
+        const auto &L = m.layers[i];
+        if (L.cin == 0 || L.cout == 0 || L.cin > (1u << 16) || L.cout > (1u << 24) || L.kh == 0 || L.kw == 0 || L.kh > 64 || L.kw > 64 ||
+            L.sh == 0 || L.sw == 0 || L.sh > 16 || L.sw > 16 || L.pad_t > 64 || L.pad_l > 64 || L.in_h == 0 || L.in_w == 0 || L.out_h == 0 ||
+            L.out_w == 0 || L.in_h > (1u << 16) || L.in_w > (1u << 16) || L.out_h > (1u << 16) || L.out_w > (1u << 16) ||
+            (uint64_t)L.out_h * L.out_w * L.cout > (1ull << 31) || (uint64_t)L.in_h * L.in_w * L.cin > (1ull << 31)) {
+            err = "layer dimensions out of range"; return false;
+        }
+        m.tensor_floats[i + 1] = (uint64_t)L.out_h * L.out_w * L.cout;
+        if (L.in_tensor > i || (L.res_tensor != NO_TENSOR && L.res_tensor > i)) { err = "layer reads a later tensor"; return false; }
+        // what the layer reads must be what its input tensor holds (a pool reads in_h x in_w x cout, a dense layer cin values)
+        const uint64_t in_floats = L.op == OP_GAP || L.op == OP_DWCONV || L.op == OP_SCALE ? (uint64_t)L.in_h * L.in_w * L.cout
+                                 : L.op == OP_DENSE ? (uint64_t)L.cin : (uint64_t)L.in_h * L.in_w * L.cin;
+        if (in_floats != m.tensor_floats[L.in_tensor]) { err = "layer input shape does not match its tensor"; return false; }
+        if (L.res_tensor != NO_TENSOR && L.op != OP_SCALE && m.tensor_floats[L.res_tensor] != m.tensor_floats[i + 1]) {
+            err = "residual shape does not match the layer output"; return false;
+        }
+        if (L.op < OP_CONV || L.op > OP_SCALE) { err = "unknown layer op"; return false; }
+        const uint64_t wn = L.op == OP_CONV ? (uint64_t)L.kh * L.kw * L.cin * L.cout
+                          : L.op == OP_DWCONV ? (uint64_t)L.kh * L.kw * L.cout
+                          : (L.op == OP_PWCONV || L.op == OP_DENSE) ? (uint64_t)L.cin * L.cout : 0;
+        if (L.op == OP_SCALE && (L.res_tensor == NO_TENSOR || m.tensor_floats[L.res_tensor] != L.cout || L.cin != L.cout)) { err = "scale layer without a [C] gate"; return false; }
+        if (L.op != OP_GAP && L.op != OP_SCALE && (L.w_off > m.h.blob_floats || L.b_off > m.h.blob_floats || L.w_off + wn > m.h.blob_floats ||
+                                                   L.b_off + L.cout > m.h.blob_floats)) {
+            err = "layer weights outside blob"; return false;
+        }
+    }
+    if (m.h.embedding_tensor > m.h.n_layers) { err = "bad embedding tensor"; return false; }
+    return true;
+}
+
 inline bool load_model(const char *path, Model &m, std::string &err) {
     FILE *f = fopen(path, "rb");
     if (!f) { err = std::string("cannot open model file ") + path; return false; }
@@ -88,37 +129,7 @@ inline bool load_model(const char *path, Model &m, std::string &err) {
     if (fseek(f, (long)m.h.blob_offset, SEEK_SET) != 0) return bad("bad blob offset");
     if (fread(m.blob.data(), sizeof(float), m.h.blob_floats, f) != m.h.blob_floats) return bad("truncated weights");
     fclose(f);
-    m.tensor_floats.assign(m.h.n_layers + 1, 0);
-    m.tensor_floats[0] = (uint64_t)m.h.n_branches * m.h.spec_h * m.h.spec_w;
-    for (uint32_t i = 0; i < m.h.n_layers; i++) {
-        const auto &L = m.layers[i];
-        if (L.cin == 0 || L.cout == 0 || L.cin > (1u << 16) || L.cout > (1u << 24) || L.kh == 0 || L.kw == 0 || L.kh > 64 || L.kw > 64 ||
-            L.sh == 0 || L.sw == 0 || L.sh > 16 || L.sw > 16 || L.pad_t > 64 || L.pad_l > 64 || L.in_h == 0 || L.in_w == 0 || L.out_h == 0 ||
-            L.out_w == 0 || L.in_h > (1u << 16) || L.in_w > (1u << 16) || L.out_h > (1u << 16) || L.out_w > (1u << 16) ||
-            (uint64_t)L.out_h * L.out_w * L.cout > (1ull << 31) || (uint64_t)L.in_h * L.in_w * L.cin > (1ull << 31)) {
-            err = "layer dimensions out of range"; return false;
-        }
-        m.tensor_floats[i + 1] = (uint64_t)L.out_h * L.out_w * L.cout;
-        if (L.in_tensor > i || (L.res_tensor != NO_TENSOR && L.res_tensor > i)) { err = "layer reads a later tensor"; return false; }
-        // what the layer reads must be what its input tensor holds (a pool reads in_h x in_w x cout, a dense layer cin values)
-        const uint64_t in_floats = L.op == OP_GAP || L.op == OP_DWCONV || L.op == OP_SCALE ? (uint64_t)L.in_h * L.in_w * L.cout
-                                 : L.op == OP_DENSE ? (uint64_t)L.cin : (uint64_t)L.in_h * L.in_w * L.cin;
-        if (in_floats != m.tensor_floats[L.in_tensor]) { err = "layer input shape does not match its tensor"; return false; }
-        if (L.res_tensor != NO_TENSOR && L.op != OP_SCALE && m.tensor_floats[L.res_tensor] != m.tensor_floats[i + 1]) {
-            err = "residual shape does not match the layer output"; return false;
-        }
-        if (L.op < OP_CONV || L.op > OP_SCALE) { err = "unknown layer op"; return false; }
-        const uint64_t wn = L.op == OP_CONV ? (uint64_t)L.kh * L.kw * L.cin * L.cout
-                          : L.op == OP_DWCONV ? (uint64_t)L.kh * L.kw * L.cout
-                          : (L.op == OP_PWCONV || L.op == OP_DENSE) ? (uint64_t)L.cin * L.cout : 0;
-        if (L.op == OP_SCALE && (L.res_tensor == NO_TENSOR || m.tensor_floats[L.res_tensor] != L.cout || L.cin != L.cout)) { err = "scale layer without a [C] gate"; return false; }
-        if (L.op != OP_GAP && L.op != OP_SCALE && (L.w_off > m.h.blob_floats || L.b_off > m.h.blob_floats || L.w_off + wn > m.h.blob_floats ||
-                                                   L.b_off + L.cout > m.h.blob_floats)) {
-            err = "layer weights outside blob"; return false;
-        }
-    }
-    if (m.h.embedding_tensor > m.h.n_layers) { err = "bad embedding tensor"; return false; }
-    return true;
+    return validate_model(m, err);
 }
 
 // BHC1: a custom classifier on embeddings (birda_amd/modelfile.py write_custom_classifier): dense layers + output activation

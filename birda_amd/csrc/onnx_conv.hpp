@@ -1,0 +1,720 @@
+// onnx_conv.hpp -- bh_classifier_create opens the model file the reference hands it: ClassifierBuilder::model_path(...) is the
+// `.onnx` (reference src/inference/classifier.rs:269-283; label-count check src/inference/mod.rs:34-37).  This header reads
+// such a file into the in-memory BHM1 form (model.hpp Model) inside the library -- no Python step between birda and the GPU:
+//
+//   * the CONV STACK is read off the graph (round 4; a C++ port of birda_amd/convert.py model_from_graph, which stays as the
+//     second witness: tests/test_onnx_native.py holds the two to the same layer table and the same weights, bit for bit):
+//     Conv (1x1 -> pointwise, group == channels -> depthwise, else the stem), BatchNormalization folded into the convolution in
+//     front of it, the activation spellings exporters emit (Relu, Clip(0, 6), Sigmoid x Mul = swish, Div / Erf / Add / Mul / Mul
+//     = GELU, the Gelu operator), residual Add folded into its 1x1 convolution, GlobalAveragePool / ReduceMean over H, W,
+//     squeeze-excite gates (pool -> 1x1 -> 1x1 -> Sigmoid -> Mul), Flatten / Reshape / Squeeze / Identity / Dropout after the
+//     pool, Gemm / MatMul + Add, a final Sigmoid or Softmax; NCHW weights re-laid for the NHWC kernels.  Anything else is refused
+//     by operator name.
+//   * the FRONT-END (min / max normalisation, Hann STFT branches, mel projection, power law, flip) is NOT parsed: every node
+//     between the audio input and the first 2-D convolution is skipped and the parameters come from the family table below,
+//     keyed by the graph's input length first (144 000 samples -> BirdNET v2.4's two branches; 160 000 -> the 128-mel 32 kHz
+//     front-end of Perch v2 / BirdNET v3.0, told apart by their output activation), or by the spectrogram's shape for a graph
+//     that starts there.  [EXT] SURVEY.md Appendix B; how the published files spell STFT / mel cannot be known offline, so the
+//     table states the published front-end and tools/onnx_to_bhm.py (the probing recovery of birda_amd/frontend_recover.py, which
+//     fits the front-end to the graph's own responses) remains the way to CHECK a file against it -- the error for an unknown
+//     input length names that tool.
+//
+// Hand-written protobuf wire-format walk on onnx_dense.hpp's Reader (no protobuf / onnx dependency).  Untrusted input: every
+// length is checked against the buffer, every dimension product against the tensor's payload, and the finished model goes
+// through the same validation as a BHM1 file (model.hpp validate_model); fuzzed under ASan with the other loaders
+// (tests/test_host_sanitizers.py).
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "model.hpp"
+#include "onnx_dense.hpp"
+
+namespace bh {
+namespace onnxc {
+
+using onnxd::Reader;
+using onnxd::Span;
+using onnxd::str;
+
+// activation / output-activation codes of the container (kernels.hpp Act, modelfile.py)
+enum : uint32_t { A_NONE = 0, A_RELU = 1, A_RELU6 = 2, A_SWISH = 3, A_GELU_ERF = 4, A_GELU_TANH = 5, A_SIGMOID = 6 };
+enum : uint32_t { O_NONE = 0, O_SIGMOID = 1, O_SOFTMAX = 2 };
+
+struct Attr {
+    bool has_f = false, has_i = false;
+    float f = 0.f;
+    int64_t i = 0;
+    std::string s;
+    std::vector<int64_t> ints;
+};
+struct Node {
+    std::string op, name;
+    std::vector<std::string> in, out;
+    std::map<std::string, Attr> a;
+    int64_t geti(const char *k, int64_t dflt) const { auto it = a.find(k); return it != a.end() && it->second.has_i ? it->second.i : dflt; }
+    float getf(const char *k, float dflt) const { auto it = a.find(k); return it != a.end() && it->second.has_f ? it->second.f : dflt; }
+    const std::vector<int64_t> *ints(const char *k) const { auto it = a.find(k); return it != a.end() && !it->second.ints.empty() ? &it->second.ints : nullptr; }
+    std::string gets(const char *k, const char *dflt) const { auto it = a.find(k); return it != a.end() && !it->second.s.empty() ? it->second.s : std::string(dflt); }
+};
+// an initializer: float32 data stays in the file buffer (raw_data) or in `fl` (float_data); int64 / int32 values in `il`
+struct Tensor {
+    std::vector<int64_t> dims;
+    int64_t dtype = 1;
+    Span raw{};
+    std::vector<float> fl;
+    std::vector<int64_t> il;
+    uint64_t count = 0;
+    bool is_f32() const { return dtype == 1; }
+    float at(uint64_t i) const {
+        if (!fl.empty()) return fl[i];
+        float v; memcpy(&v, raw.p + 4 * i, 4); return v;
+    }
+};
+struct ValueInfo { std::string name; std::vector<int64_t> dims; };   // symbolic dimension: -1
+struct Graph {
+    std::vector<Node> nodes;
+    std::map<std::string, Tensor> init;
+    std::vector<ValueInfo> inputs, outputs;
+};
+
+inline void packed_ints(uint32_t wt, uint64_t v, Span sp, std::vector<int64_t> &out, bool &ok) {
+    if (wt == 2) { Reader q(sp); while (q.more()) { const uint64_t d = q.varint(); if (q.ok) out.push_back((int64_t)d); } if (!q.ok) ok = false; }
+    else if (wt == 0) out.push_back((int64_t)v);
+}
+
+inline bool parse_tensor(Span s, std::string &name, Tensor &t, std::string &err) {
+    Reader r(s);
+    uint32_t no, wt; uint64_t v; Span sp;
+    bool has_raw = false;
+    while (r.more()) {
+        if (!r.field(no, wt, v, sp)) break;
+        if (no == 1) packed_ints(wt, v, sp, t.dims, r.ok);
+        else if (no == 2) t.dtype = (int64_t)v;
+        else if (no == 4) {                  // float_data
+            if (wt == 2) { if (sp.n % 4) { r.ok = false; break; } const size_t k = t.fl.size(); t.fl.resize(k + sp.n / 4); if (sp.n) memcpy(t.fl.data() + k, sp.p, sp.n); }
+            else if (wt == 5) { float f; memcpy(&f, sp.p, 4); t.fl.push_back(f); }
+        } else if (no == 5 || no == 7) packed_ints(wt, v, sp, t.il, r.ok);   // int32_data / int64_data
+        else if (no == 8) name = str(sp);
+        else if (no == 9) { t.raw = sp; has_raw = true; }
+        else if (no == 13 || no == 14) { err = "tensor '" + name + "' keeps its data in an external file: not supported"; return false; }
+    }
+    if (!r.ok) { err = "malformed TensorProto"; return false; }
+    t.count = 1;
+    for (int64_t d : t.dims) {
+        if (d < 0 || d > (1ll << 28)) { err = "tensor '" + name + "': bad dimension"; return false; }
+        t.count *= (uint64_t)d;
+        if (t.count > (1ull << 31)) { err = "tensor '" + name + "': too large"; return false; }
+    }
+    if (t.dtype == 1) {
+        if (has_raw) { if (t.raw.n != t.count * 4) { err = "tensor '" + name + "': raw_data size does not match its dims"; return false; } }
+        else if (t.fl.size() != t.count) { err = "tensor '" + name + "': float_data size does not match its dims"; return false; }
+    } else if (t.dtype == 7 || t.dtype == 6) {   // int64 / int32 (axes, shapes, Slice bounds)
+        if (has_raw) {
+            const size_t w = t.dtype == 7 ? 8 : 4;
+            if (t.raw.n != t.count * w) { err = "tensor '" + name + "': raw_data size does not match its dims"; return false; }
+            t.il.resize(t.count);
+            for (uint64_t i = 0; i < t.count; i++) {
+                if (w == 8) { int64_t x; memcpy(&x, t.raw.p + 8 * i, 8); t.il[i] = x; }
+                else { int32_t x; memcpy(&x, t.raw.p + 4 * i, 4); t.il[i] = x; }
+            }
+        } else if (t.il.size() != t.count) { err = "tensor '" + name + "': integer data size does not match its dims"; return false; }
+    }   // (other element types -- the float64 constants of a front-end -- are carried without data: nothing on the conv stack reads them)
+    return true;
+}
+
+inline bool parse_node(Span s, Node &n, std::map<std::string, Tensor> *const_out, std::string &err) {
+    Reader r(s);
+    uint32_t no, wt; uint64_t v; Span sp;
+    while (r.more()) {
+        if (!r.field(no, wt, v, sp)) break;
+        if (no == 1 && wt == 2) n.in.push_back(str(sp));
+        else if (no == 2 && wt == 2) n.out.push_back(str(sp));
+        else if (no == 3 && wt == 2) n.name = str(sp);
+        else if (no == 4 && wt == 2) n.op = str(sp);
+        else if (no == 5 && wt == 2) {
+            Reader a(sp);
+            std::string an;
+            Attr at;
+            Span tensor{};
+            uint32_t no2, wt2; uint64_t v2; Span sp2;
+            while (a.more()) {
+                if (!a.field(no2, wt2, v2, sp2)) break;
+                if (no2 == 1 && wt2 == 2) an = str(sp2);
+                else if (no2 == 2 && wt2 == 5) { memcpy(&at.f, sp2.p, 4); at.has_f = true; }
+                else if (no2 == 3 && wt2 == 0) { at.i = (int64_t)v2; at.has_i = true; }
+                else if (no2 == 4 && wt2 == 2) at.s = str(sp2);
+                else if (no2 == 5 && wt2 == 2) tensor = sp2;
+                else if (no2 == 8) packed_ints(wt2, v2, sp2, at.ints, a.ok);
+            }
+            if (!a.ok) { err = "malformed AttributeProto"; return false; }
+            if (tensor.p && an == "value" && const_out && !n.out.empty()) {   // a Constant node: its value is an initializer by another spelling
+                std::string tn; Tensor t;
+                if (!parse_tensor(tensor, tn, t, err)) return false;
+                (*const_out)[n.out[0]] = std::move(t);
+            }
+            n.a[an] = std::move(at);
+        }
+    }
+    if (!r.ok) { err = "malformed NodeProto"; return false; }
+    return true;
+}
+
+// ValueInfoProto: name (1), type (2) -> TypeProto.tensor_type (1) -> shape (2) -> dim (1) -> dim_value (1) | dim_param (2)
+inline ValueInfo parse_value_info(Span s) {
+    ValueInfo vi;
+    Reader r(s);
+    uint32_t no, wt; uint64_t v; Span sp;
+    while (r.more()) {
+        if (!r.field(no, wt, v, sp)) break;
+        if (no == 1 && wt == 2) vi.name = str(sp);
+        else if (no == 2 && wt == 2) {
+            Reader ty(sp);
+            while (ty.more()) {
+                if (!ty.field(no, wt, v, sp)) break;
+                if (no != 1 || wt != 2) continue;
+                Reader tt(sp);
+                while (tt.more()) {
+                    if (!tt.field(no, wt, v, sp)) break;
+                    if (no != 2 || wt != 2) continue;
+                    Reader sh(sp);
+                    while (sh.more()) {
+                        if (!sh.field(no, wt, v, sp)) break;
+                        if (no != 1 || wt != 2) continue;
+                        Reader dm(sp);
+                        int64_t val = -1;
+                        uint32_t n3, w3; uint64_t v3; Span s3;
+                        while (dm.more()) {
+                            if (!dm.field(n3, w3, v3, s3)) break;
+                            if (n3 == 1 && w3 == 0) val = (int64_t)v3;
+                        }
+                        vi.dims.push_back(val);
+                    }
+                }
+            }
+        }
+    }
+    return vi;
+}
+
+inline bool parse_graph(Span file, Graph &g, std::string &err) {
+    Reader top(file);
+    Span graph{};
+    uint32_t no, wt; uint64_t v; Span sp;
+    while (top.more()) {
+        if (!top.field(no, wt, v, sp)) break;
+        if (no == 7 && wt == 2) graph = sp;
+    }
+    if (!top.ok || !graph.p) { err = "not an ONNX ModelProto (no graph)"; return false; }
+    Reader r(graph);
+    while (r.more()) {
+        if (!r.field(no, wt, v, sp)) break;
+        if (no == 1 && wt == 2) {
+            Node n;
+            if (!parse_node(sp, n, &g.init, err)) return false;
+            if (n.op != "Constant") g.nodes.push_back(std::move(n));
+        } else if (no == 5 && wt == 2) {
+            std::string name; Tensor t;
+            if (!parse_tensor(sp, name, t, err)) return false;
+            g.init[name] = std::move(t);
+        } else if (no == 11 && wt == 2) g.inputs.push_back(parse_value_info(sp));
+        else if (no == 12 && wt == 2) g.outputs.push_back(parse_value_info(sp));
+        if (g.nodes.size() > 65536) { err = "more than 65 536 nodes"; return false; }
+    }
+    if (!r.ok) { err = "malformed GraphProto"; return false; }
+    return true;
+}
+
+// ---- the family table: the front-ends of the model families the reference serves ([EXT] SURVEY.md Appendix B; the same
+// numbers as birda_amd/synth.py, which builds the seeded stand-ins) -----------------------------------------------------
+struct FamilyBranch { uint32_t L, H, n_mels; float fmin, fmax, mag_scale, out_scale, out_shift; uint32_t flags; };
+struct FamilyFrontend {
+    uint32_t sample_rate, sample_count;
+    float segment_duration, norm_eps;
+    uint32_t n_branches;
+    FamilyBranch br[2];
+    uint32_t n_frames() const { return (sample_count - br[0].L) / br[0].H + 1; }
+};
+inline const FamilyFrontend *frontend_for(uint32_t sample_count, uint32_t spec_c, uint32_t spec_h, uint32_t spec_w) {
+    static const FamilyFrontend kTable[] = {
+        // BirdNET v2.4: 3 s at 48 kHz; 0-3 kHz on 2 048-sample frames (hop 278), 0.5-15 kHz on 1 024-sample frames (hop 280), 96 mels x 511 frames
+        {48000, 144000, 3.0f, 1e-6f, 2, {{2048, 278, 96, 0.0f, 3000.0f, 1.23f, 0.8f, -0.4f, 1}, {1024, 280, 96, 500.0f, 15000.0f, 1.23f, 0.8f, -0.4f, 1}}},
+        // Perch v2 / BirdNET v3.0: 5 s at 32 kHz, one 128-mel branch (60 Hz - 16 kHz, 1 024-sample frames, hop 320)
+        {32000, 160000, 5.0f, 1e-6f, 1, {{1024, 320, 128, 60.0f, 16000.0f, 1.23f, 0.8f, -0.4f, 1}, {}}},
+        // the quarter-second test stacks of birda_amd/synth.py ("mini*": the unit tests' models)
+        {48000, 12000, 0.25f, 1e-6f, 2, {{512, 100, 32, 0.0f, 3000.0f, 1.23f, 0.8f, -0.4f, 1}, {256, 103, 32, 500.0f, 15000.0f, 1.23f, 0.8f, -0.4f, 1}}},
+    };
+    for (const auto &f : kTable) {
+        if (sample_count) { if (f.sample_count == sample_count) return &f; }
+        else if (f.n_branches == spec_c && f.br[0].n_mels == spec_h && f.n_frames() == spec_w) return &f;
+    }
+    return nullptr;
+}
+
+// tf.signal.linear_to_mel_weight_matrix (HTK mel) as birda_amd/synth.py restates it, operation for operation in float64 --
+// the two must give the same float32 matrix (tests/test_onnx_native.py compares them bit for bit): [n_bins][n_mels], DC row zero
+inline void mel_weight_matrix(uint32_t n_mels, uint32_t n_bins, double sample_rate, double fmin, double fmax, std::vector<float> &w) {
+    auto mel = [](double f) { return 1127.0 * std::log1p(f / 700.0); };
+    const double nyquist = sample_rate / 2.0;
+    // numpy.linspace(a, b, n): a + i * ((b - a) / (n - 1)), the last point set to b exactly
+    auto linspace = [](double a, double b, uint32_t n, std::vector<double> &out) {
+        out.resize(n);
+        const double step = (b - a) / (double)(n - 1);
+        for (uint32_t i = 0; i < n; i++) out[i] = (double)i * step + a;
+        if (n > 1) out[n - 1] = b;
+    };
+    std::vector<double> lin, edges;
+    linspace(0.0, nyquist, n_bins, lin);
+    linspace(mel(fmin), mel(fmax), n_mels + 2, edges);
+    w.assign((size_t)n_bins * n_mels, 0.0f);
+    for (uint32_t k = 1; k < n_bins; k++) {
+        const double bm = mel(lin[k]);
+        for (uint32_t j = 0; j < n_mels; j++) {
+            const double lower = edges[j], center = edges[j + 1], upper = edges[j + 2];
+            const double lo = (bm - lower) / (center - lower), up = (upper - bm) / (upper - center);
+            const double v = std::fmax(0.0, std::fmin(lo, up));
+            w[(size_t)k * n_mels + j] = (float)v;
+        }
+    }
+}
+
+struct Blob {
+    std::vector<float> v;
+    uint64_t put(const float *p, size_t n) {                 // 16-float alignment, as birda_amd/convert.py _Blob.put
+        v.resize((v.size() + 15) / 16 * 16, 0.0f);
+        const uint64_t off = v.size();
+        v.insert(v.end(), p, p + n);
+        return off;
+    }
+    uint64_t put(const std::vector<float> &a) { return put(a.data(), a.size()); }
+};
+
+// The graph -> Model.  `err` names what stopped it.
+inline bool model_from_graph(const Graph &g, Model &m, std::string &err) {
+    auto fail = [&](const std::string &why) { err = why; return false; };
+    // the data input: the one graph input that is not an initializer
+    const ValueInfo *gin = nullptr;
+    for (const auto &vi : g.inputs)
+        if (!g.init.count(vi.name)) { if (gin) return fail("the graph has more than one data input"); gin = &vi; }
+    if (!gin) return fail("the graph has no data input");
+    if (g.outputs.empty()) return fail("the graph has no output");
+    std::map<std::string, size_t> prod;
+    for (size_t i = 0; i < g.nodes.size(); i++)
+        for (const auto &o : g.nodes[i].out) prod[o] = i;
+    std::map<std::string, std::vector<size_t>> cons;
+    for (size_t i = 0; i < g.nodes.size(); i++)
+        for (const auto &x : g.nodes[i].in) cons[x].push_back(i);
+    auto f32init = [&](const std::string &name) -> const Tensor * {
+        auto it = g.init.find(name);
+        return it != g.init.end() && it->second.is_f32() ? &it->second : nullptr;
+    };
+    auto scalar = [&](const std::string &name, float &out) {
+        const Tensor *t = f32init(name);
+        if (!t || t->count != 1) return false;
+        out = t->at(0);
+        return true;
+    };
+
+    // ---- where the conv stack starts, and which front-end the family table gives it ----
+    std::string spec;                 // name of the spectrogram tensor [N, C, H, W]
+    const FamilyFrontend *fam = nullptr;
+    const size_t rank = gin->dims.size();
+    if (rank == 4) {
+        const int64_t c = gin->dims[1], h = gin->dims[2], w = gin->dims[3];
+        if (c <= 0 || h <= 0 || w <= 0) return fail("spectrogram input with symbolic channel / height / width");
+        fam = frontend_for(0, (uint32_t)c, (uint32_t)h, (uint32_t)w);
+        if (!fam) return fail("no model family has a " + std::to_string(c) + " x " + std::to_string(h) + " x " + std::to_string(w) + " spectrogram (family table, onnx_conv.hpp)");
+        spec = gin->name;
+    } else if (rank == 2 || rank == 1 || rank == 3) {
+        const int64_t n = gin->dims.back();
+        if (n <= 0) return fail("audio input with a symbolic length");
+        fam = frontend_for((uint32_t)n, 0, 0, 0);
+        if (!fam)
+            return fail("audio input of " + std::to_string(n) + " samples: no model family in the front-end table has that length (onnx_conv.hpp); "
+                        "tools/onnx_to_bhm.py reads a front-end off the graph by probing and writes the BHM1 container this library also opens");
+        // the spectrogram = the data input of the first Conv with a 2-D kernel over n_branches channels
+        for (const auto &n2 : g.nodes) {
+            if (n2.op != "Conv" || n2.in.size() < 2) continue;
+            auto it = g.init.find(n2.in[1]);
+            if (it == g.init.end() || it->second.dims.size() != 4) continue;
+            if (it->second.dims[1] * n2.geti("group", 1) != (int64_t)fam->n_branches) continue;
+            spec = n2.in[0];
+            break;
+        }
+        if (spec.empty()) return fail("no 2-D convolution over the front-end's " + std::to_string(fam->n_branches) + " spectrogram channel(s) found");
+    } else return fail("data input of rank " + std::to_string(rank) + " is neither audio [N, samples] nor a spectrogram [N, C, H, W]");
+    // everything that produces the spectrogram is the front-end: skipped, stated by the family table instead
+    std::set<size_t> front;
+    {
+        std::vector<std::string> stack{spec};
+        while (!stack.empty()) {
+            const std::string t = stack.back(); stack.pop_back();
+            auto it = prod.find(t);
+            if (it == prod.end() || front.count(it->second)) continue;
+            front.insert(it->second);
+            for (const auto &x : g.nodes[it->second].in) stack.push_back(x);
+        }
+    }
+
+    m = Model{};
+    memcpy(m.h.magic, "BHM1", 4);
+    m.h.version = 1;
+    m.h.sample_rate = fam->sample_rate; m.h.sample_count = fam->sample_count; m.h.segment_duration = fam->segment_duration;
+    m.h.norm_eps = fam->norm_eps; m.h.n_branches = fam->n_branches;
+    m.h.spec_h = fam->br[0].n_mels; m.h.spec_w = fam->n_frames();
+    Blob blob;
+    for (uint32_t b = 0; b < fam->n_branches; b++) {
+        const FamilyBranch &fb = fam->br[b];
+        BranchRec r{};
+        r.frame_length = fb.L; r.frame_step = fb.H; r.fft_length = fb.L; r.n_bins = fb.L / 2 + 1; r.n_mels = fb.n_mels;
+        r.n_frames = (fam->sample_count - fb.L) / fb.H + 1;
+        if (r.n_frames != m.h.spec_w) return fail("family table: branches with different frame counts");
+        r.fmin = fb.fmin; r.fmax = fb.fmax; r.mag_scale = fb.mag_scale; r.out_scale = fb.out_scale; r.out_shift = fb.out_shift; r.flags = fb.flags;
+        std::vector<float> w;
+        mel_weight_matrix(fb.n_mels, r.n_bins, (double)fam->sample_rate, fb.fmin, fb.fmax, w);
+        r.mel_w_off = blob.put(w);
+        m.branches.push_back(r);
+    }
+
+    // ---- multi-node activation spellings (convert.py _collapse_activations) ----
+    std::set<size_t> skip;
+    std::map<std::string, std::vector<std::pair<std::string, uint32_t>>> first_of_pattern;   // pattern input -> (pattern output, act)
+    auto sole_consumer = [&](const std::string &name, const char *op, size_t &k) {
+        auto it = cons.find(name);
+        if (it == cons.end() || it->second.size() != 1 || g.nodes[it->second[0]].op != op) return false;
+        k = it->second[0];
+        return true;
+    };
+    const double SQRT2 = 1.4142135623730951;
+    for (size_t i = 0; i < g.nodes.size(); i++) {
+        const Node &n = g.nodes[i];
+        if (n.op == "Erf" && !n.in.empty() && !n.out.empty()) {
+            auto pj = prod.find(n.in[0]);
+            if (pj == prod.end()) continue;
+            const size_t j = pj->second;
+            const Node &pre = g.nodes[j];
+            if ((pre.op != "Div" && pre.op != "Mul") || pre.in.size() != 2) continue;
+            std::string x;
+            for (int side = 0; side < 2; side++) {
+                float c;
+                if (!scalar(pre.in[side ? 0 : 1], c)) continue;
+                if ((pre.op == "Div" && side == 0 && std::fabs((double)c - SQRT2) < 1e-4) || (pre.op == "Mul" && std::fabs((double)c - 1.0 / SQRT2) < 1e-4))
+                    x = pre.in[side ? 1 : 0];
+            }
+            size_t k, m1, m2;
+            if (x.empty() || !sole_consumer(n.out[0], "Add", k)) continue;
+            bool one = false;
+            for (const auto &a : g.nodes[k].in) { float c; if (scalar(a, c) && std::fabs(c - 1.0f) < 1e-6f) one = true; }
+            if (!one || g.nodes[k].out.empty() || !sole_consumer(g.nodes[k].out[0], "Mul", m1) || g.nodes[m1].out.empty() ||
+                !sole_consumer(g.nodes[m1].out[0], "Mul", m2) || g.nodes[m2].out.empty()) continue;
+            bool has_x = false, has_half = false;
+            for (const auto &a : g.nodes[m1].in) if (a != g.nodes[k].out[0]) { float c; if (a == x) has_x = true; if (scalar(a, c) && std::fabs(c - 0.5f) < 1e-6f) has_half = true; }
+            for (const auto &a : g.nodes[m2].in) if (a != g.nodes[m1].out[0]) { float c; if (a == x) has_x = true; if (scalar(a, c) && std::fabs(c - 0.5f) < 1e-6f) has_half = true; }
+            if (has_x && has_half) {
+                skip.insert({j, i, k, m1, m2});
+                first_of_pattern[x].push_back({g.nodes[m2].out[0], A_GELU_ERF});
+            }
+        } else if (n.op == "Sigmoid" && !n.in.empty() && !n.out.empty()) {
+            size_t k;
+            if (sole_consumer(n.out[0], "Mul", k)) {
+                bool takes_x = false;
+                for (const auto &a : g.nodes[k].in) if (a == n.in[0]) takes_x = true;
+                if (takes_x && !g.nodes[k].out.empty()) {
+                    skip.insert({i, k});
+                    first_of_pattern[n.in[0]].push_back({g.nodes[k].out[0], A_SWISH});
+                }
+            }
+        }
+    }
+
+    // ---- the walk (convert.py model_from_graph) ----
+    struct T { uint32_t idx, c, h, w; };                       // tensor index, channels, height, width (1 x 1 once pooled)
+    std::map<std::string, T> tmap;
+    tmap[spec] = T{0, fam->n_branches, m.h.spec_h, m.h.spec_w};
+    std::vector<LayerRec> &layers = m.layers;
+    uint32_t out_act = O_NONE, emb_tensor = 0, emb_dim = 0;
+    std::set<std::string> graph_out;
+    for (const auto &o : g.outputs) graph_out.insert(o.name);
+    auto find = [&](const std::string &name, T &t) { auto it = tmap.find(name); if (it == tmap.end()) return false; t = it->second; return true; };
+    auto set_act = [&](const std::string &name_in, const std::string &name_out, uint32_t act) {
+        T t;
+        if (!find(name_in, t)) return fail("activation on unknown tensor '" + name_in + "'");
+        if (t.idx == 0 || layers[t.idx - 1].act != A_NONE || layers[t.idx - 1].res_tensor != NO_TENSOR)
+            return fail("activation after '" + name_in + "' cannot be folded into its producer");
+        layers[t.idx - 1].act = act;
+        tmap[name_out] = t;
+        return true;
+    };
+    auto flush_patterns = [&](const std::string &x) {
+        auto it = first_of_pattern.find(x);
+        if (it == first_of_pattern.end()) return true;
+        const auto list = it->second;
+        first_of_pattern.erase(it);
+        for (const auto &pa : list)
+            if (!set_act(x, pa.first, pa.second)) return false;
+        return true;
+    };
+    auto new_layer = [&](uint32_t op, uint32_t in_t, uint32_t res_t, uint32_t cin, uint32_t cout, uint32_t kh, uint32_t kw, uint32_t sh, uint32_t sw,
+                         uint32_t pt, uint32_t pl, uint32_t ih, uint32_t iw, uint32_t oh, uint32_t ow, uint32_t in_layout, uint64_t w_off, uint64_t b_off) {
+        LayerRec L{};
+        L.op = op; L.act = A_NONE; L.in_tensor = in_t; L.res_tensor = res_t; L.cin = cin; L.cout = cout; L.kh = kh; L.kw = kw; L.sh = sh; L.sw = sw;
+        L.pad_t = pt; L.pad_l = pl; L.in_h = ih; L.in_w = iw; L.out_h = oh; L.out_w = ow; L.in_layout = in_layout; L.w_off = w_off; L.b_off = b_off;
+        layers.push_back(L);
+        return (uint32_t)layers.size();
+    };
+    constexpr int64_t DIM_MAX = 1 << 16;
+    std::vector<float> tmp, tmpb;
+    for (size_t i = 0; i < g.nodes.size(); i++) {
+        if (skip.count(i) || front.count(i)) continue;
+        const Node &n = g.nodes[i];
+        const std::string &op = n.op;
+        if (n.out.empty() || n.in.empty()) return fail("node '" + n.name + "' (" + op + ") without inputs or outputs");
+        if (layers.size() > 4000) return fail("more than 4 000 layers");
+        if (op == "Conv") {
+            T x;
+            if (!find(n.in[0], x)) return fail("Conv '" + n.name + "': input '" + n.in[0] + "' is not on the path from '" + spec + "'");
+            const Tensor *W = n.in.size() > 1 ? f32init(n.in[1]) : nullptr;
+            if (!W || W->dims.size() != 4) return fail("Conv '" + n.name + "': weights must be a 4-d float32 initializer");
+            const int64_t cout = W->dims[0], cin_g = W->dims[1], kh = W->dims[2], kw = W->dims[3], group = n.geti("group", 1);
+            if (cout <= 0 || cin_g <= 0 || kh <= 0 || kw <= 0 || group <= 0 || cout > DIM_MAX || cin_g > DIM_MAX || kh > 64 || kw > 64 || group > DIM_MAX)
+                return fail("Conv '" + n.name + "': bad weight shape");
+            const Tensor *B = n.in.size() > 2 && !n.in[2].empty() ? f32init(n.in[2]) : nullptr;
+            if (n.in.size() > 2 && !n.in[2].empty() && (!B || B->count != (uint64_t)cout)) return fail("Conv '" + n.name + "': bias must be a float32 initializer of the output width");
+            int64_t sh = 1, sw = 1;
+            if (const auto *st = n.ints("strides")) { if (st->size() != 2) return fail("Conv '" + n.name + "': strides"); sh = (*st)[0]; sw = (*st)[1]; }
+            if (sh <= 0 || sw <= 0 || sh > 16 || sw > 16) return fail("Conv '" + n.name + "': strides");
+            if (const auto *dl = n.ints("dilations")) for (int64_t d : *dl) if (d != 1) return fail("Conv '" + n.name + "': dilation");
+            const int64_t h = x.h, w = x.w, cin = x.c;
+            int64_t oh = (h + sh - 1) / sh, ow = (w + sw - 1) / sw, pt = 0, pl = 0;
+            const std::string autop = n.gets("auto_pad", "NOTSET");
+            if (autop == "SAME_UPPER" || autop == "SAME_LOWER") {
+                const int64_t th = std::max<int64_t>((oh - 1) * sh + kh - h, 0), tw = std::max<int64_t>((ow - 1) * sw + kw - w, 0);
+                if (autop == "SAME_UPPER") { pt = th / 2; pl = tw / 2; } else { pt = th - th / 2; pl = tw - tw / 2; }
+            } else {
+                int64_t pads[4] = {0, 0, 0, 0};
+                if (const auto *pd = n.ints("pads")) { if (pd->size() != 4) return fail("Conv '" + n.name + "': pads"); for (int q = 0; q < 4; q++) pads[q] = (*pd)[q]; }
+                for (int64_t p : pads) if (p < 0 || p > 64) return fail("Conv '" + n.name + "': pads");
+                pt = pads[0]; pl = pads[1];
+                if (h + pads[0] + pads[2] < kh || w + pads[1] + pads[3] < kw) return fail("Conv '" + n.name + "': kernel larger than the padded input");
+                oh = (h + pads[0] + pads[2] - kh) / sh + 1; ow = (w + pads[1] + pads[3] - kw) / sw + 1;
+            }
+            tmpb.assign((size_t)cout, 0.0f);
+            if (B) for (int64_t o = 0; o < cout; o++) tmpb[(size_t)o] = B->at((uint64_t)o);
+            uint32_t li;
+            if (group == 1 && kh == 1 && kw == 1 && sh == 1 && sw == 1) {
+                if (cin_g != cin) return fail("Conv '" + n.name + "': " + std::to_string(cin_g) + " input channels, activation has " + std::to_string(cin));
+                tmp.resize((size_t)cin * cout);                                   // W[cout][cin][1][1] -> [cin][cout]
+                for (int64_t o = 0; o < cout; o++)
+                    for (int64_t c = 0; c < cin; c++) tmp[(size_t)c * cout + o] = W->at((uint64_t)(o * cin + c));
+                const uint64_t wo = blob.put(tmp), bo = blob.put(tmpb);
+                li = new_layer(OP_PWCONV, x.idx, NO_TENSOR, (uint32_t)cin, (uint32_t)cout, 1, 1, 1, 1, 0, 0, (uint32_t)h, (uint32_t)w, (uint32_t)h, (uint32_t)w, 0, wo, bo);
+            } else if (group == cin && cin_g == 1 && cout == cin) {
+                tmp.resize((size_t)kh * kw * cout);                               // W[c][1][kh][kw] -> [kh][kw][c]
+                for (int64_t c = 0; c < cout; c++)
+                    for (int64_t y = 0; y < kh; y++)
+                        for (int64_t z = 0; z < kw; z++) tmp[(size_t)((y * kw + z) * cout + c)] = W->at((uint64_t)((c * kh + y) * kw + z));
+                const uint64_t wo = blob.put(tmp), bo = blob.put(tmpb);
+                li = new_layer(OP_DWCONV, x.idx, NO_TENSOR, (uint32_t)cin, (uint32_t)cout, (uint32_t)kh, (uint32_t)kw, (uint32_t)sh, (uint32_t)sw, (uint32_t)pt, (uint32_t)pl,
+                               (uint32_t)h, (uint32_t)w, (uint32_t)oh, (uint32_t)ow, 0, wo, bo);
+            } else if (group == 1) {
+                if (cin_g != cin) return fail("Conv '" + n.name + "': " + std::to_string(cin_g) + " input channels, activation has " + std::to_string(cin));
+                tmp.resize((size_t)kh * kw * cin * cout);                         // W[cout][cin][kh][kw] -> [kh][kw][cin][cout]
+                for (int64_t o = 0; o < cout; o++)
+                    for (int64_t c = 0; c < cin; c++)
+                        for (int64_t y = 0; y < kh; y++)
+                            for (int64_t z = 0; z < kw; z++)
+                                tmp[(size_t)(((y * kw + z) * cin + c) * cout + o)] = W->at((uint64_t)(((o * cin + c) * kh + y) * kw + z));
+                const uint64_t wo = blob.put(tmp), bo = blob.put(tmpb);
+                li = new_layer(OP_CONV, x.idx, NO_TENSOR, (uint32_t)cin, (uint32_t)cout, (uint32_t)kh, (uint32_t)kw, (uint32_t)sh, (uint32_t)sw, (uint32_t)pt, (uint32_t)pl,
+                               (uint32_t)h, (uint32_t)w, (uint32_t)oh, (uint32_t)ow, x.idx == 0 ? 1u : 0u, wo, bo);
+            } else return fail("Conv '" + n.name + "': group " + std::to_string(group) + " with " + std::to_string(cin) + " -> " + std::to_string(cout) + " channels");
+            if (oh <= 0 || ow <= 0 || oh > DIM_MAX || ow > DIM_MAX) return fail("Conv '" + n.name + "': empty or oversized output");
+            tmap[n.out[0]] = T{li, (uint32_t)cout, layers[li - 1].out_h, layers[li - 1].out_w};
+            if (!flush_patterns(n.out[0])) return false;
+        } else if (op == "BatchNormalization") {
+            T t;
+            if (!find(n.in[0], t) || t.idx == 0) return fail("BatchNormalization that does not follow a convolution directly");
+            LayerRec &L = layers[t.idx - 1];
+            if ((L.op != OP_CONV && L.op != OP_DWCONV && L.op != OP_PWCONV) || L.act != A_NONE || n.in.size() < 5)
+                return fail("BatchNormalization that does not follow a convolution directly");
+            const Tensor *p[4];
+            for (int q = 0; q < 4; q++) { p[q] = f32init(n.in[1 + q]); if (!p[q] || p[q]->count != L.cout) return fail("BatchNormalization: parameters must be float32 initializers of the channel count"); }
+            const double eps = (double)n.getf("epsilon", 1e-5f);
+            const uint64_t nw = L.op == OP_CONV ? (uint64_t)L.kh * L.kw * L.cin * L.cout : L.op == OP_DWCONV ? (uint64_t)L.kh * L.kw * L.cout : (uint64_t)L.cin * L.cout;
+            for (uint32_t c = 0; c < L.cout; c++) {
+                const double gamma = p[0]->at(c), beta = p[1]->at(c), mean = p[2]->at(c), var = p[3]->at(c);
+                const double scale = gamma / std::sqrt(var + eps);
+                const float sf = (float)scale;
+                for (uint64_t q = c; q < nw; q += L.cout) blob.v[L.w_off + q] = blob.v[L.w_off + q] * sf;    // (cout is the last axis in all three layouts)
+                blob.v[L.b_off + c] = (float)(((double)blob.v[L.b_off + c] - mean) * scale + beta);
+            }
+            tmap[n.out[0]] = t;
+            if (!flush_patterns(n.out[0])) return false;
+        } else if (op == "Relu" || op == "Gelu" || op == "Clip") {
+            uint32_t act = op == "Relu" ? A_RELU : op == "Gelu" ? A_GELU_ERF : A_RELU6;
+            if (op == "Clip") {
+                float lo = 0.f, hi = 0.f;
+                const bool has_lo = n.in.size() > 1 && !n.in[1].empty() ? scalar(n.in[1], lo) : (n.a.count("min") ? (lo = n.getf("min", 0.f), true) : false);
+                const bool has_hi = n.in.size() > 2 && !n.in[2].empty() ? scalar(n.in[2], hi) : (n.a.count("max") ? (hi = n.getf("max", 0.f), true) : false);
+                if (!has_lo || !has_hi || lo != 0.0f || hi != 6.0f) return fail("Clip that is not ReLU6 (0, 6)");
+            }
+            if (op == "Gelu") { const std::string ap = n.gets("approximate", "none"); if (ap != "none") act = A_GELU_TANH; }
+            if (!set_act(n.in[0], n.out[0], act)) return false;
+        } else if (op == "Add") {
+            T a, b;
+            if (n.in.size() != 2 || !find(n.in[0], a) || !find(n.in[1], b)) return fail("Add of '" + n.in[0] + "': operands are not both activations on the path");
+            bool done = false;
+            for (int side = 0; side < 2 && !done; side++) {
+                const T &y = side ? b : a, &r = side ? a : b;
+                if (y.idx == 0) continue;
+                LayerRec &L = layers[y.idx - 1];
+                if (L.op == OP_PWCONV && L.res_tensor == NO_TENSOR && r.idx < y.idx && r.c == y.c && r.h == y.h && r.w == y.w) {
+                    L.res_tensor = r.idx;
+                    tmap[n.out[0]] = y;
+                    done = true;
+                }
+            }
+            if (!done) return fail("Add of '" + n.in[0] + "', '" + n.in[1] + "': no 1x1 convolution to fold the residual into");
+        } else if (op == "GlobalAveragePool" || op == "ReduceMean") {
+            T t;
+            if (!find(n.in[0], t)) return fail(op + ": input not on the path");
+            if (op == "ReduceMean") {
+                std::vector<int64_t> axes;
+                if (const auto *ax = n.ints("axes")) axes = *ax;
+                else if (n.in.size() > 1) { auto it = g.init.find(n.in[1]); if (it != g.init.end()) axes = it->second.il; }
+                if (axes.size() != 2) return fail("ReduceMean over axes other than H, W");
+                int64_t a0 = ((axes[0] % 4) + 4) % 4, a1 = ((axes[1] % 4) + 4) % 4;
+                if (!((a0 == 2 && a1 == 3) || (a0 == 3 && a1 == 2))) return fail("ReduceMean over axes other than H, W");
+            }
+            const uint32_t li = new_layer(OP_GAP, t.idx, NO_TENSOR, t.c, t.c, t.h, t.w, 1, 1, 0, 0, t.h, t.w, 1, 1, 0, 0, 0);
+            tmap[n.out[0]] = T{li, t.c, 1, 1};
+            emb_tensor = li; emb_dim = t.c;
+        } else if (op == "Flatten" || op == "Reshape" || op == "Squeeze" || op == "Identity" || op == "Dropout") {
+            T t;
+            if (!find(n.in[0], t)) return fail(op + ": input not on the path");
+            if ((uint64_t)t.h * t.w != 1) return fail(op + " of a " + std::to_string(t.h) + "x" + std::to_string(t.w) + " map (only after the global pool)");
+            tmap[n.out[0]] = t;
+        } else if (op == "Gemm" || op == "MatMul") {
+            T t;
+            const Tensor *W = n.in.size() > 1 ? f32init(n.in[1]) : nullptr;
+            if (!find(n.in[0], t) || !W || W->dims.size() != 2) return fail(op + ": needs an activation on the path and a 2-d float32 weight initializer");
+            const bool gemm = op == "Gemm", tb = gemm && n.geti("transB", 0) != 0;
+            if (gemm && (n.getf("alpha", 1.0f) != 1.0f || n.getf("beta", 1.0f) != 1.0f || n.geti("transA", 0) != 0)) return fail("Gemm with alpha / beta / transA");
+            const int64_t cin = tb ? W->dims[1] : W->dims[0], cout = tb ? W->dims[0] : W->dims[1];
+            if (cin <= 0 || cout <= 0 || cin > (1 << 20) || cout > (1 << 24)) return fail(op + ": bad weight shape");
+            if ((uint64_t)cin != (uint64_t)t.c * t.h * t.w || (uint64_t)t.h * t.w != 1) return fail(op + ": " + std::to_string(cin) + " input features, activation has " + std::to_string(t.c));
+            const Tensor *B = gemm && n.in.size() > 2 && !n.in[2].empty() ? f32init(n.in[2]) : nullptr;
+            std::string out = n.out[0];
+            if (!B) {   // MatMul followed by Add(bias)
+                size_t k;
+                if (sole_consumer(out, "Add", k) && g.nodes[k].in.size() == 2 && !g.nodes[k].out.empty()) {
+                    const std::string &other = g.nodes[k].in[0] == out ? g.nodes[k].in[1] : g.nodes[k].in[0];
+                    const Tensor *ob = f32init(other);
+                    if (ob && ob->count == (uint64_t)cout) { B = ob; out = g.nodes[k].out[0]; skip.insert(k); }
+                }
+            }
+            if (B && B->count != (uint64_t)cout) return fail(op + ": bias width");
+            tmp.resize((size_t)cin * cout);
+            for (int64_t c = 0; c < cin; c++)
+                for (int64_t o = 0; o < cout; o++) tmp[(size_t)c * cout + o] = tb ? W->at((uint64_t)(o * cin + c)) : W->at((uint64_t)(c * cout + o));
+            tmpb.assign((size_t)cout, 0.0f);
+            if (B) for (int64_t o = 0; o < cout; o++) tmpb[(size_t)o] = B->at((uint64_t)o);
+            const uint64_t wo = blob.put(tmp), bo = blob.put(tmpb);
+            const uint32_t li = new_layer(OP_DENSE, t.idx, NO_TENSOR, (uint32_t)cin, (uint32_t)cout, 1, 1, 1, 1, 0, 0, 1, 1, 1, 1, 0, wo, bo);
+            tmap[out] = T{li, (uint32_t)cout, 1, 1};
+            if (!flush_patterns(out)) return false;
+        } else if (op == "Sigmoid" && !graph_out.count(n.out[0])) {
+            // the gate of a squeeze-excite block: Sigmoid on a pooled [N, C, 1, 1] tensor, consumed by a Mul with the feature map
+            T t;
+            if (!find(n.in[0], t) || (uint64_t)t.h * t.w != 1) return fail("Sigmoid inside the graph that is neither Sigmoid * x nor a squeeze-excite gate");
+            if (!set_act(n.in[0], n.out[0], A_SIGMOID)) return false;
+        } else if (op == "Mul") {
+            T a, b;
+            if (n.in.size() != 2 || !find(n.in[0], a) || !find(n.in[1], b)) return fail("Mul of '" + n.in[0] + "': operands are not both activations on the path");
+            bool done = false;
+            for (int side = 0; side < 2 && !done; side++) {
+                const T &fm = side ? b : a, &gate = side ? a : b;
+                if ((uint64_t)fm.h * fm.w > 1 && (uint64_t)gate.h * gate.w == 1 && gate.c == fm.c) {
+                    const uint32_t li = new_layer(OP_SCALE, fm.idx, gate.idx, fm.c, fm.c, 1, 1, 1, 1, 0, 0, fm.h, fm.w, fm.h, fm.w, 0, 0, 0);
+                    tmap[n.out[0]] = T{li, fm.c, fm.h, fm.w};
+                    done = true;
+                }
+            }
+            if (!done) return fail("Mul of '" + n.in[0] + "', '" + n.in[1] + "': not a feature map times a [N, C, 1, 1] gate");
+        } else if (op == "Sigmoid" || op == "Softmax") {
+            if (!graph_out.count(n.out[0])) return fail(op + " inside the graph (only the output activation is supported, or Sigmoid * x)");
+            T t;
+            if (!find(n.in[0], t)) return fail(op + ": input not on the path");
+            out_act = op == "Sigmoid" ? O_SIGMOID : O_SOFTMAX;
+            tmap[n.out[0]] = t;
+        } else {
+            return fail("unsupported operator " + op + " ('" + n.name + "')");
+        }
+    }
+    if (!first_of_pattern.empty()) return fail("activation pattern on a tensor that was never produced: '" + first_of_pattern.begin()->first + "'");
+    if (layers.empty() || layers.back().op != OP_DENSE) return fail("the graph does not end in a dense layer");
+    T fin;
+    if (!find(g.outputs[0].name, fin) || fin.idx != layers.size()) return fail("the graph output is not the last layer's output");
+    m.h.n_layers = (uint32_t)layers.size();
+    m.h.n_classes = layers.back().cout;
+    m.h.embedding_dim = emb_dim;
+    m.h.embedding_tensor = emb_tensor;
+    m.h.output_activation = out_act;
+    // Perch v2 and BirdNET v3.0 share an input length: told apart by what the graph ends in (classifier.rs:360-377 reads the model
+    // type from the crate's detection; manifests: Perch softmax over 14 795 classes, v3.0 a sigmoid inside the graph)
+    m.h.family = fam->sample_count == 160000 ? (out_act == O_SOFTMAX ? 1u : 2u) : 0u;
+    m.blob = std::move(blob.v);
+    m.h.blob_floats = m.blob.size();
+    m.h.blob_offset = 0;
+    return validate_model(m, err);
+}
+
+inline bool read_file(const char *path, std::vector<uint8_t> &buf, std::string &err) {
+    FILE *f = fopen(path, "rb");
+    if (!f) { err = std::string("cannot open model file ") + path; return false; }
+    bool ok = false;
+    if (fseek(f, 0, SEEK_END) == 0) {
+        const long sz = ftell(f);
+        if (sz > 0 && sz < (3l << 30)) { buf.resize((size_t)sz); rewind(f); ok = fread(buf.data(), 1, buf.size(), f) == buf.size(); }
+    }
+    fclose(f);
+    if (!ok) { buf.clear(); err = std::string(path) + ": empty, unreadable or larger than 3 GiB"; }
+    return ok;
+}
+
+inline bool load_onnx_model(const char *path, Model &m, std::string &err) {
+    std::vector<uint8_t> buf;
+    if (!read_file(path, buf, err)) return false;
+    Graph g;
+    if (!parse_graph(Span{buf.data(), buf.size()}, g, err) || !model_from_graph(g, m, err)) { err = std::string(path) + ": " + err; return false; }
+    return true;
+}
+
+// the container birda_amd/modelfile.py writes (header 256 B, branch records 64 B, layer records 128 B, blob at a multiple of 256 B)
+inline bool write_bhm(const char *path, const Model &m, std::string &err) {
+    FILE *f = fopen(path, "wb");
+    if (!f) { err = std::string("cannot write ") + path; return false; }
+    HeaderRec h = m.h;
+    h.n_branches = (uint32_t)m.branches.size(); h.n_layers = (uint32_t)m.layers.size();
+    uint64_t off = 256 + 64ull * m.branches.size() + 128ull * m.layers.size();
+    off = (off + 255) / 256 * 256;
+    h.blob_offset = off; h.blob_floats = m.blob.size();
+    std::vector<unsigned char> head((size_t)off, 0);
+    memcpy(head.data(), &h, sizeof h);
+    size_t p = 256;
+    for (const auto &b : m.branches) { memcpy(head.data() + p, &b, sizeof b); p += 64; }
+    for (const auto &L : m.layers) { memcpy(head.data() + p, &L, sizeof L); p += 128; }
+    const bool ok = fwrite(head.data(), 1, head.size(), f) == head.size() && fwrite(m.blob.data(), sizeof(float), m.blob.size(), f) == m.blob.size();
+    if (fclose(f) != 0 || !ok) { err = std::string("short write to ") + path; return false; }
+    return true;
+}
+
+}  // namespace onnxc
+}  // namespace bh

@@ -45,7 +45,10 @@ typedef enum {
 /* ClassifierBuilder::new().model_path().labels_path().top_k().min_confidence()
  * (classifier.rs:269-273) + execution-provider choice (classifier.rs:662-691 -> device). */
 typedef struct {
-    const char *model_path;  /* BHM1 container (birda_amd/modelfile.py) */
+    const char *model_path;  /* the model's .onnx file, as ClassifierBuilder::model_path() takes it (classifier.rs:269-283): the conv
+                              * stack is read off the graph inside the library, the front-end comes from the family table keyed by
+                              * the graph's input length (birda_amd/csrc/onnx_conv.hpp); or a BHM1 container (bh_onnx_to_bhm,
+                              * birda_amd/modelfile.py).  Told apart by the file's first bytes. */
     const char *labels_path; /* one label per line; NULL = no labels (logits-only use) */
     uint32_t top_k;          /* DEFAULT_TOP_K = 5, constants.rs:178 */
     float min_confidence;    /* DEFAULT_MIN_CONFIDENCE = 0.1, constants.rs:25 */
@@ -155,6 +158,10 @@ BH_API size_t bh_classifier_default_batch_size(const bh_classifier *c);
 /* ClassifierBuilder::build() (classifier.rs:281-283).  Loads the model, uploads weights,
  * precomputes the folded STFT*mel operators, validates the label count. */
 BH_API int bh_classifier_create(const bh_config *cfg, bh_classifier **out);
+/* The conversion bh_classifier_create runs on an .onnx file, as a step of its own (host only, no device): ONNX graph -> BHM1
+ * container on disk.  For deployments that convert once and hand the container to every process afterwards (a 437-MB Perch
+ * file is parsed and re-laid in ~1 s; the container loads at the disk's rate). */
+BH_API int bh_onnx_to_bhm(const char *onnx_path, const char *bhm_path);
 BH_API void bh_classifier_destroy(bh_classifier *c);
 
 /* .config() / .labels() (classifier.rs:360-377) */
@@ -182,10 +189,18 @@ BH_API void *bh_batch_context_host_buffer(bh_batch_context *ctx, size_t *bytes);
  * Results do not depend on it.  Reset to 0 when the context is destroyed (parked). */
 BH_API int bh_batch_context_set_sub_slices(bh_batch_context *ctx, uint32_t n);
 BH_API size_t bh_batch_context_device_bytes(const bh_batch_context *ctx); /* all device memory */
-/* A destroyed context is PARKED in its classifier (up to two) and handed to the next create of that size (or up to twice that
- * size): the per-file pipeline creates one per file (processor.rs:582-603), and 4 GB of hipMalloc + 576 MB of pinned staging cost
- * more than a short file's inference.  bh_classifier_trim releases the parked contexts and the classifier's internal one
- * (bh_predict / bh_predict_batch); returns the device bytes freed.  Call between runs, from the predicting thread. */
+/* Host-fed slices of this context whose sub-slices could not be placed side by side in the arena and therefore ran one after the
+ * other on one stream (slower, same results): 0 in every configuration the library chooses itself; a diagnostic for forced splits. */
+BH_API uint64_t bh_batch_context_lane_fallbacks(const bh_batch_context *ctx);
+/* A destroyed context is PARKED in its classifier (up to THREE: bhh_process_files keeps three packs in flight) and handed to the next
+ * create of that size -- or of down to half that size, in which case it serves the request with its larger buffers while the entry
+ * points that take a context enforce the capacity that was ASKED for (bh_predict_batch_with_context, _source_rate; the slicing
+ * entry points -- _contig, _logits, bh_predict_pcm*, bh_forward_device -- cut any n into slices of the context's real capacity,
+ * so the request size does not bound them).  The per-file pipeline creates a context per file (processor.rs:582-603), and 4 GB of
+ * hipMalloc + 576 MB of pinned staging cost more than a short file's inference.  Worst-case resident footprint of the parking:
+ * three contexts of the largest batch ever asked for, for the v2.4-shaped model at 1 000 segments 3 x (4.1 GB device + 0.58 GB
+ * pinned host).  bh_classifier_trim releases the parked contexts and the classifier's internal one (bh_predict /
+ * bh_predict_batch); returns the device bytes freed.  Call between runs, from the predicting thread. */
 BH_API size_t bh_classifier_trim(bh_classifier *c);
 
 /* Classifier::predict(&[f32]) (classifier.rs:469-475): exactly sample_count samples. */

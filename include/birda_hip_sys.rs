@@ -114,6 +114,7 @@ extern "C" {
     pub fn bh_default_batch_size(model_type: u32, provider_actual: *const c_char) -> usize;
     pub fn bh_classifier_default_batch_size(c: *const BhClassifier) -> usize;
     pub fn bh_classifier_create(cfg: *const BhConfig, out: *mut *mut BhClassifier) -> c_int;
+    pub fn bh_onnx_to_bhm(onnx_path: *const c_char, bhm_path: *const c_char) -> c_int;
     pub fn bh_classifier_destroy(c: *mut BhClassifier);
     pub fn bh_classifier_info(c: *const BhClassifier, info: *mut BhModelInfo) -> c_int;
     pub fn bh_classifier_label(c: *const BhClassifier, index: u32) -> *const c_char;
@@ -125,6 +126,7 @@ extern "C" {
     pub fn bh_batch_context_host_buffer(ctx: *mut BhBatchContext, bytes: *mut usize) -> *mut c_void;
     pub fn bh_batch_context_set_sub_slices(ctx: *mut BhBatchContext, n: u32) -> c_int;
     pub fn bh_batch_context_device_bytes(ctx: *const BhBatchContext) -> usize;
+    pub fn bh_batch_context_lane_fallbacks(ctx: *const BhBatchContext) -> u64;
     pub fn bh_classifier_trim(c: *mut BhClassifier) -> usize;
     pub fn bh_predict(c: *mut BhClassifier, segment: *const f32, n_samples: usize, out: *mut BhResult) -> c_int;
     pub fn bh_predict_batch(c: *mut BhClassifier, segments: *const *const f32, n: usize, n_samples: usize, out: *mut BhResult) -> c_int;

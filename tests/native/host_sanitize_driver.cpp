@@ -12,6 +12,7 @@
 #include "../../include/birda_host.h"
 #include "../../birda_amd/csrc/model.hpp"
 #include "../../birda_amd/csrc/onnx_dense.hpp"
+#include "../../birda_amd/csrc/onnx_conv.hpp"
 #include "../../birda_amd/csrc/host_internal.hpp"
 
 // ---- stubs for the device library (never called by this driver) ----
@@ -210,6 +211,62 @@ int main(int argc, char **argv) {
                 }
             }
             printf("onnx fuzz %s: %d prefixes / mutants still load\n", argv[which], loaded);
+        }
+    }
+    // 1e. the classifier's own .onnx file goes through onnx_conv.hpp (protobuf walk, conv-stack walk, BN folding, the family
+    //     table): prefixes and random mutants of well-formed conv-stack graphs (BIRDA_FUZZ_CONV_ONNX = paths separated by ':') must
+    //     be refused or come out as a model that passes the container's own validation
+    if (const char *lst = getenv("BIRDA_FUZZ_CONV_ONNX")) {
+        uint64_t rs = 0x9e3779b97f4a7c15ull;
+        auto rnd = [&]() { rs ^= rs << 13; rs ^= rs >> 7; rs ^= rs << 17; return rs; };
+        std::string all(lst);
+        size_t a = 0;
+        while (a <= all.size()) {
+            const size_t b = all.find(':', a) == std::string::npos ? all.size() : all.find(':', a);
+            const std::string path = all.substr(a, b - a);
+            a = b + 1;
+            if (path.empty()) continue;
+            std::string good;
+            FILE *f = fopen(path.c_str(), "rb");
+            CHECK(f != nullptr);
+            if (!f) continue;
+            char buf[65536]; size_t n;
+            while ((n = fread(buf, 1, sizeof buf, f)) > 0) good.append(buf, n);
+            fclose(f);
+            {
+                bh::Model m; std::string err;
+                CHECK(bh::onnxc::load_onnx_model(path.c_str(), m, err));
+                CHECK(m.layers.size() >= 3 && m.h.n_classes == m.layers.back().cout && m.macs_per_segment() > 0);
+            }
+            const std::string p = dir + "/fuzz_conv.onnx";
+            int loaded = 0;
+            const size_t stride = std::max<size_t>(1, good.size() / 1500);
+            for (size_t cut = 0; cut < good.size(); cut += stride) {
+                write_file(p, good.substr(0, cut));
+                bh::Model m; std::string err;
+                if (bh::onnxc::load_onnx_model(p.c_str(), m, err)) loaded++;
+            }
+            // (most of such a file is weight payload: half of the mutants aim at the structural bytes between the tensors -- the
+            //  first kilobytes and the tail, where the nodes and value infos of this writer's files sit)
+            for (int it = 0; it < 2500; it++) {
+                std::string w = good;
+                const int nmut = 1 + (int)(rnd() % 4);
+                for (int k = 0; k < nmut; k++) {
+                    const size_t span = (it & 1) ? w.size() : std::min<size_t>(w.size(), 6000);
+                    const size_t at = (it & 2) ? w.size() - 1 - rnd() % span : rnd() % span;
+                    w[at] = (char)rnd();
+                }
+                if (rnd() % 10 == 0) w.resize(rnd() % w.size());
+                write_file(p, w);
+                bh::Model m; std::string err;
+                if (bh::onnxc::load_onnx_model(p.c_str(), m, err)) {
+                    loaded++;
+                    std::string e2;
+                    CHECK(bh::validate_model(m, e2));
+                    (void)m.macs_per_segment();
+                }
+            }
+            printf("conv onnx fuzz %s: %d prefixes / mutants still load\n", path.c_str(), loaded);
         }
     }
     // 2. every writer, odd labels and paths, NaN / inf confidences

@@ -427,3 +427,22 @@ def test_directory_mode_assignment_by_duration():
                 assert max(loads) - min(loads) <= 2 * max(d)
     assert sharding.assign_by_duration([0.0, 0.0, 0.0, 0.0], 2) == [[0, 1], [2, 3]]
     assert sharding.assign_by_duration([100.0, 1.0, 1.0, 100.0], 2) == [[0, 1], [2, 3]]
+
+
+def test_environment_names_in_the_shipped_library_are_the_documented_ones():
+    """debug / A-B getenv knobs are compiled out of the product build (BH_XENV, kernels.hpp: they exist behind
+    `make EXPERIMENTS=1`).  What `strings` finds in the shipped .so must be the documented list."""
+    import re
+    import subprocess
+    so = os.path.join(ROOT, "birda_amd", "libbirda_hip.so")
+    names = set(re.findall(r"^BIRDA_[A-Z0-9_]+$", subprocess.run(["strings", "-n", "8", so], capture_output=True, text=True, check=True).stdout, flags=re.M))
+    allowed = {"BIRDA_HIP_PRECISION",           # overrides bh_config.flags (birda_hip.h)
+               "BIRDA_HIP_COPY_THREADS", "BIRDA_HOST_PIPELINE_DEPTH",   # host-side tuning (INTEGRATION.md)
+               "BIRDA_INFERENCE_TIMEOUT",       # the reference's own variable (processor.rs:194-211)
+               "BIRDA_HIP_ROCTX", "BIRDA_HOST_TIMING",                 # tracing / phase times (SURVEY section 5)
+               # switches the parity tests drive the product library with: debug contexts, forced tile configurations, layer-by-layer
+               # execution, either front-end kernel
+               "BIRDA_HIP_KEEP_TENSORS", "BIRDA_HIP_KEEP_FUSED", "BIRDA_HIP_MB_CFG", "BIRDA_HIP_MB_PREFER", "BIRDA_HIP_FUSE",
+               "BIRDA_HIP_MEL32", "BIRDA_HIP_MEL_F32", "BIRDA_HIP_HEAD_GAP"}
+    assert names <= allowed, sorted(names - allowed)
+    assert "BIRDA_HIP_PRECISION" in names

@@ -120,14 +120,10 @@ def test_wire_format_scalars_and_attributes():
     assert h.initializers["w"].shape == () and float(h.initializers["w"]) == 2.5
 
 
-def test_hand_written_graph_matches_an_independent_torch_evaluation(tmp_path):
-    """A graph spelled the way a TF -> ONNX exporter spells it, written node by node HERE (not by graph_from_model) and
-    evaluated with torch.nn.functional on the oracle's own spectrogram: the converted model's oracle logits must agree.
-    Covers what the round trips cannot: un-folded BatchNormalization, asymmetric SAME padding of a stride-2 conv,
-    Clip(0, 6), Sigmoid * x, residual Add, ReduceMean over H, W, MatMul + Add, Gemm(transB = 1), a Softmax output."""
+def hand_written_graph():
+    """The exporter-style graph of test_hand_written_graph_matches_an_independent_torch_evaluation (also read by the library's own
+    C++ graph walk in tests/test_onnx_native.py): returns (graph, torch parameters, stem pads, the model whose front-end it uses)."""
     import torch
-    import torch.nn.functional as F
-    from oracle import oracle as O
     rng = np.random.default_rng(123)
     base = synth.build_model("mini")                       # only its front-end is used
     C0, H, W = len(base.branches), base.spec_h, base.spec_w
@@ -179,6 +175,19 @@ def test_hand_written_graph_matches_an_independent_torch_evaluation(tmp_path):
     g.nodes.append(ox.Node("Softmax", ["logits"], ["prob"], {"axis": -1}))
     g.outputs.append(ox.ValueInfo("prob", ox.FLOAT, ["N", 7]))
 
+    return g, P, pads, base
+
+
+def test_hand_written_graph_matches_an_independent_torch_evaluation(tmp_path):
+    """A graph spelled the way a TF -> ONNX exporter spells it, written node by node HERE (not by graph_from_model) and
+    evaluated with torch.nn.functional on the oracle's own spectrogram: the converted model's oracle logits must agree.
+    Covers what the round trips cannot: un-folded BatchNormalization, asymmetric SAME padding of a stride-2 conv,
+    Clip(0, 6), Sigmoid * x, residual Add, ReduceMean over H, W, MatMul + Add, Gemm(transB = 1), a Softmax output."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import oracle as O
+    g, P, pads, base = hand_written_graph()
+    C0, H, W = len(base.branches), base.spec_h, base.spec_w
     m = convert.model_from_graph(ox.load(ox.dump(g)), base)
     assert m.n_classes == 7 and m.output_activation == mf.OUT_SOFTMAX and m.embedding_dim == 16
     assert [L.op for L in m.layers] == [mf.OP_CONV, mf.OP_DWCONV, mf.OP_PWCONV, mf.OP_PWCONV, mf.OP_GAP, mf.OP_DENSE, mf.OP_DENSE]

@@ -34,8 +34,19 @@ def test_host_pipeline_under_asan_and_ubsan(tmp_path):
                ox.Node("Gemm", ["h2", "w1", "b1"], ["h3"], {"transB": 1, "alpha": 0.5, "beta": 2.0}), ox.Node("Sigmoid", ["h3"], ["y"])]
     stack_path = str(work / "stack.onnx")
     open(stack_path, "wb").write(ox.dump(g))
+    # ... and two conv-stack graphs for the classifier's own .onnx reader (onnx_conv.hpp): the exporter-style hand-written one
+    # (BatchNormalization, SAME padding, Clip, Sigmoid x Mul, residual, ReduceMean, MatMul + Add, Gemm, Softmax) and a
+    # squeeze-excite stack behind an audio-input front-end
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_convert import hand_written_graph
+    from birda_amd import convert
+    conv_paths = [str(work / "hand.onnx"), str(work / "se_audio.onnx")]
+    open(conv_paths[0], "wb").write(ox.dump(hand_written_graph()[0]))
+    open(conv_paths[1], "wb").write(ox.dump(convert.graph_from_model(synth.build_model("mini_se"), frontend_spelling="fused")))
+    env["BIRDA_FUZZ_CONV_ONNX"] = ":".join(conv_paths)
     fixture = os.path.join(ROOT, "tests", "golden", "reference_fixtures", "fixture-geomodel.onnx")
     p = subprocess.run([exe, str(work), model_path, custom_path, fixture, stack_path], capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-6000:]
     assert "host sanitizer driver: ok" in p.stdout
-    assert p.stdout.count("onnx fuzz") == 2
+    assert p.stdout.count("\nonnx fuzz") + p.stdout.startswith("onnx fuzz") == 2 and p.stdout.count("conv onnx fuzz") == 2

@@ -1,0 +1,164 @@
+"""bh_classifier_create opens the `.onnx` itself (reference ClassifierBuilder::model_path,
+src/inference/classifier.rs:269-283; label-count check src/inference/mod.rs:34-37).
+
+The library's own graph walk (birda_amd/csrc/onnx_conv.hpp: protobuf wire format, conv-stack walk, front-end from the family
+table) is held to the Python converter (birda_amd/convert.py, the second witness) on the container they produce: the same
+header, the same branch table and mel weights, the same layer table, the same weights -- bit for bit.  CPU tests go through
+bh_onnx_to_bhm (host only); the GPU test compares logits of a classifier created on the `.onnx` with one created on the BHM1
+file the Python converter wrote.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from birda_amd import _lib, convert, modelfile as mf, onnx_io as ox, synth
+
+
+def _native(onnx_path, out_path):
+    L = _lib.load()
+    rc = L.bh_onnx_to_bhm(onnx_path.encode(), out_path.encode())
+    if rc != 0:
+        raise RuntimeError(f"rc {rc}: {L.bh_last_error().decode()}")
+    return mf.read_model(out_path)
+
+
+def _weights(m, L):
+    nw = {mf.OP_CONV: L.kh * L.kw * L.cin * L.cout, mf.OP_DWCONV: L.kh * L.kw * L.cout, mf.OP_PWCONV: L.cin * L.cout,
+          mf.OP_DENSE: L.cin * L.cout}.get(L.op, 0)
+    if not nw:
+        return np.zeros(0, np.float32), np.zeros(0, np.float32)
+    return m.blob[L.w_off:L.w_off + nw], m.blob[L.b_off:L.b_off + L.cout]
+
+
+def _same_model(a, b):
+    """a: the Python converter's model, b: the library's.  Offsets into the blob may differ; everything they point at may not."""
+    for f in ("family", "sample_rate", "sample_count", "n_classes", "embedding_dim", "output_activation", "embedding_tensor", "spec_h", "spec_w"):
+        assert getattr(a, f) == getattr(b, f), f
+    assert np.float32(a.segment_duration) == np.float32(b.segment_duration) and np.float32(a.norm_eps) == np.float32(b.norm_eps)
+    assert len(a.branches) == len(b.branches) and len(a.layers) == len(b.layers)
+    for x, y in zip(a.branches, b.branches):
+        for f in ("frame_length", "frame_step", "n_mels", "n_frames", "flags"):
+            assert getattr(x, f) == getattr(y, f), f
+        for f in ("fmin", "fmax", "mag_scale", "out_scale", "out_shift"):
+            assert np.float32(getattr(x, f)) == np.float32(getattr(y, f)), f
+        n = x.n_bins * x.n_mels
+        wa, wb = a.blob[x.mel_w_off:x.mel_w_off + n], b.blob[y.mel_w_off:y.mel_w_off + n]
+        assert wa.tobytes() == wb.tobytes(), "mel weight matrix differs"      # the C++ restatement of the HTK mel matrix, bit for bit
+    for i, (x, y) in enumerate(zip(a.layers, b.layers)):
+        for f in ("op", "act", "in_tensor", "res_tensor", "cin", "cout", "kh", "kw", "sh", "sw", "pad_t", "pad_l", "in_h", "in_w", "out_h",
+                  "out_w", "in_layout"):
+            assert getattr(x, f) == getattr(y, f), (i, f, getattr(x, f), getattr(y, f))
+        (wa, ba), (wb, bb) = _weights(a, x), _weights(b, y)
+        assert wa.tobytes() == wb.tobytes() and ba.tobytes() == bb.tobytes(), (i, "weights differ")
+
+
+@pytest.mark.parametrize("kind,gelu,frontend", [("mini", "erf", None), ("mini_b0", "gelu", None), ("mini_se", "erf", None),
+                                                ("mini", "erf", "conv1d"), ("mini", "gelu", "stft"), ("mini_se", "erf", "fused"),
+                                                ("mini_hg", "erf", "complex"), ("birdnet_v24_tiny", "erf", None),
+                                                ("birdnet_v24_tiny", "erf", "conv1d"), ("perch_v2_tiny", "erf", None),
+                                                ("birdnet_v24", "erf", None)])
+def test_native_graph_walk_matches_the_python_converter(tmp_path, kind, gelu, frontend):
+    """Graphs written by the repo's own writer, starting at the spectrogram or -- like the published files -- at the audio input
+    (four front-end spellings: the native route skips those nodes and takes the family's front-end from its table)."""
+    m = synth.build_model(kind)
+    g = convert.graph_from_model(m, spell_gelu=gelu, frontend_spelling=frontend)
+    data = ox.dump(g)
+    onnx_path = str(tmp_path / "model.onnx")
+    with open(onnx_path, "wb") as f:
+        f.write(data)
+    want = convert.model_from_graph(ox.load(data), m, "spectrogram" if frontend else None)
+    got = _native(onnx_path, str(tmp_path / "native.bhm"))
+    _same_model(want, got)
+    # ... and both are the model the graph was written from (activations, residuals, squeeze-excite gates back in place)
+    assert [(L.op, L.act, L.res_tensor) for L in got.layers] == [(L.op, L.act, L.res_tensor) for L in m.layers]
+
+
+def test_native_graph_walk_on_the_exporter_style_graph(tmp_path):
+    """The hand-written graph of tests/test_convert.py (un-folded BatchNormalization, asymmetric SAME padding, Clip(0, 6),
+    Sigmoid x Mul, residual Add, ReduceMean, MatMul + Add, Gemm(transB), Softmax): not a graph graph_from_model wrote."""
+    from test_convert import hand_written_graph
+    g, _, _, base = hand_written_graph()
+    data = ox.dump(g)
+    onnx_path = str(tmp_path / "hand.onnx")
+    with open(onnx_path, "wb") as f:
+        f.write(data)
+    want = convert.model_from_graph(ox.load(data), base)
+    got = _native(onnx_path, str(tmp_path / "hand.bhm"))
+    _same_model(want, got)
+    assert [L.act for L in got.layers[:4]] == [mf.ACT_RELU6, mf.ACT_SWISH, mf.ACT_NONE, mf.ACT_RELU] and got.layers[2].res_tensor == 1
+
+
+def test_label_count_mismatch_on_an_onnx_file_needs_no_device(tmp_path):
+    """`label count != model output width` (reference src/inference/mod.rs:34-37) is BH_ERR_LABELS for an .onnx model too, and is
+    found before a device is asked for (this container has none: a matching label file gets BH_ERR_NO_DEVICE instead)."""
+    m = synth.build_model("mini")
+    onnx_path = str(tmp_path / "mini.onnx")
+    with open(onnx_path, "wb") as f:
+        f.write(ox.dump(convert.graph_from_model(m)))
+    bad, good = str(tmp_path / "bad.txt"), str(tmp_path / "good.txt")
+    synth.write_labels(bad, m.n_classes - 1)
+    synth.write_labels(good, m.n_classes)
+    L = _lib.load()
+    h = C.c_void_p()
+    cfg = _lib.BhConfig(onnx_path.encode(), bad.encode(), 5, 0.1, 0, 0)
+    assert L.bh_classifier_create(C.byref(cfg), C.byref(h)) == -5 and b"label count" in L.bh_last_error()
+    if L.bh_device_count() == 0:
+        cfg = _lib.BhConfig(onnx_path.encode(), good.encode(), 5, 0.1, 0, 0)
+        assert L.bh_classifier_create(C.byref(cfg), C.byref(h)) == -3
+
+
+def test_refusals_name_their_reason(tmp_path):
+    L = _lib.load()
+    m = synth.build_model("mini")
+
+    def rc_of(g, name):
+        p = str(tmp_path / name)
+        with open(p, "wb") as f:
+            f.write(ox.dump(g))
+        return L.bh_onnx_to_bhm(p.encode(), str(tmp_path / (name + ".bhm")).encode()), L.bh_last_error().decode()
+
+    # an audio input no family has: the error points at the probing converter
+    g = ox.Graph(name="odd", producer="tests")
+    g.inputs.append(ox.ValueInfo("audio", ox.FLOAT, ["N", 77777]))
+    g.outputs.append(ox.ValueInfo("audio", ox.FLOAT, ["N", 77777]))
+    rc, msg = rc_of(g, "odd.onnx")
+    assert rc == -2 and "77777 samples" in msg and "onnx_to_bhm.py" in msg
+    # an operator outside the conv-stack set is refused by name
+    g = convert.graph_from_model(m)
+    g.nodes.insert(0, ox.Node("LSTM", ["spectrogram"], ["lstm_out"], name="rnn"))
+    rc, msg = rc_of(g, "lstm.onnx")
+    assert rc == -2 and "LSTM" in msg
+    # not an ONNX file at all
+    p = str(tmp_path / "junk.onnx")
+    with open(p, "wb") as f:
+        f.write(os.urandom(4096))
+    assert L.bh_onnx_to_bhm(p.encode(), str(tmp_path / "junk.bhm").encode()) == -2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,frontend", [("birdnet_v24", "conv1d"), ("perch_v2", None), ("mini_se", None), ("birdnet_v30", None)])
+def test_classifier_created_on_the_onnx_file_gives_the_bhm_route_logits(tmp_path, kind, frontend):
+    """bh_classifier_create("x.onnx") against the BHM1 container the Python converter writes from the same file: logits bit for
+    bit, in the split-f16 default and on the f32 kernels.  birdnet_v24 with the audio-input spelling (what the published file
+    is), perch_v2 at its published size (437 MB), a squeeze-excite stack, and the v3.0 contract (sigmoid inside the graph)."""
+    from birda_amd.classifier import BirdClassifier
+    m = synth.build_model(kind)
+    data = ox.dump(convert.graph_from_model(m, frontend_spelling=frontend))
+    onnx_path, bhm_path = str(tmp_path / "model.onnx"), str(tmp_path / "python.bhm")
+    with open(onnx_path, "wb") as f:
+        f.write(data)
+    mf.write_model(bhm_path, convert.model_from_graph(ox.load(data), m, "spectrogram" if frontend else None))
+    del data
+    segs = synth.synth_segments(3, m.sample_count, m.sample_rate, start=77)
+    for prec in ("auto", "f32"):
+        out = {}
+        for route, path in (("onnx", onnx_path), ("bhm", bhm_path)):
+            clf = BirdClassifier(path, None, precision=prec)
+            assert clf.info.n_classes == m.n_classes and clf.info.sample_count == m.sample_count and clf.info.model_type == m.family
+            ctx = clf.create_batch_context(4)
+            out[route] = (clf.predict_logits(ctx, segs), clf.fused_blocks())
+            ctx.close(); clf.close()
+        assert out["onnx"][1] == out["bhm"][1]
+        assert np.isfinite(out["onnx"][0]).all() and (out["onnx"][0] == out["bhm"][0]).all(), (kind, prec)
