@@ -38,7 +38,9 @@ SEGMENTS_PER_GPU = 1000
 PEAK_F32_MFMA_TFLOPS = 157.3             # MI355X_MICROARCH.md: v_mfma_f32_* dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0            # MI355X_MICROARCH.md: dense bf16/f16 MFMA peak
 PEAK_HBM_GBPS = 8000.0
-DTYPE = {"f32": "f32", "f16x3": "f16x3 (f32 operands split into f16 hi + lo, f32 accumulate)", "f16": "f16 (f32 accumulate)"}
+DTYPE = {"f32": "f32", "f16x3": "f16x3 (f32 operands split into f16 hi + lo, f32 accumulate)", "f16": "f16 (f32 accumulate)",
+         # the library's default (bh_config.flags = 0, BH_FLAG_AUTO): f16x3 compute; a row beyond the f16 range is re-run in f32
+         "auto": "f16x3 (f32 operands split into f16 hi + lo, f32 accumulate; BH_FLAG_AUTO: rows beyond the f16 range re-run on the f32 kernels)"}
 
 
 def mel_bytes_per_segment(m):
@@ -465,12 +467,12 @@ def main():
                     help="BASELINE.json configs: c2 = configs[1] (the bench line), c3 = 10 000 segments as 8 shards through bh_multi_*, "
                          "c4 = Perch-sized model, c5 = mixed-rate input -> resampler -> f16 MFMA")
     ap.add_argument("--precision", default=os.environ.get("BIRDA_HIP_BENCH_PRECISION", ""),
-                    choices=["", "f32", "f16x3", "f16"],
+                    choices=["", "auto", "f32", "f16x3", "f16"],
                     help="GEMM operands: f16x3 = f32 values split into f16 hi + lo, three f16 MFMAs per product, "
                          "f32 accumulate (same fp32 logit tolerance as f32); f32 = v_mfma_f32_16x16x4_f32 everywhere")
     args = ap.parse_args()
     if not args.precision:
-        args.precision = "f16" if args.config == "c5" else "f16x3"
+        args.precision = "f16" if args.config == "c5" else "auto"    # auto = the library's default (bh_config.flags = 0)
 
     import numpy as np
     import torch
@@ -669,7 +671,7 @@ def main():
                             "f16x3": "f32 operands split into f16 hi + lo, 3 x v_mfma_f32_16x16x32_f16 per product, f32 "
                                      "accumulate (|err| ~1e-7 of sum|a b|, same fp32 logit tolerance as the f32 MFMA path, "
                                      "tests/test_parity_gpu.py)",
-                            "f16": "operands rounded to f16, v_mfma_f32_16x16x32_f16, f32 accumulate"}[args.precision]},
+                            "f16": "operands rounded to f16, v_mfma_f32_16x16x32_f16, f32 accumulate"}["f16x3" if args.precision == "auto" else args.precision]},
         "repeats": {"values": [round(v, 1) for v in all_values], "median_of_5": round(statistics.median(all_values), 1),
                     "note": "five regions of exactly --steps steps each; `value` is the first"},
     }

@@ -88,8 +88,19 @@ int ctx_create(bh_classifier *c, size_t max_batch, bool keep, bh_batch_context *
     ctx->keep_tensors = keep;
     if (const char *kf = getenv("BIRDA_HIP_KEEP_FUSED")) ctx->keep_fused = kf[0] == '1';
     const auto &m = c->model;
-    HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    {   // a stream set of the classifier (api_internal.hpp: created at classifier create, a fixed stream -> hardware-queue pattern)
+        std::lock_guard<std::mutex> g(c->stream_mu);
+        for (int k = 0; k < bh_classifier::N_STREAM_SETS && ctx->stream_set < 0; k++)
+            if (!c->stream_sets[k].used && c->stream_sets[k].s[0]) { c->stream_sets[k].used = true; ctx->stream_set = k; }
+    }
+    if (ctx->stream_set >= 0) {
+        const auto &ss = c->stream_sets[ctx->stream_set];
+        ctx->stream = ss.s[0]; ctx->copy_stream = ss.s[1]; ctx->lane_stream[1] = ss.s[2]; ctx->lane_stream[2] = ss.s[3];
+        for (int l = 1; l <= 2; l++) HIPCHK(hipEventCreateWithFlags(&ctx->join_ev[l], hipEventDisableTiming));
+    } else {
+        HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    }
     const size_t in_bytes = max_batch * (size_t)m.h.sample_count * sizeof(float);
     HIPCHK(hipMalloc((void **)&ctx->d_input, in_bytes));
     HIPCHK(hipMalloc((void **)&ctx->d_minmax, max_batch * 16 * sizeof(float)));
@@ -126,9 +137,10 @@ void ctx_destroy(bh_batch_context *ctx) {
     for (auto e : ctx->ev) (void)hipEventDestroy(e);
     for (auto e : ctx->copy_ev) (void)hipEventDestroy(e);
     for (auto e : ctx->done_ev) (void)hipEventDestroy(e);
-    if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
+    const bool own_streams = ctx->stream_set < 0;   // (a set of the classifier's goes back to it, below)
+    if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); if (own_streams) (void)hipStreamDestroy(ctx->copy_stream); }
     for (int l = 1; l < bh_batch_context::MAX_LANES; l++) {
-        if (ctx->lane_stream[l]) { (void)hipStreamSynchronize(ctx->lane_stream[l]); (void)hipStreamDestroy(ctx->lane_stream[l]); }
+        if (ctx->lane_stream[l]) { (void)hipStreamSynchronize(ctx->lane_stream[l]); if (own_streams || l > 2) (void)hipStreamDestroy(ctx->lane_stream[l]); }
         if (ctx->join_ev[l]) (void)hipEventDestroy(ctx->join_ev[l]);
     }
     if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
@@ -138,7 +150,8 @@ void ctx_destroy(bh_batch_context *ctx) {
     (void)hipFree(ctx->d_raw); (void)hipHostFree(ctx->h_raw);
     (void)hipFree(ctx->d_pcm); (void)hipFree(ctx->d_starts);
     (void)hipFree(ctx->d_nonfinite); (void)hipHostFree(ctx->h_nonfinite);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->stream && own_streams) (void)hipStreamDestroy(ctx->stream);
+    if (!own_streams) { std::lock_guard<std::mutex> g(ctx->c->stream_mu); ctx->c->stream_sets[ctx->stream_set].used = false; }
     delete ctx;
 }
 
@@ -703,7 +716,10 @@ size_t bh_default_batch_size(uint32_t model_type, const char *provider_actual) {
     if (!strcmp(p, "CPU")) return 8;                                                                  // batch_size::CPU
     if (!strcmp(p, "CUDA")) return (model_type == BH_MODEL_BIRDNET_V24 || model_type == BH_MODEL_BSG_FINLAND) ? 64 : 32;
     if (!strcmp(p, "TensorRT")) return 32;
-    if (!strcmp(p, "HIP")) return 256;
+    // the largest batch birda's own validator admits (MAX_BATCH_SIZE = 512, constants.rs:55, cli/validators.rs:140): one forward is a
+    // chain of 21 dependent launches and the late blocks need >= 512 segments to fill the chip twice over -- measured
+    // device-resident, 130 k segments/s at 256 against 144 k at 512; a 512-segment context is 2.1 GB of the 288
+    if (!strcmp(p, "HIP")) return 512;
     return 16;                                                                                        // batch_size::OTHER_GPU
 }
 
@@ -733,6 +749,8 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) try {
     c->top_k = cfg->top_k;
     c->min_conf = cfg->min_confidence;
     HIPCHK(hipSetDevice(c->device));
+    for (auto &ss : c->stream_sets)          // the batch contexts' streams, all of them now (api_internal.hpp)
+        for (auto &st : ss.s) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     if (m.h.n_branches > bh::MAX_BRANCHES) return fail(BH_ERR_UNSUPPORTED, "too many front-end branches");
     // front-end operators
     // GEMM operand precision (decided here: the front-end operator layout depends on it)
@@ -908,6 +926,8 @@ void bh_classifier_destroy(bh_classifier *c) {
     if (c->internal_ctx) ctx_destroy(c->internal_ctx);
     for (bh_batch_context *p : c->parked_ctx)
         if (p) ctx_destroy(p);
+    for (auto &ss : c->stream_sets)
+        for (auto &st : ss.s) if (st) { (void)hipStreamDestroy(st); st = nullptr; }
     for (float *d : c->d_owned) (void)hipFree(d);
     (void)hipFree(c->d_blob);
     (void)hipFree(c->d_stamps);
@@ -1352,7 +1372,7 @@ int bh_classifier_frontend_kernel(const bh_classifier *c, char *out, size_t cap)
     char buf[64];
     const int nmp = c->fe.br[0].nm_pad;
     if (c->fe.prec == 32) snprintf(buf, sizeof buf, "bh::mel32_kernel<%d>", nmp / 32);
-    else snprintf(buf, sizeof buf, "bh::mel_kernel<%d, %d>", nmp / 16, c->fe.prec);
+    else snprintf(buf, sizeof buf, "bh::mel_kernel<%d, %d, 1>", nmp / 16, c->fe.prec);   // (third argument: HALVES, kernels_frontend.hip)
     const int n = (int)strlen(buf);
     if (out && cap > (size_t)n) memcpy(out, buf, (size_t)n + 1);
     return n;

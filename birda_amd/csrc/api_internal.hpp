@@ -95,6 +95,18 @@ struct bh_classifier {
     // Up to three destroyed batch contexts are parked here and handed to the next bh_batch_context_create of the same size: the
     // per-file pipeline creates and destroys a context per file (reference processor.rs:582-603), bhh_process_files keeps three in
     // flight, and a context is ~1 GB of hipMalloc plus pinned staging memory -- milliseconds per file at GPU throughput.
+    // The streams of this classifier's batch contexts, created HERE, back to back, when the classifier is created: N_STREAM_SETS
+    // sets of {compute, upload, lane 1, lane 2}.  The HIP runtime deals a process's streams onto a few hardware queues (four by
+    // default) in creation order, and streams that share a queue run one behind the other; created lazily per context (round 3),
+    // whether context B's upload stream shared a queue with context A's compute stream depended on every stream the process had
+    // ever created -- the files leg ran 90-99 k segments/s at the end of the bench process and 106-112 k in a process of its own.
+    // With whole sets of four created in one go, stream j of every set lands on queue (j + const) mod 4: uploads only ever share a
+    // queue with other uploads, whatever the process did before.  A context takes a free set at create and hands it back at
+    // destroy (parked contexts keep theirs); with all sets taken it creates streams of its own, as before.
+    static constexpr int N_STREAM_SETS = 4;
+    struct StreamSet { hipStream_t s[4] = {nullptr, nullptr, nullptr, nullptr}; bool used = false; };
+    StreamSet stream_sets[N_STREAM_SETS];
+    std::mutex stream_mu;
     static constexpr int N_PARKED = 3;
     bh_batch_context *parked_ctx[N_PARKED] = {nullptr, nullptr, nullptr};
     std::mutex parked_mu;
@@ -107,6 +119,7 @@ struct bh_batch_context {
                                  // capacity the entry points enforce
     bool keep_tensors = false;
     bool keep_fused = false;   // BIRDA_HIP_KEEP_FUSED=1: a debug context still runs the fused blocks (their outputs are readable)
+    int stream_set = -1;                     // index into the classifier's stream_sets, or -1: the streams are this context's own
     hipStream_t stream = nullptr;
     hipStream_t copy_stream = nullptr;       // H2D of host batches, ahead of the compute stream
     std::vector<hipEvent_t> copy_ev;         // one per sub-slice in flight

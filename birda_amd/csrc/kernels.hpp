@@ -189,9 +189,13 @@ __device__ __forceinline__ void gelu_erf_fast4_scaled(bh_f32x2 &v0, bh_f32x2 &v1
     v0 = __builtin_elementwise_fma(-a0, e0, m0);
     v1 = __builtin_elementwise_fma(-a1, e1, m1);
 }
-// -DBH_GELU_2X=0 restores round 3's GELU (max(v, 0) form, no factor two to fold) in the fused blocks: the A/B twin of the library
+// -DBH_GELU_2X=1 builds the fused blocks with the "twice the GELU" form below instead of round 3's gelu_erf_fast4 (max(v, 0) form,
+// no factor two to fold).  Built, parity-green and MEASURED in round 4 -- and off: in isolation the packed 2x form is 12 % cheaper
+// per pair (22.5 against 25.6 ns, profiles/r4_d_valu_throughput.txt), inside the kernels it is 0.7 % SLOWER on every one of five
+// alternations on one box (fused blocks 5.861 -> 5.902 us per segment, profiles/r4_e_gelu2x_packed_ab.txt: tools/ab.sh lib with
+// the two builds of one tree); a scalar spelling with |v| as a free source modifier measured 31.2 ns per pair.
 #ifndef BH_GELU_2X
-#define BH_GELU_2X 1
+#define BH_GELU_2X 0
 #endif
 #if BH_GELU_DEGREE == 5
 // TWICE the GELU, for the fused blocks of the f16 modes (round 4): 2 GELU(v) = (v + |v|) - |v| 2 Phi(-|v|), with

@@ -155,8 +155,13 @@ constexpr int MEL_TN = 16 * MEL_FT;
 // 64-KB span of the 128-mel one, whose workgroups have the whole register file
 
 // (128-mel front-ends need 98 KB of LDS for the reduction: one workgroup per CU, so they get the whole register file)
-template <int MT, int PREC>
-__global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void mel_kernel(const float *__restrict__ x, const float *__restrict__ mm,
+// HALVES = 2 (round 4): ONE workgroup of 8 waves per CU works a 96-frame item -- waves 0-3 the first 48 frames,
+// waves 4-7 the last 48, each four splitting K as before.  Wave w and wave w + 4 sit on the same SIMD and read the SAME operator
+// fragments within a few hundred cycles of each other, so the second read is served by the CU's L1 instead of the L2 -> CU
+// fabric (the stream that bounds this kernel: 6.5 MB per segment with 48-frame items); the staged span is shared by both
+// halves (96 frames: 115 KB), and the cross-wave reduction buffer (2 x 74 KB) aliases it.
+template <int MT, int PREC, int HALVES = 1>
+__global__ __launch_bounds__(256 * HALVES, (MT <= 6 || HALVES == 2) ? 2 : 1) void mel_kernel(const float *__restrict__ x, const float *__restrict__ mm,
                                                       float *__restrict__ spec, const FrontendParams *__restrict__ pp,
                                                       const float *__restrict__ gf0, const float *__restrict__ gf1,
                                                       const float *__restrict__ gf2, const float *__restrict__ gf3,
@@ -165,8 +170,10 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void mel_kernel(const float *
     const int n_branches = pp->n_branches;
     const int S = pp->sample_count;
     float *xs = smem;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int half = HALVES == 2 ? tid >> 8 : 0, wave = (tid >> 6) & 3;   // wave: the K quarter, as in the 4-wave kernel
     const int li = lane & 15, kq = lane >> 4;
+    constexpr int TNW = MEL_TN * HALVES, NTHR = 256 * HALVES;             // frames per item, threads
 
     // PERSISTENT workgroups: each walks the work items (segment, branch, frame tile) with stride gridDim.x, and
     // the sample span of its NEXT item is fetched into registers (MEL_SU x 16 B per thread, free at that point)
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void mel_kernel(const float *
     // it started (two per CU) exposed one HBM round trip per tile, 0.37 of this kernel's 0.95 us per segment.
     // item = (seg * n_branches + branch) * n_tiles + tile
     static_assert(MM_SPLIT == 8, "16 floats of min / max partials per segment");
-    constexpr int MEL_SU = MT <= 6 ? 15 : 16;
+    constexpr int MEL_SU = HALVES == 2 ? 14 : (MT <= 6 ? 15 : 16);   // (two halves: 28 460 floats of span over 512 threads)
     float4 q[MEL_SU], mmq[4];
     // Work items and the XCD-aware pairing.  Unpaired: item = (seg * n_branches + branch) * n_tiles + tile, workgroup b takes
     // b, b + gridDim.x, ...  Paired (n_branches > 1, grid a multiple of 8 n_branches): the branches of one (segment, tile)
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void mel_kernel(const float *
     };
     auto issue = [&](int sg, int br, int tl) __attribute__((always_inline)) {
         const int Hn = pp->br[br].H, Ln = pp->br[br].L;
-        const int sp = ((MEL_TN - 1) * Hn + Ln + 3) & ~3, g0 = tl * MEL_TN * Hn;
+        const int sp = ((TNW - 1) * Hn + Ln + 3) & ~3, g0 = tl * TNW * Hn;
         const float *xg = x + (size_t)sg * S;
         // Unconditional loads from clamped addresses: every q[u] is (re)defined on every pass, so the 64 registers are
         // live only from here to the LDS write at the top of the next pass, not across the main loop.  Pieces past the
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void mel_kernel(const float *
         // valid address and are replaced by -1 / ignored when the span is written.
         (void)sp;
 #pragma unroll
-        for (int u = 0; u < MEL_SU; u++) q[u] = *reinterpret_cast<const float4 *>(xg + min(g0 + tid * 4 + u * 1024, S - 4));
+        for (int u = 0; u < MEL_SU; u++) q[u] = *reinterpret_cast<const float4 *>(xg + min(g0 + tid * 4 + u * 4 * NTHR, S - 4));
         const float4 *mv = reinterpret_cast<const float4 *>(mm + (size_t)sg * MM_SPLIT * 2);
         mmq[0] = mv[0]; mmq[1] = mv[1]; mmq[2] = mv[2]; mmq[3] = mv[3];
     };
@@ -227,9 +234,9 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void mel_kernel(const float *
     // struct it is a generic pointer, hipcc emits flat_load, and every LDS wait then also drains the
     // prefetched operator loads
     const float *__restrict__ gfp = branch == 0 ? gf0 : branch == 1 ? gf1 : branch == 2 ? gf2 : gf3;
-    const int t0 = tile * MEL_TN;
+    const int t0 = tile * TNW;
     const int L = bp.L, H = bp.H, K = bp.K;
-    const int span = (MEL_TN - 1) * H + L;
+    const int span = (TNW - 1) * H + L;
     const int span_pad = (span + 3) & ~3;
 
     // x <- 2((x - min)/(max - min + eps) - 0.5) as a subtract and an fma per sample: (x - min) * sc - 1.
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void mel_kernel(const float *
         //  8 of the ~20 vector instructions per staged float4)
 #pragma unroll
         for (int u = 0; u < MEL_SU; u++) {
-            const int i = tid * 4 + u * 1024;
+            const int i = tid * 4 + u * 4 * NTHR;
             if (i < span_pad) {
                 float4 v = q[u];
                 v.x = fmaf(v.x - mn, sc, -1.0f); v.y = fmaf(v.y - mn, sc, -1.0f);
@@ -259,7 +266,7 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void mel_kernel(const float *
     } else {
 #pragma unroll
     for (int u = 0; u < MEL_SU; u++) {
-        const int i = tid * 4 + u * 1024;
+        const int i = tid * 4 + u * 4 * NTHR;
         if (i < span_pad) {
             float4 v = q[u];
             v.x = (g0s + i + 0 < S) ? fmaf(v.x - mn, sc, -1.0f) : -1.0f;
@@ -270,7 +277,7 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void mel_kernel(const float *
         }
     }
     }
-    for (int i = MEL_SU * 1024 + tid * 4; i < span_pad; i += 1024) {   // spans beyond the prefetch capacity (none of the built models)
+    for (int i = MEL_SU * 4 * NTHR + tid * 4; i < span_pad; i += 4 * NTHR) {   // spans beyond the prefetch capacity (none of the built models)
         float4 v;
         v.x = (g0s + i + 0 < S) ? fmaf(xseg[g0s + i + 0] - mn, sc, -1.0f) : -1.0f;
         v.y = (g0s + i + 1 < S) ? fmaf(xseg[g0s + i + 1] - mn, sc, -1.0f) : -1.0f;
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void mel_kernel(const float *
                 al[m] = gA[(((size_t)st * MT + m) * 2 + 1) * 64];
             }
         };
-        const float *xf = xs + li * H;
+        const float *xf = xs + (half * MEL_TN + li) * H;
         auto step = [&](int st, const f16x8 (&ah)[MT], const f16x8 (&al)[MT]) {
             // element jj of the lane's operand fragment is k = 32 st + 4 jj + kq (the operator planes are packed to match,
             // api.hip build_gf): the four lane groups read NEIGHBOURING samples, so the 32 lanes of an LDS access spread over
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void mel_kernel(const float *
         // `if (si + 2 < spw) load(...)` in the loop, hipcc turned the register sets into loop-carried
         // selects and waited for every load right after issuing it.
         load(sbeg, a0h, a0l);
-        if (!(dbg & 1)) {
+        if (!(dbg & 1) && (HALVES == 1 || t0 + half * MEL_TN < bp.n_frames)) {   // (a half wholly past the last frame has nothing to add)
             int si = 0;
             for (; si + 2 < spw; si += 2) {
                 load(sbeg + si + 1, a1h, a1l);
@@ -428,7 +435,7 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void mel_kernel(const float *
         const int slot = f - (f > wave ? 1 : 0);
 #pragma unroll
         for (int m = 0; m < MT; m++)
-            red[((wave * 3 + slot) * MT + m) * 64 + lane] = make_float4(acc[f][m][0], acc[f][m][1], acc[f][m][2], acc[f][m][3]);
+            red[(((half * 4 + wave) * 3 + slot) * MT + m) * 64 + lane] = make_float4(acc[f][m][0], acc[f][m][1], acc[f][m][2], acc[f][m][3]);
     }
     __syncthreads();
     if (wave < MEL_FT) {   // waves beyond the frame tiles own no epilogue tile
@@ -441,14 +448,14 @@ __global__ __launch_bounds__(256, MT <= 6 ? 2 : 1) void mel_kernel(const float *
         for (int s = 0; s < 4; s++) {
             if (s == wave || (dbg & 4)) continue;
             const int slot = wave - (wave > s ? 1 : 0);
-            const float4 q = red[((s * 3 + slot) * MT + m) * 64 + lane];
+            const float4 q = red[(((half * 4 + s) * 3 + slot) * MT + m) * 64 + lane];
             v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
         }
         tot[m] = v;
     }
 
     // epilogue: square, power law, folded-BN affine, mel flip, [mel][time] store
-    const int t = t0 + wave * 16 + li;
+    const int t = t0 + half * MEL_TN + wave * 16 + li;
     if (t < bp.n_frames) {
         float *out = spec + ((size_t)seg * n_branches + branch) * bp.n_mels * bp.n_frames;
 #pragma unroll
@@ -676,7 +683,7 @@ void launch_mel(const float *x, const float *minmax, float *spec, const Frontend
         max_span = span > max_span ? span : max_span;
         max_frames = p.br[b].n_frames > max_frames ? p.br[b].n_frames : max_frames;
     }
-    static const int dbg = BH_XENV("BIRDA_HIP_MEL_DBG") ? atoi(BH_XENV("BIRDA_HIP_MEL_DBG")) : 0;  // tuning ablations
+    static const int dbg = [] { const char *e = BH_XENV("BIRDA_HIP_MEL_DBG"); return e ? atoi(e) : 0; }();  // tuning ablations
     if (p.prec == 32) {
         int span32 = 0;
         for (int b = 0; b < p.n_branches; b++) span32 = std::max(span32, (MEL32_TN - 1) * p.br[b].H + p.br[b].L);
@@ -702,18 +709,37 @@ void launch_mel(const float *x, const float *minmax, float *spec, const Frontend
         return;
     }
     const int mt = nmp / 16;
-    const size_t span_bytes = (size_t)((max_span + 3) & ~3) * sizeof(float);
-    const size_t red_bytes = (size_t)4 * 3 * mt * 64 * sizeof(float4);
+    // 8-wave workgroups on 96-frame items (HALVES = 2 above) for the split-f16 96-mel front-ends: built, parity-green, measured and
+    // REJECTED (round 4): 0.714 against 0.661 us per segment on every one of four alternations on one box
+    // (profiles/r4_h_mel_halves.txt) -- the twin waves' second reads of the operator fragments do not come cheaper out of L1 than
+    // the one workgroup per CU loses by its eight waves meeting at every barrier of an item.  EXPERIMENTS build only,
+    // BIRDA_HIP_MEL_HALVES=2.
+    static const bool halves_on = BH_XENV("BIRDA_HIP_MEL_HALVES") && BH_XENV("BIRDA_HIP_MEL_HALVES")[0] == '2';
+    int max_span2 = 0;
+    for (int b = 0; b < p.n_branches; b++) max_span2 = std::max(max_span2, (2 * MEL_TN - 1) * p.br[b].H + p.br[b].L);
+    const bool two = halves_on && p.prec == 3 && mt == 6 && ((size_t)((max_span2 + 3) & ~3) * 4 <= 160 * 1024) && ((max_span2 + 3) & ~3) <= 14 * 2048;
+    const int tnw = two ? 2 * MEL_TN : MEL_TN;
+    const size_t span_bytes = (size_t)(((two ? max_span2 : max_span) + 3) & ~3) * sizeof(float);
+    const size_t red_bytes = (size_t)(two ? 8 : 4) * 3 * mt * 64 * sizeof(float4);
     const size_t smem = span_bytes > red_bytes ? span_bytes : red_bytes;
-    const int n_tiles = (max_frames + MEL_TN - 1) / MEL_TN, n_items = n_tiles * p.n_branches * n_seg;
+    const int n_tiles = (max_frames + tnw - 1) / tnw, n_items = n_tiles * p.n_branches * n_seg;
     const int n_cu = device_cu_count();
-    int n_wg = std::min(n_items, (mt <= 6 ? 2 : 1) * n_cu);   // persistent: as many workgroups as fit at once
+    int n_wg = std::min(n_items, ((mt <= 6 && !two) ? 2 : 1) * n_cu);   // persistent: as many workgroups as fit at once
     // branch partners on one XCD (see the kernel): needs whole groups of 8 n_branches workgroups
     static const bool pair_off = BH_XENV("BIRDA_HIP_MEL_PAIR") && BH_XENV("BIRDA_HIP_MEL_PAIR")[0] == '0';
     const int pair_group = 8 * p.n_branches;
     const int paired = (!pair_off && p.n_branches > 1 && n_wg >= pair_group) ? 1 : 0;
     if (paired) n_wg -= n_wg % pair_group;
     dim3 grid((unsigned)n_wg), block(256);
+#ifdef BIRDA_HIP_EXPERIMENTS
+    if (two) {
+        static DeviceOnce attr2;
+        attr2.run([] { (void)hipFuncSetAttribute((const void *)mel_kernel<6, 3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+        hipLaunchKernelGGL((mel_kernel<6, 3, 2>), grid, dim3(512), smem, s, x, minmax, spec, d_p, p.br[0].gf, p.br[1].gf, p.br[2].gf, p.br[3].gf,
+                           dbg, n_tiles, n_items, paired);
+        return;
+    }
+#endif
 #define BH_MEL_CASE(MTV)                                                                                   \
     case MTV: {                                                                                            \
         static DeviceOnce attr_set;                                                                        \

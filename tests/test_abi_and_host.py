@@ -321,7 +321,7 @@ def test_shipped_hot_kernels_fit_their_register_budget():
                  "5,1,32,6,2,2,2,4,3,3,4,2,2,2,0,3,0,4,3", "3,1,32,6,2,2,2,4,3,5,4,2,2,2,0,3,0,4,3"):
         vgpr, agpr, scratch, threads = k(args)
         assert threads == 512 and vgpr + agpr <= 256 and scratch <= 64, (args, k(args))   # (<= 16 spilled registers, one reload per chunk)
-    vgpr, agpr, scratch, threads = res["mel_kernel<6,3>"]
+    vgpr, agpr, scratch, threads = res["mel_kernel<6,3,1>"]
     assert scratch == 0 and vgpr + agpr <= 256
 
 

@@ -327,7 +327,7 @@ def test_default_batch_size_reference_cases_and_provider_arm(cases):
         for name, want in c["models"].items():
             assert L.bh_default_batch_size(model[name], c["provider"].encode()) == want, (c["src"], name)
     for name in model:                                   # this backend's arm; within MIN..MAX_BATCH_SIZE (constants.rs:44,55)
-        assert L.bh_default_batch_size(model[name], b"HIP") == 256 == L.bh_default_batch_size(model[name], None)
+        assert L.bh_default_batch_size(model[name], b"HIP") == 512 == L.bh_default_batch_size(model[name], None)
     st = _lib.BhProviderStatus()
     assert L.bh_select_provider(b"CPU", -1, st) == 0 and (st.requested, st.actual, st.fallback_reason) == (b"cpu", b"CPU", b"")
     assert L.bh_select_provider(b"tensorrt", -1, st) == -1          # not this backend's arm

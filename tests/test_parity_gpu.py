@@ -969,7 +969,7 @@ def test_birdnet_v30_shaped_model_matches_oracle(oracle_lib, tmp_path):
         clf = BirdClassifier(path, None, top_k=5, min_confidence=0.0, precision=prec)
         info = clf.info
         assert (info.model_type, info.output_activation, info.embedding_dim, info.n_classes) == (2, 0, 1280, 11560)
-        assert clf.default_batch_size() == 256
+        assert clf.default_batch_size() == 512
         ctx = clf.create_batch_context(4)
         got, emb = clf.predict_logits(ctx, segs, want_embeddings=True)
         assert emb.shape == (3, 1280)

@@ -72,7 +72,7 @@ def test_a_built_classifier_reports_the_same_status(model_dir):
             assert getattr(got, f) == getattr(want, f), f
         assert got.requested == b"hip"
         # determine_default_batch_size's arm for the provider the classifier runs under (lib.rs:256-288)
-        assert clf.default_batch_size() == L.bh_default_batch_size(0, got.actual) == 256
+        assert clf.default_batch_size() == L.bh_default_batch_size(0, got.actual) == 512
     finally:
         clf.close()
     assert L.bh_classifier_provider_status(None, C.byref(_lib.BhProviderStatus())) == -1

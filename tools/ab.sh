@@ -23,9 +23,11 @@ swap_in() { cp birda_amd/libbirda_hip.so /tmp/libbirda_hip_keep.so; cp "$1" bird
 swap_out() { cp /tmp/libbirda_hip_keep.so birda_amd/libbirda_hip.so; }
 [ -n "$LIBX" ] && [ "$mode" != lib ] && swap_in tools/ab/libbirda_hip_x.so
 row() {   # label -> one line: value, median of five, mel, mbconv, per-block times
-  python bench.py --no-cpu-baseline --no-extra-legs --steps ${STEPS:-10} --warmup 2 $BENCH_ARGS "${@:2}" 2>/dev/null | python -c "
+  python bench.py --no-cpu-baseline --no-extra-legs --steps ${STEPS:-10} --warmup 2 $BENCH_ARGS "${@:2}" 2>/tmp/ab_err.txt | python -c "
 import json,sys
-d=json.load(sys.stdin); f=d['fused_block_us_per_1000_segments']; s=d['stage_us_per_segment']
+t=sys.stdin.read()
+if not t.strip(): print('$1 | bench.py FAILED:', open('/tmp/ab_err.txt').read()[-300:].replace(chr(10),' '), file=sys.stderr); sys.exit(0)
+d=json.loads(t); f=d['fused_block_us_per_1000_segments']; s=d['stage_us_per_segment']
 print('$1 | %7.0f seg/s  med5 %7.0f  mel %.3f  mbconv %.3f | %s' % (d['value'], d.get('repeats',{}).get('median_of_5',0), s['mel'], s['mbconv'], ' '.join('%6.0f' % x for x in f.values())))" | tee -a /tmp/ab_rows.txt
 }
 medians() { python - <<'PY'
