@@ -360,8 +360,19 @@ int bh_multi_forward_device(bh_multi *m, const float *const *d_segments, const s
         if (hipMemcpyAsync(host_rows.data(), s0.d_all, G * max_n * row_bytes, hipMemcpyDeviceToHost, (hipStream_t)bh_batch_context_stream(s0.ctx)) != hipSuccess)
             return mfail(BH_ERR_HIP, "result download failed");
     }
+    // (BH_FLAG_AUTO: bh_batch_context_synchronize re-runs rows beyond the f16 range on the f32 kernels, in place on the device --
+    //  AFTER the rows above were copied / gathered.  A shard whose classifier's fall-back count moved is downloaded again.)
+    std::vector<uint64_t> fb_before(G);
+    for (size_t g = 0; g < G; g++) fb_before[g] = bh_classifier_fallback_segments(m->shards[g].clf);
     rc = for_each_shard(m, [&](size_t g) -> int { return bh_batch_context_synchronize(m->shards[g].ctx); });
     if (rc != BH_OK) return rc;
+    for (size_t g = 0; g < G; g++) {
+        Shard &s = m->shards[g];
+        if (!n_per_shard[g] || bh_classifier_fallback_segments(s.clf) == fb_before[g]) continue;
+        (void)hipSetDevice(s.device);
+        if (hipMemcpy(host_rows.data() + (m->use_rccl ? g * max_n : first[g]) * row_bytes, s.d_pack, n_per_shard[g] * row_bytes, hipMemcpyDeviceToHost) != hipSuccess)
+            return mfail(BH_ERR_HIP, "result download failed");
+    }
     // unpack: per shard, per micro-batch slice {idx plane, conf plane} -> bh_result rows in list order
     for (size_t g = 0; g < G; g++) {
         const char *rows = host_rows.data() + (m->use_rccl ? g * max_n : first[g]) * row_bytes;

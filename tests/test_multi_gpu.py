@@ -157,3 +157,34 @@ def test_c5_mixed_rate_list_through_logical_shards(full_model):
     assert np.array_equal(gi, wi) and np.array_equal(gc.view(np.int32), wc.view(np.int32))
     assert (wi[:, 0] >= 0).any()
     mc.close()
+
+
+def test_auto_precision_through_logical_shards(tmp_path):
+    """BH_FLAG_AUTO behind bh_multi_*: rows beyond the f16 range are re-run on the f32 kernels inside the shards' synchronise --
+    after the packed rows were already on their way to the host -- so the gathered rows must be the repaired ones: what ONE
+    auto classifier returns for the list, row for row, from the device-resident and the host entry point."""
+    import torch
+    from birda_amd import modelfile as mf, synth
+    from birda_amd.classifier import BirdClassifier
+    from birda_amd.multi import MultiClassifier
+    from test_parity_gpu import _rescale_trunk
+    m = synth.build_model("mini_b0")
+    m2, _ = _rescale_trunk(m, [2.0 ** 14])               # most rows leave the f16 range (test_parity_gpu.py)
+    path, labels = str(tmp_path / "overflow.bhm"), str(tmp_path / "labels.txt")
+    mf.write_model(path, m2)
+    synth.write_labels(labels, m.n_classes)
+    n = 24
+    segs = synth.synth_segments(n, m.sample_count, m.sample_rate, start=40)
+    clf = BirdClassifier(path, labels, top_k=5, min_confidence=0.02, precision="auto")
+    ctx = clf.create_batch_context(n)
+    want_i, want_c = _rows(clf.predict_batch_with_context(ctx, list(segs)))
+    assert clf.fallback_segments() > 0 and (want_i[:, 0] >= 0).mean() > 0.5
+    ctx.close(); clf.close()
+    mc = MultiClassifier(path, labels, devices=[0, 0, 0], top_k=5, min_confidence=0.02, precision="auto", max_batch=5)
+    x = torch.from_numpy(segs).cuda()
+    ptrs = [x.data_ptr() + lo * m.sample_count * 4 for lo in (0, 8, 16)]
+    got_i, got_c = _rows(mc.forward_device(ptrs, [8, 8, 8]))
+    assert np.array_equal(got_i, want_i) and np.allclose(got_c, want_c, atol=1e-6)
+    got_i, got_c = _rows(mc.predict_batch_contig(segs))
+    assert np.array_equal(got_i, want_i) and np.allclose(got_c, want_c, atol=1e-6)
+    mc.close()
