@@ -191,7 +191,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
     constexpr bool RESIDENT = PERSIST == 1, STRIP = PERSIST == 2;
     constexpr int KH = KS - ST;          // STRIP: grid rows a tile inherits from the tile above
     static_assert(!STRIP || (SS == 1 && COLTH == 0 && KH > 0), "strip-walking: one segment per workgroup, row tasks");
-    static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+    static_assert(NW == 2 || NW == 4 || NW == 8, "2 (experimental: half-width tiles, twice the workgroups per CU), 4 or 8 waves");
     constexpr int NT_E = CE / 16, NT_U = NT_E / NCS, CES = CE + 4, C4N = CE / 4, TW = 1 << TWL;
     constexpr int POUT_PAD = WM * MT_W * 16, NTOP = WN * NT_W;
     constexpr int XB = 1 << XBL, XBN = TW / XB, NCOL = (XB - 1) * ST + KS;
