@@ -34,8 +34,8 @@ const CfgTables &cfg_tables() { static const CfgTables T; return T; }
 // per segment (in 16x16x4 steps), or -1 when the entry cannot run this block at that height
 double mb_try_th(MbDesc &d, int ci, int th) {
     const MbCfg &c = kCfgs[ci];
-    // f16 configurations take any Cexp: the last chunk's missing channels are zero weights and biases
-    if (c.KS != d.KS || c.ST != d.ST || (c.PREC == 0 && d.Cexp % c.CE) || (!d.stem && d.Cin % 4) || d.Cexp % 4) return -1;
+    // any Cexp: the last chunk's missing channels are zero weights and biases (every activation here maps 0 to 0)
+    if (c.KS != d.KS || c.ST != d.ST || (!d.stem && d.Cin % 4) || d.Cexp % 4) return -1;
     if (c.STEM != (d.stem ? d.stem_c : 0)) return -1;
     if (d.stem && d.stem_k != 3) return -1;
     if (c.PREC != d.prec) return -1;

@@ -989,7 +989,8 @@ def test_perch_sized_model_matches_oracle(oracle_lib, tmp_path):
     5 s / 32 kHz front-end, 1 536-d embedding, 6 144-wide hidden layer, 14 795 classes -- 437 MB, 2.67 GFLOP per segment
     (manifests/Perch-v2-Models.models.json size_bytes 413 350 933; README 42 vs 183 segments/s).  All 25 expand -> depthwise ->
     project blocks and the one depthwise -> project block without an expand convolution fuse in the f16 modes (tile entries
-    115-133); the f32 mode fuses the six early ones and runs the rest layer by layer.  Three precisions against the oracle."""
+    115-133), and since round 4 in the f32 mode too (entries 181-190: the path BH_FLAG_AUTO re-runs a row on).  Three precisions
+    against the oracle."""
     from birda_amd import modelfile as mf, synth
     from birda_amd.classifier import BirdClassifier
     m = synth.build_model("perch_v2")
@@ -1000,7 +1001,7 @@ def test_perch_sized_model_matches_oracle(oracle_lib, tmp_path):
     segs = synth.synth_segments(3, m.sample_count, m.sample_rate, start=5)
     ref = oracle_lib.OracleModel(path).forward(segs)
     scale = max(1.0, float(np.abs(ref).max()))
-    for prec, n_fused, tol in (("f32", 6, LOGIT_RTOL), ("f16x3", 26, LOGIT_RTOL), ("f16", 26, F16_LOGIT_RTOL)):
+    for prec, n_fused, tol in (("f32", 26, LOGIT_RTOL), ("f16x3", 26, LOGIT_RTOL), ("f16", 26, F16_LOGIT_RTOL)):
         clf = BirdClassifier(path, None, top_k=5, min_confidence=0.0, precision=prec)
         info = clf.info
         assert info.embedding_dim == 1536 and info.model_type == 1
