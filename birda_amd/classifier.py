@@ -129,7 +129,7 @@ PRECISION_FLAGS = {"auto": 0, "f16x3": 1, "f16": 2, "f32": 3}
 
 class BirdClassifier:
     def __init__(self, model_path: str, labels_path: Optional[str] = None, top_k: int = DEFAULT_TOP_K,
-                 min_confidence: float = DEFAULT_MIN_CONFIDENCE, device: int = 0, precision: str = "f32"):
+                 min_confidence: float = DEFAULT_MIN_CONFIDENCE, device: int = 0, precision: str = "auto"):
         self._L = _lib.load()
         self._keep = (model_path.encode(), labels_path.encode() if labels_path else None)
         flags = PRECISION_FLAGS[precision]   # BH_FLAG_* (include/birda_hip.h)

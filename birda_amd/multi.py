@@ -21,7 +21,7 @@ def _mcheck(rc: int):
 
 class MultiClassifier:
     def __init__(self, model_path: str, labels_path: Optional[str] = None, devices: Optional[Sequence[int]] = None,
-                 top_k: int = 5, min_confidence: float = 0.1, precision: str = "f32", max_batch: int = 0,
+                 top_k: int = 5, min_confidence: float = 0.1, precision: str = "auto", max_batch: int = 0,
                  gather: str = "auto"):
         self._L = _lib.load()
         devs = (C.c_int32 * max(1, len(devices or [])))(*(devices or []))

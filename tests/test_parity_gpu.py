@@ -923,10 +923,10 @@ def test_perch_shaped_model_matches_oracle(oracle_lib, tmp_path, monkeypatch):
     mf.write_model(path, m)
     assert (m.sample_rate, m.sample_count, m.n_classes) == (32000, 160000, 14795)
     segs = synth.synth_segments(3, m.sample_count, m.sample_rate, start=5)
-    clf = BirdClassifier(path, None, top_k=5, min_confidence=0.0)
+    clf = BirdClassifier(path, None, top_k=5, min_confidence=0.0, precision="f32")
     assert clf.sample_rate() == 32000 and clf.sample_count() == 160000 and abs(clf.segment_duration() - 5.0) < 1e-6
     print("perch-shaped fused blocks:", clf.fused_blocks())
-    assert len(clf.fused_blocks()) >= 8       # f32: blocks whose tiles do not fit a configuration run layer by layer
+    assert len(clf.fused_blocks()) == 16      # f32: every block since round 4 (entries 191 / 192 for the 4x16 images)
     assert 21 in clf.fused_blocks()           # the 1-channel stem variant
     ctx = clf.create_batch_context(4)
     logits = clf.predict_logits(ctx, segs)
