@@ -195,8 +195,11 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
             // expand (i) -> depthwise (i+1) -> project (i+2) in one launch
             // (a launch of at most 256 segments: the one-segment-per-workgroup twin where the block has one -- the two-segment
             //  tiles would leave half of the CUs, or more, without a workgroup)
-            const bh::MbDesc &twin = c->mb_small[c->fused_at[i]];
-            bh::MbDesc d = (twin.cfg >= 0 && n <= (size_t)c->twin_max_segments) ? twin : c->mb[c->fused_at[i]];
+            // (a launch of a few dozen segments: the narrow-tile twin -- two or four workgroups per image -- while those still
+            //  number no more than two per CU: what such a launch lasts is one workgroup's walk through the chunks)
+            const bh::MbDesc &twin = c->mb_small[c->fused_at[i]], &narrow = c->mb_narrow[c->fused_at[i]];
+            bh::MbDesc d = (narrow.cfg >= 0 && n * (size_t)narrow.tiles_x <= (size_t)c->narrow_max_workgroups) ? narrow
+                         : (twin.cfg >= 0 && n <= (size_t)c->twin_max_segments) ? twin : c->mb[c->fused_at[i]];
             const size_t ip = d.noexp ? i + 1 : i + 2;   // the project layer
             const auto &LP = m.layers[ip];
             d.X = in;
@@ -910,10 +913,11 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) try {
             if (!other_reader) c->head_gap[i] = 1;
         }
     }
+    if (const char *e = BH_XENV("BIRDA_HIP_MB_NARROW_MAX")) c->narrow_max_workgroups = atoi(e);   // (A/B aid: 0 = never)
     if (const char *st = BH_XENV("BIRDA_HIP_MB_STAMPS"); st && st[0] == '1' && !c->mb.empty()) {
         HIPCHK(hipMalloc((void **)&c->d_stamps, c->mb.size() * 8 * sizeof(unsigned long long)));
         HIPCHK(hipMemset(c->d_stamps, 0, c->mb.size() * 8 * sizeof(unsigned long long)));
-        for (size_t i = 0; i < c->mb.size(); i++) { c->mb[i].stamps = c->d_stamps + i * 8; c->mb_small[i].stamps = c->mb[i].stamps; }
+        for (size_t i = 0; i < c->mb.size(); i++) { c->mb[i].stamps = c->d_stamps + i * 8; c->mb_small[i].stamps = c->mb[i].stamps; c->mb_narrow[i].stamps = c->mb[i].stamps; }
     }
     *out = c.release();
     return BH_OK;
@@ -1355,6 +1359,10 @@ int bh_plan_fused_blocks(const char *model_path, uint32_t flags, int32_t *cfgs, 
         n++;
         bh::MbDesc tw{};
         if (bh::mb_plan_twin(d, tw)) {   // the block's small-launch twin is part of what the library must ship: listed behind it
+            if (n < cap) { if (cfgs) cfgs[n] = tw.cfg; if (layers) layers[n] = (int32_t)i; }
+            n++;
+        }
+        if (bh::mb_plan_narrow(d, tw)) {   // ... and its few-segment twin
             if (n < cap) { if (cfgs) cfgs[n] = tw.cfg; if (layers) layers[n] = (int32_t)i; }
             n++;
         }

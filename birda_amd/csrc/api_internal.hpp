@@ -72,6 +72,8 @@ struct bh_classifier {
     std::vector<bh::MbDesc> mb;              // fused MBConv blocks (kernels_mbconv.hip)
     int twin_max_segments = 256;             // launches up to this size take the twins (one workgroup per CU at most either way)
     std::vector<bh::MbDesc> mb_small;        // per block: its small-launch twin (cfg < 0: none), same weights (mb_plan_twin)
+    std::vector<bh::MbDesc> mb_narrow;       // per block: its few-segment twin on narrow tiles (cfg < 0: none), same weights (mb_plan_narrow)
+    int narrow_max_workgroups = 512;         // launches whose narrow tiles number at most this take them (measured: tools/gpu_latency.py)
     int precision = 0;                       // GEMM operands of the fused blocks: 0 f32, 3 f16 hi/lo split, 1 f16
     // BH_FLAG_AUTO (the default): split-f16 compute, and a row whose logits come out inf / NaN from finite samples (an activation
     // left the f16 range) is computed again on the library's own f32 kernels -- by `fb`, a second classifier of the same model

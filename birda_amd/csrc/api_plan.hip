@@ -395,6 +395,10 @@ int plan_fusion(bh_classifier *c) {
             static const bool no_twin = BH_XENV("BIRDA_HIP_MB_TWIN") && BH_XENV("BIRDA_HIP_MB_TWIN")[0] == '0';   // (A/B aid)
             if (force_cfg < 0 && !no_twin && bh::mb_plan_twin(d, tw)) c->mb_small.push_back(tw);
             else { tw.cfg = -1; c->mb_small.push_back(tw); }
+            bh::MbDesc nw{};
+            nw.cfg = -1;
+            if (!(force_cfg < 0 && !no_twin && bh::mb_plan_narrow(d, nw))) nw.cfg = -1;
+            c->mb_narrow.push_back(nw);
         }
         i += d.noexp ? 1 : 2;
     }

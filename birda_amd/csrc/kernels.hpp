@@ -464,6 +464,7 @@ int mb_config_name(int ci, char *out, size_t cap);
 // picks the instantiation (force_cfg >= 0: that entry or fail) and fills the derived fields
 bool mb_plan(MbDesc &d, int force_cfg);
 bool mb_plan_twin(const MbDesc &d, MbDesc &twin);   // one-segment-per-workgroup twin of a two-segment configuration (small launches)
+bool mb_plan_narrow(const MbDesc &d, MbDesc &narrow);   // narrow-tile twin of a whole-image configuration (launches of a few segments)
 void launch_mbconv(const MbDesc &d, int n_seg, hipStream_t s);
 
 }  // namespace bh

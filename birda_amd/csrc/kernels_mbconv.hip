@@ -212,6 +212,29 @@ bool mb_plan_twin(const MbDesc &d, MbDesc &twin) {
     return false;
 }
 
+// The few-segment twin of a planned WHOLE-IMAGE block, if its configuration has one: the same chunk size, k steps, precision,
+// activation and project-tile count (the block's weights serve it too), one segment per workgroup, and a NARROWER tile -- two or
+// four workgroups per image, each expanding the halo columns of its own tile again.  A launch of a few dozen segments leaves most of
+// the chip without a workgroup and lasts as long as one workgroup's walk through the chunks; narrower tiles shorten that walk.
+// (A pixel's sums do not depend on the tile it is computed in: the results are bit-identical to the wide tiles'.)
+bool mb_plan_narrow(const MbDesc &d, MbDesc &narrow) {
+    if (d.cfg < 0 || d.cfg >= kNCfgs) return false;
+    const MbCfg &c = kCfgs[d.cfg];
+    if (c.PERSIST || d.tiles_x * d.tiles_y != 1) return false;
+    const int k0 = (d.cfg / kNBase) * kNBase;   // the same activation's copy of the list
+    int best_twl = 99;
+    for (int b = 0; b < kNBase; b++) {
+        const MbCfg &q = kCfgs[k0 + b];
+        if (q.S != 1 || q.COLTH != c.COLTH || q.KS != c.KS || q.ST != c.ST || q.CE != c.CE || q.KG != c.KG || q.PREC != c.PREC ||
+            q.TWL >= c.TWL || q.TWL >= best_twl || q.WM * q.WN != c.WM * c.WN || q.WN * q.NT_W != c.WN * c.NT_W || q.STEM != c.STEM || q.PERSIST) continue;
+        MbDesc t = d;
+        if (mb_try_th(t, k0 + b, q.TH) >= 0 && t.NTOP == d.NTOP && t.nchunks == d.nchunks && t.KG == d.KG && t.CE == d.CE && t.tiles_y == 1 && t.tiles_x >= 2) {
+            narrow = t; best_twl = q.TWL;
+        }
+    }
+    return best_twl != 99;
+}
+
 void launch_mbconv(const MbDesc &d, int n_seg, hipStream_t s) { kCfgs[d.cfg].launch(d, n_seg, s); }
 
 }  // namespace bh

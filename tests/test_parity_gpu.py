@@ -850,6 +850,38 @@ def test_sixty_four_distinct_segments_of_the_full_model_match_the_oracle(full_mo
         ctx.close(); clf.close()
 
 
+def test_launches_of_a_few_segments_take_the_narrow_tiles_and_give_the_same_bits(full_model):
+    """Round 4: a launch whose narrow tiles number at most 512 (a one-minute file is 20 segments) runs the late blocks on 8-column
+    tiles -- four / two workgroups per image, mbconv_cfgs.inc entries 193-202, kernels_mbconv.hip mb_plan_narrow -- and a launch of
+    at most 256 segments the one-segment twins, a larger one the two-segment tiles.  The same segments must come out BIT-identical
+    whichever of the three a call takes (a pixel's sums do not depend on the tile it is computed in), in both f16 modes and f32."""
+    import ctypes as C
+    from birda_amd import _lib, synth
+    from birda_amd.classifier import BirdClassifier
+    path, labels, m, _ = full_model
+    lib = _lib.load()
+    cfgs = (C.c_int32 * 128)(); layers = (C.c_int32 * 128)()
+    n = lib.bh_plan_fused_blocks(path.encode(), 1, cfgs, layers, 128)        # BH_FLAG_F16X3
+    n_base = 0
+    buf = C.create_string_buffer(128)
+    while lib.bh_mb_config_name(n_base, buf, 128) > 0:
+        n_base += 1
+    n_base //= 3
+    listed = {int(cfgs[i]) % n_base for i in range(n)}
+    assert {193, 195, 197, 199, 201} <= listed, sorted(listed)             # the narrow twins of the nine whole-image late blocks
+    segs = synth.synth_segments(300, m.sample_count, m.sample_rate)
+    for prec in ("f16x3", "f16", "f32"):
+        clf = BirdClassifier(path, labels, precision=prec)
+        big = clf.create_batch_context(300)
+        ref = clf.predict_logits(big, segs)                                 # two-segment tiles
+        for k in (1, 20, 64, 128, 256):                                     # narrow / narrow / narrow / narrow (3x16 only) / one-segment twins
+            ctx = clf.create_batch_context(k)
+            got = clf.predict_logits(ctx, segs[:k])
+            assert np.array_equal(got, ref[:k]), (prec, k, float(np.abs(got - ref[:k]).max()))
+            ctx.close()
+        big.close(); clf.close()
+
+
 def test_squeeze_excite_and_swish_stack_matches_oracle(model_dir, oracle_lib):
     """The EfficientNet original: swish activations and a squeeze-excite gate (pool -> 1x1 -> swish -> 1x1 -> sigmoid -> multiply)
     in every block.  Such blocks do not run fused (the fused kernel's activation is GELU and the gate sits between the depthwise
