@@ -192,7 +192,15 @@ __global__ __launch_bounds__(256) void pw_gemm16_kernel(const float *__restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * 128 + wm * 64, t0 = blockIdx.x * 8 + wn * 4;   // first row, first column tile
+    // Block -> (column block, row block), XCD-aware: workgroup ids go round-robin over the 8 XCDs, each with its own L2.  XCD k
+    // takes the column blocks k, k + 8, ... and walks ALL row blocks of one before the next, so the eight row blocks that read the
+    // same 128 columns of W run side by side on one L2 and W comes from HBM once.  (Column block fastest, as a plain 2-D grid does
+    // it, re-read the Perch-sized model's 363-MB dense plane once per row block: 2.9 GB per launch.)
+    const int n_xb = (n_tiles + 7) / 8, n_yb = (M + 127) / 128;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int yb = slot % n_yb, xb = (slot / n_yb) * 8 + xcd;
+    if (xb >= n_xb) return;
+    const int m0 = yb * 128 + wm * 64, t0 = xb * 8 + wn * 4;   // first row, first column tile
     const int steps = K / 32;
 
     f32x4 acc[4][4];
@@ -277,7 +285,8 @@ bool pw_gemm16_supports(int K, int act) { return K % 32 == 0 && (act == ACT_NONE
 void launch_pw_gemm16(const float *A, const void *Wf, const float *bias, const float *R, float *C, int M, int K, int N,
                       int act, int terms, float w_unscale, hipStream_t s) {
     const int n_tiles = (N + 15) / 16;
-    dim3 grid((n_tiles + 7) / 8, (M + 127) / 128), block(256);
+    const int n_xb = (n_tiles + 7) / 8, n_yb = (M + 127) / 128;
+    dim3 grid((unsigned)(8 * ((n_xb + 7) / 8) * n_yb)), block(256);   // (one-dimensional: the kernel deals the blocks XCD by XCD)
 #define BH_G16(T, ACTV) hipLaunchKernelGGL((pw_gemm16_kernel<T, ACTV>), grid, block, 0, s, A, (const f16x8 *)Wf, bias, R, C, M, K, N, n_tiles, w_unscale)
 #define BH_G16A(T)                                                   \
     switch (act) {                                                   \
