@@ -280,6 +280,140 @@ __global__ __launch_bounds__(256) void pw_gemm16_kernel(const float *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// The same GEMM with both operands staged through LDS (round 4).  pw_gemm16_kernel streams every wave's operand fragments
+// straight from L2: 16 KB per wave and 32-deep step for 48 MFMAs, 58 B/clk per CU with two workgroups resident -- the fabric
+// delivers about that much and no more, so the matrix pipe idled at ~20 % (the Perch-sized model's dense pair: 1.07 us per
+// segment against an MFMA floor of 0.24).  Here a workgroup's 128 x 128 tile reads each operand ONCE per step: the 128 A rows
+// are loaded by all 256 threads (two (row, 8-k group) pairs each), split into f16 hi / lo ONCE (half the splits of the streaming
+// kernel, where the two waves of a row pair each split the same rows) and written to LDS in MFMA-fragment order; the eight column
+// tiles' W fragments, which already are fragment-major 1-KiB planes, arrive by LDS-DMA, four pieces a wave.  Two stages: step
+// s + 1 is loaded while step s computes, one barrier per step.  32 KB of L2 traffic per workgroup-step instead of 64, and the
+// waves read 16 KB each from LDS (85 B/clk per workgroup, two per CU).
+// ---------------------------------------------------------------------------------------
+template <int TERMS, int ACT>
+__global__ __launch_bounds__(256, 2) void pw_gemm16s_kernel(const float *__restrict__ A, const f16x8 *__restrict__ Wf,
+                                                            const float *__restrict__ bias, const float *__restrict__ R,
+                                                            float *__restrict__ C, int M, int K, int N, int n_tiles, float w_unscale) {
+    extern __shared__ __attribute__((aligned(16))) float gsm[];   // [2 stages]{A: [8 row tiles]{hi, lo}[64 lanes][4], B: [8 column tiles]{hi, lo}[64][4]}
+    constexpr int STAGE = 2 * 8 * 2 * 256;                        // floats per stage (32 KB)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n_xb = (n_tiles + 7) / 8, n_yb = (M + 127) / 128;   // (block order: see pw_gemm16_kernel)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int yb = slot % n_yb, xb = (slot / n_yb) * 8 + xcd;
+    if (xb >= n_xb) return;
+    const int mb0 = yb * 128, tb0 = xb * 8;
+    const int steps = K / 32;
+    const unsigned lds0 = (__builtin_amdgcn_groupstaticsize() + 15u) & ~15u;
+    const int ws = __builtin_amdgcn_readfirstlane(wave);
+
+    // staging roles: pair q (0, 1) of this thread is A row (tid >> 2) + 64 q, k group tid & 3
+    const int srow = tid >> 2, skq = tid & 3;
+    const float *ag[2];
+    int adst[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int row = srow + 64 * q;
+        ag[q] = A + (size_t)min(mb0 + row, M - 1) * K + 8 * skq;                 // rows past M: clamped, never stored
+        adst[q] = (((row >> 4) * 2) * 64 + skq * 16 + (row & 15)) * 4;           // float offset of the hi fragment slot; lo: + 256
+    }
+    float4 ra[2][2];
+    auto load_a = [&](int st) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            ra[q][0] = *reinterpret_cast<const float4 *>(ag[q] + 32 * st);
+            ra[q][1] = *reinterpret_cast<const float4 *>(ag[q] + 32 * st + 4);
+        }
+    };
+    auto store_a = [&](int buf) {
+        float *as = gsm + buf * STAGE;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const float v[8] = {ra[q][0].x, ra[q][0].y, ra[q][0].z, ra[q][0].w, ra[q][1].x, ra[q][1].y, ra[q][1].z, ra[q][1].w};
+            f16x8 h, l;
+            bh_split8(v, h, l);
+            *reinterpret_cast<f16x8 *>(as + adst[q]) = h;
+            if (TERMS == 3) *reinterpret_cast<f16x8 *>(as + adst[q] + 256) = l;
+        }
+    };
+    auto dma_b = [&](int st, int buf) {   // 16 (8) pieces of 1 KiB: wave w takes column tiles w and w + 4
+#pragma unroll
+        for (int jj = 0; jj < 2; jj++) {
+            const int j = ws + 4 * jj, t = min(tb0 + j, n_tiles - 1);
+#pragma unroll
+            for (int pl = 0; pl < (TERMS == 3 ? 2 : 1); pl++) {
+                const f16x8 *src = Wf + (((size_t)st * n_tiles + t) * 2 + pl) * 64;
+                const unsigned dst = lds0 + 4u * (unsigned)(buf * STAGE + 8 * 2 * 256 + (j * 2 + pl) * 256);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                             :: "v"((unsigned)lane * 16u), "s"(src), "s"(dst) : "memory", "m0");
+            }
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    dma_b(0, 0);
+    load_a(0);
+    store_a(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int st = 0; st < steps; st++) {
+        const int cur = st & 1;
+        const bool more = st + 1 < steps;   // (uniform)
+        if (more) { dma_b(st + 1, cur ^ 1); load_a(st + 1); }
+        const float *as = gsm + cur * STAGE, *bs = as + 8 * 2 * 256;
+        f16x8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            ah[i] = *reinterpret_cast<const f16x8 *>(as + (((wm * 4 + i) * 2) * 64 + lane) * 4);
+            if (TERMS == 3) al[i] = *reinterpret_cast<const f16x8 *>(as + (((wm * 4 + i) * 2 + 1) * 64 + lane) * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            bh[j] = *reinterpret_cast<const f16x8 *>(bs + (((wn * 4 + j) * 2) * 64 + lane) * 4);
+            if (TERMS == 3) bl[j] = *reinterpret_cast<const f16x8 *>(bs + (((wn * 4 + j) * 2 + 1) * 64 + lane) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                if (TERMS == 3) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+            }
+        if (more) store_a(cur ^ 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    const int m0 = mb0 + wm * 64, t0 = tb0 + wn * 4;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int col = (t0 + j) * 16 + li;
+        if (col >= N) continue;
+        const float bv = bias[col];
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = m0 + i * 16 + kq * 4 + r;
+                if (row < M) {
+                    float v = __builtin_fmaf(acc[i][j][r], w_unscale, bv);   // the planes hold W / w_unscale
+                    v = bh_act<ACT>(v);
+                    if (R) v += R[(size_t)row * N + col];
+                    C[(size_t)row * N + col] = v;
+                }
+            }
+    }
+}
+
 bool pw_gemm16_supports(int K, int act) { return K % 32 == 0 && (act == ACT_NONE || act_is_templated(act)); }
 
 void launch_pw_gemm16(const float *A, const void *Wf, const float *bias, const float *R, float *C, int M, int K, int N,
@@ -287,7 +421,20 @@ void launch_pw_gemm16(const float *A, const void *Wf, const float *bias, const f
     const int n_tiles = (N + 15) / 16;
     const int n_xb = (n_tiles + 7) / 8, n_yb = (M + 127) / 128;
     dim3 grid((unsigned)(8 * ((n_xb + 7) / 8) * n_yb)), block(256);   // (one-dimensional: the kernel deals the blocks XCD by XCD)
-#define BH_G16(T, ACTV) hipLaunchKernelGGL((pw_gemm16_kernel<T, ACTV>), grid, block, 0, s, A, (const f16x8 *)Wf, bias, R, C, M, K, N, n_tiles, w_unscale)
+    // (the LDS-staged kernel wherever a workgroup's 128 rows exist; a handful of rows stream as before: nothing to share)
+    static const bool stream_only = [] { const char *e = BH_XENV("BIRDA_HIP_GEMM_STREAM"); return e && e[0] == '1'; }();   // A/B aid
+    const bool staged = M >= 64 && !stream_only;
+    constexpr size_t kStagedLds = 2 * (2 * 8 * 2 * 256) * sizeof(float);   // 64 KB: two workgroups per CU
+#define BH_G16(T, ACTV)                                                                                                           \
+    do {                                                                                                                          \
+        if (staged) {                                                                                                             \
+            static DeviceOnce attr;                                                                                               \
+            attr.run([] { (void)hipFuncSetAttribute((const void *)pw_gemm16s_kernel<T, ACTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStagedLds); }); \
+            hipLaunchKernelGGL((pw_gemm16s_kernel<T, ACTV>), grid, block, kStagedLds, s, A, (const f16x8 *)Wf, bias, R, C, M, K, N, n_tiles, w_unscale); \
+        } else {                                                                                                                  \
+            hipLaunchKernelGGL((pw_gemm16_kernel<T, ACTV>), grid, block, 0, s, A, (const f16x8 *)Wf, bias, R, C, M, K, N, n_tiles, w_unscale); \
+        }                                                                                                                         \
+    } while (0)
 #define BH_G16A(T)                                                   \
     switch (act) {                                                   \
     case ACT_GELU_ERF: BH_G16(T, ACT_GELU_ERF); break;               \
