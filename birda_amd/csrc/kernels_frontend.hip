@@ -148,6 +148,21 @@ void launch_segment_pcm(const void *d_pcm_origin, int sample_format, size_t n_fr
 // B = folded frames from LDS.  The four partial sums meet in LDS (reusing xs); wave w then
 // owns frame tile w for the epilogue (square, power law, affine, flip, store).
 // ---------------------------------------------------------------------------------------
+// BH_MEL_PIPE = 1: a software-pipelined main loop for the split-f16 kernel (the frame fragments of step s + 1 built under the
+// MFMAs of step s, sched_group_barrier groups of {BH_MEL_GM MFMA, BH_MEL_GD LDS reads, BH_MEL_GV VALU}).  Round 4 measured it
+// because the kernel turned out to be ISSUE-bound, not bound by the operator stream from L2 (with every step reading the same
+// operator fragments, BIRDA_HIP_MEL_DBG=16 in the EXPERIMENTS build, it is as slow: 713.9 against 712.7 us per launch): 0.704 ->
+// 0.683 us per segment (-3 %, profiles/r4_l_mel_pipe.txt).  Not the product: two full operator sets, two sets of frame fragments
+// and 72 accumulator registers leave hipcc 3-26 registers short whatever the group sizes; it spills thread-invariant offsets and
+// reloads them behind `s_waitcnt vmcnt(0)` in the reduction (or, with other group sizes, inside the MFMA tail: 1.05 us).
+#ifndef BH_MEL_PIPE
+#define BH_MEL_PIPE 0
+#endif
+#ifndef BH_MEL_GM
+#define BH_MEL_GM 6
+#define BH_MEL_GD 6
+#define BH_MEL_GV 8
+#endif
 constexpr int MEL_FT = 3;           // 16-frame tiles per block: 3 keeps the span at 60 KB -> two blocks per CU
 constexpr int MEL_TN = 16 * MEL_FT;
 
@@ -165,8 +180,14 @@ __global__ __launch_bounds__(256 * HALVES, (MT <= 6 || HALVES == 2) ? 2 : 1) voi
                                                       float *__restrict__ spec, const FrontendParams *__restrict__ pp,
                                                       const float *__restrict__ gf0, const float *__restrict__ gf1,
                                                       const float *__restrict__ gf2, const float *__restrict__ gf3,
-                                                      const int dbg, const int n_tiles, const int n_items, const int paired) {
+                                                      const int dbg_arg, const int n_tiles, const int n_items, const int paired) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    // (the ablation bits, BIRDA_HIP_MEL_DBG, exist in the EXPERIMENTS build only: a compile-time zero in the product)
+#ifdef BIRDA_HIP_EXPERIMENTS
+    const int dbg = dbg_arg;
+#else
+    constexpr int dbg = 0; (void)dbg_arg;
+#endif
     const int n_branches = pp->n_branches;
     const int S = pp->sample_count;
     float *xs = smem;
@@ -304,6 +325,7 @@ __global__ __launch_bounds__(256 * HALVES, (MT <= 6 || HALVES == 2) ? 2 : 1) voi
         const f16x8 *gA = reinterpret_cast<const f16x8 *>(gfp) + lane;
         f16x8 a0h[MT], a0l[MT], a1h[MT], a1l[MT];
         auto load = [&](int st, f16x8 (&ah)[MT], f16x8 (&al)[MT]) {
+            if (dbg & 16) st = sbeg;   // (ablation: every step reads the wave's FIRST operator fragments -- the kernel without the L2 -> CU operator stream)
 #pragma unroll
             for (int m = 0; m < MT; m++) {
                 ah[m] = gA[(((size_t)st * MT + m) * 2 + 0) * 64];
@@ -311,7 +333,7 @@ __global__ __launch_bounds__(256 * HALVES, (MT <= 6 || HALVES == 2) ? 2 : 1) voi
             }
         };
         const float *xf = xs + (half * MEL_TN + li) * H;
-        auto step = [&](int st, const f16x8 (&ah)[MT], const f16x8 (&al)[MT]) {
+        [[maybe_unused]] auto step = [&](int st, const f16x8 (&ah)[MT], const f16x8 (&al)[MT]) {
             // element jj of the lane's operand fragment is k = 32 st + 4 jj + kq (the operator planes are packed to match,
             // api.hip build_gf): the four lane groups read NEIGHBOURING samples, so the 32 lanes of an LDS access spread over
             // (16 frames x hop) + {0, 1}.  With runs of 8 k per group a hop of 278 put two lanes on every bank and 280 eight;
@@ -342,6 +364,72 @@ __global__ __launch_bounds__(256 * HALVES, (MT <= 6 || HALVES == 2) ? 2 : 1) voi
                     acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh[f], acc[f][m], 0, 0, 0);
                 }
         };
+#if BH_MEL_PIPE
+        // Software-pipelined form (round 4, -DBH_MEL_PIPE=1; measured alternative, not the product -- see the note at BH_MEL_PIPE):
+        // the folded-and-split frame fragments of step s + 1 are built WHILE the MFMAs of step s issue.
+        auto build = [&](int st, f16x8 (&bh)[MEL_FT], f16x8 (&bl)[MEL_FT]) {
+            const int j0 = st * 32 + kq;
+#pragma unroll
+            for (int f = 0; f < MEL_FT; f++) {
+                float y[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++)
+                    y[jj] = bh_add_unpacked(xf[f * 16 * H + j0 + 4 * jj + 1], xf[f * 16 * H + L - 1 - j0 - 4 * jj]);
+                bh_split8(y, bh[f], bl[f]);
+            }
+        };
+        auto mma = [&](const f16x8 (&ah)[MT], const f16x8 (&al)[MT], const f16x8 (&bh)[MEL_FT], const f16x8 (&bl)[MEL_FT]) {
+#pragma unroll
+            for (int m = 0; m < MT; m++)
+#pragma unroll
+                for (int f = 0; f < MEL_FT; f++) {
+                    acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh[f], acc[f][m], 0, 0, 0);
+                    acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl[f], acc[f][m], 0, 0, 0);
+                    acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh[f], acc[f][m], 0, 0, 0);
+                }
+        };
+        // 54 MFMAs, 72 vector instructions and 48 LDS reads per step, dealt in groups of {GM MFMA, GD DS read, GV VALU}
+        auto interleave = [&]() {
+#pragma unroll
+            for (int g = 0; g < 9 * MT / BH_MEL_GM; g++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, BH_MEL_GM, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, BH_MEL_GD, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, BH_MEL_GV, 0);
+            }
+        };
+        f16x8 b0h[MEL_FT], b0l[MEL_FT], b1h[MEL_FT], b1l[MEL_FT];
+        load(sbeg, a0h, a0l);
+        if (!(dbg & 1) && (HALVES == 1 || t0 + half * MEL_TN < bp.n_frames)) {
+            build(sbeg, b0h, b0l);
+            __builtin_amdgcn_sched_barrier(0);
+            int si = 0;
+            for (; si + 2 < spw; si += 2) {
+                load(sbeg + si + 1, a1h, a1l);
+                __builtin_amdgcn_sched_barrier(0);
+                build(sbeg + si + 1, b1h, b1l);
+                mma(a0h, a0l, b0h, b0l);
+                interleave();
+                __builtin_amdgcn_sched_barrier(0);
+                load(sbeg + si + 2, a0h, a0l);
+                __builtin_amdgcn_sched_barrier(0);
+                build(sbeg + si + 2, b0h, b0l);
+                mma(a1h, a1l, b1h, b1l);
+                interleave();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (si + 1 < spw) {
+                load(sbeg + si + 1, a1h, a1l);
+                __builtin_amdgcn_sched_barrier(0);
+                build(sbeg + si + 1, b1h, b1l);
+                mma(a0h, a0l, b0h, b0l);
+                interleave();
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a1h, a1l, b1h, b1l);
+            } else {
+                mma(a0h, a0l, b0h, b0l);
+            }
+        }
+#else
         // The last one or two steps are peeled so that no load inside the loop is conditional: with
         // `if (si + 2 < spw) load(...)` in the loop, hipcc turned the register sets into loop-carried
         // selects and waited for every load right after issuing it.
@@ -368,6 +456,7 @@ __global__ __launch_bounds__(256 * HALVES, (MT <= 6 || HALVES == 2) ? 2 : 1) voi
                 step(sbeg + si, a0h, a0l);
             }
         }
+#endif
     } else {
     // Two operator register sets, used alternately (no copies): set B is loaded while set A feeds
     // the MFMAs and vice versa.  The scheduling fences keep each load a full group (96 MFMAs)

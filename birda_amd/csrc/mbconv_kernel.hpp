@@ -191,6 +191,13 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
     constexpr bool RESIDENT = PERSIST == 1, STRIP = PERSIST == 2;
     constexpr int KH = KS - ST;          // STRIP: grid rows a tile inherits from the tile above
     static_assert(!STRIP || (SS == 1 && COLTH == 0 && KH > 0), "strip-walking: one segment per workgroup, row tasks");
+    // the ablation bits of MbDesc::dbg (tuning aids, BIRDA_HIP_MB_DBG) exist in the EXPERIMENTS build only: in the product they are a
+    // compile-time zero and every test of them folds away
+#ifdef BIRDA_HIP_EXPERIMENTS
+    const int dbgv = d.dbg;
+#else
+    constexpr int dbgv = 0;
+#endif
     static_assert(NW == 2 || NW == 4 || NW == 8, "2 (experimental: half-width tiles, twice the workgroups per CU), 4 or 8 waves");
     constexpr int NT_E = CE / 16, NT_U = NT_E / NCS, CES = CE + 4, C4N = CE / 4, TW = 1 << TWL;
     constexpr int POUT_PAD = WM * MT_W * 16, NTOP = WN * NT_W;
@@ -245,8 +252,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
     // in x, then y, then segment order): neighbours in space are neighbours in time on one L2.
     const int per_xcd = (n_tiles + 7) >> 3;
     const int tile_xcd = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
-    if (!RESIDENT && (d.dbg & 256 ? (int)blockIdx.x >= n_tiles : tile_xcd >= n_tiles)) return;   // (dbg 256: launch order, A/B aid)
-    const int tile_first = RESIDENT ? (int)blockIdx.x : (d.dbg & 256 ? (int)blockIdx.x : tile_xcd);
+    if (!RESIDENT && (dbgv & 256 ? (int)blockIdx.x >= n_tiles : tile_xcd >= n_tiles)) return;   // (dbg 256: launch order, A/B aid)
+    const int tile_first = RESIDENT ? (int)blockIdx.x : (dbgv & 256 ? (int)blockIdx.x : tile_xcd);
 #ifdef BIRDA_HIP_EXPERIMENTS
     MbClock t_last{};
     if (d.stamps) t_last.last = __builtin_readcyclecounter();
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
     const int ra = (STRIP && trow > 0) ? max(ya, KH) : ya;
     const int vh = max(yb - ra, 0), vw = max(xb - xa, 0);
     const int Mseg = vh * vw, M = Mseg * nsv, nrt = (M + 15) >> 4;
-    const int Cin = d.Cin, Cout = d.Cout, nchunks = (d.dbg & 128) ? 0 : d.nchunks;
+    const int Cin = d.Cin, Cout = d.Cout, nchunks = (dbgv & 128) ? 0 : d.nchunks;
     // STEM: X is the planar spectrogram [n][C][SH][SW]; "Cin" = kh*kw*C im2col columns
     const float *Xb = STEM ? d.X + (size_t)seg0 * d.stem_c * d.stem_h * d.stem_w : d.X + (size_t)seg0 * d.H * d.W * Cin;
     const int rw = wave / NCS, cs = wave - rw * NCS;  // P1: row-tile lane of the wave, column split
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                 eoff[i] = __mul24(sl * IH * IW + __mul24(ra + r, IW) + xa + c, CES) + 4 * kq;
                 xo[ii] = STEM ? (((iy0 + ra + r) << 16) | (ix0 + xa + c))   // stem-output pixel (y, x), gathered below
                               : __mul24(__mul24(sl * d.H + iy0 + ra + r, d.W) + ix0 + xa + c, Cin);
-                rvv[ii] = !(d.dbg & 64);
+                rvv[ii] = !(dbgv & 64);
             }
         }
         if constexpr (KG == 0) {
@@ -577,7 +584,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
 #pragma unroll
                     for (int ii = 0; ii < RG; ii++) acc[ii][j] = b4;
                 }
-                if (!(d.dbg & 8)) {
+                if (!(dbgv & 8)) {
                     if constexpr (PREC != 0) {
                         // fragment planes: [step][column tile]{hi: 64 lanes x 8 halves, lo: same}
                         const f16x8 *wf = reinterpret_cast<const f16x8 *>(WeC);
@@ -689,7 +696,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                 for (int i = tid; i < halo_fl / 4; i += NTH) hdst[i] = gsrc[i];
             }
         }
-        if (!ring && !RESIDENT && !(d.dbg & 16)) {
+        if (!ring && !RESIDENT && !(dbgv & 16)) {
             if constexpr (COLTH > 0) {
                 // (issued in parts inside the depthwise phase below)
             } else {
@@ -707,8 +714,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
             // chains per lane, as bh_act4 does for the 4-channel tasks)
             constexpr int PADT = (KS - 1) / 2, C2N = CE / 2;
             static_assert(ST == 1, "column tasks: stride 1");
-            const bool dma_on = !(d.dbg & 16);
-            if (!(tid < nsv * TW * C2N && !(d.dbg & 2))) {   // (wave-uniform)
+            const bool dma_on = !(dbgv & 16);
+            if (!(tid < nsv * TW * C2N && !(dbgv & 2))) {   // (wave-uniform)
                 if (dma_on) {
                     mb_dma_at<WE_FLOATS, NW>(d.We + (size_t)chn * WE_FLOATS, we_ba, wave, lane);
                     mb_dma_at<WP_FLOATS, NW>(d.Wp + (size_t)ch * WP_FLOATS, wp_ba, wave, lane);
@@ -782,8 +789,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
             // Ho == COLTH, one tile row, pad_t == (KS - 1) / 2 and at most 256 tasks
             constexpr int PADT = (KS - 1) / 2;
             static_assert(ST == 1, "column tasks: stride 1");
-            const bool dma_on = !(d.dbg & 16);
-            if (!(tid < nsv * TW * C4N && !(d.dbg & 2))) {   // (wave-uniform: a wave without tasks issues its pieces at once)
+            const bool dma_on = !(dbgv & 16);
+            if (!(tid < nsv * TW * C4N && !(dbgv & 2))) {   // (wave-uniform: a wave without tasks issues its pieces at once)
                 if (dma_on) {
                     mb_dma_at<WE_FLOATS, NW>(d.We + (size_t)chn * WE_FLOATS, we_ba, wave, lane);
                     mb_dma_at<WP_FLOATS, NW>(d.Wp + (size_t)ch * WP_FLOATS, wp_ba, wave, lane);
@@ -877,7 +884,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                 }
             }
         } else
-        if (!(d.dbg & 2)) {
+        if (!(dbgv & 2)) {
             for (int t = tid; t < p2_ntask; t += NTH) {
                 if (p2_ntask > NTH) p2_task(t);   // wave-uniform
                 const int c4 = p2_c4;
@@ -934,11 +941,11 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
         __syncthreads();  // B2: Ds complete; (ring == 0) WeS (next chunk) and WpS (this chunk) landed; Wds free
         if (RESIDENT) {
         } else if (!ring) {
-            if (!(d.dbg & 16)) {
+            if (!(dbgv & 16)) {
                 if constexpr (COLTH > 0) mb_dma_at<WD_FLOATS, NW>(d.Wd + (size_t)chn * WD_FLOATS, wd_ba, wave, lane);
                 else mb_dma<WD_FLOATS, NW>(d.Wd + (size_t)chn * WD_FLOATS, Wds, wave, lane);
             }
-        } else if (ch + 2 < nchunks && !(d.dbg & 16)) {
+        } else if (ch + 2 < nchunks && !(dbgv & 16)) {
             // chunk ch + 2 into the buffers chunk ch has just finished with (We, Wd: read before this barrier) and into the Wp
             // buffer of chunk ch - 1 (its project phase ended before B1 of this chunk)
             mb_dma<WE_FLOATS, NW>(d.We + (size_t)(ch + 2) * WE_FLOATS, WeS + (ch & 1) * WE_FLOATS, wave, lane);
@@ -948,7 +955,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
         mb_stamp(d.stamps, t_last, 5);
 
         // ---- P3: project -----------------------------------------------------------------
-        if (!(d.dbg & 4)) {
+        if (!(dbgv & 4)) {
             if constexpr (P16) {
                 // fragment planes: [column tile]{hi: 64 lanes x 4 halves, lo: same}; k = 4 (lane >> 4) + 0..3
                 const f16x4 *wf = reinterpret_cast<const f16x4 *>(WpC);
@@ -1065,7 +1072,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
             if (col >= Cout) continue;
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                if (orow[r] >= 0 && !(d.dbg & 32)) Yb[(size_t)orow[r] * Cout + col] = PREC != 0 ? acco[i][j][r] * p_unscale : acco[i][j][r];
+                if (orow[r] >= 0 && !(dbgv & 32)) Yb[(size_t)orow[r] * Cout + col] = PREC != 0 ? acco[i][j][r] * p_unscale : acco[i][j][r];
         }
     }
     mb_stamp(d.stamps, t_last, 7);
