@@ -37,6 +37,9 @@ double mb_try_th(MbDesc &d, int ci, int th) {
     // any Cexp: the last chunk's missing channels are zero weights and biases (every activation here maps 0 to 0)
     if (c.KS != d.KS || c.ST != d.ST || (!d.stem && d.Cin % 4) || d.Cexp % 4) return -1;
     if (c.STEM != (d.stem ? d.stem_c : 0)) return -1;
+    // (the kernel's per-lane offsets are 24-bit products and 32-bit element offsets within one workgroup's segments)
+    if ((long)c.S * d.H * d.W * std::max(d.Cin, 1) >= (1L << 24) || (long)c.S * d.Ho * d.Wo * d.Cout >= (1L << 24) ||
+        (d.stem && (long)d.stem_c * d.stem_h * d.stem_w >= (1L << 24))) return -1;
     if (d.stem && d.stem_k != 3) return -1;
     if (c.PREC != d.prec) return -1;
     if (c.KG == 0) { if (!d.noexp || d.stem) return -1; }   // the no-expand entries serve the no-expand blocks, and only them

@@ -395,21 +395,23 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
 #pragma unroll
             for (int ii = 0; ii < XBATCH; ii++) {
                 if (i0 + ii >= RT_W) continue;
-                const int sy = (xo[ii] >> 16) * d.stem_s - d.stem_pt, sx = (xo[ii] & 0xffff) * d.stem_s - d.stem_pl;
+                // (24-bit multiplies and 32-bit element offsets: v_mul_lo_u32 / v_mad_u64_u32 are quarter-rate, and a segment's
+                //  spectrogram or image is far below 2^24 elements -- mb_try_th checks it)
+                const int sy = __mul24(xo[ii] >> 16, d.stem_s) - d.stem_pt, sx = __mul24(xo[ii] & 0xffff, d.stem_s) - d.stem_pl;
                 const int bx = min(max(sx, 0), d.stem_w - 3);   // the 3-float window, kept inside the row
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     const int r = 2 * kq + q, ch = r >= 3 ? 1 : 0, dy = r - 3 * ch, y = sy + dy;
                     okr[ii][q] = rvv[ii] && r < 3 * STEM && y >= 0 && y < d.stem_h;
                     const int yc = okr[ii][q] ? y : 0, chc = okr[ii][q] ? ch : 0;
-                    t[ii][q] = *reinterpret_cast<const F3 *>(Xb + ((size_t)chc * d.stem_h + yc) * d.stem_w + bx);
+                    t[ii][q] = *reinterpret_cast<const F3 *>(Xb + (__mul24(__mul24(chc, d.stem_h) + yc, d.stem_w) + bx));
                 }
             }
 #pragma unroll
             for (int ii = 0; ii < XBATCH; ii++) {
                 const int i = i0 + ii;
                 if (i >= RT_W) continue;
-                const int sx = (xo[ii] & 0xffff) * d.stem_s - d.stem_pl;
+                const int sx = __mul24(xo[ii] & 0xffff, d.stem_s) - d.stem_pl;
                 const int sh = sx - min(max(sx, 0), d.stem_w - 3);
                 float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -505,7 +507,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                 float rres[4] = {0.f, 0.f, 0.f, 0.f};
                 if (Rb) {   // (wave-uniform)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) rres[r] = Rb[(size_t)max(orow[r], 0) * Cout + colc];
+                    for (int r = 0; r < 4; r++) rres[r] = Rb[__mul24(max(orow[r], 0), Cout) + colc];
                 }
                 const float bias = col < Cout ? braw : 0.0f;
 #pragma unroll
@@ -515,7 +517,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                 const float bias = col < Cout ? d.bp[col] : 0.0f;
 #pragma unroll
                 for (int r = 0; r < 4; r++)
-                    acco[i][j][r] = __builtin_fmaf((Rb && col < Cout && orow[r] >= 0) ? Rb[(size_t)orow[r] * Cout + col] : 0.0f, p_scale, bias);
+                    acco[i][j][r] = __builtin_fmaf((Rb && col < Cout && orow[r] >= 0) ? Rb[__mul24(orow[r], Cout) + col] : 0.0f, p_scale, bias);
             }
         }
     }
@@ -1040,7 +1042,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
             if (col >= Cout) continue;
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                if (orow[r] >= 0 && !(dbgv & 32)) Yb[(size_t)orow[r] * Cout + col] = PREC != 0 ? acco[i][j][r] * p_unscale : acco[i][j][r];
+                if (orow[r] >= 0 && !(dbgv & 32)) Yb[__mul24(orow[r], Cout) + col] = PREC != 0 ? acco[i][j][r] * p_unscale : acco[i][j][r];
         }
     }
     mb_stamp(d.stamps, t_last, 7);
