@@ -559,7 +559,7 @@ __global__ __launch_bounds__(256 * HALVES, (MT <= 6 || HALVES == 2) ? 2 : 1) voi
                     float o = (dbg & 2) ? v : __builtin_amdgcn_exp2f(__builtin_fmaf(bp.expo, __builtin_amdgcn_logf(v * v), bp.log2_bias));
                     o = o * bp.out_scale + bp.out_shift;
                     const int row = bp.flip ? (bp.n_mels - 1 - mel) : mel;
-                    if (!(dbg & 8) || o == 12345.678f) out[(size_t)row * bp.n_frames + t] = o;
+                    if (!(dbg & 8) || o == 12345.678f) out[__mul24(row, bp.n_frames) + t] = o;   // (24-bit product: a branch's [mel][time] plane is < 2^24 elements; v_mad_i64_i32 is quarter-rate)
                 }
             }
     }
