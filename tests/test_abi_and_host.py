@@ -365,6 +365,10 @@ def test_shipped_tile_configurations_are_the_reachable_ones():
     assert len(by_model["perch_v2/default/f16x3"]["fused"]) == 26 and len(by_model["perch_v2/default/f16"]["fused"]) == 26
     assert len(by_model["perch_v2/default/f32"]["fused"]) == 26 and not by_model["perch_v2/default/f32"]["unfused_triples"]   # (round 4)
     assert not by_model["perch_v2/default/f16x3"]["unfused_triples"]
+    # the small-launch twins ride behind their blocks in the listing: one-segment tiles (133 / 135) and, since round 4, the narrow
+    # 8-column tiles of the nine whole-image late blocks (193-202), each with its block's chunk and project-tile layout
+    twins = {c % n_base for _, c in by_model["birdnet_v24/default/f16x3"]["twins"]}
+    assert {133, 135} <= twins and {193, 195, 197, 199, 201} <= twins, sorted(twins)
     assert not os.path.exists(os.path.join(ROOT, "birda_amd", "csrc", "kernels_mbwave.hip"))
     so = os.path.getsize(os.path.join(ROOT, "birda_amd", "libbirda_hip.so"))
     assert so < 9 * 2 ** 20, f"libbirda_hip.so grew to {so / 2 ** 20:.1f} MiB"
