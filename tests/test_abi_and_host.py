@@ -371,7 +371,7 @@ def test_shipped_tile_configurations_are_the_reachable_ones():
     assert {133, 135} <= twins and {193, 195, 197, 199, 201} <= twins, sorted(twins)
     assert not os.path.exists(os.path.join(ROOT, "birda_amd", "csrc", "kernels_mbwave.hip"))
     so = os.path.getsize(os.path.join(ROOT, "birda_amd", "libbirda_hip.so"))
-    assert so < 9 * 2 ** 20, f"libbirda_hip.so grew to {so / 2 ** 20:.1f} MiB"
+    assert so < 10 * 2 ** 20, f"libbirda_hip.so grew to {so / 2 ** 20:.1f} MiB"   # (8.2 MiB in round 3; + the f32 twins of the Perch-sized stack and the narrow-tile twins)
 
 
 # ---------------- range filter tables (host logic, include/birda_host.h) ----------------
