@@ -224,7 +224,13 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
     // chunks are small: the early, large-image blocks): We x 2, Wp x 3, Wd x 2, refilled one whole CHUNK ahead -- a phase of
     // those blocks is a few hundred cycles, shorter than an L2 -> LDS transfer, and the waits in front of both barriers were
     // half of the kernel's wave-cycles (tools/gpu_mb_stamps.py); the ring costs 5-7 KB of LDS.
+    // (the ring is a measured alternative, BIRDA_HIP_MB_RING in the EXPERIMENTS build: in the product MbDesc::ring is never set, and
+    //  as a compile-time false its buffer selects -- `ch & 1`, `ch % 3` and their multiplies, once per chunk -- and branches fold away)
+#ifdef BIRDA_HIP_EXPERIMENTS
     const bool ring = !PERSIST && COLTH == 0 && d.ring != 0;
+#else
+    constexpr bool ring = false;
+#endif
     const int nbuf_e = RESIDENT ? d.nchunks : (ring ? 2 : 1), nbuf_p = RESIDENT ? d.nchunks : (ring ? 3 : 1);
     float *WeS = Ds + DS_FLOATS;
     _Float16 *DsH = reinterpret_cast<_Float16 *>(Ds), *DsL = DsH + POUT_PAD * DSH;   // PREC != 0
