@@ -418,6 +418,12 @@ def model_from_graph(g: ox.Graph, frontend: Optional[mf.Model] = None, spectrogr
             L = layers[t[0] - 1] if t and t[0] > 0 else None
             if L is None or L.op not in (mf.OP_CONV, mf.OP_DWCONV, mf.OP_PWCONV) or L.act != mf.ACT_NONE:
                 raise ConvertError("BatchNormalization that does not follow a convolution directly")
+            # folding rewrites the convolution's weights: a residual already folded into the layer (BN(conv + x)) or another
+            # reader of the convolution's output (a skip taken before the BN) would silently see the wrong values
+            if L.res_tensor != mf.NO_TENSOR:
+                raise ConvertError("BatchNormalization after a residual Add (BN(conv + x)) cannot be folded into the convolution")
+            if sum(n.inputs[0] in q.inputs for q in g.nodes) != 1 or n.inputs[0] in graph_out:
+                raise ConvertError("BatchNormalization of a convolution output that has other readers cannot be folded")
             gamma, beta, mean, var = (g.initializers[a].astype(np.float64) for a in n.inputs[1:5])
             scale = gamma / np.sqrt(var + float(n.attrs.get("epsilon", 1e-5)))
             nw = {mf.OP_CONV: L.kh * L.kw * L.cin * L.cout, mf.OP_DWCONV: L.kh * L.kw * L.cout, mf.OP_PWCONV: L.cin * L.cout}[L.op]

@@ -1104,6 +1104,7 @@ int bh_batch_context_create(bh_classifier *c, size_t max_batch, bh_batch_context
             *out = *pick;
             *pick = nullptr;
             (*out)->asked_batch = max_batch;
+            (*out)->pending.clear();
             return BH_OK;
         }
     }
@@ -1134,6 +1135,7 @@ void bh_batch_context_destroy(bh_batch_context *ctx) {
     bh_classifier *c = ctx->c;
     if (!ctx->keep_tensors && !ctx->profiling) {   // parked for the next create of this size (see bh_classifier::parked_ctx)
         ctx->forced_sub_slices = 0;
+        ctx->pending.clear();   // (a caller that destroys without a synchronise: the next owner must not repair into ITS freed buffers)
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(ctx->stream);
         *ctx->h_nonfinite = 0;
@@ -1241,42 +1243,13 @@ int bh_predict_batch_logits(bh_classifier *c, bh_batch_context *ctx, const float
     return predict_slices(c, ctx, nullptr, base, n, nullptr, logits, embeddings);
 } catch (...) { return on_exception(); }
 
-int bh_forward_device(bh_classifier *c, bh_batch_context *ctx, const float *d_segments, size_t n, float *d_logits,
-                      int32_t *d_topk_index, float *d_topk_conf) try {
-    int rc = check_ctx(c, ctx);
-    if (rc != BH_OK) return rc;
-    if (!d_segments || !d_logits) return fail(BH_ERR_INVALID, "forward_device: null device pointer");
-    HIPCHK(hipSetDevice(c->device));
-    const auto &h = c->model.h;
-    for (size_t b0 = 0; b0 < n; b0 += ctx->max_batch) {
-        const size_t nb = std::min(ctx->max_batch, n - b0);
-        rc = forward_slice(c, ctx, d_segments + b0 * h.sample_count, nb, d_logits + b0 * h.n_classes,
-                           d_topk_index ? d_topk_index + b0 * c->top_k : nullptr,
-                           d_topk_conf ? d_topk_conf + b0 * c->top_k : nullptr);
-        if (rc != BH_OK) return rc;
-        if (c->auto_fallback && d_topk_index && d_topk_conf) {   // what bh_batch_context_synchronize re-runs marked rows from
-            const bh_batch_context::Pending p{d_segments + b0 * h.sample_count, nb, d_logits + b0 * h.n_classes,
-                                              d_topk_index + b0 * c->top_k, d_topk_conf + b0 * c->top_k};
-            bool known = false;
-            for (const auto &q : ctx->pending) known |= q.d_seg == p.d_seg && q.n == p.n && q.d_logits == p.d_logits && q.d_idx == p.d_idx && q.d_conf == p.d_conf;
-            if (!known) {
-                if (ctx->pending.size() < 256) ctx->pending.push_back(p);
-                else ctx->pending_overflow = true;
-            }
-        }
-    }
-    return BH_OK;
-} catch (...) { return on_exception(); }
-
-int bh_batch_context_synchronize(bh_batch_context *ctx) try {
-    if (!ctx) return fail(BH_ERR_INVALID, "synchronize: null context");
-    bh_classifier *c = ctx->c;
-    HIPCHK(hipSetDevice(c->device));
+// BH_FLAG_AUTO on the device-resident path: the marked rows of every forward enqueued since the last settle, again on the f32
+// kernels (forwards that shared their buffers have been overwritten by the last one of them, whose rows these are).  Ends with
+// the stream idle, the pending list empty and the counter cleared.
+static int settle_pending(bh_classifier *c, bh_batch_context *ctx) {
     HIPCHK(fetch_nonfinite(ctx));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (*ctx->h_nonfinite && c->auto_fallback && !ctx->pending_overflow) {
-        // BH_FLAG_AUTO: the marked rows of every forward enqueued since the last synchronise, again on the f32 kernels.  (Forwards
-        // that shared their buffers have been overwritten by the last one of them, whose rows these are.)
+    if (*ctx->h_nonfinite && c->auto_fallback) {
         std::vector<int32_t> h_idx;
         std::vector<size_t> bad;
         for (const auto &p : ctx->pending) {
@@ -1291,7 +1264,44 @@ int bh_batch_context_synchronize(bh_batch_context *ctx) try {
         clear_nonfinite(ctx);
     }
     ctx->pending.clear();
-    ctx->pending_overflow = false;
+    return BH_OK;
+}
+
+int bh_forward_device(bh_classifier *c, bh_batch_context *ctx, const float *d_segments, size_t n, float *d_logits,
+                      int32_t *d_topk_index, float *d_topk_conf) try {
+    int rc = check_ctx(c, ctx);
+    if (rc != BH_OK) return rc;
+    if (!d_segments || !d_logits) return fail(BH_ERR_INVALID, "forward_device: null device pointer");
+    HIPCHK(hipSetDevice(c->device));
+    const auto &h = c->model.h;
+    for (size_t b0 = 0; b0 < n; b0 += ctx->max_batch) {
+        const size_t nb = std::min(ctx->max_batch, n - b0);
+        const bool track = c->auto_fallback && d_topk_index && d_topk_conf;   // what bh_batch_context_synchronize re-runs marked rows from
+        const bh_batch_context::Pending p{d_segments + b0 * h.sample_count, nb, d_logits + b0 * h.n_classes,
+                                          d_topk_index ? d_topk_index + b0 * c->top_k : nullptr,
+                                          d_topk_conf ? d_topk_conf + b0 * c->top_k : nullptr};
+        bool known = !track;
+        if (track)
+            for (const auto &q : ctx->pending) known |= q.d_seg == p.d_seg && q.n == p.n && q.d_logits == p.d_logits && q.d_idx == p.d_idx && q.d_conf == p.d_conf;
+        // a full list is settled HERE (an internal synchronise + repair of what is enqueued so far) rather than dropped: the header
+        // promises BH_OK with the rows re-run however many distinct forwards a caller enqueues between two synchronises
+        if (!known && ctx->pending.size() >= bh_batch_context::MAX_PENDING) {
+            rc = settle_pending(c, ctx);
+            if (rc != BH_OK) return rc;
+        }
+        rc = forward_slice(c, ctx, p.d_seg, nb, p.d_logits, p.d_idx, p.d_conf);
+        if (rc != BH_OK) return rc;
+        if (!known) ctx->pending.push_back(p);
+    }
+    return BH_OK;
+} catch (...) { return on_exception(); }
+
+int bh_batch_context_synchronize(bh_batch_context *ctx) try {
+    if (!ctx) return fail(BH_ERR_INVALID, "synchronize: null context");
+    bh_classifier *c = ctx->c;
+    HIPCHK(hipSetDevice(c->device));
+    const int rc = settle_pending(c, ctx);
+    if (rc != BH_OK) return rc;
     return nonfinite_status(c, ctx);   // BH_ERR_NONFINITE once per occurrence: the counter is cleared
 } catch (...) { return on_exception(); }
 void *bh_batch_context_stream(bh_batch_context *ctx) { return ctx ? (void *)ctx->stream : nullptr; }

@@ -163,7 +163,7 @@ struct bh_batch_context {
     // bh_forward_device calls (with top-k buffers) since the last bh_batch_context_synchronize: what BH_FLAG_AUTO re-runs from
     struct Pending { const float *d_seg; size_t n; float *d_logits; int32_t *d_idx; float *d_conf; };
     std::vector<Pending> pending;
-    bool pending_overflow = false;
+    static constexpr size_t MAX_PENDING = 256;   // a full list is settled by bh_forward_device itself (api.hip settle_pending)
     size_t device_bytes = 0;
     size_t last_n = 0;
     const float *last_logits = nullptr;

@@ -72,9 +72,11 @@ struct Tensor {
     std::vector<float> fl;
     std::vector<int64_t> il;
     uint64_t count = 0;
+    bool has_raw = false;
     bool is_f32() const { return dtype == 1; }
+    // (parse_tensor leaves exactly one payload of `count` elements: raw_data when present -- float_data beside it is dropped -- else float_data)
     float at(uint64_t i) const {
-        if (!fl.empty()) return fl[i];
+        if (!has_raw) return fl[i];
         float v; memcpy(&v, raw.p + 4 * i, 4); return v;
     }
 };
@@ -113,8 +115,11 @@ inline bool parse_tensor(Span s, std::string &name, Tensor &t, std::string &err)
         t.count *= (uint64_t)d;
         if (t.count > (1ull << 31)) { err = "tensor '" + name + "': too large"; return false; }
     }
+    t.has_raw = has_raw;
     if (t.dtype == 1) {
-        if (has_raw) { if (t.raw.n != t.count * 4) { err = "tensor '" + name + "': raw_data size does not match its dims"; return false; } }
+        // a tensor carrying BOTH raw_data and a shorter float_data was read through float_data beyond its end.
+        // raw_data wins, as in onnx's own helpers, and whatever float_data came with it is dropped.
+        if (has_raw) { if (t.raw.n != t.count * 4) { err = "tensor '" + name + "': raw_data size does not match its dims"; return false; } t.fl.clear(); }
         else if (t.fl.size() != t.count) { err = "tensor '" + name + "': float_data size does not match its dims"; return false; }
     } else if (t.dtype == 7 || t.dtype == 6) {   // int64 / int32 (axes, shapes, Slice bounds)
         if (has_raw) {
@@ -344,7 +349,8 @@ inline bool model_from_graph(const Graph &g, Model &m, std::string &err) {
             if (n2.op != "Conv" || n2.in.size() < 2) continue;
             auto it = g.init.find(n2.in[1]);
             if (it == g.init.end() || it->second.dims.size() != 4) continue;
-            if (it->second.dims[1] * n2.geti("group", 1) != (int64_t)fam->n_branches) continue;
+            const int64_t grp = n2.geti("group", 1), cin_g = it->second.dims[1];
+            if (grp < 1 || grp > 65536 || cin_g < 1 || cin_g > 65536 || cin_g * grp != (int64_t)fam->n_branches) continue;
             spec = n2.in[0];
             break;
         }
@@ -544,6 +550,11 @@ inline bool model_from_graph(const Graph &g, Model &m, std::string &err) {
             LayerRec &L = layers[t.idx - 1];
             if ((L.op != OP_CONV && L.op != OP_DWCONV && L.op != OP_PWCONV) || L.act != A_NONE || n.in.size() < 5)
                 return fail("BatchNormalization that does not follow a convolution directly");
+            // folding rewrites the convolution's weights, so the BN must be the ONLY reader of the convolution's
+            // output (a skip taken before the BN would see scaled values), and a residual already folded into the layer means the BN
+            // normalises conv + residual, which no rescaling of the conv's weights expresses
+            if (L.res_tensor != NO_TENSOR) return fail("BatchNormalization after a residual Add (BN(conv + x)) cannot be folded into the convolution");
+            { auto cit = cons.find(n.in[0]); if ((cit != cons.end() && cit->second.size() != 1) || graph_out.count(n.in[0])) return fail("BatchNormalization of a convolution output that has other readers cannot be folded"); }
             const Tensor *p[4];
             for (int q = 0; q < 4; q++) { p[q] = f32init(n.in[1 + q]); if (!p[q] || p[q]->count != L.cout) return fail("BatchNormalization: parameters must be float32 initializers of the channel count"); }
             const double eps = (double)n.getf("epsilon", 1e-5f);

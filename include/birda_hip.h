@@ -148,9 +148,9 @@ BH_API uint64_t bh_classifier_fallback_segments(const bh_classifier *c);
 #define BH_MIN_BATCH_SIZE 1   /* constants.rs:44 */
 #define BH_MAX_BATCH_SIZE 512 /* constants.rs:55 */
 /* determine_default_batch_size(model_type, ep_status) (lib.rs:256-288; constants.rs:58-73) with this backend's arm:
- * (_, "CPU") 8; (v2.4 | BSG, "CUDA") 64; (v3.0 | Perch, "CUDA") 32; (_, "TensorRT") 32; (_, "HIP") 256; else 16.
- * 256 = half of MAX_BATCH_SIZE: every launch of the late blocks then has >= 128 workgroups and one batch context
- * holds ~1 GB.  provider_actual NULL = "HIP". */
+ * (_, "CPU") 8; (v2.4 | BSG, "CUDA") 64; (v3.0 | Perch, "CUDA") 32; (_, "TensorRT") 32; (_, "HIP") 512; else 16.
+ * 512 = MAX_BATCH_SIZE, the largest batch birda's validator admits (cli/validators.rs:140): every launch of the late blocks then
+ * has >= 256 workgroups and one batch context holds ~2 GB.  provider_actual NULL = "HIP". */
 BH_API size_t bh_default_batch_size(uint32_t model_type, const char *provider_actual);
 /* the same for a built classifier (its model family, provider "HIP") */
 BH_API size_t bh_classifier_default_batch_size(const bh_classifier *c);
@@ -299,12 +299,14 @@ BH_API int bh_batch_context_layer_ms(bh_batch_context *ctx, float *ms, uint32_t 
 /* Number of expand -> depthwise -> project triples that run as one fused launch; cfgs
  * (nullable) receives the tile configuration index of each.  Environment (tuning / A-B aids, read at
  * create): BIRDA_HIP_FUSE=0 disables fusion, BIRDA_HIP_MB_CFG=<i> forces configuration i where it is
- * valid, BIRDA_HIP_MB_PREFER=<i,j,...> tries those first, BIRDA_HIP_HEAD_GAP=0 keeps the head conv and
- * the global average pool as two launches, BIRDA_HIP_STEM_F32=1 keeps the stem block on the f32 MFMA in
- * f16x3 mode, BIRDA_HIP_MEL_F32=1 the front-end, BIRDA_HIP_RESAMPLE_F32=1 the resampler; BIRDA_HIP_MEL32=0/1 forces the 16-frame-fragment /
+ * valid, BIRDA_HIP_MB_PREFER=<i,j,...> tries those first, BIRDA_HIP_KEEP_FUSED=1 materialises the fused blocks' outputs for
+ * bh_debug_read_tensor, BIRDA_HIP_HEAD_GAP=0 keeps the head conv and the global average pool as two launches,
+ * BIRDA_HIP_MEL_F32=1 keeps the front-end on the f32 MFMA in the f16 modes, BIRDA_HIP_MEL32=0/1 forces the 16-frame-fragment /
  * 32-frame-fragment front-end kernel (default: by hop).  BIRDA_HIP_COPY_THREADS=<n> (default min(8, hardware
  * threads / 2)) sets the host threads that gather the caller's segments into pinned memory in the
- * bh_predict_batch* entry points. */
+ * bh_predict_batch* entry points.  (The complete list of names the shipped library reads is held by
+ * tests/test_abi_and_host.py::test_environment_names_in_the_shipped_library_are_the_documented_ones; A/B knobs of earlier
+ * rounds -- BIRDA_HIP_STEM_F32, BIRDA_HIP_RESAMPLE_F32, BIRDA_HIP_MB_STAMPS, ... -- exist only in the `make EXPERIMENTS=1` build.) */
 BH_API int bh_classifier_fused_blocks(const bh_classifier *c, int32_t *cfgs, size_t cap);
 
 /* The same plan for a model FILE, without a device (host logic only: which expand -> depthwise -> project triples fuse and the tile
@@ -322,9 +324,9 @@ BH_API int bh_classifier_frontend_kernel(const bh_classifier *c, char *out, size
  * "mbconv_kernel<" (to match bench timings with rocprofv3 rows); returns the string length. */
 BH_API int bh_mb_config_name(int32_t cfg, char *out, size_t cap);
 
-/* Diagnostic (BIRDA_HIP_MB_STAMPS=1 at create): per fused block, 8 counters of wave-cycles spent in
- * setup, dw-weight staging, expand, barrier, depthwise, barrier, project, epilogue since the
- * last call.  Returns the number of blocks written (8 values each). */
+/* Diagnostic of the `make EXPERIMENTS=1` build (there: BIRDA_HIP_MB_STAMPS=1 at create): per fused block, 8 counters of
+ * wave-cycles spent in setup, dw-weight staging, expand, barrier, depthwise, barrier, project, epilogue since the last call.
+ * Returns the number of blocks written (8 values each); the product build has no phase clock and always returns 0. */
 BH_API int bh_debug_mb_stamps(bh_classifier *c, uint64_t *out, size_t cap);
 
 /* decode_and_stream + process_batch for source-rate input (processor.rs:84-87, 220-277): every

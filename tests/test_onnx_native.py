@@ -137,6 +137,67 @@ def test_refusals_name_their_reason(tmp_path):
     assert L.bh_onnx_to_bhm(p.encode(), str(tmp_path / "junk.bhm").encode()) == -2
 
 
+def test_tensor_with_raw_data_and_a_shorter_float_data_is_read_from_raw_data(tmp_path, monkeypatch):
+    """an initializer carrying raw_data AND one float_data element used to be read through float_data, seven
+    elements past its end.  raw_data wins (as in onnx's own helpers): the model converts to the same container as the clean file."""
+    import struct
+    m = synth.build_model("mini")
+    g = convert.graph_from_model(m)
+    clean = str(tmp_path / "clean.onnx")
+    with open(clean, "wb") as f:
+        f.write(ox.dump(g))
+    ser = ox._ser_tensor
+
+    def both(name, arr):
+        out = ser(name, arr)
+        if np.asarray(arr).dtype == np.float32 and np.asarray(arr).size >= 8:
+            out += ox._key(4, 5) + struct.pack("<f", 12345.0)        # one repeated float_data element beside the raw payload
+        return out
+    monkeypatch.setattr(ox, "_ser_tensor", both)
+    dirty = str(tmp_path / "dirty.onnx")
+    with open(dirty, "wb") as f:
+        f.write(ox.dump(g))
+    monkeypatch.undo()
+    assert os.path.getsize(dirty) > os.path.getsize(clean)
+    a, b = _native(clean, str(tmp_path / "a.bhm")), _native(dirty, str(tmp_path / "b.bhm"))
+    _same_model(a, b)
+
+
+def test_batchnorm_that_cannot_be_folded_is_refused(tmp_path):
+    """BN(conv + residual) and a BN whose convolution has another reader (a skip taken before the BN) cannot
+    be expressed by rescaling the convolution's weights: both converters refuse them instead of folding silently."""
+    from test_convert import hand_written_graph
+    L = _lib.load()
+
+    def both_refuse(g, what, name):
+        data = ox.dump(g)
+        p = str(tmp_path / name)
+        with open(p, "wb") as f:
+            f.write(data)
+        with pytest.raises(convert.ConvertError, match=what):
+            convert.model_from_graph(ox.load(data), hand_written_graph()[3])
+        assert L.bh_onnx_to_bhm(p.encode(), (p + ".bhm").encode()) == -2 and what in L.bh_last_error().decode()
+
+    rng = np.random.default_rng(8)
+
+    def bn_params(g, tag, c):
+        names = []
+        for k, v in (("g", rng.uniform(0.5, 1.5, c)), ("b", rng.normal(0, 0.1, c)), ("m", rng.normal(0, 0.1, c)), ("v", rng.uniform(0.5, 1.5, c))):
+            g.initializers[f"{tag}_{k}"] = np.asarray(v, np.float32)
+            names.append(f"{tag}_{k}")
+        return names
+    # (a) pre-activation style: Add -> BatchNormalization
+    g = hand_written_graph()[0]
+    k = next(i for i, n in enumerate(g.nodes) if n.outputs[0] == "r2")
+    g.nodes.insert(k + 1, ox.Node("BatchNormalization", ["r2"] + bn_params(g, "bnr", 8), ["r2n"], {"epsilon": 1e-3}))
+    next(n for n in g.nodes if n.outputs[0] == "c3").inputs[0] = "r2n"
+    both_refuse(g, "residual Add", "add_bn.onnx")
+    # (b) the skip is taken from the convolution's output, in front of its BatchNormalization
+    g = hand_written_graph()[0]
+    next(n for n in g.nodes if n.outputs[0] == "r2").inputs[1] = "c0"
+    both_refuse(g, "other readers", "skip_before_bn.onnx")
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,frontend", [("birdnet_v24", "conv1d"), ("perch_v2", None), ("mini_se", None), ("birdnet_v30", None)])
 def test_classifier_created_on_the_onnx_file_gives_the_bhm_route_logits(tmp_path, kind, frontend):
