@@ -62,6 +62,8 @@ SYMBOLS = [
     ("bh_classifier_provider_status", C.c_int, [_VP, C.POINTER(BhProviderStatus)]),
     ("bh_classifier_fallback_segments", C.c_uint64, [_VP]),
     ("bh_onnx_to_bhm", C.c_int, [C.c_char_p, C.c_char_p]),
+    ("bh_onnx_eval", C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_uint32, C.c_char_p,
+                               C.POINTER(C.c_double), _SZ, C.POINTER(C.c_int64), C.POINTER(C.c_uint32)]),
     ("bh_default_batch_size", _SZ, [C.c_uint32, C.c_char_p]),
     ("bh_classifier_default_batch_size", _SZ, [_VP]),
     ("bh_classifier_create", C.c_int, [C.POINTER(BhConfig), C.POINTER(_VP)]),

@@ -385,6 +385,12 @@ bool load_any_model(const char *path, bh::Model &m, std::string &err) {
     return false;
 }
 
+// A well-formed file whose front-end the kernels cannot express (or the evaluator cannot run) is BH_ERR_UNSUPPORTED, not a
+// malformed file: onnx_conv.hpp marks that refusal with this phrase.
+int model_load_status(const std::string &err) {
+    return err.find("the spectrogram front-end cannot be read off the graph") != std::string::npos ? BH_ERR_UNSUPPORTED : BH_ERR_IO;
+}
+
 int check_ctx(bh_classifier *c, bh_batch_context *ctx) {
     if (!c || !ctx) return fail(BH_ERR_INVALID, "null classifier or batch context");
     if (ctx->c != c) return fail(BH_ERR_INVALID, "batch context belongs to another classifier");
@@ -737,7 +743,7 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) try {
     if (cfg->top_k == 0 || cfg->top_k > BH_MAX_TOP_K) return fail(BH_ERR_INVALID, "top_k must be 1..%d", BH_MAX_TOP_K);
     auto c = std::make_unique<bh_classifier>();
     std::string err;
-    if (!load_any_model(cfg->model_path, c->model, err)) return fail(BH_ERR_IO, "%s", err.c_str());
+    if (!load_any_model(cfg->model_path, c->model, err)) return fail(model_load_status(err), "%s", err.c_str());
     const auto &m = c->model;
     if (cfg->labels_path) {
         int rc = read_labels(cfg->labels_path, c->labels);
@@ -1348,8 +1354,35 @@ int bh_onnx_to_bhm(const char *onnx_path, const char *bhm_path) try {
     if (!onnx_path || !bhm_path) return fail(BH_ERR_INVALID, "onnx_to_bhm: null path");
     bh::Model m;
     std::string err;
-    if (!bh::onnxc::load_onnx_model(onnx_path, m, err)) return fail(BH_ERR_IO, "%s", err.c_str());
+    if (!bh::onnxc::load_onnx_model(onnx_path, m, err)) return fail(model_load_status(err), "%s", err.c_str());
     if (!bh::onnxc::write_bhm(bhm_path, m, err)) return fail(BH_ERR_IO, "%s", err.c_str());
+    return BH_OK;
+} catch (...) { return on_exception(); }
+
+int bh_onnx_eval(const char *onnx_path, const char *feed_name, const double *feed, const int64_t *feed_dims, uint32_t feed_rank,
+                 const char *target, double *out, size_t out_cap, int64_t *out_dims, uint32_t *out_rank) try {
+    if (!onnx_path || !target || !out_dims || !out_rank || (feed_name && (!feed || (feed_rank && !feed_dims)))) return fail(BH_ERR_INVALID, "onnx_eval: null argument");
+    if (feed_rank > bh::onnxf::EVAL_MAX_RANK) return fail(BH_ERR_INVALID, "onnx_eval: feed of rank %u", feed_rank);
+    std::vector<uint8_t> buf;
+    std::string err;
+    bh::onnxc::Graph g;
+    if (!bh::onnxc::read_file(onnx_path, buf, err) || !bh::onnxc::parse_graph(bh::onnxd::Span{buf.data(), buf.size()}, g, err)) return fail(BH_ERR_IO, "%s: %s", onnx_path, err.c_str());
+    try {
+        bh::onnxf::Evaluator ev(g);
+        bh::onnxf::Evaluator::Env feeds;
+        if (feed_name) {
+            bh::onnxf::Arr a;
+            a.d.assign(feed_dims, feed_dims + feed_rank);
+            a.v.assign(feed, feed + bh::onnxf::shape_elems(a.d));
+            feeds[feed_name] = std::move(a);
+        }
+        const auto r = ev.run(feeds, {std::string(target)});
+        const bh::onnxf::Arr &t = r[0];
+        *out_rank = (uint32_t)t.rank();
+        for (size_t i = 0; i < t.rank() && i < 8; i++) out_dims[i] = t.d[i];
+        if (t.size() > out_cap || !out) return fail(BH_ERR_INVALID, "onnx_eval: tensor '%s' has %zu values, room for %zu", target, t.size(), out_cap);
+        for (size_t i = 0; i < t.size(); i++) out[i] = t.f(i);
+    } catch (const bh::onnxf::EvalError &e) { return fail(BH_ERR_IO, "%s: %s", onnx_path, e.what()); }
     return BH_OK;
 } catch (...) { return on_exception(); }
 
@@ -1357,7 +1390,7 @@ int bh_plan_fused_blocks(const char *model_path, uint32_t flags, int32_t *cfgs, 
     if (!model_path) return fail(BH_ERR_INVALID, "plan_fused_blocks: null model path");
     bh::Model m;
     std::string err;
-    if (!load_any_model(model_path, m, err)) return fail(BH_ERR_IO, "%s", err.c_str());
+    if (!load_any_model(model_path, m, err)) return fail(model_load_status(err), "%s", err.c_str());
     const uint32_t p = flags & BH_FLAG_PRECISION_MASK;
     const int precision = p == BH_FLAG_F32 ? 0 : p == BH_FLAG_F16 ? 1 : 3;
     const std::vector<int> readers = tensor_readers(m);

@@ -13,6 +13,7 @@
 // goes through bh_predict* (HIP); nothing here computes logits on the CPU.
 #include <algorithm>
 #include <atomic>
+#include <pthread.h>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -307,8 +308,9 @@ struct WatchdogHub {
     }
     uint64_t arm(uint64_t timeout_ms, size_t batch_size) {
         std::lock_guard<std::mutex> l(mu);
-        if (!thread_started) {   // created once; never per batch
-            std::thread([this] { loop(); }).detach();
+        if (!thread_started) {   // created once; never per batch.  A bare pthread: std::thread's heap-allocated state block of a thread
+            pthread_t th;        // that never ends is what LeakSanitizer reports once the process has created other threads before it
+            if (pthread_create(&th, nullptr, [](void *p) -> void * { static_cast<WatchdogHub *>(p)->loop(); return nullptr; }, this) == 0) pthread_detach(th);
             thread_started = true;
         }
         const uint64_t id = next_id++;

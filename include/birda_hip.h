@@ -35,7 +35,7 @@ typedef enum {
     BH_ERR_NO_DEVICE = -3, /* no HIP device / device index out of range */
     BH_ERR_HIP = -4,       /* a HIP runtime call failed; message carries hipGetErrorString */
     BH_ERR_LABELS = -5,    /* label count != model output width (inference/mod.rs:34-37) */
-    BH_ERR_UNSUPPORTED = -6,
+    BH_ERR_UNSUPPORTED = -6, /* a well-formed model whose spectrogram front-end the kernels cannot express, or cannot be read (bh_config.model_path) */
     BH_ERR_INTERNAL = -7,  /* host allocation failure or another C++ exception stopped at the ABI boundary */
     BH_ERR_NONFINITE = -8  /* an f16-operand forward produced inf / NaN logits (operand outside the f16 range) */
 } bh_status;
@@ -45,10 +45,21 @@ typedef enum {
 /* ClassifierBuilder::new().model_path().labels_path().top_k().min_confidence()
  * (classifier.rs:269-273) + execution-provider choice (classifier.rs:662-691 -> device). */
 typedef struct {
-    const char *model_path;  /* the model's .onnx file, as ClassifierBuilder::model_path() takes it (classifier.rs:269-283): the conv
-                              * stack is read off the graph inside the library, the front-end comes from the family table keyed by
-                              * the graph's input length (birda_amd/csrc/onnx_conv.hpp); or a BHM1 container (bh_onnx_to_bhm,
-                              * birda_amd/modelfile.py).  Told apart by the file's first bytes. */
+    const char *model_path;  /* the model's .onnx file, as ClassifierBuilder::model_path() takes it (classifier.rs:269-283), or a
+                              * BHM1 container (bh_onnx_to_bhm, birda_amd/modelfile.py); told apart by the file's first bytes.
+                              * THE FRONT-END RULE for an .onnx file: nothing about the model is assumed.  The conv stack is
+                              * read off the graph (birda_amd/csrc/onnx_conv.hpp) and so is the spectrogram front-end in front
+                              * of it (birda_amd/csrc/onnx_frontend.hpp): its nodes are run on probe signals by a float64
+                              * evaluator inside the library, frame length / step, the window x DFT x mel operator, the
+                              * power-law exponent (the LEARNED mag_scale), affine, flip and epsilon are fitted to the
+                              * responses, and the fit is verified against the closed form the kernels compute on random
+                              * audio (<= 2e-5 of the spectrogram's scale).  A graph whose front-end the kernels cannot
+                              * express -- or that uses an operator the evaluator does not run -- is REFUSED (BH_ERR_UNSUPPORTED, the
+                              * message names the operator or the property), never approximated.  Only a graph that starts
+                              * at the spectrogram [N, C, H, W] (no front-end to read) takes the published front-end of its
+                              * family from the table in onnx_conv.hpp; the sample rate, which no graph states, comes from the
+                              * same table keyed by the input length (classifier.rs:360-377).  Cost: ~1-3 s of the create for
+                              * a BirdNET-sized front-end; bh_onnx_to_bhm runs the conversion once, ahead of time. */
     const char *labels_path; /* one label per line; NULL = no labels (logits-only use) */
     uint32_t top_k;          /* DEFAULT_TOP_K = 5, constants.rs:178 */
     float min_confidence;    /* DEFAULT_MIN_CONFIDENCE = 0.1, constants.rs:25 */
@@ -162,6 +173,14 @@ BH_API int bh_classifier_create(const bh_config *cfg, bh_classifier **out);
  * container on disk.  For deployments that convert once and hand the container to every process afterwards (a 437-MB Perch
  * file is parsed and re-laid in ~1 s; the container loads at the disk's rate). */
 BH_API int bh_onnx_to_bhm(const char *onnx_path, const char *bhm_path);
+/* Diagnostic for a file the front-end rule refuses (and the hook the evaluator's own unit tests use): evaluates ONE tensor of
+ * the graph with the library's float64 front-end evaluator.  feed_name (NULL = nothing fed: `target` must be computable from
+ * constants) may be a graph input or ANY intermediate tensor -- only the nodes between it and `target` run; feed is row-major
+ * with feed_rank dims.  out receives at most out_cap values; out_dims (capacity 8) / out_rank the shape.  Returns BH_OK,
+ * BH_ERR_IO for an unreadable file or an operator outside the evaluator's set (named in bh_last_error), BH_ERR_INVALID when
+ * out_cap is too small (out_dims / out_rank are still filled).  Host only, no device. */
+BH_API int bh_onnx_eval(const char *onnx_path, const char *feed_name, const double *feed, const int64_t *feed_dims, uint32_t feed_rank,
+                        const char *target, double *out, size_t out_cap, int64_t *out_dims, uint32_t *out_rank);
 BH_API void bh_classifier_destroy(bh_classifier *c);
 
 /* .config() / .labels() (classifier.rs:360-377) */

@@ -115,6 +115,7 @@ extern "C" {
     pub fn bh_classifier_default_batch_size(c: *const BhClassifier) -> usize;
     pub fn bh_classifier_create(cfg: *const BhConfig, out: *mut *mut BhClassifier) -> c_int;
     pub fn bh_onnx_to_bhm(onnx_path: *const c_char, bhm_path: *const c_char) -> c_int;
+    pub fn bh_onnx_eval(onnx_path: *const c_char, feed_name: *const c_char, feed: *const f64, feed_dims: *const i64, feed_rank: u32, target: *const c_char, out: *mut f64, out_cap: usize, out_dims: *mut i64, out_rank: *mut u32) -> c_int;
     pub fn bh_classifier_destroy(c: *mut BhClassifier);
     pub fn bh_classifier_info(c: *const BhClassifier, info: *mut BhModelInfo) -> c_int;
     pub fn bh_classifier_label(c: *const BhClassifier, index: u32) -> *const c_char;

@@ -32,20 +32,30 @@ def _weights(m, L):
     return m.blob[L.w_off:L.w_off + nw], m.blob[L.b_off:L.b_off + L.cout]
 
 
-def _same_model(a, b):
-    """a: the Python converter's model, b: the library's.  Offsets into the blob may differ; everything they point at may not."""
+def _same_model(a, b, frontend_exact=True):
+    """a: the Python converter's model, b: the library's.  Offsets into the blob may differ; everything they point at may not.
+    frontend_exact=False: b's front-end was READ OFF an audio-input graph by probing (round 5, onnx_frontend.hpp), a's comes from
+    the manifest the graph was written from -- the same front-end to the last few bits of a fit, not bit for bit."""
     for f in ("family", "sample_rate", "sample_count", "n_classes", "embedding_dim", "output_activation", "embedding_tensor", "spec_h", "spec_w"):
         assert getattr(a, f) == getattr(b, f), f
-    assert np.float32(a.segment_duration) == np.float32(b.segment_duration) and np.float32(a.norm_eps) == np.float32(b.norm_eps)
+    assert np.float32(a.segment_duration) == np.float32(b.segment_duration)
+    assert np.float32(a.norm_eps) == np.float32(b.norm_eps) if frontend_exact else b.norm_eps == pytest.approx(a.norm_eps, rel=1e-5)
     assert len(a.branches) == len(b.branches) and len(a.layers) == len(b.layers)
     for x, y in zip(a.branches, b.branches):
-        for f in ("frame_length", "frame_step", "n_mels", "n_frames", "flags"):
+        for f in ("frame_length", "frame_step", "n_mels", "n_frames"):
             assert getattr(x, f) == getattr(y, f), f
-        for f in ("fmin", "fmax", "mag_scale", "out_scale", "out_shift"):
-            assert np.float32(getattr(x, f)) == np.float32(getattr(y, f)), f
         n = x.n_bins * x.n_mels
         wa, wb = a.blob[x.mel_w_off:x.mel_w_off + n], b.blob[y.mel_w_off:y.mel_w_off + n]
-        assert wa.tobytes() == wb.tobytes(), "mel weight matrix differs"      # the C++ restatement of the HTK mel matrix, bit for bit
+        if frontend_exact:
+            for f in ("fmin", "fmax", "mag_scale", "out_scale", "out_shift", "flags"):
+                assert np.float32(getattr(x, f)) == np.float32(getattr(y, f)), f
+            assert wa.tobytes() == wb.tobytes(), "mel weight matrix differs"      # the C++ restatement of the HTK mel matrix, bit for bit
+        else:
+            assert y.mag_scale == pytest.approx(x.mag_scale, abs=1e-5) and (y.out_scale, y.out_shift) == pytest.approx((x.out_scale, x.out_shift), rel=1e-6)
+            wb = wb.reshape(x.n_bins, x.n_mels)
+            if (x.flags ^ y.flags) & 1:          # (the 'fused' spelling folds the flip into the operator: columns reversed, no flag)
+                wb = wb[:, ::-1]
+            assert np.abs(wa.reshape(x.n_bins, x.n_mels) - wb).max() < 1e-6
     for i, (x, y) in enumerate(zip(a.layers, b.layers)):
         for f in ("op", "act", "in_tensor", "res_tensor", "cin", "cout", "kh", "kw", "sh", "sw", "pad_t", "pad_l", "in_h", "in_w", "out_h",
                   "out_w", "in_layout"):
@@ -60,8 +70,9 @@ def _same_model(a, b):
                                                 ("birdnet_v24_tiny", "erf", "conv1d"), ("perch_v2_tiny", "erf", None),
                                                 ("birdnet_v24", "erf", None)])
 def test_native_graph_walk_matches_the_python_converter(tmp_path, kind, gelu, frontend):
-    """Graphs written by the repo's own writer, starting at the spectrogram or -- like the published files -- at the audio input
-    (four front-end spellings: the native route skips those nodes and takes the family's front-end from its table)."""
+    """Graphs written by the repo's own writer, starting at the spectrogram (front-end: the family table, bit for bit the Python
+    converter's manifest) or -- like the published files -- at the audio input (four spellings: the native route reads the
+    front-end off the graph by probing, tests/test_onnx_frontend.py; the conv stack behind it bit for bit all the same)."""
     m = synth.build_model(kind)
     g = convert.graph_from_model(m, spell_gelu=gelu, frontend_spelling=frontend)
     data = ox.dump(g)
@@ -70,7 +81,7 @@ def test_native_graph_walk_matches_the_python_converter(tmp_path, kind, gelu, fr
         f.write(data)
     want = convert.model_from_graph(ox.load(data), m, "spectrogram" if frontend else None)
     got = _native(onnx_path, str(tmp_path / "native.bhm"))
-    _same_model(want, got)
+    _same_model(want, got, frontend_exact=frontend is None)
     # ... and both are the model the graph was written from (activations, residuals, squeeze-excite gates back in place)
     assert [(L.op, L.act, L.res_tensor) for L in got.layers] == [(L.op, L.act, L.res_tensor) for L in m.layers]
 
@@ -202,7 +213,8 @@ def test_batchnorm_that_cannot_be_folded_is_refused(tmp_path):
 @pytest.mark.parametrize("kind,frontend", [("birdnet_v24", "conv1d"), ("perch_v2", None), ("mini_se", None), ("birdnet_v30", None)])
 def test_classifier_created_on_the_onnx_file_gives_the_bhm_route_logits(tmp_path, kind, frontend):
     """bh_classifier_create("x.onnx") against the BHM1 container the Python converter writes from the same file: logits bit for
-    bit, in the split-f16 default and on the f32 kernels.  birdnet_v24 with the audio-input spelling (what the published file
+    bit for graphs that start at the spectrogram, within 2e-5 of the logit scale for the audio-input spelling (its front-end is
+    read off the graph by probing: the mel matrix is a fit, equal to the manifest's to ~1e-8), in the split-f16 default and on the f32 kernels.  birdnet_v24 with the audio-input spelling (what the published file
     is), perch_v2 at its published size (437 MB), a squeeze-excite stack, and the v3.0 contract (sigmoid inside the graph)."""
     from birda_amd.classifier import BirdClassifier
     m = synth.build_model(kind)
@@ -222,4 +234,8 @@ def test_classifier_created_on_the_onnx_file_gives_the_bhm_route_logits(tmp_path
             out[route] = (clf.predict_logits(ctx, segs), clf.fused_blocks())
             ctx.close(); clf.close()
         assert out["onnx"][1] == out["bhm"][1]
-        assert np.isfinite(out["onnx"][0]).all() and (out["onnx"][0] == out["bhm"][0]).all(), (kind, prec)
+        assert np.isfinite(out["onnx"][0]).all()
+        if frontend is None:
+            assert (out["onnx"][0] == out["bhm"][0]).all(), (kind, prec)
+        else:
+            assert np.abs(out["onnx"][0] - out["bhm"][0]).max() <= 2e-5 * max(1.0, float(np.abs(out["bhm"][0]).max())), (kind, prec)
