@@ -65,7 +65,9 @@ inline bool validate_model(Model &m, std::string &err) {
     m.tensor_floats[0] = (uint64_t)m.h.n_branches * m.h.spec_h * m.h.spec_w;
     for (uint32_t i = 0; i < m.h.n_layers; i++) {
         const auto &L = m.layers[i];
-        if (L.cin == 0 || L.cout == 0 || L.cin > (1u << 16) || L.cout > (1u << 24) || L.kh == 0 || L.kw == 0 || L.kh > 64 || L.kw > 64 ||
+        // (a global pool's "kernel" is its whole input image -- the squeeze of a squeeze-excite gate in an early block pools 64 x 249)
+        const uint32_t kmax = L.op == OP_GAP ? (1u << 16) : 64;
+        if (L.cin == 0 || L.cout == 0 || L.cin > (1u << 16) || L.cout > (1u << 24) || L.kh == 0 || L.kw == 0 || L.kh > kmax || L.kw > kmax ||
             L.sh == 0 || L.sw == 0 || L.sh > 16 || L.sw > 16 || L.pad_t > 64 || L.pad_l > 64 || L.in_h == 0 || L.in_w == 0 || L.out_h == 0 ||
             L.out_w == 0 || L.in_h > (1u << 16) || L.in_w > (1u << 16) || L.out_h > (1u << 16) || L.out_w > (1u << 16) ||
             (uint64_t)L.out_h * L.out_w * L.cout > (1ull << 31) || (uint64_t)L.in_h * L.in_w * L.cin > (1ull << 31)) {
