@@ -599,7 +599,7 @@ def main():
         else:
             clf.forward_device(ctx, src_ptr, n_local, logits.data_ptr(), tk_idx.data_ptr(), tk_conf.data_ptr())
 
-    def step():
+    def local_step():
         if args.config == "c5":
             off = 0
             for g in groups:     # decode_and_stream's resample_chunk + resize per segment (processor.rs:84-87), on the context stream
@@ -609,6 +609,9 @@ def main():
             forward_all(x48.data_ptr())
         else:
             forward_all(x.data_ptr())
+
+    def step():
+        local_step()
         if world > 1:
             cur = torch.cuda.current_stream()
             if ctx_stream is not None:
@@ -650,8 +653,8 @@ def main():
     # the --warmup steps follow as the contract says.
     clf.ensure_warm(min(n_local, args.micro_batch))
     t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < PRE_WARM_S:
-        step()
+    while time.perf_counter() - t_pre < PRE_WARM_S:      # (time-bounded, so rank-LOCAL work only: the forwards, no collective)
+        local_step()
         ctx.synchronize()
     for _ in range(args.warmup):
         step()

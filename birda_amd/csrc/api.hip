@@ -105,7 +105,7 @@ int ctx_create(bh_classifier *c, size_t max_batch, bool keep, bh_batch_context *
     HIPCHK(hipMalloc((void **)&ctx->d_input, in_bytes));
     HIPCHK(hipMalloc((void **)&ctx->d_minmax, max_batch * 16 * sizeof(float)));
     HIPCHK(hipMalloc((void **)&ctx->d_inbad, max_batch * 8 * sizeof(unsigned)));
-    plan_arena(m, c->fused_at, c->head_gap, max_batch, keep, ctx->t_off, ctx->arena_floats);
+    plan_arena(m, c->fused_at, c->se, c->head_gap, max_batch, keep, ctx->t_off, ctx->arena_floats);
     // (slack for the lanes: the plans of a slice's sub-slices, side by side, exceed the whole slice's plan by up to 64 floats of
     //  alignment per tensor and sub-plan; the automatic split makes up to 9 sub-slices, bh_batch_context_set_sub_slices more --
     //  16 sub-plans fit, beyond that lanes_begin falls back to one stream and counts it: bh_batch_context_lane_fallbacks)
@@ -200,6 +200,34 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
             const bh::MbDesc &twin = c->mb_small[c->fused_at[i]], &narrow = c->mb_narrow[c->fused_at[i]];
             bh::MbDesc d = (narrow.cfg >= 0 && n * (size_t)narrow.tiles_x <= (size_t)c->narrow_max_workgroups) ? narrow
                          : (twin.cfg >= 0 && n <= (size_t)c->twin_max_segments) ? twin : c->mb[c->fused_at[i]];
+            if (d.se) {
+                // A squeeze-excite block in three launches: pass A (expand -> depthwise: D and the per-tile channel sums), the gate
+                // (pool -> 1x1 -> 1x1), the project GEMM on D x gate (+ residual).  The expanded tensor stays in LDS, the scaled one
+                // never exists; D crosses HBM once each way.
+                const auto &S = c->se[c->fused_at[i]];
+                const auto &G1 = m.layers[S.iPw1], &G2 = m.layers[S.iPw2], &LP = m.layers[S.iP];
+                d.X = in;
+                d.Dout = T(S.iD + 1);
+                d.pool_part = T(S.iScale + 1);
+                bh::launch_mbconv(d, (int)n, s);
+                ctx_mark(ctx, ST_MBCONV, (int)i);
+                float *gate = T(S.iPw2 + 1);
+                const int P = d.Ho * d.Wo;
+                bh::launch_se_gate(d.pool_part, d.tiles_x * d.tiles_y, P, c->d_w[S.iPw1], c->d_blob + G1.b_off, c->ldw[S.iPw1], (int)G1.act,
+                                   c->d_w[S.iPw2], c->d_blob + G2.b_off, c->ldw[S.iPw2], (int)G2.act, gate, (int)n, d.Cexp, (int)G1.cout, s);
+                ctx_mark(ctx, ST_GAP, (int)S.iGap);
+                float *y = (S.iP == nl - 1) ? d_logits : T(S.iP + 1);
+                const float *r = LP.res_tensor != bh::NO_TENSOR ? T(LP.res_tensor) : nullptr;
+                if (c->d_w16[S.iP])
+                    bh::launch_pw_gemm16_gated(d.Dout, gate, P, c->d_w16[S.iP], c->d_blob + LP.b_off, r, y, (int)(n * (size_t)P), d.Cexp, d.Cout,
+                                               c->precision == 3 ? 3 : 1, c->w16_unscale[S.iP], s);
+                else
+                    bh::launch_pw_gemm_gated(d.Dout, gate, P, c->d_w[S.iP], c->d_blob + LP.b_off, r, y, (int)(n * (size_t)P), d.Cexp, d.Cout,
+                                             c->ldw[S.iP], (int)LP.act, s);
+                ctx_mark(ctx, ST_PW, (int)S.iP);
+                i = S.iP;
+                continue;
+            }
             const size_t ip = d.noexp ? i + 1 : i + 2;   // the project layer
             const auto &LP = m.layers[ip];
             d.X = in;
@@ -493,7 +521,7 @@ bool lanes_begin(bh_classifier *c, bh_batch_context *ctx, const std::vector<size
         auto it = ctx->plans.find(ns);
         if (it == ctx->plans.end()) {
             bh_batch_context::ArenaPlan p;
-            plan_arena(c->model, c->fused_at, c->head_gap, ns, false, p.t_off, p.total);
+            plan_arena(c->model, c->fused_at, c->se, c->head_gap, ns, false, p.t_off, p.total);
             it = ctx->plans.emplace(ns, std::move(p)).first;
         }
         if (base + it->second.total > ctx->arena_cap) { lanes.clear(); ctx->lane_fallbacks++; return false; }
@@ -870,28 +898,37 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) try {
     c->d_w16.assign(m.layers.size(), nullptr);
     c->w16_unscale.assign(m.layers.size(), 1.0f);
     if (c->precision != 0) {
-        std::vector<char> in_block(m.layers.size(), 0);
+        std::vector<char> in_block(m.layers.size(), 0), se_project(m.layers.size(), 0);
         for (size_t i = 0; i < m.layers.size(); i++)
+            if (c->fused_at[i] >= 0 && c->se[c->fused_at[i]].iP != 0) {
+                // a squeeze-excite block: its gate layers run in se_gate_kernel (f32 weights as they are), its project convolution
+                // on the gated GEMM, which takes planes of ANY K % 4 == 0 (zero-padded to whole 32-deep steps)
+                const auto &S = c->se[c->fused_at[i]];
+                for (size_t k = i; k < S.iP; k++) in_block[k] = 1;
+                se_project[S.iP] = 1;
+            } else
             if (c->fused_at[i] >= 0) {
                 in_block[i] = in_block[i + 1] = 1;
                 if (!c->mb[c->fused_at[i]].noexp) in_block[i + 2] = 1;
             }
         for (size_t i = 0; i < m.layers.size(); i++) {
             const auto &L = m.layers[i];
-            if (in_block[i] || (L.op != bh::OP_PWCONV && L.op != bh::OP_DENSE) || !bh::pw_gemm16_supports((int)L.cin, (int)L.act)) continue;
+            if (in_block[i] || (L.op != bh::OP_PWCONV && L.op != bh::OP_DENSE)) continue;
+            if (!(se_project[i] ? (L.cin % 4 == 0 && L.act == bh::ACT_NONE) : bh::pw_gemm16_supports((int)L.cin, (int)L.act))) continue;
             const int K = (int)L.cin, N = (int)L.cout, nt = (N + 15) / 16;
-            std::vector<uint16_t> planes((size_t)(K / 32) * nt * 2 * 64 * 8, 0);
+            const int ksteps = (K + 31) / 32;
+            std::vector<uint16_t> planes((size_t)ksteps * nt * 2 * 64 * 8, 0);
             const float *W = m.blob.data() + L.w_off;
             float wmax = 0.0f;
             for (size_t q = 0; q < (size_t)K * N; q++) wmax = std::max(wmax, std::fabs(W[q]));
             const int ws = bh::f16_scale_exponent(wmax);
             c->w16_unscale[i] = std::ldexp(1.0f, -ws);
-            for (int st = 0; st < K / 32; st++)
+            for (int st = 0; st < ksteps; st++)
                 for (int t = 0; t < nt; t++)
                     for (int lane = 0; lane < 64; lane++)
                         for (int jj = 0; jj < 8; jj++) {
                             const int k = 32 * st + 8 * (lane >> 4) + jj, n = 16 * t + (lane & 15);
-                            const float v = n < N ? std::ldexp(W[(size_t)k * N + n], ws) : 0.0f;
+                            const float v = (n < N && k < K) ? std::ldexp(W[(size_t)k * N + n], ws) : 0.0f;
                             const uint16_t hi = f32_to_f16(v);
                             const size_t base = (((size_t)st * nt + t) * 2) * 64 * 8;
                             planes[base + (size_t)lane * 8 + jj] = hi;

@@ -73,6 +73,10 @@ struct bh_classifier {
     int twin_max_segments = 256;             // launches up to this size take the twins (one workgroup per CU at most either way)
     std::vector<bh::MbDesc> mb_small;        // per block: its small-launch twin (cfg < 0: none), same weights (mb_plan_twin)
     std::vector<bh::MbDesc> mb_narrow;       // per block: its few-segment twin on narrow tiles (cfg < 0: none), same weights (mb_plan_narrow)
+    // per block: the layers of a squeeze-excite block (MbDesc::se; iP == 0: a plain block) and the floats per segment of its per-tile
+    // channel sums, which live in the arena slot of the (never materialised) OP_SCALE output
+    struct SeInfo { uint32_t iD = 0, iGap = 0, iPw1 = 0, iPw2 = 0, iScale = 0, iP = 0; size_t part_floats = 0; };
+    std::vector<SeInfo> se;
     int narrow_max_workgroups = 512;         // launches whose narrow tiles number at most this take them (measured: tools/gpu_latency.py)
     int precision = 0;                       // GEMM operands of the fused blocks: 0 f32, 3 f16 hi/lo split, 1 f16
     // BH_FLAG_AUTO (the default): split-f16 compute, and a row whose logits come out inf / NaN from finite samples (an activation
@@ -182,7 +186,7 @@ namespace bhi {
 uint16_t f32_to_f16(float f);
 float f16_to_f32(uint16_t h);
 std::vector<float> build_gf(const bh::BranchRec &b, const float *W, int nm_pad, int prec, int *scale_exp);
-void plan_arena(const bh::Model &m, const std::vector<int> &fused_at, const std::vector<char> &head_gap, size_t max_batch,
+void plan_arena(const bh::Model &m, const std::vector<int> &fused_at, const std::vector<bh_classifier::SeInfo> &se, const std::vector<char> &head_gap, size_t max_batch,
                 bool keep, std::vector<size_t> &off, size_t &total);
 bool describe_fused_block(const bh::Model &m, const std::vector<int> &readers, size_t i, int precision, int force_cfg, bh::MbDesc &d);
 std::vector<int> tensor_readers(const bh::Model &m);

@@ -92,7 +92,7 @@ std::vector<float> build_gf(const bh::BranchRec &b, const float *W, int nm_pad, 
 }
 // liveness-based arena plan: tensor t is born at step t (tensor 0 = front-end) and dies after
 // the last layer that reads it; the embedding tensor and the logits live to the end.
-void plan_arena(const bh::Model &m, const std::vector<int> &fused_at, const std::vector<char> &head_gap, size_t max_batch,
+void plan_arena(const bh::Model &m, const std::vector<int> &fused_at, const std::vector<bh_classifier::SeInfo> &se, const std::vector<char> &head_gap, size_t max_batch,
                 bool keep, std::vector<size_t> &off, size_t &total) {
     const size_t nt = m.layers.size() + 1;
     std::vector<size_t> last(nt, 0), sz(nt);
@@ -103,7 +103,22 @@ void plan_arena(const bh::Model &m, const std::vector<int> &fused_at, const std:
         if (L.res_tensor != bh::NO_TENSOR) last[L.res_tensor] = std::max(last[L.res_tensor], i + 1);
     }
     if (!keep)
-        for (size_t i = 0; i < fused_at.size(); i++)
+        for (size_t i = 0; i < fused_at.size(); i++) {
+            if (fused_at[i] >= 0 && (size_t)fused_at[i] < se.size() && se[fused_at[i]].iP != 0) {
+                // a squeeze-excite block = pass A (reads the block input; writes the depthwise output D and, into the slot of the
+                // OP_SCALE output, the per-tile channel sums), the gate launch (sums -> gate tensor) and the gated project GEMM
+                // (D, gate, residual -> the block output) at the project layer's step.  Everything those launches touch stays
+                // live until that step: the planner gives a tensor its bytes at the step its LAYER would have written it, and the
+                // sums are written earlier than that (with pass A) -- the block input must not have been handed on by then.
+                const auto &S = se[fused_at[i]];
+                const size_t end = (size_t)S.iP + 1;
+                last[m.layers[i].in_tensor] = std::max(last[m.layers[i].in_tensor], end);
+                last[S.iD + 1] = std::max(last[S.iD + 1], end);
+                last[S.iPw2 + 1] = std::max(last[S.iPw2 + 1], end);
+                last[S.iScale + 1] = std::max(last[S.iScale + 1], end);
+                if (S.iD != i) sz[i + 1] = 0;                                  // the expanded tensor stays in LDS
+                sz[S.iScale + 1] = align_up(S.part_floats * max_batch, 64);  // the scaled tensor never exists
+            } else
             if (fused_at[i] >= 0) {
                 // one launch reads the block input while it writes the block's last tensor (i + 3; i + 2 for a block without an
                 // expand convolution: depthwise -> project); the tensors in between stay in LDS and take no arena space
@@ -111,6 +126,7 @@ void plan_arena(const bh::Model &m, const std::vector<int> &fused_at, const std:
                 last[m.layers[i].in_tensor] = std::max(last[m.layers[i].in_tensor], i + len);
                 for (size_t k = 1; k < len; k++) sz[i + k] = 0;
             }
+        }
     if (!keep)
         for (size_t i = 0; i + 1 < head_gap.size(); i++)
             if (head_gap[i]) {
@@ -177,8 +193,65 @@ float f16_to_f32(uint16_t h) {
 // The block that starts at layer i as a fused launch: expand(1x1, or the stem conv) -> depthwise -> project(1x1) whose
 // intermediates have no other reader, described and handed to the tile planner.  Host logic only (no device): plan_fusion uses
 // it per block at create, bh_plan_fused_blocks walks a model file with it.
+// The squeeze-excite block that starts at layer i, if there is one: [expand 1x1 | stem conv] -> depthwise -> GlobalAveragePool ->
+// 1x1 (C -> Cr) -> 1x1 (Cr -> C) -> OP_SCALE (depthwise output x gate) -> project 1x1, the depthwise output read by the pool and
+// the scale only, every other intermediate by its successor only (EfficientNet's MBConv as tf2onnx / torch exporters spell it:
+// onnx_conv.hpp, convert.py).
+bool match_se_block(const bh::Model &m, const std::vector<int> &readers, size_t i, bh_classifier::SeInfo &S, bool &noexp) {
+    const size_t nl = m.layers.size();
+    noexp = m.layers[i].op == bh::OP_DWCONV;
+    const size_t iD = noexp ? i : i + 1;
+    if (iD + 5 >= nl) return false;
+    const auto &D = m.layers[iD], &G = m.layers[iD + 1], &A1 = m.layers[iD + 2], &A2 = m.layers[iD + 3], &SC = m.layers[iD + 4], &P = m.layers[iD + 5];
+    if (D.op != bh::OP_DWCONV || G.op != bh::OP_GAP || A1.op != bh::OP_PWCONV || A2.op != bh::OP_PWCONV || SC.op != bh::OP_SCALE || P.op != bh::OP_PWCONV) return false;
+    const uint32_t tD = (uint32_t)iD + 1;   // the depthwise output tensor
+    if (G.in_tensor != tD || A1.in_tensor != iD + 2 || A2.in_tensor != iD + 3 || SC.in_tensor != tD || SC.res_tensor != iD + 4 || P.in_tensor != iD + 5) return false;
+    if (readers[tD] != 2 || readers[iD + 2] != 1 || readers[iD + 3] != 1 || readers[iD + 4] != 1 || readers[iD + 5] != 1) return false;
+    if (!noexp && (m.layers[i + 1].in_tensor != i + 1 || readers[i + 1] != 1)) return false;
+    if (G.res_tensor != bh::NO_TENSOR || A1.res_tensor != bh::NO_TENSOR || A2.res_tensor != bh::NO_TENSOR || D.res_tensor != bh::NO_TENSOR) return false;
+    if (A1.in_h * A1.in_w != 1 || A2.in_h * A2.in_w != 1 || A1.cin != D.cout || A2.cout != D.cout || A1.cout != A2.cin || P.cin != D.cout) return false;
+    if (!bh::se_gate_supports((int)D.cout, (int)A1.cout)) return false;
+    S = bh_classifier::SeInfo{};
+    S.iD = (uint32_t)iD; S.iGap = (uint32_t)iD + 1; S.iPw1 = (uint32_t)iD + 2; S.iPw2 = (uint32_t)iD + 3; S.iScale = (uint32_t)iD + 4; S.iP = (uint32_t)iD + 5;
+    return true;
+}
+
 bool describe_fused_block(const bh::Model &m, const std::vector<int> &readers, size_t i, int precision, int force_cfg, bh::MbDesc &d) {
     const size_t nl = m.layers.size();
+    {
+        bh_classifier::SeInfo S;
+        bool noexp = false;
+        static const bool se_off = [] { const char *e = getenv("BIRDA_HIP_FUSE_SE"); return e && e[0] == '0'; }();
+        if (!se_off && match_se_block(m, readers, i, S, noexp)) {
+            const auto &E = m.layers[i], &D = m.layers[S.iD], &P = m.layers[S.iP];
+            const bool stem = !noexp && E.op == bh::OP_CONV && E.in_layout == 1 && E.kh == E.kw && E.sh == E.sw && E.in_tensor == 0;
+            if (!noexp && E.op != bh::OP_PWCONV && !stem) return false;
+            if (!noexp && E.res_tensor != bh::NO_TENSOR) return false;
+            if (D.kh != D.kw || D.sh != D.sw || (!noexp && E.cout != D.cout) || D.in_layout != 0) return false;
+            // (the gated project GEMM has no activation on the f16 MFMA; project convolutions of MBConv blocks have none)
+            if (P.act != bh::ACT_NONE) return false;
+            d = bh::MbDesc{};
+            d.se = 1;
+            d.noexp = noexp ? 1 : 0;
+            d.H = (int)(noexp ? D.in_h : E.in_h); d.W = (int)(noexp ? D.in_w : E.in_w);
+            d.Cin = (int)(noexp ? D.cout : E.cin); d.Cexp = (int)D.cout; d.Cout = (int)P.cout;
+            if (stem) {
+                d.stem = 1; d.stem_c = (int)E.cin; d.stem_h = (int)E.in_h; d.stem_w = (int)E.in_w; d.stem_k = (int)E.kh;
+                d.stem_s = (int)E.sh; d.stem_pt = (int)E.pad_t; d.stem_pl = (int)E.pad_l;
+                d.H = (int)E.out_h; d.W = (int)E.out_w; d.Cin = (int)(E.kh * E.kw * E.cin);
+            }
+            d.Ho = (int)D.out_h; d.Wo = (int)D.out_w; d.pad_t = (int)D.pad_t; d.pad_l = (int)D.pad_l;
+            d.KS = (int)D.kh; d.ST = (int)D.sh;
+            d.act_e = (int)(noexp ? D.act : E.act); d.act_d = (int)D.act; d.act_p = (int)P.act;
+            d.prec = precision;
+            if (!bh::mb_plan(d, force_cfg)) {
+                if (d.prec == 0) return false;
+                d.prec = 0;
+                if (!bh::mb_plan(d, force_cfg)) return false;
+            }
+            return true;
+        }
+    }
     if (i + 1 < nl && m.layers[i].op == bh::OP_DWCONV && m.layers[i + 1].op == bh::OP_PWCONV) {
         // depthwise -> project (+ residual) WITHOUT an expand convolution (the expand-ratio-1 blocks of EfficientNet after the
         // first): fused with the block input standing in for the expanded tensor (MbDesc::noexp)
@@ -254,7 +327,9 @@ int plan_fusion(bh_classifier *c) {
         bh::MbDesc d{};
         if (!describe_fused_block(m, readers, i, c->precision, force_cfg, d)) continue;
         // (a no-expand block is layers i = depthwise, i + 1 = project; E then only lends the code below a valid layer to name)
-        const auto &E = m.layers[i], &D = m.layers[d.noexp ? i : i + 1], &P = m.layers[d.noexp ? i + 1 : i + 2];
+        bh_classifier::SeInfo S;
+        if (d.se) { bool ne = false; if (!match_se_block(m, readers, i, S, ne)) continue; }
+        const auto &E = m.layers[i], &D = m.layers[d.noexp ? i : i + 1], &P = m.layers[d.se ? S.iP : d.noexp ? i + 1 : i + 2];
         // per-chunk weight blocks (kernels.hpp MbDesc)
         const int CE = d.CE, NTE = CE / 16, KG = d.KG, NTOP = d.NTOP, nch = d.nchunks, KK = d.KS * d.KS;
         const float *We = m.blob.data() + E.w_off, *Wp = m.blob.data() + P.w_off, *Wd = m.blob.data() + D.w_off;
@@ -399,7 +474,14 @@ int plan_fusion(bh_classifier *c) {
             nw.cfg = -1;
             if (!(force_cfg < 0 && !no_twin && bh::mb_plan_narrow(d, nw))) nw.cfg = -1;
             c->mb_narrow.push_back(nw);
+            // (squeeze-excite: the slot of the per-tile channel sums holds whichever of the three tilings has the most tiles)
+            size_t tiles = (size_t)d.tiles_x * d.tiles_y;
+            if (c->mb_small.back().cfg >= 0) tiles = std::max(tiles, (size_t)c->mb_small.back().tiles_x * c->mb_small.back().tiles_y);
+            if (nw.cfg >= 0) tiles = std::max(tiles, (size_t)nw.tiles_x * nw.tiles_y);
+            S.part_floats = d.se ? tiles * (size_t)d.Cexp : 0;
+            c->se.push_back(d.se ? S : bh_classifier::SeInfo{});
         }
+        if (d.se) { i = S.iP; continue; }
         i += d.noexp ? 1 : 2;
     }
     return BH_OK;

@@ -375,6 +375,17 @@ void launch_pw_gemm(const float *A, const float *W, const float *bias, const flo
 bool pw_gemm16_supports(int K, int act);
 void launch_pw_gemm16(const float *A, const void *Wf, const float *bias, const float *R, float *C, int M, int K, int N,
                       int act, int terms, float w_unscale, hipStream_t s);
+// squeeze-excite blocks (round 5): the project convolution with A = D x gate (gate [M / rows_per_seg][K]; nullptr: plain) ...
+void launch_pw_gemm_gated(const float *A, const float *gate, int rows_per_seg, const float *W, const float *bias, const float *R,
+                          float *C, int M, int K, int N, int ldw, int act, hipStream_t s);
+// ... on the f16 MFMA (no activation; K % 4 == 0, planes [ceil(K / 32)][ceil(N / 16)]{hi, lo}[64][8] zero-padded in K) ...
+void launch_pw_gemm16_gated(const float *A, const float *gate, int rows_per_seg, const void *Wf, const float *bias, const float *R,
+                            float *C, int M, int K, int N, int terms, float w_unscale, hipStream_t s);
+// ... and the gate itself: pool (from the per-tile channel sums of mbconv pass A, part [n][tiles][C]) -> 1x1 (C -> Cr, act1) -> 1x1
+// (Cr -> C, act2), one launch, fixed summation order
+bool se_gate_supports(int C, int Cr);
+void launch_se_gate(const float *part, int tiles, int P, const float *W1, const float *b1, int ld1, int act1, const float *W2, const float *b2,
+                    int ld2, int act2, float *gate, int n_seg, int C, int Cr, hipStream_t s);
 // global average pool [n][P][C] -> [n][C]
 void launch_gap(const float *in, float *out, int n_seg, int P, int C, hipStream_t s);
 // squeeze-excite gate: out[n][p][c] = in[n][p][c] * gate[n][c]   (C % 4 == 0)
@@ -458,6 +469,14 @@ struct MbDesc {
     int cfg, CE, TH, S, tiles_y, tiles_x, IH, IW, KG, nchunks, NTOP, mpad_max;
     int ring;  // 1: the chunk weights go through rings of LDS buffers (We x 2, Wp x 3, Wd x 2), refilled a whole chunk ahead
     size_t lds_bytes;
+    // Squeeze-excite blocks (round 5; EfficientNet's gate between the depthwise and the project convolution: pool -> 1x1 -> act ->
+    // 1x1 -> sigmoid -> scale).  The gate needs the pool of the WHOLE depthwise output, so the block runs as pass A (se = 1: this
+    // kernel's expand and depthwise phases -- the depthwise output D goes to HBM once, NHWC [n][Ho][Wo][Cexp] at Dout, and every
+    // workgroup leaves the per-channel sums of its tile's pixels in pool_part [n][tiles_y * tiles_x][Cexp]; no project GEMM),
+    // se_gate_kernel (the partial sums in fixed order, the two dense layers) and a project GEMM whose A operand is D times the
+    // gate (launch_pw_gemm*_gated, kernels_conv.hip).  The expanded tensor still never leaves the CU.
+    int se;
+    float *Dout, *pool_part;
 };
 int mb_config_count();
 int mb_config_name(int ci, char *out, size_t cap);

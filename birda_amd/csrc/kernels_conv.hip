@@ -24,10 +24,13 @@ __device__ __forceinline__ float act_apply(float v, int act) { return act_apply_
 // ---------------------------------------------------------------------------------------
 constexpr int PW_BK = 32;
 
-template <int BM, int NT>
+// GATE (round 5, squeeze-excite blocks): A is the depthwise output D [n][P][K] and every element is multiplied by its segment's
+// gate[n][K] on the way into LDS -- the ONNX Mul between the depthwise and the project convolution, without a pass of its own.
+template <int BM, int NT, bool GATE = false>
 __global__ __launch_bounds__(256) void pw_gemm_kernel(const float *__restrict__ A, const float *__restrict__ W,
                                                        const float *__restrict__ bias, const float *__restrict__ R,
-                                                       float *__restrict__ C, int M, int K, int N, int ldw, int act) {
+                                                       float *__restrict__ C, int M, int K, int N, int ldw, int act,
+                                                       const float *__restrict__ gate = nullptr, int rows_per_seg = 1) {
     constexpr int BN = NT * 16;
     constexpr int WM = BM / 4;
     constexpr int MT = WM / 16;
@@ -43,6 +46,11 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float *__restrict__ 
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
 
     float4 pa[A4], pb[B4];
+    const float *grow[GATE ? A4 : 1];    // GATE: the gate row of each of this thread's A rows
+    if constexpr (GATE) {
+#pragma unroll
+        for (int i = 0; i < A4; i++) grow[i] = gate + (size_t)(min(m0 + ((tid + 256 * i) >> 3), M - 1) / rows_per_seg) * K;
+    }
     auto load_chunk = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < A4; i++) {
@@ -51,6 +59,10 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float *__restrict__ 
             const int gm = m0 + row, gk = k0 + kc;
             pa[i] = (gm < M && gk < K) ? *reinterpret_cast<const float4 *>(A + (size_t)gm * K + gk)
                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (GATE) {
+                const float4 g = gk < K ? *reinterpret_cast<const float4 *>(grow[i] + gk) : make_float4(0.f, 0.f, 0.f, 0.f);
+                pa[i].x *= g.x; pa[i].y *= g.y; pa[i].z *= g.z; pa[i].w *= g.w;
+            }
         }
 #pragma unroll
         for (int i = 0; i < B4; i++) {
@@ -141,9 +153,10 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float *__restrict__ 
 
 template <int BM, int NT>
 static void pw_launch(const float *A, const float *W, const float *bias, const float *R, float *C, int M, int K,
-                      int N, int ldw, int act, hipStream_t s) {
+                      int N, int ldw, int act, hipStream_t s, const float *gate = nullptr, int rows_per_seg = 1) {
     dim3 grid((N + NT * 16 - 1) / (NT * 16), (M + BM - 1) / BM), block(256);
-    hipLaunchKernelGGL((pw_gemm_kernel<BM, NT>), grid, block, 0, s, A, W, bias, R, C, M, K, N, ldw, act);
+    if (gate) hipLaunchKernelGGL((pw_gemm_kernel<BM, NT, true>), grid, block, 0, s, A, W, bias, R, C, M, K, N, ldw, act, gate, rows_per_seg);
+    else hipLaunchKernelGGL((pw_gemm_kernel<BM, NT, false>), grid, block, 0, s, A, W, bias, R, C, M, K, N, ldw, act, nullptr, 1);
 }
 
 // pick the widest column tile that wastes the fewest padded columns
@@ -160,13 +173,19 @@ static int pick_nt(int N) {
 
 void launch_pw_gemm(const float *A, const float *W, const float *bias, const float *R, float *C, int M, int K,
                     int N, int ldw, int act, hipStream_t s) {
+    launch_pw_gemm_gated(A, nullptr, 1, W, bias, R, C, M, K, N, ldw, act, s);
+}
+
+// the same GEMM with A = D x gate (gate [M / rows_per_seg][K], nullptr: plain): the project convolution of a squeeze-excite block
+void launch_pw_gemm_gated(const float *A, const float *gate, int rows_per_seg, const float *W, const float *bias, const float *R,
+                          float *C, int M, int K, int N, int ldw, int act, hipStream_t s) {
     const int nt = pick_nt(N);
     const long blocks128 = (long)((M + 127) / 128) * ((N + nt * 16 - 1) / (nt * 16));
     const bool small = blocks128 < 512;  // keep >= 2 blocks per CU in flight when M is short
 #define BH_PW_CASE(NTV)                                                                    \
     case NTV:                                                                              \
-        if (small) pw_launch<64, NTV>(A, W, bias, R, C, M, K, N, ldw, act, s);             \
-        else pw_launch<128, NTV>(A, W, bias, R, C, M, K, N, ldw, act, s);                  \
+        if (small) pw_launch<64, NTV>(A, W, bias, R, C, M, K, N, ldw, act, s, gate, rows_per_seg);             \
+        else pw_launch<128, NTV>(A, W, bias, R, C, M, K, N, ldw, act, s, gate, rows_per_seg);                  \
         break;
     switch (nt) {
         BH_PW_CASE(1) BH_PW_CASE(2) BH_PW_CASE(3) BH_PW_CASE(4)
@@ -291,47 +310,77 @@ __global__ __launch_bounds__(256) void pw_gemm16_kernel(const float *__restrict_
 // s + 1 is loaded while step s computes, one barrier per step.  32 KB of L2 traffic per workgroup-step instead of 64, and the
 // waves read 16 KB each from LDS (85 B/clk per workgroup, two per CU).
 // ---------------------------------------------------------------------------------------
-template <int TERMS, int ACT>
+// GATE (round 5): the project convolution of a squeeze-excite block -- A is the depthwise output D [n][P][K], multiplied by its
+// segment's gate[n][K] in registers before the f16 split (the graph's Mul, without a pass of its own), and K may be any multiple
+// of 4 (the expanded widths of EfficientNet stacks: 144, 816, 1 392 ...): the last 32-deep step loads zeros beyond K, the planes
+// are zero-padded on the host.
+template <int TERMS, int ACT, bool GATE = false>
 __global__ __launch_bounds__(256, 2) void pw_gemm16s_kernel(const float *__restrict__ A, const f16x8 *__restrict__ Wf,
                                                             const float *__restrict__ bias, const float *__restrict__ R,
-                                                            float *__restrict__ C, int M, int K, int N, int n_tiles, float w_unscale) {
+                                                            float *__restrict__ C, int M, int K, int N, int n_tiles, float w_unscale,
+                                                            const float *__restrict__ gate = nullptr, int rows_per_seg = 1) {
     extern __shared__ __attribute__((aligned(16))) float gsm[];   // [2 stages]{A: [8 row tiles]{hi, lo}[64 lanes][4], B: [8 column tiles]{hi, lo}[64][4]}
     constexpr int STAGE = 2 * 8 * 2 * 256;                        // floats per stage (32 KB)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
     const int n_xb = (n_tiles + 7) / 8, n_yb = (M + 127) / 128;   // (block order: see pw_gemm16_kernel)
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int yb = slot % n_yb, xb = (slot / n_yb) * 8 + xcd;
-    if (xb >= n_xb) return;
+    int yb, xb;
+    if constexpr (GATE) {
+        // few column blocks (a project convolution: N = 24 .. 384) and very many row blocks: dealt in launch order, which
+        // spreads the row blocks over the eight XCDs (the dense layers' order would leave 8 - n_xb of them idle); W is
+        // small and lives in every L2
+        yb = (int)blockIdx.x / n_xb; xb = (int)blockIdx.x - yb * n_xb;
+        if (yb >= n_yb) return;
+    } else {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        yb = slot % n_yb; xb = (slot / n_yb) * 8 + xcd;
+        if (xb >= n_xb) return;
+    }
     const int mb0 = yb * 128, tb0 = xb * 8;
-    const int steps = K / 32;
+    const int steps = GATE ? (K + 31) / 32 : K / 32;
     const unsigned lds0 = (__builtin_amdgcn_groupstaticsize() + 15u) & ~15u;
     const int ws = __builtin_amdgcn_readfirstlane(wave);
 
     // staging roles: pair q (0, 1) of this thread is A row (tid >> 2) + 64 q, k group tid & 3
     const int srow = tid >> 2, skq = tid & 3;
-    const float *ag[2];
+    const float *ag[2], *gg[2];
     int adst[2];
 #pragma unroll
     for (int q = 0; q < 2; q++) {
-        const int row = srow + 64 * q;
-        ag[q] = A + (size_t)min(mb0 + row, M - 1) * K + 8 * skq;                 // rows past M: clamped, never stored
+        const int row = srow + 64 * q, grow = min(mb0 + row, M - 1);
+        ag[q] = A + (size_t)grow * K + 8 * skq;                                  // rows past M: clamped, never stored
+        gg[q] = GATE ? gate + (size_t)(grow / rows_per_seg) * K + 8 * skq : nullptr;
         adst[q] = (((row >> 4) * 2) * 64 + skq * 16 + (row & 15)) * 4;           // float offset of the hi fragment slot; lo: + 256
     }
-    float4 ra[2][2];
+    float4 ra[2][2], rg[GATE ? 2 : 1][2];
     auto load_a = [&](int st) {
 #pragma unroll
         for (int q = 0; q < 2; q++) {
-            ra[q][0] = *reinterpret_cast<const float4 *>(ag[q] + 32 * st);
-            ra[q][1] = *reinterpret_cast<const float4 *>(ag[q] + 32 * st + 4);
+            if constexpr (GATE) {
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const bool in = 32 * st + 8 * skq + 4 * h < K;     // (K % 4 == 0: a quad is wholly inside or outside)
+                    ra[q][h] = *reinterpret_cast<const float4 *>(ag[q] + (in ? 32 * st + 4 * h : 0));
+                    rg[q][h] = *reinterpret_cast<const float4 *>(gg[q] + (in ? 32 * st + 4 * h : 0));
+                    if (!in) { rg[q][h] = make_float4(0.f, 0.f, 0.f, 0.f); ra[q][h] = rg[q][h]; }
+                }
+            } else {
+                ra[q][0] = *reinterpret_cast<const float4 *>(ag[q] + 32 * st);
+                ra[q][1] = *reinterpret_cast<const float4 *>(ag[q] + 32 * st + 4);
+            }
         }
     };
     auto store_a = [&](int buf) {
         float *as = gsm + buf * STAGE;
 #pragma unroll
         for (int q = 0; q < 2; q++) {
-            const float v[8] = {ra[q][0].x, ra[q][0].y, ra[q][0].z, ra[q][0].w, ra[q][1].x, ra[q][1].y, ra[q][1].z, ra[q][1].w};
+            float v[8] = {ra[q][0].x, ra[q][0].y, ra[q][0].z, ra[q][0].w, ra[q][1].x, ra[q][1].y, ra[q][1].z, ra[q][1].w};
+            if constexpr (GATE) {
+                const float g[8] = {rg[q][0].x, rg[q][0].y, rg[q][0].z, rg[q][0].w, rg[q][1].x, rg[q][1].y, rg[q][1].z, rg[q][1].w};
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] *= g[j];
+            }
             f16x8 h, l;
             bh_split8(v, h, l);
             *reinterpret_cast<f16x8 *>(as + adst[q]) = h;
@@ -415,6 +464,124 @@ __global__ __launch_bounds__(256, 2) void pw_gemm16s_kernel(const float *__restr
 }
 
 bool pw_gemm16_supports(int K, int act) { return K % 32 == 0 && (act == ACT_NONE || act_is_templated(act)); }
+
+// ---------------------------------------------------------------------------------------
+// The gated project convolution of the EARLY squeeze-excite blocks: very many rows (16 000 pixels a segment), few columns
+// (N = 24 .. 48), K = 24 .. 288 -- a stream of D rows through a small weight matrix, bound by HBM (K + 2 N floats per pixel),
+// not a 128 x 128 GEMM tile.  One 8-wave workgroup keeps ALL of W (f16 hi / lo fragments, [K / 32][NT]{hi, lo}[64][8]: <= 54 KB)
+// in LDS; every wave walks 16-row tiles: a lane's 8 consecutive k of its row arrive as two 16-byte loads (the four lanes of a row
+// read one whole 128-byte line), are multiplied by the segment's gate, split into f16 hi / lo in registers and go straight into
+// the MFMA as the A operand -- no staging of A at all.  The next k step's loads are in flight while this one computes.
+// ---------------------------------------------------------------------------------------
+template <int TERMS, int NT>
+__global__ __launch_bounds__(512, 4) void pw_gemm16_thin_kernel(const float *__restrict__ A, const float *__restrict__ gate, int rows_per_seg,
+                                                                 const f16x8 *__restrict__ Wf, const float *__restrict__ bias,
+                                                                 const float *__restrict__ R, float *__restrict__ C, int M, int K, int N,
+                                                                 float w_unscale) {
+    extern __shared__ __attribute__((aligned(16))) float tsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int steps = (K + 31) / 32;
+    {   // all of W, once per workgroup
+        const float4 *src = reinterpret_cast<const float4 *>(Wf);
+        float4 *dst = reinterpret_cast<float4 *>(tsm);
+        const int n4 = steps * NT * 2 * 64;            // float4s: [step][tile]{hi, lo}[64 lanes] x 16 B (8 halves)
+        for (int i = tid; i < n4; i += 512) dst[i] = src[i];
+    }
+    __syncthreads();
+    const f16x8 *wf = reinterpret_cast<const f16x8 *>(tsm);
+    const int n_rt = (M + 15) >> 4;
+    const float rcp_p = 1.0f / (float)rows_per_seg;
+    for (int rt = blockIdx.x * 8 + wave; rt < n_rt; rt += gridDim.x * 8) {
+        const int row = min(rt * 16 + li, M - 1);                       // rows past M: clamped, never stored
+        int seg = (int)((float)row * rcp_p);                            // row / rows_per_seg through the reciprocal, fixed up
+        seg += (row - seg * rows_per_seg >= rows_per_seg) ? 1 : 0;
+        seg -= (row - seg * rows_per_seg < 0) ? 1 : 0;
+        const float *ap = A + (size_t)row * K + 8 * kq, *gp = gate + (size_t)seg * K + 8 * kq;
+        f32x4 acc[NT];
+#pragma unroll
+        for (int j = 0; j < NT; j++) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float4 ra[2], rg[2], na[2], ng[2];
+        auto load = [&](int st, float4 (&a)[2], float4 (&g)[2]) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const bool in = 32 * st + 8 * kq + 4 * h < K;       // (K % 4 == 0)
+                a[h] = *reinterpret_cast<const float4 *>(ap + (in ? 32 * st + 4 * h : 0));
+                g[h] = *reinterpret_cast<const float4 *>(gp + (in ? 32 * st + 4 * h : 0));
+                if (!in) { a[h] = make_float4(0.f, 0.f, 0.f, 0.f); g[h] = a[h]; }
+            }
+        };
+        load(0, ra, rg);
+        for (int st = 0; st < steps; st++) {
+            if (st + 1 < steps) load(st + 1, na, ng);
+            const float v[8] = {ra[0].x * rg[0].x, ra[0].y * rg[0].y, ra[0].z * rg[0].z, ra[0].w * rg[0].w,
+                                ra[1].x * rg[1].x, ra[1].y * rg[1].y, ra[1].z * rg[1].z, ra[1].w * rg[1].w};
+            f16x8 ah, al;
+            bh_split8(v, ah, al);
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                const f16x8 bh = wf[((st * NT + j) * 2 + 0) * 64 + lane];
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[j], 0, 0, 0);
+                if (TERMS == 3) {
+                    const f16x8 bl = wf[((st * NT + j) * 2 + 1) * 64 + lane];
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[j], 0, 0, 0);
+                }
+            }
+            if (st + 1 < steps) { ra[0] = na[0]; ra[1] = na[1]; rg[0] = ng[0]; rg[1] = ng[1]; }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const int col = j * 16 + li;
+            if (col >= N) continue;
+            const float bv = bias[col];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int orow = rt * 16 + kq * 4 + r;
+                if (orow < M) {
+                    float v = __builtin_fmaf(acc[j][r], w_unscale, bv);
+                    if (R) v += R[(size_t)orow * N + col];
+                    C[(size_t)orow * N + col] = v;
+                }
+            }
+        }
+    }
+}
+
+// the project convolution of a squeeze-excite block on the f16 MFMA: C = (D x gate) W + bias (+ R), no activation; K % 4 == 0,
+// planes [ceil(K / 32)][ceil(N / 16)]{hi, lo}[64][8] zero-padded in K
+void launch_pw_gemm16_gated(const float *A, const float *gate, int rows_per_seg, const void *Wf, const float *bias, const float *R,
+                            float *C, int M, int K, int N, int terms, float w_unscale, hipStream_t s) {
+    const int n_tiles = (N + 15) / 16;
+    // few columns, all of W in LDS (<= 64 KB), many rows: the streaming kernel above
+    const size_t w_bytes = (size_t)((K + 31) / 32) * n_tiles * 2 * 1024;
+    if (n_tiles <= 3 && w_bytes <= 64 * 1024 && M >= 4096) {
+        const int n_rt = (M + 15) / 16;
+        const int wgs = std::min((n_rt + 7) / 8, 2 * device_cu_count());     // two 8-wave workgroups per CU, walking the row tiles
+#define BH_THIN(T, NTV)                                                                                                            \
+        do {                                                                                                                       \
+            static DeviceOnce attr;                                                                                                \
+            attr.run([] { (void)hipFuncSetAttribute((const void *)pw_gemm16_thin_kernel<T, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); }); \
+            hipLaunchKernelGGL((pw_gemm16_thin_kernel<T, NTV>), dim3(wgs), dim3(512), w_bytes, s, A, gate, rows_per_seg, (const f16x8 *)Wf, bias, R, C, M, K, N, w_unscale); \
+        } while (0)
+        if (terms == 3) { if (n_tiles == 1) BH_THIN(3, 1); else if (n_tiles == 2) BH_THIN(3, 2); else BH_THIN(3, 3); }
+        else { if (n_tiles == 1) BH_THIN(1, 1); else if (n_tiles == 2) BH_THIN(1, 2); else BH_THIN(1, 3); }
+#undef BH_THIN
+        return;
+    }
+    const int n_xb = (n_tiles + 7) / 8, n_yb = (M + 127) / 128;
+    dim3 grid((unsigned)(n_xb * n_yb)), block(256);
+    constexpr size_t kStagedLds = 2 * (2 * 8 * 2 * 256) * sizeof(float);
+    if (terms == 3) {
+        static DeviceOnce attr;
+        attr.run([] { (void)hipFuncSetAttribute((const void *)pw_gemm16s_kernel<3, ACT_NONE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStagedLds); });
+        hipLaunchKernelGGL((pw_gemm16s_kernel<3, ACT_NONE, true>), grid, block, kStagedLds, s, A, (const f16x8 *)Wf, bias, R, C, M, K, N, n_tiles, w_unscale, gate, rows_per_seg);
+    } else {
+        static DeviceOnce attr;
+        attr.run([] { (void)hipFuncSetAttribute((const void *)pw_gemm16s_kernel<1, ACT_NONE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStagedLds); });
+        hipLaunchKernelGGL((pw_gemm16s_kernel<1, ACT_NONE, true>), grid, block, kStagedLds, s, A, (const f16x8 *)Wf, bias, R, C, M, K, N, n_tiles, w_unscale, gate, rows_per_seg);
+    }
+}
 
 void launch_pw_gemm16(const float *A, const void *Wf, const float *bias, const float *R, float *C, int M, int K, int N,
                       int act, int terms, float w_unscale, hipStream_t s) {
@@ -741,6 +908,61 @@ __global__ __launch_bounds__(256) void gap_kernel(const float *__restrict__ in, 
 void launch_gap(const float *in, float *out, int n_seg, int P, int C, hipStream_t s) {
     const long total = (long)n_seg * (C / 4);
     hipLaunchKernelGGL(gap_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, n_seg, P, C);
+}
+
+// ---------------------------------------------------------------------------------------
+// The gate of a squeeze-excite block in one launch (round 5): GlobalAveragePool -> 1x1 conv (C -> Cr, act1) -> 1x1 conv (Cr -> C,
+// act2 = sigmoid) of the ONNX graph, from the per-tile channel sums pass A of the fused block left (mbconv_kernel SE = 1).
+// One workgroup per segment; every sum runs in a fixed order (no atomics: identical segments give identical gates).
+//   part [n][tiles][C]   W1 [C][ld1]  b1 [Cr]   W2 [Cr][ld2]  b2 [C]   gate [n][C]
+// LDS: pooled [C] | partial dot products [256] | hidden [Cr]
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void se_gate_kernel(const float *__restrict__ part, int tiles, float inv_p, const float *__restrict__ W1,
+                                                       const float *__restrict__ b1, int ld1, int act1, const float *__restrict__ W2,
+                                                       const float *__restrict__ b2, int ld2, int act2, float *__restrict__ gate, int C, int Cr,
+                                                       int crp) {
+    extern __shared__ __attribute__((aligned(16))) float gs[];
+    float *pooled = gs, *hp = gs + C, *hid = hp + 256;
+    const int tid = threadIdx.x, seg = blockIdx.x;
+    const float *ps = part + (size_t)seg * tiles * C;
+    for (int c = tid; c < C; c += 256) {
+        float sum = 0.0f;
+        for (int t = 0; t < tiles; t++) sum += ps[(size_t)t * C + c];
+        pooled[c] = sum * inv_p;
+    }
+    __syncthreads();
+    // hidden layer: thread (r, part) sums its slice of the channels; crp = the power of two >= Cr, 256 / crp slices
+    const int nparts = 256 / crp, r = tid & (crp - 1), pt = tid / crp, slice = (C + nparts - 1) / nparts;
+    {
+        float sum = 0.0f;
+        if (r < Cr) {
+            const int c0 = pt * slice, c1 = min(C, c0 + slice);
+            for (int c = c0; c < c1; c++) sum = __builtin_fmaf(pooled[c], W1[(size_t)c * ld1 + r], sum);
+        }
+        hp[tid] = sum;
+    }
+    __syncthreads();
+    if (tid < Cr) {
+        float sum = b1[tid];
+        for (int q = 0; q < nparts; q++) sum += hp[q * crp + tid];
+        hid[tid] = act_apply(sum, act1);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float sum = b2[c];
+        for (int q = 0; q < Cr; q++) sum = __builtin_fmaf(hid[q], W2[(size_t)q * ld2 + c], sum);
+        gate[(size_t)seg * C + c] = act_apply(sum, act2);
+    }
+}
+
+bool se_gate_supports(int C, int Cr) { return C >= 1 && Cr >= 1 && Cr <= 256 && C <= 16384; }
+
+void launch_se_gate(const float *part, int tiles, int P, const float *W1, const float *b1, int ld1, int act1, const float *W2, const float *b2,
+                    int ld2, int act2, float *gate, int n_seg, int C, int Cr, hipStream_t s) {
+    int crp = 4;
+    while (crp < Cr) crp <<= 1;
+    const size_t lds = ((size_t)C + 256 + Cr) * sizeof(float);
+    hipLaunchKernelGGL(se_gate_kernel, dim3(n_seg), dim3(256), lds, s, part, tiles, 1.0f / (float)P, W1, b1, ld1, act1, W2, b2, ld2, act2, gate, C, Cr, crp);
 }
 
 // ---------------------------------------------------------------------------------------

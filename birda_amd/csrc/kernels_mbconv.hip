@@ -42,9 +42,10 @@ double mb_try_th(MbDesc &d, int ci, int th) {
         (d.stem && (long)d.stem_c * d.stem_h * d.stem_w >= (1L << 24))) return -1;
     if (d.stem && d.stem_k != 3) return -1;
     if (c.PREC != d.prec) return -1;
+    if (d.se && (!c.launch_se || c.PERSIST)) return -1;   // pass A of a squeeze-excite block: only where it is instantiated (mbconv_kernel.hpp MB_WITH_SE)
     if (c.KG == 0) { if (!d.noexp || d.stem) return -1; }   // the no-expand entries serve the no-expand blocks, and only them
     else if (d.noexp || (d.Cin + (c.PREC ? 31 : 15)) / (c.PREC ? 32 : 16) != c.KG) return -1;
-    if (d.act_e != c.ACT || d.act_d != c.ACT || d.act_p != ACT_NONE) return -1;
+    if (d.act_e != c.ACT || d.act_d != c.ACT || (!d.se && d.act_p != ACT_NONE)) return -1;   // (se: the project conv is another launch)
     if (c.COLTH) {   // column tasks: the tile is the whole image, COLTH rows high, symmetric padding, one task per thread
         if (th != c.COLTH || d.Ho != c.COLTH || d.H != c.COLTH || d.ST != 1 || d.pad_t != (c.KS - 1) / 2) return -1;
         if (c.S * (1 << c.TWL) * (c.CE / (c.WM * c.WN == 8 ? 2 : 4)) > 64 * c.WM * c.WN) return -1;   // one task per thread
@@ -238,6 +239,9 @@ bool mb_plan_narrow(const MbDesc &d, MbDesc &narrow) {
     return best_twl != 99;
 }
 
-void launch_mbconv(const MbDesc &d, int n_seg, hipStream_t s) { kCfgs[d.cfg].launch(d, n_seg, s); }
+void launch_mbconv(const MbDesc &d, int n_seg, hipStream_t s) {
+    if (d.se) kCfgs[d.cfg].launch_se(d, n_seg, s);
+    else kCfgs[d.cfg].launch(d, n_seg, s);
+}
 
 }  // namespace bh

@@ -1,4 +1,7 @@
 // The fused MBConv kernel's tile configurations (mbconv_cfgs.inc) instantiated for ONE activation: ACT_SWISH.
+// ... and, swish being the activation of the stacks that carry squeeze-excite gates (EfficientNet: Perch v2's backbone), every
+// entry a second time as pass A of such a block (MB_WITH_SE, mbconv_kernel.hpp SE = 1).
+#define MB_WITH_SE 1
 #include "mbconv_kernel.hpp"
 
 namespace bh {

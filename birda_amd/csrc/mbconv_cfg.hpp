@@ -11,6 +11,7 @@ namespace bh {
 struct MbCfg {
     int KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC, PERSIST, ACT, COLTH;
     void (*launch)(const MbDesc &, int, hipStream_t);   // nullptr: not part of this build (KS = 0 matches no block)
+    void (*launch_se)(const MbDesc &, int, hipStream_t);   // pass A of a squeeze-excite block (MbDesc::se); nullptr: not instantiated for this activation / entry
 };
 
 const MbCfg *mb_table_gelu(int *n);

@@ -179,10 +179,15 @@ __device__ __forceinline__ bh_f32x2 mb_act2(bh_f32x2 v) {
 //               (large images, few channels): a tile's compute is ~5k cycles, and 12 barriers each waiting for a freshly
 //               issued L2 -> LDS transfer plus the launch and set-up of 48-96 workgroups per segment were 70 % of their time
 //               (tools/abl2.sh: chunk loop without any compute 417 of 1061 us, set-up + epilogue 303).
+//   SE          1: pass A of a squeeze-excite block (MbDesc::se): the expand and depthwise phases only -- the depthwise output goes to HBM
+//               (d.Dout, f32 NHWC) instead of the LDS planes of the project GEMM, and the per-channel sums of the tile's pixels to
+//               d.pool_part, summed in a FIXED order (per-task partial sums through LDS, one thread per channel adds them up: no
+//               atomics, so identical segments give identical bits wherever they sit in a batch); no project phase, no epilogue
 template <int KS, int ST, int CE, int KG, int RT_W, int NCS, int WM, int WN, int MT_W, int NT_W, int TWL, int XBL,
-          int SS, int OCC, int STEM, int PREC, int PERSIST = 0, int ACT = ACT_GELU_ERF, int COLTH = 0>
+          int SS, int OCC, int STEM, int PREC, int PERSIST = 0, int ACT = ACT_GELU_ERF, int COLTH = 0, int SE = 0>
 __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc d, const int n_seg) {
     static_assert(!STEM || SS == 1, "the stem variant handles one segment per workgroup");
+    static_assert(!SE || (PERSIST == 0 && !mb_gelu2x<ACT, PREC>()), "squeeze-excite pass A: plain workgroups, activations at their own scale");
     static_assert(PREC == 0 || CE % 32 == 0 || CE == 16, "f16 project GEMM: 32-deep steps, or one 16-deep step for 16-channel chunks");
     // NW waves: 4 (one per SIMD; the workgroups of a CU interleave) or 8 (two per SIMD inside ONE workgroup: the late blocks, whose
     // whole-image tiles leave room for a single workgroup per CU -- with one wave per SIMD nothing fills the issue bubbles of its
@@ -498,6 +503,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
     float *Yb = d.Y + (size_t)seg0 * d.Ho * d.Wo * Cout;
     const float *Rb = d.R ? d.R + (size_t)seg0 * d.Ho * d.Wo * Cout : nullptr;
     f32x4 acco[MT_W][NT_W];
+    // SE (pass A of a squeeze-excite block): where the depthwise output and the tile's channel sums go
+    float *Dg = SE ? d.Dout + (size_t)seg0 * d.Ho * d.Wo * d.Cexp : nullptr;
+    if constexpr (!SE)
 #pragma unroll
     for (int i = 0; i < MT_W; i++) {
         const int4 o4 = *reinterpret_cast<const int4 *>(&omap[(wm * MT_W + i) * 16 + 4 * kq]);
@@ -542,6 +550,21 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
     };
     p2_task(tid);
 
+    // SE: the channel sums of chunk `se_pending` wait in LDS as per-wave partial sums (WpS: [slot][wave][CE]); thread (slot, channel)
+    // adds them in wave order and stores the tile's sum
+    int se_pending = -1;
+    auto se_flush = [&]() {
+        if (se_pending >= 0 && tid < SS * CE) {
+            const int sl = tid / CE, c = tid - sl * CE;
+            if (sl < nsv && se_pending * CE + c < d.Cexp) {
+                float sum = 0.0f;
+#pragma unroll
+                for (int w = 0; w < NW; w++) sum += WpS[(sl * NW + w) * CE + c];
+                d.pool_part[((size_t)(seg0 + sl) * tiles_xy + txy) * d.Cexp + se_pending * CE + c] = sum;
+            }
+        }
+        se_pending = -1;
+    };
     for (int ch = 0; ch < nchunks; ch++) {
         // (STRIP: behind the last chunk comes chunk 0 of the next tile row -- its weights arrive under this tile's last phases)
         const int chn = STRIP ? (ch + 1 < nchunks ? ch + 1 : 0) : min(ch + 1, nchunks - 1);
@@ -695,6 +718,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
         mb_stamp(d.stamps, t_last, 2);
         if (!ring && !RESIDENT) mb_dma_wait();
         __syncthreads();  // B1: Es complete; (ring == 0) WeS / WpS free; Wds (DMA issued after the last B2) landed
+        if constexpr (SE) se_flush();   // the previous chunk's wave sums are all in LDS now (their next writer sits behind B2)
         if constexpr (STRIP) {
             // ... and this chunk's bottom rows for the tile below: grid rows [TH * ST, TH * ST + KH) -> halo store.  (Read-only in
             // this phase; the store's next reader is this chunk's P1 phase of the next tile row, many barriers from here.)
@@ -709,12 +733,13 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                 // (issued in parts inside the depthwise phase below)
             } else {
                 mb_dma<WE_FLOATS, NW>(d.We + (size_t)chn * WE_FLOATS, WeS, wave, lane);
-                mb_dma<WP_FLOATS, NW>(d.Wp + (size_t)ch * WP_FLOATS, WpS, wave, lane);
+                if constexpr (!SE) mb_dma<WP_FLOATS, NW>(d.Wp + (size_t)ch * WP_FLOATS, WpS, wave, lane);
             }
         }
         mb_stamp(d.stamps, t_last, 3);
 
         // ---- P2: depthwise, XB output pixels x 4 channels per lane ---------------------------
+        // (SE: every variant leaves the chunk's depthwise output in the LDS D buffer as f32 rows [pixel][CE + 4], the f32 mode's layout)
         if constexpr (COLTH > 0 && NW == 8) {
             // column tasks of the 8-wave workgroups: one lane = one output column (all COLTH rows) x TWO channels, so that
             // SS * TW * CE / 2 = 512 tasks fill the workgroup and a task's rows (COLTH x KS float2) fit beside the resident A
@@ -726,7 +751,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
             if (!(tid < nsv * TW * C2N && !(dbgv & 2))) {   // (wave-uniform)
                 if (dma_on) {
                     mb_dma_at<WE_FLOATS, NW>(d.We + (size_t)chn * WE_FLOATS, we_ba, wave, lane);
-                    mb_dma_at<WP_FLOATS, NW>(d.Wp + (size_t)ch * WP_FLOATS, wp_ba, wave, lane);
+                    if constexpr (!SE) mb_dma_at<WP_FLOATS, NW>(d.Wp + (size_t)ch * WP_FLOATS, wp_ba, wave, lane);
                 }
             } else {
                 const int c2 = tid % C2N, q = tid / C2N, x = q & (TW - 1), sl = q >> TWL;
@@ -762,7 +787,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                     // measured, no difference -- 6.16 / 6.19 / 6.17 / 6.19 us per segment over all blocks, three alternations.)
                     if (dma_on) {
                         mb_dma_at_part<WE_FLOATS, NW>(d.We + (size_t)chn * WE_FLOATS, we_ba, wave, lane, dx, KS);
-                        mb_dma_at_part<WP_FLOATS, NW>(d.Wp + (size_t)ch * WP_FLOATS, wp_ba, wave, lane, dx, KS);
+                        if constexpr (!SE) mb_dma_at_part<WP_FLOATS, NW>(d.Wp + (size_t)ch * WP_FLOATS, wp_ba, wave, lane, dx, KS);
                     }
                     // the sums are pinned here: left alone, hipcc sinks this column's FMAs below the next columns' loads (three
                     // columns of the window and their taps in flight: +60 registers, which the 136- and 232-channel blocks of the
@@ -781,12 +806,12 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                         if (r + k >= COLTH) continue;
                         const f32x2 g = k ? g1 : g0;
                         const int prow = sl * THTW + ((r + k) << TWL) + x;
-                        if constexpr (PREC == 3) {
+                        if constexpr (PREC == 3 && !SE) {
                             bh_f16x2 h, l;
                             bh_split2(g[0], g[1], h, l);
                             *reinterpret_cast<bh_f16x2 *>(&DsH[prow * DSH + 2 * c2]) = h;
                             *reinterpret_cast<bh_f16x2 *>(&DsL[prow * DSH + 2 * c2]) = l;
-                        } else if constexpr (PREC == 1) {
+                        } else if constexpr (PREC == 1 && !SE) {
                             *reinterpret_cast<bh_f16x2 *>(&DsH[prow * DSH + 2 * c2]) = (bh_f16x2){(_Float16)g[0], (_Float16)g[1]};
                         } else {
                             *reinterpret_cast<f32x2 *>(&Ds[prow * CES + 2 * c2]) = g;
@@ -804,7 +829,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
             if (!(tid < nsv * TW * C4N && !(dbgv & 2))) {   // (wave-uniform: a wave without tasks issues its pieces at once)
                 if (dma_on) {
                     mb_dma_at<WE_FLOATS, NW>(d.We + (size_t)chn * WE_FLOATS, we_ba, wave, lane);
-                    mb_dma_at<WP_FLOATS, NW>(d.Wp + (size_t)ch * WP_FLOATS, wp_ba, wave, lane);
+                    if constexpr (!SE) mb_dma_at<WP_FLOATS, NW>(d.Wp + (size_t)ch * WP_FLOATS, wp_ba, wave, lane);
                 }
             } else {
                 const int c4 = tid % C4N, q = tid / C4N, x = q & (TW - 1), sl = q >> TWL;
@@ -836,7 +861,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                     }
                     if (dma_on) {   // this row's share of the next chunk's expand weights and this chunk's project weights
                         mb_dma_at_part<WE_FLOATS, NW>(d.We + (size_t)chn * WE_FLOATS, we_ba, wave, lane, dy, KS);
-                        mb_dma_at_part<WP_FLOATS, NW>(d.Wp + (size_t)ch * WP_FLOATS, wp_ba, wave, lane, dy, KS);
+                        if constexpr (!SE) mb_dma_at_part<WP_FLOATS, NW>(d.Wp + (size_t)ch * WP_FLOATS, wp_ba, wave, lane, dy, KS);
                     }
                     __builtin_amdgcn_sched_barrier(0);   // one kernel row of weight loads in flight
                 }
@@ -845,13 +870,13 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                     f32x2 g0 = acc[r][0], g1 = acc[r][1];
                     mb_act4<ACT, PREC>(g0, g1);
                     const int prow = sl * THTW + (r << TWL) + x;
-                    if constexpr (PREC == 3) {
+                    if constexpr (PREC == 3 && !SE) {
                         bh_f16x2 h0, l0, h1, l1;
                         bh_split2(g0[0], g0[1], h0, l0);
                         bh_split2(g1[0], g1[1], h1, l1);
                         *reinterpret_cast<f16x4 *>(&DsH[prow * DSH + 4 * c4]) = (f16x4){h0[0], h0[1], h1[0], h1[1]};
                         *reinterpret_cast<f16x4 *>(&DsL[prow * DSH + 4 * c4]) = (f16x4){l0[0], l0[1], l1[0], l1[1]};
-                    } else if constexpr (PREC == 1) {
+                    } else if constexpr (PREC == 1 && !SE) {
                         *reinterpret_cast<f16x4 *>(&DsH[prow * DSH + 4 * c4]) =
                             (f16x4){(_Float16)g0[0], (_Float16)g0[1], (_Float16)g1[0], (_Float16)g1[1]};
                     } else {
@@ -894,7 +919,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                     mb_act4<ACT, PREC>(g0, g1);
                     const float4 v = make_float4(g0[0], g0[1], g1[0], g1[1]);
                     const int prow = p2_prow + x;
-                    if constexpr (PREC != 0) {   // the project GEMM's A operand: f16 hi (+ lo) planes
+                    if constexpr (PREC != 0 && !SE) {   // the project GEMM's A operand: f16 hi (+ lo) planes
                         if (PREC == 3) {
                             bh_f16x2 h0, l0, h1, l1;
                             bh_split2(v.x, v.y, h0, l0);
@@ -930,6 +955,42 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
         }
         mb_stamp(d.stamps, t_last, 5);
 
+        if constexpr (SE) {
+            // ---- S: the chunk's depthwise output leaves for HBM, and its channel sums are taken on the way ----------------------
+            // Thread = (channel quad c4 = tid % C4N, pixel p = tid / C4N, stepping by NTH / C4N): a pixel's CE channels are one
+            // contiguous run in LDS and in D (64 or 128 bytes).  Sums: per thread over its pixels (one accumulator per segment
+            // slot), then across the lanes of the wave that share the quad (xor-shuffles: a fixed tree, no atomics -- identical
+            // segments give identical bits wherever they sit in a batch); lanes 0 .. C4N - 1 leave the wave's sums in LDS (the
+            // project weights' buffer, unused in this pass), and after the NEXT barrier one thread per channel adds the waves' up.
+            static_assert(64 % C4N == 0 && NTH % C4N == 0, "squeeze-excite pass A: the channel quads of a chunk divide a wave");
+            const int c4 = tid % C4N, cg = ch * CE + 4 * c4;
+            const int npix = nsv * THTW;
+            f32x4 ssum[SS];
+#pragma unroll
+            for (int q = 0; q < SS; q++) ssum[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int p0 = tid / C4N; p0 < npix; p0 += NTH / C4N) {
+                const int o = omap[p0];
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(&Ds[p0 * CES + 4 * c4]);
+                if (o >= 0) {
+                    if (cg < d.Cexp) *reinterpret_cast<f32x4 *>(Dg + (size_t)o * d.Cexp + cg) = v;
+                    if (SS == 1 || p0 < THTW) ssum[0] += v; else ssum[SS - 1] += v;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < SS; q++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    float x = ssum[q][j];
+#pragma unroll
+                    for (int mask = C4N; mask < 64; mask <<= 1) x += __shfl_xor(x, mask, 64);
+                    ssum[q][j] = x;
+                }
+            if (lane < C4N) {
+#pragma unroll
+                for (int q = 0; q < SS; q++) *reinterpret_cast<f32x4 *>(&WpS[((q * NW + wave) * C4N + lane) * 4]) = ssum[q];
+            }
+            se_pending = ch;
+        } else
         // ---- P3: project -----------------------------------------------------------------
         if (!(dbgv & 4)) {
             if constexpr (P16) {
@@ -1037,7 +1098,12 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
         // (which rewrites Ds) sits behind B1, which also drains the Wd DMA issued above.
     }
 
+    if constexpr (SE) {
+        __syncthreads();
+        se_flush();
+    }
     // ---- epilogue: store (bias and residual are already in the accumulators) -------------------
+    if constexpr (!SE)
 #pragma unroll
     for (int i = 0; i < MT_W; i++) {
         const int4 o4 = *reinterpret_cast<const int4 *>(&omap[(wm * MT_W + i) * 16 + 4 * kq]);
@@ -1061,9 +1127,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
 }
 
 template <int KS, int ST, int CE, int KG, int RT_W, int NCS, int WM, int WN, int MT_W, int NT_W, int TWL, int XBL,
-          int SS, int OCC, int STEM, int PREC, int PERSIST, int ACT, int COLTH = 0>
+          int SS, int OCC, int STEM, int PREC, int PERSIST, int ACT, int COLTH = 0, int SE = 0>
 void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
-    auto kern = mbconv_kernel<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, SS, OCC, STEM, PREC, PERSIST, ACT, COLTH>;
+    auto kern = mbconv_kernel<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, SS, OCC, STEM, PREC, PERSIST, ACT, COLTH, SE>;
     static DeviceOnce attr_set;
     attr_set.run([&] { (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
     // (PERSIST == 2, strip-walking: one workgroup per tile COLUMN and segment)
@@ -1078,24 +1144,46 @@ void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
 }
 
 // (MB_A: the activation the table is being expanded for, see kCfgs below)
+// MB_WITH_SE (defined by the translation unit of the activation squeeze-excite stacks use: swish, EfficientNet's): every product entry
+// is also instantiated as pass A of a squeeze-excite block (SE = 1); elsewhere the slot is nullptr and such blocks run layer by layer
+// (pass A sums the tile's channels with a wave-level tree: the channel quads of a chunk must divide a wave -- the entries that do
+//  not qualify keep a nullptr and such blocks run layer by layer)
+template <int KS, int ST, int CE, int KG, int RT_W, int NCS, int WM, int WN, int MT_W, int NT_W, int TWL, int XBL,
+          int SS, int OCC, int STEM, int PREC, int PERSIST, int ACT, int COLTH>
+constexpr auto mb_se_fn() -> void (*)(const MbDesc &, int, hipStream_t) {
+    constexpr int NW = WM * WN, C4N = CE / 4;
+    // (the wave sums of a chunk, [SS][NW][CE] floats, wait in the project weights' LDS buffer, which this pass does not fill)
+    constexpr int WPF = (PREC != 0 && CE == 16) ? WN * NT_W * 256 : (PREC ? (CE + 31) / 32 : CE / 16) * WN * NT_W * (PREC ? 512 : 256);
+    if constexpr (64 % C4N == 0 && (64 * NW) % C4N == 0 && SS * NW * CE <= WPF)
+        return mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, SS, OCC, STEM, PREC, PERSIST, ACT, COLTH, 1>;
+    else
+        return nullptr;
+}
+#ifdef MB_WITH_SE
+#define MB_SE_FN(...) mb_se_fn<__VA_ARGS__>()
+#else
+#define MB_SE_FN(...) nullptr
+#endif
 #define MB_ENTRY_P(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, PREC) \
     {KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC, 0, MB_A, 0,     \
-     mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC, STEM, PREC, 0, MB_A>}
+     mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC, STEM, PREC, 0, MB_A>,  \
+     MB_SE_FN(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC, STEM, PREC, 0, MB_A, 0)}
 // column-task depthwise phase (COLTH = TH = the image height), split-f16 and plain-f16 twins
 #define MB_ENTRY_PC(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, PREC) \
     {KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC, 0, MB_A, TH,    \
-     mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC, STEM, PREC, 0, MB_A, TH>}
+     mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC, STEM, PREC, 0, MB_A, TH>, \
+     MB_SE_FN(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC, STEM, PREC, 0, MB_A, TH)}
 #define MB_ENTRY_HC(KS, ST, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM)            \
     MB_ENTRY_PC(KS, ST, 32, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, 3),         \
     MB_ENTRY_PC(KS, ST, 32, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, 1)
 // persistent workgroups, every chunk's weights resident in LDS (the early blocks)
 #define MB_ENTRY_PP(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, PREC) \
     {KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC, 1, MB_A, 0,      \
-     mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC, STEM, PREC, 1, MB_A>}
+     mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC, STEM, PREC, 1, MB_A>, nullptr}
 // strip-walking workgroups (PERSIST = 2): the early blocks on large batches
 #define MB_ENTRY_PW(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, PREC) \
     {KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, TH, S, STEM, XBL, OCC, PREC, 2, MB_A, 0,      \
-     mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC, STEM, PREC, 2, MB_A>}
+     mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, S, OCC, STEM, PREC, 2, MB_A>, nullptr}
 #define MB_ENTRY_S(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM) \
     MB_ENTRY_P(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, 0)
 #define MB_ENTRY(KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC) \
@@ -1106,7 +1194,7 @@ void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
     MB_ENTRY_P(KS, ST, 32, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, TH, S, OCC, STEM, 1)
 // A configuration that is not part of this build (measured alternatives live behind -DBIRDA_HIP_EXPERIMENTS, see mbconv_cfgs.inc):
 // keeps its index, matches no block (KS = 0).
-#define MB_NONE {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, MB_A, 0, nullptr}
+#define MB_NONE {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, MB_A, 0, nullptr, nullptr}
 #define MB_NONE2 MB_NONE, MB_NONE
 #ifdef BIRDA_HIP_EXPERIMENTS
 #define MB_XENTRY(...) MB_ENTRY(__VA_ARGS__)

@@ -177,12 +177,12 @@ def build_model(kind: str = "birdnet_v24", seed: int = WEIGHT_SEED,
         sr, n, dur = 32000, 160000, 5.0
         branches = [mf.Branch(1024, 320, 128, (n - 1024) // 320 + 1, 60.0, 16000.0, 1.23)]
         stages, stem, head, ncls, family, out_act = _B0_STAGES, 32, 1280, 11560, 2, mf.OUT_NONE
-    elif kind in ("perch_v2", "perch_v2_tiny"):
+    elif kind in ("perch_v2", "perch_v2_tiny", "perch_v2_nose"):
         # Perch v2: 5 s @ 32 kHz, 14 795 classes, softmax (manifests/Perch-v2-*).
         sr, n, dur = 32000, 160000, 5.0
         branches = [mf.Branch(1024, 320, 128, (n - 1024) // 320 + 1, 60.0, 16000.0, 1.23)]
         stages, stem, head, ncls, family, out_act = _B0_STAGES, 32, 1280, 14795, 1, mf.OUT_SOFTMAX
-        if kind == "perch_v2":
+        if kind in ("perch_v2", "perch_v2_nose"):   # ('perch_v2_nose': round 4's plan, the same stack without the gates -- what they cost is measured against it)
             # Sized after the reference's own figures for the published model: manifests/Perch-v2-Models.models.json size_bytes
             # 413 350 933 (fp32: ~103 M parameters) and README 42 against 183 segments/s for v2.4 on one CPU (4.4x the work).
             # [EXT] The paper names EfficientNet-B3 (12 M parameters); what the other ~90 M are cannot be read offline (a

@@ -884,8 +884,9 @@ def test_launches_of_a_few_segments_take_the_narrow_tiles_and_give_the_same_bits
 
 def test_squeeze_excite_and_swish_stack_matches_oracle(model_dir, oracle_lib):
     """The EfficientNet original: swish activations and a squeeze-excite gate (pool -> 1x1 -> swish -> 1x1 -> sigmoid -> multiply)
-    in every block.  Such blocks do not run fused (the fused kernel's activation is GELU and the gate sits between the depthwise
-    and the project conv): they take the layer kernels + the gate kernel, correct in every precision mode."""
+    in every block.  Round 5: such blocks run as pass A of the fused kernel (expand -> depthwise, the depthwise output to HBM once,
+    per-tile channel sums), one gate launch and a project GEMM on D x gate -- against the oracle in every precision mode, and against
+    the same blocks run layer by layer (BIRDA_HIP_FUSE_SE=0: expand / depthwise / pool / 1x1 / 1x1 / scale / project)."""
     from birda_amd import synth
     from birda_amd.classifier import BirdClassifier
     path, labels, m, _ = model_dir["mini_se"]
@@ -894,13 +895,31 @@ def test_squeeze_excite_and_swish_stack_matches_oracle(model_dir, oracle_lib):
     segs = synth.synth_segments(5, m.sample_count, m.sample_rate, start=21)
     ref = oracle_lib.OracleModel(path).forward(segs)
     scale = max(1.0, float(np.abs(ref).max()))
-    for prec, tol in (("f32", LOGIT_RTOL), ("f16x3", LOGIT_RTOL), ("f16", F16_LOGIT_RTOL)):
+    for prec, tol in (("f32", LOGIT_RTOL), ("f16x3", LOGIT_RTOL), ("auto", LOGIT_RTOL), ("f16", F16_LOGIT_RTOL)):
         clf = BirdClassifier(path, labels, precision=prec)
-        assert clf.fused_blocks() == []
+        assert len(clf.fused_blocks()) >= 2, (prec, clf.fused_blocks())
         ctx = clf.create_batch_context(3)
         got = clf.predict_logits(ctx, segs)
         assert np.isfinite(got).all() and np.abs(got - ref).max() <= tol * scale, (prec, float(np.abs(got - ref).max()))
+        again = clf.predict_logits(ctx, segs)          # (fixed summation order in the pooled sums: run to run, bit for bit)
+        assert (again == got).all()
         ctx.close(); clf.close()
+    import subprocess, sys, textwrap
+    # the layer-by-layer path of the same blocks, in a process of its own (the switch is read once per process)
+    code = textwrap.dedent(f"""
+        import numpy as np, sys
+        sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+        from birda_amd import synth
+        from birda_amd.classifier import BirdClassifier
+        clf = BirdClassifier({path!r}, None, precision="f16x3")
+        assert clf.fused_blocks() == [], clf.fused_blocks()
+        ctx = clf.create_batch_context(3)
+        m = clf.info
+        np.save({str(path) + ".layers.npy"!r}, clf.predict_logits(ctx, synth.synth_segments(5, m.sample_count, m.sample_rate, start=21)))
+    """)
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, BIRDA_HIP_FUSE_SE="0"), timeout=300)
+    layers = np.load(str(path) + ".layers.npy")
+    assert np.abs(layers - ref).max() <= LOGIT_RTOL * scale
 
 
 def test_fused_head_pool_on_a_small_arena(model_dir, oracle_lib):
