@@ -213,6 +213,15 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
                 ctx_mark(ctx, ST_MBCONV, (int)i);
                 float *gate = T(S.iPw2 + 1);
                 const int P = d.Ho * d.Wo;
+                // (the pool + the two dense layers as GEMMs over all segments, through the arena slots of the layers they stand for --
+                //  whatever the launch size: a segment's gate is then the same bits in a launch of 3 and of 1 000.  The one-launch
+                //  se_gate_kernel, a workgroup per segment, is kept for A/B: BIRDA_HIP_SE_GATE1=1 in the EXPERIMENTS build.)
+                static const bool gate1 = [] { const char *e = BH_XENV("BIRDA_HIP_SE_GATE1"); return e && e[0] == '1'; }();
+                if (!gate1)
+                    bh::launch_se_gate_gemm(d.pool_part, d.tiles_x * d.tiles_y, P, T(S.iGap + 1), T(S.iPw1 + 1), c->d_w[S.iPw1], c->d_blob + G1.b_off,
+                                            c->ldw[S.iPw1], (int)G1.act, c->d_w[S.iPw2], c->d_blob + G2.b_off, c->ldw[S.iPw2], (int)G2.act, gate, (int)n,
+                                            d.Cexp, (int)G1.cout, s);
+                else
                 bh::launch_se_gate(d.pool_part, d.tiles_x * d.tiles_y, P, c->d_w[S.iPw1], c->d_blob + G1.b_off, c->ldw[S.iPw1], (int)G1.act,
                                    c->d_w[S.iPw2], c->d_blob + G2.b_off, c->ldw[S.iPw2], (int)G2.act, gate, (int)n, d.Cexp, (int)G1.cout, s);
                 ctx_mark(ctx, ST_GAP, (int)S.iGap);

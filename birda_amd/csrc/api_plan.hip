@@ -468,11 +468,13 @@ int plan_fusion(bh_classifier *c) {
             bh::MbDesc tw{};
             tw.cfg = -1;
             static const bool no_twin = BH_XENV("BIRDA_HIP_MB_TWIN") && BH_XENV("BIRDA_HIP_MB_TWIN")[0] == '0';   // (A/B aid)
-            if (force_cfg < 0 && !no_twin && bh::mb_plan_twin(d, tw)) c->mb_small.push_back(tw);
+            // (squeeze-excite blocks keep ONE tiling: the pooled sums are added tile by tile, and a segment's logits must not depend
+            //  on the size of the launch it ran in)
+            if (force_cfg < 0 && !no_twin && !d.se && bh::mb_plan_twin(d, tw)) c->mb_small.push_back(tw);
             else { tw.cfg = -1; c->mb_small.push_back(tw); }
             bh::MbDesc nw{};
             nw.cfg = -1;
-            if (!(force_cfg < 0 && !no_twin && bh::mb_plan_narrow(d, nw))) nw.cfg = -1;
+            if (!(force_cfg < 0 && !no_twin && !d.se && bh::mb_plan_narrow(d, nw))) nw.cfg = -1;
             c->mb_narrow.push_back(nw);
             // (squeeze-excite: the slot of the per-tile channel sums holds whichever of the three tilings has the most tiles)
             size_t tiles = (size_t)d.tiles_x * d.tiles_y;

@@ -384,6 +384,9 @@ void launch_pw_gemm16_gated(const float *A, const float *gate, int rows_per_seg,
 // ... and the gate itself: pool (from the per-tile channel sums of mbconv pass A, part [n][tiles][C]) -> 1x1 (C -> Cr, act1) -> 1x1
 // (Cr -> C, act2), one launch, fixed summation order
 bool se_gate_supports(int C, int Cr);
+// (the same gate as three launches -- the pool, then the two dense layers as GEMMs over all segments: launches of many segments)
+void launch_se_gate_gemm(const float *part, int tiles, int P, float *pooled, float *hidden, const float *W1, const float *b1, int ld1, int act1,
+                         const float *W2, const float *b2, int ld2, int act2, float *gate, int n_seg, int C, int Cr, hipStream_t s);
 void launch_se_gate(const float *part, int tiles, int P, const float *W1, const float *b1, int ld1, int act1, const float *W2, const float *b2,
                     int ld2, int act2, float *gate, int n_seg, int C, int Cr, hipStream_t s);
 // global average pool [n][P][C] -> [n][C]

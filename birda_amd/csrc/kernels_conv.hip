@@ -314,17 +314,21 @@ __global__ __launch_bounds__(256) void pw_gemm16_kernel(const float *__restrict_
 // segment's gate[n][K] in registers before the f16 split (the graph's Mul, without a pass of its own), and K may be any multiple
 // of 4 (the expanded widths of EfficientNet stacks: 144, 816, 1 392 ...): the last 32-deep step loads zeros beyond K, the planes
 // are zero-padded on the host.
-template <int TERMS, int ACT, bool GATE = false>
+// NTB: column tiles (of 16) per workgroup -- 8 for the dense layers; the gated project convolutions pick 6, 8 or 10 to fit N = 96, 136,
+// 232, 384 with little padding (wave (wm, wn) owns 64 rows x NTB / 2 column tiles)
+template <int TERMS, int ACT, bool GATE = false, int NTB = 8>
 __global__ __launch_bounds__(256, 2) void pw_gemm16s_kernel(const float *__restrict__ A, const f16x8 *__restrict__ Wf,
                                                             const float *__restrict__ bias, const float *__restrict__ R,
                                                             float *__restrict__ C, int M, int K, int N, int n_tiles, float w_unscale,
                                                             const float *__restrict__ gate = nullptr, int rows_per_seg = 1) {
-    extern __shared__ __attribute__((aligned(16))) float gsm[];   // [2 stages]{A: [8 row tiles]{hi, lo}[64 lanes][4], B: [8 column tiles]{hi, lo}[64][4]}
-    constexpr int STAGE = 2 * 8 * 2 * 256;                        // floats per stage (32 KB)
+    extern __shared__ __attribute__((aligned(16))) float gsm[];   // [2 stages]{A: [8 row tiles]{hi, lo}[64 lanes][4], B: [NTB column tiles]{hi, lo}[64][4]}
+    constexpr int STAGE = (8 + NTB) * 2 * 256;                    // floats per stage (32 KB at NTB = 8)
+    constexpr int NJ = NTB / 2;                                   // column tiles per wave
+    static_assert(NTB % 2 == 0 && NTB >= 2 && NTB <= 12, "column tiles per workgroup");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;
-    const int n_xb = (n_tiles + 7) / 8, n_yb = (M + 127) / 128;   // (block order: see pw_gemm16_kernel)
+    const int n_xb = (n_tiles + NTB - 1) / NTB, n_yb = (M + 127) / 128;   // (block order: see pw_gemm16_kernel)
     int yb, xb;
     if constexpr (GATE) {
         // few column blocks (a project convolution: N = 24 .. 384) and very many row blocks: dealt in launch order, which
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm16s_kernel(const float *__restr
         yb = slot % n_yb; xb = (slot / n_yb) * 8 + xcd;
         if (xb >= n_xb) return;
     }
-    const int mb0 = yb * 128, tb0 = xb * 8;
+    const int mb0 = yb * 128, tb0 = xb * NTB;
     const int steps = GATE ? (K + 31) / 32 : K / 32;
     const unsigned lds0 = (__builtin_amdgcn_groupstaticsize() + 15u) & ~15u;
     const int ws = __builtin_amdgcn_readfirstlane(wave);
@@ -387,10 +391,11 @@ __global__ __launch_bounds__(256, 2) void pw_gemm16s_kernel(const float *__restr
             if (TERMS == 3) *reinterpret_cast<f16x8 *>(as + adst[q] + 256) = l;
         }
     };
-    auto dma_b = [&](int st, int buf) {   // 16 (8) pieces of 1 KiB: wave w takes column tiles w and w + 4
+    auto dma_b = [&](int st, int buf) {   // 2 NTB (NTB) pieces of 1 KiB: wave w takes column tiles w, w + 4, ...
 #pragma unroll
-        for (int jj = 0; jj < 2; jj++) {
+        for (int jj = 0; jj < (NTB + 3) / 4; jj++) {
             const int j = ws + 4 * jj, t = min(tb0 + j, n_tiles - 1);
+            if (j >= NTB) continue;     // (wave-uniform)
 #pragma unroll
             for (int pl = 0; pl < (TERMS == 3 ? 2 : 1); pl++) {
                 const f16x8 *src = Wf + (((size_t)st * n_tiles + t) * 2 + pl) * 64;
@@ -401,11 +406,11 @@ __global__ __launch_bounds__(256, 2) void pw_gemm16s_kernel(const float *__restr
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     dma_b(0, 0);
     load_a(0);
@@ -417,21 +422,21 @@ __global__ __launch_bounds__(256, 2) void pw_gemm16s_kernel(const float *__restr
         const bool more = st + 1 < steps;   // (uniform)
         if (more) { dma_b(st + 1, cur ^ 1); load_a(st + 1); }
         const float *as = gsm + cur * STAGE, *bs = as + 8 * 2 * 256;
-        f16x8 ah[4], al[4], bh[4], bl[4];
+        f16x8 ah[4], al[4], bh[NJ], bl[NJ];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             ah[i] = *reinterpret_cast<const f16x8 *>(as + (((wm * 4 + i) * 2) * 64 + lane) * 4);
             if (TERMS == 3) al[i] = *reinterpret_cast<const f16x8 *>(as + (((wm * 4 + i) * 2 + 1) * 64 + lane) * 4);
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            bh[j] = *reinterpret_cast<const f16x8 *>(bs + (((wn * 4 + j) * 2) * 64 + lane) * 4);
-            if (TERMS == 3) bl[j] = *reinterpret_cast<const f16x8 *>(bs + (((wn * 4 + j) * 2 + 1) * 64 + lane) * 4);
+        for (int j = 0; j < NJ; j++) {
+            bh[j] = *reinterpret_cast<const f16x8 *>(bs + (((wn * NJ + j) * 2) * 64 + lane) * 4);
+            if (TERMS == 3) bl[j] = *reinterpret_cast<const f16x8 *>(bs + (((wn * NJ + j) * 2 + 1) * 64 + lane) * 4);
         }
 #pragma unroll
         for (int i = 0; i < 4; i++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < NJ; j++) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 if (TERMS == 3) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
@@ -442,9 +447,9 @@ __global__ __launch_bounds__(256, 2) void pw_gemm16s_kernel(const float *__restr
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
-    const int m0 = mb0 + wm * 64, t0 = tb0 + wn * 4;
+    const int m0 = mb0 + wm * 64, t0 = tb0 + wn * NJ;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < NJ; j++) {
         const int col = (t0 + j) * 16 + li;
         if (col >= N) continue;
         const float bv = bias[col];
@@ -569,18 +574,27 @@ void launch_pw_gemm16_gated(const float *A, const float *gate, int rows_per_seg,
 #undef BH_THIN
         return;
     }
-    const int n_xb = (n_tiles + 7) / 8, n_yb = (M + 127) / 128;
-    dim3 grid((unsigned)(n_xb * n_yb)), block(256);
-    constexpr size_t kStagedLds = 2 * (2 * 8 * 2 * 256) * sizeof(float);
-    if (terms == 3) {
-        static DeviceOnce attr;
-        attr.run([] { (void)hipFuncSetAttribute((const void *)pw_gemm16s_kernel<3, ACT_NONE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStagedLds); });
-        hipLaunchKernelGGL((pw_gemm16s_kernel<3, ACT_NONE, true>), grid, block, kStagedLds, s, A, (const f16x8 *)Wf, bias, R, C, M, K, N, n_tiles, w_unscale, gate, rows_per_seg);
-    } else {
-        static DeviceOnce attr;
-        attr.run([] { (void)hipFuncSetAttribute((const void *)pw_gemm16s_kernel<1, ACT_NONE, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStagedLds); });
-        hipLaunchKernelGGL((pw_gemm16s_kernel<1, ACT_NONE, true>), grid, block, kStagedLds, s, A, (const f16x8 *)Wf, bias, R, C, M, K, N, n_tiles, w_unscale, gate, rows_per_seg);
+    // column tiles per workgroup: the width that pads N least (96 -> 6, 136 -> 10, 232 -> 8 + 8, 384 -> 3 x 8); ties go to the wider
+    int ntb = 8;
+    {
+        long best = -1;
+        for (int cand : {10, 8, 6}) {
+            const long padded = (long)((n_tiles + cand - 1) / cand) * cand;
+            if (best < 0 || padded < best) { best = padded; ntb = cand; }
+        }
     }
+    const int n_xb = (n_tiles + ntb - 1) / ntb, n_yb = (M + 127) / 128;
+    dim3 grid((unsigned)(n_xb * n_yb)), block(256);
+#define BH_GS(T, NTBV)                                                                                                            \
+    do {                                                                                                                          \
+        constexpr size_t lds = 2 * ((8 + NTBV) * 2 * 256) * sizeof(float);                                                       \
+        static DeviceOnce attr;                                                                                                   \
+        attr.run([] { (void)hipFuncSetAttribute((const void *)pw_gemm16s_kernel<T, ACT_NONE, true, NTBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }); \
+        hipLaunchKernelGGL((pw_gemm16s_kernel<T, ACT_NONE, true, NTBV>), grid, block, lds, s, A, (const f16x8 *)Wf, bias, R, C, M, K, N, n_tiles, w_unscale, gate, rows_per_seg); \
+    } while (0)
+    if (terms == 3) { if (ntb == 6) BH_GS(3, 6); else if (ntb == 10) BH_GS(3, 10); else BH_GS(3, 8); }
+    else { if (ntb == 6) BH_GS(1, 6); else if (ntb == 10) BH_GS(1, 10); else BH_GS(1, 8); }
+#undef BH_GS
 }
 
 void launch_pw_gemm16(const float *A, const void *Wf, const float *bias, const float *R, float *C, int M, int K, int N,
@@ -956,6 +970,28 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float *__restrict__ 
 }
 
 bool se_gate_supports(int C, int Cr) { return C >= 1 && Cr >= 1 && Cr <= 256 && C <= 16384; }
+
+// the pool alone: pooled[n][C] = (sum over tiles of part[n][tiles][C]) / P, tiles in index order (fixed)
+__global__ __launch_bounds__(256) void se_pool_kernel(const float *__restrict__ part, int tiles, float inv_p, float *__restrict__ pooled, int n_seg, int C) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)n_seg * C) return;
+    const size_t seg = i / C, c = i - seg * C;
+    const float *ps = part + seg * tiles * C + c;
+    float sum = 0.0f;
+    for (int t = 0; t < tiles; t++) sum += ps[(size_t)t * C];
+    pooled[i] = sum * inv_p;
+}
+
+// The gate for a LARGE launch: the two dense layers as GEMMs over all segments (the per-segment kernel above re-reads both weight
+// matrices for every segment -- 1.8 MB at C = 2 304 -- and runs their dot products as serial loops: 0.5 us per segment for the last
+// block alone), pooled and hidden in the arena slots of the layers they stand for
+void launch_se_gate_gemm(const float *part, int tiles, int P, float *pooled, float *hidden, const float *W1, const float *b1, int ld1, int act1,
+                         const float *W2, const float *b2, int ld2, int act2, float *gate, int n_seg, int C, int Cr, hipStream_t s) {
+    const size_t n = (size_t)n_seg * C;
+    hipLaunchKernelGGL(se_pool_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, tiles, 1.0f / (float)P, pooled, n_seg, C);
+    launch_pw_gemm(pooled, W1, b1, nullptr, hidden, n_seg, C, Cr, ld1, act1, s);
+    launch_pw_gemm(hidden, W2, b2, nullptr, gate, n_seg, Cr, C, ld2, act2, s);
+}
 
 void launch_se_gate(const float *part, int tiles, int P, const float *W1, const float *b1, int ld1, int act1, const float *W2, const float *b2,
                     int ld2, int act2, float *gate, int n_seg, int C, int Cr, hipStream_t s) {
