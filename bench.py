@@ -177,6 +177,78 @@ def pmc_traffic(kernel_key):
     return None
 
 
+def se_blocks(m):
+    """The squeeze-excite blocks of a layer table as the library matches them (api_plan.hip match_se_block): [expand | stem] ->
+    depthwise -> pool -> 1x1 -> 1x1 -> scale -> project.  Returns (first layer, depthwise, pool, project) index tuples."""
+    from birda_amd import modelfile as mf
+    L, out, i = m.layers, [], 0
+    while i < len(L):
+        noexp = L[i].op == mf.OP_DWCONV
+        d = i if noexp else i + 1
+        if (d + 5 < len(L) and L[d].op == mf.OP_DWCONV and L[d + 1].op == mf.OP_GAP and L[d + 2].op == mf.OP_PWCONV and L[d + 3].op == mf.OP_PWCONV
+                and L[d + 4].op == mf.OP_SCALE and L[d + 5].op == mf.OP_PWCONV and (noexp or L[i].op in (mf.OP_PWCONV, mf.OP_CONV))):
+            out.append((i, d, d + 1, d + 5))
+            i = d + 6
+        else:
+            i += 1
+    return out
+
+
+def analyse_se(clf, m, fused, layer_tot, segs_done, steps, slices_per_step, precision):
+    """The per-kernel picture of a plan whose blocks carry squeeze-excite gates (config 4, round 5): every block is pass A of the
+    fused kernel (booked on the block's first layer), the gate (booked on the pool layer) and the gated project GEMM (booked on the
+    project layer).  `roofline` = the kernel with the largest total time; for the Perch-sized plan that is the streaming gated GEMM
+    of the early blocks -- bound by HBM: per pixel it reads the K floats of the depthwise output (and N of the residual) and writes N."""
+    from birda_amd import modelfile as mf
+    per_step = steps * slices_per_step
+    groups, a_us, b_us, g_us = {}, {}, {}, 0.0
+    fi = 0
+    for (i0, d, g, p) in se_blocks(m):
+        if layer_tot[i0][1] == 0 or layer_tot[p][1] == 0 or (i0 != d and layer_tot[d][1] != 0):
+            continue    # (not run as a fused squeeze-excite block)
+        E, D, P = m.layers[i0], m.layers[d], m.layers[p]
+        px = D.out_h * D.out_w
+        kname = clf.fused_kernel_name(fused[fi]) if fi < len(fused) else "mbconv<?>"
+        fi += 1
+        a_macs = (0 if i0 == d else (E.out_h * E.out_w * (E.kh * E.kw * E.cin) * E.cout)) + px * D.kh * D.kw * D.cout
+        ga = groups.setdefault(("A", kname), {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0, "kind": "mfma"})
+        ga["ms"] += layer_tot[i0][0]; ga["launches"] += layer_tot[i0][1]; ga["flops"] += 2.0 * a_macs * segs_done
+        a_us[kname] = a_us.get(kname, 0.0) + layer_tot[i0][0] * 1e3 / segs_done * 1000
+        g_us += layer_tot[g][0] * 1e3 / segs_done * 1000
+        K, N = P.cin, P.cout
+        nt = -(-N // 16)
+        thin = nt <= 3 and -(-K // 32) * nt * 2048 <= 65536 and px * (segs_done // per_step) >= 4096
+        bname = ("pw_gemm16_thin_kernel<3, %d>" % nt) if (thin and precision != "f32") else ("gated project GEMM %d -> %d" % (K, N))
+        gb = groups.setdefault(("B", bname), {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0, "kind": "hbm" if thin else "mfma"})
+        gb["ms"] += layer_tot[p][0]; gb["launches"] += layer_tot[p][1]
+        gb["flops"] += 2.0 * px * K * N * segs_done
+        gb["bytes"] += 4.0 * px * (K + N + (N if P.res_tensor != mf.NO_TENSOR else 0)) * segs_done
+        b_us["%d->%d @%dx%d" % (K, N, D.out_h, D.out_w)] = b_us.get("%d->%d @%dx%d" % (K, N, D.out_h, D.out_w), 0.0) + layer_tot[p][0] * 1e3 / segs_done * 1000
+    out = {}
+    if not groups:
+        return out
+    (kind, name), dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
+    avg_us = dom["ms"] * 1e3 / max(dom["launches"], 1)
+    if dom["kind"] == "hbm":
+        gbps = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+        out["roofline"] = {"kernel": name + " (gated project convolution of the early squeeze-excite blocks: D x gate -> 1x1, streaming)",
+                           "bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
+                           "traffic": pmc_traffic("bh::" + name), "rocprof_name": "bh::" + name, "launches": dom["launches"], "avg_launch_us": round(avg_us, 2),
+                           "algorithmic_gb_per_launch": round(dom["bytes"] / max(dom["launches"], 1) / 1e9, 4),
+                           "algorithmic_bytes": "per pixel: K floats of the depthwise output read + N written (+ N of the residual read)"}
+    else:
+        peak = PEAK_F32_MFMA_TFLOPS if precision == "f32" else PEAK_F16_MFMA_TFLOPS / (3.0 if precision in ("auto", "f16x3") else 1.0)
+        tflops = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        out["roofline"] = {"kernel": ("mbconv_kernel pass A (expand -> depthwise of a squeeze-excite block) " if kind == "A" else "") + name,
+                           "bound": "mfma", "achieved": round(tflops, 2), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(tflops / peak, 4),
+                           "traffic": None, "launches": dom["launches"], "avg_launch_us": round(avg_us, 2)}
+    out["squeeze_excite"] = {"blocks": fi, "pass_a_us_per_1000_segments": {k: round(v, 1) for k, v in a_us.items()},
+                             "gate_us_per_1000_segments": round(g_us, 1),
+                             "gated_project_us_per_1000_segments": {k: round(v, 1) for k, v in b_us.items()},
+                             "us_per_segment": {"pass_a": round(sum(a_us.values()) / 1000, 3), "gate": round(g_us / 1000, 3), "gated_project": round(sum(b_us.values()) / 1000, 3)}}
+    return out
+
+
 def analyse(clf, m, info, fused, stage_tot, layer_tot, segs_done, steps, slices_per_step, precision):
     """Roofline objects from the HIP-event timings of one timed region."""
     from birda_amd import modelfile as mf
@@ -290,6 +362,8 @@ def analyse(clf, m, info, fused, stage_tot, layer_tot, segs_done, steps, slices_
                                        "launches": mb_launches, "us_per_segment": round(mb_ms * 1e3 / segs_done, 3)}
             out["fused_block_us_per_1000_segments"] = {g["kernel"]: round(g["ms"] * 1e3 / segs_done * 1000 / max(1, g["launches"] // (steps * slices_per_step)), 1)
                                                        for g in groups.values()}
+    if "roofline" not in out and fused and any(L.op == mf.OP_SCALE for L in layers):
+        out.update(analyse_se(clf, m, fused, layer_tot, segs_done, steps, slices_per_step, precision))
     mel_ms, mel_launches = stage_tot["mel"]
     mel_b = mel_bytes_per_segment(m)
     mel_gbps = mel_b * segs_done / (mel_ms * 1e-3) / 1e9

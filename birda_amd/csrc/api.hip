@@ -489,6 +489,13 @@ std::vector<size_t> sub_slice_cuts(const bh_classifier *c, size_t nb, size_t ali
         size_t v0 = sub;
         if (first && first < sub && nb >= 512) { cuts.push_back(up(first)); v0 = up(first) + sub; }
         for (size_t v = v0; v + 64 <= nb; v += sub) cuts.push_back(v);   // (a tail under 64 segments joins the last sub-slice)
+        // the upload is the LONGER side (f32 segments): what is left when the last byte has arrived is the last sub-slice's forward,
+        // so that one is kept short -- 64 segments (a forward of 64 lasts 0.9 ms, one of 128 1.2: tools/gpu_latency.py)
+        if (upload_us >= compute_us && first_env < 0) {
+            const size_t last = cuts.empty() ? 0 : cuts.back();
+            const size_t tail = (nb - 64) / align * align;
+            if (tail > last + 32 && nb - tail >= 32) cuts.push_back(tail);
+        }
     } else
     if (!single && nb >= 512) {
         const double upload_us = (double)bytes_per_segment / 55e3;
@@ -597,28 +604,30 @@ int predict_slices(bh_classifier *c, bh_batch_context *ctx, const float *const *
             HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             ctx->copy_ev.push_back(e);
         }
-        auto gather = [&](size_t j) {
+        // Every worker takes ITS share of every chunk, chunk after chunk (round 5): with one whole chunk per thread the first eight
+        // chunks all completed together, 1.3 ms into a 512-segment call, and the upload -- the longer side -- started that late.
+        // Now chunk 0 is on the copy stream after a few segments' worth of copying.  Streaming stores: bh_internal_stream_copy.
+        auto gather_part = [&](size_t j, unsigned t, unsigned nt) {
             const size_t i1 = std::min(nb, (j + 1) * CH);
-            for (size_t i = j * CH; i < i1; i++) {
+            for (size_t i = j * CH + t; i < i1; i += nt) {
                 const float *src = segments ? segments[b0 + i] : contig + (b0 + i) * S;
-                memcpy(ctx->h_input + i * S, src, S * sizeof(float));
+                bh_internal_stream_copy(ctx->h_input + i * S, src, S * sizeof(float));
             }
         };
-        const unsigned nthreads = pinned_src ? 1u : (unsigned)std::min<size_t>(copy_threads(), nchunks);
+        const unsigned nthreads = pinned_src ? 1u : (unsigned)std::min<size_t>(copy_threads(), CH);
         std::vector<std::atomic<int>> done(nchunks);
         for (auto &d : done) d.store(0, std::memory_order_relaxed);
-        std::atomic<size_t> next{0};
         std::vector<std::thread> workers;
         if (nthreads > 1)
-            for (unsigned t = 0; t < nthreads; t++)
-                workers.emplace_back([&] {
-                    for (size_t j; (j = next.fetch_add(1)) < nchunks;) { gather(j); done[j].store(1, std::memory_order_release); }
+            for (unsigned t = 1; t < nthreads; t++)
+                workers.emplace_back([&, t] {
+                    for (size_t j = 0; j < nchunks; j++) { gather_part(j, t, nthreads); done[j].fetch_add(1, std::memory_order_release); }
                 });
         int rc = BH_OK;
         size_t si_next = 0;
         for (size_t j = 0; j < nchunks && rc == BH_OK; j++) {
-            if (nthreads > 1) while (!done[j].load(std::memory_order_acquire)) std::this_thread::yield();
-            else if (!pinned_src) gather(j);
+            if (!pinned_src) gather_part(j, 0, nthreads);     // (the calling thread is worker 0)
+            if (nthreads > 1) while (done[j].load(std::memory_order_acquire) < (int)nthreads - 1) std::this_thread::yield();
             const size_t i0 = j * CH, i1 = std::min(nb, (j + 1) * CH);
             const float *h_src = pinned_src ? contig + (b0 + i0) * S : ctx->h_input + i0 * S;
             if (hipMemcpyAsync(ctx->d_input + i0 * S, h_src, (i1 - i0) * S * sizeof(float), hipMemcpyHostToDevice,
@@ -1722,24 +1731,28 @@ static int predict_pcm16_core(bh_classifier *c, bh_batch_context *ctx, const voi
             HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
             ctx->done_ev.push_back(e);
         }
-        const unsigned nthreads = staged ? (unsigned)std::min<size_t>(copy_threads(), npieces) : 1;
+        // (every worker its share of every piece, piece after piece: the first piece is on the copy stream at once; see predict_slices)
+        const unsigned nthreads = staged ? copy_threads() : 1;
         std::vector<std::atomic<int>> done(npieces);
         for (auto &d : done) d.store(0, std::memory_order_relaxed);
-        std::atomic<size_t> next{0};
-        auto gather = [&](size_t j) { const size_t o = j * PIECE; memcpy(stage + o, src + o, std::min(PIECE, bytes - o)); };
+        auto gather_part = [&](size_t j, unsigned t, unsigned nt) {
+            const size_t o = j * PIECE, len = std::min(PIECE, bytes - o);
+            const size_t share = ((len + nt - 1) / nt + 4095) & ~(size_t)4095, a = std::min(len, (size_t)t * share), b = std::min(len, a + share);
+            if (b > a) bh_internal_stream_copy(stage + o + a, src + o + a, b - a);
+        };
         std::vector<std::thread> workers;
         if (nthreads > 1)
-            for (unsigned t = 0; t < nthreads; t++)
-                workers.emplace_back([&] {
-                    for (size_t j; (j = next.fetch_add(1)) < npieces;) { gather(j); done[j].store(1, std::memory_order_release); }
+            for (unsigned t = 1; t < nthreads; t++)
+                workers.emplace_back([&, t] {
+                    for (size_t j = 0; j < npieces; j++) { gather_part(j, t, nthreads); done[j].fetch_add(1, std::memory_order_release); }
                 });
         size_t si = 0;   // next sub-slice to launch
         rc = BH_OK;
         for (size_t j = 0; j < npieces && rc == BH_OK; j++) {
             size_t sent;   // bytes of the span on the copy stream after this piece
             if (staged) {
-                if (nthreads > 1) while (!done[j].load(std::memory_order_acquire)) std::this_thread::yield();
-                else gather(j);
+                gather_part(j, 0, nthreads);     // (the calling thread is worker 0)
+                if (nthreads > 1) while (done[j].load(std::memory_order_acquire) < (int)nthreads - 1) std::this_thread::yield();
                 const size_t o = j * PIECE, len = std::min(PIECE, bytes - o);
                 if (hipMemcpyAsync(reinterpret_cast<char *>(ctx->d_pcm) + o, stage + o, len, hipMemcpyHostToDevice, ctx->copy_stream) != hipSuccess)
                     { rc = fail(BH_ERR_HIP, "predict_pcm16: upload failed"); break; }

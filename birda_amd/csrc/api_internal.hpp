@@ -180,6 +180,9 @@ struct bh_batch_context {
     uint32_t stage_launches[BH_N_STAGES] = {0};
 };
 
+// host_pipeline.cpp: memcpy into pinned staging memory with non-temporal stores (what the DMA engine, not a core, reads next)
+extern "C" void bh_internal_stream_copy(void *dst, const void *src, size_t bytes);
+
 namespace bhi {
 
 // api_plan.hip

@@ -479,7 +479,7 @@ bool pw_gemm16_supports(int K, int act) { return K % 32 == 0 && (act == ACT_NONE
 // the MFMA as the A operand -- no staging of A at all.  The next k step's loads are in flight while this one computes.
 // ---------------------------------------------------------------------------------------
 template <int TERMS, int NT>
-__global__ __launch_bounds__(512, 4) void pw_gemm16_thin_kernel(const float *__restrict__ A, const float *__restrict__ gate, int rows_per_seg,
+__global__ __launch_bounds__(512, 2) void pw_gemm16_thin_kernel(const float *__restrict__ A, const float *__restrict__ gate, int rows_per_seg,
                                                                  const f16x8 *__restrict__ Wf, const float *__restrict__ bias,
                                                                  const float *__restrict__ R, float *__restrict__ C, int M, int K, int N,
                                                                  float w_unscale) {
@@ -497,59 +497,85 @@ __global__ __launch_bounds__(512, 4) void pw_gemm16_thin_kernel(const float *__r
     const f16x8 *wf = reinterpret_cast<const f16x8 *>(tsm);
     const int n_rt = (M + 15) >> 4;
     const float rcp_p = 1.0f / (float)rows_per_seg;
-    for (int rt = blockIdx.x * 8 + wave; rt < n_rt; rt += gridDim.x * 8) {
-        const int row = min(rt * 16 + li, M - 1);                       // rows past M: clamped, never stored
-        int seg = (int)((float)row * rcp_p);                            // row / rows_per_seg through the reciprocal, fixed up
-        seg += (row - seg * rows_per_seg >= rows_per_seg) ? 1 : 0;
-        seg -= (row - seg * rows_per_seg < 0) ? 1 : 0;
-        const float *ap = A + (size_t)row * K + 8 * kq, *gp = gate + (size_t)seg * K + 8 * kq;
-        f32x4 acc[NT];
+    // RB row tiles per wave and pass, their loads issued together: one tile at a time exposed a whole HBM round trip per 16 rows
+    // (K = 24: one k step, nothing to prefetch under) -- 1.9 ms per 1 000 segments for the 24 -> 24 block, 2.4 TB/s
+    constexpr int RB = NT <= 2 ? 4 : 3;
+    for (int rt0 = (blockIdx.x * 8 + wave) * RB; rt0 < n_rt; rt0 += gridDim.x * 8 * RB) {
+        const float *ap[RB], *gp[RB];
 #pragma unroll
-        for (int j = 0; j < NT; j++) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        float4 ra[2], rg[2], na[2], ng[2];
-        auto load = [&](int st, float4 (&a)[2], float4 (&g)[2]) {
+        for (int r = 0; r < RB; r++) {
+            const int row = min((rt0 + r) * 16 + li, M - 1);                // rows past M: clamped, never stored
+            int seg = (int)((float)row * rcp_p);                            // row / rows_per_seg through the reciprocal, fixed up
+            seg += (row - seg * rows_per_seg >= rows_per_seg) ? 1 : 0;
+            seg -= (row - seg * rows_per_seg < 0) ? 1 : 0;
+            ap[r] = A + (size_t)row * K + 8 * kq;
+            gp[r] = gate + (size_t)seg * K + 8 * kq;
+        }
+        f32x4 acc[RB][NT];
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const bool in = 32 * st + 8 * kq + 4 * h < K;       // (K % 4 == 0)
-                a[h] = *reinterpret_cast<const float4 *>(ap + (in ? 32 * st + 4 * h : 0));
-                g[h] = *reinterpret_cast<const float4 *>(gp + (in ? 32 * st + 4 * h : 0));
-                if (!in) { a[h] = make_float4(0.f, 0.f, 0.f, 0.f); g[h] = a[h]; }
-            }
+        for (int r = 0; r < RB; r++)
+#pragma unroll
+            for (int j = 0; j < NT; j++) acc[r][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float4 ra[RB][2], rg[RB][2];    // (no second register set: RB tiles x 8 waves in flight per CU cover the round trip)
+        auto load = [&](int st, float4 (&a)[RB][2], float4 (&g)[RB][2]) {
+#pragma unroll
+            for (int r = 0; r < RB; r++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const bool in = 32 * st + 8 * kq + 4 * h < K;       // (K % 4 == 0)
+                    a[r][h] = *reinterpret_cast<const float4 *>(ap[r] + (in ? 32 * st + 4 * h : 0));
+                    g[r][h] = *reinterpret_cast<const float4 *>(gp[r] + (in ? 32 * st + 4 * h : 0));
+                    if (!in) { a[r][h] = make_float4(0.f, 0.f, 0.f, 0.f); g[r][h] = a[r][h]; }
+                }
         };
-        load(0, ra, rg);
         for (int st = 0; st < steps; st++) {
-            if (st + 1 < steps) load(st + 1, na, ng);
-            const float v[8] = {ra[0].x * rg[0].x, ra[0].y * rg[0].y, ra[0].z * rg[0].z, ra[0].w * rg[0].w,
-                                ra[1].x * rg[1].x, ra[1].y * rg[1].y, ra[1].z * rg[1].z, ra[1].w * rg[1].w};
-            f16x8 ah, al;
-            bh_split8(v, ah, al);
+            load(st, ra, rg);
+            f16x8 ah[RB], al[RB];
+#pragma unroll
+            for (int r = 0; r < RB; r++) {
+                const float v[8] = {ra[r][0].x * rg[r][0].x, ra[r][0].y * rg[r][0].y, ra[r][0].z * rg[r][0].z, ra[r][0].w * rg[r][0].w,
+                                    ra[r][1].x * rg[r][1].x, ra[r][1].y * rg[r][1].y, ra[r][1].z * rg[r][1].z, ra[r][1].w * rg[r][1].w};
+                bh_split8(v, ah[r], al[r]);
+            }
 #pragma unroll
             for (int j = 0; j < NT; j++) {
                 const f16x8 bh = wf[((st * NT + j) * 2 + 0) * 64 + lane];
-                acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh, acc[j], 0, 0, 0);
-                if (TERMS == 3) {
-                    const f16x8 bl = wf[((st * NT + j) * 2 + 1) * 64 + lane];
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh, acc[j], 0, 0, 0);
-                }
-            }
-            if (st + 1 < steps) { ra[0] = na[0]; ra[1] = na[1]; rg[0] = ng[0]; rg[1] = ng[1]; }
-        }
+                f16x8 bl;
+                if (TERMS == 3) bl = wf[((st * NT + j) * 2 + 1) * 64 + lane];
 #pragma unroll
-        for (int j = 0; j < NT; j++) {
-            const int col = j * 16 + li;
-            if (col >= N) continue;
-            const float bv = bias[col];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int orow = rt * 16 + kq * 4 + r;
-                if (orow < M) {
-                    float v = __builtin_fmaf(acc[j][r], w_unscale, bv);
-                    if (R) v += R[(size_t)orow * N + col];
-                    C[(size_t)orow * N + col] = v;
+                for (int r = 0; r < RB; r++) {
+                    acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[r], bh, acc[r][j], 0, 0, 0);
+                    if (TERMS == 3) {
+                        acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[r], bl, acc[r][j], 0, 0, 0);
+                        acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[r], bh, acc[r][j], 0, 0, 0);
+                    }
                 }
             }
         }
+        // (the residual rows first, all at once, then the stores)
+        float resv[RB][NT][4];
+#pragma unroll
+        for (int r = 0; r < RB; r++)
+#pragma unroll
+            for (int j = 0; j < NT; j++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int col = j * 16 + li, orow = (rt0 + r) * 16 + kq * 4 + q;
+                    resv[r][j][q] = (R && col < N && orow < M) ? R[(size_t)orow * N + col] : 0.0f;
+                }
+#pragma unroll
+        for (int r = 0; r < RB; r++)
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                const int col = j * 16 + li;
+                if (col >= N) continue;
+                const float bv = bias[col];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int orow = (rt0 + r) * 16 + kq * 4 + q;
+                    if (orow < M) C[(size_t)orow * N + col] = __builtin_fmaf(acc[r][j][q], w_unscale, bv) + resv[r][j][q];
+                }
+            }
     }
 }
 
@@ -562,7 +588,7 @@ void launch_pw_gemm16_gated(const float *A, const float *gate, int rows_per_seg,
     const size_t w_bytes = (size_t)((K + 31) / 32) * n_tiles * 2 * 1024;
     if (n_tiles <= 3 && w_bytes <= 64 * 1024 && M >= 4096) {
         const int n_rt = (M + 15) / 16;
-        const int wgs = std::min((n_rt + 7) / 8, 2 * device_cu_count());     // two 8-wave workgroups per CU, walking the row tiles
+        const int wgs = std::min((n_rt + 31) / 32, 2 * device_cu_count());   // 8-wave workgroups walking the row tiles, 3-4 per wave and pass (one or two resident per CU)
 #define BH_THIN(T, NTV)                                                                                                            \
         do {                                                                                                                       \
             static DeviceOnce attr;                                                                                                \
