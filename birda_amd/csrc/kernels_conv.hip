@@ -552,17 +552,11 @@ __global__ __launch_bounds__(512, 2) void pw_gemm16_thin_kernel(const float *__r
                 }
             }
         }
-        // (the residual rows first, all at once, then the stores)
-        float resv[RB][NT][4];
-#pragma unroll
-        for (int r = 0; r < RB; r++)
-#pragma unroll
-            for (int j = 0; j < NT; j++)
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int col = j * 16 + li, orow = (rt0 + r) * 16 + kq * 4 + q;
-                    resv[r][j][q] = (R && col < N && orow < M) ? R[(size_t)orow * N + col] : 0.0f;
-                }
+        // Epilogue through LDS: the RB x 16 rows x N columns of this pass are ONE contiguous run of the output (row-major, N floats a
+        // row), so the wave parks its accumulators there as that run and then moves it with whole 16-byte accesses -- residual in,
+        // sums out.  Stored straight from the MFMA layout a 96-byte row (N = 24) went out as a 64- and a 32-byte piece per
+        // instruction, four rows at a time: 2.4 TB/s on the 24 -> 24 block.
+        float *ep = tsm + (size_t)steps * NT * 2 * 256 + (size_t)wave * (RB * 16 * NT * 16);
 #pragma unroll
         for (int r = 0; r < RB; r++)
 #pragma unroll
@@ -571,11 +565,20 @@ __global__ __launch_bounds__(512, 2) void pw_gemm16_thin_kernel(const float *__r
                 if (col >= N) continue;
                 const float bv = bias[col];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int orow = (rt0 + r) * 16 + kq * 4 + q;
-                    if (orow < M) C[(size_t)orow * N + col] = __builtin_fmaf(acc[r][j][q], w_unscale, bv) + resv[r][j][q];
-                }
+                for (int q = 0; q < 4; q++) ep[(r * 16 + kq * 4 + q) * N + col] = __builtin_fmaf(acc[r][j][q], w_unscale, bv);
             }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (wave-private LDS: in-order within the wave; this keeps the compiler from reordering)
+        __builtin_amdgcn_wave_barrier();
+        const int row0 = rt0 * 16, nrows = min(RB * 16, M - row0);
+        const int nflt = nrows * N;                                   // (N % 4 == 0: whole float4s)
+        float *cg = C + (size_t)row0 * N;
+        const float *rgp = R ? R + (size_t)row0 * N : nullptr;
+        for (int f = lane * 4; f < nflt; f += 256) {
+            float4 v = *reinterpret_cast<const float4 *>(ep + f);
+            if (rgp) { const float4 rr = *reinterpret_cast<const float4 *>(rgp + f); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
+            *reinterpret_cast<float4 *>(cg + f) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -586,14 +589,15 @@ void launch_pw_gemm16_gated(const float *A, const float *gate, int rows_per_seg,
     const int n_tiles = (N + 15) / 16;
     // few columns, all of W in LDS (<= 64 KB), many rows: the streaming kernel above
     const size_t w_bytes = (size_t)((K + 31) / 32) * n_tiles * 2 * 1024;
-    if (n_tiles <= 3 && w_bytes <= 64 * 1024 && M >= 4096) {
+    if (n_tiles <= 3 && w_bytes <= 64 * 1024 && M >= 4096 && N % 4 == 0) {
+        const size_t thin_lds = w_bytes + (size_t)8 * (n_tiles <= 2 ? 4 : 3) * 16 * n_tiles * 16 * sizeof(float);   // + the waves' epilogue tiles
         const int n_rt = (M + 15) / 16;
         const int wgs = std::min((n_rt + 31) / 32, 2 * device_cu_count());   // 8-wave workgroups walking the row tiles, 3-4 per wave and pass (one or two resident per CU)
 #define BH_THIN(T, NTV)                                                                                                            \
         do {                                                                                                                       \
             static DeviceOnce attr;                                                                                                \
-            attr.run([] { (void)hipFuncSetAttribute((const void *)pw_gemm16_thin_kernel<T, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024); }); \
-            hipLaunchKernelGGL((pw_gemm16_thin_kernel<T, NTV>), dim3(wgs), dim3(512), w_bytes, s, A, gate, rows_per_seg, (const f16x8 *)Wf, bias, R, C, M, K, N, w_unscale); \
+            attr.run([] { (void)hipFuncSetAttribute((const void *)pw_gemm16_thin_kernel<T, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); }); \
+            hipLaunchKernelGGL((pw_gemm16_thin_kernel<T, NTV>), dim3(wgs), dim3(512), thin_lds, s, A, gate, rows_per_seg, (const f16x8 *)Wf, bias, R, C, M, K, N, w_unscale); \
         } while (0)
         if (terms == 3) { if (n_tiles == 1) BH_THIN(3, 1); else if (n_tiles == 2) BH_THIN(3, 2); else BH_THIN(3, 3); }
         else { if (n_tiles == 1) BH_THIN(1, 1); else if (n_tiles == 2) BH_THIN(1, 2); else BH_THIN(1, 3); }
