@@ -505,6 +505,19 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
     f32x4 acco[MT_W][NT_W];
     // SE (pass A of a squeeze-excite block): where the depthwise output and the tile's channel sums go
     float *Dg = SE ? d.Dout + (size_t)seg0 * d.Ho * d.Wo * d.Cexp : nullptr;
+    // SE store phase: thread (channel quad tid % C4N, pixel tid / C4N + k NTH / C4N) -- the same pixels in every chunk, so their rows
+    // of D are looked up once per tile (nullptr: outside the image or the batch)
+    constexpr int SE_NP = SE ? (POUT_PAD + NTH / C4N - 1) / (NTH / C4N) : 1;
+    float *se_dst[SE_NP];
+    const int npix_pad = nsv * THTW;
+    if constexpr (SE) {
+#pragma unroll
+        for (int k = 0; k < SE_NP; k++) {
+            const int p0 = tid / C4N + k * (NTH / C4N);
+            const int o = p0 < npix_pad ? omap[p0] : -1;
+            se_dst[k] = o >= 0 ? Dg + (size_t)o * d.Cexp : nullptr;
+        }
+    }
     if constexpr (!SE)
 #pragma unroll
     for (int i = 0; i < MT_W; i++) {
@@ -550,8 +563,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
     };
     p2_task(tid);
 
-    // SE: the channel sums of chunk `se_pending` wait in LDS as per-wave partial sums (WpS: [slot][wave][CE]); thread (slot, channel)
-    // adds them in wave order and stores the tile's sum
+    // SE: the channel sums of chunk `se_pending` wait in LDS as partial sums per wave and row of 16 lanes (WpS: [slot][wave][row][CE]);
+    // thread (slot, channel) adds them in (wave, row) order and stores the tile's sum
     int se_pending = -1;
     auto se_flush = [&]() {
         if (se_pending >= 0 && tid < SS * CE) {
@@ -559,7 +572,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
             if (sl < nsv && se_pending * CE + c < d.Cexp) {
                 float sum = 0.0f;
 #pragma unroll
-                for (int w = 0; w < NW; w++) sum += WpS[(sl * NW + w) * CE + c];
+                for (int w = 0; w < NW * 4; w++) sum += WpS[(sl * NW * 4 + w) * CE + c];
                 d.pool_part[((size_t)(seg0 + sl) * tiles_xy + txy) * d.Cexp + se_pending * CE + c] = sum;
             }
         }
@@ -959,35 +972,40 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
             // ---- S: the chunk's depthwise output leaves for HBM, and its channel sums are taken on the way ----------------------
             // Thread = (channel quad c4 = tid % C4N, pixel p = tid / C4N, stepping by NTH / C4N): a pixel's CE channels are one
             // contiguous run in LDS and in D (64 or 128 bytes).  Sums: per thread over its pixels (one accumulator per segment
-            // slot), then across the lanes of the wave that share the quad (xor-shuffles: a fixed tree, no atomics -- identical
-            // segments give identical bits wherever they sit in a batch); lanes 0 .. C4N - 1 leave the wave's sums in LDS (the
-            // project weights' buffer, unused in this pass), and after the NEXT barrier one thread per channel adds the waves' up.
-            static_assert(64 % C4N == 0 && NTH % C4N == 0, "squeeze-excite pass A: the channel quads of a chunk divide a wave");
+            // slot), then across the lanes of a ROW of 16 that share the quad (row rotations folded into the adds: a fixed tree, no
+            // atomics -- identical segments give identical bits wherever they sit in a batch); lanes 0 .. C4N - 1 of every row leave
+            // the row's sums in LDS (the project weights' buffer, unused in this pass), and after the NEXT barrier one thread per
+            // channel adds the 4 NW of them up.  (A first version: xor-shuffles over the whole wave, 16 ds_bpermute per thread and
+            // chunk, and the D rows looked up per chunk: pass A of the early blocks 7-33 % SLOWER than the whole gate-free block.)
+            static_assert(16 % C4N == 0 && NTH % C4N == 0, "squeeze-excite pass A: the channel quads of a chunk divide a row of 16 lanes");
             const int c4 = tid % C4N, cg = ch * CE + 4 * c4;
-            const int npix = nsv * THTW;
             f32x4 ssum[SS];
 #pragma unroll
             for (int q = 0; q < SS; q++) ssum[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            for (int p0 = tid / C4N; p0 < npix; p0 += NTH / C4N) {
-                const int o = omap[p0];
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(&Ds[p0 * CES + 4 * c4]);
-                if (o >= 0) {
-                    if (cg < d.Cexp) *reinterpret_cast<f32x4 *>(Dg + (size_t)o * d.Cexp + cg) = v;
-                    if (SS == 1 || p0 < THTW) ssum[0] += v; else ssum[SS - 1] += v;
+#pragma unroll
+            for (int k = 0; k < SE_NP; k++) {
+                const int p0 = tid / C4N + k * (NTH / C4N);
+                if (p0 < npix_pad) {      // (uniform but for the last pass)
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(&Ds[p0 * CES + 4 * c4]);
+                    if (se_dst[k]) {
+                        if (cg < d.Cexp) *reinterpret_cast<f32x4 *>(se_dst[k] + cg) = v;
+                        if (SS == 1 || p0 < THTW) ssum[0] += v; else ssum[SS - 1] += v;
+                    }
                 }
             }
+            // lanes of a ROW of 16 that share the quad: rotations within the row, folded into the add (DPP: no LDS traffic)
 #pragma unroll
             for (int q = 0; q < SS; q++)
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     float x = ssum[q][j];
-#pragma unroll
-                    for (int mask = C4N; mask < 64; mask <<= 1) x += __shfl_xor(x, mask, 64);
+                    if constexpr (C4N <= 4) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xf, 0xf, false));   // row_ror:4
+                    if constexpr (C4N <= 8) x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));   // row_ror:8
                     ssum[q][j] = x;
                 }
-            if (lane < C4N) {
+            if ((lane & 15) < C4N) {
 #pragma unroll
-                for (int q = 0; q < SS; q++) *reinterpret_cast<f32x4 *>(&WpS[((q * NW + wave) * C4N + lane) * 4]) = ssum[q];
+                for (int q = 0; q < SS; q++) *reinterpret_cast<f32x4 *>(&WpS[(((q * NW + wave) * 4 + (lane >> 4)) * C4N + (lane & 15)) * 4]) = ssum[q];
             }
             se_pending = ch;
         } else
@@ -1154,7 +1172,7 @@ constexpr auto mb_se_fn() -> void (*)(const MbDesc &, int, hipStream_t) {
     constexpr int NW = WM * WN, C4N = CE / 4;
     // (the wave sums of a chunk, [SS][NW][CE] floats, wait in the project weights' LDS buffer, which this pass does not fill)
     constexpr int WPF = (PREC != 0 && CE == 16) ? WN * NT_W * 256 : (PREC ? (CE + 31) / 32 : CE / 16) * WN * NT_W * (PREC ? 512 : 256);
-    if constexpr (64 % C4N == 0 && (64 * NW) % C4N == 0 && SS * NW * CE <= WPF)
+    if constexpr (16 % C4N == 0 && (64 * NW) % C4N == 0 && SS * NW * 4 * CE <= WPF)
         return mb_launch<KS, ST, CE, KG, RT_W, NCS, WM, WN, MT_W, NT_W, TWL, XBL, SS, OCC, STEM, PREC, PERSIST, ACT, COLTH, 1>;
     else
         return nullptr;
