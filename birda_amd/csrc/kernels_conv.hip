@@ -582,6 +582,140 @@ __global__ __launch_bounds__(512, 2) void pw_gemm16_thin_kernel(const float *__r
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// The gated project convolution of the MIDDLE squeeze-excite blocks (N = 96 .. 144, K = 288 .. 816, 256 pixels a segment): the
+// streaming kernel above with W too large to stay in LDS.  One 8-wave workgroup walks passes of 8 x RB row tiles; within a pass W
+// goes through LDS KC k-steps at a time (all waves need the same steps at the same time: two barriers per chunk), every wave keeps
+// its RB x NT accumulator tiles across the chunks, and a W fragment read from LDS feeds RB MFMA groups -- 0.17 KB of LDS reads per
+// MFMA at RB = 4 against the 128 x 128 staged tile's 0.33, and no staging of A at all (a lane's 8 consecutive k of its row: two
+// 16-byte loads, gate applied, split in registers).  W is re-read from L2 once per pass of 512 (256) rows: 0.4-1.8 KB per row
+// against the row's own 2.3-3.3 KB from HBM.
+// ---------------------------------------------------------------------------------------
+template <int TERMS, int NT, int RB>
+__global__ __launch_bounds__(512, 2) void pw_gemm16_rows_kernel(const float *__restrict__ A, const float *__restrict__ gate, int rows_per_seg,
+                                                                 const f16x8 *__restrict__ Wf, const float *__restrict__ bias,
+                                                                 const float *__restrict__ R, float *__restrict__ C, int M, int K, int N,
+                                                                 float w_unscale, int kc) {
+    // LDS: two W chunk buffers [kc][NT]{hi, lo}[64][8 halves] (the next chunk arrives by LDS-DMA under this one's MFMAs) | per-wave
+    // epilogue tile [16][N]
+    extern __shared__ __attribute__((aligned(16))) float rsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int steps = (K + 31) / 32;
+    const int chunk_fl = kc * NT * 2 * 256;                       // floats per W chunk buffer
+    float *ep = rsm + 2 * (size_t)chunk_fl + (size_t)wave * (16 * NT * 16);
+    const int n_rt = (M + 15) >> 4;
+    const float rcp_p = 1.0f / (float)rows_per_seg;
+    const unsigned lds0 = (__builtin_amdgcn_groupstaticsize() + 15u) & ~15u;
+    const int ws = __builtin_amdgcn_readfirstlane(wave);
+    // chunk `c` (k steps c kc ..) -> buffer `buf`: 1-KiB pieces dealt round-robin to the 8 waves
+    auto dma_w = [&](int c, int buf) {
+        const int s0 = c * kc, ns = min(kc, steps - s0), np = ns * NT * 2;
+        for (int p = ws; p < np; p += 8) {
+            const f16x8 *src = Wf + ((size_t)s0 * NT * 2 + p) * 64;
+            const unsigned dst = lds0 + 4u * (unsigned)(buf * chunk_fl + p * 256);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                         :: "v"((unsigned)lane * 16u), "s"(src), "s"(dst) : "memory", "m0");
+        }
+    };
+    const int nchunks = (steps + kc - 1) / kc;
+    for (int rtb = blockIdx.x * 8 * RB; rtb < n_rt; rtb += gridDim.x * 8 * RB) {      // (uniform over the workgroup: barriers inside)
+        const int rt0 = rtb + wave * RB;
+        const float *ap[RB], *gp[RB];
+#pragma unroll
+        for (int r = 0; r < RB; r++) {
+            const int row = min((rt0 + r) * 16 + li, M - 1);                // rows past M: clamped, never stored
+            int seg = (int)((float)row * rcp_p);
+            seg += (row - seg * rows_per_seg >= rows_per_seg) ? 1 : 0;
+            seg -= (row - seg * rows_per_seg < 0) ? 1 : 0;
+            ap[r] = A + (size_t)row * K + 8 * kq;
+            gp[r] = gate + (size_t)seg * K + 8 * kq;
+        }
+        f32x4 acc[RB][NT];
+#pragma unroll
+        for (int r = 0; r < RB; r++)
+#pragma unroll
+            for (int j = 0; j < NT; j++) acc[r][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float4 ra[RB][2], rg[RB][2];
+        auto load = [&](int st) {
+#pragma unroll
+            for (int r = 0; r < RB; r++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const bool in = 32 * st + 8 * kq + 4 * h < K;       // (K % 4 == 0)
+                    ra[r][h] = *reinterpret_cast<const float4 *>(ap[r] + (in ? 32 * st + 4 * h : 0));
+                    rg[r][h] = *reinterpret_cast<const float4 *>(gp[r] + (in ? 32 * st + 4 * h : 0));
+                    if (!in) { ra[r][h] = make_float4(0.f, 0.f, 0.f, 0.f); rg[r][h] = ra[r][h]; }
+                }
+        };
+        __syncthreads();          // the previous pass is done with both W buffers
+        dma_w(0, 0);
+        load(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();          // chunk 0 has landed
+        for (int c = 0; c < nchunks; c++) {
+            const int s0 = c * kc, ns = min(kc, steps - s0);
+            const f16x8 *wf = reinterpret_cast<const f16x8 *>(rsm + (size_t)(c & 1) * chunk_fl);
+            for (int sl = 0; sl < ns; sl++) {
+                const int st = s0 + sl;
+                f16x8 ah[RB], al[RB];
+#pragma unroll
+                for (int r = 0; r < RB; r++) {
+                    const float v[8] = {ra[r][0].x * rg[r][0].x, ra[r][0].y * rg[r][0].y, ra[r][0].z * rg[r][0].z, ra[r][0].w * rg[r][0].w,
+                                        ra[r][1].x * rg[r][1].x, ra[r][1].y * rg[r][1].y, ra[r][1].z * rg[r][1].z, ra[r][1].w * rg[r][1].w};
+                    bh_split8(v, ah[r], al[r]);
+                }
+                // (issue order matters: vmcnt counts in order, the compiler does not see the DMA -- the next chunk's pieces go out
+                //  BEHIND the wait for this step's rows and IN FRONT of the next step's loads, whose wait then covers them)
+                if (sl == 0 && c + 1 < nchunks) dma_w(c + 1, (c + 1) & 1);
+                if (st + 1 < steps) load(st + 1);     // the next step's rows: in flight under this step's MFMAs
+#pragma unroll
+                for (int j = 0; j < NT; j++) {
+                    const f16x8 bh = wf[((sl * NT + j) * 2 + 0) * 64 + lane];
+                    f16x8 bl;
+                    if (TERMS == 3) bl = wf[((sl * NT + j) * 2 + 1) * 64 + lane];
+#pragma unroll
+                    for (int r = 0; r < RB; r++) {
+                        acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[r], bh, acc[r][j], 0, 0, 0);
+                        if (TERMS == 3) {
+                            acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[r], bl, acc[r][j], 0, 0, 0);
+                            acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[r], bh, acc[r][j], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the next chunk (and the next step's rows)
+            __syncthreads();                                      // everyone's pieces have landed; everyone is done with this chunk's buffer
+        }
+        // epilogue, one row tile at a time through the wave's LDS tile (see pw_gemm16_thin_kernel)
+#pragma unroll
+        for (int r = 0; r < RB; r++) {
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                const int col = j * 16 + li;
+                if (col >= N) continue;
+                const float bv = bias[col];
+#pragma unroll
+                for (int q = 0; q < 4; q++) ep[(kq * 4 + q) * N + col] = __builtin_fmaf(acc[r][j][q], w_unscale, bv);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int row0 = (rt0 + r) * 16, nrows = min(16, M - row0);
+            const int nflt = nrows * N;
+            if (nflt > 0) {
+                float *cg = C + (size_t)row0 * N;
+                const float *rgp = R ? R + (size_t)row0 * N : nullptr;
+                for (int f = lane * 4; f < nflt; f += 256) {
+                    float4 v = *reinterpret_cast<const float4 *>(ep + f);
+                    if (rgp) { const float4 rr = *reinterpret_cast<const float4 *>(rgp + f); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
+                    *reinterpret_cast<float4 *>(cg + f) = v;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 // the project convolution of a squeeze-excite block on the f16 MFMA: C = (D x gate) W + bias (+ R), no activation; K % 4 == 0,
 // planes [ceil(K / 32)][ceil(N / 16)]{hi, lo}[64][8] zero-padded in K
 void launch_pw_gemm16_gated(const float *A, const float *gate, int rows_per_seg, const void *Wf, const float *bias, const float *R,
@@ -602,6 +736,29 @@ void launch_pw_gemm16_gated(const float *A, const float *gate, int rows_per_seg,
         if (terms == 3) { if (n_tiles == 1) BH_THIN(3, 1); else if (n_tiles == 2) BH_THIN(3, 2); else BH_THIN(3, 3); }
         else { if (n_tiles == 1) BH_THIN(1, 1); else if (n_tiles == 2) BH_THIN(1, 2); else BH_THIN(1, 3); }
 #undef BH_THIN
+        return;
+    }
+    // N = 64 .. 144 with many rows: the row-streaming kernel (W through LDS a few k steps at a time)
+    if (n_tiles >= 4 && n_tiles <= 9 && M >= 4096 && N % 4 == 0) {
+        const int rb = n_tiles <= 5 ? 4 : n_tiles == 6 ? 3 : 2;      // (N = 96 at four row tiles a wave: 256 registers and 36 bytes of scratch)
+        const int kc = std::max(1, std::min((K + 31) / 32, (24 * 1024) / (n_tiles * 2048)));      // <= 24 KB of W per chunk, two buffers
+        const size_t lds = 2 * (size_t)kc * n_tiles * 2048 + (size_t)8 * 16 * n_tiles * 16 * sizeof(float);
+        const int n_rt = (M + 15) / 16;
+        const int wgs = std::min((n_rt + 8 * rb - 1) / (8 * rb), device_cu_count());
+#define BH_ROWS(T, NTV, RBV)                                                                                                        \
+        do {                                                                                                                       \
+            static DeviceOnce attr;                                                                                                \
+            attr.run([] { (void)hipFuncSetAttribute((const void *)pw_gemm16_rows_kernel<T, NTV, RBV>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); }); \
+            hipLaunchKernelGGL((pw_gemm16_rows_kernel<T, NTV, RBV>), dim3(wgs), dim3(512), lds, s, A, gate, rows_per_seg, (const f16x8 *)Wf, bias, R, C, M, K, N, w_unscale, kc); \
+        } while (0)
+#define BH_ROWS_T(T)                                                                             \
+        switch (n_tiles) {                                                                      \
+        case 4: BH_ROWS(T, 4, 4); break; case 5: BH_ROWS(T, 5, 4); break; case 6: BH_ROWS(T, 6, 3); break;       \
+        case 7: BH_ROWS(T, 7, 2); break; case 8: BH_ROWS(T, 8, 2); break; default: BH_ROWS(T, 9, 2); break; }
+        if (terms == 3) { BH_ROWS_T(3) } else { BH_ROWS_T(1) }
+#undef BH_ROWS_T
+#undef BH_ROWS
+        (void)rb;
         return;
     }
     // column tiles per workgroup: the width that pads N least (96 -> 6, 136 -> 10, 232 -> 8 + 8, 384 -> 3 x 8); ties go to the wider
