@@ -487,8 +487,27 @@ std::vector<size_t> sub_slice_cuts(const bh_classifier *c, size_t nb, size_t ali
         const double compute_us = (2.0 * (double)c->model.macs_per_segment() + (double)c->mel_flops) / 130e6;
         const size_t first = first_env >= 0 ? (size_t)first_env : (upload_us < compute_us ? 64 : 0);
         size_t v0 = sub;
+        constexpr double growth = 1.5;
+        if (upload_us < compute_us && nb >= 512 && first_env < 0) {
+            // the upload is the SHORTER side (PCM16: 5.2 against 6.5 us per segment): after the first sub-slices the data is always
+            // there, and what a sub-slice costs beyond its segments (the launch chain, the late blocks' half-empty grids) is paid
+            // per sub-slice -- so the sizes GROW, 64, 96, 160, 224, 320 ..., each next one arriving about when the one before
+            // finishes.  Measured, 1 000 PCM16 segments from pinned memory, one box, interleaved (profiles/r5_d_subslice_growth.txt):
+            // equal 128s 110.3 k segments/s, growth 1.25 116.7, 1.35 116.6, 1.5 119.4, 1.75 113.6, 2.0 99.5; bhh_process_file 91.4 ->
+            // 97.0 k
+            double size = 64.0;
+            size_t v = 0;
+            while (true) {
+                const size_t sz = std::max<size_t>(align, (size_t)(size / 32.0 + 0.5) * 32);
+                if (v + sz + 96 > nb) break;
+                v += sz;
+                cuts.push_back(up(v));
+                size *= growth;
+            }
+        } else {
         if (first && first < sub && nb >= 512) { cuts.push_back(up(first)); v0 = up(first) + sub; }
         for (size_t v = v0; v + 64 <= nb; v += sub) cuts.push_back(v);   // (a tail under 64 segments joins the last sub-slice)
+        }
         // the upload is the LONGER side (f32 segments): what is left when the last byte has arrived is the last sub-slice's forward,
         // so that one is kept short -- 64 segments (a forward of 64 lasts 0.9 ms, one of 128 1.2: tools/gpu_latency.py)
         if (upload_us >= compute_us && first_env < 0) {
