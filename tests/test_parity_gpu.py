@@ -798,6 +798,27 @@ def test_auto_precision_reruns_the_rows_beyond_the_f16_range(model_dir, oracle_l
         assert clf.fallback_segments() >= 3 * nfb
         st = clf.provider_status()
         assert b"f32 kernels" in st.fallback_reason
+        # more than 256 DISTINCT device-resident forwards between two synchronises -- the list of what a
+        # synchronise repairs is settled by bh_forward_device itself when it is full, not dropped: still BH_OK, every row repaired
+        K = 300
+        lgs = torch.zeros((K, 2, m.n_classes), device="cuda"); tis = torch.zeros((K, 2, 5), dtype=torch.int32, device="cuda"); tcs = torch.zeros((K, 2, 5), device="cuda")
+        for k in range(K):
+            clf.forward_device(ctx, x.data_ptr() + (k % (N // 2)) * 2 * m.sample_count * 4, 2, lgs[k].data_ptr(), tis[k].data_ptr(), tcs[k].data_ptr())
+        ctx.synchronize()
+        assert bool(torch.isfinite(lgs).all()) and bool((tis[:, :, 0] != -2).all())
+        for k in (0, 1, 255, 256, 257, K - 1):
+            j = (k % (N // 2)) * 2
+            assert (lgs[k].cpu().numpy() == got[j:j + 2]).all(), k
+        # ... and a context that is destroyed (parked) WITHOUT a synchronise forgets its pending forwards: the next owner's
+        # synchronise must not repair into the first owner's buffers
+        lg2 = torch.zeros((N, m.n_classes), device="cuda"); ti2 = torch.zeros((N, 5), dtype=torch.int32, device="cuda"); tc2 = torch.zeros((N, 5), device="cuda")
+        clf.forward_device(ctx, x.data_ptr(), N, lg2.data_ptr(), ti2.data_ptr(), tc2.data_ptr())
+        ctx.close()
+        ctx = clf.create_batch_context(N)
+        torch.cuda.synchronize()
+        snapshot = lg2.clone()
+        ctx.synchronize()                                   # nothing of this owner's is pending
+        assert torch.equal(torch.nan_to_num(snapshot), torch.nan_to_num(lg2))
         ctx.close(); clf.close()
     assert mixed is not None, "no trunk scale left some rows inside and some outside the f16 range"
 
