@@ -68,9 +68,11 @@ struct RecoverError : std::runtime_error { using std::runtime_error::runtime_err
 constexpr size_t EVAL_MAX_ELEMS = 1u << 26;            // 64 M elements (512 MB of float64) per array
 constexpr uint64_t EVAL_MAX_MACS = 1ull << 37;         // per operator (the largest legitimate one: 8 rows of a 2048-tap DFT Conv = 1.7e10)
 constexpr size_t EVAL_MAX_RANK = 8;
+constexpr size_t EVAL_MAX_LIVE = (size_t)3 << 28;      // 768 M elements alive at once (6 GB of float64); a BirdNET front-end peaks at ~40 M
+constexpr size_t RECOVER_MAX_NODES = 4096;             // nodes between the audio input and the spectrogram (the published front-ends: a few dozen)
 
 // ---- threads: the cores this process is GRANTED (affinity mask and cgroup quota), at most 16 ---------------------------------
-inline unsigned usable_threads() {
+inline unsigned usable_threads_uncached() {
     unsigned n = std::thread::hardware_concurrency();
     if (n == 0) n = 1;
 #if defined(__linux__)
@@ -87,6 +89,7 @@ inline unsigned usable_threads() {
 #endif
     return std::max(1u, std::min(n, 16u));
 }
+inline unsigned usable_threads() { static const unsigned n = usable_threads_uncached(); return n; }
 
 template <class F> inline void parallel_for(size_t n, size_t min_per_thread, F &&body) {
     const size_t nt = std::min<size_t>(usable_threads(), std::max<size_t>(1, n / std::max<size_t>(1, min_per_thread)));
@@ -373,6 +376,10 @@ public:
             std::vector<Arr> out = op(n, in);
             for (size_t k = 0; k < n.out.size() && k < out.size(); k++) if (!n.out[k].empty()) env[n.out[k]] = std::move(out[k]);
             for (const auto &x : n.in) if (!x.empty() && !keep.count(x) && !feeds.count(x) && last[x] == i && !is_const(x)) env.erase(x);
+            // (a hostile graph may keep many large intermediates alive at once: the evaluation's footprint is bounded as a whole)
+            size_t live = 0;
+            for (const auto &kv : env) live += kv.second.size();
+            if (live > EVAL_MAX_LIVE) throw EvalError("the front-end's intermediates exceed the evaluator's memory bound");
         }
         std::vector<Arr> res;
         for (const auto &t : targets) {
@@ -990,16 +997,19 @@ inline Recovered recover_frontend(const Graph &g, const onnxc::ValueInfo &audio)
 
     // 1. the spectrogram tensor and the branch tensors
     std::string spec;
+    int candidates = 0;
     for (const auto &n : g.nodes) {
         if (n.op != "Conv" || n.in.size() < 2) continue;
         auto it = g.init.find(n.in[1]);
         if (it == g.init.end() || it->second.dims.size() != 4 || it->second.dims[2] <= 1 || it->second.dims[3] <= 1) continue;
+        if (++candidates > 64) break;     // (each test walks the graph: a hostile file must not make this quadratic)
         if (!ev.depends_on(n.in[0], audio.name)) continue;
         spec = n.in[0];
         break;
     }
     if (spec.empty()) throw RecoverError("no 2-D convolution downstream of the audio input: nowhere to enter the conv stack");
     const auto front = ev.ancestors({spec}, {audio.name});
+    if (front.size() > RECOVER_MAX_NODES) throw RecoverError(std::to_string(front.size()) + " nodes in front of the first 2-D convolution: not a spectrogram front-end");
     std::vector<size_t> squarers;
     for (size_t i : front) {
         const Node &n = g.nodes[i];
