@@ -114,6 +114,8 @@ void plan_arena(const bh::Model &m, const std::vector<int> &fused_at, const std:
                 const size_t end = (size_t)S.iP + 1;
                 last[m.layers[i].in_tensor] = std::max(last[m.layers[i].in_tensor], end);
                 last[S.iD + 1] = std::max(last[S.iD + 1], end);
+                last[S.iGap + 1] = std::max(last[S.iGap + 1], end);     // (the pooled sums and the hidden layer of the gate launches:
+                last[S.iPw1 + 1] = std::max(last[S.iPw1 + 1], end);     //  written while the per-tile sums -- born "later" -- are read)
                 last[S.iPw2 + 1] = std::max(last[S.iPw2 + 1], end);
                 last[S.iScale + 1] = std::max(last[S.iScale + 1], end);
                 if (S.iD != i) sz[i + 1] = 0;                                  // the expanded tensor stays in LDS

@@ -924,7 +924,20 @@ def test_squeeze_excite_and_swish_stack_matches_oracle(model_dir, oracle_lib):
         assert np.isfinite(got).all() and np.abs(got - ref).max() <= tol * scale, (prec, float(np.abs(got - ref).max()))
         again = clf.predict_logits(ctx, segs)          # (fixed summation order in the pooled sums: run to run, bit for bit)
         assert (again == got).all()
-        ctx.close(); clf.close()
+        ctx.close()
+        if prec == "f16x3":
+            # many segments, so that the workgroups of pass A, the gate launches and the gated GEMM really overlap in time: the arena
+            # plan must keep the block input, D, the per-tile sums (written EARLIER than the layer whose slot they use), the pooled
+            # sums, the hidden layer and the gate apart -- and a segment's row must not depend on the launch it ran in
+            many = synth.synth_segments(96, m.sample_count, m.sample_rate, start=21)
+            ref_many = oracle_lib.OracleModel(path).forward(many)
+            big = clf.create_batch_context(96)
+            for _ in range(3):
+                g96 = clf.predict_logits(big, many)
+                assert np.abs(g96 - ref_many).max() <= tol * max(1.0, float(np.abs(ref_many).max()))
+            assert (g96[:5] == got).all()
+            big.close()
+        clf.close()
     import subprocess, sys, textwrap
     # the layer-by-layer path of the same blocks, in a process of its own (the switch is read once per process)
     code = textwrap.dedent(f"""
