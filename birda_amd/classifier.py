@@ -9,6 +9,7 @@ happens in libbirda_hip.so; nothing here falls back to the CPU.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -68,6 +69,7 @@ class BatchInferenceContext:
         h = C.c_void_p()
         check(self._L.bh_batch_context_create(classifier._h, max_batch_size, C.byref(h)))
         self._h = h
+        classifier._register_context(self)
 
     def input_buffer_bytes(self) -> int:  # processor.rs:588
         return int(self._L.bh_batch_context_bytes(self._h))
@@ -112,7 +114,9 @@ class BatchInferenceContext:
 
     def close(self):
         if getattr(self, "_h", None):
-            if not getattr(self, "_borrowed", False):
+            # (a context outlives its classifier only by accident -- two module globals collected in the wrong order at interpreter
+            #  exit: the classifier's close() has closed it already, see BirdClassifier.close)
+            if not getattr(self, "_borrowed", False) and getattr(self.classifier, "_h", None):
                 self._L.bh_batch_context_destroy(self._h)
             self._h = None
 
@@ -391,8 +395,17 @@ class BirdClassifier:
         self.info, self.top_k, self.min_confidence, self.device = info, top_k, min_confidence, device
         return self
 
+    def _register_context(self, ctx) -> None:
+        if not hasattr(self, "_contexts"):
+            self._contexts = weakref.WeakSet()
+        self._contexts.add(ctx)
+
     def close(self):
         if getattr(self, "_h", None):
+            # batch contexts hold pointers into their classifier (stream sets, parked-context slots): they go first, whichever
+            # object the garbage collector happens to finalise first
+            for ctx in list(getattr(self, "_contexts", ())):
+                ctx.close()
             if not getattr(self, "_borrowed", False):
                 self._L.bh_classifier_destroy(self._h)
             self._h = None
