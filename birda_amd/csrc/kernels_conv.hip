@@ -478,6 +478,10 @@ bool pw_gemm16_supports(int K, int act) { return K % 32 == 0 && (act == ACT_NONE
 // read one whole 128-byte line), are multiplied by the segment's gate, split into f16 hi / lo in registers and go straight into
 // the MFMA as the A operand -- no staging of A at all.  The next k step's loads are in flight while this one computes.
 // ---------------------------------------------------------------------------------------
+// (D is read exactly once by these kernels, yet NON-TEMPORAL loads of it are slower, measured: 905 -> 1 625, 651 -> 1 087, 353 -> 416 us
+//  per 1 000 segments -- pass A wrote those lines microseconds earlier and much of them still sits in the write-back L2 / Infinity
+//  Cache, which a streaming load goes around.)
+#define BH_LOAD_STREAM(p) (*(p))
 template <int TERMS, int NT>
 __global__ __launch_bounds__(512, 2) void pw_gemm16_thin_kernel(const float *__restrict__ A, const float *__restrict__ gate, int rows_per_seg,
                                                                  const f16x8 *__restrict__ Wf, const float *__restrict__ bias,
@@ -523,7 +527,7 @@ __global__ __launch_bounds__(512, 2) void pw_gemm16_thin_kernel(const float *__r
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     const bool in = 32 * st + 8 * kq + 4 * h < K;       // (K % 4 == 0)
-                    a[r][h] = *reinterpret_cast<const float4 *>(ap[r] + (in ? 32 * st + 4 * h : 0));
+                    a[r][h] = BH_LOAD_STREAM(reinterpret_cast<const float4 *>(ap[r] + (in ? 32 * st + 4 * h : 0)));
                     g[r][h] = *reinterpret_cast<const float4 *>(gp[r] + (in ? 32 * st + 4 * h : 0));
                     if (!in) { a[r][h] = make_float4(0.f, 0.f, 0.f, 0.f); g[r][h] = a[r][h]; }
                 }
@@ -643,7 +647,7 @@ __global__ __launch_bounds__(512, 2) void pw_gemm16_rows_kernel(const float *__r
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     const bool in = 32 * st + 8 * kq + 4 * h < K;       // (K % 4 == 0)
-                    ra[r][h] = *reinterpret_cast<const float4 *>(ap[r] + (in ? 32 * st + 4 * h : 0));
+                    ra[r][h] = BH_LOAD_STREAM(reinterpret_cast<const float4 *>(ap[r] + (in ? 32 * st + 4 * h : 0)));
                     rg[r][h] = *reinterpret_cast<const float4 *>(gp[r] + (in ? 32 * st + 4 * h : 0));
                     if (!in) { ra[r][h] = make_float4(0.f, 0.f, 0.f, 0.f); rg[r][h] = ra[r][h]; }
                 }
