@@ -213,11 +213,13 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
                 ctx_mark(ctx, ST_MBCONV, (int)i);
                 float *gate = T(S.iPw2 + 1);
                 const int P = d.Ho * d.Wo;
-                // (the pool + the two dense layers as GEMMs over all segments, through the arena slots of the layers they stand for --
-                //  whatever the launch size: a segment's gate is then the same bits in a launch of 3 and of 1 000.  The one-launch
-                //  se_gate_kernel, a workgroup per segment, is kept for A/B: BIRDA_HIP_SE_GATE1=1 in the EXPERIMENTS build.)
+                // (the gate: one launch, a workgroup per segment (se_gate_kernel), or the pool + the two dense layers as GEMMs over all
+                //  segments, through the arena slots of the layers they stand for.  Either way every sum runs in a fixed order.)
+                // (which of the two a BLOCK takes depends on its width alone, never on the launch: up to 576 expanded channels the
+                //  one-launch kernel is the faster one -- three launches cost ~27 us per 1 000 segments whatever their size, measured
+                //  13-36 against 27-50 us; beyond, its per-segment re-read of both weight matrices is: 59-490 against 37-143 us)
                 static const bool gate1 = [] { const char *e = BH_XENV("BIRDA_HIP_SE_GATE1"); return e && e[0] == '1'; }();
-                if (!gate1)
+                if (!gate1 && d.Cexp > 576)
                     bh::launch_se_gate_gemm(d.pool_part, d.tiles_x * d.tiles_y, P, T(S.iGap + 1), T(S.iPw1 + 1), c->d_w[S.iPw1], c->d_blob + G1.b_off,
                                             c->ldw[S.iPw1], (int)G1.act, c->d_w[S.iPw2], c->d_blob + G2.b_off, c->ldw[S.iPw2], (int)G2.act, gate, (int)n,
                                             d.Cexp, (int)G1.cout, s);
