@@ -635,7 +635,8 @@ int predict_slices(bh_classifier *c, bh_batch_context *ctx, const float *const *
                 bh_internal_stream_copy(ctx->h_input + i * S, src, S * sizeof(float));
             }
         };
-        const unsigned nthreads = pinned_src ? 1u : (unsigned)std::min<size_t>(copy_threads(), CH);
+        // (a call of a few segments copies them itself: eight thread starts cost more than 18 MB of memcpy)
+        const unsigned nthreads = (pinned_src || nb < 16) ? 1u : (unsigned)std::min<size_t>(copy_threads(), CH);
         std::vector<std::atomic<int>> done(nchunks);
         for (auto &d : done) d.store(0, std::memory_order_relaxed);
         std::vector<std::thread> workers;
@@ -1753,7 +1754,7 @@ static int predict_pcm16_core(bh_classifier *c, bh_batch_context *ctx, const voi
             ctx->done_ev.push_back(e);
         }
         // (every worker its share of every piece, piece after piece: the first piece is on the copy stream at once; see predict_slices)
-        const unsigned nthreads = staged ? copy_threads() : 1;
+        const unsigned nthreads = (staged && bytes >= ((size_t)16 << 20)) ? copy_threads() : 1;
         std::vector<std::atomic<int>> done(npieces);
         for (auto &d : done) d.store(0, std::memory_order_relaxed);
         auto gather_part = [&](size_t j, unsigned t, unsigned nt) {
