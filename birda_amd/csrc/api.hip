@@ -639,12 +639,12 @@ int predict_slices(bh_classifier *c, bh_batch_context *ctx, const float *const *
         const unsigned nthreads = (pinned_src || nb < 16) ? 1u : (unsigned)std::min<size_t>(copy_threads(), CH);
         std::vector<std::atomic<int>> done(nchunks);
         for (auto &d : done) d.store(0, std::memory_order_relaxed);
-        std::vector<std::thread> workers;
-        if (nthreads > 1)
-            for (unsigned t = 1; t < nthreads; t++)
-                workers.emplace_back([&, t] {
-                    for (size_t j = 0; j < nchunks; j++) { gather_part(j, t, nthreads); done[j].fetch_add(1, std::memory_order_release); }
-                });
+        if (nthreads > 1) {
+            if (!ctx->pool) ctx->pool.reset(new GatherPool());
+            ctx->pool->start(nthreads - 1, [&](unsigned t) {
+                for (size_t j = 0; j < nchunks; j++) { gather_part(j, t, nthreads); done[j].fetch_add(1, std::memory_order_release); }
+            });
+        }
         int rc = BH_OK;
         size_t si_next = 0;
         for (size_t j = 0; j < nchunks && rc == BH_OK; j++) {
@@ -663,7 +663,7 @@ int predict_slices(bh_classifier *c, bh_batch_context *ctx, const float *const *
                                    ctx->d_topk_conf + s0 * TK, lane);
             }
         }
-        for (auto &w : workers) w.join();
+        if (nthreads > 1) ctx->pool->wait();
         if (rc == BH_OK && lanes_end(ctx, lanes) != hipSuccess) rc = fail(BH_ERR_HIP, "stream event failed");
         if (rc != BH_OK) {
             (void)hipStreamSynchronize(ctx->copy_stream); lanes_sync(ctx); (void)hipStreamSynchronize(ctx->stream);
@@ -1762,12 +1762,12 @@ static int predict_pcm16_core(bh_classifier *c, bh_batch_context *ctx, const voi
             const size_t share = ((len + nt - 1) / nt + 4095) & ~(size_t)4095, a = std::min(len, (size_t)t * share), b = std::min(len, a + share);
             if (b > a) bh_internal_stream_copy(stage + o + a, src + o + a, b - a);
         };
-        std::vector<std::thread> workers;
-        if (nthreads > 1)
-            for (unsigned t = 1; t < nthreads; t++)
-                workers.emplace_back([&, t] {
-                    for (size_t j = 0; j < npieces; j++) { gather_part(j, t, nthreads); done[j].fetch_add(1, std::memory_order_release); }
-                });
+        if (nthreads > 1) {
+            if (!ctx->pool) ctx->pool.reset(new GatherPool());
+            ctx->pool->start(nthreads - 1, [&](unsigned t) {
+                for (size_t j = 0; j < npieces; j++) { gather_part(j, t, nthreads); done[j].fetch_add(1, std::memory_order_release); }
+            });
+        }
         size_t si = 0;   // next sub-slice to launch
         rc = BH_OK;
         for (size_t j = 0; j < npieces && rc == BH_OK; j++) {
@@ -1819,7 +1819,7 @@ static int predict_pcm16_core(bh_classifier *c, bh_batch_context *ctx, const voi
                 si++;
             }
         }
-        for (auto &w : workers) w.join();
+        if (nthreads > 1) ctx->pool->wait();
         if (rc == BH_OK && lanes_end(ctx, lanes) != hipSuccess) rc = fail(BH_ERR_HIP, "stream event failed");
         if (rc != BH_OK) {
             (void)hipStreamSynchronize(ctx->copy_stream); lanes_sync(ctx); (void)hipStreamSynchronize(ctx->stream);
