@@ -470,9 +470,12 @@ def host_legs(clf, m, model_path, precision, tmp):
     wav = os.path.join(tmp, "bench_1000_segments.wav")
     synth.write_wav_pcm16(wav, host.reshape(-1), m.sample_rate)
     labels = os.path.join(tmp, "bench_labels.txt")
-    synth.write_labels(labels, m.n_classes)
-    from birda_amd.classifier import BirdClassifier
-    c2 = BirdClassifier(model_path, labels, top_k=5, min_confidence=0.1, device=clf.device, precision=precision)
+    if not os.path.exists(labels):
+        synth.write_labels(labels, m.n_classes)
+    # ONE classifier per process, as in a birda process (lib.rs:1003-1100 builds one and shares it by reference): the timed
+    # classifier itself, which main() builds with this label file.  (Rounds 3-4 built a second one here, beside the first and its
+    # parked 4-GB contexts: these legs then ran 5-20 % below the same code in a process of its own.)
+    c2 = clf
     e2e = {}
     for fe, reps in (("device", 3), ("host", 1)):
         pipeline.process_file(c2, wav, tmp, front_end=fe)
@@ -539,7 +542,6 @@ def host_legs(clf, m, model_path, precision, tmp):
     except Exception as ex:  # noqa: BLE001 -- a leg that cannot run is reported, not fatal
         got = {"error": str(ex)[:200]}
     e2e["files_pipelined_own_process"] = got
-    c2.close()
     out["end_to_end"] = {"what": "bhh_process_file on a synthetic %d-segment PCM16 WAV -> CSV (reference metric: segments / wall seconds, "
                                  "processor.rs:771-788), default batch size" % n, **e2e}
     return out
@@ -620,7 +622,10 @@ def main():
                                   "configs[1] per GPU: 1000 synthetic 3 s/48 kHz segments per GPU per step, HBM-resident, one shard per GPU, "
                                   "packed top-k rows gathered to the host")
 
-    clf = BirdClassifier(model_path, None, top_k=5, min_confidence=0.1, device=local_rank, precision=args.precision)
+    # (with labels: the end-to-end legs write CSV rows through this same classifier)
+    labels_path = os.path.join(tmp, "bench_labels.txt")
+    synth.write_labels(labels_path, m.n_classes)
+    clf = BirdClassifier(model_path, labels_path, top_k=5, min_confidence=0.1, device=local_rank, precision=args.precision)
     ctx = clf.create_batch_context(args.micro_batch)
     info = clf.info
     fused = clf.fused_blocks()

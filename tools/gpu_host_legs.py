@@ -5,7 +5,8 @@ from birda_amd import modelfile as mf, synth
 from birda_amd.classifier import BirdClassifier
 tmp = tempfile.mkdtemp()
 m = synth.build_model("birdnet_v24"); path = os.path.join(tmp, "m.bhm"); mf.write_model(path, m)
-clf = BirdClassifier(path, None, precision="auto")
+labels = os.path.join(tmp, "bench_labels.txt"); synth.write_labels(labels, m.n_classes)
+clf = BirdClassifier(path, labels, precision="auto")
 legs = bench.host_legs(clf, m, path, "auto", tmp)
 e2e = legs.pop("end_to_end")
 print(json.dumps({k: v["value"] for k, v in legs.items()}))
