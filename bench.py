@@ -208,7 +208,7 @@ def analyse_se(clf, m, fused, layer_tot, segs_done, steps, slices_per_step, prec
             continue    # (not run as a fused squeeze-excite block)
         E, D, P = m.layers[i0], m.layers[d], m.layers[p]
         px = D.out_h * D.out_w
-        kname = clf.fused_kernel_name(fused[fi]) if fi < len(fused) else "mbconv<?>"
+        kname = clf.fused_kernel_name(fused[fi], se=True) if fi < len(fused) else "mbconv<?>"
         fi += 1
         a_macs = (0 if i0 == d else (E.out_h * E.out_w * (E.kh * E.kw * E.cin) * E.cout)) + px * D.kh * D.kw * D.cout
         ga = groups.setdefault(("A", kname), {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0, "kind": "mfma"})

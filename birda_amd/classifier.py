@@ -171,11 +171,13 @@ class BirdClassifier:
         n = int(self._L.bh_classifier_fused_blocks(self._h, buf, 256))
         return [int(buf[i]) for i in range(min(n, 256))]
 
-    def fused_kernel_name(self, cfg: int) -> str:
+    def fused_kernel_name(self, cfg: int, se: bool = False) -> str:
+        """The block's instantiation as rocprofv3 prints it: the 19 tile arguments of bh_mb_config_name and the twentieth, SE (1 for
+        pass A of a squeeze-excite block)."""
         buf = C.create_string_buffer(128)
         self._L.bh_mb_config_name(cfg, buf, 128)
         name = buf.value.decode()
-        return "mbconv<" + name + ">"
+        return "mbconv<" + name + ("," + str(int(se)) if name else "") + ">"
 
     def mel_kernel_name(self) -> str:
         """The front-end kernel instantiation as a profiler prints it (e.g. "bh::mel_kernel<6, 3>")."""

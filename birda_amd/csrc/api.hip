@@ -209,6 +209,8 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
                 d.X = in;
                 d.Dout = T(S.iD + 1);
                 d.pool_part = T(S.iScale + 1);
+                // (D blocked for the f16 gated GEMMs: kernels.hpp MbDesc::dblk)
+                d.dblk = c->d_w16[S.iP] && bh::pw_gemm16_gated_wants_blocked(d.Cexp, d.Cout, d.Ho * d.Wo);
                 bh::launch_mbconv(d, (int)n, s);
                 ctx_mark(ctx, ST_MBCONV, (int)i);
                 float *gate = T(S.iPw2 + 1);
@@ -231,7 +233,7 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
                 const float *r = LP.res_tensor != bh::NO_TENSOR ? T(LP.res_tensor) : nullptr;
                 if (c->d_w16[S.iP])
                     bh::launch_pw_gemm16_gated(d.Dout, gate, P, c->d_w16[S.iP], c->d_blob + LP.b_off, r, y, (int)(n * (size_t)P), d.Cexp, d.Cout,
-                                               c->precision == 3 ? 3 : 1, c->w16_unscale[S.iP], s);
+                                               c->precision == 3 ? 3 : 1, c->w16_unscale[S.iP], d.dblk, s);
                 else
                     bh::launch_pw_gemm_gated(d.Dout, gate, P, c->d_w[S.iP], c->d_blob + LP.b_off, r, y, (int)(n * (size_t)P), d.Cexp, d.Cout,
                                              c->ldw[S.iP], (int)LP.act, s);

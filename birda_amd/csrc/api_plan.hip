@@ -234,6 +234,7 @@ bool describe_fused_block(const bh::Model &m, const std::vector<int> &readers, s
             if (P.act != bh::ACT_NONE) return false;
             d = bh::MbDesc{};
             d.se = 1;
+            d.dblk = 0;      // (set per forward: api.hip forward_slice)
             d.noexp = noexp ? 1 : 0;
             d.H = (int)(noexp ? D.in_h : E.in_h); d.W = (int)(noexp ? D.in_w : E.in_w);
             d.Cin = (int)(noexp ? D.cout : E.cin); d.Cexp = (int)D.cout; d.Cout = (int)P.cout;

@@ -379,8 +379,11 @@ void launch_pw_gemm16(const float *A, const void *Wf, const float *bias, const f
 void launch_pw_gemm_gated(const float *A, const float *gate, int rows_per_seg, const float *W, const float *bias, const float *R,
                           float *C, int M, int K, int N, int ldw, int act, hipStream_t s);
 // ... on the f16 MFMA (no activation; K % 4 == 0, planes [ceil(K / 32)][ceil(N / 16)]{hi, lo}[64][8] zero-padded in K) ...
+// (a_blocked: A in MbDesc::dblk's layout -- every kernel behind this entry reads either; pw_gemm16_gated_wants_blocked: the
+//  shapes whose kernel is the faster for it, a property of the BLOCK, never of the launch)
+bool pw_gemm16_gated_wants_blocked(int K, int N, int rows_per_seg);
 void launch_pw_gemm16_gated(const float *A, const float *gate, int rows_per_seg, const void *Wf, const float *bias, const float *R,
-                            float *C, int M, int K, int N, int terms, float w_unscale, hipStream_t s);
+                            float *C, int M, int K, int N, int terms, float w_unscale, int a_blocked, hipStream_t s);
 // ... and the gate itself: pool (from the per-tile channel sums of mbconv pass A, part [n][tiles][C]) -> 1x1 (C -> Cr, act1) -> 1x1
 // (Cr -> C, act2), one launch, fixed summation order
 bool se_gate_supports(int C, int Cr);
@@ -480,6 +483,12 @@ struct MbDesc {
     // gate (launch_pw_gemm*_gated, kernels_conv.hip).  The expanded tensor still never leaves the CU.
     int se;
     float *Dout, *pool_part;
+    // dblk = 1: D is written BLOCKED -- [row tile of 16 pixels][Cexp / 16][16 rows][16 channels] (rows = n Ho Wo, channels a
+    // multiple of 16, Ho Wo a multiple of 16): the 2 KB a wave of the project GEMM needs for one 32-deep step of a row tile are ONE
+    // contiguous run, and a tile's steps follow each other -- DRAM sees sequential reads instead of 128-byte pieces a row apart (the
+    // late blocks: 3.2-3.6 TB/s on NHWC), and pass A's stores are 1-KB runs instead of 64-byte ones.  Only pass A and the gated GEMMs
+    // ever see D (api.hip forward_slice sets the flag for both).
+    int dblk;
 };
 int mb_config_count();
 int mb_config_name(int ci, char *out, size_t cap);

@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void pw_gemm16_kernel(const float *__restrict_
 // are zero-padded on the host.
 // NTB: column tiles (of 16) per workgroup -- 8 for the dense layers; the gated project convolutions pick 6, 8 or 10 to fit N = 96, 136,
 // 232, 384 with little padding (wave (wm, wn) owns 64 rows x NTB / 2 column tiles)
-template <int TERMS, int ACT, bool GATE = false, int NTB = 8>
+template <int TERMS, int ACT, bool GATE = false, int NTB = 8, bool BLK = false>
 __global__ __launch_bounds__(256, 2) void pw_gemm16s_kernel(const float *__restrict__ A, const f16x8 *__restrict__ Wf,
                                                             const float *__restrict__ bias, const float *__restrict__ R,
                                                             float *__restrict__ C, int M, int K, int N, int n_tiles, float w_unscale,
@@ -353,11 +353,13 @@ __global__ __launch_bounds__(256, 2) void pw_gemm16s_kernel(const float *__restr
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         const int row = srow + 64 * q, grow = min(mb0 + row, M - 1);
-        ag[q] = A + (size_t)grow * K + 8 * skq;                                  // rows past M: clamped, never stored
+        // rows past M: clamped, never stored.  (BLK: MbDesc::dblk's layout -- the 8 floats sit in block 2 st + (skq >> 1), row grow & 15)
+        ag[q] = BLK ? A + (size_t)(grow >> 4) * 16 * K + ((skq >> 1) * 16 + (grow & 15)) * 16 + (skq & 1) * 8 : A + (size_t)grow * K + 8 * skq;
         gg[q] = GATE ? gate + (size_t)(grow / rows_per_seg) * K + 8 * skq : nullptr;
         adst[q] = (((row >> 4) * 2) * 64 + skq * 16 + (row & 15)) * 4;           // float offset of the hi fragment slot; lo: + 256
     }
     float4 ra[2][2], rg[GATE ? 2 : 1][2];
+    constexpr int a_step = BLK ? 512 : 32;                // floats from one 32-deep step of a row to the next
     auto load_a = [&](int st) {
 #pragma unroll
         for (int q = 0; q < 2; q++) {
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void pw_gemm16s_kernel(const float *__restr
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     const bool in = 32 * st + 8 * skq + 4 * h < K;     // (K % 4 == 0: a quad is wholly inside or outside)
-                    ra[q][h] = *reinterpret_cast<const float4 *>(ag[q] + (in ? 32 * st + 4 * h : 0));
+                    ra[q][h] = *reinterpret_cast<const float4 *>(ag[q] + (in ? a_step * st + 4 * h : 0));
                     rg[q][h] = *reinterpret_cast<const float4 *>(gg[q] + (in ? 32 * st + 4 * h : 0));
                     if (!in) { rg[q][h] = make_float4(0.f, 0.f, 0.f, 0.f); ra[q][h] = rg[q][h]; }
                 }
@@ -587,147 +589,254 @@ __global__ __launch_bounds__(512, 2) void pw_gemm16_thin_kernel(const float *__r
 }
 
 // ---------------------------------------------------------------------------------------
-// The gated project convolution of the MIDDLE squeeze-excite blocks (N = 96 .. 144, K = 288 .. 816, 256 pixels a segment): the
-// streaming kernel above with W too large to stay in LDS.  One 8-wave workgroup walks passes of 8 x RB row tiles; within a pass W
-// goes through LDS KC k-steps at a time (all waves need the same steps at the same time: two barriers per chunk), every wave keeps
-// its RB x NT accumulator tiles across the chunks, and a W fragment read from LDS feeds RB MFMA groups -- 0.17 KB of LDS reads per
-// MFMA at RB = 4 against the 128 x 128 staged tile's 0.33, and no staging of A at all (a lane's 8 consecutive k of its row: two
-// 16-byte loads, gate applied, split in registers).  W is re-read from L2 once per pass of 512 (256) rows: 0.4-1.8 KB per row
-// against the row's own 2.3-3.3 KB from HBM.
+// The gated project convolution of the MIDDLE and LATE squeeze-excite blocks (N = 64 .. 240, K = 288 .. 1 392; 256 or 64 pixels a
+// segment): the streaming kernel above with W too large to stay in LDS -- it goes through LDS one 32-deep step at a time (LDS-DMA,
+// a barrier per step), every wave keeps its RB x NT accumulator tiles across the steps, and a W fragment read from LDS feeds RB
+// MFMA groups; no staging of A at all (a lane's 8 consecutive k of its row: two 16-byte loads, gate applied, split in registers).
+// ONE workgroup per CU (256 registers a lane), the D rows PF k steps ahead and the W pieces PF - 1 ahead.  A first version (two
+// workgroups per CU, rows one step ahead, W in chunks of <= 24 KB; N <= 144) reached 3.2-3.6 TB/s and left N = 232 to 128 x 128
+// staged tiles that read D twice.  What the phases of such a kernel cost was measured with each switched off in turn
+// (tools/microbench/gated_gemm.hip, profiles/r5_f_gated_gemm_phases.txt): with rows two steps and pieces one step ahead nothing
+// overlapped -- a step lasted as long as the rows' round trip / 2 (4 us under load: 2 us a step) PLUS its MFMAs, a step of a narrow layer as long as the LDS-DMA's 1.1 us,
+// and the epilogue's residual loads were waited for one row tile at a time.  The vector-memory counter retires IN ORDER and the W
+// pieces share it with the row loads: waiting for the pieces issued one step ago forces every older row load home, however many
+// register sets hold rows.  So the pieces go out earlier too (PF W buffers in LDS): at the top of step X the newest
+// ND + (PF - 2)(PIECES + ND) operations may stay in flight -- rows X + 1 .. X + PF - 1 and pieces X + 1 .. X + PF - 2 -- an immediate,
+// since every wave issues the same number of pieces (the last may repeat one: same bytes to the same place).  The gate rows of
+// the pass's segments sit in LDS (zero beyond K): no second stream of global loads.  Order of a step: [wait] split this step's
+// rows -> barrier -> issue {pieces X + PF - 1, rows X + PF} -> MFMAs.
+// Epilogue: every wave parks a row tile in LDS (the W buffers, free by then) as the contiguous run of the output it is, its
+// residual loads already in flight, and moves it with whole 16-byte accesses.
 // ---------------------------------------------------------------------------------------
-template <int TERMS, int NT, int RB>
-__global__ __launch_bounds__(512, 2) void pw_gemm16_rows_kernel(const float *__restrict__ A, const float *__restrict__ gate, int rows_per_seg,
+// (DBG: tools/microbench/gated_gemm.hip switches phases off at compile time -- 1 no MFMAs and no W reads, 2 no row loads, 4 no W pieces,
+//  8 no epilogue, 16 MFMAs without the W reads, 32 W reads without the MFMAs; the product instantiates DBG = 0 only)
+#define BH_GDBG(bit) ((DBG & (bit)) != 0)
+template <int N_> __device__ __forceinline__ void bh_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N_) : "memory"); }
+template <int TERMS, int NT, int RB, int PF, int DBG = 0>
+__global__ __launch_bounds__(512, 1) void pw_gemm16_wide_kernel(const float *__restrict__ A, const float *__restrict__ gate, int rows_per_seg,
                                                                  const f16x8 *__restrict__ Wf, const float *__restrict__ bias,
                                                                  const float *__restrict__ R, float *__restrict__ C, int M, int K, int N,
-                                                                 float w_unscale, int kc) {
-    // LDS: two W chunk buffers [kc][NT]{hi, lo}[64][8 halves] (the next chunk arrives by LDS-DMA under this one's MFMAs) | per-wave
-    // epilogue tile [16][N]
-    extern __shared__ __attribute__((aligned(16))) float rsm[];
+                                                                 float w_unscale, int gs_max, int a_blocked) {
+    // LDS: PF W step buffers [NT]{hi, lo}[64][8 halves] | the gate rows of the pass's segments [gs_max][32 steps], zero beyond K;
+    // the epilogue's per-wave tiles [16][N] lie over both
+    extern __shared__ __attribute__((aligned(16))) float wsm[];
+    constexpr int STEP_FL = NT * 2 * 256;                         // floats per W step buffer
+    constexpr int PIECES = (NT * 2 + 7) / 8;                      // 1-KiB pieces per wave and step
+    constexpr int ND = RB * 2;                                    // row loads per lane and step
+    constexpr int INFLIGHT = ND + (PF - 2) * (PIECES + ND);       // what may stay in flight at the top of a step (see above)
+    static_assert(PF >= 2 && PF <= 4 && INFLIGHT <= 63, "prefetch depth");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
-    const int steps = (K + 31) / 32;
-    const int chunk_fl = kc * NT * 2 * 256;                       // floats per W chunk buffer
-    float *ep = rsm + 2 * (size_t)chunk_fl + (size_t)wave * (16 * NT * 16);
+    const int steps = (K + 31) / 32, KP = steps * 32;
+    float *gs = wsm + PF * STEP_FL;
+    float *ep = wsm + (size_t)wave * (16 * NT * 16);
     const int n_rt = (M + 15) >> 4;
     const float rcp_p = 1.0f / (float)rows_per_seg;
     const unsigned lds0 = (__builtin_amdgcn_groupstaticsize() + 15u) & ~15u;
     const int ws = __builtin_amdgcn_readfirstlane(wave);
-    // chunk `c` (k steps c kc ..) -> buffer `buf`: 1-KiB pieces dealt round-robin to the 8 waves
-    auto dma_w = [&](int c, int buf) {
-        const int s0 = c * kc, ns = min(kc, steps - s0), np = ns * NT * 2;
-        for (int p = ws; p < np; p += 8) {
-            const f16x8 *src = Wf + ((size_t)s0 * NT * 2 + p) * 64;
-            const unsigned dst = lds0 + 4u * (unsigned)(buf * chunk_fl + p * 256);
+    auto dma_w = [&](int st) {
+        const int buf = st % PF;
+#pragma unroll
+        for (int i = 0; i < PIECES; i++) {
+            const int p = min(ws + 8 * i, NT * 2 - 1);
+            const f16x8 *src = Wf + ((size_t)st * NT * 2 + p) * 64;
+            const unsigned dst = lds0 + 4u * (unsigned)(buf * STEP_FL + p * 256);
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                          :: "v"((unsigned)lane * 16u), "s"(src), "s"(dst) : "memory", "m0");
         }
     };
-    const int nchunks = (steps + kc - 1) / kc;
     for (int rtb = blockIdx.x * 8 * RB; rtb < n_rt; rtb += gridDim.x * 8 * RB) {      // (uniform over the workgroup: barriers inside)
         const int rt0 = rtb + wave * RB;
-        const float *ap[RB], *gp[RB];
+        const int seg_lo = (rtb * 16) / rows_per_seg;
+        const int seg_hi = (min((rtb + 8 * RB) * 16, M) - 1) / rows_per_seg;
+        const float *ap[RB];
+        const float *gl[RB];        // this lane's gate quads in LDS
 #pragma unroll
         for (int r = 0; r < RB; r++) {
             const int row = min((rt0 + r) * 16 + li, M - 1);                // rows past M: clamped, never stored
-            int seg = (int)((float)row * rcp_p);
+            int seg = (int)((float)row * rcp_p);                            // row / rows_per_seg through the reciprocal, fixed up
             seg += (row - seg * rows_per_seg >= rows_per_seg) ? 1 : 0;
             seg -= (row - seg * rows_per_seg < 0) ? 1 : 0;
-            ap[r] = A + (size_t)row * K + 8 * kq;
-            gp[r] = gate + (size_t)seg * K + 8 * kq;
+            ap[r] = a_blocked ? A + (size_t)(row >> 4) * 16 * K + ((kq >> 1) * 16 + (row & 15)) * 16 + (kq & 1) * 8 : A + (size_t)row * K + 8 * kq;
+            gl[r] = gs + (size_t)(seg - seg_lo) * KP + 8 * kq;
         }
+        const int a_step = a_blocked ? 512 : 32;
         f32x4 acc[RB][NT];
 #pragma unroll
         for (int r = 0; r < RB; r++)
 #pragma unroll
             for (int j = 0; j < NT; j++) acc[r][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        float4 ra[RB][2], rg[RB][2];
-        auto load = [&](int st) {
+        float4 ra[PF][RB][2];
+        auto load_d = [&](int st, float4 (&a)[RB][2]) {
 #pragma unroll
             for (int r = 0; r < RB; r++)
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
-                    const bool in = 32 * st + 8 * kq + 4 * h < K;       // (K % 4 == 0)
-                    ra[r][h] = BH_LOAD_STREAM(reinterpret_cast<const float4 *>(ap[r] + (in ? 32 * st + 4 * h : 0)));
-                    rg[r][h] = *reinterpret_cast<const float4 *>(gp[r] + (in ? 32 * st + 4 * h : 0));
-                    if (!in) { ra[r][h] = make_float4(0.f, 0.f, 0.f, 0.f); rg[r][h] = ra[r][h]; }
+                    const bool in = 32 * st + 8 * kq + 4 * h < K;       // (K % 4 == 0); beyond K the gate in LDS is zero, so any finite row bytes do
+                    a[r][h] = *reinterpret_cast<const float4 *>(ap[r] + (in ? a_step * st + 4 * h : 0));
                 }
         };
-        __syncthreads();          // the previous pass is done with both W buffers
-        dma_w(0, 0);
-        load(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();          // chunk 0 has landed
-        for (int c = 0; c < nchunks; c++) {
-            const int s0 = c * kc, ns = min(kc, steps - s0);
-            const f16x8 *wf = reinterpret_cast<const f16x8 *>(rsm + (size_t)(c & 1) * chunk_fl);
-            for (int sl = 0; sl < ns; sl++) {
-                const int st = s0 + sl;
-                f16x8 ah[RB], al[RB];
+        auto step = [&](int st, float4 (&cur)[RB][2]) {
+            float4 rg[RB][2];
 #pragma unroll
-                for (int r = 0; r < RB; r++) {
-                    const float v[8] = {ra[r][0].x * rg[r][0].x, ra[r][0].y * rg[r][0].y, ra[r][0].z * rg[r][0].z, ra[r][0].w * rg[r][0].w,
-                                        ra[r][1].x * rg[r][1].x, ra[r][1].y * rg[r][1].y, ra[r][1].z * rg[r][1].z, ra[r][1].w * rg[r][1].w};
-                    bh_split8(v, ah[r], al[r]);
-                }
-                // (issue order matters: vmcnt counts in order, the compiler does not see the DMA -- the next chunk's pieces go out
-                //  BEHIND the wait for this step's rows and IN FRONT of the next step's loads, whose wait then covers them)
-                if (sl == 0 && c + 1 < nchunks) dma_w(c + 1, (c + 1) & 1);
-                if (st + 1 < steps) load(st + 1);     // the next step's rows: in flight under this step's MFMAs
+            for (int r = 0; r < RB; r++) {
+                rg[r][0] = *reinterpret_cast<const float4 *>(gl[r] + 32 * st);
+                rg[r][1] = *reinterpret_cast<const float4 *>(gl[r] + 32 * st + 4);
+            }
+            if (st + PF - 1 < steps && !BH_GDBG(2 | 4)) bh_wait_vm<INFLIGHT>();
+            else bh_wait_vm<0>();         // (the last PF - 1 steps: fewer operations went out behind this step's)
+            f16x8 ah[RB], al[RB];
 #pragma unroll
-                for (int j = 0; j < NT; j++) {
-                    const f16x8 bh = wf[((sl * NT + j) * 2 + 0) * 64 + lane];
-                    f16x8 bl;
-                    if (TERMS == 3) bl = wf[((sl * NT + j) * 2 + 1) * 64 + lane];
+            for (int r = 0; r < RB; r++) {
+                const float v[8] = {cur[r][0].x * rg[r][0].x, cur[r][0].y * rg[r][0].y, cur[r][0].z * rg[r][0].z, cur[r][0].w * rg[r][0].w,
+                                    cur[r][1].x * rg[r][1].x, cur[r][1].y * rg[r][1].y, cur[r][1].z * rg[r][1].z, cur[r][1].w * rg[r][1].w};
+                bh_split8(v, ah[r], al[r]);
+            }
+            __syncthreads();      // everyone's pieces of this step's W have landed; everyone is done with the buffer of step - 1
+            if (st + PF - 1 < steps && !BH_GDBG(4)) dma_w(st + PF - 1);
+            if (st + PF < steps && !BH_GDBG(2)) load_d(st + PF, cur);
+            const f16x8 *wf = reinterpret_cast<const f16x8 *>(wsm + (size_t)(st % PF) * STEP_FL);
+            if constexpr (BH_GDBG(1)) { acc[0][0][0] += (float)ah[0][0] + (float)al[RB - 1][7]; return; }
+            if constexpr (BH_GDBG(16)) {      // MFMAs on whatever the first fragments hold: no LDS reads
+                const f16x8 bh = wf[lane], bl = wf[64 + lane];
+#pragma unroll
+                for (int j = 0; j < NT; j++)
 #pragma unroll
                     for (int r = 0; r < RB; r++) {
                         acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[r], bh, acc[r][j], 0, 0, 0);
-                        if (TERMS == 3) {
-                            acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[r], bl, acc[r][j], 0, 0, 0);
-                            acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[r], bh, acc[r][j], 0, 0, 0);
-                        }
+                        acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[r], bl, acc[r][j], 0, 0, 0);
+                        acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[r], bh, acc[r][j], 0, 0, 0);
                     }
-                }
+                return;
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of the next chunk (and the next step's rows)
-            __syncthreads();                                      // everyone's pieces have landed; everyone is done with this chunk's buffer
+            if constexpr (BH_GDBG(32)) {      // the LDS reads without the MFMAs
+#pragma unroll
+                for (int j = 0; j < NT; j++) {
+                    const f16x8 bh = wf[(j * 2 + 0) * 64 + lane], bl = wf[(j * 2 + 1) * 64 + lane];
+                    acc[0][j][0] += (float)bh[0] + (float)bl[7] + (float)ah[0][0] + (float)al[RB - 1][7];
+                }
+                return;
+            }
+            // the next column tile's fragments are read while this one's MFMAs run; the three products of an accumulator keep
+            // their order (hi hi, hi lo, lo hi), the row tiles alternate so that no MFMA waits for the one in front of it
+            f16x8 bh = wf[lane], bl = bh;
+            if (TERMS == 3) bl = wf[64 + lane];
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                f16x8 nh = bh, nl = bl;
+                if (j + 1 < NT) {
+                    nh = wf[((j + 1) * 2 + 0) * 64 + lane];
+                    if (TERMS == 3) nl = wf[((j + 1) * 2 + 1) * 64 + lane];
+                }
+#pragma unroll
+                for (int r = 0; r < RB; r++) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[r], bh, acc[r][j], 0, 0, 0);
+                if (TERMS == 3) {
+#pragma unroll
+                    for (int r = 0; r < RB; r++) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[r], bl, acc[r][j], 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < RB; r++) acc[r][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[r], bh, acc[r][j], 0, 0, 0);
+                }
+                bh = nh; bl = nl;
+            }
+        };
+        __syncthreads();          // the previous pass is done with the W buffers, the gate rows and the epilogue tiles
+        long long t_0 = 0, t_1 = 0, t_2 = 0;
+        if constexpr (BH_GDBG(64)) t_0 = __builtin_readcyclecounter();
+        // issue order = the order the steps would have issued in: pieces s + PF - 1 in front of rows s + PF
+#pragma unroll
+        for (int s0 = 0; s0 < PF - 1; s0++) if (s0 < steps) dma_w(s0);
+#pragma unroll
+        for (int s0 = 0; s0 < PF; s0++) if (s0 < steps) load_d(s0, ra[s0]);
+        {   // the gate rows of this pass's segments, zero beyond K
+            const int ngs = (seg_hi - seg_lo + 1) * KP;
+            for (int i = tid * 4; i < ngs; i += 512 * 4) {
+                const int sg = i / KP, k = i - sg * KP;
+                float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < K) g = *reinterpret_cast<const float4 *>(gate + (size_t)(seg_lo + sg) * K + k);
+                *reinterpret_cast<float4 *>(gs + i) = g;
+            }
         }
-        // epilogue, one row tile at a time through the wave's LDS tile (see pw_gemm16_thin_kernel)
+        __syncthreads();
+        for (int st = 0; st < steps; st += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; u++)
+                if (st + u < steps) step(st + u, ra[u]);
+        }
+        if constexpr (BH_GDBG(64)) t_1 = __builtin_readcyclecounter();
+        __syncthreads();          // everyone is done with the last W buffers: the epilogue tiles lie over them
+        if constexpr (BH_GDBG(64)) t_2 = __builtin_readcyclecounter();
+        if constexpr (BH_GDBG(8)) {      // (keeps the accumulators alive)
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < RB; r++)
+#pragma unroll
+                for (int j = 0; j < NT; j++) t += acc[r][j][0] + acc[r][j][1] + acc[r][j][2] + acc[r][j][3];
+            if (t == 12345.678f) C[0] = t;
+            continue;
+        }
+        const int Nn = N;
 #pragma unroll
         for (int r = 0; r < RB; r++) {
+            const int row0 = (rt0 + r) * 16, nrows = min(16, M - row0);
+            const int nflt = nrows * Nn;                                  // (N % 4 == 0: whole float4s)
+            float4 rr[NT];                                                // this tile of the residual: in flight while the tile is parked
+            const float *rgp = R ? R + (size_t)min(row0, M - 1) * Nn : nullptr;
+#pragma unroll
+            for (int f = 0; f < NT; f++) {
+                rr[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rgp) rr[f] = *reinterpret_cast<const float4 *>(rgp + max(min(lane * 4 + f * 256, nflt - 4), 0));     // (clamped: unused beyond the tile)
+            }
 #pragma unroll
             for (int j = 0; j < NT; j++) {
                 const int col = j * 16 + li;
-                if (col >= N) continue;
+                if (col >= Nn) continue;
                 const float bv = bias[col];
 #pragma unroll
-                for (int q = 0; q < 4; q++) ep[(kq * 4 + q) * N + col] = __builtin_fmaf(acc[r][j][q], w_unscale, bv);
+                for (int q = 0; q < 4; q++) ep[(kq * 4 + q) * Nn + col] = __builtin_fmaf(acc[r][j][q], w_unscale, bv);
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            const int row0 = (rt0 + r) * 16, nrows = min(16, M - row0);
-            const int nflt = nrows * N;
             if (nflt > 0) {
-                float *cg = C + (size_t)row0 * N;
-                const float *rgp = R ? R + (size_t)row0 * N : nullptr;
-                for (int f = lane * 4; f < nflt; f += 256) {
-                    float4 v = *reinterpret_cast<const float4 *>(ep + f);
-                    if (rgp) { const float4 rr = *reinterpret_cast<const float4 *>(rgp + f); v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w; }
-                    *reinterpret_cast<float4 *>(cg + f) = v;
+                float *cg = C + (size_t)row0 * Nn;
+#pragma unroll
+                for (int f = 0; f < NT; f++) {
+                    if (lane * 4 + f * 256 < nflt) {
+                        float4 v = *reinterpret_cast<const float4 *>(ep + lane * 4 + f * 256);
+                        if (rgp) { v.x += rr[f].x; v.y += rr[f].y; v.z += rr[f].z; v.w += rr[f].w; }
+                        *reinterpret_cast<float4 *>(cg + lane * 4 + f * 256) = v;
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");       // (the next tile's residual loads stay behind this tile's stores: one set of registers)
+        }
+        if constexpr (BH_GDBG(64)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const long long t_3 = __builtin_readcyclecounter();
+            if (lane == 0) {
+                long long *st = reinterpret_cast<long long *>(C + (size_t)M * N) + ((size_t)blockIdx.x * 8 + wave) * 4;
+                st[0] = t_1 - t_0; st[1] = t_2 - t_1; st[2] = t_3 - t_2; st[3] = t_0;
+            }
         }
     }
 }
 
 // the project convolution of a squeeze-excite block on the f16 MFMA: C = (D x gate) W + bias (+ R), no activation; K % 4 == 0,
 // planes [ceil(K / 32)][ceil(N / 16)]{hi, lo}[64][8] zero-padded in K
+// D blocked (kernels.hpp MbDesc::dblk) where the wide row-streaming kernel takes the layer (N = 96 .. 240): measured on the
+// Perch-sized plan, 816 -> 136: 320 -> 280 us per 1 000 segments; the streaming kernel of the early blocks (whole tiles are
+// contiguous in NHWC already) and the 128 x 128 staged tiles (N = 384) are 1.1-2x SLOWER on blocked rows
+bool pw_gemm16_gated_wants_blocked(int K, int N, int rows_per_seg) {
+    const int n_tiles = (N + 15) / 16;
+    return K % 16 == 0 && rows_per_seg % 16 == 0 && N % 4 == 0 && n_tiles >= 6 && n_tiles <= 15;
+}
+
 void launch_pw_gemm16_gated(const float *A, const float *gate, int rows_per_seg, const void *Wf, const float *bias, const float *R,
-                            float *C, int M, int K, int N, int terms, float w_unscale, hipStream_t s) {
+                            float *C, int M, int K, int N, int terms, float w_unscale, int a_blocked, hipStream_t s) {
     const int n_tiles = (N + 15) / 16;
     // few columns, all of W in LDS (<= 64 KB), many rows: the streaming kernel above
     const size_t w_bytes = (size_t)((K + 31) / 32) * n_tiles * 2 * 1024;
-    if (n_tiles <= 3 && w_bytes <= 64 * 1024 && M >= 4096 && N % 4 == 0) {
+    if (n_tiles <= 3 && w_bytes <= 64 * 1024 && M >= 4096 && N % 4 == 0 && !a_blocked) {      // (blocked rows: N >= 64 only, pw_gemm16_gated_wants_blocked)
         const size_t thin_lds = w_bytes + (size_t)8 * (n_tiles <= 2 ? 4 : 3) * 16 * n_tiles * 16 * sizeof(float);   // + the waves' epilogue tiles
         const int n_rt = (M + 15) / 16;
         const int wgs = std::min((n_rt + 31) / 32, 2 * device_cu_count());   // 8-wave workgroups walking the row tiles, 3-4 per wave and pass (one or two resident per CU)
@@ -742,28 +851,29 @@ void launch_pw_gemm16_gated(const float *A, const float *gate, int rows_per_seg,
 #undef BH_THIN
         return;
     }
-    // N = 64 .. 144 with many rows: the row-streaming kernel (W through LDS a few k steps at a time)
-    if (n_tiles >= 4 && n_tiles <= 9 && M >= 4096 && N % 4 == 0) {
-        const int rb = n_tiles <= 5 ? 4 : n_tiles == 6 ? 3 : 2;      // (N = 96 at four row tiles a wave: 256 registers and 36 bytes of scratch)
-        const int kc = std::max(1, std::min((K + 31) / 32, (24 * 1024) / (n_tiles * 2048)));      // <= 24 KB of W per chunk, two buffers
-        const size_t lds = 2 * (size_t)kc * n_tiles * 2048 + (size_t)8 * 16 * n_tiles * 16 * sizeof(float);
+    // N = 64 .. 240 with many rows: the row-streaming kernel with one workgroup per CU, rows and W pieces several steps ahead
+    if (n_tiles >= 4 && n_tiles <= 15 && M >= 4096 && N % 4 == 0) {
         const int n_rt = (M + 15) / 16;
-        const int wgs = std::min((n_rt + 8 * rb - 1) / (8 * rb), device_cu_count());
-#define BH_ROWS(T, NTV, RBV)                                                                                                        \
+#define BH_WIDE(T, NTV, RBV, PFV)                                                                                                  \
         do {                                                                                                                       \
+            const int gs_max = (8 * RBV * 16 + rows_per_seg - 2) / rows_per_seg + 1;                                              \
+            const size_t lds = std::max((size_t)PFV * NTV * 2048 + (size_t)gs_max * ((K + 31) / 32 * 32) * sizeof(float),         \
+                                        (size_t)8 * 16 * NTV * 16 * sizeof(float));                                              \
+            if (lds > 160 * 1024) break;     /* (very many segments a pass: the staged kernel below) */                           \
+            const int wgs = std::min((n_rt + 8 * RBV - 1) / (8 * RBV), device_cu_count());                                       \
             static DeviceOnce attr;                                                                                                \
-            attr.run([] { (void)hipFuncSetAttribute((const void *)pw_gemm16_rows_kernel<T, NTV, RBV>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); }); \
-            hipLaunchKernelGGL((pw_gemm16_rows_kernel<T, NTV, RBV>), dim3(wgs), dim3(512), lds, s, A, gate, rows_per_seg, (const f16x8 *)Wf, bias, R, C, M, K, N, w_unscale, kc); \
+            attr.run([] { (void)hipFuncSetAttribute((const void *)pw_gemm16_wide_kernel<T, NTV, RBV, PFV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
+            hipLaunchKernelGGL((pw_gemm16_wide_kernel<T, NTV, RBV, PFV>), dim3(wgs), dim3(512), lds, s, A, gate, rows_per_seg, (const f16x8 *)Wf, bias, R, C, M, K, N, w_unscale, gs_max, a_blocked); \
+            return;                                                                                                                \
         } while (0)
-#define BH_ROWS_T(T)                                                                             \
+#define BH_WIDE_T(T)                                                                             \
         switch (n_tiles) {                                                                      \
-        case 4: BH_ROWS(T, 4, 4); break; case 5: BH_ROWS(T, 5, 4); break; case 6: BH_ROWS(T, 6, 3); break;       \
-        case 7: BH_ROWS(T, 7, 2); break; case 8: BH_ROWS(T, 8, 2); break; default: BH_ROWS(T, 9, 2); break; }
-        if (terms == 3) { BH_ROWS_T(3) } else { BH_ROWS_T(1) }
-#undef BH_ROWS_T
-#undef BH_ROWS
-        (void)rb;
-        return;
+        case 4: BH_WIDE(T, 4, 3, 3); break; case 5: BH_WIDE(T, 5, 3, 3); break; case 6: BH_WIDE(T, 6, 3, 3); break; case 7: BH_WIDE(T, 7, 3, 3); break; case 8: BH_WIDE(T, 8, 2, 4); break; case 9: BH_WIDE(T, 9, 2, 4); break;  \
+        case 10: BH_WIDE(T, 10, 2, 3); break; case 11: BH_WIDE(T, 11, 2, 3); break; case 12: BH_WIDE(T, 12, 2, 3); break; case 13: BH_WIDE(T, 13, 2, 3); break; \
+        case 14: BH_WIDE(T, 14, 2, 3); break; default: BH_WIDE(T, 15, 2, 3); break; }
+        if (terms == 3) { BH_WIDE_T(3) } else { BH_WIDE_T(1) }
+#undef BH_WIDE_T
+#undef BH_WIDE
     }
     // column tiles per workgroup: the width that pads N least (96 -> 6, 136 -> 10, 232 -> 8 + 8, 384 -> 3 x 8); ties go to the wider
     int ntb = 8;
@@ -776,15 +886,17 @@ void launch_pw_gemm16_gated(const float *A, const float *gate, int rows_per_seg,
     }
     const int n_xb = (n_tiles + ntb - 1) / ntb, n_yb = (M + 127) / 128;
     dim3 grid((unsigned)(n_xb * n_yb)), block(256);
-#define BH_GS(T, NTBV)                                                                                                            \
+#define BH_GS(T, NTBV, BLKV)                                                                                                      \
     do {                                                                                                                          \
         constexpr size_t lds = 2 * ((8 + NTBV) * 2 * 256) * sizeof(float);                                                       \
         static DeviceOnce attr;                                                                                                   \
-        attr.run([] { (void)hipFuncSetAttribute((const void *)pw_gemm16s_kernel<T, ACT_NONE, true, NTBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }); \
-        hipLaunchKernelGGL((pw_gemm16s_kernel<T, ACT_NONE, true, NTBV>), grid, block, lds, s, A, (const f16x8 *)Wf, bias, R, C, M, K, N, n_tiles, w_unscale, gate, rows_per_seg); \
+        attr.run([] { (void)hipFuncSetAttribute((const void *)pw_gemm16s_kernel<T, ACT_NONE, true, NTBV, BLKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }); \
+        hipLaunchKernelGGL((pw_gemm16s_kernel<T, ACT_NONE, true, NTBV, BLKV>), grid, block, lds, s, A, (const f16x8 *)Wf, bias, R, C, M, K, N, n_tiles, w_unscale, gate, rows_per_seg); \
     } while (0)
-    if (terms == 3) { if (ntb == 6) BH_GS(3, 6); else if (ntb == 10) BH_GS(3, 10); else BH_GS(3, 8); }
-    else { if (ntb == 6) BH_GS(1, 6); else if (ntb == 10) BH_GS(1, 10); else BH_GS(1, 8); }
+#define BH_GS_B(T, NTBV) do { if (a_blocked) BH_GS(T, NTBV, true); else BH_GS(T, NTBV, false); } while (0)
+    if (terms == 3) { if (ntb == 6) BH_GS_B(3, 6); else if (ntb == 10) BH_GS_B(3, 10); else BH_GS_B(3, 8); }
+    else { if (ntb == 6) BH_GS_B(1, 6); else if (ntb == 10) BH_GS_B(1, 10); else BH_GS_B(1, 8); }
+#undef BH_GS_B
 #undef BH_GS
 }
 

@@ -122,7 +122,8 @@ int mb_config_count() { return kNCfgs; }
 int mb_config_name(int ci, char *out, size_t cap) {
     if (ci < 0 || ci >= kNCfgs) return 0;
     const MbCfg &c = kCfgs[ci];
-    // all 19 template arguments, as a profiler prints them (the last three: persistent instantiation, activation, column tasks)
+    // the first 19 template arguments, as a profiler prints them (the last three: persistent instantiation, activation, column tasks);
+    // the twentieth, SE, belongs to the launch, not the table entry: the caller appends it (classifier.py fused_kernel_name)
     return snprintf(out, cap, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", c.KS, c.ST, c.CE, c.KG, c.RT_W, c.NCS, c.WM,
                     c.WN, c.MT_W, c.NT_W, c.TWL, c.XBL, c.S, c.OCC, c.STEM, c.PREC, c.PERSIST, c.ACT, c.COLTH);
 }

@@ -510,12 +510,17 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
     constexpr int SE_NP = SE ? (POUT_PAD + NTH / C4N - 1) / (NTH / C4N) : 1;
     float *se_dst[SE_NP];
     const int npix_pad = nsv * THTW;
+    const int se_cstr = SE && d.dblk ? CE * 16 : CE;      // floats from one chunk's channels to the next's in D
     if constexpr (SE) {
 #pragma unroll
         for (int k = 0; k < SE_NP; k++) {
             const int p0 = tid / C4N + k * (NTH / C4N);
             const int o = p0 < npix_pad ? omap[p0] : -1;
-            se_dst[k] = o >= 0 ? Dg + (size_t)o * d.Cexp : nullptr;
+            // (dblk: [row tile][Cexp / 16][16 rows][16 channels] -- a segment's pixels are whole tiles, kernels.hpp MbDesc::dblk; the
+            //  thread's own channel quad is folded in here, the chunk adds a uniform ch * se_cstr)
+            const int c4s = tid % C4N;
+            se_dst[k] = o < 0 ? nullptr : d.dblk ? Dg + (size_t)(o >> 4) * 16 * d.Cexp + (o & 15) * 16 + ((c4s >> 2) << 8) + 4 * (c4s & 3)
+                                                 : Dg + (size_t)o * d.Cexp + 4 * c4s;
         }
     }
     if constexpr (!SE)
@@ -979,6 +984,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
             // chunk, and the D rows looked up per chunk: pass A of the early blocks 7-33 % SLOWER than the whole gate-free block.)
             static_assert(16 % C4N == 0 && NTH % C4N == 0, "squeeze-excite pass A: the channel quads of a chunk divide a row of 16 lanes");
             const int c4 = tid % C4N, cg = ch * CE + 4 * c4;
+            const int cgo = ch * se_cstr;                                   // the chunk's offset from the thread's place in its pixel of D
             f32x4 ssum[SS];
 #pragma unroll
             for (int q = 0; q < SS; q++) ssum[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -988,7 +994,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                 if (p0 < npix_pad) {      // (uniform but for the last pass)
                     const f32x4 v = *reinterpret_cast<const f32x4 *>(&Ds[p0 * CES + 4 * c4]);
                     if (se_dst[k]) {
-                        if (cg < d.Cexp) *reinterpret_cast<f32x4 *>(se_dst[k] + cg) = v;
+                        if (cg < d.Cexp) *reinterpret_cast<f32x4 *>(se_dst[k] + cgo) = v;
                         if (SS == 1 || p0 < THTW) ssum[0] += v; else ssum[SS - 1] += v;
                     }
                 }

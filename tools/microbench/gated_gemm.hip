@@ -1,0 +1,80 @@
+// The gated project GEMM of a squeeze-excite block (launch_pw_gemm16_gated, kernels_conv.hip) on synthetic operands, with the wide
+// kernel's phases switched off one at a time (BH_GATED_DBG): which of {row loads, W pieces, MFMAs, epilogue} its time is made of.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 --Wno-inline-asm -o tools/microbench/gated_gemm.bin tools/microbench/gated_gemm.hip
+//   tools/microbench/gated_gemm.bin M K N rows_per_seg blocked
+#include "../../birda_amd/csrc/kernels_conv.hip"
+#include <cstdio>
+#include <vector>
+int main(int argc, char **argv) {
+    const int M = argc > 1 ? atoi(argv[1]) : 64000, K = argc > 2 ? atoi(argv[2]) : 1392, N = argc > 3 ? atoi(argv[3]) : 232;
+    const int P = argc > 4 ? atoi(argv[4]) : 64, blocked = argc > 5 ? atoi(argv[5]) : 0;
+    const int steps = (K + 31) / 32, nt = (N + 15) / 16;
+    float *A, *gate, *bias, *R, *C; void *W;
+    hipMalloc(&A, (size_t)M * K * 4); hipMalloc(&gate, (size_t)(M / P) * K * 4); hipMalloc(&bias, N * 4);
+    hipMalloc(&R, (size_t)M * N * 4); hipMalloc(&C, (size_t)M * N * 4 + 256 * 8 * 32); hipMalloc(&W, (size_t)steps * nt * 2048);
+    std::vector<float> h((size_t)M * K);
+    unsigned x = 12345;
+    for (auto &v : h) { x = x * 1664525u + 1013904223u; v = (float)(x >> 8) * (1.0f / 16777216.0f) - 0.5f; }
+    hipMemcpy(A, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(gate, h.data(), (size_t)(M / P) * K * 4, hipMemcpyHostToDevice);
+    hipMemcpy(R, h.data(), (size_t)M * N * 4, hipMemcpyHostToDevice);
+    hipMemcpy(bias, h.data(), N * 4, hipMemcpyHostToDevice);
+    std::vector<_Float16> hw((size_t)steps * nt * 1024);
+    for (auto &v : hw) { x = x * 1664525u + 1013904223u; v = (_Float16)((float)(x >> 8) * (1.0f / 16777216.0f) - 0.5f); }
+    hipMemcpy(W, hw.data(), hw.size() * 2, hipMemcpyHostToDevice);
+    hipStream_t s; hipStreamCreate(&s);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const double bytes = (double)M * K * 4 + (double)M * N * 8;
+    const int n_rt = (M + 15) / 16;
+    auto run = [&](const char *what, auto launch) {
+        for (int i = 0; i < 3; i++) launch();
+        hipEventRecord(e0, s);
+        const int reps = 10;
+        for (int i = 0; i < reps; i++) launch();
+        hipEventRecord(e1, s); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("M %d K %d N %d P %d blocked %d %-46s: %8.1f us  (%.2f TB/s of D + R + C)\n", M, K, N, P, blocked, what, ms * 1e3 / reps, bytes / (ms * 1e-3 / reps) / 1e12);
+    };
+    run("product dispatch", [&] { bh::launch_pw_gemm16_gated(A, gate, P, W, bias, R, C, M, K, N, 3, 1.0f, blocked, s); });
+#define GG(NTV, RBV, PFV, DBGV, what)                                                                                              \
+    if (nt == NTV) {                                                                                                               \
+        const int gs_max = (8 * RBV * 16 + P - 2) / P + 1;                                                                         \
+        const size_t lds = std::max((size_t)PFV * NTV * 2048 + (size_t)gs_max * ((K + 31) / 32 * 32) * sizeof(float), (size_t)8 * 16 * NTV * 16 * sizeof(float)); \
+        const int wgs = std::min((n_rt + 8 * RBV - 1) / (8 * RBV), bh::device_cu_count());                                         \
+        (void)hipFuncSetAttribute((const void *)bh::pw_gemm16_wide_kernel<3, NTV, RBV, PFV, DBGV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        run(what, [&] { hipLaunchKernelGGL((bh::pw_gemm16_wide_kernel<3, NTV, RBV, PFV, DBGV>), dim3(wgs), dim3(512), lds, s, A, gate, P, (const bh::f16x8 *)W, bias, R, C, M, K, N, 1.0f, gs_max, blocked); }); \
+    }
+#define GG_ALL(NTV, RBV, PFV)                                                      \
+    GG(NTV, RBV, PFV, 0, "all")                                                    \
+    { const float *Rk = R; R = nullptr; GG(NTV, RBV, PFV, 0, "all, no residual") R = (float *)Rk; }   \
+    GG(NTV, RBV, PFV, 1 | 2 | 4, "epilogue only")                                  \
+    { const float *Rk = R; R = nullptr; GG(NTV, RBV, PFV, 1 | 2 | 4, "epilogue only, no residual") R = (float *)Rk; }   \
+    GG(NTV, RBV, PFV, 8, "-epilogue")                                              \
+    GG(NTV, RBV, PFV, 8 | 1, "-epilogue -mfma -Wreads")                            \
+    GG(NTV, RBV, PFV, 8 | 16, "-epilogue -Wreads")                                 \
+    GG(NTV, RBV, PFV, 8 | 32, "-epilogue -mfma")                                   \
+    GG(NTV, RBV, PFV, 8 | 4, "-epilogue -Wpieces")                                 \
+    GG(NTV, RBV, PFV, 8 | 4 | 16, "-epilogue -Wpieces -Wreads")                    \
+    GG(NTV, RBV, PFV, 8 | 2, "-epilogue -rows")                                    \
+    GG(NTV, RBV, PFV, 8 | 2 | 16, "-epilogue -rows -Wreads")                       \
+    GG(NTV, RBV, PFV, 8 | 1 | 2, "-epilogue -rows -mfma -Wreads")                  \
+    GG(NTV, RBV, PFV, 8 | 1 | 2 | 4, "-epilogue -rows -mfma -Wreads -Wpieces")
+#define GG_STAMPS(NTV, RBV, PFV)                                                                                                    \
+    if (nt == NTV) {                                                                                                               \
+        GG(NTV, RBV, PFV, 64, "all, with the phase clock")                                                                         \
+        std::vector<long long> st(256 * 8 * 4);                                                                                    \
+        hipMemcpy(st.data(), C + (size_t)M * N, st.size() * 8, hipMemcpyDeviceToHost);                                             \
+        const int wgs = std::min((n_rt + 8 * RBV - 1) / (8 * RBV), bh::device_cu_count());                                         \
+        double a[3] = {0, 0, 0}, mx[3] = {0, 0, 0};                                                                               \
+        for (int w = 0; w < wgs * 8; w++) for (int k = 0; k < 3; k++) { a[k] += (double)st[w * 4 + k]; mx[k] = std::max(mx[k], (double)st[w * 4 + k]); } \
+        printf("  last pass of every wave, cycles (mean / max): main loop %.0f / %.0f, barrier %.0f / %.0f, epilogue %.0f / %.0f\n",  \
+               a[0] / (wgs * 8), mx[0], a[1] / (wgs * 8), mx[1], a[2] / (wgs * 8), mx[2]);                                          \
+    }
+    GG_STAMPS(15, 2, 3)
+    GG_STAMPS(9, 2, 4)
+    GG_STAMPS(6, 3, 3)
+    GG_ALL(15, 2, 3)
+    GG_ALL(9, 2, 4)
+    GG_ALL(6, 3, 3)
+    return 0;
+}
