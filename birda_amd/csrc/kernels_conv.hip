@@ -484,8 +484,11 @@ bool pw_gemm16_supports(int K, int act) { return K % 32 == 0 && (act == ACT_NONE
 //  per 1 000 segments -- pass A wrote those lines microseconds earlier and much of them still sits in the write-back L2 / Infinity
 //  Cache, which a streaming load goes around.)
 #define BH_LOAD_STREAM(p) (*(p))
-template <int TERMS, int NT>
-__global__ __launch_bounds__(512, 2) void pw_gemm16_thin_kernel(const float *__restrict__ A, const float *__restrict__ gate, int rows_per_seg,
+// SHALLOW (K <= 32: one k step a pass, the 24 -> 24 block): 3 (2) row tiles a wave in 128 registers, so that TWO workgroups share a CU
+// -- a pass is load -> wait -> 6 MFMAs -> residual -> wait -> store, and only more waves put anything under those waits: 1 410 -> 1 000 us
+// per 1 000 segments; deeper layers have their own next step to wait under and lose 0-5 % that way (tools/microbench/gated_gemm.hip).
+template <int TERMS, int NT, bool SHALLOW = false, int DBG = 0>      // (DBG: the microbench's switches -- 1 no MFMAs, 8 no epilogue; the product instantiates 0)
+__global__ __launch_bounds__(512, SHALLOW ? 4 : 2) void pw_gemm16_thin_kernel(const float *__restrict__ A, const float *__restrict__ gate, int rows_per_seg,
                                                                  const f16x8 *__restrict__ Wf, const float *__restrict__ bias,
                                                                  const float *__restrict__ R, float *__restrict__ C, int M, int K, int N,
                                                                  float w_unscale) {
@@ -505,7 +508,7 @@ __global__ __launch_bounds__(512, 2) void pw_gemm16_thin_kernel(const float *__r
     const float rcp_p = 1.0f / (float)rows_per_seg;
     // RB row tiles per wave and pass, their loads issued together: one tile at a time exposed a whole HBM round trip per 16 rows
     // (K = 24: one k step, nothing to prefetch under) -- 1.9 ms per 1 000 segments for the 24 -> 24 block, 2.4 TB/s
-    constexpr int RB = NT <= 2 ? 4 : 3;
+    constexpr int RB = SHALLOW ? (NT <= 2 ? 3 : 2) : (NT <= 2 ? 4 : 3);
     for (int rt0 = (blockIdx.x * 8 + wave) * RB; rt0 < n_rt; rt0 += gridDim.x * 8 * RB) {
         const float *ap[RB], *gp[RB];
 #pragma unroll
@@ -543,6 +546,11 @@ __global__ __launch_bounds__(512, 2) void pw_gemm16_thin_kernel(const float *__r
                                     ra[r][1].x * rg[r][1].x, ra[r][1].y * rg[r][1].y, ra[r][1].z * rg[r][1].z, ra[r][1].w * rg[r][1].w};
                 bh_split8(v, ah[r], al[r]);
             }
+            if constexpr ((DBG & 1) != 0) {
+#pragma unroll
+                for (int r = 0; r < RB; r++) acc[r][0][0] += (float)ah[r][0] + (float)al[r][7];
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < NT; j++) {
                 const f16x8 bh = wf[((st * NT + j) * 2 + 0) * 64 + lane];
@@ -562,6 +570,15 @@ __global__ __launch_bounds__(512, 2) void pw_gemm16_thin_kernel(const float *__r
         // row), so the wave parks its accumulators there as that run and then moves it with whole 16-byte accesses -- residual in,
         // sums out.  Stored straight from the MFMA layout a 96-byte row (N = 24) went out as a 64- and a 32-byte piece per
         // instruction, four rows at a time: 2.4 TB/s on the 24 -> 24 block.
+        if constexpr ((DBG & 8) != 0) {      // (keeps the accumulators alive)
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < RB; r++)
+#pragma unroll
+                for (int j = 0; j < NT; j++) t += acc[r][j][0] + acc[r][j][1] + acc[r][j][2] + acc[r][j][3];
+            if (t == 12345.678f) C[0] = t;
+            continue;
+        }
         float *ep = tsm + (size_t)steps * NT * 2 * 256 + (size_t)wave * (RB * 16 * NT * 16);
 #pragma unroll
         for (int r = 0; r < RB; r++)
@@ -837,17 +854,20 @@ void launch_pw_gemm16_gated(const float *A, const float *gate, int rows_per_seg,
     // few columns, all of W in LDS (<= 64 KB), many rows: the streaming kernel above
     const size_t w_bytes = (size_t)((K + 31) / 32) * n_tiles * 2 * 1024;
     if (n_tiles <= 3 && w_bytes <= 64 * 1024 && M >= 4096 && N % 4 == 0 && !a_blocked) {      // (blocked rows: N >= 64 only, pw_gemm16_gated_wants_blocked)
-        const size_t thin_lds = w_bytes + (size_t)8 * (n_tiles <= 2 ? 4 : 3) * 16 * n_tiles * 16 * sizeof(float);   // + the waves' epilogue tiles
+        const bool shallow = K <= 32;
+        const size_t thin_lds = w_bytes + (size_t)8 * (shallow ? (n_tiles <= 2 ? 3 : 2) : (n_tiles <= 2 ? 4 : 3)) * 16 * n_tiles * 16 * sizeof(float);   // + the waves' epilogue tiles
         const int n_rt = (M + 15) / 16;
-        const int wgs = std::min((n_rt + 31) / 32, 2 * device_cu_count());   // 8-wave workgroups walking the row tiles, 3-4 per wave and pass (one or two resident per CU)
-#define BH_THIN(T, NTV)                                                                                                            \
+        const int wgs = std::min((n_rt + 31) / 32, 2 * device_cu_count());   // 8-wave workgroups walking the row tiles, 2-4 per wave and pass (one or two resident per CU)
+#define BH_THIN(T, NTV, SH)                                                                                                        \
         do {                                                                                                                       \
             static DeviceOnce attr;                                                                                                \
-            attr.run([] { (void)hipFuncSetAttribute((const void *)pw_gemm16_thin_kernel<T, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); }); \
-            hipLaunchKernelGGL((pw_gemm16_thin_kernel<T, NTV>), dim3(wgs), dim3(512), thin_lds, s, A, gate, rows_per_seg, (const f16x8 *)Wf, bias, R, C, M, K, N, w_unscale); \
+            attr.run([] { (void)hipFuncSetAttribute((const void *)pw_gemm16_thin_kernel<T, NTV, SH>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); }); \
+            hipLaunchKernelGGL((pw_gemm16_thin_kernel<T, NTV, SH>), dim3(wgs), dim3(512), thin_lds, s, A, gate, rows_per_seg, (const f16x8 *)Wf, bias, R, C, M, K, N, w_unscale); \
         } while (0)
-        if (terms == 3) { if (n_tiles == 1) BH_THIN(3, 1); else if (n_tiles == 2) BH_THIN(3, 2); else BH_THIN(3, 3); }
-        else { if (n_tiles == 1) BH_THIN(1, 1); else if (n_tiles == 2) BH_THIN(1, 2); else BH_THIN(1, 3); }
+#define BH_THIN_S(T, NTV) do { if (shallow) BH_THIN(T, NTV, true); else BH_THIN(T, NTV, false); } while (0)
+        if (terms == 3) { if (n_tiles == 1) BH_THIN_S(3, 1); else if (n_tiles == 2) BH_THIN_S(3, 2); else BH_THIN_S(3, 3); }
+        else { if (n_tiles == 1) BH_THIN_S(1, 1); else if (n_tiles == 2) BH_THIN_S(1, 2); else BH_THIN_S(1, 3); }
+#undef BH_THIN_S
 #undef BH_THIN
         return;
     }

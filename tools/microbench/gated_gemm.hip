@@ -70,6 +70,23 @@ int main(int argc, char **argv) {
         printf("  last pass of every wave, cycles (mean / max): main loop %.0f / %.0f, barrier %.0f / %.0f, epilogue %.0f / %.0f\n",  \
                a[0] / (wgs * 8), mx[0], a[1] / (wgs * 8), mx[1], a[2] / (wgs * 8), mx[2]);                                          \
     }
+    // the streaming kernel of the early blocks (N <= 48, all of W in LDS)
+#define GT(NTV, SH, DBGV, what)                                                                                                        \
+    if (nt == NTV && nt <= 3) {                                                                                                    \
+        const size_t w_bytes = (size_t)steps * NTV * 2 * 1024;                                                                     \
+        const size_t lds = w_bytes + (size_t)8 * (SH ? (NTV <= 2 ? 3 : 2) : (NTV <= 2 ? 4 : 3)) * 16 * NTV * 16 * sizeof(float);                               \
+        const int wgs = std::min((n_rt + 31) / 32, 2 * bh::device_cu_count());                                                     \
+        (void)hipFuncSetAttribute((const void *)bh::pw_gemm16_thin_kernel<3, NTV, SH, DBGV>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); \
+        run(what, [&] { hipLaunchKernelGGL((bh::pw_gemm16_thin_kernel<3, NTV, SH, DBGV>), dim3(wgs), dim3(512), lds, s, A, gate, P, (const bh::f16x8 *)W, bias, R, C, M, K, N, 1.0f); }); \
+    }
+#define GT_ALL(NTV, SH, tag)                                                       \
+    GT(NTV, SH, 0, tag "streaming kernel, all")                                    \
+    { const float *Rk = R; R = nullptr; GT(NTV, SH, 0, tag "streaming kernel, no residual") R = (float *)Rk; } \
+    GT(NTV, SH, 1, tag "streaming kernel -mfma")                                   \
+    GT(NTV, SH, 8, tag "streaming kernel -epilogue")                               \
+    GT(NTV, SH, 9, tag "streaming kernel -mfma -epilogue (row loads only)")
+    GT_ALL(1, false, "") GT_ALL(2, false, "") GT_ALL(3, false, "")
+    GT_ALL(1, true, "2 wg/CU: ") GT_ALL(2, true, "2 wg/CU: ") GT_ALL(3, true, "2 wg/CU: ")
     GG_STAMPS(15, 2, 3)
     GG_STAMPS(9, 2, 4)
     GG_STAMPS(6, 3, 3)
