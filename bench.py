@@ -217,9 +217,21 @@ def analyse_se(clf, m, fused, layer_tot, segs_done, steps, slices_per_step, prec
         g_us += layer_tot[g][0] * 1e3 / segs_done * 1000
         K, N = P.cin, P.cout
         nt = -(-N // 16)
-        thin = nt <= 3 and -(-K // 32) * nt * 2048 <= 65536 and px * (segs_done // per_step) >= 4096
-        bname = ("pw_gemm16_thin_kernel<3, %d>" % nt) if (thin and precision != "f32") else ("gated project GEMM %d -> %d" % (K, N))
-        gb = groups.setdefault(("B", bname), {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0, "kind": "hbm" if thin else "mfma"})
+        # which kernel launch_pw_gemm16_gated (kernels_conv.hip) takes, named as rocprofv3 prints it
+        rows = px * (segs_done // per_step)
+        thin = nt <= 3 and -(-K // 32) * nt * 2048 <= 65536 and rows >= 4096 and N % 4 == 0
+        wide = 4 <= nt <= 15 and rows >= 4096 and N % 4 == 0
+        terms = 3 if precision in ("auto", "f16x3") else 1
+        if precision == "f32":
+            bname, bkind = "gated project GEMM %d -> %d (pw_gemm_kernel, f32 MFMA)" % (K, N), "mfma"
+        elif thin:
+            bname, bkind = "pw_gemm16_thin_kernel<%d, %d, %s, 0>" % (terms, nt, "true" if K <= 32 else "false"), "hbm"
+        elif wide:
+            rb, pf = (3, 3) if nt <= 7 else (2, 4) if nt <= 9 else (2, 3)
+            bname, bkind = "pw_gemm16_wide_kernel<%d, %d, %d, %d, 0>" % (terms, nt, rb, pf), "hbm"
+        else:
+            bname, bkind = "gated project GEMM %d -> %d (pw_gemm16s_kernel, 128 x 128 staged tiles)" % (K, N), "mfma"
+        gb = groups.setdefault(("B", bname), {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0, "kind": bkind})
         gb["ms"] += layer_tot[p][0]; gb["launches"] += layer_tot[p][1]
         gb["flops"] += 2.0 * px * K * N * segs_done
         gb["bytes"] += 4.0 * px * (K + N + (N if P.res_tensor != mf.NO_TENSOR else 0)) * segs_done
@@ -231,7 +243,7 @@ def analyse_se(clf, m, fused, layer_tot, segs_done, steps, slices_per_step, prec
     avg_us = dom["ms"] * 1e3 / max(dom["launches"], 1)
     if dom["kind"] == "hbm":
         gbps = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
-        out["roofline"] = {"kernel": name + " (gated project convolution of the early squeeze-excite blocks: D x gate -> 1x1, streaming)",
+        out["roofline"] = {"kernel": name + " (gated project convolution of squeeze-excite blocks: D x gate -> 1x1, rows streamed once)",
                            "bound": "hbm", "achieved": round(gbps, 1), "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(gbps / PEAK_HBM_GBPS, 4),
                            "traffic": pmc_traffic("bh::" + name), "rocprof_name": "bh::" + name, "launches": dom["launches"], "avg_launch_us": round(avg_us, 2),
                            "algorithmic_gb_per_launch": round(dom["bytes"] / max(dom["launches"], 1) / 1e9, 4),

@@ -1,7 +1,9 @@
-// The gated project GEMM of a squeeze-excite block (launch_pw_gemm16_gated, kernels_conv.hip) on synthetic operands, with the wide
-// kernel's phases switched off one at a time (BH_GATED_DBG): which of {row loads, W pieces, MFMAs, epilogue} its time is made of.
-//   hipcc -O3 -std=c++17 --offload-arch=gfx950 --Wno-inline-asm -o tools/microbench/gated_gemm.bin tools/microbench/gated_gemm.hip
-//   tools/microbench/gated_gemm.bin M K N rows_per_seg blocked
+// The gated project GEMMs of the squeeze-excite blocks (launch_pw_gemm16_gated, kernels_conv.hip) on synthetic operands: the product
+// dispatch, then the row-streaming kernel (N = 64 .. 240) and the streaming kernel (N <= 48) with their phases switched off at
+// compile time (their DBG template argument) -- which of {row loads, W pieces, W reads, MFMAs, epilogue, residual} a launch is made
+// of -- and a phase clock around the main loop and the epilogue of every wave.  Includes kernels_conv.hip itself: the shipped code.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -Wno-inline-asm -Wno-unused-result -o tools/microbench/gated_gemm.bin tools/microbench/gated_gemm.hip
+//   tools/microbench/gated_gemm.bin M K N rows_per_segment blocked        (e.g. 64000 1392 232 64 1; 15936000 24 24 15936 0)
 #include "../../birda_amd/csrc/kernels_conv.hip"
 #include <cstdio>
 #include <vector>
