@@ -1,4 +1,5 @@
-"""Where the fused MBConv kernels spend their wave-cycles (diagnostic build of the same kernels)."""
+"""Where the fused MBConv kernels spend their wave-cycles (diagnostic build of the same kernels: LIBX=1 tools/ab.sh x python
+tools/gpu_mb_stamps.py [n] [kind]; for pass A of a squeeze-excite block the "P3" column is its store phase)."""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["BIRDA_HIP_MB_STAMPS"] = "1"
@@ -7,8 +8,9 @@ from birda_amd import modelfile as mf, synth
 from birda_amd.classifier import BirdClassifier
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-m = synth.build_model("birdnet_v24")
-path = "/tmp/v24.bhm"; mf.write_model(path, m)
+KIND = sys.argv[2] if len(sys.argv) > 2 else "birdnet_v24"
+m = synth.build_model(KIND)
+path = f"/tmp/{KIND}.bhm"; mf.write_model(path, m)
 clf = BirdClassifier(path, precision=os.environ.get("PREC", "f16x3"))
 ctx = clf.create_batch_context(N)
 base = synth.synth_segments(8, m.sample_count, m.sample_rate)
