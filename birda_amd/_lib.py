@@ -102,6 +102,7 @@ SYMBOLS = [
     ("bh_mb_config_name", C.c_int, [C.c_int32, C.c_char_p, _SZ]),
     ("bh_classifier_frontend_kernel", C.c_int, [_VP, C.c_char_p, _SZ]),
     ("bh_debug_mb_stamps", C.c_int, [_VP, _VP, _SZ]),
+    ("bh_debug_gated_gemm", C.c_int, [C.c_int, _VP, _VP, _VP, _VP, _VP, _VP, _SZ, _SZ, _SZ, _SZ, C.c_int, C.c_int]),
     ("bh_predict_batch_source_rate", C.c_int, [_VP, _VP, C.POINTER(_VP), _SZ, _SZ, C.c_uint32, C.POINTER(BhResult)]),
     ("bh_segment_starts", _SZ, [_SZ, _SZ, _SZ, _VP, _SZ]),
     ("bh_predict_pcm16", C.c_int, [_VP, _VP, _VP, _SZ, C.c_uint32, C.c_uint32, _SZ, C.POINTER(BhResult), _SZ,

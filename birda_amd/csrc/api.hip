@@ -36,6 +36,30 @@ using namespace bhi;
 
 namespace bhi {
 
+// f16 operand planes of a [K][N] weight matrix for the split-f16 GEMMs: [ceil(K / 32)][ceil(N / 16)]{hi, lo}[64 lanes][8 halves],
+// lane (n & 15, k group) holding k = 32 step + 8 (lane >> 4) + 0..7 of column n, scaled by a power of two (1 / *unscale) that puts
+// the largest weight in the f16 range, zero beyond K and N
+std::vector<uint16_t> w16_planes(const float *W, int K, int N, float *unscale) {
+    const int nt = (N + 15) / 16, ksteps = (K + 31) / 32;
+    std::vector<uint16_t> planes((size_t)ksteps * nt * 2 * 64 * 8, 0);
+    float wmax = 0.0f;
+    for (size_t q = 0; q < (size_t)K * N; q++) wmax = std::max(wmax, std::fabs(W[q]));
+    const int ws = bh::f16_scale_exponent(wmax);
+    *unscale = std::ldexp(1.0f, -ws);
+    for (int st = 0; st < ksteps; st++)
+        for (int t = 0; t < nt; t++)
+            for (int lane = 0; lane < 64; lane++)
+                for (int jj = 0; jj < 8; jj++) {
+                    const int k = 32 * st + 8 * (lane >> 4) + jj, n = 16 * t + (lane & 15);
+                    const float v = (n < N && k < K) ? std::ldexp(W[(size_t)k * N + n], ws) : 0.0f;
+                    const uint16_t hi = f32_to_f16(v);
+                    const size_t base = (((size_t)st * nt + t) * 2) * 64 * 8;
+                    planes[base + (size_t)lane * 8 + jj] = hi;
+                    planes[base + 64 * 8 + (size_t)lane * 8 + jj] = f32_to_f16(v - f16_to_f32(hi));
+                }
+    return planes;
+}
+
 int upload(const void *src, size_t bytes, float **dst) {
     HIPCHK(hipMalloc((void **)dst, bytes ? bytes : 4));
     if (bytes) HIPCHK(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
@@ -957,25 +981,7 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) try {
             const auto &L = m.layers[i];
             if (in_block[i] || (L.op != bh::OP_PWCONV && L.op != bh::OP_DENSE)) continue;
             if (!(se_project[i] ? (L.cin % 4 == 0 && L.act == bh::ACT_NONE) : bh::pw_gemm16_supports((int)L.cin, (int)L.act))) continue;
-            const int K = (int)L.cin, N = (int)L.cout, nt = (N + 15) / 16;
-            const int ksteps = (K + 31) / 32;
-            std::vector<uint16_t> planes((size_t)ksteps * nt * 2 * 64 * 8, 0);
-            const float *W = m.blob.data() + L.w_off;
-            float wmax = 0.0f;
-            for (size_t q = 0; q < (size_t)K * N; q++) wmax = std::max(wmax, std::fabs(W[q]));
-            const int ws = bh::f16_scale_exponent(wmax);
-            c->w16_unscale[i] = std::ldexp(1.0f, -ws);
-            for (int st = 0; st < ksteps; st++)
-                for (int t = 0; t < nt; t++)
-                    for (int lane = 0; lane < 64; lane++)
-                        for (int jj = 0; jj < 8; jj++) {
-                            const int k = 32 * st + 8 * (lane >> 4) + jj, n = 16 * t + (lane & 15);
-                            const float v = (n < N && k < K) ? std::ldexp(W[(size_t)k * N + n], ws) : 0.0f;
-                            const uint16_t hi = f32_to_f16(v);
-                            const size_t base = (((size_t)st * nt + t) * 2) * 64 * 8;
-                            planes[base + (size_t)lane * 8 + jj] = hi;
-                            planes[base + 64 * 8 + (size_t)lane * 8 + jj] = f32_to_f16(v - f16_to_f32(hi));
-                        }
+            const std::vector<uint16_t> planes = w16_planes(m.blob.data() + L.w_off, (int)L.cin, (int)L.cout, &c->w16_unscale[i]);
             float *d = nullptr;
             rc = upload(planes.data(), planes.size() * sizeof(uint16_t), &d);
             if (rc != BH_OK) return rc;
@@ -1507,6 +1513,37 @@ int bh_classifier_frontend_kernel(const bh_classifier *c, char *out, size_t cap)
     if (out && cap > (size_t)n) memcpy(out, buf, (size_t)n + 1);
     return n;
 }
+
+// The gated project GEMM of a squeeze-excite block on operands of the caller's (tests: any shape, both layouts of D, every kernel
+// behind launch_pw_gemm16_gated, without a model around it): C = (A x gate[row / rows_per_seg]) W + bias (+ R).
+int bh_debug_gated_gemm(int device, const float *A, const float *gate, const float *W, const float *bias, const float *R, float *C,
+                        size_t M, size_t K, size_t N, size_t rows_per_seg, int terms, int blocked) try {
+    if (!A || !gate || !W || !bias || !C || !M || !K || !N || !rows_per_seg || M % rows_per_seg || K % 4 || (terms != 1 && terms != 3))
+        return fail(BH_ERR_INVALID, "debug_gated_gemm: bad arguments");
+    if (blocked && (K % 16 || M % 16)) return fail(BH_ERR_INVALID, "debug_gated_gemm: blocked rows need K % 16 == 0 and M % 16 == 0");
+    HIPCHK(hipSetDevice(device));
+    float unscale = 1.0f;
+    const std::vector<uint16_t> planes = w16_planes(W, (int)K, (int)N, &unscale);
+    std::vector<float> Ab;
+    if (blocked) {     // kernels.hpp MbDesc::dblk: [row tile of 16][K / 16][16 rows][16 channels]
+        Ab.resize(M * K);
+        for (size_t r = 0; r < M; r++)
+            for (size_t k = 0; k < K; k++) Ab[((r >> 4) * (K / 16) + (k >> 4)) * 256 + (r & 15) * 16 + (k & 15)] = A[r * K + k];
+    }
+    struct Dev { void *p = nullptr; ~Dev() { if (p) (void)hipFree(p); } } dA, dG, dW, dB, dR, dC;
+    auto put = [](Dev &d, const void *src, size_t bytes) {
+        if (hipMalloc(&d.p, bytes) != hipSuccess) return false;
+        return !src || hipMemcpy(d.p, src, bytes, hipMemcpyHostToDevice) == hipSuccess;
+    };
+    if (!put(dA, blocked ? Ab.data() : A, M * K * 4) || !put(dG, gate, M / rows_per_seg * K * 4) || !put(dW, planes.data(), planes.size() * 2) ||
+        !put(dB, bias, N * 4) || (R && !put(dR, R, M * N * 4)) || !put(dC, nullptr, M * N * 4))
+        return fail(BH_ERR_HIP, "debug_gated_gemm: device memory");
+    bh::launch_pw_gemm16_gated((const float *)dA.p, (const float *)dG.p, (int)rows_per_seg, dW.p, (const float *)dB.p, (const float *)dR.p,
+                               (float *)dC.p, (int)M, (int)K, (int)N, terms, unscale, blocked, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(C, dC.p, M * N * 4, hipMemcpyDeviceToHost));
+    return BH_OK;
+} catch (...) { return on_exception(); }
 
 int bh_debug_mb_stamps(bh_classifier *c, uint64_t *out, size_t cap) {
     if (!c || !c->d_stamps) return 0;

@@ -344,6 +344,13 @@ BH_API int bh_classifier_frontend_kernel(const bh_classifier *c, char *out, size
  * "mbconv_kernel<" (to match bench timings with rocprofv3 rows); returns the string length. */
 BH_API int bh_mb_config_name(int32_t cfg, char *out, size_t cap);
 
+/* Diagnostic: the gated project GEMM of a squeeze-excite block alone, on host operands -- C[M][N] = (A[M][K] x gate[M /
+ * rows_per_seg][K]) W[K][N] + bias[N] (+ R[M][N], may be NULL) on the split-f16 MFMA (terms: 1 = f16, 3 = f16x3), through the same
+ * dispatch a forward pass takes (streaming / row-streaming / staged kernels by N and M); blocked != 0 lays A out the way pass A of
+ * the fused block writes it for N = 96 .. 240.  K % 4 == 0; M a multiple of rows_per_seg.  Tests only. */
+BH_API int bh_debug_gated_gemm(int device, const float *A, const float *gate, const float *W, const float *bias, const float *R,
+                               float *C, size_t M, size_t K, size_t N, size_t rows_per_seg, int terms, int blocked);
+
 /* Diagnostic of the `make EXPERIMENTS=1` build (there: BIRDA_HIP_MB_STAMPS=1 at create): per fused block, 8 counters of
  * wave-cycles spent in setup, dw-weight staging, expand, barrier, depthwise, barrier, project, epilogue since the last call.
  * Returns the number of blocks written (8 values each); the product build has no phase clock and always returns 0. */

@@ -154,6 +154,7 @@ extern "C" {
     pub fn bh_plan_fused_blocks(model_path: *const c_char, flags: u32, cfgs: *mut i32, layers: *mut i32, cap: usize) -> c_int;
     pub fn bh_classifier_frontend_kernel(c: *const BhClassifier, out: *mut c_char, cap: usize) -> c_int;
     pub fn bh_mb_config_name(cfg: i32, out: *mut c_char, cap: usize) -> c_int;
+    pub fn bh_debug_gated_gemm(device: c_int, A: *const f32, gate: *const f32, W: *const f32, bias: *const f32, R: *const f32, C: *mut f32, M: usize, K: usize, N: usize, rows_per_seg: usize, terms: c_int, blocked: c_int) -> c_int;
     pub fn bh_debug_mb_stamps(c: *mut BhClassifier, out: *mut u64, cap: usize) -> c_int;
     pub fn bh_predict_batch_source_rate(c: *mut BhClassifier, ctx: *mut BhBatchContext, segments: *const *const f32, n: usize, n_src_samples: usize, source_rate: u32, out: *mut BhResult) -> c_int;
     pub fn bh_segment_starts(n_frames: usize, segment_samples: usize, overlap_samples: usize, starts: *mut u64, cap: usize) -> usize;
