@@ -872,7 +872,11 @@ void launch_pw_gemm16_gated(const float *A, const float *gate, int rows_per_seg,
         return;
     }
     // N = 64 .. 240 with many rows: the row-streaming kernel with one workgroup per CU, rows and W pieces several steps ahead
-    if (n_tiles >= 4 && n_tiles <= 15 && M >= 4096 && N % 4 == 0) {
+    // (N > 144: two row tiles a wave, 256 rows a pass, and a pass lasts ~125 us however few there are -- below ~40 000 rows, fewer
+    //  passes than three quarters of the CUs, the staged tiles' 2 x M / 128 workgroups win: 1 392 -> 232 at 16 384 rows 88 against
+    //  128 us, at 32 768 110 against 144, at 64 000 294 against 187; N <= 144 wins from 16 384 rows down to the 4 096 measured.
+    //  The same bits either way.)
+    if (n_tiles >= 4 && n_tiles <= 15 && M >= (n_tiles >= 10 ? 40960 : 4096) && N % 4 == 0) {
         const int n_rt = (M + 15) / 16;
 #define BH_WIDE(T, NTV, RBV, PFV)                                                                                                  \
         do {                                                                                                                       \

@@ -50,8 +50,9 @@ SHAPES = [
     (65, 64, 304, 100, True, 1),     # ... seven column tiles over blocked rows, K % 32 != 0
     (17, 256, 816, 136, True, 1),    # ... the 8x32 stage's shape, blocked
     (17, 256, 816, 136, False, 0),   # ... and in NHWC
-    (64, 64, 336, 232, True, 1),     # ... fifteen column tiles (the 4x16 stage's width), blocked
-    (64, 64, 336, 232, True, 0),
+    (640, 64, 336, 232, True, 1),    # ... fifteen column tiles (the 4x16 stage's width; N > 144 streams from 40 960 rows up), blocked
+    (641, 64, 176, 232, True, 0),
+    (64, 64, 336, 232, True, 1),     # the same width below 40 960 rows: staged tiles
     (83, 50, 60, 84, True, 0),       # ... partial last tile, tiles straddling segments, gate rows of several segments a pass
     (64, 64, 128, 384, True, 0),     # 128 x 128 staged tiles (N = 384)
     (3, 64, 304, 100, True, 1),      # fewer than 4 096 rows: staged tiles over blocked rows
@@ -72,7 +73,7 @@ def test_gated_gemm_matches_float64(shape):
         assert np.isfinite(got).all() and err.max() <= tol, (shape, terms, float(err.max()))
 
 
-@pytest.mark.parametrize("shape", [(80, 64, 336, 232, True), (20, 256, 816, 136, True), (6, 1008, 24, 24, True), (6, 1008, 192, 32, True),
+@pytest.mark.parametrize("shape", [(650, 64, 336, 232, True), (20, 256, 816, 136, True), (6, 1008, 24, 24, True), (6, 1008, 192, 32, True),
                                    (90, 64, 128, 64, False)], ids=lambda s: "n%d_P%d_K%d_N%d_r%d" % s)
 def test_a_rows_bits_do_not_depend_on_the_kernel(shape):
     """The first segments of a large launch (streaming / row-streaming kernels) against the same segments as a launch of their own

@@ -38,6 +38,19 @@ int main(int argc, char **argv) {
         printf("M %d K %d N %d P %d blocked %d %-46s: %8.1f us  (%.2f TB/s of D + R + C)\n", M, K, N, P, blocked, what, ms * 1e3 / reps, bytes / (ms * 1e-3 / reps) / 1e12);
     };
     run("product dispatch", [&] { bh::launch_pw_gemm16_gated(A, gate, P, W, bias, R, C, M, K, N, 3, 1.0f, blocked, s); });
+    if (nt > 3) {      // the 128 x 128 staged tiles the dispatch keeps for small launches and N > 240
+        int ntb = 8; long best = -1;
+        for (int cand : {10, 8, 6}) { const long padded = (long)((nt + cand - 1) / cand) * cand; if (best < 0 || padded < best) { best = padded; ntb = cand; } }
+        const int n_xb = (nt + ntb - 1) / ntb, n_yb = (M + 127) / 128;
+        dim3 grid((unsigned)(n_xb * n_yb)), block(256);
+#define GS(NTBV, BLKV)                                                                                                             \
+        if (ntb == NTBV && (blocked != 0) == BLKV) {                                                                               \
+            constexpr size_t lds = 2 * ((8 + NTBV) * 2 * 256) * sizeof(float);                                                     \
+            (void)hipFuncSetAttribute((const void *)bh::pw_gemm16s_kernel<3, bh::ACT_NONE, true, NTBV, BLKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            run("staged 128 x 128 tiles", [&] { hipLaunchKernelGGL((bh::pw_gemm16s_kernel<3, bh::ACT_NONE, true, NTBV, BLKV>), grid, block, lds, s, A, (const bh::f16x8 *)W, bias, R, C, M, K, N, nt, 1.0f, gate, P); }); \
+        }
+        GS(6, false) GS(6, true) GS(8, false) GS(8, true) GS(10, false) GS(10, true)
+    }
 #define GG(NTV, RBV, PFV, DBGV, what)                                                                                              \
     if (nt == NTV) {                                                                                                               \
         const int gs_max = (8 * RBV * 16 + P - 2) / P + 1;                                                                         \
