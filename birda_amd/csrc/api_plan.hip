@@ -471,9 +471,10 @@ int plan_fusion(bh_classifier *c) {
             bh::MbDesc tw{};
             tw.cfg = -1;
             static const bool no_twin = BH_XENV("BIRDA_HIP_MB_TWIN") && BH_XENV("BIRDA_HIP_MB_TWIN")[0] == '0';   // (A/B aid)
-            // (squeeze-excite blocks keep ONE tiling: the pooled sums are added tile by tile, and a segment's logits must not depend
-            //  on the size of the launch it ran in)
-            if (force_cfg < 0 && !no_twin && !d.se && bh::mb_plan_twin(d, tw)) c->mb_small.push_back(tw);
+            // (squeeze-excite blocks keep ONE tiling -- the pooled sums are added tile by tile, and a segment's logits must not depend
+            //  on the size of the launch it ran in -- except where the one-segment twin adds them in the very same order:
+            //  mb_twin_sums_match, the 4x16 stages' whole-image tiles)
+            if (force_cfg < 0 && !no_twin && bh::mb_plan_twin(d, tw) && (!d.se || bh::mb_twin_sums_match(d, tw))) c->mb_small.push_back(tw);
             else { tw.cfg = -1; c->mb_small.push_back(tw); }
             bh::MbDesc nw{};
             nw.cfg = -1;

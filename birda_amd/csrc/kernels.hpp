@@ -494,7 +494,8 @@ int mb_config_count();
 int mb_config_name(int ci, char *out, size_t cap);
 // picks the instantiation (force_cfg >= 0: that entry or fail) and fills the derived fields
 bool mb_plan(MbDesc &d, int force_cfg);
-bool mb_plan_twin(const MbDesc &d, MbDesc &twin);   // one-segment-per-workgroup twin of a two-segment configuration (small launches)
+bool mb_plan_twin(const MbDesc &d, MbDesc &twin);
+bool mb_twin_sums_match(const MbDesc &d, const MbDesc &twin);   // squeeze-excite pass A: the twin's pooled sums are the block's, bit for bit   // one-segment-per-workgroup twin of a two-segment configuration (small launches)
 bool mb_plan_narrow(const MbDesc &d, MbDesc &narrow);   // narrow-tile twin of a whole-image configuration (launches of a few segments)
 void launch_mbconv(const MbDesc &d, int n_seg, hipStream_t s);
 

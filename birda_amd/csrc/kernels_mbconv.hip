@@ -217,6 +217,20 @@ bool mb_plan_twin(const MbDesc &d, MbDesc &twin) {
     return false;
 }
 
+// Pass A of a squeeze-excite block on its one-segment twin: the pooled sums must come out bit for bit as from the two-segment tile
+// (a segment's logits do not depend on the launch it ran in).  The store phase gives thread tid the pixels tid / C4N + k NTH / C4N
+// of the workgroup's segments and adds up per thread, per row of 16 lanes, then over (wave, row) in order: when a segment's pixels
+// (whole image = one tile) are a multiple of NTH / C4N, segment slot 1 of the two-segment tile maps its pixels to threads exactly
+// as slot 0 does, and as the twin's only slot does -- the same additions in the same order.
+bool mb_twin_sums_match(const MbDesc &d, const MbDesc &tw) {
+    if (d.cfg < 0 || tw.cfg < 0 || d.cfg >= kNCfgs || tw.cfg >= kNCfgs) return false;
+    const MbCfg &c = kCfgs[d.cfg], &q = kCfgs[tw.cfg];
+    if (!q.launch_se || d.tiles_x * d.tiles_y != 1 || tw.tiles_x * tw.tiles_y != 1) return false;
+    if (c.CE != q.CE || c.WM * c.WN != q.WM * q.WN || c.TWL != q.TWL || d.TH != tw.TH || q.S != 1) return false;
+    const int nth = 64 * c.WM * c.WN, step = nth / (c.CE / 4), thtw = d.TH << c.TWL;
+    return step > 0 && thtw % step == 0;
+}
+
 // The few-segment twin of a planned WHOLE-IMAGE block, if its configuration has one: the same chunk size, k steps, precision,
 // activation and project-tile count (the block's weights serve it too), one segment per workgroup, and a NARROWER tile -- two or
 // four workgroups per image, each expanding the halo columns of its own tile again.  A launch of a few dozen segments leaves most of

@@ -1106,12 +1106,14 @@ def test_perch_sized_model_matches_oracle(oracle_lib, tmp_path):
                 assert np.allclose([p.confidence for p in r.predictions], conf, rtol=2e-3, atol=1e-7)
         if prec != "f32":
             # a segment's row does not depend on the launch it ran in: 3 segments take the 128 x 128 staged tiles of the gated project
-            # GEMM (fewer than 4 096 rows), 80 take the streaming / row-streaming kernels -- over D in NHWC and, for N = 96 .. 232,
-            # blocked (kernels.hpp MbDesc::dblk); pass A runs its one-segment and narrow-tile twins in the small launch
-            big = clf.create_batch_context(80)
-            g80 = clf.predict_logits(big, np.ascontiguousarray(np.tile(segs, (27, 1))[:80]))
-            assert (g80[:3] == got).all() and (g80[78:80] == got[:2]).all(), prec
-            big.close()
+            # GEMM (fewer than 4 096 rows), 80 and 300 take the streaming / row-streaming kernels -- over D in NHWC and, for N = 96 ..
+            # 232, blocked (kernels.hpp MbDesc::dblk); pass A of the 4x16 stages runs its one-segment twins up to 256 segments
+            # (mb_twin_sums_match: the pooled sums in the two-segment tile's order) and the two-segment tiles beyond
+            for nbig in (80, 300):
+                big = clf.create_batch_context(nbig)
+                gb = clf.predict_logits(big, np.ascontiguousarray(np.tile(segs, (nbig // 3 + 1, 1))[:nbig]))
+                assert all((gb[i] == got[i % 3]).all() for i in range(nbig)), (prec, nbig)
+                big.close()
         ctx.close(); clf.close()
 
 
