@@ -79,7 +79,9 @@ struct bh_classifier {
     // channel sums, which live in the arena slot of the (never materialised) OP_SCALE output
     struct SeInfo { uint32_t iD = 0, iGap = 0, iPw1 = 0, iPw2 = 0, iScale = 0, iP = 0; size_t part_floats = 0; };
     std::vector<SeInfo> se;
-    int narrow_max_workgroups = 512;         // launches whose narrow tiles number at most this take them (measured: tools/gpu_latency.py)
+    int narrow_max_workgroups = 256;         // launches whose narrow tiles number at most this take them: one workgroup a CU at most (round 5, swept
+                                             // per layer at 32 .. 256 segments, profiles/r5_g_narrow_tiles_sweep.txt: beyond, every extra workgroup streams
+                                             // the block's 2 MB of weights again -- at 512 a launch of 160-256 segments lost 3-4 %)
     int precision = 0;                       // GEMM operands of the fused blocks: 0 f32, 3 f16 hi/lo split, 1 f16
     // BH_FLAG_AUTO (the default): split-f16 compute, and a row whose logits come out inf / NaN from finite samples (an activation
     // left the f16 range) is computed again on the library's own f32 kernels -- by `fb`, a second classifier of the same model

@@ -872,7 +872,7 @@ def test_sixty_four_distinct_segments_of_the_full_model_match_the_oracle(full_mo
 
 
 def test_launches_of_a_few_segments_take_the_narrow_tiles_and_give_the_same_bits(full_model):
-    """Round 4: a launch whose narrow tiles number at most 512 (a one-minute file is 20 segments) runs the late blocks on 8-column
+    """Round 4: a launch whose narrow tiles number at most 256 (512 until round 5; a one-minute file is 20 segments) runs the late blocks on 8-column
     tiles -- four / two workgroups per image, mbconv_cfgs.inc entries 193-202, kernels_mbconv.hip mb_plan_narrow -- and a launch of
     at most 256 segments the one-segment twins, a larger one the two-segment tiles.  The same segments must come out BIT-identical
     whichever of the three a call takes (a pixel's sums do not depend on the tile it is computed in), in both f16 modes and f32."""
@@ -895,7 +895,7 @@ def test_launches_of_a_few_segments_take_the_narrow_tiles_and_give_the_same_bits
         clf = BirdClassifier(path, labels, precision=prec)
         big = clf.create_batch_context(300)
         ref = clf.predict_logits(big, segs)                                 # two-segment tiles
-        for k in (1, 20, 64, 128, 256):                                     # narrow / narrow / narrow / narrow (3x16 only) / one-segment twins
+        for k in (1, 20, 64, 128, 256):                                     # narrow / narrow / narrow (6x32: 256 tiles) / narrow (3x16 only) / one-segment twins
             ctx = clf.create_batch_context(k)
             got = clf.predict_logits(ctx, segs[:k])
             assert np.array_equal(got, ref[:k]), (prec, k, float(np.abs(got - ref[:k]).max()))
