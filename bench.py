@@ -238,7 +238,9 @@ def analyse_se(clf, m, fused, layer_tot, segs_done, steps, slices_per_step, prec
         thin = nt <= 3 and -(-K // 32) * nt * 2048 <= 65536 and rows >= 4096 and N % 4 == 0
         wide = 4 <= nt <= 15 and rows >= 4096 and N % 4 == 0
         terms = 3 if precision in ("auto", "f16x3") else 1
-        if precision == "f32":
+        if i0 == d:     # a block without an expand convolution: D is computed again by the gated one-launch block (kernels.hpp MbDesc::gate)
+            bname, bkind = clf.fused_kernel_name(fused[fi - 1], se=False) + " (no-expand block: depthwise x gate -> project + residual in one launch)", "hbm"
+        elif precision == "f32":
             bname, bkind = "gated project GEMM %d -> %d (pw_gemm_kernel, f32 MFMA)" % (K, N), "mfma"
         elif thin:
             bname, bkind = "pw_gemm16_thin_kernel<%d, %d, %s, 0>" % (terms, nt, "true" if K <= 32 else "false"), "hbm"
@@ -250,7 +252,7 @@ def analyse_se(clf, m, fused, layer_tot, segs_done, steps, slices_per_step, prec
         gb = groups.setdefault(("B", bname), {"ms": 0.0, "launches": 0, "flops": 0.0, "bytes": 0.0, "kind": bkind})
         gb["ms"] += layer_tot[p][0]; gb["launches"] += layer_tot[p][1]
         gb["flops"] += 2.0 * px * K * N * segs_done
-        gb["bytes"] += 4.0 * px * (K + N + (N if P.res_tensor != mf.NO_TENSOR else 0)) * segs_done
+        gb["bytes"] += 4.0 * px * (K + N + (N if (P.res_tensor != mf.NO_TENSOR and i0 != d) else 0)) * segs_done     # (no-expand: the residual IS the input it reads)
         b_us["%d->%d @%dx%d" % (K, N, D.out_h, D.out_w)] = b_us.get("%d->%d @%dx%d" % (K, N, D.out_h, D.out_w), 0.0) + layer_tot[p][0] * 1e3 / segs_done * 1000
     out = {}
     if not groups:

@@ -231,10 +231,14 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
                 const auto &S = c->se[c->fused_at[i]];
                 const auto &G1 = m.layers[S.iPw1], &G2 = m.layers[S.iPw2], &LP = m.layers[S.iP];
                 d.X = in;
-                d.Dout = T(S.iD + 1);
+                // (a block without an expand convolution computes D twice instead of keeping it: pass A leaves only the channel sums,
+                //  the gated one-launch block below does the rest -- kernels.hpp MbDesc::gate)
+                const bool recompute = d.noexp != 0;
+                d.Dout = recompute ? nullptr : T(S.iD + 1);
                 d.pool_part = T(S.iScale + 1);
+                d.gate = nullptr;
                 // (D blocked for the f16 gated GEMMs: kernels.hpp MbDesc::dblk)
-                d.dblk = c->d_w16[S.iP] && bh::pw_gemm16_gated_wants_blocked(d.Cexp, d.Cout, d.Ho * d.Wo);
+                d.dblk = !recompute && c->d_w16[S.iP] && bh::pw_gemm16_gated_wants_blocked(d.Cexp, d.Cout, d.Ho * d.Wo);
                 bh::launch_mbconv(d, (int)n, s);
                 ctx_mark(ctx, ST_MBCONV, (int)i);
                 float *gate = T(S.iPw2 + 1);
@@ -255,6 +259,11 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
                 ctx_mark(ctx, ST_GAP, (int)S.iGap);
                 float *y = (S.iP == nl - 1) ? d_logits : T(S.iP + 1);
                 const float *r = LP.res_tensor != bh::NO_TENSOR ? T(LP.res_tensor) : nullptr;
+                if (recompute) {      // depthwise -> x gate -> project (+ residual) in one launch, the block's own weights and tiling
+                    bh::MbDesc g = d;
+                    g.se = 0; g.gate = gate; g.Y = y; g.R = r; g.Dout = nullptr; g.pool_part = nullptr;
+                    bh::launch_mbconv(g, (int)n, s);
+                } else
                 if (c->d_w16[S.iP])
                     bh::launch_pw_gemm16_gated(d.Dout, gate, P, c->d_w16[S.iP], c->d_blob + LP.b_off, r, y, (int)(n * (size_t)P), d.Cexp, d.Cout,
                                                c->precision == 3 ? 3 : 1, c->w16_unscale[S.iP], d.dblk, s);

@@ -489,6 +489,11 @@ struct MbDesc {
     // late blocks: 3.2-3.6 TB/s on NHWC), and pass A's stores are 1-KB runs instead of 64-byte ones.  Only pass A and the gated GEMMs
     // ever see D (api.hip forward_slice sets the flag for both).
     int dblk;
+    // A squeeze-excite block WITHOUT an expand convolution (KG = 0; EfficientNet's expand-ratio-1 blocks: D is no larger than the
+    // block input) is cheaper to compute twice than to keep: pass A runs with Dout = nullptr (channel sums only, nothing stored),
+    // and the one-launch block (se = 0) takes gate != nullptr -- [n][Cexp], multiplied into the depthwise output in front of the
+    // project phase's f16 split, where the gated GEMMs apply it too.  D never exists (api.hip forward_slice).
+    const float *gate;
 };
 int mb_config_count();
 int mb_config_name(int ci, char *out, size_t cap);

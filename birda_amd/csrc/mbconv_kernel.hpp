@@ -504,7 +504,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
     const float *Rb = d.R ? d.R + (size_t)seg0 * d.Ho * d.Wo * Cout : nullptr;
     f32x4 acco[MT_W][NT_W];
     // SE (pass A of a squeeze-excite block): where the depthwise output and the tile's channel sums go
-    float *Dg = SE ? d.Dout + (size_t)seg0 * d.Ho * d.Wo * d.Cexp : nullptr;
+    const bool se_store = SE && d.Dout != nullptr;      // (nullptr: sums only -- the no-expand blocks, whose D is computed again by the gated one-launch block)
+    float *Dg = SE ? (se_store ? d.Dout : reinterpret_cast<float *>(size_t(1) << 30)) + (size_t)seg0 * d.Ho * d.Wo * d.Cexp : nullptr;   // (never dereferenced without se_store)
     // SE store phase: thread (channel quad tid % C4N, pixel tid / C4N + k NTH / C4N) -- the same pixels in every chunk, so their rows
     // of D are looked up once per tile (nullptr: outside the image or the batch)
     constexpr int SE_NP = SE ? (POUT_PAD + NTH / C4N - 1) / (NTH / C4N) : 1;
@@ -909,6 +910,14 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                 const int c4 = p2_c4;
                 const float *eb = Es + p2_eoff;
                 const float4 bd4 = *reinterpret_cast<const float4 *>(&bds[4 * c4]);
+                f32x2 gq0 = (f32x2){1.f, 1.f}, gq1 = gq0;     // (KG = 0, se = 0, gate: the squeeze-excite gate of a no-expand block, MbDesc::gate)
+                if constexpr (KG == 0 && !SE) {
+                    if (d.gate) {
+                        const int sl = (SS > 1 && p2_prow >= THTW) ? 1 : 0, cgq = ch * CE + 4 * c4;
+                        const float4 gv = *reinterpret_cast<const float4 *>(d.gate + (size_t)min(seg0 + sl, n_seg - 1) * d.Cexp + min(cgq, d.Cexp - 4));
+                        if (cgq < d.Cexp) { gq0 = (f32x2){gv.x, gv.y}; gq1 = (f32x2){gv.z, gv.w}; }
+                    }
+                }
                 // two-wide vectors so the taps become v_pk_fma_f32 (2 FMAs per instruction)
                 f32x2 acc[XB][2];
 #pragma unroll
@@ -935,6 +944,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                 for (int x = 0; x < XB; x++) {
                     f32x2 g0 = acc[x][0], g1 = acc[x][1];
                     mb_act4<ACT, PREC>(g0, g1);
+                    if constexpr (KG == 0 && !SE) { g0 *= gq0; g1 *= gq1; }
                     const float4 v = make_float4(g0[0], g0[1], g1[0], g1[1]);
                     const int prow = p2_prow + x;
                     if constexpr (PREC != 0 && !SE) {   // the project GEMM's A operand: f16 hi (+ lo) planes
@@ -994,7 +1004,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                 if (p0 < npix_pad) {      // (uniform but for the last pass)
                     const f32x4 v = *reinterpret_cast<const f32x4 *>(&Ds[p0 * CES + 4 * c4]);
                     if (se_dst[k]) {
-                        if (cg < d.Cexp) *reinterpret_cast<f32x4 *>(se_dst[k] + cgo) = v;
+                        if (se_store && cg < d.Cexp) *reinterpret_cast<f32x4 *>(se_dst[k] + cgo) = v;
                         if (SS == 1 || p0 < THTW) ssum[0] += v; else ssum[SS - 1] += v;
                     }
                 }

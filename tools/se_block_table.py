@@ -16,7 +16,9 @@ def load(path):
     return out
 
 
-def gated_kernel(K, N, rows):
+def gated_kernel(K, N, rows, noexp=False):
+    if noexp:
+        return "fused"      # no expand convolution: depthwise x gate -> project in one launch, D computed again
     nt = -(-N // 16)
     if nt <= 3 and -(-K // 32) * nt * 2048 <= 65536 and rows >= 4096:
         return "thin x2" if K <= 32 else "thin"
@@ -41,5 +43,5 @@ for b, (i0, d, g, p) in enumerate(blocks):
     a, gt, pb = se.get(i0, 0.0), se.get(g, 0.0), se.get(p, 0.0)
     nf = nose.get(firsts[b], 0.0) if b < len(firsts) else 0.0
     ta += a; tg += gt; tb += pb; tn += nf
-    print(f"{b + 1:5d} {i0:12d}  {D.out_h}x{D.out_w:<6d} {P.cin:5d}->{P.cout:4d}     {D.kh} {D.sh} | {a:7.1f} {gt:7.1f} {pb:8.1f}  ({gated_kernel(P.cin, P.cout, 1000 * D.out_h * D.out_w):7s}) | {nf:8.1f}")
+    print(f"{b + 1:5d} {i0:12d}  {D.out_h}x{D.out_w:<6d} {P.cin:5d}->{P.cout:4d}     {D.kh} {D.sh} | {a:7.1f} {gt:7.1f} {pb:8.1f}  ({gated_kernel(P.cin, P.cout, 1000 * D.out_h * D.out_w, i0 == d):7s}) | {nf:8.1f}")
 print(f"\nsum: pass A {ta / 1000:.2f} us per segment, gate {tg / 1000:.2f}, pass B {tb / 1000:.2f}; gate-free fused blocks {tn / 1000:.2f}")
