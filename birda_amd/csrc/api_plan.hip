@@ -379,8 +379,8 @@ int plan_fusion(bh_classifier *c) {
         //  8 kq + 3 q + dx of the one 32-deep step is tap (dy, dx) of channel ch with run 2 kq + q = 3 ch + dy)
         auto we_at = [&](int k, int n) {
             if (d.stem && h16) {
-                const int kq = k >> 3, jj = k & 7, r = 2 * kq + jj / 3, dx = jj % 3;
-                if (k >= 32 || jj >= 6 || r >= 3 * d.stem_c) return 0.0f;
+                const int g = k >> 5, kq = (k & 31) >> 3, jj = k & 7, r = 8 * g + 2 * kq + jj / 3, dx = jj % 3;
+                if (jj >= 6 || r >= 3 * d.stem_c) return 0.0f;
                 const int ch = r / 3, dy = r - 3 * ch;
                 k = (dy * 3 + dx) * d.stem_c + ch;
             }

@@ -32,29 +32,41 @@ const CfgTables &cfg_tables() { static const CfgTables T; return T; }
 
 // fills the derived fields for entry `ci` with tile height `th`; returns the estimated MFMA work
 // per segment (in 16x16x4 steps), or -1 when the entry cannot run this block at that height
-double mb_try_th(MbDesc &d, int ci, int th) {
+// (why an entry was refused, counted per reason while BIRDA_HIP_MB_WHY is set: tools/plan_coverage.py --why)
+thread_local int g_why[16];
+#define MB_NO(r) do { g_why[r]++; return -1; } while (0)
+double mb_try_th(MbDesc &d, int ci, int th, bool relax_kg = false) {
     const MbCfg &c = kCfgs[ci];
     // any Cexp: the last chunk's missing channels are zero weights and biases (every activation here maps 0 to 0)
     if (c.KS != d.KS || c.ST != d.ST || (!d.stem && d.Cin % 4) || d.Cexp % 4) return -1;
-    if (c.STEM != (d.stem ? d.stem_c : 0)) return -1;
+    if (c.PREC != d.prec) return -1;
+    if (d.act_e != c.ACT || d.act_d != c.ACT || (!d.se && d.act_p != ACT_NONE)) MB_NO(1);   // (se: the project conv is another launch)
+    if (c.STEM != (d.stem ? d.stem_c : 0)) MB_NO(2);
     // (the kernel's per-lane offsets are 24-bit products and 32-bit element offsets within one workgroup's segments)
     if ((long)c.S * d.H * d.W * std::max(d.Cin, 1) >= (1L << 24) || (long)c.S * d.Ho * d.Wo * d.Cout >= (1L << 24) ||
         (d.stem && (long)d.stem_c * d.stem_h * d.stem_w >= (1L << 24))) return -1;
-    if (d.stem && d.stem_k != 3) return -1;
-    if (c.PREC != d.prec) return -1;
-    if (d.se && (!c.launch_se || c.PERSIST)) return -1;   // pass A of a squeeze-excite block: only where it is instantiated (mbconv_kernel.hpp MB_WITH_SE)
+    if (d.stem && d.stem_k != 3) MB_NO(3);
+    if (d.se && (!c.launch_se || c.PERSIST)) MB_NO(4);   // pass A of a squeeze-excite block: only where it is instantiated (mbconv_kernel.hpp MB_WITH_SE)
     if (c.KG == 0) { if (!d.noexp || d.stem) return -1; }   // the no-expand entries serve the no-expand blocks, and only them
-    else if (d.noexp || (d.Cin + (c.PREC ? 31 : 15)) / (c.PREC ? 32 : 16) != c.KG) return -1;
-    if (d.act_e != c.ACT || d.act_d != c.ACT || (!d.se && d.act_p != ACT_NONE)) return -1;   // (se: the project conv is another launch)
+    else {
+        // k steps of the expand GEMM: the entry's own number, or (relax_kg: a block no entry was shaped for) any number up to it --
+        // the columns past Cin are zero weights (plan_fusion) against zeroed operands (the kernel masks its loads at Cin)
+        // (stem block in the f16 modes: the im2col columns are packed by memory runs, 8 runs of three taps to a step)
+        const int need = (d.stem && c.PREC) ? (3 * d.stem_c + 7) / 8 : (d.Cin + (c.PREC ? 31 : 15)) / (c.PREC ? 32 : 16);
+        if (d.noexp) return -1;
+        if (need != c.KG && !(relax_kg && need < c.KG && !d.stem)) MB_NO(5);
+    }
     if (c.COLTH) {   // column tasks: the tile is the whole image, COLTH rows high, symmetric padding, one task per thread
-        if (th != c.COLTH || d.Ho != c.COLTH || d.H != c.COLTH || d.ST != 1 || d.pad_t != (c.KS - 1) / 2) return -1;
-        if (c.S * (1 << c.TWL) * (c.CE / (c.WM * c.WN == 8 ? 2 : 4)) > 64 * c.WM * c.WN) return -1;   // one task per thread
+        // (relaxed: any image up to COLTH rows high -- the rows below it are grid rows that stay zero, exactly the padding a column
+        //  task skips at compile time above and below the image; their outputs are computed and never stored)
+        if (th != c.COLTH || d.Ho > c.COLTH || d.H > c.COLTH || (!relax_kg && d.H != c.COLTH) || d.ST != 1 || d.pad_t != (c.KS - 1) / 2) MB_NO(6);
+        if (c.S * (1 << c.TWL) * (c.CE / (c.WM * c.WN == 8 ? 2 : 4)) > 64 * c.WM * c.WN) MB_NO(6);   // one task per thread
     }
     const int nto = (d.Cout + 15) / 16;
-    if (nto > c.WN * c.NT_W) return -1;
+    if (nto > c.WN * c.NT_W) MB_NO(7);
     const int TW = 1 << c.TWL;
     const int ces = c.CE + 4, pout_pad = c.WM * c.MT_W * 16;
-    if (th < 1 || c.S * th * TW > pout_pad) return -1;
+    if (th < 1 || c.S * th * TW > pout_pad) MB_NO(8);
     MbDesc t = d;
     t.cfg = ci; t.TH = th; t.S = c.S;
     t.tiles_y = (d.Ho + th - 1) / th; t.tiles_x = (d.Wo + TW - 1) / TW;
@@ -62,7 +74,7 @@ double mb_try_th(MbDesc &d, int ci, int th) {
     t.KG = c.KG; t.nchunks = (d.Cexp + c.CE - 1) / c.CE; t.NTOP = c.WN * c.NT_W; t.CE = c.CE;
     const int mseg = std::min(t.IH, d.H) * std::min(t.IW, d.W);
     t.mpad_max = (c.S * mseg + 15) / 16 * 16;
-    if (t.mpad_max / 16 > c.RT_W * (c.WM * c.WN / c.NCS)) return -1;  // a wave keeps all its rows of X in registers
+    if (t.mpad_max / 16 > c.RT_W * (c.WM * c.WN / c.NCS)) MB_NO(9);  // a wave keeps all its rows of X in registers
     const size_t frag = c.PREC ? 512 : 256, psteps = c.PREC ? (c.CE + 31) / 32 : c.CE / 16;
     const bool p16 = c.PREC && c.CE == 16;   // one 16-deep project step, half-size fragments and D rows
     const size_t we_fl = (size_t)c.KG * (c.CE / 16) * frag + c.CE, wp_fl = p16 ? (size_t)t.NTOP * 256 : psteps * t.NTOP * frag;
@@ -74,7 +86,7 @@ double mb_try_th(MbDesc &d, int ci, int th) {
     const size_t halo_bytes = c.PERSIST == 2 ? (size_t)t.nchunks * (c.KS - c.ST) * t.IW * ces * 4 : 0;   // [chunk][KS - ST rows][IW][ces]
     const size_t lds_base = (((size_t)c.S * t.IH * t.IW + 1) * ces + ds_fl) * 4 + (size_t)pout_pad * 4 + halo_bytes;
     t.lds_bytes = lds_base + (we_fl + wp_fl + wd_fl) * 4 * (c.PERSIST == 1 ? (size_t)t.nchunks : 1);   // persistent: every chunk resident
-    if (t.lds_bytes > 160 * 1024) return -1;
+    if (t.lds_bytes > 160 * 1024) MB_NO(10);
     if (c.PERSIST == 1 && t.lds_bytes > 80 * 1024) return -1;   // one workgroup per CU cannot hide its own set-up
     // weight ring (We x 2, Wp x 3, Wd x 2, a whole chunk of prefetch distance): for 16-channel chunks, when the workgroups the
     // entry's register budget allows per CU still fit in LDS with it.  BIRDA_HIP_MB_RING=0/1 forces it off / on where it fits.
@@ -105,10 +117,16 @@ int mb_act_index(const MbDesc &d, int base) {
 }
 
 // the entry's own tile height if it fits this block's image, else the tallest one that does
-double mb_try(MbDesc &d, int ci) {
+double mb_try(MbDesc &d, int ci, bool relax_kg = false) {
+    if (kCfgs[ci].COLTH) {   // column tasks: the entry's height or nothing (a lower image leaves the rows below it unused)
+        MbDesc t = d;
+        const double w = mb_try_th(t, ci, kCfgs[ci].COLTH, relax_kg);
+        if (w >= 0) d = t;
+        return w;
+    }
     for (int th = std::min(kCfgs[ci].TH, std::max(d.Ho, 1)); th >= 1; th--) {
         MbDesc t = d;
-        const double w = mb_try_th(t, ci, th);
+        const double w = mb_try_th(t, ci, th, relax_kg);
         if (w >= 0) { d = t; return w; }
     }
     return -1;
@@ -186,18 +204,28 @@ bool mb_plan(MbDesc &d, int force_cfg) {
             if (ci >= 0 && mb_try_th(t, ci, kCfgs[ci].TH) >= 0) { d = t; return true; }
         }
     }
-    double best = -1;
-    MbDesc bestd = d;
-    for (int ci = 0; ci < kNCfgs; ci++) {
-        if (kCfgs[ci].PERSIST) continue;   // persistent entries only through the preferred list (measured shapes)
-        MbDesc t = d;
-        const double w = mb_try(t, ci);
-        if (w < 0) continue;
-        if (best < 0 || w < best) { best = w; bestd = t; }
+    // ... then any entry that can run the block, the one with the least MFMA work: first among the entries whose k steps are the
+    // block's own (the shapes of this repo's plans land here or above, unchanged since round 4), then -- a stack nobody tiled by
+    // hand -- among those with MORE k steps than the block needs, the surplus zero-padded
+    static const bool why = getenv("BIRDA_HIP_MB_WHY") != nullptr;
+    for (int relax = 0; relax < 2; relax++) {
+        double best = -1;
+        MbDesc bestd = d;
+        if (why) std::fill(g_why, g_why + 16, 0);
+        for (int ci = 0; ci < kNCfgs; ci++) {
+            if (kCfgs[ci].PERSIST) continue;   // persistent entries only through the preferred list (measured shapes)
+            MbDesc t = d;
+            const double w = mb_try(t, ci, relax != 0);
+            if (w < 0) continue;
+            if (best < 0 || w < best) { best = w; bestd = t; }
+        }
+        if (best >= 0) { d = bestd; return true; }
     }
-    if (best < 0) return false;
-    d = bestd;
-    return true;
+    if (why)
+        fprintf(stderr, "mb_plan: no entry for %s%d -> %d -> %d k%d s%d %dx%d -> %dx%d act %d prec %d se %d: refused by act %d stem %d stemk %d se %d kg %d colth %d nto %d pout %d rows %d lds %d\n",
+                d.stem ? "stem " : d.noexp ? "noexp " : "", d.Cin, d.Cexp, d.Cout, d.KS, d.ST, d.H, d.W, d.Ho, d.Wo, d.act_e, d.prec, d.se,
+                g_why[1], g_why[2], g_why[3], g_why[4], g_why[5], g_why[6], g_why[7], g_why[8], g_why[9], g_why[10]);
+    return false;
 }
 
 // The small-batch twin of a planned block, if its configuration has one: the same chunk size, k steps, precision, activation and
@@ -212,7 +240,8 @@ bool mb_plan_twin(const MbDesc &d, MbDesc &twin) {
         if (q.S != 1 || q.COLTH != c.COLTH || q.KS != c.KS || q.ST != c.ST || q.CE != c.CE || q.KG != c.KG || q.PREC != c.PREC ||
             q.TWL != c.TWL || q.WM * q.WN != 8 || q.WN * q.NT_W != c.WN * c.NT_W || q.STEM != c.STEM || q.PERSIST) continue;
         MbDesc t = d;
-        if (mb_try_th(t, k0 + b, q.TH) >= 0 && t.NTOP == d.NTOP && t.nchunks == d.nchunks && t.KG == d.KG && t.CE == d.CE) { twin = t; return true; }
+        // (relaxed: the block may have come to its entry through the relaxed pass -- fewer k steps than the entry's, a lower image)
+        if (mb_try_th(t, k0 + b, q.TH, true) >= 0 && t.NTOP == d.NTOP && t.nchunks == d.nchunks && t.KG == d.KG && t.CE == d.CE) { twin = t; return true; }
     }
     return false;
 }
@@ -247,7 +276,7 @@ bool mb_plan_narrow(const MbDesc &d, MbDesc &narrow) {
         if (q.S != 1 || q.COLTH != c.COLTH || q.KS != c.KS || q.ST != c.ST || q.CE != c.CE || q.KG != c.KG || q.PREC != c.PREC ||
             q.TWL >= c.TWL || q.TWL >= best_twl || q.WM * q.WN != c.WM * c.WN || q.WN * q.NT_W != c.WN * c.NT_W || q.STEM != c.STEM || q.PERSIST) continue;
         MbDesc t = d;
-        if (mb_try_th(t, k0 + b, q.TH) >= 0 && t.NTOP == d.NTOP && t.nchunks == d.nchunks && t.KG == d.KG && t.CE == d.CE && t.tiles_y == 1 && t.tiles_x >= 2) {
+        if (mb_try_th(t, k0 + b, q.TH, true) >= 0 && t.NTOP == d.NTOP && t.nchunks == d.nchunks && t.KG == d.KG && t.CE == d.CE && t.tiles_y == 1 && t.tiles_x >= 2) {
             narrow = t; best_twl = q.TWL;
         }
     }

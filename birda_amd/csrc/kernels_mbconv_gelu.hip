@@ -1,4 +1,6 @@
 // The fused MBConv kernel's tile configurations (mbconv_cfgs.inc) instantiated for ONE activation: ACT_GELU_ERF.
+// (round 6: every entry also as pass A of a squeeze-excite block, as the swish unit since round 5 -- gated GELU / ReLU6 stacks)
+#define MB_WITH_SE 1
 #include "mbconv_kernel.hpp"
 
 namespace bh {

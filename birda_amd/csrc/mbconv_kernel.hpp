@@ -400,9 +400,10 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
             // (dx = 0, 1, 2) of one (channel, dy); elements 6, 7 of the group are zero (api.hip plan_fusion packs the weight rows
             // to match).  Two 12-byte loads per lane and row tile instead of eight scalar ones with a division chain per
             // element: the gather was the stem block's largest single cost (tools/abl.sh).
-            static_assert(STEM == 0 || PREC == 0 || (STEM <= 2 && KG == 1), "3 STEM runs fit the 8 run slots of one step");
-            F3 t[XBATCH][2];
-            bool okr[XBATCH][2];
+            // (more than two spectrogram channels -- a front-end of three mel branches: 9 runs -- take a second step: run 8 g + 2 kq + q)
+            static_assert(STEM == 0 || PREC == 0 || 3 * STEM <= 8 * KG, "3 STEM runs fit the 8 run slots of each step");
+            F3 t[XBATCH][KG][2];
+            bool okr[XBATCH][KG][2];
 #pragma unroll
             for (int ii = 0; ii < XBATCH; ii++) {
                 if (i0 + ii >= RT_W) continue;
@@ -411,11 +412,13 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                 const int sy = __mul24(xo[ii] >> 16, d.stem_s) - d.stem_pt, sx = __mul24(xo[ii] & 0xffff, d.stem_s) - d.stem_pl;
                 const int bx = min(max(sx, 0), d.stem_w - 3);   // the 3-float window, kept inside the row
 #pragma unroll
+                for (int g = 0; g < KG; g++)
+#pragma unroll
                 for (int q = 0; q < 2; q++) {
-                    const int r = 2 * kq + q, ch = r >= 3 ? 1 : 0, dy = r - 3 * ch, y = sy + dy;
-                    okr[ii][q] = rvv[ii] && r < 3 * STEM && y >= 0 && y < d.stem_h;
-                    const int yc = okr[ii][q] ? y : 0, chc = okr[ii][q] ? ch : 0;
-                    t[ii][q] = *reinterpret_cast<const F3 *>(Xb + (__mul24(__mul24(chc, d.stem_h) + yc, d.stem_w) + bx));
+                    const int r = 8 * g + 2 * kq + q, ch = STEM <= 2 ? (r >= 3 ? 1 : 0) : r / 3, dy = r - 3 * ch, y = sy + dy;
+                    okr[ii][g][q] = rvv[ii] && r < 3 * STEM && y >= 0 && y < d.stem_h;
+                    const int yc = okr[ii][g][q] ? y : 0, chc = okr[ii][g][q] ? ch : 0;
+                    t[ii][g][q] = *reinterpret_cast<const F3 *>(Xb + (__mul24(__mul24(chc, d.stem_h) + yc, d.stem_w) + bx));
                 }
             }
 #pragma unroll
@@ -424,19 +427,22 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                 if (i >= RT_W) continue;
                 const int sx = __mul24(xo[ii] & 0xffff, d.stem_s) - d.stem_pl;
                 const int sh = sx - min(max(sx, 0), d.stem_w - 3);
+#pragma unroll
+                for (int g = 0; g < KG; g++) {
                 float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int q = 0; q < 2; q++) {
                     // element dx is column sx + dx = bx + sh + dx; sh is -1 / 0 / +1 at the left edge / inside / at the right edge
-                    const F3 tt = t[ii][q];
+                    const F3 tt = t[ii][g][q];
                     const float e0 = sh == 0 ? tt.a : sh > 0 ? tt.b : 0.0f;
                     const float e1 = sh == 0 ? tt.b : sh > 0 ? tt.c : tt.a;
                     const float e2 = sh == 0 ? tt.c : sh > 0 ? 0.0f : tt.b;
-                    v[3 * q] = (okr[ii][q] && sx >= 0) ? e0 : 0.0f;
-                    v[3 * q + 1] = (okr[ii][q] && sx + 1 >= 0 && sx + 1 < d.stem_w) ? e1 : 0.0f;
-                    v[3 * q + 2] = (okr[ii][q] && sx + 2 < d.stem_w) ? e2 : 0.0f;
+                    v[3 * q] = (okr[ii][g][q] && sx >= 0) ? e0 : 0.0f;
+                    v[3 * q + 1] = (okr[ii][g][q] && sx + 1 >= 0 && sx + 1 < d.stem_w) ? e1 : 0.0f;
+                    v[3 * q + 2] = (okr[ii][g][q] && sx + 2 < d.stem_w) ? e2 : 0.0f;
                 }
-                bh_split8(v, ah[i][0], al[i][0]);
+                bh_split8(v, ah[i][g], al[i][g]);
+                }
             }
         } else {
             float4 raw[XBATCH][KG][NQ];
@@ -607,6 +613,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
             // tile i moves channels 16 j + 4 kq .. + 3 of its row: one 16-byte load and one ds_write_b128, the slots the GEMM's
             // epilogue would have written.
             static_assert(KG != 0 || NCS == 1, "no-expand blocks: no column split");
+            static_assert(KG != 0 || COLTH == 0, "no-expand blocks: row tasks (the gate of MbDesc::gate is applied in the row-task depthwise phase only)");
             float4 xv[RT_W][NT_E];
 #pragma unroll
             for (int i = 0; i < RT_W; i++)

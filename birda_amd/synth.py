@@ -270,20 +270,18 @@ def random_plan(seed: int, big: bool = False) -> dict:
     ri = lambda lo, hi: int(rng.integers(lo, hi + 1))
     n_br = ri(1, 3)
     n_mels = int(rng.choice([96, 128, 90, 121])) if big else ri(17, 32)
-    frames = ri(120, 260) if big else ri(33, 90)
-    sr = int(rng.choice([48000, 32000]))
-    fl0, hop0 = int(rng.choice([256, 512])), ri(60, 140)
-    n = (fl0 + (frames - 1) * hop0 + ri(0, hop0 - 1)) // 4 * 4
-    while (n - fl0) // hop0 + 1 != frames:
-        n += 4
+    # (the input length is one the reference's families have -- no graph states its sample rate, the library reads it off the length,
+    #  onnx_conv.hpp frontend_for -- the frames then follow from frame length and hop: odd and even counts alike)
+    sr, n = (48000, 12000) if not big else ((48000, 144000) if rng.integers(0, 2) else (32000, 160000))
+    fl0 = int(rng.choice([1024, 2048])) if big else int(rng.choice([256, 512]))
+    hop0 = ri(520, min(1100, fl0)) if big else ri(100, min(290, fl0))      # (frames overlap or touch, as every published front-end's do)
+    frames = (n - fl0) // hop0 + 1
     branches = [(fl0, hop0)]
     for _ in range(n_br - 1):
         found = None
-        for fl in rng.permutation([256, 512, 1024, 384]):
+        for fl in rng.permutation([1024, 2048, 512] if big else [256, 512, 1024, 384]):
             fl = int(fl)
-            if fl >= n:
-                continue
-            hs = [h for h in range(40, 200) if (n - fl) // h + 1 == frames]
+            hs = [h for h in range(60, fl + 1) if (n - fl) // h + 1 == frames]
             if hs:
                 found = (fl, int(rng.choice(hs)))
                 break

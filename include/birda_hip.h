@@ -319,7 +319,8 @@ BH_API int bh_batch_context_layer_ms(bh_batch_context *ctx, float *ms, uint32_t 
  * (nullable) receives the tile configuration index of each.  Environment (tuning / A-B aids, read at
  * create): BIRDA_HIP_FUSE=0 disables fusion (BIRDA_HIP_FUSE_SE=0: of the squeeze-excite blocks only, which then run as expand /
  * depthwise / pool / 1x1 / 1x1 / scale / project layers), BIRDA_HIP_MB_CFG=<i> forces configuration i where it is
- * valid, BIRDA_HIP_MB_PREFER=<i,j,...> tries those first, BIRDA_HIP_KEEP_FUSED=1 materialises the fused blocks' outputs for
+ * valid, BIRDA_HIP_MB_PREFER=<i,j,...> tries those first, BIRDA_HIP_MB_WHY=1 prints to stderr, for a block that found no tile
+ * configuration, how many entries each rule refused (tools/plan_coverage.py), BIRDA_HIP_KEEP_FUSED=1 materialises the fused blocks' outputs for
  * bh_debug_read_tensor, BIRDA_HIP_HEAD_GAP=0 keeps the head conv and the global average pool as two launches,
  * BIRDA_HIP_MEL_F32=1 keeps the front-end on the f32 MFMA in the f16 modes, BIRDA_HIP_MEL32=0/1 forces the 16-frame-fragment /
  * 32-frame-fragment front-end kernel (default: by hop).  BIRDA_HIP_COPY_THREADS=<n> (default min(8, hardware

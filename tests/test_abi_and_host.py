@@ -362,7 +362,11 @@ def test_shipped_tile_configurations_are_the_reachable_ones():
             assert args[16] == 0, f"configuration {ci}: a persistent-workgroup instantiation in the product build"
     reach, by_model = plan_models.survey(acts=(None, mf.ACT_SWISH, mf.ACT_RELU6))
     assert reach <= shipped
-    unreached = sorted({c % n_base for c in shipped} - {c % n_base for c in reach})
+    # Round 6: entries 211 .. are GENERIC -- shaped for a class of blocks (input / output width x depthwise kernel / stride), not for
+    # a block of this repo's plans; what holds them is tests/test_plan_coverage.py (every block of 57 plans nobody tiled by hand runs
+    # fused) and tests/test_random_plans_gpu.py.  Below 211 the rule stands: shipped = what the planner reaches on the repo's models.
+    GENERIC0 = 211
+    unreached = sorted({c % n_base for c in shipped if c % n_base < GENERIC0} - {c % n_base for c in reach})
     assert not unreached, f"shipped but never picked by the planner: {unreached}"
     # the headline models fuse every block they can in the f16 modes
     assert len(by_model["birdnet_v24/default/f16x3"]["fused"]) == 16 and not by_model["birdnet_v24/default/f16x3"]["unfused_triples"]
@@ -377,7 +381,8 @@ def test_shipped_tile_configurations_are_the_reachable_ones():
     so = os.path.getsize(os.path.join(ROOT, "birda_amd", "libbirda_hip.so"))
     # (8.2 MiB in round 3; + the f32 twins of the Perch-sized stack and the narrow-tile twins: 9.0; round 5: + every swish entry a second
     #  time as pass A of a squeeze-excite block, and the front-end evaluator: 10.8)
-    assert so < 12 * 2 ** 20, f"libbirda_hip.so grew to {so / 2 ** 20:.1f} MiB"
+    #  round 6: + 58 generic entries x 3 activations, and pass A of a squeeze-excite block for GELU and ReLU6 as well: 19.6)
+    assert so < 22 * 2 ** 20, f"libbirda_hip.so grew to {so / 2 ** 20:.1f} MiB"
 
 
 # ---------------- range filter tables (host logic, include/birda_host.h) ----------------
@@ -460,7 +465,7 @@ def test_environment_names_in_the_shipped_library_are_the_documented_ones():
                "BIRDA_HIP_ROCTX", "BIRDA_HOST_TIMING",                 # tracing / phase times
                # switches the parity tests drive the product library with: debug contexts, forced tile configurations, layer-by-layer
                # execution, either front-end kernel
-               "BIRDA_HIP_KEEP_TENSORS", "BIRDA_HIP_KEEP_FUSED", "BIRDA_HIP_MB_CFG", "BIRDA_HIP_MB_PREFER", "BIRDA_HIP_FUSE",
+               "BIRDA_HIP_KEEP_TENSORS", "BIRDA_HIP_KEEP_FUSED", "BIRDA_HIP_MB_CFG", "BIRDA_HIP_MB_PREFER", "BIRDA_HIP_MB_WHY", "BIRDA_HIP_FUSE",
                "BIRDA_HIP_MEL32", "BIRDA_HIP_MEL_F32", "BIRDA_HIP_HEAD_GAP",
                "BIRDA_HIP_FUSE_SE"}             # round 5: =0 runs squeeze-excite blocks layer by layer (::test_squeeze_excite_and_swish_stack_matches_oracle)
     assert names <= allowed, sorted(names - allowed)

@@ -64,11 +64,14 @@ def survey(plans, why=False, out=sys.stdout):
             missing = {}
             for prec, flag in PRECISIONS.items():
                 got = fused_layers(p, flag)
-                nf = sum(1 for (i, _) in starts if i in got)
+                # (a stem block no entry serves runs its stem conv as a layer of its own and the rest as a no-expand block: fused)
+                dwi = {id(D): k for k, D in enumerate(m.layers)}
+                is_fused = lambda i, D: i in got or dwi[id(D)] in got
+                nf = sum(1 for (i, D) in starts if is_fused(i, D))
                 tot[prec][0] += nf
                 tot[prec][1] += len(starts)
                 line += f"   {prec} {nf:3d}/{len(starts):<3d}"
-                missing[prec] = [(i, D) for (i, D) in starts if i not in got]
+                missing[prec] = [(i, D) for (i, D) in starts if not is_fused(i, D)]
             print(line, file=out)
             if why:
                 for prec, miss in missing.items():
