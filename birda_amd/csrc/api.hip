@@ -926,6 +926,9 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) try {
         p.out_scale = br.out_scale; p.out_shift = br.out_shift; p.flip = (int)(br.flags & 1u);
         c->mel_flops += 2ull * (uint64_t)p.K * nm_pad * br.n_frames;
     }
+    if (bh::mel_lds_bytes(c->fe) > 160 * 1024)
+        return fail(BH_ERR_UNSUPPORTED, "front-end: a tile of frames at this hop and frame length spans %zu KB of samples, more than a CU's 160 KB of LDS",
+                    bh::mel_lds_bytes(c->fe) / 1024);
     {
         float *d = nullptr;
         int rcf = upload(&c->fe, sizeof c->fe, &d);
@@ -959,7 +962,7 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) try {
             if (L.cout % 4 || L.kh != L.kw || L.sh != L.sw || !((L.kh == 3 || L.kh == 5) && (L.sh == 1 || L.sh == 2)))
                 return fail(BH_ERR_UNSUPPORTED, "layer %zu: depthwise %ux%u stride %u channels %u not built", i, L.kh, L.kw, L.sh, L.cout);
         } else if (L.op == bh::OP_CONV) {
-            if (L.cout % 8 || (size_t)L.kh * L.kw * L.cin * L.cout * 4 > 64 * 1024)
+            if (L.cout % 4 || (size_t)L.kh * L.kw * L.cin * L.cout * 4 > 64 * 1024)
                 return fail(BH_ERR_UNSUPPORTED, "layer %zu: direct conv shape not built", i);
         } else if (L.op == bh::OP_GAP || L.op == bh::OP_SCALE) {
             if (L.cout % 4) return fail(BH_ERR_UNSUPPORTED, "layer %zu: channels %u not a multiple of 4", i, L.cout);

@@ -218,6 +218,19 @@ bool match_se_block(const bh::Model &m, const std::vector<int> &readers, size_t 
     return true;
 }
 
+// The tile planner in the block's precision, then in the next more exact one that has an entry for its shape: a plain-f16 block
+// (BH_FLAG_F16) without a plain-f16 instantiation runs on the split-f16 one -- more exact AND faster than the f32 MFMA -- and only
+// then, as a split-f16 block without an entry does, on the f32 MFMA.
+static bool plan_in_some_precision(bh::MbDesc &d, int force_cfg) {
+    const int order[3] = {d.prec, d.prec == 1 ? 3 : 0, 0};
+    for (int k = 0; k < 3; k++) {
+        if (k > 0 && order[k] == order[k - 1]) continue;
+        d.prec = order[k];
+        if (bh::mb_plan(d, force_cfg)) return true;
+    }
+    return false;
+}
+
 bool describe_fused_block(const bh::Model &m, const std::vector<int> &readers, size_t i, int precision, int force_cfg, bh::MbDesc &d) {
     const size_t nl = m.layers.size();
     {
@@ -247,12 +260,7 @@ bool describe_fused_block(const bh::Model &m, const std::vector<int> &readers, s
             d.KS = (int)D.kh; d.ST = (int)D.sh;
             d.act_e = (int)(noexp ? D.act : E.act); d.act_d = (int)D.act; d.act_p = (int)P.act;
             d.prec = precision;
-            if (!bh::mb_plan(d, force_cfg)) {
-                if (d.prec == 0) return false;
-                d.prec = 0;
-                if (!bh::mb_plan(d, force_cfg)) return false;
-            }
-            return true;
+            return plan_in_some_precision(d, force_cfg);
         }
     }
     if (i + 1 < nl && m.layers[i].op == bh::OP_DWCONV && m.layers[i + 1].op == bh::OP_PWCONV) {
@@ -269,12 +277,7 @@ bool describe_fused_block(const bh::Model &m, const std::vector<int> &readers, s
         d.act_e = (int)D.act; d.act_d = (int)D.act; d.act_p = (int)P.act;   // (no expand activation: the kernel template is keyed on one)
         if (const char *dbg = BH_XENV("BIRDA_HIP_MB_DBG")) d.dbg = atoi(dbg);
         d.prec = precision;
-        if (!bh::mb_plan(d, force_cfg)) {
-            if (d.prec == 0) return false;
-            d.prec = 0;
-            if (!bh::mb_plan(d, force_cfg)) return false;
-        }
-        return true;
+        return plan_in_some_precision(d, force_cfg);
     }
     if (i + 2 >= nl) return false;
     const auto &E = m.layers[i], &D = m.layers[i + 1], &P = m.layers[i + 2];
@@ -298,12 +301,7 @@ bool describe_fused_block(const bh::Model &m, const std::vector<int> &readers, s
     // The split-f16 MFMA and the f32 MFMA agree to ~1e-7 of sum|a b|; measured (profiles/), f16x3 is
     // the faster one on every block, the stem's 18-column im2col GEMM included.
     if (d.stem && precision == 3 && BH_XENV("BIRDA_HIP_STEM_F32")) d.prec = 0;   // A/B aid
-    if (!bh::mb_plan(d, force_cfg)) {
-        if (d.prec == 0) return false;
-        d.prec = 0;                       // no f16 instantiation for this shape: f32 one, if any
-        if (!bh::mb_plan(d, force_cfg)) return false;
-    }
-    return true;
+    return plan_in_some_precision(d, force_cfg);
 }
 
 std::vector<int> tensor_readers(const bh::Model &m) {

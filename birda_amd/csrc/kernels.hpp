@@ -350,6 +350,7 @@ void launch_segment_pcm(const void *d_pcm_origin, int sample_format, size_t n_fr
                         int n_seg, int seg_len, float *d_out, size_t out_stride, hipStream_t s);
 // minmax [n_seg][8][2]: min / max of eight slices of every segment; in_bad (nullable) [n_seg][8]: 1 where the slice holds an inf / NaN
 void launch_minmax(const float *x, float *minmax, unsigned *in_bad, int n_seg, int sample_count, hipStream_t s);
+size_t mel_lds_bytes(const FrontendParams &p);   // LDS the front-end launch needs (create refuses a model beyond 160 KB)
 void launch_mel(const float *x, const float *minmax, float *spec, const FrontendParams &p,
                 const FrontendParams *d_p, int n_seg, hipStream_t s);
 

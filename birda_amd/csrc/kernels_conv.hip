@@ -1168,8 +1168,9 @@ void launch_dwconv(const float *in, const float *w, const float *b, float *out, 
 
 // ---------------------------------------------------------------------------------------
 // Direct conv for the stem (Cin = n_branches = 2): weights [kh][kw][cin][cout] in LDS,
-// one lane = one output pixel x 8 output channels.
+// one lane = one output pixel x NC = 8 output channels (4 where the width is not a multiple of 8: stems of 20, 28, 36 ... channels).
 // ---------------------------------------------------------------------------------------
+template <int NC>
 __global__ __launch_bounds__(256) void conv_direct_kernel(const float *__restrict__ in, const float *__restrict__ w,
                                                            const float *__restrict__ b, float *__restrict__ out,
                                                            ConvParams p, int n_seg) {
@@ -1177,7 +1178,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const float *__restric
     const int wn = p.kh * p.kw * p.cin * p.cout;
     for (int i = threadIdx.x; i < wn; i += 256) ws[i] = w[i];
     __syncthreads();
-    const int cgn = p.cout >> 3;
+    const int cgn = p.cout / NC;
     const long total = (long)n_seg * p.out_h * p.out_w * cgn;
     for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long)gridDim.x * 256) {
         const int cg = (int)(g % cgn);
@@ -1186,10 +1187,10 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const float *__restric
         px /= p.out_w;
         const int oy = (int)(px % p.out_h);
         const int seg = (int)(px / p.out_h);
-        const int co = cg << 3;
-        float acc[8];
+        const int co = cg * NC;
+        float acc[NC];
 #pragma unroll
-        for (int n = 0; n < 8; n++) acc[n] = b[co + n];
+        for (int n = 0; n < NC; n++) acc[n] = b[co + n];
         const float *ib = in + (size_t)seg * p.in_h * p.in_w * p.cin;
         for (int dy = 0; dy < p.kh; dy++) {
             const int iy = oy * p.sh - p.pad_t + dy;
@@ -1202,27 +1203,27 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const float *__restric
                                                      : ib[((size_t)iy * p.in_w + ix) * p.cin + c];
                     const float *wr = ws + ((dy * p.kw + dx) * p.cin + c) * p.cout + co;
 #pragma unroll
-                    for (int n = 0; n < 8; n++) acc[n] += a * wr[n];
+                    for (int n = 0; n < NC; n++) acc[n] += a * wr[n];
                 }
             }
         }
         float *o = out + (((size_t)seg * p.out_h + oy) * p.out_w + ox) * p.cout + co;
-        float4 v0 = make_float4(act_apply(acc[0], p.act), act_apply(acc[1], p.act), act_apply(acc[2], p.act),
-                                act_apply(acc[3], p.act));
-        float4 v1 = make_float4(act_apply(acc[4], p.act), act_apply(acc[5], p.act), act_apply(acc[6], p.act),
-                                act_apply(acc[7], p.act));
-        *reinterpret_cast<float4 *>(o) = v0;
-        *reinterpret_cast<float4 *>(o + 4) = v1;
+#pragma unroll
+        for (int q = 0; q < NC; q += 4)
+            *reinterpret_cast<float4 *>(o + q) = make_float4(act_apply(acc[q], p.act), act_apply(acc[q + 1], p.act), act_apply(acc[q + 2], p.act),
+                                                             act_apply(acc[q + 3], p.act));
     }
 }
 
 void launch_conv_direct(const float *in, const float *w, const float *b, float *out, const ConvParams &p,
                         int n_seg, hipStream_t s) {
-    const long total = (long)n_seg * p.out_h * p.out_w * (p.cout / 8);
+    const int nc = p.cout % 8 ? 4 : 8;
+    const long total = (long)n_seg * p.out_h * p.out_w * (p.cout / nc);
     long blocks = (total + 255) / 256;
     if (blocks > 256L * 32) blocks = 256L * 32;
     const size_t smem = (size_t)p.kh * p.kw * p.cin * p.cout * sizeof(float);
-    hipLaunchKernelGGL(conv_direct_kernel, dim3((unsigned)blocks), dim3(256), smem, s, in, w, b, out, p, n_seg);
+    if (nc == 8) hipLaunchKernelGGL(conv_direct_kernel<8>, dim3((unsigned)blocks), dim3(256), smem, s, in, w, b, out, p, n_seg);
+    else hipLaunchKernelGGL(conv_direct_kernel<4>, dim3((unsigned)blocks), dim3(256), smem, s, in, w, b, out, p, n_seg);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -764,6 +764,20 @@ __global__ __launch_bounds__(256, 2) void mel32_kernel(const float *__restrict__
     }
 }
 
+// LDS the front-end kernel of `p` asks for: a frame tile's sample span (+ the staged rows of mel32_kernel), or the reduction buffer.
+// A hop so long that the span of one tile exceeds a CU's 160 KB cannot be launched: bh_classifier_create refuses the model.
+size_t mel_lds_bytes(const FrontendParams &p) {
+    int max_span = 0, span32 = 0;
+    const int nmp = p.br[0].nm_pad;
+    for (int b = 0; b < p.n_branches; b++) {
+        max_span = std::max(max_span, (MEL_TN - 1) * p.br[b].H + p.br[b].L);
+        span32 = std::max(span32, (MEL32_TN - 1) * p.br[b].H + p.br[b].L);
+    }
+    if (p.prec == 32)
+        return std::max((size_t)(((span32 + 3) & ~3) + 4 * 2 * 32 * MEL32_YP) * sizeof(float), (size_t)4 * (nmp / 32) * 4 * 64 * sizeof(float4));
+    return std::max((size_t)((max_span + 3) & ~3) * sizeof(float), (size_t)4 * 3 * (nmp / 16) * 64 * sizeof(float4));
+}
+
 void launch_mel(const float *x, const float *minmax, float *spec, const FrontendParams &p,
                 const FrontendParams *d_p, int n_seg, hipStream_t s) {
     int max_span = 0, max_frames = 0, nmp = p.br[0].nm_pad;

@@ -102,6 +102,12 @@ double mb_try_th(MbDesc &d, int ci, int th, bool relax_kg = false) {
     }
     d = t;
     const double tiles = (double)t.tiles_y * t.tiles_x / c.S;
+    // (relaxed pass: the weights every workgroup streams count too -- 1 / 192 of an MFMA step per byte: 64 bytes a clock into a CU's
+    //  LDS against four SIMDs each a split-f16 step in 48.  Whole-image tiles of a late block then beat narrow ones that stream
+    //  its 3-6 MB of weights two to four times an image.)
+    if (relax_kg)
+        return tiles * ((double)t.mpad_max / 16 * t.KG * 4 * (d.Cexp / 16) + (double)pout_pad / 16 * t.NTOP * (d.Cexp / 4) +
+                        (double)t.nchunks * (double)(we_fl + wp_fl + wd_fl) * 4.0 / 192.0);
     if (c.PERSIST == 2)   // (the halo rows are not expanded again: TH * ST new rows per step)
         return tiles * ((double)(c.S * std::min(th * c.ST, d.H) * std::min(t.IW, d.W) + 15) / 16 * t.KG * 4 * (d.Cexp / 16) + (double)pout_pad / 16 * t.NTOP * (d.Cexp / 4));
     return tiles * ((double)t.mpad_max / 16 * t.KG * 4 * (d.Cexp / 16) + (double)pout_pad / 16 * t.NTOP * (d.Cexp / 4));
@@ -151,7 +157,8 @@ bool mb_plan(MbDesc &d, int force_cfg) {
     if (force_cfg >= 0) {   // (a base index: the block's own activation selects the copy)
         const int ci = mb_act_index(d, force_cfg);
         MbDesc t = d;
-        if (ci < 0 || mb_try(t, ci) < 0) return false;
+        if (ci < 0) return false;
+        if (mb_try(t, ci) < 0) { t = d; if (mb_try(t, ci, true) < 0) return false; }
         d = t;
         return true;
     }
@@ -160,6 +167,8 @@ bool mb_plan(MbDesc &d, int force_cfg) {
             const int ci = mb_act_index(d, atoi(q));
             MbDesc t = d;
             if (ci >= 0 && mb_try(t, ci) >= 0) { d = t; return true; }
+            t = d;
+            if (ci >= 0 && mb_try(t, ci, true) >= 0) { d = t; return true; }
             while (*q && *q != ',') q++;
             if (*q == ',') q++;
         }
@@ -214,12 +223,32 @@ bool mb_plan(MbDesc &d, int force_cfg) {
         if (why) std::fill(g_why, g_why + 16, 0);
         for (int ci = 0; ci < kNCfgs; ci++) {
             if (kCfgs[ci].PERSIST) continue;   // persistent entries only through the preferred list (measured shapes)
+            // (the generic entries, mbconv_cfgs.inc from 211 on, belong to the relaxed pass whatever their k steps: there a hand-shaped
+            //  entry that fits the block by relaxation competes with them on cost, weights streamed included)
+            if (!relax && ci % kNBase >= 211) continue;
             MbDesc t = d;
             const double w = mb_try(t, ci, relax != 0);
+            if (why && getenv("BIRDA_HIP_MB_WHY")[0] == '2' && kCfgs[ci].ACT == d.act_e && kCfgs[ci].KS == d.KS && kCfgs[ci].ST == d.ST && kCfgs[ci].PREC == d.prec)
+                fprintf(stderr, "  relax %d entry %d (KG %d COLTH %d): %g\n", relax, ci % kNBase, kCfgs[ci].KG, kCfgs[ci].COLTH, w);
             if (w < 0) continue;
             if (best < 0 || w < best) { best = w; bestd = t; }
         }
-        if (best >= 0) { d = bestd; return true; }
+        if (best >= 0) {
+            // f32 MFMA, relaxed pass: a block whose best entry issues more than 2.5 times the MFMA steps the block itself holds (k steps
+            // and project tiles padded far beyond its widths, a halo several times the tile) stays layer by layer -- on the f32 MFMA the
+            // padded steps are the kernel's time, and the GEMMs of the layer path do not pad (measured, profiles/r6_c_plan_coverage_f32.txt:
+            // 72 -> 216 -> 72 5x5 at 32x69 on entry 6 0.44 of the layer path's speed at 2.9 times the steps, 96 -> 576 -> 160 stride 2 0.52
+            // at 3.1; everything below 2.5 within 0.8-1.5).  Split-f16 entries never lost to the layer path (r6_c_plan_coverage_f16x3.txt).
+            if (relax && d.prec == 0) {
+                const MbCfg &c = kCfgs[bestd.cfg];
+                const double tiles = (double)bestd.tiles_y * bestd.tiles_x / c.S, pout_pad = c.WM * c.MT_W * 16;
+                const double steps = tiles * ((double)bestd.mpad_max / 16 * bestd.KG * 4 * (d.Cexp / 16.0) + pout_pad / 16 * bestd.NTOP * (d.Cexp / 4.0));
+                const double own = (double)d.H * d.W / 16 * ((d.noexp ? 0 : d.Cin) / 4.0) * (d.Cexp / 16.0) + (double)d.Ho * d.Wo / 16 * (d.Cout / 16.0) * (d.Cexp / 4.0);
+                if (steps > 2.5 * own && d.Cin >= 64 && d.Cexp >= 192) return false;   // (narrow blocks pad as much on the layer path's GEMM tiles)
+            }
+            d = bestd;
+            return true;
+        }
     }
     if (why)
         fprintf(stderr, "mb_plan: no entry for %s%d -> %d -> %d k%d s%d %dx%d -> %dx%d act %d prec %d se %d: refused by act %d stem %d stemk %d se %d kg %d colth %d nto %d pout %d rows %d lds %d\n",

@@ -1314,8 +1314,33 @@ inline Recovered recover_frontend(const Graph &g, const onnxc::ValueInfo &audio)
     double err = 0, wmax = 0;
     for (size_t i = 0; i < want.size(); i++) { err = std::fmax(err, std::fabs(got.v[i] - want[i])); wmax = std::fmax(wmax, std::fabs(want[i])); if (!std::isfinite(got.v[i])) err = INFINITY; }
     rec.verify_err = err / std::fmax(wmax, 1e-300);
-    if (!(rec.verify_err <= 2e-5))
-        throw RecoverError("recovered front-end differs from the graph on random audio (relative error " + std::to_string(rec.verify_err) + ")");
+    if (!(rec.verify_err <= 2e-5)) {
+        // The spectrogram ends in |v|^(2 expo), which is not Lipschitz at v = 0: where a mel projection all but vanishes, the float32
+        // rounding of the fitted mel matrix (1e-7 of the largest projection) moves the pixel by |dv|^(2 expo) -- 5e-5 of the largest
+        // pixel at an exponent of 0.19 (a learned mag_scale of 1.45), found by the random plans of round 6.  Such a front-end IS the
+        // graph's: it is held to the graph BEFORE the power law instead -- both spectrograms taken back through the fitted affine and
+        // exponent to |v|, which a wrong exponent, affine, window or matrix moves by far more than 1e-5 of the largest projection.
+        const size_t C = rec.branches.size(), Hs = rec.branches[0].n_mels, Ws = rec.branches[0].n_frames;
+        double lin = 0;
+        for (size_t c = 0; c < C && std::isfinite(lin); c++) {
+            const RecoveredBranch &b = rec.branches[c];
+            const double expo = 1.0 / (1.0 + std::exp((double)(float)std::log(1.0 / b.expo - 1.0)));
+            const double scale = (double)(float)b.scale, shift = (double)(float)b.shift, inv = 1.0 / (2.0 * expo);
+            double umax = 0, uerr = 0;
+            for (size_t i = 0; i < NV; i++)
+                for (size_t q = 0; q < Hs * Ws; q++) {
+                    const size_t at = (i * C + c) * Hs * Ws + q;
+                    const double ua = std::pow(std::fmax((got.v[at] - shift) / scale, 0.0), inv), ub = std::pow(std::fmax((want[at] - shift) / scale, 0.0), inv);
+                    umax = std::fmax(umax, ub);
+                    uerr = std::fmax(uerr, std::fabs(ua - ub));
+                    if (!std::isfinite(ua)) uerr = INFINITY;
+                }
+            lin = std::fmax(lin, uerr / std::fmax(umax, 1e-300));
+        }
+        if (!(lin <= 1e-5))
+            throw RecoverError("recovered front-end differs from the graph on random audio (relative error " + std::to_string(rec.verify_err) +
+                               ", " + std::to_string(lin) + " in front of the power law)");
+    }
     return rec;
 }
 

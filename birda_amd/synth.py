@@ -274,14 +274,14 @@ def random_plan(seed: int, big: bool = False) -> dict:
     #  onnx_conv.hpp frontend_for -- the frames then follow from frame length and hop: odd and even counts alike)
     sr, n = (48000, 12000) if not big else ((48000, 144000) if rng.integers(0, 2) else (32000, 160000))
     fl0 = int(rng.choice([1024, 2048])) if big else int(rng.choice([256, 512]))
-    hop0 = ri(520, min(1100, fl0)) if big else ri(100, min(290, fl0))      # (frames overlap or touch, as every published front-end's do)
+    hop0 = ri(300, min(760, fl0)) if big else ri(100, min(290, fl0))      # (frames overlap or touch, as every published front-end's do)
     frames = (n - fl0) // hop0 + 1
     branches = [(fl0, hop0)]
     for _ in range(n_br - 1):
         found = None
         for fl in rng.permutation([1024, 2048, 512] if big else [256, 512, 1024, 384]):
             fl = int(fl)
-            hs = [h for h in range(60, fl + 1) if (n - fl) // h + 1 == frames]
+            hs = [h for h in range(60, min(fl, 760) + 1) if (n - fl) // h + 1 == frames]
             if hs:
                 found = (fl, int(rng.choice(hs)))
                 break

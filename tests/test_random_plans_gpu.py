@@ -22,6 +22,7 @@ from birda_amd import convert, modelfile as mf, onnx_io as ox, synth
 pytestmark = pytest.mark.gpu
 
 LOGIT_RTOL = 2e-5          # the stated fp32 tolerance (tests/test_parity_gpu.py): max |dlogit| <= 2e-5 max(1, max |logit|)
+F16_LOGIT_RTOL = 3e-3      # plain f16 MFMA operands (BH_FLAG_F16, BASELINE config 5), as tests/test_parity_gpu.py
 SPELLINGS = ("conv1d", "stft", "complex", "fused")
 N_SMALL, BIG = 40, (1000, 1001, 1002, 1003)
 
@@ -48,7 +49,13 @@ def _check(m, bhm, onnx, oracle_lib, sizes=(3, 80, 300), precisions=("f32", "f16
     worst = 0.0
     for prec in precisions:
         clf = BirdClassifier(onnx, None, precision=prec)
-        assert len(clf.fused_blocks()) == _n_blocks(m), (prec, clf.fused_blocks(), _n_blocks(m))
+        # every block fused on the split-f16 MFMA; on the f32 MFMA (the path BH_FLAG_AUTO re-runs an overflowing row on) the planner
+        # leaves a wide block whose best entry pads its MFMA work 2.5-fold to the layer kernels (kernels_mbconv.hip mb_plan)
+        if prec != "f32":
+            assert len(clf.fused_blocks()) == _n_blocks(m), (prec, clf.fused_blocks(), _n_blocks(m))
+        else:
+            assert len(clf.fused_blocks()) >= _n_blocks(m) - 3, (prec, clf.fused_blocks(), _n_blocks(m))
+        tol = F16_LOGIT_RTOL if prec == "f16" else LOGIT_RTOL
         first = None
         for n in sizes:
             ctx = clf.create_batch_context(n)
@@ -57,7 +64,7 @@ def _check(m, bhm, onnx, oracle_lib, sizes=(3, 80, 300), precisions=("f32", "f16
             ctx.close()
             assert np.isfinite(got).all(), (prec, n)
             err = float(np.abs(got[:3] - ref).max())
-            assert err <= LOGIT_RTOL * scale, (prec, n, err, scale)
+            assert err <= tol * scale, (prec, n, err, scale)
             worst = max(worst, err / scale)
             if first is None:
                 first = got[:3].copy()
@@ -71,7 +78,8 @@ def _check(m, bhm, onnx, oracle_lib, sizes=(3, 80, 300), precisions=("f32", "f16
 def test_random_stack_matches_the_oracle_fused_in_every_precision(seed, tmp_path, oracle_lib):
     plan = synth.random_plan(seed)
     m, bhm, onnx = _write(tmp_path, f"r{seed}", plan, SPELLINGS[seed % 4])
-    _check(m, bhm, onnx, oracle_lib)
+    # (every fifth stack also with plain f16 operands: its blocks run on plain-f16 entries where one fits, else on split-f16 ones)
+    _check(m, bhm, onnx, oracle_lib, precisions=("f32", "f16x3", "auto") + (("f16",) if seed % 5 == 0 else ()))
 
 
 @pytest.mark.parametrize("seed", BIG)
