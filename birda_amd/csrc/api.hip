@@ -462,7 +462,7 @@ bool load_any_model(const char *path, bh::Model &m, std::string &err) {
 // A well-formed file whose front-end the kernels cannot express (or the evaluator cannot run) is BH_ERR_UNSUPPORTED, not a
 // malformed file: onnx_conv.hpp marks that refusal with this phrase.
 int model_load_status(const std::string &err) {
-    return err.find("the spectrogram front-end cannot be read off the graph") != std::string::npos ? BH_ERR_UNSUPPORTED : BH_ERR_IO;
+    return err.find(bh::onnxc::kFrontendRefusal) != std::string::npos ? BH_ERR_UNSUPPORTED : BH_ERR_IO;
 }
 
 int check_ctx(bh_classifier *c, bh_batch_context *ctx) {
@@ -1479,7 +1479,11 @@ int bh_onnx_eval(const char *onnx_path, const char *feed_name, const double *fee
         for (size_t i = 0; i < t.rank() && i < 8; i++) out_dims[i] = t.d[i];
         if (t.size() > out_cap || !out) return fail(BH_ERR_INVALID, "onnx_eval: tensor '%s' has %zu values, room for %zu", target, t.size(), out_cap);
         for (size_t i = 0; i < t.size(); i++) out[i] = t.f(i);
-    } catch (const bh::onnxf::EvalError &e) { return fail(BH_ERR_IO, "%s: %s", onnx_path, e.what()); }
+    } catch (const bh::onnxf::EvalError &e) {
+        // (a well-formed graph the evaluator cannot run -- an operator outside its set, a shape beyond its bounds -- is the same
+        //  condition bh_classifier_create reports as BH_ERR_UNSUPPORTED; a file that does not parse was BH_ERR_IO above)
+        return fail(BH_ERR_UNSUPPORTED, "%s: %s", onnx_path, e.what());
+    } catch (const std::bad_alloc &) { return fail(BH_ERR_UNSUPPORTED, "%s: out of memory while evaluating the graph", onnx_path); }
     return BH_OK;
 } catch (...) { return on_exception(); }
 

@@ -1297,7 +1297,8 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float *__restrict__ 
     }
 }
 
-bool se_gate_supports(int C, int Cr) { return C >= 1 && Cr >= 1 && Cr <= 256 && C <= 16384; }
+// (se_gate_kernel keeps pooled [C] + partial sums [256] + hidden [Cr] in LDS and is launched without a raised dynamic-LDS limit: 64 KB)
+bool se_gate_supports(int C, int Cr) { return C >= 1 && Cr >= 1 && Cr <= 256 && ((size_t)C + 256 + (size_t)Cr) * sizeof(float) <= 64 * 1024; }
 
 // the pool alone: pooled[n][C] = (sum over tiles of part[n][tiles][C]) / P, tiles in index order (fixed)
 __global__ __launch_bounds__(256) void se_pool_kernel(const float *__restrict__ part, int tiles, float inv_p, float *__restrict__ pooled, int n_seg, int C) {

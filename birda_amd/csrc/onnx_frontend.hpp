@@ -291,7 +291,11 @@ inline Arr arr_of_tensor(const Tensor &t, const std::string &name) {
     Arr a;
     a.d = t.dims;
     const size_t n = shape_elems(a.d);
-    if (t.dtype == 1) { a.v.resize(n); for (size_t i = 0; i < n; i++) a.v[i] = (double)t.at(i); }
+    if (t.dtype == 1) {
+        if (t.has_raw ? t.raw.n != n * 4 : t.fl.size() != n) throw EvalError("constant '" + name + "' without data");     // (never read past the payload)
+        a.v.resize(n);
+        for (size_t i = 0; i < n; i++) a.v[i] = (double)t.at(i);
+    }
     else if (t.dtype == 11) { if (t.dl.size() != n) throw EvalError("constant '" + name + "' without data"); a.v = t.dl; }
     else if (t.dtype == 7 || t.dtype == 6 || t.dtype == 9) { if (t.il.size() != n) throw EvalError("constant '" + name + "' without data"); a.is_int = true; a.iv = t.il; }
     else throw EvalError("constant '" + name + "' of element type " + std::to_string(t.dtype) + " (float32, float64, int64, int32 and bool are read)");
@@ -642,8 +646,13 @@ private:
             const auto ss = strides_of(a.d);
             for (size_t i = 0; i < a.rank(); i++) st[i] = (int64_t)ss[i];
             int64_t off = 0;
+            std::vector<char> seen_ax(a.rank(), 0);
             for (size_t k = 0; k < starts.size(); k++) {
                 const size_t ax = (size_t)norm_axis(axes[k], a.rank(), "Slice");
+                // (ONNX forbids a repeated axis; the clamps below are against the ORIGINAL extent, so a second slice of one axis would
+                //  place its offset past the first slice's end -- ADVICE r5: x[10], starts [5, 9], axes [0, 0] read x[14])
+                if (seen_ax[ax]) throw EvalError("Slice: axis " + std::to_string(ax) + " given twice");
+                seen_ax[ax] = 1;
                 const int64_t dim = a.d[ax], step = steps[k];
                 if (step == 0) throw EvalError("Slice: step 0");
                 int64_t s = starts[k], e = ends[k];
@@ -653,10 +662,19 @@ private:
                 int64_t cnt;
                 if (step > 0) { s = std::min(std::max<int64_t>(s, 0), dim); e = std::min(std::max<int64_t>(e, 0), dim); cnt = e > s ? (e - s + step - 1) / step : 0; }
                 else { s = std::min(std::max<int64_t>(s, -1), dim - 1); e = std::min(std::max<int64_t>(e, -1), dim - 1); cnt = s > e ? (s - e + (-step) - 1) / (-step) : 0; }
-                // (a second slice of the same axis composes with the first)
                 off += s * st[ax] * (cnt > 0 ? 1 : 0);
                 st[ax] *= step;
                 d[ax] = cnt;
+            }
+            {   // the view's first and last element lie inside the array, whatever the arguments were (every strided view is held to this)
+                int64_t lo = off, hi = off;
+                bool empty = false;
+                for (size_t i = 0; i < a.rank(); i++) {
+                    if (d[i] == 0) empty = true;
+                    else if (st[i] > 0) hi += (d[i] - 1) * st[i];
+                    else lo += (d[i] - 1) * st[i];
+                }
+                if (!empty && (lo < 0 || hi >= (int64_t)a.size())) throw EvalError("Slice: view outside its array");
             }
             return one(take(a, d, view_map(d, st, off)));
         }

@@ -137,6 +137,12 @@ inline bool parse_tensor(Span s, std::string &name, Tensor &t, std::string &err)
 inline bool parse_node(Span s, Node &n, std::map<std::string, Tensor> *const_out, std::string &err) {
     Reader r(s);
     uint32_t no, wt; uint64_t v; Span sp;
+    // A Constant node's value in whichever spelling it arrives (`value` tensor, `value_float` / `value_int` / `value_floats` /
+    // `value_ints`): kept aside until the whole node is read -- `op_type` may follow the attributes on the wire, and only a node
+    // that IS a Constant turns into an initializer (a ConstantOfShape's `value` tensor was hoisted in its output's place).
+    Span const_tensor{};
+    std::string const_kind;
+    Attr const_attr;
     while (r.more()) {
         if (!r.field(no, wt, v, sp)) break;
         if (no == 1 && wt == 2) n.in.push_back(str(sp));
@@ -163,23 +169,27 @@ inline bool parse_node(Span s, Node &n, std::map<std::string, Tensor> *const_out
                 else if (no2 == 8) packed_ints(wt2, v2, sp2, at.ints, a.ok);
             }
             if (!a.ok) { err = "malformed AttributeProto"; return false; }
-            if (tensor.p && an == "value" && const_out && !n.out.empty()) {   // a Constant node: its value is an initializer by another spelling
-                std::string tn; Tensor t;
-                if (!parse_tensor(tensor, tn, t, err)) return false;
-                (*const_out)[n.out[0]] = std::move(t);
-            } else if (const_out && !n.out.empty() && (an == "value_float" || an == "value_int" || an == "value_floats" || an == "value_ints")) {
-                Tensor t;                        // the scalar / list spellings of a Constant node (opset 12+)
-                if (an == "value_float" && at.has_f) { t.dtype = 1; t.fl = {at.f}; }
-                else if (an == "value_int" && at.has_i) { t.dtype = 7; t.il = {at.i}; }
-                else if (an == "value_floats") { t.dtype = 1; t.fl = at.floats; t.dims = {(int64_t)at.floats.size()}; }
-                else if (an == "value_ints") { t.dtype = 7; t.il = at.ints; t.dims = {(int64_t)at.ints.size()}; }
-                t.count = t.dtype == 1 ? t.fl.size() : t.il.size();
-                (*const_out)[n.out[0]] = std::move(t);
-            }
+            if (an == "value" && tensor.p) { const_tensor = tensor; const_kind = an; }
+            else if (an == "value_float" || an == "value_int" || an == "value_floats" || an == "value_ints") { const_kind = an; const_attr = at; }
             n.a[an] = std::move(at);
         }
     }
     if (!r.ok) { err = "malformed NodeProto"; return false; }
+    if (const_out && n.op == "Constant") {
+        // its value is an initializer by another spelling -- registered only with the payload its spelling names (a `value_float`
+        // attribute that carries an integer, a `value_int` without one: "malformed", not a one-element tensor without data)
+        if (n.out.empty() || const_kind.empty()) { err = "Constant node '" + n.name + "' without an output or without a value this reader knows (value, value_float, value_int, value_floats, value_ints)"; return false; }
+        Tensor t;
+        if (const_kind == "value") {
+            std::string tn;
+            if (!parse_tensor(const_tensor, tn, t, err)) return false;
+        } else if (const_kind == "value_float" && const_attr.has_f) { t.dtype = 1; t.fl = {const_attr.f}; t.count = 1; }
+        else if (const_kind == "value_int" && const_attr.has_i) { t.dtype = 7; t.il = {const_attr.i}; t.count = 1; }
+        else if (const_kind == "value_floats") { t.dtype = 1; t.fl = const_attr.floats; t.dims = {(int64_t)const_attr.floats.size()}; t.count = t.fl.size(); }
+        else if (const_kind == "value_ints") { t.dtype = 7; t.il = const_attr.ints; t.dims = {(int64_t)const_attr.ints.size()}; t.count = t.il.size(); }
+        else { err = "malformed Constant node '" + n.name + "': attribute " + const_kind + " without its payload"; return false; }
+        (*const_out)[n.out[0]] = std::move(t);
+    }
     return true;
 }
 

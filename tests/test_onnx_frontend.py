@@ -298,3 +298,37 @@ def test_classifier_created_on_a_retrained_onnx_file_gives_its_own_logits(tmp_pa
     scale = max(1.0, float(np.abs(out["bhm"]).max()))
     assert np.isfinite(out["onnx"]).all() and np.abs(out["onnx"] - out["bhm"]).max() <= 2e-5 * scale
     assert np.abs(out["table"] - out["bhm"]).max() > 1e-3 * scale      # the assumption round 4 made would have been visible here
+
+
+def test_constant_spellings_and_repeated_slice_axes_are_held_to_their_payload(tmp_path):
+    """ADVICE r5 (medium x 2).  (1) A Constant whose `value_float` attribute carries no float (here: an integer) was registered as a
+    one-element tensor WITHOUT data and read -- a crash inside bh_onnx_eval / bh_classifier_create on an untrusted file; and any
+    node with a tensor attribute called `value` (ConstantOfShape) had that tensor hoisted in its output's place.  (2) Slice with a
+    repeated axis clamped against the original extent and read past the array (x[10], starts [5, 9], axes [0, 0] -> x[14])."""
+    x = np.arange(10, dtype=np.float64)
+    # the good spellings still work
+    got = _eval([ox.Node("Constant", [], ["c"], {"value_float": 2.5}), ox.Node("Add", ["x", "c"], ["y"])], {}, "x", x, "y", tmp_path)
+    assert np.array_equal(got, x + 2.5)
+    got = _eval([ox.Node("Constant", [], ["c"], {"value_floats": [1.0, 2.0]}), ox.Node("Identity", ["c"], ["y"])], {}, "x", x, "y", tmp_path)
+    assert np.array_equal(got, [1.0, 2.0])
+    got = _eval([ox.Node("Constant", [], ["c"], {"value": np.asarray([3, 4], np.int64)}), ox.Node("Identity", ["c"], ["y"])], {}, "x", x, "y", tmp_path)
+    assert np.array_equal(got, [3, 4])
+    # `value_float` holding an integer: malformed, by name (was: a segmentation fault)
+    with pytest.raises(RuntimeError, match="malformed Constant"):
+        _eval([ox.Node("Constant", [], ["c"], {"value_float": 3}), ox.Node("Add", ["x", "c"], ["y"])], {}, "x", x, "y", tmp_path)
+    with pytest.raises(RuntimeError, match="malformed Constant"):
+        _eval([ox.Node("Constant", [], ["c"], {"value_int": 3.0}), ox.Node("Add", ["x", "c"], ["y"])], {}, "x", x, "y", tmp_path)
+    with pytest.raises(RuntimeError, match="without an output or without a value"):
+        _eval([ox.Node("Constant", [], ["c"], {"value_string": "a"}), ox.Node("Add", ["x", "c"], ["y"])], {}, "x", x, "y", tmp_path)
+    # a `value` tensor on a node that is not a Constant stays that node's attribute: the evaluator answers for ConstantOfShape itself
+    with pytest.raises(RuntimeError, match="ConstantOfShape"):
+        _eval([ox.Node("ConstantOfShape", ["s"], ["c"], {"value": np.asarray([7.0], np.float32)}), ox.Node("Identity", ["c"], ["y"])],
+              {"s": np.asarray([3], np.int64)}, "x", x, "y", tmp_path)
+    # Slice: a repeated axis is refused; the ordinary two-axis slice is untouched
+    inits = {"st": np.asarray([5, 9], np.int64), "en": np.asarray([8, 10], np.int64), "ax": np.asarray([0, 0], np.int64)}
+    with pytest.raises(RuntimeError, match="given twice"):
+        _eval([ox.Node("Slice", ["x", "st", "en", "ax"], ["y"])], inits, "x", x, "y", tmp_path)
+    x2 = np.arange(24, dtype=np.float64).reshape(4, 6)
+    inits = {"st": np.asarray([1, -4], np.int64), "en": np.asarray([3, 100], np.int64), "ax": np.asarray([0, 1], np.int64), "sp": np.asarray([1, 2], np.int64)}
+    got = _eval([ox.Node("Slice", ["x", "st", "en", "ax", "sp"], ["y"])], inits, "x", x2, "y", tmp_path)
+    assert np.array_equal(got, x2[1:3, -4:100:2])
