@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "../../include/birda_hip.h"
+#include "../../include/birda_hip_debug.h"
 #include "kernels.hpp"
 #include "trace.hpp"
 #include "model.hpp"

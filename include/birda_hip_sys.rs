@@ -145,7 +145,6 @@ extern "C" {
     pub fn bh_forward_device(c: *mut BhClassifier, ctx: *mut BhBatchContext, d_segments: *const f32, n: usize, d_logits: *mut f32, d_topk_index: *mut i32, d_topk_conf: *mut f32) -> c_int;
     pub fn bh_batch_context_synchronize(ctx: *mut BhBatchContext) -> c_int;
     pub fn bh_batch_context_stream(ctx: *mut BhBatchContext) -> *mut c_void;
-    pub fn bh_debug_read_tensor(c: *mut BhClassifier, ctx: *mut BhBatchContext, tensor: u32, host: *mut f32, max_floats: usize) -> c_int;
     pub fn bh_tensor_floats(c: *const BhClassifier, tensor: u32) -> u64;
     pub fn bh_batch_context_set_profiling(ctx: *mut BhBatchContext, enabled: c_int) -> c_int;
     pub fn bh_batch_context_stage_ms(ctx: *mut BhBatchContext, ms: *mut f32, launches: *mut u32) -> c_int;
@@ -154,8 +153,6 @@ extern "C" {
     pub fn bh_plan_fused_blocks(model_path: *const c_char, flags: u32, cfgs: *mut i32, layers: *mut i32, cap: usize) -> c_int;
     pub fn bh_classifier_frontend_kernel(c: *const BhClassifier, out: *mut c_char, cap: usize) -> c_int;
     pub fn bh_mb_config_name(cfg: i32, out: *mut c_char, cap: usize) -> c_int;
-    pub fn bh_debug_gated_gemm(device: c_int, A: *const f32, gate: *const f32, W: *const f32, bias: *const f32, R: *const f32, C: *mut f32, M: usize, K: usize, N: usize, rows_per_seg: usize, terms: c_int, blocked: c_int) -> c_int;
-    pub fn bh_debug_mb_stamps(c: *mut BhClassifier, out: *mut u64, cap: usize) -> c_int;
     pub fn bh_predict_batch_source_rate(c: *mut BhClassifier, ctx: *mut BhBatchContext, segments: *const *const f32, n: usize, n_src_samples: usize, source_rate: u32, out: *mut BhResult) -> c_int;
     pub fn bh_segment_starts(n_frames: usize, segment_samples: usize, overlap_samples: usize, starts: *mut u64, cap: usize) -> usize;
     pub fn bh_predict_pcm16(c: *mut BhClassifier, ctx: *mut BhBatchContext, pcm: *const i16, n_frames: usize, channels: u32, source_rate: u32, overlap_samples: usize, out: *mut BhResult, out_cap: usize, n_segments: *mut usize, start_samples: *mut u64) -> c_int;

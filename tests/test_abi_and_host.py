@@ -34,8 +34,12 @@ def _declared(header):
 
 def test_library_exports_every_declared_symbol(L):
     from birda_amd import _lib
-    names = _declared("birda_hip.h") + _declared("birda_host.h")
+    names = _declared("birda_hip.h") + _declared("birda_host.h") + _declared("birda_hip_debug.h")
     assert len(names) >= 40
+    # the diagnostic entry points live in their own header: the one birda binds (and the Rust text generated from it) has none
+    assert _declared("birda_hip_debug.h") == ["bh_debug_gated_gemm", "bh_debug_mb_stamps", "bh_debug_read_tensor"]
+    assert not [n for n in _declared("birda_hip.h") if "debug" in n]
+    assert "bh_debug" not in open(os.path.join(ROOT, "include", "birda_hip_sys.rs")).read()
     bound = {n for n, _, _ in _lib.SYMBOLS + _lib.HOST_SYMBOLS}
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/ but not exported"
@@ -381,8 +385,8 @@ def test_shipped_tile_configurations_are_the_reachable_ones():
     so = os.path.getsize(os.path.join(ROOT, "birda_amd", "libbirda_hip.so"))
     # (8.2 MiB in round 3; + the f32 twins of the Perch-sized stack and the narrow-tile twins: 9.0; round 5: + every swish entry a second
     #  time as pass A of a squeeze-excite block, and the front-end evaluator: 10.8)
-    #  round 6: + 58 generic entries x 3 activations, and pass A of a squeeze-excite block for GELU and ReLU6 as well: 19.6)
-    assert so < 22 * 2 ** 20, f"libbirda_hip.so grew to {so / 2 ** 20:.1f} MiB"
+    #  round 6: + 82 generic / late-stage entries x 3 activations, and pass A of a squeeze-excite block for GELU and ReLU6 as well: 22.5)
+    assert so < 25 * 2 ** 20, f"libbirda_hip.so grew to {so / 2 ** 20:.1f} MiB"
 
 
 # ---------------- range filter tables (host logic, include/birda_host.h) ----------------

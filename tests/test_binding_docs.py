@@ -141,7 +141,11 @@ def test_ctypes_mirror_matches_the_header(header):
         assert C.sizeof(cls) == A.layout(want)[0], name
         for f, off in A.layout(want)[1]:
             assert getattr(cls, f).offset == off, (name, f)
-    for table, fns in ((_lib.SYMBOLS, functions), (_lib.HOST_SYMBOLS, hf)):
+    # (the ctypes table also binds the diagnostic entry points of include/birda_hip_debug.h, which the tests call)
+    _, dbg_functions, _ = A.parse_c_header(os.path.join(ROOT, "include", "birda_hip_debug.h"))
+    dbg_functions = {k: v for k, v in dbg_functions.items() if k.startswith("bh_debug_")}
+    assert len(dbg_functions) == 3
+    for table, fns in ((_lib.SYMBOLS, {**functions, **dbg_functions}), (_lib.HOST_SYMBOLS, hf)):
         assert {n for n, _, _ in table} == set(fns)
         for name, res, args in table:
             want_ret, want_args = fns[name]
