@@ -64,10 +64,31 @@ class ClockSampler:
         import threading
         self._stop = threading.Event()
         self._thread = None
-        self.sclk, self.power, self.source = [], [], "unavailable"
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
-        self._dpm = cards[min(device_index, len(cards) - 1)] if cards else None
-        base = os.path.dirname(self._dpm) if self._dpm else None
+        self.sclk, self.power, self.source, self.card = [], [], "unavailable", None
+        # the sysfs node of THIS HIP device: by PCI address (a box shows every GPU of its host in sysfs, one of them granted -- the
+        # first card is usually somebody else's idle GPU); without the address, the card whose clock is highest right now
+        base = None
+        try:
+            import torch
+            pr = torch.cuda.get_device_properties(device_index)
+            addr = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+            if os.path.exists(f"/sys/bus/pci/devices/{addr}/pp_dpm_sclk"):
+                base = f"/sys/bus/pci/devices/{addr}"
+                self.card = addr
+        except Exception:   # noqa: BLE001
+            base = None
+        if base is None:
+            cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+
+            def mhz(pth):
+                try:
+                    return max(float(l.split(":")[1].lower().replace("mhz", "").replace("*", "")) for l in open(pth).read().splitlines() if l.rstrip().endswith("*"))
+                except (OSError, ValueError, IndexError):
+                    return -1.0
+            if cards:
+                base = os.path.dirname(max(cards, key=mhz))
+                self.card = base
+        self._dpm = base + "/pp_dpm_sclk" if base else None
         self._pw = (sorted(glob.glob(base + "/hwmon/hwmon*/power1_average")) + sorted(glob.glob(base + "/hwmon/hwmon*/power1_input"))) if base else []
         self._fq = sorted(glob.glob(base + "/hwmon/hwmon*/freq1_input")) if base else []
         self._threading = threading
@@ -125,7 +146,8 @@ class ClockSampler:
     def summary(self):
         med = lambda v: round(statistics.median(v), 1) if v else None
         return {"sclk_mhz": med(self.sclk), "sclk_mhz_min_max": [round(min(self.sclk), 1), round(max(self.sclk), 1)] if self.sclk else None,
-                "power_w": med(self.power), "samples": max(len(self.sclk), len(self.power)), "clock_source": self.source}
+                "power_w": med(self.power), "power_w_min_max": [round(min(self.power), 1), round(max(self.power), 1)] if self.power else None,
+                "samples": max(len(self.sclk), len(self.power)), "clock_source": self.source, "clock_card": self.card}
 
 
 def c4_child_leg(precision):

@@ -474,6 +474,9 @@ struct MbDesc {
               // 16 no weight DMA, 32 no output store.  Results are wrong when non-zero.
     // filled by mb_plan()
     int cfg, CE, TH, S, tiles_y, tiles_x, IH, IW, KG, nchunks, NTOP, mpad_max;
+    // floor(2^32 / tiles_x) + 1 and floor(2^32 / (tiles_x tiles_y)) + 1 (saturated at 2^32 - 1): the kernel decodes its tile index with
+    // them instead of dividing (mbconv_kernel.hpp BH_MB_HOSTRCP)
+    unsigned rcp_tiles_x, rcp_tiles_xy;
     int ring;  // 1: the chunk weights go through rings of LDS buffers (We x 2, Wp x 3, Wd x 2), refilled a whole chunk ahead
     size_t lds_bytes;
     // Squeeze-excite blocks (round 5; EfficientNet's gate between the depthwise and the project convolution: pool -> 1x1 -> act ->

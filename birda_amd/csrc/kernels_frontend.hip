@@ -155,8 +155,14 @@ void launch_segment_pcm(const void *d_pcm_origin, int sample_format, size_t n_fr
 // 0.683 us per segment (-3 %, profiles/r4_l_mel_pipe.txt).  Not the product: two full operator sets, two sets of frame fragments
 // and 72 accumulator registers leave hipcc 3-26 registers short whatever the group sizes; it spills thread-invariant offsets and
 // reloads them behind `s_waitcnt vmcnt(0)` in the reduction (or, with other group sizes, inside the MFMA tail: 1.05 us).
+// BH_MEL_PIPE = 2 (round 6, THE PRODUCT): the same pipeline with the operator held half a step at a time -- one register set per half
+// of the mel tiles instead of two whole sets (48 registers instead of 96): 16 bytes of scratch instead of 148, and the loop that
+// round 4 could only measure ships: 0.706 -> 0.678 us per segment on a box in its slow mode, -4.2 % with the fused blocks of the same
+// runs as the clock reference (profiles/r6_g_mel_pipe_tuning.txt: group sizes 3 / 6 / 9 and the split of the fragment build over the
+// two phases within 1 % of each other; round 4's form on today's compiler 1.17 us -- it spills inside the MFMA tail).  0 restores the
+// plain loop (two operator sets, fragments built in front of their MFMAs).
 #ifndef BH_MEL_PIPE
-#define BH_MEL_PIPE 0
+#define BH_MEL_PIPE 2
 #endif
 #ifndef BH_MEL_GM
 #define BH_MEL_GM 6
@@ -323,8 +329,8 @@ __global__ __launch_bounds__(256 * HALVES, (MT <= 6 || HALVES == 2) ? 2 : 1) voi
         // the folded frame samples are split here, 8 consecutive k per lane and 32-deep step.
         const int spw = K / 128, sbeg = wave * spw;              // 32-deep steps per wave (L % 256 == 0, checked at create)
         const f16x8 *gA = reinterpret_cast<const f16x8 *>(gfp) + lane;
-        f16x8 a0h[MT], a0l[MT], a1h[MT], a1l[MT];
-        auto load = [&](int st, f16x8 (&ah)[MT], f16x8 (&al)[MT]) {
+        [[maybe_unused]] f16x8 a0h[MT], a0l[MT], a1h[MT], a1l[MT];
+        [[maybe_unused]] auto load = [&](int st, f16x8 (&ah)[MT], f16x8 (&al)[MT]) {
             if (dbg & 16) st = sbeg;   // (ablation: every step reads the wave's FIRST operator fragments -- the kernel without the L2 -> CU operator stream)
 #pragma unroll
             for (int m = 0; m < MT; m++) {
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(256 * HALVES, (MT <= 6 || HALVES == 2) ? 2 : 1) voi
                     acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh[f], acc[f][m], 0, 0, 0);
                 }
         };
-#if BH_MEL_PIPE
+#if BH_MEL_PIPE == 1
         // Software-pipelined form (round 4, -DBH_MEL_PIPE=1; measured alternative, not the product -- see the note at BH_MEL_PIPE):
         // the folded-and-split frame fragments of step s + 1 are built WHILE the MFMAs of step s issue.
         auto build = [&](int st, f16x8 (&bh)[MEL_FT], f16x8 (&bl)[MEL_FT]) {
@@ -427,6 +433,96 @@ __global__ __launch_bounds__(256 * HALVES, (MT <= 6 || HALVES == 2) ? 2 : 1) voi
                 mma(a1h, a1l, b1h, b1l);
             } else {
                 mma(a0h, a0l, b0h, b0l);
+            }
+        }
+#elif BH_MEL_PIPE == 2
+        // Round 6: the pipelined loop with the operator held HALF a step at a time.  Round 4's form kept two whole
+        // operator sets (96 registers) beside two sets of frame fragments (48) and the accumulators (72) and was 3-26 registers
+        // short of two workgroups per CU.  Here the step's mel tiles are two halves L and H with ONE register set each (48 in all):
+        //     phase 1   MFMAs of half L on the current fragments  |  the next step's fragments of frame tiles 0, 1 built beside them
+        //               -> half L of the NEXT step is fetched (its registers were read by the MFMAs just issued)
+        //     phase 2   MFMAs of half H                           |  frame tile 2 built beside them
+        //               -> half H of the next step is fetched
+        // so every operator fragment is in flight for half a step (27 MFMAs, ~450 cycles: an L2 round trip) instead of a whole one.
+        #ifndef BH_MEL_FT1
+#define BH_MEL_FT1 ((MEL_FT + 1) / 2)
+#endif
+        constexpr int MH = MT / 2, FT1 = BH_MEL_FT1;
+        static_assert(MT % 2 == 0, "two halves of mel tiles");
+        f16x8 aLh[MH], aLl[MH], aHh[MH], aHl[MH];
+        auto load_half = [&](int st, int h, f16x8 (&ah)[MH], f16x8 (&al)[MH]) {
+            if (dbg & 16) st = sbeg;
+#pragma unroll
+            for (int m = 0; m < MH; m++) {
+                ah[m] = gA[(((size_t)st * MT + h * MH + m) * 2 + 0) * 64];
+                al[m] = gA[(((size_t)st * MT + h * MH + m) * 2 + 1) * 64];
+            }
+        };
+        auto build_f = [&](int st, int f0, int f1, f16x8 (&bh)[MEL_FT], f16x8 (&bl)[MEL_FT]) {
+            const int j0 = st * 32 + kq;
+#pragma unroll
+            for (int f = 0; f < MEL_FT; f++) {
+                if (f < f0 || f >= f1) continue;
+                float y[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++)
+                    y[jj] = bh_add_unpacked(xf[f * 16 * H + j0 + 4 * jj + 1], xf[f * 16 * H + L - 1 - j0 - 4 * jj]);
+                bh_split8(y, bh[f], bl[f]);
+            }
+        };
+        auto mma_half = [&](int h, const f16x8 (&ah)[MH], const f16x8 (&al)[MH], const f16x8 (&bh)[MEL_FT], const f16x8 (&bl)[MEL_FT]) {
+#pragma unroll
+            for (int m = 0; m < MH; m++)
+#pragma unroll
+                for (int f = 0; f < MEL_FT; f++) {
+                    acc[f][h * MH + m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh[f], acc[f][h * MH + m], 0, 0, 0);
+                    acc[f][h * MH + m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl[f], acc[f][h * MH + m], 0, 0, 0);
+                    acc[f][h * MH + m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh[f], acc[f][h * MH + m], 0, 0, 0);
+                }
+        };
+        // (per phase: 9 MH MFMAs beside 24 VALU + 16 LDS reads per frame tile built)
+        auto interleave = [&](int nf) {
+            constexpr int NM = 9 * MH;
+            const int groups = NM / BH_MEL_GM;
+#pragma unroll
+            for (int g = 0; g < NM / BH_MEL_GM; g++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, BH_MEL_GM, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, (16 * FT1 + NM / BH_MEL_GM - 1) / (NM / BH_MEL_GM), 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, (24 * FT1 + NM / BH_MEL_GM - 1) / (NM / BH_MEL_GM), 0);
+            }
+            (void)groups; (void)nf;
+        };
+        f16x8 b0h[MEL_FT], b0l[MEL_FT], b1h[MEL_FT], b1l[MEL_FT];
+        load_half(sbeg, 0, aLh, aLl);
+        load_half(sbeg, 1, aHh, aHl);
+        if (!(dbg & 1) && (HALVES == 1 || t0 + half * MEL_TN < bp.n_frames)) {
+            build_f(sbeg, 0, MEL_FT, b0h, b0l);
+            __builtin_amdgcn_sched_barrier(0);
+            // one step: MFMAs on (cur), fragments of the next step into (nxt); `more`: there is a next step (compile-time per call site)
+            auto one = [&](int st, const f16x8 (&ch)[MEL_FT], const f16x8 (&cl)[MEL_FT], f16x8 (&nh)[MEL_FT], f16x8 (&nl)[MEL_FT], bool more) __attribute__((always_inline)) {
+                if (more) build_f(st + 1, 0, FT1, nh, nl);
+                mma_half(0, aLh, aLl, ch, cl);
+                if (more) interleave(FT1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) load_half(st + 1, 0, aLh, aLl);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) build_f(st + 1, FT1, MEL_FT, nh, nl);
+                mma_half(1, aHh, aHl, ch, cl);
+                if (more) interleave(MEL_FT - FT1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) load_half(st + 1, 1, aHh, aHl);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            int si = 0;
+            for (; si + 2 < spw; si += 2) {
+                one(sbeg + si, b0h, b0l, b1h, b1l, true);
+                one(sbeg + si + 1, b1h, b1l, b0h, b0l, true);
+            }
+            if (si + 1 < spw) {
+                one(sbeg + si, b0h, b0l, b1h, b1l, true);
+                one(sbeg + si + 1, b1h, b1l, b0h, b0l, false);
+            } else {
+                one(sbeg + si, b0h, b0l, b1h, b1l, false);
             }
         }
 #else

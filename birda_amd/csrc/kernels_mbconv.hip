@@ -70,6 +70,10 @@ double mb_try_th(MbDesc &d, int ci, int th, bool relax_kg = false) {
     MbDesc t = d;
     t.cfg = ci; t.TH = th; t.S = c.S;
     t.tiles_y = (d.Ho + th - 1) / th; t.tiles_x = (d.Wo + TW - 1) / TW;
+    {
+        auto magic = [](unsigned dv) { const unsigned long long q = (1ull << 32) / dv + 1; return (unsigned)std::min<unsigned long long>(q, 0xffffffffull); };
+        t.rcp_tiles_x = magic((unsigned)t.tiles_x); t.rcp_tiles_xy = magic((unsigned)(t.tiles_x * t.tiles_y));
+    }
     t.IH = (th - 1) * c.ST + c.KS; t.IW = (TW - 1) * c.ST + c.KS;
     t.KG = c.KG; t.nchunks = (d.Cexp + c.CE - 1) / c.CE; t.NTOP = c.WN * c.NT_W; t.CE = c.CE;
     const int mseg = std::min(t.IH, d.H) * std::min(t.IW, d.W);

@@ -32,8 +32,32 @@
 
 namespace bh {
 
+// Round 6, VERDICT r5 next #2: the fixed cost of a tile, each lead BUILT and measured on its own (profiles/r6_e_setup_leads.txt):
+//   BH_MB_BUFLOAD   the wave's rows of X through a buffer descriptor: lanes that must read zero (rows past the tile, columns past
+//                   Cin) take an out-of-range offset and the hardware's range check returns 0 -- no select per loaded value, 32-bit
+//                   offsets instead of 64-bit addresses
+//   BH_MB_HOSTRCP   tile decode (tile -> segment group, tile row, tile column) by host-computed reciprocals (MbDesc::rcp_*): two
+//                   s_mul_hi_u32 instead of two expanded 32-bit divisions
+//   BH_MB_CONSTDIV  row decode of a tile whose rectangle lies inside the image (valid width = the tile's own IW, a compile-time
+//                   number): division by a constant
+#ifndef BH_MB_BUFLOAD
+#define BH_MB_BUFLOAD 1
+#endif
+#ifndef BH_MB_HOSTRCP
+#define BH_MB_HOSTRCP 1
+#endif
+#ifndef BH_MB_CONSTDIV
+#define BH_MB_CONSTDIV 1
+#endif
+//   BH_MB_BUFSTORE  the epilogue's stores (and the residual loads the accumulators start from) through buffer descriptors: a lane
+//                   without a pixel or past Cout takes an out-of-range offset -- no exec-mask branch per store, 32-bit offsets
+#ifndef BH_MB_BUFSTORE
+#define BH_MB_BUFSTORE 1
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
@@ -304,8 +328,22 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
     if constexpr (PERSIST != 0) asm volatile("" : "+v"(tid));
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
+#if BH_MB_HOSTRCP
+    // q = floor(n / dv) as mulhi(n, floor(2^32 / dv) + 1): the estimate exceeds the quotient by n e / (dv 2^32) < 1 (e = the
+    // multiplier's rounding, at most dv), i.e. by at most one for any 32-bit n -- one fix-up step either way makes it exact (and
+    // serves dv = 1, whose multiplier saturates one short)
+    auto udiv = [](unsigned nn, unsigned dv, unsigned magic) {
+        unsigned q = __umulhi(nn, magic);
+        const int rem = (int)(nn - q * dv);
+        q += (rem >= (int)dv ? 1 : 0) - (rem < 0 ? 1 : 0);
+        return (int)q;
+    };
+    const int tz = udiv((unsigned)tile, (unsigned)tiles_xy, STRIP ? d.rcp_tiles_x : d.rcp_tiles_xy), txy = tile - tz * tiles_xy;
+    const int tyi = STRIP ? trow : udiv((unsigned)txy, (unsigned)d.tiles_x, d.rcp_tiles_x), txi = STRIP ? txy : txy - tyi * d.tiles_x;
+#else
     const int tz = tile / tiles_xy, txy = tile - tz * tiles_xy;
     const int tyi = STRIP ? trow : txy / d.tiles_x, txi = STRIP ? txy : txy - tyi * d.tiles_x;
+#endif
     const int seg0 = tz * SS;
     const int nsv = min(SS, n_seg - seg0);
     const int oy0 = tyi * TH, ox0 = txi * TW;
@@ -364,7 +402,15 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
             const int m = rt * 16 + li;
             if (rt < nrt && m < M) {
                 const int sl = SS > 1 ? (m >= Mseg ? 1 : 0) : 0, mm = m - sl * Mseg;
+#if BH_MB_CONSTDIV
+                // (vw == IWC, wave-uniform: the tile's rectangle is inside the image in x -- every tile but the last column's, and
+                //  the first's under left padding; IWC is a compile-time number, so the division is a multiply and a shift)
+                constexpr int IWC = ((1 << TWL) - 1) * ST + KS;
+                const int r = vw == IWC ? (int)(((unsigned)mm * (unsigned)((65536 + IWC - 1) / IWC)) >> 16) : mb_div(mm, vw, rcp_vw), c = mm - __mul24(r, vw);
+                static_assert((long)(SS * 64 * 16 * 8) * IWC < 65536L * 8, "row index times the rounding error of the reciprocal stays below one");
+#else
                 const int r = mb_div(mm, vw, rcp_vw), c = mm - __mul24(r, vw);
+#endif
                 eoff[i] = __mul24(sl * IH * IW + __mul24(ra + r, IW) + xa + c, CES) + 4 * kq;
                 xo[ii] = STEM ? (((iy0 + ra + r) << 16) | (ix0 + xa + c))   // stem-output pixel (y, x), gathered below
                               : __mul24(__mul24(sl * d.H + iy0 + ra + r, d.W) + ix0 + xa + c, Cin);
@@ -446,6 +492,10 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
             }
         } else {
             float4 raw[XBATCH][KG][NQ];
+#if BH_MB_BUFLOAD
+            // the workgroup's segments of X as ONE buffer: a lane that must read zero takes offset 2^32 - 1 and the range check answers 0
+            const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Xb), 0, __builtin_amdgcn_readfirstlane(__mul24(nsv * d.H, d.W) * Cin * 4), 0x00020000);
+#endif
 #pragma unroll
             for (int ii = 0; ii < XBATCH; ii++) {
                 if (i0 + ii >= RT_W) continue;
@@ -455,7 +505,11 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                     for (int q = 0; q < NQ; q++) {
                         const int kk = (PREC ? 32 * g + 8 * kq : 16 * g + 4 * kq) + 4 * q;
                         const bool ok = rvv[ii] && kk < Cin;
+#if BH_MB_BUFLOAD
+                        raw[ii][g][q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? (unsigned)(xo[ii] + kk) * 4u : 0xffffffffu, 0, 0));
+#else
                         raw[ii][g][q] = *reinterpret_cast<const float4 *>(Xb + (ok ? xo[ii] + kk : 0));
+#endif
                     }
             }
 #pragma unroll
@@ -470,8 +524,13 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                         const int kk = (PREC ? 32 * g + 8 * kq : 16 * g + 4 * kq) + 4 * q;
                         const bool ok = rvv[ii] && kk < Cin;
                         const float4 t = raw[ii][g][q];
+#if BH_MB_BUFLOAD
+                        (void)ok; (void)kk;
+                        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;     // (zeros came back from the range check)
+#else
                         v[4 * q] = ok ? t.x : 0.0f; v[4 * q + 1] = ok ? t.y : 0.0f;
                         v[4 * q + 2] = ok ? t.z : 0.0f; v[4 * q + 3] = ok ? t.w : 0.0f;
+#endif
                     }
                     if constexpr (PREC != 0) bh_split8(v, ah[i][g], al[i][g]);
                     else afr[i][g] = make_float4(v[0], v[1], v[2], v[3]);
@@ -509,6 +568,12 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
     float *Yb = d.Y + (size_t)seg0 * d.Ho * d.Wo * Cout;
     const float *Rb = d.R ? d.R + (size_t)seg0 * d.Ho * d.Wo * Cout : nullptr;
     f32x4 acco[MT_W][NT_W];
+#if BH_MB_BUFSTORE
+    // the workgroup's segments of Y (and of the residual, shaped alike) as buffers
+    const unsigned y_bytes = (unsigned)__builtin_amdgcn_readfirstlane(__mul24(nsv * d.Ho, d.Wo) * Cout * 4);
+    const auto yrs = __builtin_amdgcn_make_buffer_rsrc(Yb, 0, SE ? 0 : y_bytes, 0x00020000);
+    const auto yrs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Rb ? Rb : Yb), 0, (SE || !Rb) ? 0 : y_bytes, 0x00020000);
+#endif
     // SE (pass A of a squeeze-excite block): where the depthwise output and the tile's channel sums go
     const bool se_store = SE && d.Dout != nullptr;      // (nullptr: sums only -- the no-expand blocks, whose D is computed again by the gated one-launch block)
     float *Dg = SE ? (se_store ? d.Dout : reinterpret_cast<float *>(size_t(1) << 30)) + (size_t)seg0 * d.Ho * d.Wo * d.Cexp : nullptr;   // (never dereferenced without se_store)
@@ -544,14 +609,29 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                                                 //  that many loads in flight cost registers the late blocks do not have)
                 const float braw = d.bp[colc];
                 float rres[4] = {0.f, 0.f, 0.f, 0.f};
+                const float bias = col < Cout ? braw : 0.0f;
+#if BH_MB_BUFSTORE
+                if (Rb) {   // (wave-uniform) lanes without a pixel or past Cout: offset 2^32 - 1, the range check answers 0
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+                        rres[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yrs_r, (col < Cout && orow[r] >= 0) ? (unsigned)(__mul24(orow[r], Cout) + col) * 4u : 0xffffffffu, 0, 0));
+                }
+                // (the scale through an opaque vector register: with the kernel argument's SGPR pair as operand hipcc packs these four
+                //  FMAs as v_pk_fma_f32 ... op_sel:[0,1,0] -- a half-selecting packed-f32 form; tests/test_abi_and_host.py
+                //  ::test_device_code_has_no_half_swapped_packed_f32_ops keeps every such form out of the library)
+                float ps_v = p_scale;
+                asm volatile("" : "+v"(ps_v));
+#pragma unroll
+                for (int r = 0; r < 4; r++) acco[i][j][r] = __builtin_fmaf(rres[r], ps_v, bias);
+#else
                 if (Rb) {   // (wave-uniform)
 #pragma unroll
                     for (int r = 0; r < 4; r++) rres[r] = Rb[__mul24(max(orow[r], 0), Cout) + colc];
                 }
-                const float bias = col < Cout ? braw : 0.0f;
 #pragma unroll
                 for (int r = 0; r < 4; r++)
                     acco[i][j][r] = __builtin_fmaf((col < Cout && orow[r] >= 0) ? rres[r] : 0.0f, p_scale, bias);
+#endif
             } else {
                 const float bias = col < Cout ? d.bp[col] : 0.0f;
 #pragma unroll
@@ -1152,10 +1232,18 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
 #pragma unroll
         for (int j = 0; j < NT_W; j++) {
             const int col = (wn * NT_W + j) * 16 + li;
+#if BH_MB_BUFSTORE
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float yv = PREC != 0 ? acco[i][j][r] * p_unscale : acco[i][j][r];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yv), yrs, (col < Cout && orow[r] >= 0 && !(dbgv & 32)) ? (unsigned)(__mul24(orow[r], Cout) + col) * 4u : 0xffffffffu, 0, 0);
+            }
+#else
             if (col >= Cout) continue;
 #pragma unroll
             for (int r = 0; r < 4; r++)
                 if (orow[r] >= 0 && !(dbgv & 32)) Yb[__mul24(orow[r], Cout) + col] = PREC != 0 ? acco[i][j][r] * p_unscale : acco[i][j][r];
+#endif
         }
     }
     mb_stamp(d.stamps, t_last, 7);

@@ -336,8 +336,11 @@ def test_shipped_hot_kernels_fit_their_register_budget():
         # more (a first version that stored D from the depthwise tasks themselves cost 40-120 registers and spilled)
         v2, a2, s2, t2 = k(args, se=1)
         assert t2 == 512 and s2 == 0 and v2 + a2 <= 256, (args, k(args, se=1))
+    # (round 6: the software-pipelined loop -- BH_MEL_PIPE 2, the operator held half a step at a time -- parks three thread-invariant
+    #  dwords in scratch and reloads them once per work item, at the loop's exit; measured 4.2 % faster than the spill-free plain loop,
+    #  profiles/r6_g_mel_pipe_tuning.txt.  Round 4's pipelined form needed 148 bytes and reloaded them inside the MFMA tail.)
     vgpr, agpr, scratch, threads = res["mel_kernel<6,3,1>"]
-    assert scratch == 0 and vgpr + agpr <= 256
+    assert scratch <= 16 and vgpr + agpr <= 256
 
 
 def test_shipped_tile_configurations_are_the_reachable_ones():

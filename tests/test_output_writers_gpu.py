@@ -73,7 +73,7 @@ def test_every_format_written_from_a_device_run_is_what_the_oracles_detections_g
     # the same six files from the oracle's detections through the host writers
     for fmt in FORMATS:
         p = pipeline.output_path_for(wav, str(out_ref), fmt)
-        w = pipeline.OutputWriter(fmt, p, source_file=wav, model="birdnet-v24-tiny", min_confidence=min_conf, overlap=overlap,
+        w = pipeline.OutputWriter(fmt, p, source_file=os.path.basename(wav), model="birdnet-v24-tiny", min_confidence=min_conf, overlap=overlap,
                                   audio_duration=res.audio_duration_secs, lat=60.17, lon=24.94, week=22)
         w.write_header()
         for d in dets:

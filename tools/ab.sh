@@ -38,6 +38,11 @@ for l in open('/tmp/ab_rows.txt'):
 for lab,r in rows.items():
     m=[st.median(c) for c in zip(*r)]
     print('MEDIAN %-28s | %7.0f seg/s  med5 %7.0f  mel %.3f  mbconv %.3f | %s' % (lab, m[0], m[1], m[2], m[3], ' '.join('%6.0f' % x for x in m[4:])))
+# ... and, per run, every block's time over the SAME run's mel time (a kernel no variant of the fused block touches): a box that
+# changes mode between runs (+-7 %, every kernel alike: profiles/r5_h_repeat_bench.txt) moves numerator and denominator together
+for lab,r in rows.items():
+    q=[st.median([row[4+k]/row[2] for row in r]) for k in range(len(r[0])-4)]
+    print('PER-MEL %-28s | mbconv/mel %.3f | %s' % (lab, st.median([row[3]/row[2] for row in r]), ' '.join('%6.0f' % x for x in q)))
 PY
 }
 case $mode in
@@ -48,6 +53,10 @@ lib)  cp birda_amd/libbirda_hip.so /tmp/libbirda_hip_new.so; rm -f /tmp/ab_rows.
         cp tools/ab/libbirda_hip_old.so birda_amd/libbirda_hip.so; row old "$@"
         cp /tmp/libbirda_hip_new.so birda_amd/libbirda_hip.so; row new "$@"
       done; cp /tmp/libbirda_hip_new.so birda_amd/libbirda_hip.so; medians ;;
+libs) # tools/ab.sh libs tagA tagB ...: tools/ab/libbirda_hip_<tag>.so in turn (tools/build_variants.sh), REPS alternations, medians
+      cp birda_amd/libbirda_hip.so /tmp/libbirda_hip_new.so; rm -f /tmp/ab_rows.txt
+      for rep in $(seq 1 ${REPS:-2}); do for tag in "$@"; do cp tools/ab/libbirda_hip_$tag.so birda_amd/libbirda_hip.so; row $tag; done; done
+      cp /tmp/libbirda_hip_new.so birda_amd/libbirda_hip.so; medians ;;
 legs) for set in "$@"; do
         env $set python bench.py --no-cpu-baseline --steps ${STEPS:-5} --warmup 2 $BENCH_ARGS 2>/dev/null | python -c "
 import json,sys
