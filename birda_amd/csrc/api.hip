@@ -230,6 +230,54 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
                 // never exists; D crosses HBM once each way.
                 const auto &S = c->se[c->fused_at[i]];
                 const auto &G1 = m.layers[S.iPw1], &G2 = m.layers[S.iPw2], &LP = m.layers[S.iP];
+                // Round 6 (VERDICT r5 next #3a): a block whose D is large -- the early stages: 1.5-2.3 MB a segment -- runs its three
+                // launches per GROUP of segments, so that the D pass A writes is still in the 256 MB Infinity Cache when the gated
+                // project GEMM reads it (at 1 000 segments a launch it crosses HBM both ways).  The tiling -- hence every pooled sum's
+                // order, hence the bits -- is the whole launch's; only the launches are cut.  c->se_group_bytes: the D one group may
+                // hold (0: never); blocks whose whole D fits run as before.
+                {
+                    const size_t d_seg_bytes = (size_t)d.Ho * d.Wo * d.Cexp * sizeof(float);
+                    size_t grp = (!d.noexp && c->se_group_bytes && d_seg_bytes * n > c->se_group_bytes) ? std::max<size_t>(c->se_group_bytes / d_seg_bytes, 16) : n;
+                    if (grp < n) grp -= grp % (size_t)std::max(d.S, 1);     // (whole S-segment workgroups per group)
+                    if (grp < n) {
+                        const size_t P = (size_t)d.Ho * d.Wo, tiles = (size_t)d.tiles_x * d.tiles_y;
+                        const size_t in_seg = d.stem ? (size_t)d.stem_c * d.stem_h * d.stem_w : (size_t)d.H * d.W * d.Cin;
+                        float *gate = T(S.iPw2 + 1);
+                        float *y = (S.iP == nl - 1) ? d_logits : T(S.iP + 1);
+                        const float *r = LP.res_tensor != bh::NO_TENSOR ? T(LP.res_tensor) : nullptr;
+                        const bool blocked = c->d_w16[S.iP] && bh::pw_gemm16_gated_wants_blocked(d.Cexp, d.Cout, d.Ho * d.Wo);
+                        for (size_t s0 = 0; s0 < n; s0 += grp) {
+                            const size_t ng = std::min(grp, n - s0);
+                            bh::MbDesc g = d;
+                            g.X = in + s0 * in_seg;
+                            g.Dout = T(S.iD + 1) + s0 * P * d.Cexp;
+                            g.pool_part = T(S.iScale + 1) + s0 * tiles * d.Cexp;
+                            g.gate = nullptr;
+                            g.dblk = blocked;
+                            bh::launch_mbconv(g, (int)ng, s);
+                            float *gg = gate + s0 * d.Cexp;
+                            static const bool gate1g = [] { const char *e = BH_XENV("BIRDA_HIP_SE_GATE1"); return e && e[0] == '1'; }();
+                            if (!gate1g && d.Cexp > 576)
+                                bh::launch_se_gate_gemm(g.pool_part, (int)tiles, (int)P, T(S.iGap + 1) + s0 * d.Cexp, T(S.iPw1 + 1) + s0 * G1.cout, c->d_w[S.iPw1], c->d_blob + G1.b_off,
+                                                        c->ldw[S.iPw1], (int)G1.act, c->d_w[S.iPw2], c->d_blob + G2.b_off, c->ldw[S.iPw2], (int)G2.act, gg, (int)ng,
+                                                        d.Cexp, (int)G1.cout, s);
+                            else
+                                bh::launch_se_gate(g.pool_part, (int)tiles, (int)P, c->d_w[S.iPw1], c->d_blob + G1.b_off, c->ldw[S.iPw1], (int)G1.act,
+                                                   c->d_w[S.iPw2], c->d_blob + G2.b_off, c->ldw[S.iPw2], (int)G2.act, gg, (int)ng, d.Cexp, (int)G1.cout, s);
+                            float *yg = y + s0 * P * d.Cout;
+                            const float *rg = r ? r + s0 * P * d.Cout : nullptr;
+                            if (c->d_w16[S.iP])
+                                bh::launch_pw_gemm16_gated(g.Dout, gg, (int)P, c->d_w16[S.iP], c->d_blob + LP.b_off, rg, yg, (int)(ng * P), d.Cexp, d.Cout,
+                                                           c->precision == 3 ? 3 : 1, c->w16_unscale[S.iP], g.dblk, s);
+                            else
+                                bh::launch_pw_gemm_gated(g.Dout, gg, (int)P, c->d_w[S.iP], c->d_blob + LP.b_off, rg, yg, (int)(ng * P), d.Cexp, d.Cout,
+                                                         c->ldw[S.iP], (int)LP.act, s);
+                        }
+                        ctx_mark(ctx, ST_MBCONV, (int)i);
+                        i = S.iP;
+                        continue;
+                    }
+                }
                 d.X = in;
                 // (a block without an expand convolution computes D twice instead of keeping it: pass A leaves only the channel sums,
                 //  the gated one-launch block below does the rest -- kernels.hpp MbDesc::gate)
@@ -1017,6 +1065,7 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) try {
         }
     }
     if (const char *e = BH_XENV("BIRDA_HIP_MB_NARROW_MAX")) c->narrow_max_workgroups = atoi(e);   // (A/B aid: 0 = never)
+    if (const char *e = getenv("BIRDA_HIP_SE_GROUP_MB")) c->se_group_bytes = (size_t)atol(e) << 20;   // (MB of D per group of segments; 0: whole launches)
     if (const char *st = BH_XENV("BIRDA_HIP_MB_STAMPS"); st && st[0] == '1' && !c->mb.empty()) {
         HIPCHK(hipMalloc((void **)&c->d_stamps, c->mb.size() * 8 * sizeof(unsigned long long)));
         HIPCHK(hipMemset(c->d_stamps, 0, c->mb.size() * 8 * sizeof(unsigned long long)));

@@ -80,6 +80,9 @@ struct bh_classifier {
     // channel sums, which live in the arena slot of the (never materialised) OP_SCALE output
     struct SeInfo { uint32_t iD = 0, iGap = 0, iPw1 = 0, iPw2 = 0, iScale = 0, iP = 0; size_t part_floats = 0; };
     std::vector<SeInfo> se;
+    // squeeze-excite blocks: the D one group of segments may hold between pass A and the gated project GEMM (api.hip forward_slice);
+    // 0 = whole launches (round 5).  Measured: profiles/r6_i_se_groups.txt
+    size_t se_group_bytes = 0;
     int narrow_max_workgroups = 256;         // launches whose narrow tiles number at most this take them: one workgroup a CU at most (round 5, swept
                                              // per layer at 32 .. 256 segments, profiles/r5_g_narrow_tiles_sweep.txt: beyond, every extra workgroup streams
                                              // the block's 2 MB of weights again -- at 512 a launch of 160-256 segments lost 3-4 %)

@@ -94,7 +94,7 @@ def test_v24_frontend_geometry_matches_float64_vectors(oracle_lib, model_dir, ve
 FULL_GOLDEN_TOL = 2e-5    # of max(1, max |logit|): the f32 oracle against the float64 evaluation (measured 1e-6 ... 4e-6)
 
 
-@pytest.mark.parametrize("kind", ["birdnet_v24", "perch_v2", "birdnet_v30", "mini_se"])
+@pytest.mark.parametrize("kind", ["birdnet_v24", "perch_v2", "birdnet_v30", "mini_se", "birdnet_v30_sized"])
 def test_oracle_matches_float64_vectors_of_the_full_models(oracle_lib, tmp_path, kind):
     from birda_amd import modelfile as mf, synth
     g = np.load(os.path.join(GOLDEN, "full_model_vectors.npz"))

@@ -823,7 +823,7 @@ def test_auto_precision_reruns_the_rows_beyond_the_f16_range(model_dir, oracle_l
     assert mixed is not None, "no trunk scale left some rows inside and some outside the f16 range"
 
 
-@pytest.mark.parametrize("kind", ["birdnet_v24", "perch_v2", "birdnet_v30", "mini_se"])
+@pytest.mark.parametrize("kind", ["birdnet_v24", "perch_v2", "birdnet_v30", "mini_se", "birdnet_v30_sized"])
 def test_hip_matches_float64_vectors_of_the_full_models(tmp_path, kind):
     """The HIP path against the committed float64 torch / numpy logits of the models the bench runs (tests/golden/
     full_model_vectors.npz, tools/gen_golden.py full) -- directly, without the oracle in between (VERDICT r3 next #4)."""
@@ -838,7 +838,7 @@ def test_hip_matches_float64_vectors_of_the_full_models(tmp_path, kind):
     scale = max(1.0, float(np.abs(ref).max()))
     # (birdnet_v30 applies its sigmoid inside the model: its outputs are probabilities, scale 1, while the plain-f16 error is
     #  made on pre-sigmoid values of size ~10 -- 3e-3 of THAT scale; measured 3.0e-3 of the probabilities, bound stated at 6e-3)
-    f16_tol = 2 * F16_LOGIT_RTOL if kind == "birdnet_v30" else F16_LOGIT_RTOL
+    f16_tol = 2 * F16_LOGIT_RTOL if kind in ("birdnet_v30", "birdnet_v30_sized") else F16_LOGIT_RTOL
     for prec, tol in (("f32", LOGIT_RTOL), ("f16x3", LOGIT_RTOL), ("auto", LOGIT_RTOL), ("f16", f16_tol)):
         clf = BirdClassifier(path, None, precision=prec)
         ctx = clf.create_batch_context(4)
@@ -1114,6 +1114,44 @@ def test_perch_sized_model_matches_oracle(oracle_lib, tmp_path):
                 gb = clf.predict_logits(big, np.ascontiguousarray(np.tile(segs, (nbig // 3 + 1, 1))[:nbig]))
                 assert all((gb[i] == got[i % 3]).all() for i in range(nbig)), (prec, nbig)
                 big.close()
+        ctx.close(); clf.close()
+
+
+def test_birdnet_v30_at_its_published_size_matches_oracle(oracle_lib, tmp_path):
+    """BirdNET v3.0 at the size of the published file (VERDICT r5 missing #3; reference manifests/BirdNET-v3.0-Models.models.json:
+    557 212 256 bytes, 1 280-d `embeddings`, 11 560 classes whose sigmoid sits inside the graph, 5 s at 32 kHz): the B0 stand-in of
+    rounds 3-5 was a quarter of a percent of that.  [EXT] The trunk is not published offline; `birdnet_v30_sized` is the
+    EfficientNetV2-L stage plan (the one trunk that fits 139 M parameters AND a 1 280-d embedding) with its fused-MBConv stages
+    spelled as MBConv, swish and squeeze-excite gates: 553 MB, 83 blocks, 21.5 GFLOP per segment.  76 blocks run fused (the seven of
+    the 640-channel stage are beyond the widest tile entries -- 384 channels in, 512 out -- and run layer by layer); logits
+    (probabilities: the output layer carries the sigmoid) against the oracle in the f32-grade modes, bit-identical across launch
+    sizes."""
+    from birda_amd import modelfile as mf, synth
+    from birda_amd.classifier import BirdClassifier
+    m = synth.build_model("birdnet_v30_sized")
+    path = str(tmp_path / "v30_sized.bhm")
+    mf.write_model(path, m)
+    assert 540e6 < os.path.getsize(path) < 575e6
+    assert (m.sample_rate, m.sample_count, m.n_classes, m.embedding_dim, m.output_activation) == (32000, 160000, 11560, 1280, mf.OUT_NONE)
+    segs = synth.synth_segments(2, m.sample_count, m.sample_rate, start=15)
+    ref, ref_emb = oracle_lib.OracleModel(path).forward(segs, want_embeddings=True)
+    assert ref.min() >= 0.0 and ref.max() <= 1.0
+    for prec in ("f16x3", "auto", "f32"):
+        clf = BirdClassifier(path, None, top_k=5, min_confidence=0.0, precision=prec)
+        blocks = clf.fused_blocks()
+        print(f"v3.0-sized {prec}: {len(blocks)} of 83 blocks fused, {2 * clf.info.macs_per_segment / 1e9:.2f} GFLOP per segment")
+        assert len(blocks) >= (76 if prec != "f32" else 60), (prec, len(blocks))
+        ctx = clf.create_batch_context(2)
+        got, emb = clf.predict_logits(ctx, segs, want_embeddings=True)
+        err = float(np.abs(got - ref).max())
+        escale = max(1.0, float(np.abs(ref_emb).max()))
+        print(f"v3.0-sized {prec}: max |dp| = {err:.3e} (probabilities), embeddings {float(np.abs(emb - ref_emb).max()) / escale:.3e} of their scale")
+        assert np.isfinite(got).all() and err <= LOGIT_RTOL and np.abs(emb - ref_emb).max() <= LOGIT_RTOL * escale, (prec, err)
+        if prec == "f16x3":
+            big = clf.create_batch_context(40)
+            gb = clf.predict_logits(big, np.ascontiguousarray(np.tile(segs, (20, 1))))
+            assert all((gb[i] == got[i % 2]).all() for i in range(40))
+            big.close()
         ctx.close(); clf.close()
 
 

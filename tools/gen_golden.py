@@ -253,12 +253,19 @@ REFERENCE_UNIT_CASES = {
 
 # The models bench.py and the GPU parity tests actually run: float64 torch / numpy logits of a few segments of
 # the FULL synthetic stacks, so that the oracle is not the sole authority for them.  kind -> (segments, first segment's seed index)
-FULL_MODELS = {"birdnet_v24": (4, 300), "perch_v2": (3, 310), "birdnet_v30": (3, 320), "mini_se": (3, 330)}
+FULL_MODELS = {"birdnet_v24": (4, 300), "perch_v2": (3, 310), "birdnet_v30": (3, 320), "mini_se": (3, 330),
+               "birdnet_v30_sized": (2, 340)}      # (round 6: the v3.0 contract at the published file's size, 553 MB / 21.5 GFLOP)
 
 
-def gen_full_models():
+def gen_full_models(only=()):
+    """`only`: regenerate just these kinds and keep the other models' committed vectors as they are (`full kind ...`)"""
     store = {}
+    path = os.path.join(OUT, "full_model_vectors.npz")
+    if only and os.path.exists(path):
+        store = dict(np.load(path))
     for kind, (n, start) in FULL_MODELS.items():
+        if only and kind not in only:
+            continue
         m = synth.build_model(kind)
         segs = synth.synth_segments(n, m.sample_count, m.sample_rate, start=start)
         rows = []
@@ -274,7 +281,7 @@ def gen_full_models():
 def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "full":   # (minutes of float64 CPU work: on request)
-        gen_full_models()
+        gen_full_models(tuple(sys.argv[2:]))
         return
     with open(os.path.join(OUT, "reference_unit_cases.json"), "w") as f:
         json.dump(REFERENCE_UNIT_CASES, f, indent=1)
