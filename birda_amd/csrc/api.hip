@@ -954,8 +954,8 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) try {
     for (uint32_t b = 0; b < m.h.n_branches; b++) {
         const auto &br = m.branches[b];
         const int nm_pad = (int)align_up(br.n_mels, 16);
-        if (nm_pad != 32 && nm_pad != 96 && nm_pad != 128)
-            return fail(BH_ERR_UNSUPPORTED, "front-end: n_mels %u not built (32/96/128)", br.n_mels);
+        if (nm_pad < 32 || nm_pad > 128)
+            return fail(BH_ERR_UNSUPPORTED, "front-end: n_mels %u not built (17 .. 128)", br.n_mels);
         if (b > 0 && nm_pad != c->fe.br[0].nm_pad) return fail(BH_ERR_UNSUPPORTED, "front-end: branches differ in n_mels");
         if (br.frame_length % 128 || br.fft_length != br.frame_length)
             return fail(BH_ERR_UNSUPPORTED, "front-end: frame_length %u must be a multiple of 128 and equal fft_length", br.frame_length);

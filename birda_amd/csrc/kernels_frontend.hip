@@ -447,13 +447,15 @@ __global__ __launch_bounds__(256 * HALVES, (MT <= 6 || HALVES == 2) ? 2 : 1) voi
         #ifndef BH_MEL_FT1
 #define BH_MEL_FT1 ((MEL_FT + 1) / 2)
 #endif
-        constexpr int MH = MT / 2, FT1 = BH_MEL_FT1;
-        static_assert(MT % 2 == 0, "two halves of mel tiles");
+        // (an odd number of mel tiles -- 48, 80, 112 mels -- splits as MH + (MH - 1): the register sets are MH wide, the short half leaves
+        //  its last slot unused)
+        constexpr int MH = (MT + 1) / 2, FT1 = BH_MEL_FT1;
         f16x8 aLh[MH], aLl[MH], aHh[MH], aHl[MH];
         auto load_half = [&](int st, int h, f16x8 (&ah)[MH], f16x8 (&al)[MH]) {
             if (dbg & 16) st = sbeg;
 #pragma unroll
             for (int m = 0; m < MH; m++) {
+                if (h * MH + m >= MT) continue;
                 ah[m] = gA[(((size_t)st * MT + h * MH + m) * 2 + 0) * 64];
                 al[m] = gA[(((size_t)st * MT + h * MH + m) * 2 + 1) * 64];
             }
@@ -475,9 +477,11 @@ __global__ __launch_bounds__(256 * HALVES, (MT <= 6 || HALVES == 2) ? 2 : 1) voi
             for (int m = 0; m < MH; m++)
 #pragma unroll
                 for (int f = 0; f < MEL_FT; f++) {
-                    acc[f][h * MH + m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh[f], acc[f][h * MH + m], 0, 0, 0);
-                    acc[f][h * MH + m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl[f], acc[f][h * MH + m], 0, 0, 0);
-                    acc[f][h * MH + m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh[f], acc[f][h * MH + m], 0, 0, 0);
+                    if (h * MH + m >= MT) continue;
+                    const int mm = h * MH + m < MT ? h * MH + m : 0;
+                    acc[f][mm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh[f], acc[f][mm], 0, 0, 0);
+                    acc[f][mm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl[f], acc[f][mm], 0, 0, 0);
+                    acc[f][mm] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh[f], acc[f][mm], 0, 0, 0);
                 }
         };
         // (per phase: 9 MH MFMAs beside 24 VALU + 16 LDS reads per frame tile built)
@@ -900,6 +904,7 @@ void launch_mel(const float *x, const float *minmax, float *spec, const Frontend
     } break;
         switch (mt32) {
             BH_MEL32(1)
+            BH_MEL32(2)
             BH_MEL32(3)
             BH_MEL32(4)
         default: break;
@@ -955,9 +960,13 @@ void launch_mel(const float *x, const float *minmax, float *spec, const Frontend
             hipLaunchKernelGGL((mel_kernel<MTV, 0>), grid, block, smem, s, x, minmax, spec, d_p, p.br[0].gf,   \
                                p.br[1].gf, p.br[2].gf, p.br[3].gf, dbg, n_tiles, n_items, paired);                 \
     } break;
-    switch (mt) {
+    switch (mt) {      // (32, 96 and 128 mels are the published families'; 48 / 64 / 80 / 112 -- round 6 -- whatever else a model file holds)
         BH_MEL_CASE(2)
+        BH_MEL_CASE(3)
+        BH_MEL_CASE(4)
+        BH_MEL_CASE(5)
         BH_MEL_CASE(6)
+        BH_MEL_CASE(7)
         BH_MEL_CASE(8)
     default: break;
     }

@@ -276,13 +276,14 @@ def build_model(kind: str = "birdnet_v24", seed: int = WEIGHT_SEED,
 def random_plan(seed: int, big: bool = False) -> dict:
     """A seeded inverted-residual stack this repo did NOT design: stem 16-64 channels, widths any multiple
     of 4 or 8, expand ratio in {1, 3, 4, 6}, kernels 3 / 5, strides 1 / 2, odd image sizes (asymmetric SAME padding follows), gates
-    on / off, GELU / swish / ReLU6, 1-3 mel branches.  `big`: a 96- or 128-mel spectrogram and up to 5 stages (the tile planner
-    sees BirdNET- / Perch-sized images); otherwise a 17-32-mel one that the C oracle finishes in well under a second per segment.
+    on / off, GELU / swish / ReLU6, 1-3 mel branches.  `big`: a 64- to 128-mel spectrogram of a 3 s / 5 s segment and up to 5 stages (the
+    tile planner sees BirdNET- / Perch-sized images); otherwise 17-80 mels of a quarter-second segment, which the C oracle finishes
+    in well under a second.
     Feed to build_model("custom", plan=...)."""
     rng = np.random.default_rng(0x51AB + seed)
     ri = lambda lo, hi: int(rng.integers(lo, hi + 1))
     n_br = ri(1, 3)
-    n_mels = int(rng.choice([96, 128, 90, 121])) if big else ri(17, 32)
+    n_mels = int(rng.choice([96, 128, 90, 121, 64, 80, 112, 70])) if big else (ri(17, 32) if rng.integers(0, 3) else ri(33, 80))
     # (the input length is one the reference's families have -- no graph states its sample rate, the library reads it off the length,
     #  onnx_conv.hpp frontend_for -- the frames then follow from frame length and hop: odd and even counts alike)
     sr, n = (48000, 12000) if not big else ((48000, 144000) if rng.integers(0, 2) else (32000, 160000))
