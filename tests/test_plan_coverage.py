@@ -1,6 +1,6 @@
 """Host-side half of VERDICT r5 next #1: the tile planner on conv stacks this repo did not design (no GPU: bh_plan_fused_blocks).
 
-The reference runs whatever `.onnx` it is handed (src/inference/classifier.rs:293-283); the fused MBConv path must not depend on
+The reference runs whatever `.onnx` it is handed (src/inference/classifier.rs:269-283); the fused MBConv path must not depend on
 the two channel plans of birda_amd/synth.py.  Every inverted-residual block of the five probe plans the round-5 judge used (1 / 16
 ... 16 / 23 fused then) and of 50 seeded random stacks must find a tile entry, in split-f16 AND in f32 (the path BH_FLAG_AUTO
 re-runs an overflowing row on).  The device side -- the same plans against the oracle -- is tests/test_random_plans_gpu.py.
@@ -39,5 +39,5 @@ def test_this_repos_own_plans_keep_their_hand_tuned_entries():
     import plan_models
     _, by_model = plan_models.survey(models=["birdnet_v24", "perch_v2"])
     assert [c for _, c in by_model["birdnet_v24/default/f16x3"]["fused"]] == [65, 48, 49, 50, 51, 52, 113, 113, 99, 101, 101, 58, 103, 103, 103, 105]
-    got = [c % 293 for _, c in by_model["perch_v2/default/f16x3"]["fused"]]
+    got = [c % 301 for _, c in by_model["perch_v2/default/f16x3"]["fused"]]
     assert len(got) == 26 and max(got) < 211, got

@@ -91,7 +91,7 @@ def main():
         scale = max(1.0, float(np.abs(ol).max()))
         print(f"== {name}: {nf} of {len(bl)} blocks fused, {N} segments a launch, {PREC}; fused vs layer by layer max |dlogit| {np.abs(of - ol).max() / scale:.1e} of the logit scale")
         sf = sl = 0.0
-        n_base = 293
+        n_base = 301
         for k, (a, b, desc) in enumerate(bl):
             tf, tl = sum(lf[a:b + 1]), sum(ll[a:b + 1])
             sf += tf
