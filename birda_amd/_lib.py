@@ -109,7 +109,9 @@ SYMBOLS = [
                                    C.POINTER(_SZ), _VP]),
     ("bh_predict_pcm", C.c_int, [_VP, _VP, _VP, C.c_uint32, _SZ, C.c_uint32, C.c_uint32, _SZ, C.POINTER(BhResult), _SZ, C.POINTER(_SZ), _VP]),
     ("bh_predict_pcm_rows", C.c_int, [_VP, _VP, _VP, C.c_uint32, _SZ, C.c_uint32, C.c_uint32, _SZ, C.POINTER(BhResult), _SZ, C.POINTER(_SZ), _VP,
-                                       BhRowsFn, _VP]),
+                                      BhRowsFn, _VP]),
+    ("bh_predict_pcm_fd_rows", C.c_int, [_VP, _VP, C.c_int, C.c_uint64, C.c_uint32, _SZ, C.c_uint32, C.c_uint32, _SZ, C.POINTER(BhResult), _SZ,
+                                         C.POINTER(_SZ), _VP, BhRowsFn, _VP]),
     ("bh_predict_pcm_at", C.c_int, [_VP, _VP, _VP, C.c_uint32, _SZ, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), _SZ, C.POINTER(BhResult)]),
     ("bh_predict_pcm16_at", C.c_int, [_VP, _VP, _VP, _SZ, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), _SZ, C.POINTER(BhResult)]),
     ("bh_resample", C.c_int, [_VP, _VP, _SZ, C.c_uint32, C.c_uint32, _VP, _SZ, C.POINTER(_SZ)]),

@@ -593,8 +593,11 @@ int run_host_front_end(bh_classifier *clf, const FilePlan &pl, const bh_model_in
 // but the last span end on a full segment, whose trailing overlap remainder belongs to the next span and is dropped here.
 int run_device_front_end(bh_classifier *clf, const FilePlan &pl, const bh_model_info &info, bh_batch_context *ctx, const unsigned char *pcm,
                          uint32_t fmt, size_t bps, size_t n_frames, uint32_t channels, std::vector<Detection> &detections, RunStats &st,
-                         std::string &fail_msg) {
+                         std::string &fail_msg, int fd = -1, uint64_t data_offset = 0) {
     (void)info;
+    // the file's bytes by pread into the pinned staging buffer (round 6) unless BIRDA_HOST_PREAD=0 (A/B aid: the mapped route of rounds 3-5)
+    static const bool pread_off = [] { const char *e = getenv("BIRDA_HOST_PREAD"); return e && e[0] == '0'; }();
+    bool use_fd = fd >= 0 && !pread_off;
     const size_t seg = pl.src_segment_samples, ovl = pl.src_overlap_samples;
     if (ovl >= seg) {   // next_segment's check, decode.rs:156-162
         fail_msg = "overlap_samples (" + std::to_string(ovl) + ") must be less than segment_samples (" + std::to_string(seg) + ")";
@@ -627,6 +630,13 @@ int run_device_front_end(bh_classifier *clf, const FilePlan &pl, const bh_model_
         void *guard = bhh_watchdog_start(watchdog_timeout_secs() * 1000, std::min(pl.effective, span_segments));
         int r;
         try {
+            r = BH_ERR_UNSUPPORTED;
+            if (use_fd) {
+                r = bh_predict_pcm_fd_rows(clf, ctx, fd, data_offset + (uint64_t)f0 * channels * bps, fmt, frames, channels, pl.source_rate, pl.overlap_samples,
+                                           results.data(), results.size(), &n_seg, starts.data(), &Sink::rows, &sink);
+                if (r == BH_ERR_UNSUPPORTED) use_fd = false;     // (a slice wider than the staging buffer: nothing was delivered; the mapped route)
+            }
+            if (!use_fd)
             r = bh_predict_pcm_rows(clf, ctx, pcm + f0 * channels * bps, fmt, frames, channels, pl.source_rate, pl.overlap_samples, results.data(),
                                     results.size(), &n_seg, starts.data(), &Sink::rows, &sink);
         } catch (...) { bhh_watchdog_cancel(guard); throw; }
@@ -649,18 +659,21 @@ struct PcmMapping {
     uint32_t fmt = 0;                     // BH_PCM_*
     size_t bps = 0;                       // bytes per sample
     size_t n_frames = 0;
-    ~PcmMapping() { if (base != MAP_FAILED) munmap(base, length); }
+    int fd = -1;                          // kept open: bh_predict_pcm_fd_rows reads the data chunk straight into pinned staging
+    uint64_t data_offset = 0;
+    ~PcmMapping() { if (base != MAP_FAILED) munmap(base, length); if (fd >= 0) ::close(fd); }
     bool open(const bh_decoder &d) {
         fmt = d.fmt == FMT_S16 ? BH_PCM_S16 : d.fmt == FMT_S24 ? BH_PCM_S24 : d.fmt == FMT_S32 ? BH_PCM_S32 : d.fmt == FMT_F32 ? BH_PCM_F32 : 0;
         bps = fmt == BH_PCM_S16 ? 2 : fmt == BH_PCM_S24 ? 3 : 4;
         if (!fmt) return false;            // (8-bit PCM and everything symphonia decodes stay on the host front end)
-        const int fd = ::open(d.path.c_str(), O_RDONLY);
+        fd = ::open(d.path.c_str(), O_RDONLY);
         if (fd < 0) return false;
+        data_offset = d.data_offset;
         length = (size_t)(d.data_offset + d.data_bytes);
         // (no MAP_POPULATE: the minor faults are taken inside the upload workers' copies, eight threads at once; populating
         //  the 70 000 pages of a 1 000-segment file here, on one thread, was slower end to end)
+        // (the mapping costs nothing until it is touched: the route of streams wider than the staging buffer, and of BIRDA_HOST_PREAD=0)
         if (d.data_bytes) base = mmap(nullptr, length, PROT_READ, MAP_PRIVATE, fd, 0);
-        ::close(fd);
         if (d.data_bytes && base == MAP_FAILED) return false;
         if (base != MAP_FAILED) (void)madvise(base, length, MADV_SEQUENTIAL);
         pcm = base != MAP_FAILED ? static_cast<const unsigned char *>(base) + d.data_offset : nullptr;
@@ -826,7 +839,7 @@ extern "C" int bhh_process_file(bh_classifier *clf, const bhh_processing_config 
     std::vector<Detection> detections;
     RunStats st;
     std::string fail_msg;
-    const int fail_code = device ? run_device_front_end(clf, pl, info, ctx, map.pcm, map.fmt, map.bps, map.n_frames, channels, detections, st, fail_msg)
+    const int fail_code = device ? run_device_front_end(clf, pl, info, ctx, map.pcm, map.fmt, map.bps, map.n_frames, channels, detections, st, fail_msg, map.fd, map.data_offset)
                                  : run_host_front_end(clf, pl, info, ctx, detections, st, fail_msg);
     lap("inference");
     ctx_own.reset();

@@ -387,6 +387,15 @@ typedef void (*bh_rows_fn)(void *user, size_t first_segment, size_t n_segments, 
 BH_API int bh_predict_pcm_rows(bh_classifier *c, bh_batch_context *ctx, const void *pcm, uint32_t sample_format, size_t n_frames,
                                uint32_t channels, uint32_t source_rate, size_t overlap_samples, bh_result *out, size_t out_cap,
                                size_t *n_segments, uint64_t *start_samples, bh_rows_fn on_rows, void *user);
+/* bh_predict_pcm_rows on a stream that still lies in a FILE: the `n_frames` frames start at byte `file_offset` of the open descriptor
+ * `fd` (a WAV file's data chunk).  The library's copy workers `pread` the bytes straight into the context's pinned staging buffer --
+ * one copy out of the page cache, no mapping of the file, no page faults -- where bh_predict_pcm_rows on a mapped file copies the
+ * same bytes behind a minor fault per page (70 000 for a 1 000-segment file).  BH_ERR_UNSUPPORTED when one slice of the stream
+ * exceeds the staging buffer (more than two channels of 32-bit samples): map the file and call bh_predict_pcm_rows then.
+ * BH_ERR_IO when the file ends inside the stream.  The descriptor is not closed and its offset is not moved. */
+BH_API int bh_predict_pcm_fd_rows(bh_classifier *c, bh_batch_context *ctx, int fd, uint64_t file_offset, uint32_t sample_format, size_t n_frames,
+                                  uint32_t channels, uint32_t source_rate, size_t overlap_samples, bh_result *out, size_t out_cap,
+                                  size_t *n_segments, uint64_t *start_samples, bh_rows_fn on_rows, void *user);
 /* The same with the segment starts given (frames, not decreasing, each < n_frames; a segment that runs past n_frames is zero
  * padded): several short recordings packed into ONE stream -- each followed by a segment's length of silence, so that its
  * trailing segment pads with zeros as next_segment does (decode.rs:188-196) -- go through one upload and one forward

@@ -159,6 +159,7 @@ extern "C" {
     pub fn bh_predict_pcm(c: *mut BhClassifier, ctx: *mut BhBatchContext, pcm: *const c_void, sample_format: u32, n_frames: usize, channels: u32, source_rate: u32, overlap_samples: usize, out: *mut BhResult, out_cap: usize, n_segments: *mut usize, start_samples: *mut u64) -> c_int;
     pub fn bh_predict_pcm_at(c: *mut BhClassifier, ctx: *mut BhBatchContext, pcm: *const c_void, sample_format: u32, n_frames: usize, channels: u32, source_rate: u32, start_samples: *const u64, n_segments: usize, out: *mut BhResult) -> c_int;
     pub fn bh_predict_pcm_rows(c: *mut BhClassifier, ctx: *mut BhBatchContext, pcm: *const c_void, sample_format: u32, n_frames: usize, channels: u32, source_rate: u32, overlap_samples: usize, out: *mut BhResult, out_cap: usize, n_segments: *mut usize, start_samples: *mut u64, on_rows: bh_rows_fn, user: *mut c_void) -> c_int;
+    pub fn bh_predict_pcm_fd_rows(c: *mut BhClassifier, ctx: *mut BhBatchContext, fd: c_int, file_offset: u64, sample_format: u32, n_frames: usize, channels: u32, source_rate: u32, overlap_samples: usize, out: *mut BhResult, out_cap: usize, n_segments: *mut usize, start_samples: *mut u64, on_rows: bh_rows_fn, user: *mut c_void) -> c_int;
     pub fn bh_predict_pcm16_at(c: *mut BhClassifier, ctx: *mut BhBatchContext, pcm: *const i16, n_frames: usize, channels: u32, source_rate: u32, start_samples: *const u64, n_segments: usize, out: *mut BhResult) -> c_int;
     pub fn bh_resample(c: *mut BhClassifier, in_: *const f32, n_in: usize, from_rate: u32, to_rate: u32, out: *mut f32, out_cap: usize, n_out: *mut usize) -> c_int;
     pub fn bh_resample_output_len(n_in: usize, from_rate: u32, to_rate: u32, n_out: *mut usize) -> c_int;

@@ -317,6 +317,64 @@ def test_c1_wav_to_csv_matches_oracle(full_model, oracle_lib, tmp_path):
     clf.close()
 
 
+def test_file_descriptor_route_gives_the_mapped_routes_rows(clf_tiny, model_dir, tmp_path, monkeypatch):
+    """bh_predict_pcm_fd_rows (round 6): the WAV's data chunk read by `pread` straight into the pinned staging
+    buffer gives, row for row and bit for bit, what bh_predict_pcm_rows gives on the same bytes in memory; a stream that ends
+    before its frames do is BH_ERR_IO; and bhh_process_file writes the same CSV by either route (BIRDA_HOST_PREAD=0: the mapped
+    route of rounds 3-5)."""
+    import ctypes as C
+    from birda_amd import _lib, pipeline, synth
+    path, labels, m, names = model_dir["birdnet_v24_tiny"]
+    L = _lib.load()
+    x = synth.synth_segments(40, m.sample_count, m.sample_rate, start=2).reshape(-1)[: int(118.3 * m.sample_rate)]
+    wav = str(tmp_path / "long.wav")
+    synth.write_wav_pcm16(wav, x, m.sample_rate)
+    raw = open(wav, "rb").read()
+    off = raw.index(b"data") + 8
+    pcm = np.frombuffer(raw[off:], np.int16).copy()
+    n_frames = pcm.size
+    ovl = m.sample_count // 3
+    ctx = clf_tiny.create_batch_context(16)          # several slices: the descriptor route walks the file slice by slice
+    cap = 128
+    def run(fn, *head):
+        out = (_lib.BhResult * cap)()
+        nseg = C.c_size_t()
+        starts = (C.c_uint64 * cap)()
+        rc = fn(clf_tiny._h, ctx._h, *head, 1, n_frames, 1, m.sample_rate, ovl, out, cap, C.byref(nseg), starts, _lib.BhRowsFn(), None)
+        return rc, [(int(starts[i]), out[i].n_pred, list(out[i].index[:out[i].n_pred]), list(out[i].confidence[:out[i].n_pred])) for i in range(nseg.value)]
+    rc_p, rows_p = run(L.bh_predict_pcm_rows, pcm.ctypes.data_as(C.c_void_p))
+    fd = os.open(wav, os.O_RDONLY)
+    try:
+        rc_f, rows_f = run(L.bh_predict_pcm_fd_rows, fd, off)
+        assert rc_p == 0 and rc_f == 0, L.bh_last_error()
+        assert len(rows_f) == len(rows_p) >= 55 and rows_f == rows_p
+        assert os.lseek(fd, 0, os.SEEK_CUR) == 0                       # the descriptor's own offset is not moved
+        # frames promised beyond the end of the file
+        out = (_lib.BhResult * 4096)()
+        nseg = C.c_size_t()
+        rc = L.bh_predict_pcm_fd_rows(clf_tiny._h, ctx._h, fd, off, 1, n_frames + 40 * m.sample_count, 1, m.sample_rate, 0, out, 4096, C.byref(nseg), None, _lib.BhRowsFn(), None)
+        assert rc == -2, (rc, L.bh_last_error())      # BH_ERR_IO
+    finally:
+        os.close(fd)
+    ctx.close()
+    a, b = tmp_path / "by_fd", tmp_path / "mapped"
+    a.mkdir(); b.mkdir()
+    ra = pipeline.process_file(clf_tiny, wav, str(a), min_confidence=0.05, overlap=1.0)
+    assert ra.front_end == "device"
+    import subprocess, sys, textwrap
+    code = textwrap.dedent(f"""
+        import sys
+        sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+        from birda_amd import pipeline
+        from birda_amd.classifier import BirdClassifier
+        clf = BirdClassifier({path!r}, {labels!r}, top_k=5, min_confidence=0.1)
+        r = pipeline.process_file(clf, {wav!r}, {str(b)!r}, min_confidence=0.05, overlap=1.0)
+        assert r.front_end == "device"
+    """)
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, BIRDA_HOST_PREAD="0"), timeout=300)
+    assert open(ra.output_path, "rb").read() == open(os.path.join(str(b), os.path.basename(ra.output_path)), "rb").read()
+
+
 def test_overlap_and_short_file_batching(clf_tiny, model_dir, oracle_lib, tmp_path):
     from birda_amd import pipeline, synth
     path, _, m, names = model_dir["birdnet_v24_tiny"]
