@@ -595,9 +595,12 @@ int run_device_front_end(bh_classifier *clf, const FilePlan &pl, const bh_model_
                          uint32_t fmt, size_t bps, size_t n_frames, uint32_t channels, std::vector<Detection> &detections, RunStats &st,
                          std::string &fail_msg, int fd = -1, uint64_t data_offset = 0) {
     (void)info;
-    // the file's bytes by pread into the pinned staging buffer (round 6) unless BIRDA_HOST_PREAD=0 (A/B aid: the mapped route of rounds 3-5)
-    static const bool pread_off = [] { const char *e = getenv("BIRDA_HOST_PREAD"); return e && e[0] == '0'; }();
-    bool use_fd = fd >= 0 && !pread_off;
+    // BIRDA_HOST_PREAD=1: the file's bytes by pread into the pinned staging buffer (bh_predict_pcm_fd_rows, round 6) instead of a gather
+    // from the mapping.  Built for VERDICT r5 next #8 and measured: no gain -- WAV -> CSV 96.6 / 90.4 k segments/s by descriptor against
+    // 98.0 / 99.3 k mapped (0.63-0.68 against 0.64 of the same run's device-resident rate, profiles/r6_k_pread.txt): as round 5's
+    // MADV_POPULATE_READ probe said, the page faults are not what the file path costs; the inference under it is.  Off by default.
+    static const bool pread_on = [] { const char *e = getenv("BIRDA_HOST_PREAD"); return e && e[0] == '1'; }();
+    bool use_fd = fd >= 0 && pread_on;
     const size_t seg = pl.src_segment_samples, ovl = pl.src_overlap_samples;
     if (ovl >= seg) {   // next_segment's check, decode.rs:156-162
         fail_msg = "overlap_samples (" + std::to_string(ovl) + ") must be less than segment_samples (" + std::to_string(seg) + ")";

@@ -392,7 +392,9 @@ BH_API int bh_predict_pcm_rows(bh_classifier *c, bh_batch_context *ctx, const vo
  * one copy out of the page cache, no mapping of the file, no page faults -- where bh_predict_pcm_rows on a mapped file copies the
  * same bytes behind a minor fault per page (70 000 for a 1 000-segment file).  BH_ERR_UNSUPPORTED when one slice of the stream
  * exceeds the staging buffer (more than two channels of 32-bit samples): map the file and call bh_predict_pcm_rows then.
- * BH_ERR_IO when the file ends inside the stream.  The descriptor is not closed and its offset is not moved. */
+ * BH_ERR_IO when the file ends inside the stream.  The descriptor is not closed and its offset is not moved.  (Measured on the pool's
+ * hosts: no faster than the mapped route end to end -- the inference under the copy is what a file costs; bhh_process_file takes it
+ * with BIRDA_HOST_PREAD=1.) */
 BH_API int bh_predict_pcm_fd_rows(bh_classifier *c, bh_batch_context *ctx, int fd, uint64_t file_offset, uint32_t sample_format, size_t n_frames,
                                   uint32_t channels, uint32_t source_rate, size_t overlap_samples, bh_result *out, size_t out_cap,
                                   size_t *n_segments, uint64_t *start_samples, bh_rows_fn on_rows, void *user);

@@ -468,7 +468,7 @@ def test_environment_names_in_the_shipped_library_are_the_documented_ones():
     names = set(re.findall(r"^BIRDA_[A-Z0-9_]+$", subprocess.run(["strings", "-n", "8", so], capture_output=True, text=True, check=True).stdout, flags=re.M))
     allowed = {"BIRDA_HIP_PRECISION",           # overrides bh_config.flags (birda_hip.h)
                "BIRDA_HIP_COPY_THREADS", "BIRDA_HOST_PIPELINE_DEPTH",   # host-side tuning
-               "BIRDA_HOST_PREAD",              # =0: bhh_process_file hands the WAV over mapped instead of by descriptor (round 6 A/B aid)
+               "BIRDA_HOST_PREAD",              # =1: bhh_process_file hands the WAV over by descriptor (bh_predict_pcm_fd_rows) instead of mapped: measured, no gain
                "BIRDA_HIP_SE_GROUP_MB",         # squeeze-excite blocks in groups of segments (measured and left off: profiles/r6_i_se_groups.txt)
                "BIRDA_INFERENCE_TIMEOUT",       # the reference's own variable (processor.rs:194-211)
                "BIRDA_HIP_ROCTX", "BIRDA_HOST_TIMING",                 # tracing / phase times

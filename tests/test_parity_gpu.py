@@ -320,8 +320,8 @@ def test_c1_wav_to_csv_matches_oracle(full_model, oracle_lib, tmp_path):
 def test_file_descriptor_route_gives_the_mapped_routes_rows(clf_tiny, model_dir, tmp_path, monkeypatch):
     """bh_predict_pcm_fd_rows (round 6): the WAV's data chunk read by `pread` straight into the pinned staging
     buffer gives, row for row and bit for bit, what bh_predict_pcm_rows gives on the same bytes in memory; a stream that ends
-    before its frames do is BH_ERR_IO; and bhh_process_file writes the same CSV by either route (BIRDA_HOST_PREAD=0: the mapped
-    route of rounds 3-5)."""
+    before its frames do is BH_ERR_IO; and bhh_process_file writes the same CSV by either route (BIRDA_HOST_PREAD=1: by descriptor;
+    the default stays the mapped route -- the descriptor route measured no faster, profiles/r6_k_pread.txt)."""
     import ctypes as C
     from birda_amd import _lib, pipeline, synth
     path, labels, m, names = model_dir["birdnet_v24_tiny"]
@@ -357,7 +357,7 @@ def test_file_descriptor_route_gives_the_mapped_routes_rows(clf_tiny, model_dir,
     finally:
         os.close(fd)
     ctx.close()
-    a, b = tmp_path / "by_fd", tmp_path / "mapped"
+    a, b = tmp_path / "mapped", tmp_path / "by_fd"
     a.mkdir(); b.mkdir()
     ra = pipeline.process_file(clf_tiny, wav, str(a), min_confidence=0.05, overlap=1.0)
     assert ra.front_end == "device"
@@ -371,7 +371,7 @@ def test_file_descriptor_route_gives_the_mapped_routes_rows(clf_tiny, model_dir,
         r = pipeline.process_file(clf, {wav!r}, {str(b)!r}, min_confidence=0.05, overlap=1.0)
         assert r.front_end == "device"
     """)
-    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, BIRDA_HOST_PREAD="0"), timeout=300)
+    subprocess.run([sys.executable, "-c", code], check=True, env=dict(os.environ, BIRDA_HOST_PREAD="1"), timeout=300)
     assert open(ra.output_path, "rb").read() == open(os.path.join(str(b), os.path.basename(ra.output_path)), "rb").read()
 
 
