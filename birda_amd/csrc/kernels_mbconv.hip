@@ -1,6 +1,7 @@
 // Planner of the fused inverted-residual (MBConv) blocks: picks, per block, one of the tile configurations of mbconv_cfgs.inc
 // (the kernel itself is mbconv_kernel.hpp, instantiated per activation in kernels_mbconv_gelu.hip / _swish.hip / _relu6.hip).
 #include <algorithm>
+#include <vector>
 #include <cstdio>
 #include <cstdlib>
 
@@ -16,12 +17,20 @@ namespace {
 constexpr int kActs[] = {ACT_GELU_ERF, ACT_SWISH, ACT_RELU6};
 constexpr int kNActs = (int)(sizeof(kActs) / sizeof(kActs[0]));
 struct CfgTables {
-    const MbCfg *t[kNActs];
+    std::vector<MbCfg> t[kNActs];     // (each activation's list, put together from its three translation units)
     int n_base;
     CfgTables() {
-        int n[kNActs];
-        t[0] = mb_table_gelu(&n[0]); t[1] = mb_table_swish(&n[1]); t[2] = mb_table_relu6(&n[2]);
-        n_base = (n[0] == n[1] && n[1] == n[2]) ? n[0] : 0;   // the three copies are the same list
+        typedef const MbCfg *(*Part)(int *);
+        static const Part parts[kNActs][3] = {{mb_table_gelu_p0, mb_table_gelu_p1, mb_table_gelu_p2},
+                                              {mb_table_swish_p0, mb_table_swish_p1, mb_table_swish_p2},
+                                              {mb_table_relu6_p0, mb_table_relu6_p1, mb_table_relu6_p2}};
+        for (int a = 0; a < kNActs; a++)
+            for (int k = 0; k < 3; k++) {
+                int n = 0;
+                const MbCfg *p = parts[a][k](&n);
+                t[a].insert(t[a].end(), p, p + n);
+            }
+        n_base = (t[0].size() == t[1].size() && t[1].size() == t[2].size()) ? (int)t[0].size() : 0;   // the three copies are the same list
     }
     const MbCfg &operator[](int ci) const { return t[ci / n_base][ci % n_base]; }
 };

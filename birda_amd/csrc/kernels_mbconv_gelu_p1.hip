@@ -1,4 +1,4 @@
-// The fused MBConv kernel's tile configurations (mbconv_cfgs.inc, part 0 of 3) instantiated for ONE activation: ACT_RELU6,
+// The fused MBConv kernel's tile configurations (mbconv_cfgs.inc, part 1 of 3) instantiated for ONE activation: ACT_GELU_ERF,
 // every entry a second time as pass A of a squeeze-excite block (MB_WITH_SE, mbconv_kernel.hpp SE = 1: swish since round 5 --
 // EfficientNet's, Perch v2's backbone -- GELU and ReLU6 since round 6).
 #define MB_WITH_SE 1
@@ -7,8 +7,8 @@
 namespace bh {
 
 namespace {
-#define MB_A ACT_RELU6
-#define MB_PART 0
+#define MB_A ACT_GELU_ERF
+#define MB_PART 1
 const MbCfg kTable[] = {
 #include "mbconv_cfgs.inc"
 };
@@ -16,7 +16,7 @@ const MbCfg kTable[] = {
 #undef MB_A
 }  // namespace
 
-const MbCfg *mb_table_relu6_p0(int *n) {
+const MbCfg *mb_table_gelu_p1(int *n) {
     if (n) *n = (int)(sizeof(kTable) / sizeof(kTable[0]));
     return kTable;
 }

@@ -1,6 +1,6 @@
-// The fused MBConv kernel's tile configurations (mbconv_cfgs.inc) instantiated for ONE activation: ACT_SWISH.
-// ... and, swish being the activation of the stacks that carry squeeze-excite gates (EfficientNet: Perch v2's backbone), every
-// entry a second time as pass A of such a block (MB_WITH_SE, mbconv_kernel.hpp SE = 1).
+// The fused MBConv kernel's tile configurations (mbconv_cfgs.inc, part 0 of 3) instantiated for ONE activation: ACT_SWISH,
+// every entry a second time as pass A of a squeeze-excite block (MB_WITH_SE, mbconv_kernel.hpp SE = 1: swish since round 5 --
+// EfficientNet's, Perch v2's backbone -- GELU and ReLU6 since round 6).
 #define MB_WITH_SE 1
 #include "mbconv_kernel.hpp"
 
@@ -8,13 +8,15 @@ namespace bh {
 
 namespace {
 #define MB_A ACT_SWISH
+#define MB_PART 0
 const MbCfg kTable[] = {
 #include "mbconv_cfgs.inc"
 };
+#undef MB_PART
 #undef MB_A
 }  // namespace
 
-const MbCfg *mb_table_swish(int *n) {
+const MbCfg *mb_table_swish_p0(int *n) {
     if (n) *n = (int)(sizeof(kTable) / sizeof(kTable[0]));
     return kTable;
 }

@@ -14,8 +14,9 @@ struct MbCfg {
     void (*launch_se)(const MbDesc &, int, hipStream_t);   // pass A of a squeeze-excite block (MbDesc::se); nullptr: not instantiated for this activation / entry
 };
 
-const MbCfg *mb_table_gelu(int *n);
-const MbCfg *mb_table_swish(int *n);
-const MbCfg *mb_table_relu6(int *n);
+// (three parts of the list per activation, one translation unit each: kernels_mbconv_<act>[_p1 | _p2].hip)
+#define BH_MB_TABLE_DECL(act) const MbCfg *mb_table_##act##_p0(int *n); const MbCfg *mb_table_##act##_p1(int *n); const MbCfg *mb_table_##act##_p2(int *n);
+BH_MB_TABLE_DECL(gelu) BH_MB_TABLE_DECL(swish) BH_MB_TABLE_DECL(relu6)
+#undef BH_MB_TABLE_DECL
 
 }  // namespace bh
