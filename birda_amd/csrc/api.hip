@@ -239,7 +239,7 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
                 // hold (0: never); blocks whose whole D fits run as before.
                 {
                     const size_t d_seg_bytes = (size_t)d.Ho * d.Wo * d.Cexp * sizeof(float);
-                    size_t grp = (!d.noexp && c->se_group_bytes && d_seg_bytes * n > c->se_group_bytes) ? std::max<size_t>(c->se_group_bytes / d_seg_bytes, 16) : n;
+                    size_t grp = (!d.noexp && !d.stem && c->se_group_bytes && d_seg_bytes * n > c->se_group_bytes) ? std::max<size_t>(c->se_group_bytes / d_seg_bytes, 16) : n;
                     if (grp < n) grp -= grp % (size_t)std::max(d.S, 1);     // (whole S-segment workgroups per group)
                     if (grp < n) {
                         const size_t P = (size_t)d.Ho * d.Wo, tiles = (size_t)d.tiles_x * d.tiles_y;
@@ -283,7 +283,12 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
                 d.X = in;
                 // (a block without an expand convolution computes D twice instead of keeping it: pass A leaves only the channel sums,
                 //  the gated one-launch block below does the rest -- kernels.hpp MbDesc::gate)
-                const bool recompute = d.noexp != 0;
+                // (round 6: the same for the STEM block -- its input, the planar spectrogram, is a tenth of its D -- was built (the stem
+                //  instantiations take MbDesc::gate) and measured on the Perch-sized plan: 38.75 -> 38.45 k segments/s, three alternations
+                //  on one box at one clock, profiles/r6_n_stem_recompute.txt: the sums-only pass costs more than D's round trip saves.
+                //  Not taken; BIRDA_HIP_SE_STEM_RECOMPUTE=1 in the EXPERIMENTS build.)
+                static const bool stem_recompute = [] { const char *e = BH_XENV("BIRDA_HIP_SE_STEM_RECOMPUTE"); return e && e[0] == '1'; }();
+                const bool recompute = d.noexp != 0 || (d.stem != 0 && stem_recompute);
                 d.Dout = recompute ? nullptr : T(S.iD + 1);
                 d.pool_part = T(S.iScale + 1);
                 d.gate = nullptr;

@@ -694,6 +694,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
             // epilogue would have written.
             static_assert(KG != 0 || NCS == 1, "no-expand blocks: no column split");
             static_assert(KG != 0 || COLTH == 0, "no-expand blocks: row tasks (the gate of MbDesc::gate is applied in the row-task depthwise phase only)");
+            static_assert(STEM == 0 || COLTH == 0, "stem blocks: row tasks (they take MbDesc::gate too)");
             float4 xv[RT_W][NT_E];
 #pragma unroll
             for (int i = 0; i < RT_W; i++)
@@ -998,7 +999,9 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                 const float *eb = Es + p2_eoff;
                 const float4 bd4 = *reinterpret_cast<const float4 *>(&bds[4 * c4]);
                 f32x2 gq0 = (f32x2){1.f, 1.f}, gq1 = gq0;     // (KG = 0, se = 0, gate: the squeeze-excite gate of a no-expand block, MbDesc::gate)
-                if constexpr (KG == 0 && !SE) {
+                // (round 6: the STEM block takes the gate here too -- its D, 40 channels at the stem's output size, is ten times its input, the
+                //  planar spectrogram: cheaper computed twice than kept, like the no-expand blocks)
+                if constexpr ((KG == 0 || STEM != 0) && !SE) {
                     if (d.gate) {
                         const int sl = (SS > 1 && p2_prow >= THTW) ? 1 : 0, cgq = ch * CE + 4 * c4;
                         const float4 gv = *reinterpret_cast<const float4 *>(d.gate + (size_t)min(seg0 + sl, n_seg - 1) * d.Cexp + min(cgq, d.Cexp - 4));
@@ -1031,7 +1034,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                 for (int x = 0; x < XB; x++) {
                     f32x2 g0 = acc[x][0], g1 = acc[x][1];
                     mb_act4<ACT, PREC>(g0, g1);
-                    if constexpr (KG == 0 && !SE) { g0 *= gq0; g1 *= gq1; }
+                    if constexpr ((KG == 0 || STEM != 0) && !SE) { g0 *= gq0; g1 *= gq1; }
                     const float4 v = make_float4(g0[0], g0[1], g1[0], g1[1]);
                     const int prow = p2_prow + x;
                     if constexpr (PREC != 0 && !SE) {   // the project GEMM's A operand: f16 hi (+ lo) planes
