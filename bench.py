@@ -982,6 +982,7 @@ def main():
     ctx.close()
     clf.close()
     if extra and args.config == "c2":
+        out["small_calls"] = small_calls_leg(model_path, args.precision)
         out["value_c4"] = c4_child_leg(args.precision)      # (after this process has let go of its contexts)
     if world > 1:
         dist.barrier()
@@ -1106,6 +1107,54 @@ def bench_inproc_multi(args, m, model_path, tmp, devices, n_total, scaling, work
     print(json.dumps(out), flush=True)
 
 
+def child_latency(argv):
+    """`bench.py --child-latency model precision`: what a SMALL call lasts (forward_device + synchronise, device-resident input, median of
+    30) for 1 / 8 / 20 / 32 segments -- a one-minute file is 20 -- with the library's default flags and with BH_FLAG_LOW_LATENCY
+    (late blocks split over their expanded channels, VERDICT r5 next #5), in a process of its own."""
+    import numpy as np
+    import torch
+    from birda_amd import modelfile as mf, synth
+    from birda_amd.classifier import BirdClassifier
+    model_path, precision = argv[0], argv[1]
+    m = mf.read_model(model_path)
+    base = synth.synth_segments(16, m.sample_count, m.sample_rate)
+    res = {}
+    for ll in (False, True):
+        clf = BirdClassifier(model_path, None, precision=precision, low_latency=ll)
+        for n in (1, 8, 20, 32):
+            ctx = clf.create_batch_context(n)
+            x = torch.from_numpy(np.ascontiguousarray(np.tile(base, (n // 16 + 1, 1))[:n])).cuda()
+            logits = torch.empty((n, m.n_classes), device="cuda")
+            idx = torch.empty((n, 5), dtype=torch.int32, device="cuda")
+            conf = torch.empty((n, 5), device="cuda")
+            ts = []
+            for it in range(36):
+                t = time.perf_counter()
+                clf.forward_device(ctx, x.data_ptr(), n, logits.data_ptr(), idx.data_ptr(), conf.data_ptr())
+                ctx.synchronize()
+                if it >= 6:
+                    ts.append(time.perf_counter() - t)
+            res.setdefault(str(n), {})["low_latency" if ll else "default"] = round(statistics.median(ts) * 1e3, 3)
+            ctx.close()
+        clf.close()
+    print(json.dumps({"unit": "ms per call (forward_device + synchronise, median of 30)", "segments": res,
+                      "note": "BH_FLAG_LOW_LATENCY: forwards of at most 32 segments split the late blocks' expanded channels over 2-8 workgroups each "
+                              "(fixed-order partial sums: a rounding of its own, launch-invariant within the regime)"}))
+
+
+def small_calls_leg(model_path, precision):
+    import subprocess
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child-latency", model_path, precision if precision in ("auto", "f16x3", "f32", "f16") else "auto"],
+                           capture_output=True, text=True, timeout=180)
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        d["wall_s"] = round(time.perf_counter() - t0, 1)
+        return d
+    except Exception as e:   # noqa: BLE001
+        return {"error": str(e)[:200]}
+
+
 def child_files(argv):
     """`bench.py --child-files model labels precision out_dir wav...`: the files_pipelined leg in a process of its own (no torch)."""
     model_path, labels, precision, out_dir, wavs = argv[0], argv[1], argv[2], argv[3], argv[4:]
@@ -1127,5 +1176,7 @@ def child_files(argv):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "--child-files":
         child_files(sys.argv[2:])
+    elif len(sys.argv) > 1 and sys.argv[1] == "--child-latency":
+        child_latency(sys.argv[2:])
     else:
         main()

@@ -133,10 +133,10 @@ PRECISION_FLAGS = {"auto": 0, "f16x3": 1, "f16": 2, "f32": 3}
 
 class BirdClassifier:
     def __init__(self, model_path: str, labels_path: Optional[str] = None, top_k: int = DEFAULT_TOP_K,
-                 min_confidence: float = DEFAULT_MIN_CONFIDENCE, device: int = 0, precision: str = "auto"):
+                 min_confidence: float = DEFAULT_MIN_CONFIDENCE, device: int = 0, precision: str = "auto", low_latency: bool = False):
         self._L = _lib.load()
         self._keep = (model_path.encode(), labels_path.encode() if labels_path else None)
-        flags = PRECISION_FLAGS[precision]   # BH_FLAG_* (include/birda_hip.h)
+        flags = PRECISION_FLAGS[precision] | (0x10 if low_latency else 0)   # BH_FLAG_* (include/birda_hip.h); 0x10 = BH_FLAG_LOW_LATENCY
         cfg = BhConfig(self._keep[0], self._keep[1], top_k, min_confidence, device, flags)
         h = C.c_void_p()
         check(self._L.bh_classifier_create(C.byref(cfg), C.byref(h)))

@@ -174,7 +174,7 @@ void ctx_destroy(bh_batch_context *ctx) {
     (void)hipFree(ctx->d_logits); (void)hipFree(ctx->d_topk_idx); (void)hipFree(ctx->d_topk_conf);
     (void)hipHostFree(ctx->h_input); (void)hipHostFree(ctx->h_topk_idx); (void)hipHostFree(ctx->h_topk_conf);
     (void)hipFree(ctx->d_raw); (void)hipHostFree(ctx->h_raw);
-    (void)hipFree(ctx->d_pcm); (void)hipFree(ctx->d_starts);
+    (void)hipFree(ctx->d_pcm); (void)hipFree(ctx->d_starts); (void)hipFree(ctx->d_partial);
     (void)hipFree(ctx->d_nonfinite); (void)hipHostFree(ctx->h_nonfinite);
     if (ctx->stream && own_streams) (void)hipStreamDestroy(ctx->stream);
     if (!own_streams) { std::lock_guard<std::mutex> g(ctx->c->stream_mu); ctx->c->stream_sets[ctx->stream_set].used = false; }
@@ -186,6 +186,14 @@ void ctx_destroy(bh_batch_context *ctx) {
 //  and its first segment's index within the slice, which places its rows of the per-segment scratch; nullptr: the context's stream
 //  and whole arena)
 struct SliceLane { hipStream_t s; float *arena; const size_t *t_off; size_t seg0; };
+// BH_FLAG_LOW_LATENCY: launches of up to this many segments split a late block's expanded channels over workgroups, 2 deep from 8
+// chunks, 4 deep from 16, 8 deep from 32 (fused blocks without a gate: pass A of a squeeze-excite block has no project sums to split)
+constexpr size_t kLowLatencyMaxSegments = 32;
+static inline int mb_ksplit_of(const bh::MbDesc &d) {
+    static const int cap = [] { const char *e = getenv("BIRDA_HIP_KSPLIT_MAX"); return e ? atoi(e) : 8; }();     // (tuning aid)
+    const int k = (d.se || d.Cout % 4) ? 1 : d.nchunks >= 32 ? 8 : d.nchunks >= 16 ? 4 : d.nchunks >= 8 ? 2 : 1;
+    return std::min(k, std::max(cap, 1));
+}
 int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, size_t n, float *d_logits,
                   int32_t *d_idx, float *d_conf, const SliceLane *lane = nullptr) {
     const auto &m = c->model;
@@ -334,6 +342,22 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
             d.X = in;
             d.Y = (ip == nl - 1) ? d_logits : T(ip + 1);
             d.R = LP.res_tensor != bh::NO_TENSOR ? T(LP.res_tensor) : nullptr;
+            // BH_FLAG_LOW_LATENCY, a launch of at most 32 segments on the context's own stream: a block of many chunks runs 2 or 4
+            // workgroups deep, each walking its share of the expanded channels (kernels.hpp MbDesc::ksplit) -- a handful of
+            // workgroups on the whole chip each streaming ALL of a late block's weights is what such a forward lasts.  The depth is
+            // the block's alone (never the launch's), so within the regime a segment's bits still do not depend on its launch.
+            const int ksp = (c->low_latency && !lane && n <= kLowLatencyMaxSegments) ? mb_ksplit_of(d) : 1;
+            if (ksp > 1) {
+                if (!ctx->d_partial) {
+                    size_t need = 0;
+                    for (const auto &b : c->mb) need = std::max(need, (size_t)mb_ksplit_of(b) * kLowLatencyMaxSegments * b.Ho * b.Wo * b.Cout);
+                    HIPCHK(hipMalloc((void **)&ctx->d_partial, std::max<size_t>(need, 4) * sizeof(float)));
+                }
+                d.ksplit = ksp;
+                d.partial = ctx->d_partial;
+                bh::launch_mbconv(d, (int)n, s);
+                bh::launch_mb_reduce_partials(ctx->d_partial, d.Y, ksp, n * (size_t)d.Ho * d.Wo * d.Cout, d.prec != 0 ? d.p_unscale : 1.0f, s);
+            } else
             bh::launch_mbconv(d, (int)n, s);
             ctx_mark(ctx, ST_MBCONV, (int)i);
             i = ip;
@@ -926,6 +950,7 @@ int bh_classifier_create(const bh_config *cfg, bh_classifier **out) try {
         const uint32_t pf = cfg->flags & BH_FLAG_PRECISION_MASK;
         c->precision = pf == BH_FLAG_F32 ? 0 : pf == BH_FLAG_F16 ? 1 : 3;
         c->auto_fallback = pf == BH_FLAG_AUTO;
+        c->low_latency = (cfg->flags & BH_FLAG_LOW_LATENCY) != 0;
         c->model_path = cfg->model_path;
     }
     if (const char *pe = (cfg->flags & FLAG_INTERNAL_NO_ENV) ? nullptr : getenv("BIRDA_HIP_PRECISION")) {

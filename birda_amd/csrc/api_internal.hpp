@@ -83,6 +83,7 @@ struct bh_classifier {
     // squeeze-excite blocks: the D one group of segments may hold between pass A and the gated project GEMM (api.hip forward_slice);
     // 0 = whole launches (round 5).  Measured: profiles/r6_i_se_groups.txt
     size_t se_group_bytes = 0;
+    bool low_latency = false;                // BH_FLAG_LOW_LATENCY (birda_hip.h)
     int narrow_max_workgroups = 256;         // launches whose narrow tiles number at most this take them: one workgroup a CU at most (round 5, swept
                                              // per layer at 32 .. 256 segments, profiles/r5_g_narrow_tiles_sweep.txt: beyond, every extra workgroup streams
                                              // the block's 2 MB of weights again -- at 512 a launch of 160-256 segments lost 3-4 %)
@@ -214,6 +215,7 @@ struct bh_batch_context {
     int16_t *d_pcm = nullptr;    // bh_predict_pcm16: the slice's span of the decoded stream (grow-only)
     size_t pcm_cap = 0;          // bytes
     unsigned long long *d_starts = nullptr;
+    float *d_partial = nullptr;              // BH_FLAG_LOW_LATENCY: the channel-split blocks' partial project sums (allocated on first use)
     size_t starts_cap = 0;       // entries
     float *d_raw = nullptr;      // source-rate segments awaiting the resampler [max_batch][raw_len]
     float *h_raw = nullptr;

@@ -498,7 +498,14 @@ struct MbDesc {
     // and the one-launch block (se = 0) takes gate != nullptr -- [n][Cexp], multiplied into the depthwise output in front of the
     // project phase's f16 split, where the gated GEMMs apply it too.  D never exists (api.hip forward_slice).
     const float *gate;
+    // Channel split for launches of a few segments (round 6, BH_FLAG_LOW_LATENCY): ksplit > 1 runs the launch ksplit workgroups deep,
+    // each walking 1 / ksplit of the chunks and leaving raw project accumulators in partial [ksplit][n][Ho Wo][Cout]; the caller
+    // follows with mb_reduce_partials (parts added in index order, then x p_unscale): a rounding of its own, fixed for the regime.
+    int ksplit;
+    float *partial;
 };
+// Y[i] = (partial[0][i] + partial[1][i] + ...) * unscale, parts in index order
+void launch_mb_reduce_partials(const float *partial, float *Y, int ksplit, size_t count, float unscale, hipStream_t s);
 int mb_config_count();
 int mb_config_name(int ci, char *out, size_t cap);
 // picks the instantiation (force_cfg >= 0: that entry or fail) and fills the derived fields

@@ -300,6 +300,81 @@ __global__ __launch_bounds__(256) void pw_gemm16_kernel(const float *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------
+// The same GEMM for a handful of rows (M <= 16: the dense layer of a forward of one to sixteen segments; round 6).  With one row
+// tile there is nothing to share and almost nothing to compute: the layer is its weights streamed once (26.7 MB for the 1 024 ->
+// 6 522 head), and pw_gemm16_kernel, one 32-deep step ahead on 51 workgroups, waited a memory round trip per step -- 32 of them,
+// 35 us, for a launch that moves its bytes in 5.  Here a wave owns TWO column tiles and keeps EIGHT steps of their fragments in
+// flight (128 registers), four waves a workgroup, ceil(n_tiles / 8) workgroups.  Per element the same products in the same order
+// as the other two kernels: the same bits.
+// ---------------------------------------------------------------------------------------
+template <int TERMS, int ACT>
+__global__ __launch_bounds__(256) void pw_gemm16_skinny_kernel(const float *__restrict__ A, const f16x8 *__restrict__ Wf,
+                                                                const float *__restrict__ bias, const float *__restrict__ R,
+                                                                float *__restrict__ C, int M, int K, int N, int n_tiles, float w_unscale) {
+    constexpr int PF = 8, NT = 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kq = lane >> 4;
+    const int t0 = ((int)blockIdx.x * 4 + wave) * NT;
+    if (t0 >= n_tiles) return;
+    const int steps = K / 32;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float *arow = A + (size_t)min(li, M - 1) * K + 8 * kq;   // rows past M: clamped, never stored
+    float4 ra[PF][2];
+    f16x8 bh[PF][NT], bl[PF][NT];
+    auto load = [&](int st, float4 (&a)[2], f16x8 (&h)[NT], f16x8 (&l)[NT]) {
+        a[0] = *reinterpret_cast<const float4 *>(arow + 32 * st);
+        a[1] = *reinterpret_cast<const float4 *>(arow + 32 * st + 4);
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const int t = min(t0 + j, n_tiles - 1);
+            h[j] = Wf[(((size_t)st * n_tiles + t) * 2 + 0) * 64 + lane];
+            if (TERMS == 3) l[j] = Wf[(((size_t)st * n_tiles + t) * 2 + 1) * 64 + lane];
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < PF; u++)
+        if (u < steps) load(u, ra[u], bh[u], bl[u]);
+    for (int st0 = 0; st0 < steps; st0 += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int st = st0 + u;
+            if (st < steps) {       // (wave-uniform)
+                const float v[8] = {ra[u][0].x, ra[u][0].y, ra[u][0].z, ra[u][0].w, ra[u][1].x, ra[u][1].y, ra[u][1].z, ra[u][1].w};
+                f16x8 ah, al;
+                bh_split8(v, ah, al);
+#pragma unroll
+                for (int j = 0; j < NT; j++) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[u][j], acc[j], 0, 0, 0);
+                    if (TERMS == 3) {
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[u][j], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[u][j], acc[j], 0, 0, 0);
+                    }
+                }
+                if (st + PF < steps) load(st + PF, ra[u], bh[u], bl[u]);   // (the slot's registers have been read)
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+        const int col = (t0 + j) * 16 + li;
+        if (col >= N) continue;
+        const float bv = bias[col];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = kq * 4 + r;
+            if (row < M) {
+                float v = __builtin_fmaf(acc[j][r], w_unscale, bv);
+                v = bh_act<ACT>(v);
+                if (R) v += R[(size_t)row * N + col];
+                C[(size_t)row * N + col] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // The same GEMM with both operands staged through LDS (round 4).  pw_gemm16_kernel streams every wave's operand fragments
 // straight from L2: 16 KB per wave and 32-deep step for 48 MFMAs, 58 B/clk per CU with two workgroups resident -- the fabric
 // delivers about that much and no more, so the matrix pipe idled at ~20 % (the Perch-sized model's dense pair: 1.07 us per
@@ -939,6 +1014,10 @@ void launch_pw_gemm16(const float *A, const void *Wf, const float *bias, const f
             static DeviceOnce attr;                                                                                               \
             attr.run([] { (void)hipFuncSetAttribute((const void *)pw_gemm16s_kernel<T, ACTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStagedLds); }); \
             hipLaunchKernelGGL((pw_gemm16s_kernel<T, ACTV>), grid, block, kStagedLds, s, A, (const f16x8 *)Wf, bias, R, C, M, K, N, n_tiles, w_unscale); \
+        } else if (M <= 32) {    /* one or two row tiles: the skinny kernel per row tile, eight steps in flight (the same bits) */ \
+            for (int m0 = 0; m0 < M; m0 += 16)                                                                                    \
+                hipLaunchKernelGGL((pw_gemm16_skinny_kernel<T, ACTV>), dim3((unsigned)((n_tiles + 7) / 8)), block, 0, s, A + (size_t)m0 * K, (const f16x8 *)Wf, bias, \
+                                   R ? R + (size_t)m0 * N : nullptr, C + (size_t)m0 * N, std::min(16, M - m0), K, N, n_tiles, w_unscale); \
         } else {                                                                                                                  \
             hipLaunchKernelGGL((pw_gemm16_kernel<T, ACTV>), grid, block, 0, s, A, (const f16x8 *)Wf, bias, R, C, M, K, N, n_tiles, w_unscale); \
         }                                                                                                                         \
@@ -971,11 +1050,14 @@ void launch_pw_gemm16(const float *A, const void *Wf, const float *bias, const f
 // Blocks that share their rows of X are placed on the same XCD (blockIdx % 8) back to back, so X is
 // fetched from HBM once and re-read from that XCD's L2 by the other column blocks.
 // ---------------------------------------------------------------------------------------
-template <int PT, int SW, int TERMS, int ACT>
+// CT: column tiles a workgroup owns -- 8 (128 output channels), or 2 for launches of a few segments (round 6): the grid is then four
+// times as wide and a workgroup's per-step work a quarter, which is what a launch that cannot fill the chip lasts (35 -> ~15 us for
+// one segment).  The same products in the same order either way.
+template <int PT, int SW, int TERMS, int ACT, int CT = 8>
 __global__ __launch_bounds__(256, 1) void head_gap16_kernel(const float *__restrict__ A, const f16x8 *__restrict__ Wf,
                                                              const float *__restrict__ bias, float *__restrict__ out,
                                                              int n_seg, int P, int K, int N, int n_tiles, int n_cb, float w_unscale) {
-    constexpr int RT = PT * SW, CT = 8;
+    constexpr int RT = PT * SW;
     __shared__ __attribute__((aligned(16))) f16x8 Bs[2][CT * 2 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
@@ -989,8 +1071,9 @@ __global__ __launch_bounds__(256, 1) void head_gap16_kernel(const float *__restr
     auto dma = [&](int st, int buf) {
         const f16x8 *src = Wf + ((size_t)st * n_tiles + cb * CT) * 2 * 64;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < (CT * 2 + 3) / 4; q++) {
             const int piece = q * 4 + wave;
+            if (piece >= CT * 2) continue;     // (CT = 2: one piece a wave)
             const unsigned la = (unsigned)(size_t)(&Bs[buf][piece * 64]);
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
                          :: "v"(src + piece * 64 + lane), "s"(__builtin_amdgcn_readfirstlane(la)) : "memory", "m0");
@@ -1093,12 +1176,15 @@ bool head_gap16_supports(int P, int K, int N, int act) {
 
 void launch_head_gap16(const float *A, const void *Wf, const float *bias, float *out, int n_seg, int P, int K, int N,
                        int act, int terms, float w_unscale, hipStream_t s) {
-    const int n_tiles = N / 16, n_cb = N / 128;
+    const bool few = n_seg <= 32;      // (a launch that leaves most of the chip idle: two column tiles a workgroup, four times the workgroups)
+    const int n_tiles = N / 16, n_cb = few ? N / 32 : N / 128;
     const int pt = (P + 15) / 16, sw = pt <= 3 ? 2 : 1;
     const int n_mb = (n_seg + 4 * sw - 1) / (4 * sw);
     dim3 grid((unsigned)(((n_mb + 7) / 8) * n_cb * 8)), block(256);
-#define BH_HG(PTV, SWV, T, ACTV) hipLaunchKernelGGL((head_gap16_kernel<PTV, SWV, T, ACTV>), grid, block, 0, s, A, (const f16x8 *)Wf, bias, out, \
-                                                    n_seg, P, K, N, n_tiles, n_cb, w_unscale)
+#define BH_HG(PTV, SWV, T, ACTV) do { if (few) hipLaunchKernelGGL((head_gap16_kernel<PTV, SWV, T, ACTV, 2>), grid, block, 0, s, A, (const f16x8 *)Wf, bias, out, \
+                                                    n_seg, P, K, N, n_tiles, n_cb, w_unscale); \
+    else hipLaunchKernelGGL((head_gap16_kernel<PTV, SWV, T, ACTV, 8>), grid, block, 0, s, A, (const f16x8 *)Wf, bias, out, \
+                                                    n_seg, P, K, N, n_tiles, n_cb, w_unscale); } while (0)
 #define BH_HGA(PTV, SWV, T)                                          \
     switch (act) {                                                   \
     case ACT_SWISH: BH_HG(PTV, SWV, T, ACT_SWISH); break;            \
@@ -1376,7 +1462,18 @@ __global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ log
     const float *lg = logits + (size_t)seg * n_classes;
     float m = -INFINITY;
     bool bad = false;   // an inf / NaN logit
-    for (int i = tid; i < n_classes; i += 256) { const float v = lg[i]; row[i] = v; m = fmaxf(m, v); bad |= !(fabsf(v) <= 3.4028235e38f); }
+    // (eight loads in flight a thread: one at a time, each waiting for its own round trip, was 13 of the kernel's 27 us on a single
+    //  row -- a forward of one segment is 0.42 ms in all)
+    for (int i0 = tid; i0 < n_classes; i0 += 8 * 256) {
+        float v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v8[u] = lg[min(i0 + u * 256, n_classes - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int i = i0 + u * 256;
+            if (i < n_classes) { const float v = v8[u]; row[i] = v; m = fmaxf(m, v); bad |= !(fabsf(v) <= 3.4028235e38f); }
+        }
+    }
     const int any_bad = __syncthreads_or(bad ? 1 : 0);
     bool mark = false;   // (thread 0) this row is counted: it leaves with index -2 in its first slot (BH_TOPK_NONFINITE, birda_hip.h)
     if (nonfinite && any_bad && tid == 0) {
@@ -1400,6 +1497,7 @@ __global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ log
         // orders differ by ~1e-7 relative, far inside the confidence tolerance -- and a single lane walking 14 795 classes was
         // 1.8 us per segment of the Perch-shaped model, an eighth of its whole forward.)
         float sacc = 0.f;
+#pragma unroll 4
         for (int i = tid; i < n_classes; i += 256) sacc += expf(row[i] - mx);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 64);
@@ -1415,10 +1513,17 @@ __global__ __launch_bounds__(256) void topk_kernel(const float *__restrict__ log
     for (int k = 0; k < top_k; k++) {
         float bv = -INFINITY; int bi = -1;
         if (!stop) {
-            for (int i = tid; i < n_classes; i += 256) {
-                const float v = row[i];
-                if (v != v) continue;          // NaN logit, or a class already chosen
-                if (bi < 0 || v > bv) { bv = v; bi = i; }   // ascending i: ties keep the lower index
+            for (int i0 = tid; i0 < n_classes; i0 += 8 * 256) {     // (eight LDS reads in flight, then the comparisons in index order)
+                float v8[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) v8[u] = row[min(i0 + u * 256, n_classes - 1)];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int i = i0 + u * 256;
+                    const float v = v8[u];
+                    if (i >= n_classes || v != v) continue;          // NaN logit, or a class already chosen
+                    if (bi < 0 || v > bv) { bv = v; bi = i; }   // ascending i: ties keep the lower index
+                }
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) topk_better(bv, bi, __shfl_xor(bv, o, 64), __shfl_xor(bi, o, 64));

@@ -325,6 +325,22 @@ bool mb_plan_narrow(const MbDesc &d, MbDesc &narrow) {
     return best_twl != 99;
 }
 
+__global__ __launch_bounds__(256) void mb_reduce_partials_kernel(const float4 *__restrict__ partial, float4 *__restrict__ Y, int ksplit, size_t count4, float unscale) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count4) return;
+    float4 a = partial[i];
+    for (int k = 1; k < ksplit; k++) {      // (index order: the regime's one summation order)
+        const float4 b = partial[(size_t)k * count4 + i];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    Y[i] = make_float4(a.x * unscale, a.y * unscale, a.z * unscale, a.w * unscale);
+}
+
+void launch_mb_reduce_partials(const float *partial, float *Y, int ksplit, size_t count, float unscale, hipStream_t s) {
+    const size_t count4 = count / 4;      // (Cout % 4 == 0: every fused block's width is)
+    hipLaunchKernelGGL(mb_reduce_partials_kernel, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, s, (const float4 *)partial, (float4 *)Y, ksplit, count4, unscale);
+}
+
 void launch_mbconv(const MbDesc &d, int n_seg, hipStream_t s) {
     if (d.se) kCfgs[d.cfg].launch_se(d, n_seg, s);
     else kCfgs[d.cfg].launch(d, n_seg, s);

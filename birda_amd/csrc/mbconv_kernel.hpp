@@ -285,6 +285,17 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
     // sectors at the rectangle's edges -- land on DIFFERENT XCDs and every shared sector is fetched from HBM once per XCD (stem
     // block: 832 MB read per 1 000 segments against 392 MB of input).  XCD x instead takes the x-th EIGHTH of the tile list (tiles
     // in x, then y, then segment order): neighbours in space are neighbours in time on one L2.
+    // CHANNEL SPLIT (round 6; MbDesc::ksplit > 1, launches of a few segments under BH_FLAG_LOW_LATENCY): the
+    // launch is ksplit workgroups deep (blockIdx.y) and workgroup ks walks the chunks [c0, c1) only -- a quarter of the block's
+    // weights instead of all of them, which at a handful of workgroups on the whole chip is what a late block's time consists of --
+    // leaving its project accumulators, raw, in d.partial [ks][n][Ho Wo][Cout]; mb_reduce_partials adds the ksplit parts in order.
+    // (ksplit is a power of two: shifts, not the 40-instruction expansion of a scalar division in every workgroup's set-up)
+#ifndef BH_MB_KSPLIT
+#define BH_MB_KSPLIT 1      // (0: the channel split compiled out -- A/B aid for what its set-up arithmetic costs the large launches)
+#endif
+    const int ksp = (BH_MB_KSPLIT && !SE && PERSIST == 0 && d.ksplit > 1) ? d.ksplit : 1, ks = ksp > 1 ? (int)blockIdx.y : 0;
+    const int ksl = ksp >= 8 ? 3 : ksp >= 4 ? 2 : ksp >= 2 ? 1 : 0;
+    const int c0 = (ks * d.nchunks) >> ksl, c1 = ((ks + 1) * d.nchunks) >> ksl;
     const int per_xcd = (n_tiles + 7) >> 3;
     const int tile_xcd = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
     if (!RESIDENT && (dbgv & 256 ? (int)blockIdx.x >= n_tiles : tile_xcd >= n_tiles)) return;   // (dbg 256: launch order, A/B aid)
@@ -301,11 +312,11 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
         }
     } else {
         if constexpr (COLTH > 0) {
-            mb_dma_at<WE_FLOATS, NW>(d.We, we_ba, wave0, lane0);
-            mb_dma_at<WD_FLOATS, NW>(d.Wd, wd_ba, wave0, lane0);
+            mb_dma_at<WE_FLOATS, NW>(d.We + (size_t)c0 * WE_FLOATS, we_ba, wave0, lane0);
+            mb_dma_at<WD_FLOATS, NW>(d.Wd + (size_t)c0 * WD_FLOATS, wd_ba, wave0, lane0);
         } else {
-            mb_dma<WE_FLOATS, NW>(d.We, WeS, wave0, lane0);
-            mb_dma<WD_FLOATS, NW>(d.Wd, Wds, wave0, lane0);
+            mb_dma<WE_FLOATS, NW>(d.We + (size_t)c0 * WE_FLOATS, WeS, wave0, lane0);
+            mb_dma<WD_FLOATS, NW>(d.Wd + (size_t)c0 * WD_FLOATS, Wds, wave0, lane0);
         }
         if (ring) {
             mb_dma<WP_FLOATS, NW>(d.Wp, WpS, wave0, lane0);
@@ -565,8 +576,10 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
 
     // The project accumulators start at bias + residual: those loads overlap the first chunk
     // instead of stalling the epilogue, which is then nothing but stores.
-    float *Yb = d.Y + (size_t)seg0 * d.Ho * d.Wo * Cout;
-    const float *Rb = d.R ? d.R + (size_t)seg0 * d.Ho * d.Wo * Cout : nullptr;
+    // (channel split: the raw accumulators go to this part's slab of d.partial; bias and residual start part 0 only)
+    float *Yb = (ksp > 1 ? d.partial + (size_t)ks * n_seg * d.Ho * d.Wo * Cout : d.Y) + (size_t)seg0 * d.Ho * d.Wo * Cout;
+    const float *Rb = (d.R && ks == 0) ? d.R + (size_t)seg0 * d.Ho * d.Wo * Cout : nullptr;
+    const float bias_on = ks == 0 ? 1.0f : 0.0f, y_unscale = ksp > 1 ? 1.0f : p_unscale;
     f32x4 acco[MT_W][NT_W];
 #if BH_MB_BUFSTORE
     // the workgroup's segments of Y (and of the residual, shaped alike) as buffers
@@ -609,7 +622,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                                                 //  that many loads in flight cost registers the late blocks do not have)
                 const float braw = d.bp[colc];
                 float rres[4] = {0.f, 0.f, 0.f, 0.f};
-                const float bias = col < Cout ? braw : 0.0f;
+                const float bias = col < Cout ? braw * bias_on : 0.0f;
 #if BH_MB_BUFSTORE
                 if (Rb) {   // (wave-uniform) lanes without a pixel or past Cout: offset 2^32 - 1, the range check answers 0
 #pragma unroll
@@ -633,7 +646,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                     acco[i][j][r] = __builtin_fmaf((col < Cout && orow[r] >= 0) ? rres[r] : 0.0f, p_scale, bias);
 #endif
             } else {
-                const float bias = col < Cout ? d.bp[col] : 0.0f;
+                const float bias = col < Cout ? d.bp[col] * bias_on : 0.0f;
 #pragma unroll
                 for (int r = 0; r < 4; r++)
                     acco[i][j][r] = __builtin_fmaf((Rb && col < Cout && orow[r] >= 0) ? Rb[__mul24(orow[r], Cout) + col] : 0.0f, p_scale, bias);
@@ -670,7 +683,7 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
         }
         se_pending = -1;
     };
-    for (int ch = 0; ch < nchunks; ch++) {
+    for (int ch = (dbgv & 128) ? nchunks : c0; ch < ((dbgv & 128) ? nchunks : c1); ch++) {
         // (STRIP: behind the last chunk comes chunk 0 of the next tile row -- its weights arrive under this tile's last phases)
         const int chn = STRIP ? (ch + 1 < nchunks ? ch + 1 : 0) : min(ch + 1, nchunks - 1);
         // this chunk's weights
@@ -1238,14 +1251,14 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
 #if BH_MB_BUFSTORE
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const float yv = PREC != 0 ? acco[i][j][r] * p_unscale : acco[i][j][r];
+                const float yv = PREC != 0 ? acco[i][j][r] * y_unscale : acco[i][j][r];
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, yv), yrs, (col < Cout && orow[r] >= 0 && !(dbgv & 32)) ? (unsigned)(__mul24(orow[r], Cout) + col) * 4u : 0xffffffffu, 0, 0);
             }
 #else
             if (col >= Cout) continue;
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                if (orow[r] >= 0 && !(dbgv & 32)) Yb[__mul24(orow[r], Cout) + col] = PREC != 0 ? acco[i][j][r] * p_unscale : acco[i][j][r];
+                if (orow[r] >= 0 && !(dbgv & 32)) Yb[__mul24(orow[r], Cout) + col] = PREC != 0 ? acco[i][j][r] * y_unscale : acco[i][j][r];
 #endif
         }
     }
@@ -1272,6 +1285,7 @@ void mb_launch(const MbDesc &d, int n_seg, hipStream_t s) {
         const long per_cu = std::max<long>(1, std::min<long>(OCC, (160 * 1024) / (long)(d.lds_bytes + 256)));
         grid = dim3((unsigned)std::min<long>(total, per_cu * device_cu_count()));
     }
+    if (!SE && PERSIST == 0 && d.ksplit > 1) grid.y = (unsigned)d.ksplit;   // (channel split: gridDim.x stays a multiple of 8, so workgroup (x, y) still lands on XCD x % 8)
     hipLaunchKernelGGL(kern, grid, block, d.lds_bytes, s, d, n_seg);
 }
 

@@ -4,6 +4,7 @@
 use std::ffi::{c_char, c_int, c_void};
 
 pub const BH_MAX_TOP_K: usize = 32;
+pub const BH_FLAG_LOW_LATENCY: u32 = 0x10;
 pub const BH_FLAG_PRECISION_MASK: u32 = 0x3;
 pub const BH_FLAG_AUTO: u32 = 0x0;
 pub const BH_FLAG_F16X3: u32 = 0x1;

@@ -317,6 +317,36 @@ def test_c1_wav_to_csv_matches_oracle(full_model, oracle_lib, tmp_path):
     clf.close()
 
 
+def test_low_latency_flag_splits_late_blocks_and_keeps_its_own_bits(full_model, oracle_lib):
+    """BH_FLAG_LOW_LATENCY (round 6): forwards of at most 32 segments run the late blocks 2 / 4 / 8 workgroups
+    deep over their expanded channels and add the partial project sums in index order (0.70 -> 0.38 ms for one segment of the
+    BirdNET-shaped model).  The depth belongs to the block, never to the launch: within the regime (1, 8, 20, 32 segments) a
+    segment's logits are bit-identical whatever launch it ran in; beyond it (64) the flag changes nothing; against the oracle the
+    regime holds the fp32 tolerance like every other path; and WITHOUT the flag every launch size gives the same bits, as before."""
+    from birda_amd import synth
+    from birda_amd.classifier import BirdClassifier
+    path, labels, m, _ = full_model
+    segs = synth.synth_segments(64, m.sample_count, m.sample_rate, start=7)
+    ref = oracle_lib.OracleModel(path).forward(segs[:8])
+    scale = max(1.0, float(np.abs(ref).max()))
+    out = {}
+    for ll in (False, True):
+        clf = BirdClassifier(path, labels, low_latency=ll)
+        for n in (1, 8, 20, 32, 64):
+            ctx = clf.create_batch_context(n)
+            out[(ll, n)] = clf.predict_logits(ctx, segs[:n])
+            ctx.close()
+        clf.close()
+    for n in (1, 8, 20, 32, 64):                               # plain: one set of bits for every launch size
+        assert (out[(False, n)] == out[(False, 64)][:n]).all(), n
+    for n in (1, 8, 20):                                       # the regime: its own bits, the same for every launch size inside it
+        assert (out[(True, n)] == out[(True, 32)][:n]).all(), n
+    assert (out[(True, 64)] == out[(False, 64)]).all()         # beyond 32 segments the flag does nothing
+    d = float(np.abs(out[(True, 32)] - out[(False, 32)]).max())
+    assert 0.0 < d <= 2e-6 * scale, d                          # another summation order, ~1e-7 of the logit scale
+    assert np.abs(out[(True, 8)] - ref).max() <= LOGIT_RTOL * scale and np.abs(out[(False, 8)] - ref).max() <= LOGIT_RTOL * scale
+
+
 def test_file_descriptor_route_gives_the_mapped_routes_rows(clf_tiny, model_dir, tmp_path, monkeypatch):
     """bh_predict_pcm_fd_rows (round 6): the WAV's data chunk read by `pread` straight into the pinned staging
     buffer gives, row for row and bit for bit, what bh_predict_pcm_rows gives on the same bytes in memory; a stream that ends

@@ -9,7 +9,7 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 prec = sys.argv[3] if len(sys.argv) > 3 else "f16x3"
 m = synth.build_model(kind)
 path = f"/tmp/{kind}.bhm"; mf.write_model(path, m)
-clf = BirdClassifier(path, precision=prec)
+clf = BirdClassifier(path, precision=prec, low_latency=os.environ.get("LL") == "1")
 ctx = clf.create_batch_context(N)
 base = synth.synth_segments(16, m.sample_count, m.sample_rate)
 x = torch.from_numpy(np.tile(base, (N // 16 + 1, 1))[:N]).cuda()

@@ -2,7 +2,7 @@
 of BIRDA_HOST_TIMING.  usage: gpu_short_files.py [n_files] [segments_per_file]"""
 import os, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["BIRDA_HOST_TIMING"] = "1"
+if os.environ.get("TIMING"): os.environ["BIRDA_HOST_TIMING"] = "1"
 import numpy as np, torch
 from birda_amd import modelfile as mf, pipeline, synth
 from birda_amd.classifier import BirdClassifier
@@ -17,7 +17,7 @@ files = []
 for k in range(nf):
     x = np.tile(uniq, (per // 16 + 1, 1))[:per].reshape(-1)
     f = os.path.join(d, f"r{k:03d}.wav"); synth.write_wav_pcm16(f, x, m.sample_rate); files.append(f)
-clf = BirdClassifier(path, labels, precision="f16x3")
+clf = BirdClassifier(path, labels, precision="auto", low_latency=os.environ.get("LL") == "1")
 out = os.path.join(d, "out"); os.makedirs(out)
 for rep in range(3):
     t = time.perf_counter(); res, st = pipeline.process_files_packed(clf, files, out); dt = time.perf_counter() - t
