@@ -190,7 +190,7 @@ struct SliceLane { hipStream_t s; float *arena; const size_t *t_off; size_t seg0
 // chunks, 4 deep from 16, 8 deep from 32 (fused blocks without a gate: pass A of a squeeze-excite block has no project sums to split)
 constexpr size_t kLowLatencyMaxSegments = 32;
 static inline int mb_ksplit_of(const bh::MbDesc &d) {
-    static const int cap = [] { const char *e = getenv("BIRDA_HIP_KSPLIT_MAX"); return e ? atoi(e) : 8; }();     // (tuning aid)
+    static const int cap = [] { const char *e = BH_XENV("BIRDA_HIP_KSPLIT_MAX"); return e ? atoi(e) : 8; }();     // (tuning aid of the EXPERIMENTS build)
     const int k = (d.se || d.Cout % 4) ? 1 : d.nchunks >= 32 ? 8 : d.nchunks >= 16 ? 4 : d.nchunks >= 8 ? 2 : 1;
     return std::min(k, std::max(cap, 1));
 }
