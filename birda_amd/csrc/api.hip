@@ -186,12 +186,12 @@ void ctx_destroy(bh_batch_context *ctx) {
 //  and its first segment's index within the slice, which places its rows of the per-segment scratch; nullptr: the context's stream
 //  and whole arena)
 struct SliceLane { hipStream_t s; float *arena; const size_t *t_off; size_t seg0; };
-// BH_FLAG_LOW_LATENCY: launches of up to this many segments split a late block's expanded channels over workgroups, 2 deep from 8
-// chunks, 4 deep from 16, 8 deep from 32 (fused blocks without a gate: pass A of a squeeze-excite block has no project sums to split)
+// BH_FLAG_LOW_LATENCY: launches of up to this many segments split a late block's expanded channels over workgroups, 2 deep from 6
+// chunks, 4 deep from 12, 8 deep from 32 (fused blocks without a gate: pass A of a squeeze-excite block has no project sums to split)
 constexpr size_t kLowLatencyMaxSegments = 32;
 static inline int mb_ksplit_of(const bh::MbDesc &d) {
     static const int cap = [] { const char *e = BH_XENV("BIRDA_HIP_KSPLIT_MAX"); return e ? atoi(e) : 8; }();     // (tuning aid of the EXPERIMENTS build)
-    const int k = (d.se || d.Cout % 4) ? 1 : d.nchunks >= 32 ? 8 : d.nchunks >= 16 ? 4 : d.nchunks >= 8 ? 2 : 1;
+    const int k = (d.se || d.Cout % 4) ? 1 : d.nchunks >= 32 ? 8 : d.nchunks >= 12 ? 4 : d.nchunks >= 6 ? 2 : 1;
     return std::min(k, std::max(cap, 1));
 }
 int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, size_t n, float *d_logits,

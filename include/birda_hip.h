@@ -81,7 +81,7 @@ typedef struct {
  *   BH_FLAG_F32    v_mfma_f32_16x16x4_f32: exact f32 fmaf chains (0.6x the throughput of the split-f16 path)
  * The environment variable BIRDA_HIP_PRECISION = auto | f32 | f16x3 | f16 overrides the flag. */
 /*   BH_FLAG_LOW_LATENCY  (or-ed onto the precision) forwards of at most 32 segments split the expanded channels of the late blocks
- *                  over 2 or 4 workgroups each and add the partial sums in a fixed order: 0.73 -> ~0.5 ms for a call of 1-32 segments
+ *                  over 2 or 4 workgroups each and add the partial sums in a fixed order: 0.69-0.79 -> 0.34-0.57 ms for a call of 1-32 segments
  *                  (a one-minute file at a time; the reference's per-file loop, processor.rs:582-603).  The split is a property of the
  *                  BLOCK, never of the launch, so within the regime a segment's results still do not depend on the launch it ran in;
  *                  they differ from the large-launch path's by the summation order (~1e-7 of the logit scale, inside the fp32
