@@ -1137,7 +1137,33 @@ def child_latency(argv):
             res.setdefault(str(n), {})["low_latency" if ll else "default"] = round(statistics.median(ts) * 1e3, 3)
             ctx.close()
         clf.close()
-    print(json.dumps({"unit": "ms per call (forward_device + synchronise, median of 30)", "segments": res,
+    # ... and the reference's per-file loop on one-minute recordings (process_file per file, processor.rs:418-796) under the flag:
+    # 50 PCM16 WAV files of 20 segments each -> 50 CSV files, one at a time
+    files_rate = None
+    try:
+        from birda_amd import pipeline
+        d = tempfile.mkdtemp(prefix="birda_bench_ll_")
+        labels = os.path.join(d, "labels.txt")
+        synth.write_labels(labels, m.n_classes)
+        wavs = []
+        for k in range(50):
+            f = os.path.join(d, f"r{k:03d}.wav")
+            synth.write_wav_pcm16(f, np.tile(base, (2, 1))[:20].reshape(-1), m.sample_rate)
+            wavs.append(f)
+        out_dir = os.path.join(d, "out")
+        os.makedirs(out_dir)
+        clf = BirdClassifier(model_path, labels, top_k=5, min_confidence=0.1, precision=precision, low_latency=True)
+        rates = []
+        for rep in range(3):
+            t = time.perf_counter()
+            n = sum(pipeline.process_file(clf, f, out_dir).segments for f in wavs)
+            rates.append(n / (time.perf_counter() - t))
+        clf.close()
+        files_rate = {"value": round(sorted(rates)[1], 1), "unit": "segments/s", "what": "50 PCM16 WAV files of 20 segments each, bhh_process_file one at a time, "
+                      "BH_FLAG_LOW_LATENCY classifier, median of 3 passes (the default-flags figure is end_to_end.short_files.one_file_at_a_time)"}
+    except Exception as e:   # noqa: BLE001
+        files_rate = {"error": str(e)[:200]}
+    print(json.dumps({"unit": "ms per call (forward_device + synchronise, median of 30)", "segments": res, "one_minute_files_low_latency": files_rate,
                       "note": "BH_FLAG_LOW_LATENCY: forwards of at most 32 segments split the late blocks' expanded channels over 2-8 workgroups each "
                               "(fixed-order partial sums: a rounding of its own, launch-invariant within the regime)"}))
 
