@@ -40,6 +40,24 @@ def _n_blocks(m):
     return sum(1 for L in m.layers if L.op == mf.OP_DWCONV)
 
 
+def _check_low_latency(m, bhm, onnx, oracle_lib):
+    """BH_FLAG_LOW_LATENCY on a stack nobody tiled: launches of 3 and 20 segments split the blocks of six chunks and more over their
+    channels -- the oracle's tolerance, and one set of bits inside the regime"""
+    from birda_amd.classifier import BirdClassifier
+    segs = synth.synth_segments(20, m.sample_count, m.sample_rate, start=5)
+    ref = oracle_lib.OracleModel(bhm).forward(segs[:3])
+    scale = max(1.0, float(np.abs(ref).max()))
+    clf = BirdClassifier(onnx, None, precision="auto", low_latency=True)
+    outs = []
+    for n in (3, 20):
+        ctx = clf.create_batch_context(n)
+        outs.append(clf.predict_logits(ctx, segs[:n]))
+        ctx.close()
+    clf.close()
+    assert np.isfinite(outs[1]).all() and float(np.abs(outs[0] - ref).max()) <= LOGIT_RTOL * scale
+    assert (outs[1][:3] == outs[0]).all()
+
+
 def _check(m, bhm, onnx, oracle_lib, sizes=(3, 80, 300), precisions=("f32", "f16x3", "auto")):
     from birda_amd.classifier import BirdClassifier
     segs = synth.synth_segments(3, m.sample_count, m.sample_rate, start=5)
@@ -80,6 +98,8 @@ def test_random_stack_matches_the_oracle_fused_in_every_precision(seed, tmp_path
     m, bhm, onnx = _write(tmp_path, f"r{seed}", plan, SPELLINGS[seed % 4])
     # (every fifth stack also with plain f16 operands: its blocks run on plain-f16 entries where one fits, else on split-f16 ones)
     _check(m, bhm, onnx, oracle_lib, precisions=("f32", "f16x3", "auto") + (("f16",) if seed % 5 == 0 else ()))
+    if seed % 4 == 1:
+        _check_low_latency(m, bhm, onnx, oracle_lib)
 
 
 @pytest.mark.parametrize("seed", BIG)
