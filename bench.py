@@ -353,7 +353,12 @@ def analyse_se(clf, m, fused, layer_tot, segs_done, steps, slices_per_step, prec
         # which kernel launch_pw_gemm16_gated (kernels_conv.hip) takes, named as rocprofv3 prints it
         rows = px * (segs_done // per_step)
         thin = nt <= 3 and -(-K // 32) * nt * 2048 <= 65536 and rows >= 4096 and N % 4 == 0
-        wide = 4 <= nt <= 15 and rows >= 4096 and N % 4 == 0
+        # (the row-streaming kernel takes N > 144 from 40 960 rows up only, and not when a pass's segments' gates and its W
+        #  pieces exceed a CU's LDS -- kernels_conv.hip launch_pw_gemm16_gated; below, the staged tiles run)
+        rb_, pf_ = (3, 3) if nt <= 7 else (2, 4) if nt <= 9 else (2, 3)
+        gs_max = (8 * rb_ * 16 + px - 2) // px + 1
+        wide_lds = max(pf_ * nt * 2048 + gs_max * (-(-K // 32) * 32) * 4, 8 * 16 * nt * 16 * 4)
+        wide = 4 <= nt <= 15 and rows >= (40960 if nt >= 10 else 4096) and N % 4 == 0 and wide_lds <= 160 * 1024
         terms = 3 if precision in ("auto", "f16x3") else 1
         if i0 == d:     # a block without an expand convolution: D is computed again by the gated one-launch block (kernels.hpp MbDesc::gate)
             bname, bkind = clf.fused_kernel_name(fused[fi - 1], se=False) + " (no-expand block: depthwise x gate -> project + residual in one launch)", "hbm"
