@@ -203,6 +203,9 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
     float *const d_minmax = ctx->d_minmax + (lane ? lane->seg0 * 16 : 0);
     unsigned *const d_inbad = ctx->d_inbad + (lane ? lane->seg0 * 8 : 0);
     auto T = [&](uint32_t t) { return arena + t_off[t]; };
+#ifndef BH_SE_GATE16_MIN
+#define BH_SE_GATE16_MIN 577
+#endif
     const uint32_t nl = (uint32_t)m.layers.size();
     bh::TraceRange tr_slice("bh_forward_slice");   // ROCTx ranges (BIRDA_HIP_ROCTX=1): the slice, its front end, every layer group
     ctx_mark(ctx, -1);
@@ -312,7 +315,13 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
                 //  one-launch kernel is the faster one -- three launches cost ~27 us per 1 000 segments whatever their size, measured
                 //  13-36 against 27-50 us; beyond, its per-segment re-read of both weight matrices is: 59-490 against 37-143 us)
                 static const bool gate1 = [] { const char *e = BH_XENV("BIRDA_HIP_SE_GATE1"); return e && e[0] == '1'; }();
-                if (!gate1 && d.Cexp > 576)
+                // (round 6: beyond 576 channels two launches of sixteen-segment workgroups -- the pooled rows x W1 split over channel
+                //  slices, then hidden x W2 -- instead of pool + two GEMMs of a handful of tiles: kernels_conv.hip se_hidden_kernel)
+                if (!gate1 && d.Cexp >= BH_SE_GATE16_MIN && bh::se_gate16_supports(d.Cexp, (int)G1.cout))
+                    bh::launch_se_gate16(d.pool_part, d.tiles_x * d.tiles_y, P, T(S.iGap + 1), c->d_w[S.iPw1], c->d_blob + G1.b_off, c->ldw[S.iPw1],
+                                         (int)G1.act, c->d_w[S.iPw2], c->d_blob + G2.b_off, c->ldw[S.iPw2], (int)G2.act, gate, (int)n, d.Cexp,
+                                         (int)G1.cout, s);
+                else if (!gate1 && d.Cexp > 576)
                     bh::launch_se_gate_gemm(d.pool_part, d.tiles_x * d.tiles_y, P, T(S.iGap + 1), T(S.iPw1 + 1), c->d_w[S.iPw1], c->d_blob + G1.b_off,
                                             c->ldw[S.iPw1], (int)G1.act, c->d_w[S.iPw2], c->d_blob + G2.b_off, c->ldw[S.iPw2], (int)G2.act, gate, (int)n,
                                             d.Cexp, (int)G1.cout, s);

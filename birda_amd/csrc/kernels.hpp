@@ -387,6 +387,10 @@ void launch_pw_gemm16_gated(const float *A, const float *gate, int rows_per_seg,
                             float *C, int M, int K, int N, int terms, float w_unscale, int a_blocked, hipStream_t s);
 // ... and the gate itself: pool (from the per-tile channel sums of mbconv pass A, part [n][tiles][C]) -> 1x1 (C -> Cr, act1) -> 1x1
 // (Cr -> C, act2), one launch, fixed summation order
+// the gate beyond 576 channels in two launches of sixteen-segment workgroups (hpart: scratch of n_seg x C floats)
+bool se_gate16_supports(int C, int Cr);
+void launch_se_gate16(const float *part, int tiles, int P, float *hpart, const float *W1, const float *b1, int ld1, int act1, const float *W2,
+                      const float *b2, int ld2, int act2, float *gate, int n_seg, int C, int Cr, hipStream_t s);
 bool se_gate_supports(int C, int Cr);
 // (the same gate as three launches -- the pool, then the two dense layers as GEMMs over all segments: launches of many segments)
 void launch_se_gate_gemm(const float *part, int tiles, int P, float *pooled, float *hidden, const float *W1, const float *b1, int ld1, int act1,
