@@ -1353,11 +1353,31 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float *__restrict__ 
     float *pooled = gs, *hp = gs + C, *hid = hp + 256;
     const int tid = threadIdx.x, seg = blockIdx.x;
     const float *ps = part + (size_t)seg * tiles * C;
-    for (int c = tid; c < C; c += 256) {
+    // (round 6: the early blocks arrive as 64-128 tile rows of 24-144 channels -- 256 / C lanes of threads share the tiles of a channel,
+    //  lane l the tiles l, l + lanes, ..., and the lanes' sums add in lane order: a tenth of the dependent loads, the same order
+    //  whatever the launch)
+    const int lanes = C <= 128 && tiles >= 8 ? 256 / C : 1;
+    if (lanes > 1) {
+        const int c = tid % C, l = tid / C;
         float sum = 0.0f;
-        for (int t = 0; t < tiles; t++) sum += ps[(size_t)t * C + c];
-        pooled[c] = sum * inv_p;
-    }
+        if (l < lanes) {
+#pragma unroll 8
+            for (int t = l; t < tiles; t += lanes) sum += ps[(size_t)t * C + c];
+            hp[l * C + c] = sum;
+        }
+        __syncthreads();
+        if (tid < C) {
+            float tot = hp[tid];
+            for (int q = 1; q < lanes; q++) tot += hp[q * C + tid];
+            pooled[tid] = tot * inv_p;
+        }
+    } else
+        for (int c = tid; c < C; c += 256) {
+            float sum = 0.0f;
+#pragma unroll 8
+            for (int t = 0; t < tiles; t++) sum += ps[(size_t)t * C + c];
+            pooled[c] = sum * inv_p;
+        }
     __syncthreads();
     // hidden layer: thread (r, part) sums its slice of the channels; crp = the power of two >= Cr, 256 / crp slices
     const int nparts = 256 / crp, r = tid & (crp - 1), pt = tid / crp, slice = (C + nparts - 1) / nparts;
@@ -1365,6 +1385,7 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float *__restrict__ 
         float sum = 0.0f;
         if (r < Cr) {
             const int c0 = pt * slice, c1 = min(C, c0 + slice);
+#pragma unroll 16
             for (int c = c0; c < c1; c++) sum = __builtin_fmaf(pooled[c], W1[(size_t)c * ld1 + r], sum);
         }
         hp[tid] = sum;
@@ -1378,21 +1399,38 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float *__restrict__ 
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
         float sum = b2[c];
+#pragma unroll 16
         for (int q = 0; q < Cr; q++) sum = __builtin_fmaf(hid[q], W2[(size_t)q * ld2 + c], sum);
         gate[(size_t)seg * C + c] = act_apply(sum, act2);
     }
 }
 
-// The gate beyond 576 channels (round 6, VERDICT r5 next #3b: it was three launches -- pool, GEMM, GEMM -- whose first GEMM has a
-// handful of tiles and a K loop of 816-3 840 channels: 64-134 us per launch set whatever the block).  Two launches of many small
-// workgroups instead, sixteen segments each:
-//   se_hidden_kernel   grid (groups of 16 segments, KS channel slices of <= 256): pools its slice of the per-tile channel sums into LDS
-//                      (tiles in ascending order, x 1/P), multiplies by its rows of W1, leaves PARTIAL hidden sums [KS][n][Cr];
-//   se_gate16_kernel   grid (groups, 512-channel column blocks): hidden = act1(b1 + the KS partials in ascending order) into LDS,
-//                      gate = act2(b2 + hidden x W2), two channels a thread.
+// The gate of the wide blocks (round 6, VERDICT r5 next #3b: beyond 576 channels it was three launches -- pool, GEMM, GEMM -- whose
+// first GEMM has a handful of tiles and a K loop of 816-3 840 channels: 64-134 us per launch set whatever the block).  Two launches of
+// many small workgroups instead, sixteen segments each:
+//   se_hidden_kernel   grid (groups of 16 segments, KS channel slices): pools its slice of the per-tile channel sums into LDS (tiles in
+//                      ascending order, x 1/P), multiplies by its rows of W1, leaves PARTIAL hidden sums [KS][n][Cr];
+//   se_gate16_kernel   grid (groups, 256-channel column blocks): hidden = act1(b1 + the KS partials in ascending order) into LDS,
+//                      gate = act2(b2 + hidden x W2), a channel a thread.
+// What these launches cost is DEPENDENT MEMORY ROUNDS, not bytes or flops: a block's gate weights are touched once a forward, every
+// load of them is an HBM miss (~0.55 us measured per round trip), and a workgroup is a chain of such round trips whatever the launch
+// size (tools/microbench/se_gate.hip, tools/se_trace.py).  So: the slice width is chosen for <= 32 rows of W1 a thread, every batch
+// of loads is issued whole (up to 32 in flight a thread, indices clamped and the weight of a row beyond the end zeroed: no branch
+// between the loads and their uses -- with one the compiler sinks each load to its use and the chain is back), the first batch of
+// weights is on its way before the pooled sums / the partial sums are.
 // KS and every summation order depend on the block's widths alone: a segment's gate does not depend on the launch it ran in.
 constexpr int SE_SG = 16;
-static inline int se_hidden_slices(int C) { return (C + 255) / 256; }
+constexpr int SE_RB = 32;          // weight rows in flight a thread
+struct SeHiddenShape { int slice, slices; };
+static inline SeHiddenShape se_hidden_shape(int C, int Cr) {
+    int slice = 256;
+    while (slice > 64 && slice * Cr > SE_RB * 256) slice >>= 1;                             // <= 32 rows of W1 a thread
+    while (slice < 256 && ((C + slice - 1) / slice) * Cr > C) slice <<= 1;                    // the partial sums must fit their scratch
+    return {slice, (C + slice - 1) / slice};
+}
+// keeps a batch of loaded values where it was loaded (see above)
+#define SE_PIN(arr, n)                                                                                                                     \
+    _Pragma("unroll") for (int j_ = 0; j_ < (n); j_++) asm volatile("" : "+v"((arr)[j_]))
 
 __global__ __launch_bounds__(256) void se_hidden_kernel(const float *__restrict__ part, int tiles, float inv_p, const float *__restrict__ W1, int ld1,
                                                          float *__restrict__ hpart, int n_seg, int C, int Cr, int slice) {
@@ -1400,6 +1438,13 @@ __global__ __launch_bounds__(256) void se_hidden_kernel(const float *__restrict_
     float *pooledT = gs, *hp = gs + (size_t)slice * SE_SG;          // [slice][16] | [256][16]
     const int tid = threadIdx.x, seg0 = blockIdx.x * SE_SG, ns = min(SE_SG, n_seg - seg0), ks = blockIdx.y;
     const int c0 = ks * slice, len = min(slice, C - c0);
+    // thread (r, pt): hidden unit r over the rows [s0, s1) of the slice
+    const int nparts = 256 / Cr, r = tid % Cr, pt = tid / Cr, sub = (len + nparts - 1) / nparts;
+    const int s0 = min(pt * sub, len), s1 = pt < nparts ? min(len, s0 + sub) : s0, last = max(s1 - 1, 0);
+    const float *w1 = W1 + (size_t)c0 * ld1 + r;
+    float w[SE_RB];
+#pragma unroll
+    for (int j = 0; j < SE_RB; j++) w[j] = w1[(size_t)min(s0 + j, last) * ld1];
     // a thread pools ONE channel of the sixteen segments: sixteen independent loads a tile (a segment beyond the batch reads the
     // last one's sums again and is never written)
     if (tid < len) {
@@ -1411,34 +1456,39 @@ __global__ __launch_bounds__(256) void se_hidden_kernel(const float *__restrict_
         for (int t = 0; t < tiles; t++)
 #pragma unroll
             for (int sg = 0; sg < SE_SG; sg++) acc[sg] += ps[sg][(size_t)t * C];
+        float ip = inv_p;
+        asm volatile("" : "+v"(ip));          // (a VGPR: the scalar pair would make these v_pk_mul_f32 with op_sel -- tests/test_abi_and_host.py)
 #pragma unroll
         for (int v = 0; v < SE_SG / 4; v++)
-            reinterpret_cast<float4 *>(pooledT + tid * SE_SG)[v] = make_float4(acc[4 * v] * inv_p, acc[4 * v + 1] * inv_p, acc[4 * v + 2] * inv_p, acc[4 * v + 3] * inv_p);
+            reinterpret_cast<float4 *>(pooledT + tid * SE_SG)[v] = make_float4(acc[4 * v] * ip, acc[4 * v + 1] * ip, acc[4 * v + 2] * ip, acc[4 * v + 3] * ip);
     }
     __syncthreads();
-    const int nparts = 256 / Cr, r = tid % Cr, pt = tid / Cr, sub = (len + nparts - 1) / nparts;
     float sum[SE_SG];
 #pragma unroll
     for (int sg = 0; sg < SE_SG; sg++) sum[sg] = 0.0f;
-    if (pt < nparts) {
-        const int s0 = pt * sub, s1 = min(len, s0 + sub);
-        const float *w1 = W1 + (size_t)c0 * ld1 + r;
-#pragma unroll 8
-        for (int cl = s0; cl < s1; cl++) {
-            const float w = w1[(size_t)cl * ld1];
-            const float4 *pp = reinterpret_cast<const float4 *>(pooledT + cl * SE_SG);
+    for (int b0 = s0; b0 < s1; b0 += SE_RB) {
+        if (b0 != s0) {
+#pragma unroll
+            for (int j = 0; j < SE_RB; j++) w[j] = w1[(size_t)min(b0 + j, last) * ld1];
+        }
+        SE_PIN(w, SE_RB);
+#pragma unroll
+        for (int j = 0; j < SE_RB; j++) {
+            const float wj = b0 + j < s1 ? w[j] : 0.0f;
+            const float4 *pp = reinterpret_cast<const float4 *>(pooledT + min(b0 + j, last) * SE_SG);
 #pragma unroll
             for (int v = 0; v < SE_SG / 4; v++) {
                 const float4 p = pp[v];
-                sum[4 * v + 0] = __builtin_fmaf(p.x, w, sum[4 * v + 0]);
-                sum[4 * v + 1] = __builtin_fmaf(p.y, w, sum[4 * v + 1]);
-                sum[4 * v + 2] = __builtin_fmaf(p.z, w, sum[4 * v + 2]);
-                sum[4 * v + 3] = __builtin_fmaf(p.w, w, sum[4 * v + 3]);
+                sum[4 * v + 0] = __builtin_fmaf(p.x, wj, sum[4 * v + 0]);
+                sum[4 * v + 1] = __builtin_fmaf(p.y, wj, sum[4 * v + 1]);
+                sum[4 * v + 2] = __builtin_fmaf(p.z, wj, sum[4 * v + 2]);
+                sum[4 * v + 3] = __builtin_fmaf(p.w, wj, sum[4 * v + 3]);
             }
         }
     }
 #pragma unroll
-    for (int sg = 0; sg < SE_SG; sg++) hp[tid * SE_SG + sg] = sum[sg];
+    for (int v = 0; v < SE_SG / 4; v++)
+        reinterpret_cast<float4 *>(hp + tid * SE_SG)[v] = make_float4(sum[4 * v], sum[4 * v + 1], sum[4 * v + 2], sum[4 * v + 3]);
     __syncthreads();
     for (int idx = tid; idx < ns * Cr; idx += 256) {
         const int sg = idx / Cr, q = idx - sg * Cr;
@@ -1453,57 +1503,82 @@ __global__ __launch_bounds__(256) void se_gate16_kernel(const float *__restrict_
                                                          float *__restrict__ gate, int n_seg, int C, int Cr) {
     __shared__ __attribute__((aligned(16))) float hidT[256 * SE_SG];          // [Cr][16]
     const int tid = threadIdx.x, seg0 = blockIdx.x * SE_SG, ns = min(SE_SG, n_seg - seg0);
-    for (int idx = tid; idx < SE_SG * Cr; idx += 256) {
-        const int sg = idx / Cr, q = idx - sg * Cr;
-        float sum = 0.0f;
-        if (sg < ns) {
-            sum = b1[q];
-            for (int ks = 0; ks < nslices; ks++) sum += hpart[((size_t)ks * n_seg + seg0 + sg) * Cr + q];
-            sum = act_apply(sum, act1);
+    const bool has = (int)blockIdx.y * 256 + tid < C;
+    const int c = min((int)blockIdx.y * 256 + tid, C - 1);          // (clamped: a thread beyond the last channel loads and drops)
+    const float *w2 = W2 + c;
+    float w[SE_RB];
+#pragma unroll
+    for (int j = 0; j < SE_RB; j++) w[j] = w2[(size_t)min(j, Cr - 1) * ld2];
+    const float bias = b2[c];
+    // hidden units: the group's partial sums are one contiguous run of ns x Cr floats per slice; two units x sixteen slices in flight
+    const int nval = ns * Cr;
+    const float *hp0 = hpart + (size_t)seg0 * Cr;
+    const size_t kstride = (size_t)n_seg * Cr;
+    for (int i0 = tid; i0 < SE_SG * Cr; i0 += 512) {
+        const int ia = min(i0, nval - 1), ib = min(i0 + 256, nval - 1);
+        const int qa = ia % Cr, qb = ib % Cr;
+        float suma = b1[qa], sumb = b1[qb];
+        for (int k0 = 0; k0 < nslices; k0 += 16) {
+            float va[16], vb[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const size_t off = (size_t)min(k0 + k, nslices - 1) * kstride;
+                va[k] = hp0[off + ia], vb[k] = hp0[off + ib];
+            }
+            SE_PIN(va, 16);
+            SE_PIN(vb, 16);
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                suma += k0 + k < nslices ? va[k] : 0.0f;
+                sumb += k0 + k < nslices ? vb[k] : 0.0f;
+            }
         }
-        hidT[q * SE_SG + sg] = sum;
+        // (unit i of the run is hidden unit i % Cr of segment i / Cr)
+        if (i0 < SE_SG * Cr) hidT[(i0 % Cr) * SE_SG + i0 / Cr] = i0 < nval ? act_apply(suma, act1) : 0.0f;
+        if (i0 + 256 < SE_SG * Cr) hidT[((i0 + 256) % Cr) * SE_SG + (i0 + 256) / Cr] = i0 + 256 < nval ? act_apply(sumb, act1) : 0.0f;
     }
     __syncthreads();
-    const int ca = blockIdx.y * 512 + tid, cb = ca + 256;
-    if (ca >= C) return;
-    const bool two = cb < C;
-    float sa[SE_SG], sb[SE_SG];
-    {
-        const float ba = b2[ca], bb = two ? b2[cb] : 0.0f;
+    float s[SE_SG];
 #pragma unroll
-        for (int sg = 0; sg < SE_SG; sg++) sa[sg] = ba, sb[sg] = bb;
-    }
-#pragma unroll 8
-    for (int q = 0; q < Cr; q++) {
-        const float wa = W2[(size_t)q * ld2 + ca], wb = two ? W2[(size_t)q * ld2 + cb] : 0.0f;
-        const float4 *hh = reinterpret_cast<const float4 *>(hidT + q * SE_SG);
+    for (int sg = 0; sg < SE_SG; sg++) s[sg] = bias;
+    for (int q0 = 0; q0 < Cr; q0 += SE_RB) {
+        if (q0) {
 #pragma unroll
-        for (int v = 0; v < SE_SG / 4; v++) {
-            const float4 h = hh[v];
-            sa[4 * v + 0] = __builtin_fmaf(h.x, wa, sa[4 * v + 0]), sb[4 * v + 0] = __builtin_fmaf(h.x, wb, sb[4 * v + 0]);
-            sa[4 * v + 1] = __builtin_fmaf(h.y, wa, sa[4 * v + 1]), sb[4 * v + 1] = __builtin_fmaf(h.y, wb, sb[4 * v + 1]);
-            sa[4 * v + 2] = __builtin_fmaf(h.z, wa, sa[4 * v + 2]), sb[4 * v + 2] = __builtin_fmaf(h.z, wb, sb[4 * v + 2]);
-            sa[4 * v + 3] = __builtin_fmaf(h.w, wa, sa[4 * v + 3]), sb[4 * v + 3] = __builtin_fmaf(h.w, wb, sb[4 * v + 3]);
+            for (int j = 0; j < SE_RB; j++) w[j] = w2[(size_t)min(q0 + j, Cr - 1) * ld2];
+        }
+        SE_PIN(w, SE_RB);
+#pragma unroll
+        for (int j = 0; j < SE_RB; j++) {
+            const float wj = q0 + j < Cr ? w[j] : 0.0f;
+            const float4 *hh = reinterpret_cast<const float4 *>(hidT + min(q0 + j, Cr - 1) * SE_SG);
+#pragma unroll
+            for (int v = 0; v < SE_SG / 4; v++) {
+                const float4 h = hh[v];
+                s[4 * v + 0] = __builtin_fmaf(h.x, wj, s[4 * v + 0]);
+                s[4 * v + 1] = __builtin_fmaf(h.y, wj, s[4 * v + 1]);
+                s[4 * v + 2] = __builtin_fmaf(h.z, wj, s[4 * v + 2]);
+                s[4 * v + 3] = __builtin_fmaf(h.w, wj, s[4 * v + 3]);
+            }
         }
     }
+    if (has)
 #pragma unroll
-    for (int sg = 0; sg < SE_SG; sg++)
-        if (sg < ns) {
-            gate[(size_t)(seg0 + sg) * C + ca] = act_apply(sa[sg], act2);
-            if (two) gate[(size_t)(seg0 + sg) * C + cb] = act_apply(sb[sg], act2);
-        }
+        for (int sg = 0; sg < SE_SG; sg++)
+            if (sg < ns) gate[(size_t)(seg0 + sg) * C + c] = act_apply(s[sg], act2);
 }
 
 // (the partial hidden sums live in the caller's pooled-tensor scratch, [n][C] floats: KS x Cr <= C is asked of the block)
-bool se_gate16_supports(int C, int Cr) { return C >= 1 && Cr >= 1 && Cr <= 256 && se_hidden_slices(C) * Cr <= C; }
+bool se_gate16_supports(int C, int Cr) { return C >= 1 && Cr >= 1 && Cr <= 256 && se_hidden_shape(C, Cr).slices * Cr <= C; }
 
 void launch_se_gate16(const float *part, int tiles, int P, float *hpart, const float *W1, const float *b1, int ld1, int act1, const float *W2,
                       const float *b2, int ld2, int act2, float *gate, int n_seg, int C, int Cr, hipStream_t s) {
-    const int ksn = se_hidden_slices(C), slice = (C + ksn - 1) / ksn, groups = (n_seg + SE_SG - 1) / SE_SG;
-    const size_t lds = ((size_t)slice * SE_SG + 256 * SE_SG) * sizeof(float);          // 32 KB at most
-    hipLaunchKernelGGL(se_hidden_kernel, dim3((unsigned)groups, (unsigned)ksn), dim3(256), lds, s, part, tiles, 1.0f / (float)P, W1, ld1, hpart, n_seg, C, Cr, slice);
-    hipLaunchKernelGGL(se_gate16_kernel, dim3((unsigned)groups, (unsigned)((C + 511) / 512)), dim3(256), 0, s, hpart, ksn, b1, act1, W2, b2, ld2, act2, gate,
-                       n_seg, C, Cr);
+    const SeHiddenShape sh = se_hidden_shape(C, Cr);
+    const int groups = (n_seg + SE_SG - 1) / SE_SG;
+    const size_t lds = ((size_t)sh.slice * SE_SG + 256 * SE_SG) * sizeof(float);          // 32 KB at most
+    hipLaunchKernelGGL(se_hidden_kernel, dim3((unsigned)groups, (unsigned)sh.slices), dim3(256), lds, s, part, tiles, 1.0f / (float)P, W1, ld1, hpart, n_seg, C, Cr,
+                       sh.slice);
+    hipLaunchKernelGGL(se_gate16_kernel, dim3((unsigned)groups, (unsigned)((C + 255) / 256)), dim3(256), 0, s, hpart, sh.slices, b1, act1, W2, b2, ld2, act2,
+                       gate, n_seg, C, Cr);
 }
 
 // (se_gate_kernel keeps pooled [C] + partial sums [256] + hidden [Cr] in LDS and is launched without a raised dynamic-LDS limit: 64 KB)
