@@ -1007,13 +1007,23 @@ void launch_pw_gemm16(const float *A, const void *Wf, const float *bias, const f
     // (the LDS-staged kernel wherever a workgroup's 128 rows exist; a handful of rows stream as before: nothing to share)
     static const bool stream_only = [] { const char *e = BH_XENV("BIRDA_HIP_GEMM_STREAM"); return e && e[0] == '1'; }();   // A/B aid
     const bool staged = M >= 64 && !stream_only;
-    constexpr size_t kStagedLds = 2 * (2 * 8 * 2 * 256) * sizeof(float);   // 64 KB: two workgroups per CU
+    // (round 6: a launch of a few hundred rows has one or two row blocks, and with eight column tiles a workgroup the dense layers
+    //  leave half the CUs idle and every workgroup alone on its CU, its step a bare HBM round trip + its MFMAs: four or two column
+    //  tiles a workgroup while the grid stays under ~1.5 workgroups a CU.  The same products in the same order: the same bits.)
+    const int ntb = !staged ? 8 : n_xb * n_yb >= 384 ? 8 : ((n_tiles + 3) / 4) * n_yb >= 384 ? 4 : 2;
+    const int n_xb_s = (n_tiles + ntb - 1) / ntb;
+    const dim3 grid_s((unsigned)(8 * ((n_xb_s + 7) / 8) * n_yb));
+#define BH_G16S(T, ACTV, NTBV)                                                                                                    \
+    do {                                                                                                                          \
+        constexpr size_t lds = 2 * ((8 + NTBV) * 2 * 256) * sizeof(float);                                                        \
+        static DeviceOnce attr;                                                                                                   \
+        attr.run([] { (void)hipFuncSetAttribute((const void *)pw_gemm16s_kernel<T, ACTV, false, NTBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); }); \
+        hipLaunchKernelGGL((pw_gemm16s_kernel<T, ACTV, false, NTBV>), grid_s, block, lds, s, A, (const f16x8 *)Wf, bias, R, C, M, K, N, n_tiles, w_unscale); \
+    } while (0)
 #define BH_G16(T, ACTV)                                                                                                           \
     do {                                                                                                                          \
         if (staged) {                                                                                                             \
-            static DeviceOnce attr;                                                                                               \
-            attr.run([] { (void)hipFuncSetAttribute((const void *)pw_gemm16s_kernel<T, ACTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kStagedLds); }); \
-            hipLaunchKernelGGL((pw_gemm16s_kernel<T, ACTV>), grid, block, kStagedLds, s, A, (const f16x8 *)Wf, bias, R, C, M, K, N, n_tiles, w_unscale); \
+            if (ntb == 8) BH_G16S(T, ACTV, 8); else if (ntb == 4) BH_G16S(T, ACTV, 4); else BH_G16S(T, ACTV, 2);                  \
         } else if (M <= 32) {    /* one or two row tiles: the skinny kernel per row tile, eight steps in flight (the same bits) */ \
             for (int m0 = 0; m0 < M; m0 += 16)                                                                                    \
                 hipLaunchKernelGGL((pw_gemm16_skinny_kernel<T, ACTV>), dim3((unsigned)((n_tiles + 7) / 8)), block, 0, s, A + (size_t)m0 * K, (const f16x8 *)Wf, bias, \
@@ -1032,6 +1042,7 @@ void launch_pw_gemm16(const float *A, const void *Wf, const float *bias, const f
     if (terms == 3) { BH_G16A(3) } else { BH_G16A(1) }
 #undef BH_G16A
 #undef BH_G16
+#undef BH_G16S
 }
 
 // ---------------------------------------------------------------------------------------
