@@ -317,6 +317,43 @@ def test_c1_wav_to_csv_matches_oracle(full_model, oracle_lib, tmp_path):
     clf.close()
 
 
+@pytest.mark.parametrize("se_div", [1, 2, 6])
+def test_wide_squeeze_excite_gates_match_oracle_at_every_hidden_width(se_div, tmp_path, oracle_lib):
+    """The two-launch gate of the blocks beyond 576 expanded channels (kernels_conv.hip se_hidden_kernel + se_gate16_kernel, round 6)
+    on gates this repo's own plans do not have: hidden layers of 16-160 units (EfficientNet's own ratio is 1 / 24 of the expanded
+    width; here 1 / 6, 1 / 12, 1 / 36), i.e. one, two, ... sixteen threads a hidden unit and channel slices of 256 or 128, expanded
+    widths that are no multiple of 256 (600, 960), one gate of exactly 576 channels on the one-launch kernel beside them, and
+    launches of 1, 17 and 50 segments (a last group of sixteen that is partly empty).  Held to the oracle at the fp32 logit
+    tolerance; a segment's logits must not depend on the launch.  (reference: any published .onnx goes to the classifier,
+    src/inference/classifier.rs:269-283.)"""
+    from birda_amd import modelfile as mf, synth
+    from birda_amd.classifier import BirdClassifier
+    plan = dict(sr=48000, n=144000, branches=[(1024, 560, 40, 0.0, 12000.0)], stem=32, act=mf.ACT_SWISH, se=True, se_div=se_div, head=256,
+                classes=120, stages=[(1, 3, 1, 24, 1), (6, 3, 2, 96, 2), (6, 5, 2, 100, 2), (6, 3, 2, 160, 2), (4, 3, 1, 232, 1)])
+    m = synth.build_model("custom", plan=plan)
+    bhm = str(tmp_path / "wide_gates.bhm")
+    mf.write_model(bhm, m)
+    n_blocks = sum(1 for L in m.layers if L.op == mf.OP_DWCONV)
+    segs = synth.synth_segments(50, m.sample_count, m.sample_rate, start=21)
+    ref = oracle_lib.OracleModel(bhm).forward(segs[:5])
+    scale = max(1.0, float(np.abs(ref).max()))
+    for prec in ("f16x3", "f32"):
+        clf = BirdClassifier(bhm, None, precision=prec)
+        # (f32 MFMA: the planner leaves a wide block whose best entry pads its MFMA work 2.5-fold to the layer kernels -- their gate is the
+        #  pool + GEMM form; tests/test_random_plans_gpu.py)
+        assert len(clf.fused_blocks()) >= n_blocks - (3 if prec == "f32" else 0), (prec, clf.fused_blocks(), n_blocks)
+        outs = {}
+        for n in (1, 17, 50):
+            ctx = clf.create_batch_context(n)
+            outs[n] = clf.predict_logits(ctx, segs[:n])
+            ctx.close()
+        clf.close()
+        assert np.isfinite(outs[50]).all()
+        err = float(np.abs(outs[50][:5] - ref).max())
+        assert err <= LOGIT_RTOL * scale, (prec, se_div, err, scale)
+        assert (outs[17] == outs[50][:17]).all() and (outs[1] == outs[50][:1]).all(), (prec, se_div)
+
+
 def test_low_latency_flag_splits_late_blocks_and_keeps_its_own_bits(full_model, oracle_lib):
     """BH_FLAG_LOW_LATENCY (round 6): forwards of at most 32 segments run the late blocks 2 / 4 / 8 workgroups
     deep over their expanded channels and add the partial project sums in index order (0.70 -> 0.38 ms for one segment of the
