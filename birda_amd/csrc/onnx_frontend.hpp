@@ -1213,18 +1213,22 @@ inline Recovered recover_frontend(const Graph &g, const onnxc::ValueInfo &audio)
         const double lo_h = (double)p0 / ((double)t_hi + 1.0), hi_h = ((double)p0 + 2.0) / (double)t_hi;
         std::vector<int64_t> cands;
         for (int64_t h = std::max<int64_t>(1, (int64_t)std::floor(lo_h)); h <= (int64_t)std::ceil(hi_h) && cands.size() < 16; h++) cands.push_back(h);
-        const int64_t pm = S / 2;
-        std::vector<std::vector<int64_t>> rows{{pm}};
+        // (TWO impulse positions, 37 samples apart: a Hann-windowed cosine operator is even about L / 2, so ONE impulse that lands on
+        //  row L / 2 + j passes a wrong step H - 2 j as well -- row L / 2 - j of the next frame holds the same numbers; seeded plan
+        //  158 of the soak run, L 512 / H 261, read as 257.  No step but the true one maps both positions onto equal rows.)
+        const int64_t pm = S / 2, pm2 = pm + 37;
+        std::vector<std::vector<int64_t>> rows{{pm}, {pm2}};
         std::vector<int64_t> tried;
-        for (int64_t h : cands) if (pm + h < S) { rows.push_back({pm + h}); tried.push_back(h); }
+        for (int64_t h : cands) if (pm2 + h < S) { rows.push_back({pm + h}); rows.push_back({pm2 + h}); tried.push_back(h); }
         const auto dmh = responses(b, rows, 1.0);
-        const double *dm = dmh.data();
-        const double dm_max = absmax(dm, FM);
+        const double dm_max = std::fmax(absmax(dmh.data(), FM), absmax(dmh.data() + FM, FM));
         int64_t H = 0;
         for (size_t k = 0; k < tried.size() && !H; k++) {
-            const double *dh = dmh.data() + (k + 1) * FM;
             double diff = 0;
-            for (size_t t = 1; t < n_frames; t++) for (size_t m = 0; m < n_mels; m++) diff = std::fmax(diff, std::fabs(dh[t * n_mels + m] - dm[(t - 1) * n_mels + m]));
+            for (size_t which = 0; which < 2; which++) {
+                const double *dm = dmh.data() + which * FM, *dh = dmh.data() + (2 + 2 * k + which) * FM;
+                for (size_t t = 1; t < n_frames; t++) for (size_t m = 0; m < n_mels; m++) diff = std::fmax(diff, std::fabs(dh[t * n_mels + m] - dm[(t - 1) * n_mels + m]));
+            }
             if (diff <= 1e-11 * std::fmax(dm_max, 1e-300) && dm_max > 0) H = tried[k];
         }
         if (!H) throw RecoverError("branch " + std::to_string(b) + ": no frame step near " + std::to_string(lo_h) + " makes the response shift-invariant");
@@ -1233,8 +1237,10 @@ inline Recovered recover_frontend(const Graph &g, const onnxc::ValueInfo &audio)
         // eps from the same impulse on a signal 1000 x smaller: delta T = 2 s u / (2 s + eps) . G[row]
         const double s_small = 1e-3;
         const auto ds = responses(b, {{pm}}, s_small);
+        const double *dm = dmh.data();          // (the response to the impulse at pm)
+        const double dm_top = absmax(dm, FM);
         std::vector<double> ratios;
-        for (size_t i = 0; i < FM; i++) if (std::fabs(dm[i]) > 0.1 * dm_max) ratios.push_back(dm[i] / ds[i]);
+        for (size_t i = 0; i < FM; i++) if (std::fabs(dm[i]) > 0.1 * dm_top) ratios.push_back(dm[i] / ds[i]);
         const double rr = median_of(ratios);
         if (!std::isfinite(rr) || std::fabs(rr * s_small - 1.0) < 1e-9) throw RecoverError("the front-end does not normalise by the segment's range (min / max): not the container's front-end");
         double eps = 2.0 * s_small * (1.0 - rr) / (rr * s_small - 1.0);

@@ -262,13 +262,16 @@ def recover_frontend(g: ox.Graph, sample_rate: int, family: int = 0, audio_input
         lo_h, hi_h = p0 / (t_hi + 1.0), (p0 + 2.0) / t_hi
         cands = [h for h in range(max(1, int(math.floor(lo_h))), int(math.ceil(hi_h)) + 1)]
         H = None
-        pm = S // 2
-        dm = responses(b, [pm])[0]
+        # (TWO impulse positions, 37 samples apart: the operator is even about L / 2, so one impulse landing on row L / 2 + j passes
+        #  a wrong step H - 2 j as well -- onnx_frontend.hpp, seeded plan 158)
+        pm, pm2 = S // 2, S // 2 + 37
+        dm, dm2 = responses(b, [pm, pm2])
         for h in cands:
-            if pm + h >= S:
+            if pm2 + h >= S:
                 continue
-            dh = responses(b, [pm + h])[0]
-            if np.abs(dh[1:] - dm[:-1]).max() <= 1e-11 * max(float(np.abs(dm).max()), 1e-300) and np.abs(dm).max() > 0:
+            dh, dh2 = responses(b, [pm + h, pm2 + h])
+            top = max(float(np.abs(dm).max()), float(np.abs(dm2).max()), 1e-300)
+            if max(np.abs(dh[1:] - dm[:-1]).max(), np.abs(dh2[1:] - dm2[:-1]).max()) <= 1e-11 * top and np.abs(dm).max() > 0:
                 H = h
                 break
         if H is None:

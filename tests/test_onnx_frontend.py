@@ -95,6 +95,27 @@ def test_front_end_is_read_off_the_graph_whatever_the_spelling(spelling, tmp_pat
     assert np.abs(O.OracleModel(pt).forward(segs) - la).max() > 1e-3 * np.abs(la).max()
 
 
+@pytest.mark.parametrize("j,L,H", [(2, 512, 261), (-2, 448, 321), (-1, 512, 383), (1, 448, 275), (2, 640, 334)])
+def test_frame_step_is_not_mistaken_when_the_probe_lands_beside_the_window_centre(j, L, H, tmp_path):
+    """A Hann-windowed cosine operator is even about L / 2: an impulse that lands on row L / 2 + j of a frame gives, one frame on and
+    2 j samples short of the true step, the same numbers (row L / 2 - j).  With ONE probe position the recovery read seeded random
+    plan 158 (L 512, H 261 over 12 000 samples: the probe at S / 2 lands on row 258) as H = 257 and then refused the file for a
+    front-end it is (found by a soak run of tests/test_random_plans_gpu.py's checks over seeds 100-180, round 6).  Both readers now
+    probe two positions 37 samples apart.  Here: frame steps chosen so that the probe at S / 2 lands on row L / 2 + j."""
+    S = 12000
+    assert (S // 2) % H == L // 2 + j
+    plan = dict(sr=48000, n=S, branches=[(L, H, 22, 0.0, 3000.0)], stem=16, stages=[(1, 3, 1, 16, 1)], head=32, classes=10)
+    m = synth.build_model("custom", plan=plan)
+    assert m.branches[0].frame_step == H
+    for spelling in ("complex", "conv1d"):
+        g = convert.graph_from_model(m, frontend_spelling=spelling)
+        rc, msg, m2 = _native(g, tmp_path, name=f"s{L}_{H}{spelling}")
+        assert rc == 0, msg
+        _same_front_end(m, m2, spelling)
+        py = convert.model_from_graph(ox.load(ox.dump(g)), None, sample_rate=m.sample_rate)
+        assert (py.branches[0].frame_length, py.branches[0].frame_step) == (L, H)
+
+
 @pytest.mark.parametrize("kind,spelling", [("birdnet_v24_tiny", "conv1d"), ("birdnet_v24_tiny", "stft"), ("perch_v2_tiny", "complex")])
 def test_full_size_front_ends_are_read_in_seconds(kind, spelling, tmp_path):
     """BirdNET v2.4's two branches (2 048 / 278 and 1 024 / 280 over 144 000 samples) and the 128-mel 32 kHz branch: six probe rows
