@@ -257,7 +257,13 @@ bool mb_plan(MbDesc &d, int force_cfg) {
                 const double tiles = (double)bestd.tiles_y * bestd.tiles_x / c.S, pout_pad = c.WM * c.MT_W * 16;
                 const double steps = tiles * ((double)bestd.mpad_max / 16 * bestd.KG * 4 * (d.Cexp / 16.0) + pout_pad / 16 * bestd.NTOP * (d.Cexp / 4.0));
                 const double own = (double)d.H * d.W / 16 * ((d.noexp ? 0 : d.Cin) / 4.0) * (d.Cexp / 16.0) + (double)d.Ho * d.Wo / 16 * (d.Cout / 16.0) * (d.Cexp / 4.0);
-                if (steps > 2.5 * own && d.Cin >= 64 && d.Cexp >= 192) return false;   // (narrow blocks pad as much on the layer path's GEMM tiles)
+                static const double pad_max = [] { const char *e = BH_XENV("BIRDA_HIP_MB_F32_PAD"); return e ? atof(e) : 2.5; }();   // (A/B aid)
+                if (steps > pad_max * own && d.Cin >= 64 && d.Cexp >= 192) {   // (narrow blocks pad as much on the layer path's GEMM tiles)
+                    if (why)
+                        fprintf(stderr, "mb_plan: %d -> %d -> %d k%d s%d %dx%d left to the layer kernels on the f32 MFMA: best entry %d issues %.1f x the block's own MFMA steps\n",
+                                d.Cin, d.Cexp, d.Cout, d.KS, d.ST, d.H, d.W, bestd.cfg % kNBase, steps / own);
+                    return false;
+                }
             }
             d = bestd;
             return true;
