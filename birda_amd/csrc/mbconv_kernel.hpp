@@ -75,6 +75,12 @@ __device__ __forceinline__ int mb_div(int n, int d, float rcp_d) {
 
 // diagnostic phase clock (only when d.stamps != nullptr): cycles since the last stamp are summed per
 // phase in registers and added to the global counters once, at the end, by lane 0 of every wave
+// a pointer of the descriptor as what it is, a global one: the buffer descriptors below are made from it, and where the compiler
+// cannot infer the address space (the EXPERIMENTS build's persistent / ring variants) a generic pointer costs an aperture test --
+// which this compiler emits as an illegal V_CMP on src_shared_base
+typedef __attribute__((address_space(1))) float mb_gfloat;
+static __device__ __forceinline__ mb_gfloat *mb_global(const float *p) { return (mb_gfloat *)const_cast<float *>(p); }
+
 struct MbClock {
     unsigned long long last, acc[8];
 };
@@ -417,8 +423,10 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                 // (vw == IWC, wave-uniform: the tile's rectangle is inside the image in x -- every tile but the last column's, and
                 //  the first's under left padding; IWC is a compile-time number, so the division is a multiply and a shift)
                 constexpr int IWC = ((1 << TWL) - 1) * ST + KS;
-                const int r = vw == IWC ? (int)(((unsigned)mm * (unsigned)((65536 + IWC - 1) / IWC)) >> 16) : mb_div(mm, vw, rcp_vw), c = mm - __mul24(r, vw);
-                static_assert((long)(SS * 64 * 16 * 8) * IWC < 65536L * 8, "row index times the rounding error of the reciprocal stays below one");
+                // (exact while row index x the rounding error of the 16-bit reciprocal stays below one: every shipped entry; a tile as wide
+                //  as the EXPERIMENTS build's 65-column ones divides as before)
+                constexpr bool kConstDiv = (long)(SS * 64 * 16) * IWC < 65536L;
+                const int r = kConstDiv && vw == IWC ? (int)(((unsigned)mm * (unsigned)((65536 + IWC - 1) / IWC)) >> 16) : mb_div(mm, vw, rcp_vw), c = mm - __mul24(r, vw);
 #else
                 const int r = mb_div(mm, vw, rcp_vw), c = mm - __mul24(r, vw);
 #endif
@@ -503,9 +511,18 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
             }
         } else {
             float4 raw[XBATCH][KG][NQ];
+            // (EXPERIMENTS build, ONE instantiation -- entry 15 on the f32 MFMA, 3x3 stride 2 with three k groups: with the phase clock and the
+            //  ablation bits compiled in, this compiler (ROCm 7.2 clang) emits "V_CMP_NE_U32 0, src_shared_base" for it, an illegal
+            //  instruction, whenever its X rows go through the buffer descriptor; found by bisection over the table, no source construct to
+            //  point at.  That instantiation of that build loads X through pointers as in round 5: the same values.)
+#if defined(BIRDA_HIP_EXPERIMENTS)
+            constexpr bool kBufLoad = BH_MB_BUFLOAD != 0 && !(KS == 3 && ST == 2 && CE == 16 && KG == 3 && RT_W == 7 && PREC == 0);
+#else
+            constexpr bool kBufLoad = BH_MB_BUFLOAD != 0;
+#endif
 #if BH_MB_BUFLOAD
             // the workgroup's segments of X as ONE buffer: a lane that must read zero takes offset 2^32 - 1 and the range check answers 0
-            const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Xb), 0, __builtin_amdgcn_readfirstlane(__mul24(nsv * d.H, d.W) * Cin * 4), 0x00020000);
+            const auto xrs = __builtin_amdgcn_make_buffer_rsrc(mb_global(Xb), 0, __builtin_amdgcn_readfirstlane(__mul24(nsv * d.H, d.W) * Cin * 4), 0x00020000);
 #endif
 #pragma unroll
             for (int ii = 0; ii < XBATCH; ii++) {
@@ -517,10 +534,11 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                         const int kk = (PREC ? 32 * g + 8 * kq : 16 * g + 4 * kq) + 4 * q;
                         const bool ok = rvv[ii] && kk < Cin;
 #if BH_MB_BUFLOAD
-                        raw[ii][g][q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? (unsigned)(xo[ii] + kk) * 4u : 0xffffffffu, 0, 0));
-#else
-                        raw[ii][g][q] = *reinterpret_cast<const float4 *>(Xb + (ok ? xo[ii] + kk : 0));
+                        if constexpr (kBufLoad)
+                            raw[ii][g][q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, ok ? (unsigned)(xo[ii] + kk) * 4u : 0xffffffffu, 0, 0));
+                        else
 #endif
+                        raw[ii][g][q] = *reinterpret_cast<const float4 *>(Xb + (ok ? xo[ii] + kk : 0));
                     }
             }
 #pragma unroll
@@ -535,13 +553,12 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
                         const int kk = (PREC ? 32 * g + 8 * kq : 16 * g + 4 * kq) + 4 * q;
                         const bool ok = rvv[ii] && kk < Cin;
                         const float4 t = raw[ii][g][q];
-#if BH_MB_BUFLOAD
-                        (void)ok; (void)kk;
-                        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;     // (zeros came back from the range check)
-#else
-                        v[4 * q] = ok ? t.x : 0.0f; v[4 * q + 1] = ok ? t.y : 0.0f;
-                        v[4 * q + 2] = ok ? t.z : 0.0f; v[4 * q + 3] = ok ? t.w : 0.0f;
-#endif
+                        if constexpr (kBufLoad) {
+                            v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;     // (zeros came back from the range check)
+                        } else {
+                            v[4 * q] = ok ? t.x : 0.0f; v[4 * q + 1] = ok ? t.y : 0.0f;
+                            v[4 * q + 2] = ok ? t.z : 0.0f; v[4 * q + 3] = ok ? t.w : 0.0f;
+                        }
                     }
                     if constexpr (PREC != 0) bh_split8(v, ah[i][g], al[i][g]);
                     else afr[i][g] = make_float4(v[0], v[1], v[2], v[3]);
@@ -584,8 +601,8 @@ __global__ __launch_bounds__(64 * WM * WN, OCC) void mbconv_kernel(const MbDesc 
 #if BH_MB_BUFSTORE
     // the workgroup's segments of Y (and of the residual, shaped alike) as buffers
     const unsigned y_bytes = (unsigned)__builtin_amdgcn_readfirstlane(__mul24(nsv * d.Ho, d.Wo) * Cout * 4);
-    const auto yrs = __builtin_amdgcn_make_buffer_rsrc(Yb, 0, SE ? 0 : y_bytes, 0x00020000);
-    const auto yrs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(Rb ? Rb : Yb), 0, (SE || !Rb) ? 0 : y_bytes, 0x00020000);
+    const auto yrs = __builtin_amdgcn_make_buffer_rsrc(mb_global(Yb), 0, SE ? 0 : y_bytes, 0x00020000);
+    const auto yrs_r = __builtin_amdgcn_make_buffer_rsrc(mb_global(Rb ? Rb : Yb), 0, (SE || !Rb) ? 0 : y_bytes, 0x00020000);
 #endif
     // SE (pass A of a squeeze-excite block): where the depthwise output and the tile's channel sums go
     const bool se_store = SE && d.Dout != nullptr;      // (nullptr: sums only -- the no-expand blocks, whose D is computed again by the gated one-launch block)
