@@ -1,7 +1,7 @@
 cd ${GRAFT_REPO_ROOT:-.}
-mkdir -p gpurun_out
-{
-REPS=3 bash tools/ab.sh lib
-python -m pytest tests/test_parity_gpu.py tests/test_random_plans_gpu.py -x -q 2>&1 | tail -2
-for sd in 309 451 1001; do LIBX=1 bash tools/ab.sh x python tools/gpu_f32_pad_rule.py $sd 256 2>&1 | grep seed; done
-} > gpurun_out/ab_lib.txt 2>&1
+mkdir -p gpurun_out/zz
+python bench.py --gpus 1 --steps 20 --warmup 3 > gpurun_out/zz/bench.json 2> gpurun_out/zz/bench.log
+python bench.py --config c4 --steps 10 --warmup 2 > gpurun_out/zz/bench_c4.json 2>> gpurun_out/zz/bench.log
+python bench.py --config c4 --micro-batch 256 --steps 10 --warmup 2 --no-cpu-baseline --no-extra-legs > gpurun_out/zz/bench_c4_mb256.json 2>> gpurun_out/zz/bench.log
+python tools/gpu_latency.py > gpurun_out/zz/latency.txt 2>&1
+python tools/gpu_latency_ll.py >> gpurun_out/zz/latency.txt 2>&1
