@@ -10,14 +10,16 @@ from birda_amd import synth
 from oracle import oracle as O
 O.build()
 lo, hi = int(sys.argv[1]), int(sys.argv[2])
+seeds = [int(x) for x in sys.argv[3:]] or list(range(lo, hi))          # (or explicit seeds after a dummy range)
+slack = int(os.environ.get("F32_SLACK", "3"))          # f32 blocks the planner may leave to the layer kernels (its padding rule)
 bad = 0
-for seed in range(lo, hi):
+for seed in seeds:
     big = seed >= 2000
     try:
         with tempfile.TemporaryDirectory() as d:
             plan = synth.random_plan(seed, big=big)
             m, bhm, onnx = T._write(pathlib.Path(d), f"r{seed}", plan, T.SPELLINGS[seed % 4])
-            w = T._check(m, bhm, onnx, O, sizes=(3, 40) if big else (3, 80, 300))
+            w = T._check(m, bhm, onnx, O, sizes=(3, 40) if big else (3, 80, 300), f32_slack=slack)
             if seed % 3 == 0 and not big:
                 T._check_low_latency(m, bhm, onnx, O)
             print(seed, "ok", f"{w:.1e}", flush=True)
