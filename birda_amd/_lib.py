@@ -116,6 +116,7 @@ SYMBOLS = [
     ("bh_predict_pcm16_at", C.c_int, [_VP, _VP, _VP, _SZ, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64), _SZ, C.POINTER(BhResult)]),
     ("bh_resample", C.c_int, [_VP, _VP, _SZ, C.c_uint32, C.c_uint32, _VP, _SZ, C.POINTER(_SZ)]),
     ("bh_resample_output_len", C.c_int, [_SZ, C.c_uint32, C.c_uint32, C.POINTER(_SZ)]),
+    ("bh_resample_supported", C.c_int, [_VP, C.c_uint32, C.c_uint32]),
     ("bh_resample_device", C.c_int, [_VP, _VP, _VP, _SZ, _SZ, C.c_uint32, C.c_uint32, _VP, _SZ, _SZ, _SZ]),
     ("bh_classifier_set_range_filter", C.c_int, [_VP, _VP, _SZ, C.c_float, C.c_int, C.c_int]),
     ("bh_classifier_set_species_list", C.c_int, [_VP, _VP, _SZ]),

@@ -20,6 +20,11 @@ int fail(int code, const char *fmt, ...) {
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
     g_err = buf;
+    // A failed runtime call leaves its code in the thread's last-error slot, and the NEXT forward's launch check (hipGetLastError() at the
+    // end of forward_slice) would report it as its own: a recording whose header asks for more device memory than there is made the
+    // following, innocent file fail with "out of memory" (round 6, tools/fuzz_wav_decoder.py).  Reading the slot clears it; an
+    // error that is really sticky (a dead context) comes back by itself.
+    if (code == BH_ERR_HIP) (void)hipGetLastError();
     return code;
 }
 
@@ -1709,6 +1714,12 @@ int bh_predict_batch_source_rate(bh_classifier *c, bh_batch_context *ctx, const 
         if (n > ctx->asked_batch) return fail(BH_ERR_INVALID, "batch of %zu exceeds context capacity %zu", n, ctx->asked_batch);
     }
     HIPCHK(hipSetDevice(c->device));
+    {   // the rate pair first: a header that names a rate the resampler has no operator for is "unsupported", not the "out of memory" its
+        // source-rate staging buffer would end in
+        const char *perr = nullptr;
+        if (!bh::resample_plan(source_rate, h.sample_rate, &perr))
+            return fail(BH_ERR_UNSUPPORTED, "%s (%u -> %u Hz)", perr ? perr : "resampler", source_rate, h.sample_rate);
+    }
     if (ctx->raw_len < n_src_samples) {
         (void)hipFree(ctx->d_raw); (void)hipHostFree(ctx->h_raw);
         ctx->d_raw = nullptr; ctx->h_raw = nullptr; ctx->raw_len = 0;
@@ -2049,6 +2060,15 @@ extern "C" {
 int bh_resample_output_len(size_t n_in, uint32_t from_rate, uint32_t to_rate, size_t *n_out) try {
     if (!n_out || from_rate == 0 || to_rate == 0) return fail(BH_ERR_INVALID, "resample_output_len: bad arguments");
     *n_out = bh::resample_output_len(n_in, from_rate, to_rate);
+    return BH_OK;
+} catch (...) { return on_exception(); }
+
+int bh_resample_supported(bh_classifier *c, uint32_t from_rate, uint32_t to_rate) try {
+    if (!c || from_rate == 0 || to_rate == 0) return fail(BH_ERR_INVALID, "resample_supported: bad arguments");
+    if (from_rate == to_rate) return BH_OK;
+    HIPCHK(hipSetDevice(c->device));
+    const char *err = nullptr;
+    if (!bh::resample_plan(from_rate, to_rate, &err)) return fail(BH_ERR_UNSUPPORTED, "%s (%u -> %u Hz)", err ? err : "resampler", from_rate, to_rate);
     return BH_OK;
 } catch (...) { return on_exception(); }
 

@@ -800,6 +800,10 @@ extern "C" int bhh_process_file(bh_classifier *clf, const bhh_processing_config 
     if (pl.segment_samples != info.sample_count)
         return hfail(BH_ERR_INVALID, "segment_duration * sample_rate != model sample_count");
     pl.resampling = pl.source_rate != pl.target_rate;   // raw source-rate segments go to the device resampler
+    // (a header may name any rate: the resampler is asked BEFORE a segment of that many source samples is sized, decoded or staged --
+    //  a 1.5 GHz header had the host front end gather 4.7 G samples per segment first; tools/fuzz_wav_decoder.py)
+    if (pl.resampling && bh_resample_supported(clf, pl.source_rate, pl.target_rate) != BH_OK)
+        return hfail(BH_ERR_UNSUPPORTED, std::string("AudioDecode: ") + cfg->input_path + ": " + bh_last_error());
     pl.src_segment_samples = bhh_source_samples(pl.segment_samples, pl.source_rate, pl.target_rate);   // :67-71
     pl.src_overlap_samples = bhh_source_samples(pl.overlap_samples, pl.source_rate, pl.target_rate);   // :78-82
 
@@ -891,6 +895,7 @@ bool plan_packable(bh_classifier *clf, const bh_model_info &info, const bhh_proc
     pl.min_confidence = cfg->min_confidence;
     if (pl.segment_samples != info.sample_count) return false;
     pl.resampling = pl.source_rate != pl.target_rate;
+    if (pl.resampling && bh_resample_supported(clf, pl.source_rate, pl.target_rate) != BH_OK) return false;      // bhh_process_file reports it
     pl.src_segment_samples = bhh_source_samples(pl.segment_samples, pl.source_rate, pl.target_rate);
     pl.src_overlap_samples = bhh_source_samples(pl.overlap_samples, pl.source_rate, pl.target_rate);
     if (pl.src_overlap_samples >= pl.src_segment_samples) return false;      // bhh_process_file reports it

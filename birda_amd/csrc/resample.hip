@@ -73,8 +73,10 @@ void resample_sizes(uint32_t from, uint32_t to, int *fft_in, int *fft_out) {
     const uint32_t g = std::gcd(from, to);
     const uint32_t min_in = from / g;
     const uint32_t chunks = (uint32_t)std::ceil(1024.0 / (double)min_in);
-    *fft_in = (int)(chunks * (from / g));
-    *fft_out = (int)(chunks * (to / g));
+    // (a header may name any 32-bit rate: the products saturate instead of wrapping -- resample_plan refuses such a pair by size)
+    const uint64_t fi = (uint64_t)chunks * (from / g), fo = (uint64_t)chunks * (to / g);
+    *fft_in = (int)std::min<uint64_t>(fi, 1u << 30);
+    *fft_out = (int)std::min<uint64_t>(fo, 1u << 30);
 }
 
 size_t resample_output_len(size_t n, uint32_t from, uint32_t to) {
@@ -99,6 +101,13 @@ const ResamplePlan *resample_plan(uint32_t from, uint32_t to, const char **err) 
     const int P = (int)(from / g), Q = (int)(to / g);
     const int N = std::lcm(Q, 160), q = N / Q, hop = q * P;
     if (hop > ni || N > 2 * no) { *err = "resampler: rate pair outside the built range"; return nullptr; }
+    // Refused BEFORE the operator is computed (round 6: found by tools/fuzz_wav_decoder.py -- a header that says 47 999 Hz, or 128 Hz, or
+    // 1.5 GHz, asked for `hop` FFTs of length 2 fft_out and a table of hop x 2 fft_out doubles (36 GB for 47 999 -> 48 000) before the
+    // LDS check below could say no: the process sat in here until the inference watchdog killed it, one bad file ending a whole
+    // directory run).  The kernel's frame tile holds 63 hop + K (>= 128) input samples in LDS; every pair whose rates share a divisor
+    // of a few hundred -- 8 / 11.025 / 16 / 22.05 / 32 / 44.1 / 96 / 192 / 250 / 384 kHz against 32 / 48 kHz -- has hop <= 441.
+    if (((size_t)63 * hop + 128) * 4 > 150 * 1024) { *err = "resampler: frame span exceeds LDS (the two sample rates share too small a divisor)"; return nullptr; }
+    if (ni > 32768 || no > 32768) { *err = "resampler: rate ratio outside the built range"; return nullptr; }
     // rubato's filter: windowed sinc of length fft_in, unit sum, scaled 1 / (2 fft_in)
     const double cutoff = ni > no ? (double)powf(0.4f, 16.0f / (float)ni) * (double)no / (double)ni
                                   : (double)powf(0.4f, 16.0f / (float)ni);

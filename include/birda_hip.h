@@ -421,6 +421,11 @@ BH_API int bh_resample(bh_classifier *c, const float *in, size_t n_in, uint32_t 
                        uint32_t to_rate, float *out, size_t out_cap, size_t *n_out);
 /* the length resample() returns for n_in input samples (whole blocks + ceil of the tail, :58-88) */
 BH_API int bh_resample_output_len(size_t n_in, uint32_t from_rate, uint32_t to_rate, size_t *n_out);
+/* Whether the device resampler has an operator for this rate pair (equal rates: always).  The reference builds its rubato resampler
+ * per segment and takes what it gets (resample.rs:19-33, an error only from rubato's constructor); here a pair whose rates share too
+ * small a divisor -- a header that says 47 999 Hz -- has no operator that fits a CU, and the caller learns it BEFORE it decodes,
+ * stages or uploads anything at that rate: BH_OK, or BH_ERR_UNSUPPORTED with the reason in bh_last_error(). */
+BH_API int bh_resample_supported(bh_classifier *c, uint32_t from_rate, uint32_t to_rate);
 /* decode_and_stream's per-segment step for a batch (processor.rs:84-87): every row of d_in
  * [n_seg][in_stride] holds src_len source-rate samples of one raw segment; row i of d_out
  * [n_seg][out_stride] receives resample_chunk(..) followed by resize(out_len, 0.0).  Enqueued on

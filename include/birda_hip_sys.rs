@@ -164,6 +164,7 @@ extern "C" {
     pub fn bh_predict_pcm16_at(c: *mut BhClassifier, ctx: *mut BhBatchContext, pcm: *const i16, n_frames: usize, channels: u32, source_rate: u32, start_samples: *const u64, n_segments: usize, out: *mut BhResult) -> c_int;
     pub fn bh_resample(c: *mut BhClassifier, in_: *const f32, n_in: usize, from_rate: u32, to_rate: u32, out: *mut f32, out_cap: usize, n_out: *mut usize) -> c_int;
     pub fn bh_resample_output_len(n_in: usize, from_rate: u32, to_rate: u32, n_out: *mut usize) -> c_int;
+    pub fn bh_resample_supported(c: *mut BhClassifier, from_rate: u32, to_rate: u32) -> c_int;
     pub fn bh_resample_device(c: *mut BhClassifier, ctx: *mut BhBatchContext, d_in: *const f32, in_stride: usize, src_len: usize, from_rate: u32, to_rate: u32, d_out: *mut f32, out_stride: usize, out_len: usize, n_seg: usize) -> c_int;
     pub fn bh_custom_classifier_create(model_path: *const c_char, labels_path: *const c_char, device: i32, top_k: u32, out: *mut *mut BhCustomClassifier) -> c_int;
     pub fn bh_custom_classifier_destroy(cc: *mut BhCustomClassifier);

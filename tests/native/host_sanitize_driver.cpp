@@ -36,6 +36,7 @@ int bh_predict_pcm_rows(bh_classifier *, bh_batch_context *, const void *, uint3
                         bh_rows_fn, void *) { return BH_ERR_NO_DEVICE; }
 int bh_predict_pcm_fd_rows(bh_classifier *, bh_batch_context *, int, uint64_t, uint32_t, size_t, uint32_t, uint32_t, size_t, bh_result *, size_t, size_t *, uint64_t *,
                            bh_rows_fn, void *) { return BH_ERR_NO_DEVICE; }
+int bh_resample_supported(bh_classifier *, uint32_t, uint32_t) { return BH_OK; }
 int bh_batch_context_set_sub_slices(bh_batch_context *, uint32_t) { return BH_OK; }
 void *bh_batch_context_host_buffer(bh_batch_context *, size_t *) { return nullptr; }
 int bh_predict_batch_two_stage(bh_classifier *, bh_batch_context *, bh_custom_classifier *, const float *const *, size_t, size_t, bh_result *, float *) { return BH_ERR_NO_DEVICE; }

@@ -1517,6 +1517,39 @@ def _write_wav(path, x, rate, fmt):
         f.write(hdr + b"data" + struct.pack("<I", len(data)) + data)
 
 
+def test_a_recording_the_resampler_cannot_take_is_refused_at_once(clf_tiny, model_dir, tmp_path):
+    """A header may name any sample rate.  47 999 Hz against the model's 48 000 shares no divisor: the block resampler's operator would
+    be 36 GB, and computing it kept the process inside the guarded region until the inference watchdog KILLED it -- one bad file ending
+    a directory run (round 6, tools/fuzz_wav_decoder.py through bhh_process_file; also 128 Hz and 1.5 GHz headers).  Such a pair is
+    refused before anything is computed (BH_ERR_UNSUPPORTED, both front ends, well under a second), and a failed device allocation no
+    longer leaves its error code for the next, innocent call to find (api.hip fail())."""
+    import time
+    from birda_amd import pipeline, synth
+    from birda_amd._lib import BirdaHipError
+    _, _, m, _ = model_dir["birdnet_v24_tiny"]
+    x = synth.synth_segments(3, m.sample_count, m.sample_rate, start=77).reshape(-1)
+    good = str(tmp_path / "good.wav")
+    _write_wav(good, x, m.sample_rate, "s16")
+    out = tmp_path / "out"; out.mkdir()
+    for rate in (47999, 128, 1_574_851_774):
+        bad = str(tmp_path / f"bad_{rate}.wav")
+        _write_wav(bad, x[: m.sample_count], rate, "s16")
+        for fe in ("device", "host"):
+            t = time.perf_counter()
+            with pytest.raises(Exception) as ei:
+                pipeline.process_file(clf_tiny, bad, str(out), min_confidence=0.05, front_end=fe)
+            assert time.perf_counter() - t < 5.0, (rate, fe)
+            assert getattr(ei.value, "code", None) == -6 and "resampler" in str(ei.value), (rate, fe, str(ei.value))
+            r = pipeline.process_file(clf_tiny, good, str(out), min_confidence=0.05, front_end=fe)     # the next file is not harmed
+            assert r.segments == 3
+    # a device allocation that fails (a context of ten million segments) is reported, and the next forward does not inherit its code
+    with pytest.raises(BirdaHipError) as ei:
+        clf_tiny.create_batch_context(10_000_000)
+    assert ei.value.code in (-4, -1, -7), str(ei.value)
+    r = pipeline.process_file(clf_tiny, good, str(out), min_confidence=0.05, front_end="device")
+    assert r.segments == 3
+
+
 @pytest.mark.parametrize("fmt", ["s24", "s32", "f32"])
 def test_device_front_end_takes_every_wav_sample_format(clf_tiny, model_dir, tmp_path, fmt):
     """24-bit, 32-bit and float32 WAV streams are uploaded in the file's own layout and scaled on the device exactly as the host

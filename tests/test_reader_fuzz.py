@@ -18,3 +18,14 @@ def test_mutated_model_files_are_refused_or_read_never_a_crash():
     assert last.startswith("240 mutants, 0 bad batches"), r.stdout[-800:]
     # the mutants reach past the first byte: some are read, some refused as malformed, some as unsupported
     assert "'0':" in last and "'-2':" in last, last
+
+
+def test_mutated_recordings_are_decoded_or_refused_never_a_crash():
+    """The host WAV decoder (bhh_decoder_open / _next_segment: reference src/audio/decode.rs:54-411) on mutated files of every sample
+    format: header fields overwritten with 0 / 1 / 2^31 / 2^32 - 1, truncations, insertions (tools/fuzz_wav_decoder.py; the same mutants
+    through bhh_process_file on the GPU box: tests/test_parity_gpu.py::test_a_recording_the_resampler_cannot_take_is_refused_at_once)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_wav_decoder.py"), "300", "3"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-600:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert last.startswith("300 mutants, 0 bad batches"), r.stdout[-800:]
+    assert "'0':" in last and "'-2':" in last, last
