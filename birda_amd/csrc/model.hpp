@@ -1,5 +1,6 @@
 // BHM1 model container reader (format: birda_amd/modelfile.py).  Host only.
 #pragma once
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -61,6 +62,18 @@ inline bool validate_model(Model &m, std::string &err) {
         m.layers.size() != m.h.n_layers || m.blob.size() != m.h.blob_floats) { err = "bad counts"; return false; }
     if (m.h.sample_count == 0 || m.h.sample_count > (1u << 24) || m.h.sample_rate == 0 || m.h.n_classes == 0 || m.h.n_classes > (1u << 24) ||
         m.h.spec_h == 0 || m.h.spec_w == 0 || m.h.spec_h > (1u << 14) || m.h.spec_w > (1u << 16)) { err = "bad model dimensions"; return false; }
+    // the front-end's branches (round 6, tools/fuzz_create.py: a mutated mel_w_off -- 4.5e18 -- passed every check here and the operator
+    // build read the blob there: SIGBUS.  None of these fields was checked against the blob, the segment or the spectrogram before.)
+    for (const auto &b : m.branches) {
+        if (b.frame_length < 4 || b.frame_length > (1u << 16) || (b.frame_length & 1) || b.fft_length != b.frame_length || b.n_bins != b.frame_length / 2 + 1 ||
+            b.frame_step == 0 || b.frame_step > (1u << 16) || b.n_mels == 0 || b.n_mels != m.h.spec_h || b.n_frames == 0 || b.n_frames != m.h.spec_w) {
+            err = "front-end branch geometry out of range (frame length / step / bins / mels / frames against the spectrogram)"; return false;
+        }
+        if ((uint64_t)(b.n_frames - 1) * b.frame_step + b.frame_length > m.h.sample_count) { err = "front-end frames run past the segment"; return false; }
+        if (b.mel_w_off > m.h.blob_floats || (uint64_t)b.n_bins * b.n_mels > m.h.blob_floats - b.mel_w_off) { err = "mel matrix outside blob"; return false; }
+        if (!std::isfinite(b.mag_scale) || !std::isfinite(b.out_scale) || !std::isfinite(b.out_shift)) { err = "front-end constants are not finite"; return false; }
+    }
+    if (!std::isfinite(m.h.norm_eps) || m.h.norm_eps < 0) { err = "normalisation epsilon out of range"; return false; }
     m.tensor_floats.assign(m.h.n_layers + 1, 0);
     m.tensor_floats[0] = (uint64_t)m.h.n_branches * m.h.spec_h * m.h.spec_w;
     for (uint32_t i = 0; i < m.h.n_layers; i++) {
