@@ -29,3 +29,36 @@ def test_mutated_recordings_are_decoded_or_refused_never_a_crash():
     last = r.stdout.strip().splitlines()[-1]
     assert last.startswith("300 mutants, 0 bad batches"), r.stdout[-800:]
     assert "'0':" in last and "'-2':" in last, last
+
+
+def test_a_front_end_branch_that_points_outside_the_file_is_refused(tmp_path):
+    """validate_model (birda_amd/csrc/model.hpp) held every LAYER to the blob and to its producer and nothing of the front-end's
+    BRANCHES: a branch record whose mel_w_off said 4.5e18 reached the operator build, which read the blob there (SIGBUS in
+    bh_classifier_create; tools/fuzz_create.py on the GPU box, round 6).  Branch records rewritten one field at a time: each is
+    refused as malformed by name -- through the host-side planner, which loads and validates the container without a GPU."""
+    import ctypes as C
+    import struct
+    sys.path.insert(0, ROOT)
+    from birda_amd import _lib, modelfile as mf, synth
+    L = _lib.load()
+    m = synth.build_model("mini_se")
+    base = str(tmp_path / "base.bhm")
+    mf.write_model(base, m)
+    raw = open(base, "rb").read()
+    cfgs, layers = (C.c_int32 * 64)(), (C.c_int32 * 64)()
+    assert L.bh_plan_fused_blocks(base.encode(), 1, cfgs, layers, 64) >= 0
+    off = 256                                  # the first branch record (BRANCH_FMT "<IIIIIIfffffIQ": 64 bytes behind the header)
+    rec = list(struct.unpack_from(mf.BRANCH_FMT, raw, off))
+    fields = {"frame_length": 0, "frame_step": 1, "fft_length": 2, "n_bins": 3, "n_mels": 4, "n_frames": 5, "mag_scale": 8, "mel_w_off": 12}
+    cases = [("mel_w_off", 4496763963580612608, "mel matrix outside blob"), ("mel_w_off", len(m.blob) - 5, "mel matrix outside blob"),
+             ("n_frames", rec[5] + 40, "front-end"), ("frame_step", 0, "front-end"), ("frame_step", rec[1] * 3, "front-end"),
+             ("frame_length", rec[0] * 64, "front-end"), ("n_bins", rec[3] + 1, "front-end"), ("n_mels", rec[4] + 16, "front-end"),
+             ("fft_length", rec[2] * 2, "front-end"), ("mag_scale", float("nan"), "not finite")]
+    for name, value, why in cases:
+        r = list(rec)
+        r[fields[name]] = value
+        bad = str(tmp_path / f"bad_{name}.bhm")
+        open(bad, "wb").write(raw[:off] + struct.pack(mf.BRANCH_FMT, *r) + raw[off + struct.calcsize(mf.BRANCH_FMT):])
+        rc = L.bh_plan_fused_blocks(bad.encode(), 1, cfgs, layers, 64)
+        msg = L.bh_last_error().decode()
+        assert rc == -2 and why in msg, (name, value, rc, msg)
