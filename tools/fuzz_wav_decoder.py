@@ -45,6 +45,12 @@ def child_process(paths):
     mp, lp = os.path.join(d, "m.bhm"), os.path.join(d, "l.txt")
     mf.write_model(mp, m); synth.write_labels(lp, m.n_classes)
     clf = BirdClassifier(mp, lp, top_k=3, min_confidence=0.5)
+    # ... and all of them at once through bhh_process_files (packed uploads: a file's header decides where its frames sit in the pack)
+    try:
+        res, status = pipeline.process_files_packed(clf, list(paths), d, min_confidence=0.5, overlap=0.0)
+        print("# packed:", sum(1 for s_ in status if s_ == 0), "of", len(paths), "processed", file=sys.stderr, flush=True)
+    except Exception as e:
+        print("# packed call failed:", type(e).__name__, str(e)[:200], file=sys.stderr, flush=True)
     for p in paths:
         for fe in ("device", "host"):
             try:
