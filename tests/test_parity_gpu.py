@@ -1517,6 +1517,76 @@ def _write_wav(path, x, rate, fmt):
         f.write(hdr + b"data" + struct.pack("<I", len(data)) + data)
 
 
+@pytest.mark.parametrize("low_latency", [False, True])
+def test_contexts_on_one_classifier_run_concurrently_with_the_sequential_bits(model_dir, low_latency):
+    """One classifier, one batch context per thread (how bhh_process_files keeps three files in flight, host_pipeline.cpp; the
+    reference shares its session between the pipeline's threads the same way, src/pipeline/processor.rs): six threads, each with its
+    own context and its own stream of calls -- forwards of different sizes, the source-rate route through the shared resampler plan
+    cache, PCM16 streams -- started together.  Every result must be bit for bit what the same call gives alone: nothing a context
+    touches may be shared unguarded (lazily built plans, the low-latency regime's partial-sum scratch, the launch-once attributes)."""
+    import threading
+    from birda_amd import synth
+    from birda_amd.classifier import BirdClassifier
+    path, labels, m, _ = model_dir["birdnet_v24_tiny"]
+    clf = BirdClassifier(path, labels, top_k=5, min_confidence=0.0, low_latency=low_latency)
+    S, rate = m.sample_count, m.sample_rate
+    sizes = [1, 3, 17, 40, 5, 33]
+    inputs = [synth.synth_segments(n, S, rate, start=100 * k) for k, n in enumerate(sizes)]
+    src_rate = 44100
+    n_src = int(np.ceil(S * src_rate / rate))
+    pcm = [np.round(synth.synth_segments(3, n_src, src_rate, start=900 + k).reshape(-1)[: int(2.5 * n_src)] * 32767.0).astype(np.int16) for k in range(len(sizes))]
+
+    def work(k, ctx, out):
+        got = []
+        for rep in range(6):
+            got.append(clf.predict_logits(ctx, inputs[k]).copy())
+            r = clf.predict_batch_with_context(ctx, [inputs[k][i] for i in range(min(sizes[k], 4))])
+            got.append(np.array([[p.confidence for p in res.predictions] for res in r], np.float32))
+            r2, starts = clf.predict_pcm16(ctx, pcm[k], src_rate)          # (the source-rate route: resampler plan cache, PCM staging)
+            got.append(np.array([[p.confidence for p in res.predictions] for res in r2], np.float32))
+            got.append(np.array(starts, np.float64))
+        out[k] = got
+
+    ctxs = [clf.create_batch_context(max(n, 4)) for n in sizes]
+    alone, together = {}, {}
+    for k in range(len(sizes)):
+        work(k, ctxs[k], alone)
+    threads = [threading.Thread(target=work, args=(k, ctxs[k], together)) for k in range(len(sizes))]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    for k in range(len(sizes)):
+        assert len(alone[k]) == len(together[k]) and len(alone[k]) >= 24
+        for a, b in zip(alone[k], together[k]):
+            assert a.shape == b.shape and (a == b).all(), (low_latency, k, float(np.abs(a - b).max()))
+    for c in ctxs: c.close()
+    # context-less calls share the classifier's internal context behind its mutex: four threads, the sequential bits
+    segs = [inputs[3][i] for i in range(6)]
+    want = np.array([[p.confidence for p in r.predictions] for r in clf.predict_batch(segs)], np.float32)
+    outs = {}
+
+    def plain(k):
+        outs[k] = [np.array([[p.confidence for p in r.predictions] for r in clf.predict_batch(segs)], np.float32) for _ in range(5)]
+
+    threads = [threading.Thread(target=plain, args=(k,)) for k in range(4)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert all((o == want).all() for k in range(4) for o in outs[k])
+    clf.close()
+    # ... and two classifiers built at the same moment (lazily initialised kernel attributes, the plan tables) give what one gives
+    built = {}
+
+    def build(k):
+        c2 = BirdClassifier(path, labels, top_k=5, min_confidence=0.0, low_latency=low_latency)
+        ctx2 = c2.create_batch_context(8)
+        built[k] = c2.predict_logits(ctx2, inputs[3][:8]).copy()
+        ctx2.close(); c2.close()
+
+    threads = [threading.Thread(target=build, args=(k,)) for k in range(3)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    assert (built[0] == built[1]).all() and (built[0] == built[2]).all() and (built[0] == alone[3][0][:8]).all()
+
+
 def test_a_recording_the_resampler_cannot_take_is_refused_at_once(clf_tiny, model_dir, tmp_path):
     """A header may name any sample rate.  47 999 Hz against the model's 48 000 shares no divisor: the block resampler's operator would
     be 36 GB, and computing it kept the process inside the guarded region until the inference watchdog KILLED it -- one bad file ending
