@@ -1827,6 +1827,11 @@ static int predict_pcm_rows_any(bh_classifier *c, bh_batch_context *ctx, const v
     if ((!pcm && fd < 0) || !out || !n_segments || channels == 0 || !pcm_bytes_per_sample(sample_format)) return fail(BH_ERR_INVALID, "predict_pcm: bad arguments");
     const auto &h = c->model.h;
     const bool resampling = source_rate != h.sample_rate;
+    if (source_rate == 0) return fail(BH_ERR_INVALID, "predict_pcm: a sample rate of 0");
+    if (resampling) {   // the rate pair before a frame of the stream is read or staged
+        const int rs = bh_resample_supported(c, source_rate, h.sample_rate);
+        if (rs != BH_OK) return rs;
+    }
     // segment and overlap lengths at the source rate (processor.rs:67-82)
     const size_t seg = resampling ? (size_t)std::ceil((double)h.sample_count * source_rate / h.sample_rate) : h.sample_count;
     const size_t ovl = resampling ? (size_t)std::ceil((double)overlap_samples * source_rate / h.sample_rate) : overlap_samples;
@@ -1853,6 +1858,11 @@ int bh_predict_pcm_at(bh_classifier *c, bh_batch_context *ctx, const void *pcm, 
     if (!pcm || !out || !start_samples || channels == 0 || !pcm_bytes_per_sample(sample_format)) return fail(BH_ERR_INVALID, "predict_pcm_at: bad arguments");
     if (n_segments == 0) return BH_OK;
     const auto &h = c->model.h;
+    if (source_rate == 0) return fail(BH_ERR_INVALID, "predict_pcm_at: a sample rate of 0");
+    if (source_rate != h.sample_rate) {
+        const int rs = bh_resample_supported(c, source_rate, h.sample_rate);
+        if (rs != BH_OK) return rs;
+    }
     const size_t seg = source_rate != h.sample_rate ? (size_t)std::ceil((double)h.sample_count * source_rate / h.sample_rate) : h.sample_count;
     std::vector<uint64_t> starts(start_samples, start_samples + n_segments);
     for (size_t i = 0; i < n_segments; i++)
@@ -2102,6 +2112,7 @@ int bh_resample_device(bh_classifier *c, bh_batch_context *ctx, const float *d_i
 int bh_resample(bh_classifier *c, const float *in, size_t n_in, uint32_t from_rate, uint32_t to_rate, float *out,
                 size_t out_cap, size_t *n_out) try {
     if (!c || !in || !out || !n_out) return fail(BH_ERR_INVALID, "resample: null argument");
+    if (from_rate == 0 || to_rate == 0) return fail(BH_ERR_INVALID, "resample: a sample rate of 0");   // (was a division by zero: tools/fuzz_args.py)
     const size_t need = bh::resample_output_len(n_in, from_rate, to_rate);
     if (need > out_cap) return fail(BH_ERR_INVALID, "resample: output buffer too small (%zu < %zu)", out_cap, need);
     *n_out = need;

@@ -1612,6 +1612,14 @@ def test_a_recording_the_resampler_cannot_take_is_refused_at_once(clf_tiny, mode
             assert getattr(ei.value, "code", None) == -6 and "resampler" in str(ei.value), (rate, fe, str(ei.value))
             r = pipeline.process_file(clf_tiny, good, str(out), min_confidence=0.05, front_end=fe)     # the next file is not harmed
             assert r.segments == 3
+    # a rate of 0 is a bad argument, not a division by zero (tools/fuzz_args.py: SIGFPE in bh_resample)
+    for fr, to in ((0, 48000), (48000, 0), (0, 0)):
+        with pytest.raises(BirdaHipError) as ei:
+            clf_tiny.resample(x[:1000], fr, to)
+        assert ei.value.code == -1, str(ei.value)
+    with pytest.raises(BirdaHipError) as ei:
+        clf_tiny.predict_pcm16(clf_tiny.create_batch_context(4), np.zeros(3 * m.sample_count, np.int16), 0)
+    assert ei.value.code == -1, str(ei.value)
     # a device allocation that fails (a context of ten million segments) is reported, and the next forward does not inherit its code
     with pytest.raises(BirdaHipError) as ei:
         clf_tiny.create_batch_context(10_000_000)
