@@ -62,3 +62,39 @@ def test_a_front_end_branch_that_points_outside_the_file_is_refused(tmp_path):
         rc = L.bh_plan_fused_blocks(bad.encode(), 1, cfgs, layers, 64)
         msg = L.bh_last_error().decode()
         assert rc == -2 and why in msg, (name, value, rc, msg)
+
+
+def test_text_out_functions_never_write_past_the_capacity_they_are_given():
+    """The host ABI's text-out functions (include/birda_host.h: `char *out, size_t cap` -> the length needed) with labels, paths and
+    floats of every kind and capacities from 0 up: 64 canary bytes behind the buffer must survive every call."""
+    import ctypes as C
+    import random
+    import struct
+    sys.path.insert(0, ROOT)
+    from birda_amd import _lib
+    L = _lib.load()
+    rng = random.Random(3)
+    alphabet = ["a", "Z", " ", "_", ",", '"', "\n", "\t", "\x01", "\u00e9", "\u9ce5", "\U0001F600", "/", ".", "\\", "-"]
+    canary = b"\xA5" * 64
+
+    def word(n=20):
+        return "".join(rng.choice(alphabet) for _ in range(rng.randrange(0, n)))
+
+    def call(fn, args, hint=512):
+        for cap in (0, 1, 2, 5, 17, 64, hint):
+            buf = C.create_string_buffer(cap + 64)
+            buf.raw = b"\x5a" * cap + canary
+            fn(*args, buf, cap)
+            assert buf.raw[cap:cap + 64] == canary, (fn.__name__, args, cap)
+
+    for _ in range(400):
+        lab, path = (word() + "_" + word()).encode(), ("/d/" + word()).encode()
+        call(L.bhh_csv_row, (lab, C.c_float(rng.uniform(-1e9, 1e9)), C.c_float(rng.uniform(0, 1e6)),
+                             C.c_float(rng.choice([0.5, float("nan"), float("inf"), 1e-30, -0.0, 3.4e38])), path))
+        call(L.bhh_csv_header, (rng.randrange(2),))
+        call(L.bhh_output_path_for, (("/x/" + word(40) + rng.choice([".wav", ".WAV", "", ".flac", "."])).encode(),
+                                     rng.choice([None, b"", ("/o/" + word()).encode()]), rng.choice([0, 1, 2, 4, 8, 16, 32, 64, 3, 0xFFFFFFFF])))
+        call(L.bhh_species_code, (word(30).encode(),))
+        v = rng.choice([0.0, -0.0, 1.0, 0.1, 1e-7, 1e21, 1e-310, float("nan"), float("inf"), -float("inf"), rng.uniform(-1e6, 1e6),
+                        struct.unpack("<d", struct.pack("<Q", rng.getrandbits(64)))[0]])
+        call(L.bhh_format_float, (rng.randrange(-1, 6), C.c_double(v)))
