@@ -412,10 +412,36 @@ int forward_slice(bh_classifier *c, bh_batch_context *ctx, const float *d_seg, s
                                (int)L.act, s);
             ctx_mark(ctx, ST_DENSE, (int)i);
             break;
-        case bh::OP_GAP:
+        case bh::OP_GAP: {
+            // The gate of a squeeze-excite block that runs LAYER BY LAYER (wider than the fused entries -- the v3.0-sized model's
+            // 640 -> 3 840 -> 640 blocks -- or left there by the f32 planner): pool -> 1x1 -> 1x1 were a pool launch and two GEMMs of
+            // M = n rows, the first with a handful of tiles under a K loop of the whole width (171 us per 256 segments for 3 840 ->
+            // 160).  On a small image the two gate launches of the fused path take the whole chain: se_hidden_kernel pools the
+            // depthwise output itself (its "tiles" are the image's pixels, in order), the pool layer's own tensor holds the partial
+            // sums.  Which path a block takes depends on its shapes alone.
+            const bool small_image = L.in_h * L.in_w <= 64 && L.cout >= BH_SE_GATE16_MIN;
+            if (small_image && !ctx->keep_tensors && i + 2 < nl) {
+                const auto &G1 = m.layers[i + 1], &G2 = m.layers[i + 2];
+                bool ok = G1.op == bh::OP_PWCONV && G2.op == bh::OP_PWCONV && G1.in_h * G1.in_w == 1 && G2.in_h * G2.in_w == 1 &&
+                          G1.in_tensor == i + 1 && G2.in_tensor == i + 2 && G1.res_tensor == bh::NO_TENSOR && G2.res_tensor == bh::NO_TENSOR &&
+                          G1.cin == L.cout && G2.cin == G1.cout && G2.cout == L.cout && m.h.embedding_tensor != i + 1 && m.h.embedding_tensor != i + 2 &&
+                          bh::se_gate16_supports((int)L.cout, (int)G1.cout);
+                for (uint32_t j = i + 1; ok && j < nl; j++)          // nobody else may read the pooled or the hidden tensor
+                    if ((j > i + 1 && m.layers[j].in_tensor == i + 1) || (j > i + 2 && m.layers[j].in_tensor == i + 2) ||
+                        m.layers[j].res_tensor == i + 1 || m.layers[j].res_tensor == i + 2) ok = false;
+                if (ok) {
+                    const int P = (int)(L.in_h * L.in_w);
+                    bh::launch_se_gate16(in, P, P, out, c->d_w[i + 1], c->d_blob + G1.b_off, c->ldw[i + 1], (int)G1.act, c->d_w[i + 2],
+                                         c->d_blob + G2.b_off, c->ldw[i + 2], (int)G2.act, T(i + 3), (int)n, (int)L.cout, (int)G1.cout, s);
+                    ctx_mark(ctx, ST_GAP, (int)i);
+                    i += 2;          // the two dense layers of the gate are done
+                    break;
+                }
+            }
             bh::launch_gap(in, out, (int)n, (int)(L.in_h * L.in_w), (int)L.cout, s);
             ctx_mark(ctx, ST_GAP, (int)i);
             break;
+        }
         case bh::OP_SCALE:   // squeeze-excite: the feature map times its [n][C] gate (res = the gate tensor)
             bh::launch_scale(in, res, out, (int)n, (int)(L.out_h * L.out_w), (int)L.cout, s);
             ctx_mark(ctx, ST_DW, (int)i);
