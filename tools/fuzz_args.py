@@ -32,9 +32,15 @@ def child(seed, n):
     def choice(seq):
         v = _choice(seq); print(f"  arg {v}", file=sys.stderr, flush=True); return v
     rng.choice = choice
+    from birda_amd.classifier import RangeFilter
+    GEO = os.path.join(ROOT, "tests", "golden", "reference_fixtures")
+    rf = RangeFilter(os.path.join(GEO, "fixture-geomodel.onnx"), os.path.join(GEO, "fixture-geomodel-labels.txt"), threshold=0.03)
+    nsp = rf.num_species()
+    NC = clf.n_classes() if callable(clf.n_classes) else clf.n_classes
+    odd = [0.0, -0.0, 1.0, -1.0, 90.0, -90.0, 180.0, 1e30, -1e30, float("nan"), float("inf"), -float("inf"), 60.17]
     for i in range(n):
         print(f"call {i}", file=sys.stderr, flush=True)
-        which = rng.randrange(6)
+        which = rng.randrange(10)
         print(f" which {which}", file=sys.stderr, flush=True)
         st = rng.getstate()
         try:
@@ -55,8 +61,35 @@ def child(seed, n):
                                    out.ctypes.data, rng.choice((0, 1, out.size)), C.byref(got))
             elif which == 4:
                 h = C.c_void_p()
-                rc = L.bh_batch_context_create(clf._h, rng.choice((0, 1, 64, 1 << 20, 1 << 40, (1 << 63))), C.byref(h))
+                rc = L.bh_batch_context_create(clf._h, rng.choice((0, 1, 64, 1 << 40, (1 << 63))), C.byref(h))
                 if rc == 0: L.bh_batch_context_destroy(h)
+            elif which == 6:     # the geomodel query: coordinates and dates of every kind, capacities at the edges
+                sc = np.zeros(nsp + 4, np.float32); ix = np.zeros(nsp + 4, np.uint32); kept = C.c_size_t()
+                if rng.random() < 0.5:
+                    rc = L.bh_range_filter_predict(rf._h, rng.choice(odd), rng.choice(odd), rng.choice((0, 1, 2, 12, 13, 255, (1 << 32) - 1)), rng.choice((0, 1, 28, 29, 30, 31, 32, (1 << 32) - 1)),
+                                                   sc.ctypes.data, rng.choice((0, 1, nsp - 1, nsp, nsp + 4)), ix.ctypes.data, C.byref(kept))
+                else:
+                    rc = L.bh_range_filter_predict_week(rf._h, rng.choice(odd), rng.choice(odd), rng.choice(odd + [48.0, 49.0, 0.5]), sc.ctypes.data,
+                                                        rng.choice((0, 1, nsp, nsp + 4)), ix.ctypes.data, C.byref(kept))
+            elif which == 7:     # the filter tables: class counts that do not match, NaN / inf scores and thresholds
+                k = rng.choice((0, 1, NC - 1, NC, NC + 1))
+                tab = np.array([rng.choice(odd) for _ in range(max(k, 1))], np.float32)
+                rc = L.bh_classifier_set_range_filter(clf._h, tab.ctypes.data, k, rng.choice(odd), rng.randrange(-1, 3), rng.randrange(-1, 3))
+                if rc == 0: clf.predict_logits(ctx, f32); clf.predict_batch_with_context(ctx, [f32[0], f32[1]])
+                L.bh_classifier_clear_filters(clf._h)
+            elif which == 8:
+                k = rng.choice((0, 1, NC - 1, NC, NC + 1))
+                keep = np.array([rng.choice((0, 1, 255)) for _ in range(max(k, 1))], np.uint8)
+                rc = L.bh_classifier_set_species_list(clf._h, keep.ctypes.data, k)
+                if rc == 0: clf.predict_batch_with_context(ctx, [f32[0], f32[1]])
+                L.bh_classifier_clear_filters(clf._h)
+            elif which == 9:     # BSG calibration tables
+                k = rng.choice((0, 1, NC - 1, NC, NC + 1))
+                a = np.array([rng.choice(odd) for _ in range(max(k, 1))], np.float32); b = np.array([rng.choice(odd) for _ in range(max(k, 1))], np.float32)
+                pr = np.array([rng.choice(odd) for _ in range(max(k, 1))], np.float32)
+                rc = L.bh_classifier_set_bsg(clf._h, a.ctypes.data, b.ctypes.data, pr.ctypes.data if rng.random() < 0.5 else None, k)
+                if rc == 0: clf.predict_batch_with_context(ctx, [f32[0], f32[1]])
+                L.bh_classifier_clear_bsg(clf._h)
             else:
                 n_out = C.c_size_t()
                 rc = L.bh_resample_output_len(rng.choice(edge), rng.choice((0, 1, 44100, (1 << 32) - 1)), rng.choice((0, 1, 48000, (1 << 32) - 1)), C.byref(n_out))
