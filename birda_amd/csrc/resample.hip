@@ -64,6 +64,7 @@ double blackman_harris2(int i, int n) {
     return w * w;
 }
 
+constexpr size_t kResampleLdsBytes = 150 * 1024;          // what a workgroup's input span may take of the CU's 160 KB
 std::mutex g_plan_mu;
 std::map<std::tuple<int, uint32_t, uint32_t>, ResamplePlan> g_plans;  // the operator lives in ONE device's memory: keyed by device ordinal too
 
@@ -99,14 +100,25 @@ const ResamplePlan *resample_plan(uint32_t from, uint32_t to, const char **err) 
     resample_sizes(from, to, &ni, &no);
     const uint32_t g = std::gcd(from, to);
     const int P = (int)(from / g), Q = (int)(to / g);
-    const int N = std::lcm(Q, 160), q = N / Q, hop = q * P;
-    if (hop > ni || N > 2 * no) { *err = "resampler: rate pair outside the built range"; return nullptr; }
+    // Two forms of the same operator.  POLYPHASE (up-sampling and decimation by at most 1.5): the composite is shift-invariant with
+    // period (P, Q), a frame is `hop` = q P input samples and N = q Q = lcm(Q, 160) output phases, the taps come from impulses in the
+    // first `hop` positions of a block.  BLOCK (round 6; decimation by more than 1.5 -- 88.2 / 96 / 192 / 256 / 384 kHz recordings):
+    // rubato's block is NOT shift-invariant there.  It truncates the 2 fft_in-point spectrum to 2 fft_out bins -- a brick wall that
+    // is circular in time -- and what leaks past a block's end is overlap-added into the NEXT block's output: two recordings that
+    // differ by a shift of `hop` samples come out 1e-4 (96 -> 48 kHz) to 5e-3 (384 -> 48 kHz) apart in the oracle itself, and the
+    // polyphase form was that far from it (untested before: the four pairs of tests/test_resampler_gpu.py all decimate by <= 1.5).
+    // What IS invariant is a shift by a whole block: a frame is one block (hop = fft_in input samples, N = fft_out outputs), K spans
+    // the previous and the current block, and tap() below -- written for the polyphase form -- is then exact.
+    const bool block_form = (uint64_t)from * 2 > (uint64_t)to * 3;
+    const int N = block_form ? no : std::lcm(Q, 160), q = block_form ? 0 : N / Q, hop = block_form ? ni : q * P;
+    if (!block_form && (hop > ni || N > 2 * no)) { *err = "resampler: rate pair outside the built range"; return nullptr; }
     // Refused BEFORE the operator is computed (round 6: found by tools/fuzz_wav_decoder.py -- a header that says 47 999 Hz, or 128 Hz, or
     // 1.5 GHz, asked for `hop` FFTs of length 2 fft_out and a table of hop x 2 fft_out doubles (36 GB for 47 999 -> 48 000) before the
     // LDS check below could say no: the process sat in here until the inference watchdog killed it, one bad file ending a whole
     // directory run).  The kernel's frame tile holds 63 hop + K (>= 128) input samples in LDS; every pair whose rates share a divisor
-    // of a few hundred -- 8 / 11.025 / 16 / 22.05 / 32 / 44.1 / 96 / 192 / 250 / 384 kHz against 32 / 48 kHz -- has hop <= 441.
-    if (((size_t)63 * hop + 128) * 4 > 150 * 1024) { *err = "resampler: frame span exceeds LDS (the two sample rates share too small a divisor)"; return nullptr; }
+    // of a few hundred -- 8 / 11.025 / 16 / 22.05 / 32 / 44.1 / 88.2 / 96 kHz against 32 / 48 kHz -- has hop <= 480; the recorders that
+    // sample at 192 / 256 / 300 / 384 kHz have 640-1 920 and take fewer frames a workgroup (launch_resample).
+    if (((size_t)15 * hop + 128) * 4 + 32 > kResampleLdsBytes) { *err = "resampler: frame span exceeds LDS (the two sample rates share too small a divisor)"; return nullptr; }
     if (ni > 32768 || no > 32768) { *err = "resampler: rate ratio outside the built range"; return nullptr; }
     // rubato's filter: windowed sinc of length fft_in, unit sum, scaled 1 / (2 fft_in)
     const double cutoff = ni > no ? (double)powf(0.4f, 16.0f / (float)ni) * (double)no / (double)ni
@@ -142,7 +154,7 @@ const ResamplePlan *resample_plan(uint32_t from, uint32_t to, const char **err) 
     auto tap = [&](int p, int d) -> double {
         const int m = d >= 0 ? -(d / hop) : (-d + hop - 1) / hop;
         const int i = hop * m + d, n = N * m + p;
-        if (i < 0 || i >= hop || n < 0 || n >= 2 * no) return 0.0;
+        if (p >= N || i < 0 || i >= hop || n < 0 || n >= 2 * no) return 0.0;   // (p >= N: the padding columns of the last 160-phase block)
         return R[(size_t)i * 2 * no + n];
     };
     double tmax = 0.0;
@@ -156,10 +168,10 @@ const ResamplePlan *resample_plan(uint32_t from, uint32_t to, const char **err) 
     }
     if (dmax < dmin) { *err = "resampler: empty operator"; return nullptr; }
     ResamplePlan pl{};
-    pl.from = from; pl.to = to; pl.hop = hop; pl.N = N; pl.nblk = N / 160; pl.dmin = dmin;
+    pl.from = from; pl.to = to; pl.hop = hop; pl.N = N; pl.nblk = (N + 159) / 160; pl.dmin = dmin;
     pl.K = (dmax - dmin + 1 + 127) / 128 * 128;   // 4 waves x an even number of 16-deep groups
-    const size_t span_floats = (size_t)63 * hop + pl.K;
-    if (span_floats * 4 > 150 * 1024) { *err = "resampler: frame span exceeds LDS"; return nullptr; }
+    const size_t span_floats = (size_t)15 * hop + pl.K;          // one frame row tile a workgroup at the least (launch_resample picks 4 / 2 / 1)
+    if (span_floats * 4 + 32 > kResampleLdsBytes) { *err = "resampler: frame span exceeds LDS"; return nullptr; }
     // fragment-major operator per 160-column block: [blk][K/16][10][64 lanes][4]
     std::vector<float> frag((size_t)pl.nblk * pl.K * 160);
     for (int cb = 0; cb < pl.nblk; cb++)
@@ -213,16 +225,21 @@ const ResamplePlan *resample_plan(uint32_t from, uint32_t to, const char **err) 
 // ---------------------------------------------------------------------------------------
 constexpr int RS_MT = 10;
 
+// FT: frame row tiles (of 16) a workgroup owns -- 4 (64 frames) while the tile's input span, (16 FT - 1) hop + K samples, fits
+// the LDS; 2 or 1 for the pairs that decimate by a large factor (round 6: 192 / 256 / 384 kHz recorders against 48 / 32 kHz models have
+// hop 640-1 920 and were refused).  The K reduction stays split over the four waves; waves 0 .. FT - 1 own the frame tiles.  Every
+// output sample is the same sum in the same order whatever FT (the waves' partial sums meet in wave order).
+template <int FT>
 __global__ __launch_bounds__(256) void resample_kernel(const float *__restrict__ in, size_t in_stride, int src_len,
                                                        float *__restrict__ out, size_t out_stride, int out_len,
                                                        int n_valid, const float *__restrict__ op, int hop, int N,
                                                        int K, int dmin) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int seg = blockIdx.z, cb = blockIdx.y, t0 = blockIdx.x * 64;
+    const int seg = blockIdx.z, cb = blockIdx.y, t0 = blockIdx.x * (16 * FT);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const float *xseg = in + (size_t)seg * in_stride;
-    const int span = 63 * hop + K;
+    const int span = (16 * FT - 1) * hop + K;
     const int g0 = t0 * hop + dmin;
     for (int i0 = tid; i0 < span; i0 += 256 * 8) {   // 8 independent loads in flight per thread
         float v[8];
@@ -237,9 +254,9 @@ __global__ __launch_bounds__(256) void resample_kernel(const float *__restrict__
     }
     __syncthreads();
 
-    f32x4 acc[4][RS_MT];
+    f32x4 acc[FT][RS_MT];
 #pragma unroll
-    for (int f = 0; f < 4; f++)
+    for (int f = 0; f < FT; f++)
 #pragma unroll
         for (int m = 0; m < RS_MT; m++) acc[f][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -252,18 +269,18 @@ __global__ __launch_bounds__(256) void resample_kernel(const float *__restrict__
     const float *xf = smem + li * hop;
     auto group = [&](int g, const float4 (&a)[RS_MT]) {
         const int jb = g * 16 + 4 * kq;
-        float b[4][4];
+        float b[4][FT];
 #pragma unroll
         for (int c = 0; c < 4; c++)
 #pragma unroll
-            for (int f = 0; f < 4; f++) b[c][f] = xf[f * 16 * hop + jb + c];
+            for (int f = 0; f < FT; f++) b[c][f] = xf[f * 16 * hop + jb + c];
 #pragma unroll
         for (int c = 0; c < 4; c++)
 #pragma unroll
             for (int m = 0; m < RS_MT; m++) {
                 const float av = c == 0 ? a[m].x : c == 1 ? a[m].y : c == 2 ? a[m].z : a[m].w;
 #pragma unroll
-                for (int f = 0; f < 4; f++)
+                for (int f = 0; f < FT; f++)
                     acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[c][f], acc[f][m], 0, 0, 0);
             }
     };
@@ -286,34 +303,40 @@ __global__ __launch_bounds__(256) void resample_kernel(const float *__restrict__
 
     __syncthreads();  // every wave is done reading the span
     float4 *red = reinterpret_cast<float4 *>(smem);
+    // red[owner frame tile f][source wave, the owner's own left out][m][lane]
 #pragma unroll
-    for (int f = 0; f < 4; f++) {
+    for (int f = 0; f < FT; f++) {
         if (f == wave) continue;
-        const int slot = f - (f > wave ? 1 : 0);
+        const int slot = wave - (wave > f ? 1 : 0);
 #pragma unroll
         for (int m = 0; m < RS_MT; m++)
-            red[((wave * 3 + slot) * RS_MT + m) * 64 + lane] = make_float4(acc[f][m][0], acc[f][m][1], acc[f][m][2], acc[f][m][3]);
+            red[((f * 3 + slot) * RS_MT + m) * 64 + lane] = make_float4(acc[f][m][0], acc[f][m][1], acc[f][m][2], acc[f][m][3]);
     }
     __syncthreads();
+    if (wave >= FT) return;          // (after the last barrier)
     const int t = t0 + wave * 16 + li;
     float *oseg = out + (size_t)seg * out_stride;
 #pragma unroll
     for (int m = 0; m < RS_MT; m++) {
-        f32x4 v = wave == 0 ? acc[0][m] : wave == 1 ? acc[1][m] : wave == 2 ? acc[2][m] : acc[3][m];
+        f32x4 v = acc[0][m];
+#pragma unroll
+        for (int f = 1; f < FT; f++)
+            if (wave == f) v = acc[f][m];
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             if (s == wave) continue;
-            const int slot = wave - (wave > s ? 1 : 0);
-            const float4 q = red[((s * 3 + slot) * RS_MT + m) * 64 + lane];
+            const int slot = s - (s > wave ? 1 : 0);
+            const float4 q = red[((wave * 3 + slot) * RS_MT + m) * 64 + lane];
             v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
         }
-        const long o = (long)t * N + cb * 160 + m * 16 + kq * 4;  // 4 consecutive output samples
-        if (o + 3 < out_len && o + 3 < n_valid) {
+        const int pc = cb * 160 + m * 16 + kq * 4;                // 4 consecutive output phases (the block form's N is any number:
+        const long o = (long)t * N + pc;                          //  columns past it are padding, and rows may start unaligned)
+        if (pc + 3 < N && (N & 3) == 0 && o + 3 < out_len && o + 3 < n_valid) {
             *reinterpret_cast<float4 *>(oseg + o) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                if (o + r < out_len) oseg[o + r] = (o + r < n_valid) ? v[r] : 0.0f;  // resize(.., 0.0) pads
+                if (pc + r < N && o + r < out_len) oseg[o + r] = (o + r < n_valid) ? v[r] : 0.0f;  // resize(.., 0.0) pads
         }
     }
 }
@@ -324,16 +347,17 @@ __global__ __launch_bounds__(256) void resample_kernel(const float *__restrict__
 // (157 TFLOP/s), this one at 2.5 PFLOP/s / 3.  Same staging, K split, reduction and stores as above.
 typedef _Float16 rs_f16x8 __attribute__((ext_vector_type(8)));
 constexpr int RS16_MT = 5;   // column blocks of 80 phases: 80 accumulator + 80 operator registers, two workgroups per CU
+template <int FT>
 __global__ __launch_bounds__(256, 2) void resample16_kernel(const float *__restrict__ in, size_t in_stride, int src_len,
                                                          float *__restrict__ out, size_t out_stride, int out_len,
                                                          int n_valid, const rs_f16x8 *__restrict__ op, int hop, int N,
                                                          int K, int dmin, float op_unscale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int seg = blockIdx.z, cb = blockIdx.y, t0 = blockIdx.x * 64;
+    const int seg = blockIdx.z, cb = blockIdx.y, t0 = blockIdx.x * (16 * FT);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kq = lane >> 4;
     const float *xseg = in + (size_t)seg * in_stride;
-    const int span = 63 * hop + K;
+    const int span = (16 * FT - 1) * hop + K;
     const int g0 = t0 * hop + dmin;
     float amax = 0.0f;   // largest |sample| of this workgroup's span
     for (int i0 = tid; i0 < span; i0 += 256 * 8) {   // 8 independent loads in flight per thread
@@ -366,9 +390,9 @@ __global__ __launch_bounds__(256, 2) void resample16_kernel(const float *__restr
     }
     __syncthreads();
 
-    f32x4 acc[4][RS16_MT];
+    f32x4 acc[FT][RS16_MT];
 #pragma unroll
-    for (int f = 0; f < 4; f++)
+    for (int f = 0; f < FT; f++)
 #pragma unroll
         for (int m = 0; m < RS16_MT; m++) acc[f][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -385,9 +409,9 @@ __global__ __launch_bounds__(256, 2) void resample16_kernel(const float *__restr
     const float *xf = smem + li * hop;
     auto step = [&](int st, const rs_f16x8 (&ah)[RS16_MT], const rs_f16x8 (&al)[RS16_MT]) {
         const int j0 = st * 32 + 8 * kq;
-        bh_f16x8 bh[4], bl[4];
+        bh_f16x8 bh[FT], bl[FT];
 #pragma unroll
-        for (int f = 0; f < 4; f++) {
+        for (int f = 0; f < FT; f++) {
             float y[8];
 #pragma unroll
             for (int jj = 0; jj < 8; jj++) y[jj] = xf[f * 16 * hop + j0 + jj];
@@ -397,7 +421,7 @@ __global__ __launch_bounds__(256, 2) void resample16_kernel(const float *__restr
 #pragma unroll
         for (int m = 0; m < RS16_MT; m++)
 #pragma unroll
-            for (int f = 0; f < 4; f++) {
+            for (int f = 0; f < FT; f++) {
                 acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh[f], acc[f][m], 0, 0, 0);
                 acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl[f], acc[f][m], 0, 0, 0);
                 acc[f][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh[f], acc[f][m], 0, 0, 0);
@@ -430,36 +454,42 @@ __global__ __launch_bounds__(256, 2) void resample16_kernel(const float *__restr
 
     __syncthreads();  // every wave is done reading the span
     float4 *red = reinterpret_cast<float4 *>(smem);
+    // red[owner frame tile f][source wave, the owner's own left out][m][lane]
 #pragma unroll
-    for (int f = 0; f < 4; f++) {
+    for (int f = 0; f < FT; f++) {
         if (f == wave) continue;
-        const int slot = f - (f > wave ? 1 : 0);
+        const int slot = wave - (wave > f ? 1 : 0);
 #pragma unroll
         for (int m = 0; m < RS16_MT; m++)
-            red[((wave * 3 + slot) * RS16_MT + m) * 64 + lane] = make_float4(acc[f][m][0], acc[f][m][1], acc[f][m][2], acc[f][m][3]);
+            red[((f * 3 + slot) * RS16_MT + m) * 64 + lane] = make_float4(acc[f][m][0], acc[f][m][1], acc[f][m][2], acc[f][m][3]);
     }
     __syncthreads();
+    if (wave >= FT) return;          // (after the last barrier)
     const int t = t0 + wave * 16 + li;
     float *oseg = out + (size_t)seg * out_stride;
 #pragma unroll
     for (int m = 0; m < RS16_MT; m++) {
-        f32x4 v = wave == 0 ? acc[0][m] : wave == 1 ? acc[1][m] : wave == 2 ? acc[2][m] : acc[3][m];
+        f32x4 v = acc[0][m];
+#pragma unroll
+        for (int f = 1; f < FT; f++)
+            if (wave == f) v = acc[f][m];
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             if (s == wave) continue;
-            const int slot = wave - (wave > s ? 1 : 0);
-            const float4 q = red[((s * 3 + slot) * RS16_MT + m) * 64 + lane];
+            const int slot = s - (s > wave ? 1 : 0);
+            const float4 q = red[((wave * 3 + slot) * RS16_MT + m) * 64 + lane];
             v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) v[r] *= out_unscale;   // the operator planes hold G * 2^s, the span x * 2^(140 - ex)
-        const long o = (long)t * N + cb * 80 + m * 16 + kq * 4;  // 4 consecutive output samples
-        if (o + 3 < out_len && o + 3 < n_valid) {
+        const int pc = cb * 80 + m * 16 + kq * 4;                // 4 consecutive output phases (the block form's N is any number:
+        const long o = (long)t * N + pc;                          //  columns past it are padding, and rows may start unaligned)
+        if (pc + 3 < N && (N & 3) == 0 && o + 3 < out_len && o + 3 < n_valid) {
             *reinterpret_cast<float4 *>(oseg + o) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                if (o + r < out_len) oseg[o + r] = (o + r < n_valid) ? v[r] : 0.0f;  // resize(.., 0.0) pads
+                if (pc + r < N && o + r < out_len) oseg[o + r] = (o + r < n_valid) ? v[r] : 0.0f;  // resize(.., 0.0) pads
         }
     }
 }
@@ -468,23 +498,31 @@ void launch_resample(const ResamplePlan &pl, const float *d_in, size_t in_stride
                      size_t out_stride, int out_len, int n_seg, bool split_f16, hipStream_t s) {
     const int n_valid = (int)std::min<size_t>((size_t)out_len, resample_output_len((size_t)src_len, pl.from, pl.to));
     const int frames = (out_len + pl.N - 1) / pl.N;
-    const size_t span_bytes = ((size_t)63 * pl.hop + pl.K) * sizeof(float);
-    const size_t red_bytes = (size_t)4 * 3 * RS_MT * 64 * sizeof(float4);
-    const size_t smem = std::max(span_bytes, red_bytes);
-    static DeviceOnce attr_set;
-    attr_set.run([] { (void)hipFuncSetAttribute((const void *)resample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-    dim3 grid((frames + 63) / 64, pl.nblk, n_seg), block(256);
-    if (split_f16) {
-        static DeviceOnce attr16_set;
-        attr16_set.run([] { (void)hipFuncSetAttribute((const void *)resample16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
-        const size_t smem16 = std::max(span_bytes + 32, (size_t)4 * 3 * RS16_MT * 64 * sizeof(float4));   // + the 4 wave maxima behind the span
-        dim3 grid16((frames + 63) / 64, 2 * pl.nblk, n_seg);
-        hipLaunchKernelGGL(resample16_kernel, grid16, block, smem16, s, d_in, in_stride, src_len, d_out, out_stride, out_len,
-                           n_valid, (const rs_f16x8 *)pl.d_op16, pl.hop, pl.N, pl.K, pl.dmin, pl.op16_unscale);
-        return;
-    }
-    hipLaunchKernelGGL(resample_kernel, grid, block, smem, s, d_in, in_stride, src_len, d_out, out_stride, out_len,
-                       n_valid, pl.d_op, pl.hop, pl.N, pl.K, pl.dmin);
+    // frame row tiles a workgroup: as many of 4 / 2 / 1 as the input span leaves room for (resample_plan refused what not even one fits)
+    auto span_bytes_of = [&](int ft) { return ((size_t)(16 * ft - 1) * pl.hop + pl.K) * sizeof(float) + 32; };   // (+ the f16 kernel's 4 wave maxima)
+    const int ft = span_bytes_of(4) <= kResampleLdsBytes ? 4 : span_bytes_of(2) <= kResampleLdsBytes ? 2 : 1;
+    const size_t span_bytes = span_bytes_of(ft);
+    dim3 block(256);
+#define BH_RS_LAUNCH(FTV)                                                                                                                  \
+    do {                                                                                                                                   \
+        if (split_f16) {                                                                                                                   \
+            static DeviceOnce attr16_set;                                                                                                  \
+            attr16_set.run([] { (void)hipFuncSetAttribute((const void *)resample16_kernel<FTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
+            const size_t smem16 = std::max(span_bytes, (size_t)FTV * 3 * RS16_MT * 64 * sizeof(float4));                                   \
+            dim3 grid16((frames + 16 * FTV - 1) / (16 * FTV), 2 * pl.nblk, n_seg);                                                          \
+            hipLaunchKernelGGL(resample16_kernel<FTV>, grid16, block, smem16, s, d_in, in_stride, src_len, d_out, out_stride, out_len,     \
+                               n_valid, (const rs_f16x8 *)pl.d_op16, pl.hop, pl.N, pl.K, pl.dmin, pl.op16_unscale);                        \
+        } else {                                                                                                                           \
+            static DeviceOnce attr_set;                                                                                                    \
+            attr_set.run([] { (void)hipFuncSetAttribute((const void *)resample_kernel<FTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
+            const size_t smem = std::max(span_bytes, (size_t)FTV * 3 * RS_MT * 64 * sizeof(float4));                                       \
+            dim3 grid((frames + 16 * FTV - 1) / (16 * FTV), pl.nblk, n_seg);                                                                \
+            hipLaunchKernelGGL(resample_kernel<FTV>, grid, block, smem, s, d_in, in_stride, src_len, d_out, out_stride, out_len,            \
+                               n_valid, pl.d_op, pl.hop, pl.N, pl.K, pl.dmin);                                                             \
+        }                                                                                                                                  \
+    } while (0)
+    if (ft == 4) BH_RS_LAUNCH(4); else if (ft == 2) BH_RS_LAUNCH(2); else BH_RS_LAUNCH(1);
+#undef BH_RS_LAUNCH
 }
 
 }  // namespace bh

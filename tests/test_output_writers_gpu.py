@@ -126,3 +126,39 @@ def test_every_format_written_from_a_device_run_is_what_the_oracles_detections_g
         assert a["scientific_name"] == sci and a["common_name"] == (com or sci)
         assert abs(a["start_time"] - start) < 1e-6 and abs(a["end_time"] - end) < 1e-6 and abs(a["confidence"] - conf) <= CONF_ATOL
     clf.close()
+
+
+@pytest.mark.parametrize("rate", [96000, 192000, 384000])
+def test_high_rate_recordings_give_the_oracles_detections(rate, model_dir, oracle_lib, tmp_path):
+    """96 / 192 / 384 kHz recordings (recorders that sample far above the model's 48 kHz) through `bhh_process_file`, device and host
+    front end: the detections are the oracle's, whose resampler restates rubato's block FFT (reference src/audio/resample.rs:10-91).
+    Round 6: decimation by more than 1.5 takes the block form of the device resampler (resample.hip) -- 96 kHz had come out 1e-4 from
+    the oracle on the polyphase form (rubato's block is not shift-invariant there), 192 kHz and beyond were refused."""
+    from birda_amd import pipeline, synth
+    from birda_amd.classifier import BirdClassifier
+    path, labels, m, names = model_dir["birdnet_v24_tiny"]
+    seconds = 7.3
+    n = int(seconds * rate)
+    t = np.arange(n) / rate
+    rng = np.random.default_rng(rate)
+    x = np.clip(0.25 * np.sin(2 * np.pi * 2310.0 * t) + 0.2 * np.sin(2 * np.pi * 7100.0 * t * (1 + 0.02 * t)) + 0.05 * rng.standard_normal(n), -1, 1)
+    wav = str(tmp_path / f"rec_{rate}.wav")
+    synth.write_wav_pcm16(wav, x.astype(np.float32), rate)
+    pcm = np.clip(np.round(x * 32767.0), -32768, 32767).astype(np.int16)
+    mono = np.zeros(pcm.size, np.float32)
+    oracle_lib.lib().bo_pcm16_to_mono(pcm.ctypes.data, pcm.size, 1, mono)
+    dets, st = _oracle_detections(oracle_lib, path, names, mono, rate, 0.0, 0.02, wav)
+    assert st.n_segments == 3 and len(dets) >= 3
+    clf = BirdClassifier(path, labels, top_k=5, min_confidence=0.02)
+    for fe in ("device", "host"):
+        out = tmp_path / fe
+        out.mkdir()
+        res = pipeline.process_file(clf, wav, str(out), min_confidence=0.02, overlap=0.0, front_end=fe)
+        assert res.segments == st.n_segments and res.detections == len(dets), (fe, res.segments, res.detections, len(dets))
+        import csv as csvmod
+        rows = list(csvmod.reader(open(pipeline.output_path_for(wav, str(out), "csv"), encoding="utf-8-sig").read().splitlines()))[1:]
+        assert len(rows) == len(dets)
+        for row, (lab, conf, start, end, _) in zip(rows, dets):
+            sci, _, com = lab.partition("_")
+            assert row[2] == sci and abs(float(row[4]) - conf) <= CONF_ATOL and abs(float(row[0]) - start) < 1e-3, (fe, row, lab, conf)
+    clf.close()
