@@ -414,7 +414,9 @@ BH_API int bh_predict_pcm16_at(bh_classifier *c, bh_batch_context *ctx, const in
 
 /* ---- resampler (reference src/audio/resample.rs:10-105; rubato Fft<f32>, FixedSync::Both,
  * chunk 1024, one new resampler per segment).  The device kernel applies rubato's block
- * operator as a polyphase GEMM (birda_amd/csrc/resample.hip); identity when the rates are equal.
+ * operator as a GEMM (birda_amd/csrc/resample.hip: polyphase with period (from, to) / gcd where the block operator is shift-
+ * invariant -- up-sampling, decimation by at most 1.5 --, one rubato block a frame beyond: 88.2 ... 500 kHz recordings); identity when
+ * the rates are equal.
  * Tolerance vs the block-FFT restatement in the oracle: 2e-5 absolute on |x| <= 1 inputs. */
 /* resample(samples, from, to) -> Vec<f32> (resample.rs:10-91): host in, host out */
 BH_API int bh_resample(bh_classifier *c, const float *in, size_t n_in, uint32_t from_rate,
