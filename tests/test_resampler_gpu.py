@@ -20,6 +20,8 @@ pytestmark = pytest.mark.gpu
 
 RESAMPLE_ATOL = 2e-5
 PAIRS = [(44100, 48000), (22050, 48000), (48000, 32000), (44100, 32000),
+         # up-sampling by large factors and the odd rates of old recorders (polyphase form)
+         (8000, 48000), (11025, 48000), (16000, 48000), (24000, 48000), (32000, 48000), (37800, 48000), (8000, 32000), (16000, 32000), (22050, 32000),
          # (round 6) decimation by more than 1.5 -- 88.2 / 96 kHz were taken by the polyphase form and came out 1e-4 from the oracle
          # (rubato's block is not shift-invariant there: resample.hip), 192 kHz and beyond were refused: the block form, a frame =
          # one rubato block, 32 or 16 frames a workgroup
