@@ -1628,6 +1628,37 @@ def test_a_recording_the_resampler_cannot_take_is_refused_at_once(clf_tiny, mode
     assert r.segments == 3
 
 
+@pytest.mark.parametrize("poison", [float("nan"), float("inf")])
+def test_a_non_finite_sample_costs_its_own_segment_and_nothing_else(clf_tiny, model_dir, tmp_path, poison):
+    """A float32 WAV may hold NaN or inf.  The reference hands the samples to its runtime, whose logits for that segment are NaN and
+    pass no confidence threshold (processor.rs:375); here the segment that holds the sample yields no detection, every other segment
+    of the file is what the clean file gives, on both front ends, and the call does not fail (the non-finite counter of the f16
+    modes is about finite samples whose activations overflow: tests above)."""
+    from birda_amd import pipeline, synth
+    _, _, m, _ = model_dir["birdnet_v24_tiny"]
+    S = m.sample_count
+    x = synth.synth_segments(4, S, m.sample_rate, start=3).reshape(-1).astype(np.float32)
+    y = x.copy()
+    y[S + 5000] = poison                                   # inside the second segment
+    clean, bad = str(tmp_path / "clean.wav"), str(tmp_path / "bad.wav")
+    _write_wav(clean, x.astype(np.float64), m.sample_rate, "f32")
+    import struct
+    data = y.astype("<f4").tobytes()                       # (_write_wav goes through float64 arithmetic: written raw here)
+    hdr = b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 3, 1, m.sample_rate, m.sample_rate * 4, 4, 32)
+    open(bad, "wb").write(hdr + b"data" + struct.pack("<I", len(data)) + data)
+    for fe in ("device", "host"):
+        rows = {}
+        for name, p in (("clean", clean), ("bad", bad)):
+            out = tmp_path / f"{fe}_{name}"
+            out.mkdir()
+            r = pipeline.process_file(clf_tiny, p, str(out), min_confidence=0.05, front_end=fe)
+            assert r.segments == 4
+            rows[name] = [ln.split(",")[:5] for ln in open(pipeline.output_path_for(p, str(out), "csv"), encoding="utf-8-sig").read().splitlines()[1:]]
+        assert any(rw[0] == "3.0" for rw in rows["clean"])
+        assert not any(rw[0] == "3.0" for rw in rows["bad"]), fe
+        assert [rw for rw in rows["clean"] if rw[0] != "3.0"] == rows["bad"], fe
+
+
 @pytest.mark.parametrize("fmt", ["s24", "s32", "f32"])
 def test_device_front_end_takes_every_wav_sample_format(clf_tiny, model_dir, tmp_path, fmt):
     """24-bit, 32-bit and float32 WAV streams are uploaded in the file's own layout and scaled on the device exactly as the host
