@@ -115,7 +115,7 @@ const ResamplePlan *resample_plan(uint32_t from, uint32_t to, const char **err) 
     // Refused BEFORE the operator is computed (round 6: found by tools/fuzz_wav_decoder.py -- a header that says 47 999 Hz, or 128 Hz, or
     // 1.5 GHz, asked for `hop` FFTs of length 2 fft_out and a table of hop x 2 fft_out doubles (36 GB for 47 999 -> 48 000) before the
     // LDS check below could say no: the process sat in here until the inference watchdog killed it, one bad file ending a whole
-    // directory run).  The kernel's frame tile holds 63 hop + K (>= 128) input samples in LDS; every pair whose rates share a divisor
+    // directory run).  The kernel's frame tile holds (16 FT - 1) hop + K (>= 128) input samples in LDS, FT = 1 at the least; every pair whose rates share a divisor
     // of a few hundred -- 8 / 11.025 / 16 / 22.05 / 32 / 44.1 / 88.2 / 96 kHz against 32 / 48 kHz -- has hop <= 480; the recorders that
     // sample at 192 / 256 / 300 / 384 kHz have 640-1 920 and take fewer frames a workgroup (launch_resample).
     if (((size_t)15 * hop + 128) * 4 + 32 > kResampleLdsBytes) { *err = "resampler: frame span exceeds LDS (the two sample rates share too small a divisor)"; return nullptr; }
@@ -218,7 +218,7 @@ const ResamplePlan *resample_plan(uint32_t from, uint32_t to, const char **err) 
 }
 
 // ---------------------------------------------------------------------------------------
-// grid (frame tiles of 64, column blocks of 160 phases, n_seg), block 256 = 4 waves.
+// grid (frame tiles of 16 FT, column blocks of 160 phases, n_seg), block 256 = 4 waves.
 // LDS holds the tile's input span (zero outside [0, src_len)); the K reduction is split across
 // the 4 waves, the operator streams from L2 in fragment-major 1-KiB loads, partial sums meet in
 // LDS and wave w stores frame tile w (4 consecutive outputs per lane: 16-B stores).
